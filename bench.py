@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd views/s of the surfel rasterizer hot path on MI355X (BASELINE.json metric).
+
+A "step" is one full render of one view, forward AND backward, through the drop-in
+`materialrefgs_amd.rasterizer.GaussianRasterizer` (preprocess -> depth sort -> pair emission -> tile sort ->
+per-tile blend -> analytic backward), on the synthetic shell scene of SURVEY.md section 8d with the inputs
+resident in HBM.  Workload at N=1: C2 = BASELINE.json configs[1] (P=300000 surfels, 800x800, SH degree 3,
+S=0).  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank renders its own view
+of the step and the dense per-gaussian gradients are summed with ONE RCCL all-reduce ("weak" scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is computed for the dominant kernel from HIP-event durations recorded
+on the launch stream during the timed region; `cpu_baseline` times the CPU oracle (a port, not the reference
+itself: the reference has no CPU path) on one view of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (P, H, W, S, description)
+    "C2": (300000, 800, 800, 0, "C2 shell scene: P=300000 surfels, 800x800, SH deg 3, S=0 (diffuse-only surfel raster), fwd+bwd"),
+    "C3": (300000, 800, 800, 8, "C3 shell scene: P=300000 surfels, 800x800, SH deg 3, S=8 material channels, fwd+bwd"),
+    "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
+}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(kernel, P, R, HW, S):
+    """Algorithmic HBM bytes of ONE launch (DESIGN.md section 'Kernels'); each datum moved once per kernel."""
+    if kernel == "render_bwd":
+        # staged records + ids, per-pixel inputs (dL_dpix 3+S, dL_dothers 7, final_T 3, n_contrib 2), one RMW of the
+        # (18+S)-float gradient row per (tile, gaussian) pair
+        return (4 + 80 + 4 * S) * R + (60 + 4 * S) * HW + 8 * (18 + S) * R
+    if kernel == "render_fwd":
+        # staged records + ids, per-pixel outputs (color 3, feature S, others 7, final_T 3, n_contrib 2)
+        return (4 + 80 + 4 * S) * R + (60 + 4 * S) * HW
+    raise KeyError(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also skips grad_max_rel_err)")
+    args = ap.parse_args()
+
+    from materialrefgs_amd import dist as mdist
+    env = mdist.init_from_env()
+    world, rank, local = env["world"], env["rank"], env["local"]
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from materialrefgs_amd import _lib
+    from materialrefgs_amd._lib import MrgsKernelTimes
+    from materialrefgs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera, upstream_grads
+    L = _lib.lib()
+
+    P, H, W, S, desc = WORKLOADS[args.workload]
+    scene_cpu = make_shell_scene(P, S=S, seed=0, radius_px=7.0 * max(H, W) / 800.0 if args.workload == "tiny" else 7.0, image_size=max(H, W))
+    scene = scene_cpu.to(dev)
+    cams = [orbit_camera(v, H, W) for v in range(8)]
+    settings = []
+    for cam in cams:
+        settings.append(GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
+            projmatrix=cam.full_proj_transform.to(dev), sh_degree=3, campos=cam.camera_center.to(dev), prefiltered=False,
+            debug=False))
+    g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
+
+    params = {"means3D": scene.means3D, "opacity": scene.opacities, "scales": scene.scales, "rotations": scene.rotations,
+              "sh": scene.shs}
+    if S > 0:
+        params["features"] = scene.features
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    means2D = torch.zeros_like(scene.means3D, requires_grad=True)   # screenspace_points (gaussian_renderer/__init__.py:229)
+    grad_names = list(params.keys()) + ["means2D"]
+    bucket = mdist.GradBucket([params[k].shape for k in params] + [means2D.shape], dev) if world > 1 else None
+    state = {"R": 0}
+
+    def step(i):
+        view = (i * world + rank) % len(settings)
+        for t in list(params.values()) + [means2D]:
+            t.grad = None
+        rast = GaussianRasterizer(settings[view])
+        contrib, color, feature, radii, allmap = rast(
+            means3D=params["means3D"], means2D=means2D, opacities=params["opacity"], shs=params["sh"],
+            features=params.get("features"), scales=params["scales"], rotations=params["rotations"])
+        state["R"] = color.grad_fn.num_rendered
+        outs, grads = [color, allmap], [g_color, g_others]
+        if S > 0:
+            outs.append(feature)
+            grads.append(g_feat)
+        torch.autograd.backward(outs, grads)
+        if world > 1:
+            mdist.allreduce_gradients(bucket, [params[k].grad for k in params] + [means2D.grad])
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    L.mrgs_set_profiling(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    times = MrgsKernelTimes()
+    L.mrgs_get_kernel_times(times)
+    L.mrgs_set_profiling(0)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    views = args.steps * world
+    value = views / elapsed
+
+    out = {
+        "metric": "full-render fwd+bwd views/sec at 800x800/300k surfels; grad max-rel-err vs ref",
+        "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "P": P, "H": H, "W": W, "S": S, "sh_degree": 3, "num_rendered": int(state["R"]),
+                   "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
+    }
+    if rank == 0:
+        R, HW = int(state["R"]), H * W
+        stage_ms = {"preprocess_fwd": times.preprocess_ms, "depth_sort_scan": times.sort_ms, "duplicate_tilesort_ranges": times.duplicate_ms,
+                    "render_fwd": times.render_fwd_ms, "render_bwd": times.render_bwd_ms, "preprocess_bwd": times.preprocess_bwd_ms}
+        dom = "render_bwd" if times.render_bwd_ms >= times.render_fwd_ms else "render_fwd"
+        dom_ms = stage_ms[dom]
+        nbytes = algorithmic_bytes(dom, P, R, HW, S)
+        achieved = nbytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(dom_ms, 4)}
+        out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+
+        if not args.no_cpu_baseline:
+            from oracle import raster_oracle as ro
+            cam = cams[0]
+            t = time.perf_counter()
+            orc = ro.render_scene(scene_cpu, cam)
+            go = orc.backward(g_color.cpu(), g_feat.cpu(), g_others.cpu())
+            cpu_s = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "views/s", "cores": ro.num_threads(), "kind": "port",
+                                   "sample": f"1 view fwd+bwd of the same workload ({args.workload}, view 0) through oracle/mrgs_oracle.c "
+                                             f"(OpenMP, {cpu_s:.1f} s)"}
+            # gradient parity of this very configuration against the oracle (view 0)
+            for t_ in list(params.values()) + [means2D]:
+                t_.grad = None
+            rast = GaussianRasterizer(settings[0])
+            contrib, color, feature, radii, allmap = rast(
+                means3D=params["means3D"], means2D=means2D, opacities=params["opacity"], shs=params["sh"],
+                features=params.get("features"), scales=params["scales"], rotations=params["rotations"])
+            outs, grads = [color, allmap], [g_color, g_others]
+            if S > 0:
+                outs.append(feature)
+                grads.append(g_feat)
+            torch.autograd.backward(outs, grads)
+            torch.cuda.synchronize(dev)
+            import numpy as np
+            errs = {}
+            for k, ko in [("means3D", "means3D"), ("opacity", "opacity"), ("scales", "scales"), ("rotations", "rotations"),
+                          ("sh", "sh"), ("features", "features")]:
+                if k in params:
+                    a = params[k].grad.detach().cpu().numpy().astype(np.float64).reshape(go[ko].shape)
+                    b = go[ko].astype(np.float64)
+                    errs[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+            a = means2D.grad.detach().cpu().numpy().astype(np.float64)
+            errs["means2D"] = float(np.abs(a - go["means2D"]).max() / max(np.abs(go["means2D"]).max(), 1e-30))
+            out["grad_max_rel_err"] = round(max(errs.values()), 8)
+            out["grad_rel_err"] = {k: float(f"{v:.3e}") for k, v in errs.items()}
+            out["num_rendered_matches_oracle"] = bool(orc.R == color.grad_fn.num_rendered)
+            orc.close()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * mrgs.h -- C ABI of libmrgs.so, the MI355X (gfx950) surfel rasterizer + BRDF shading library.
+ *
+ * Drop-in boundary for the reference's rasterizer extension `diff_surfel_rasterization._C`
+ * (pybind: /root/reference/submodules/diff-surfel-rasterization/ext.cpp:15-19).  Every entry point below
+ * names the reference interface it replaces.  Plain pointers and sizes only -- no torch types; every
+ * pointer is a DEVICE pointer unless its name ends in _host.  The library never allocates or frees device
+ * memory: the caller owns the outputs and the three opaque workspaces (sizes from mrgs_*_bytes), exactly as
+ * the reference's geomBuffer / binningBuffer / imgBuffer tensors are owned by Python
+ * (rasterize_points.cu:95-103, diff_surfel_rasterization/__init__.py:101).  All work is enqueued on the
+ * caller's hipStream_t (pass torch.cuda.current_stream().cuda_stream); calls on distinct streams/devices are
+ * independent.  Return value: 0 on success, otherwise an MRGS_E_* code (mrgs_strerror gives the text);
+ * nothing throws across the ABI.
+ */
+#ifndef MRGS_H_INCLUDED
+#define MRGS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRGS_MAX_FEATURES 24 /* cuda_rasterizer/config.h:17 */
+#define MRGS_TILE 16         /* cuda_rasterizer/config.h:19-20 */
+#define MRGS_NUM_OTHERS 7    /* auxiliary.h:25-29: depth, alpha, normal xyz, median depth, distortion */
+
+enum {
+    MRGS_OK = 0,
+    MRGS_E_BAD_ARG = 1,       /* shape / pointer contract violated (AT_ERROR in rasterize_points.cu:64-66) */
+    MRGS_E_TOO_MANY_FEATURES = 2,
+    MRGS_E_NEED_COLORS = 3,   /* neither SH nor precomputed colours (rasterizer_impl.cu:248-251) */
+    MRGS_E_HIP = 4,           /* a HIP runtime call failed; see mrgs_last_hip_error() */
+    MRGS_E_WORKSPACE = 5,     /* workspace too small for this call */
+    MRGS_E_UNSUPPORTED = 6
+};
+
+/* Scalar arguments shared by forward and backward; mirrors GaussianRasterizationSettings
+ * (diff_surfel_rasterization/__init__.py:167-179) plus the tensor extents the pybind layer derives
+ * (rasterize_points.cu:69-72,116-121). */
+typedef struct MrgsRasterConfig {
+    int32_t P;            /* number of gaussians (means3D.size(0)) */
+    int32_t S;            /* extra feature channels (features.size(1)), 0..MRGS_MAX_FEATURES */
+    int32_t D;            /* active SH degree (raster_settings.sh_degree) */
+    int32_t M;            /* SH coefficients per gaussian (sh.size(1)), 0 when colours are precomputed */
+    int32_t H, W;         /* image_height, image_width */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t debug;        /* nonzero: synchronise the stream and report HIP errors after every kernel (CHECK_CUDA, auxiliary.h:303-310) */
+} MrgsRasterConfig;
+
+/* Per-gaussian inputs (device pointers, contiguous fp32, the GaussianModel getter layout):
+ * means3D[P,3], shs[P,M,3] or NULL, colors_precomp[P,3] or NULL, features[P,S] (may be NULL when S==0),
+ * opacities[P], scales[P,2]+rotations[P,4] (w,x,y,z) or both NULL with transMat_precomp[P,9] given.
+ * Camera: viewmatrix[16], projmatrix[16] (row-vector convention tensors, read as stored), campos[3], bg[3]. */
+typedef struct MrgsRasterInputs {
+    const float* bg;
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* features;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* transMat_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+} MrgsRasterInputs;
+
+/* Workspace sizes.  geom <-> geomBuffer (GeometryState, rasterizer_impl.cu:157-172), img <-> imgBuffer
+ * (ImageState, :174-181), binning <-> binningBuffer (BinningState, :183-196; sized from num_rendered). */
+size_t mrgs_geom_bytes(int32_t P, int32_t H, int32_t W);
+size_t mrgs_img_bytes(int32_t H, int32_t W);
+size_t mrgs_binning_bytes(int64_t num_rendered);
+
+/* Forward, phase 1 of 2.  Replaces the first half of CudaRasterizer::Rasterizer::forward
+ * (rasterizer_impl.cu:200-291: preprocess, prefix sum, blocking read-back of num_rendered).
+ * Writes radii[P] (int32), fills geom_ws, and returns the number of (tile, gaussian) pairs in
+ * *num_rendered_host after synchronising `stream` (the reference does the same blocking 4-byte copy, :287). */
+int mrgs_rasterize_forward_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                                int32_t* radii, int64_t* num_rendered_host, void* stream);
+
+/* Forward, phase 2 of 2.  Replaces rasterizer_impl.cu:293-348 (duplicateWithKeys, tile sort, tile ranges,
+ * per-tile blend).  Outputs (caller-allocated; fully written, no pre-zeroing needed): out_color[3,H,W],
+ * out_feature[S,H,W], out_others[7,H,W].  binning_ws must hold mrgs_binning_bytes(num_rendered). */
+int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, void* binning_ws,
+                                  size_t binning_bytes, void* img_ws, int64_t num_rendered, float* out_color,
+                                  float* out_feature, float* out_others, void* stream);
+
+/* Gradient outputs of mrgs_rasterize_backward, the tuple returned by RasterizeGaussiansBackwardCUDA
+ * (rasterize_points.cu:146-252): all fully written by the call (no pre-zeroing needed). */
+typedef struct MrgsRasterGrads {
+    float* dL_dmeans2D;    /* [P,3]  (.xy = densification proxy, backward.cu:665-668; .z = 0) */
+    float* dL_dcolors;     /* [P,3] */
+    float* dL_dfeatures;   /* [P,S] */
+    float* dL_dopacity;    /* [P,1] */
+    float* dL_dmeans3D;    /* [P,3] */
+    float* dL_dtransMat;   /* [P,9] */
+    float* dL_dsh;         /* [P,M,3] */
+    float* dL_dscales;     /* [P,2] */
+    float* dL_drotations;  /* [P,4] */
+} MrgsRasterGrads;
+
+/* Backward.  Replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:353-462).  The three
+ * workspaces must be the ones the forward of the same view filled.  grad_ws: scratch of
+ * mrgs_grad_bytes(P,S) bytes for the packed per-gaussian accumulators. */
+size_t mrgs_grad_bytes(int32_t P, int32_t S);
+int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                            const void* binning_ws, const void* img_ws, int64_t num_rendered, const float* dL_dout_color,
+                            const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws,
+                            const MrgsRasterGrads* grads, void* stream);
+
+/* Replaces markVisible (rasterize_points.cu:254-273, rasterizer_impl.cu:56-68,143-155). present: uint8[P]. */
+int mrgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                      void* stream);
+
+/* Introspection used by the parity tests: copies of internal state in the reference's layouts.
+ * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
+ * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],
+ * 10 n_contrib u32[2,H,W], 11 depth-sorted gaussian order u32[P].  dst is a device pointer. */
+int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const void* binning_ws, const void* img_ws,
+                      int64_t num_rendered, int32_t which, void* dst, void* stream);
+
+/* HIP-event timing of the last forward_render / backward call's dominant kernels on their stream (bench.py). */
+typedef struct MrgsKernelTimes {
+    float preprocess_ms, sort_ms, duplicate_ms, render_fwd_ms, render_bwd_ms, preprocess_bwd_ms;
+} MrgsKernelTimes;
+int mrgs_set_profiling(int32_t enabled);
+int mrgs_get_kernel_times(MrgsKernelTimes* out);
+
+const char* mrgs_strerror(int code);
+const char* mrgs_last_hip_error(void);
+const char* mrgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRGS_H_INCLUDED */

@@ -1,0 +1,96 @@
+"""ctypes binding of libmrgs.so (the C ABI declared in include/mrgs.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the rasterizer
+raises.  torch is imported first so that libmrgs.so binds to the HIP runtime torch already loaded
+(same SONAME libamdhip64.so.7) and therefore shares its devices, streams and allocations.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libmrgs.so")
+
+c_int32, c_int64, c_float, c_void_p, c_size_t = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class MrgsRasterConfig(ctypes.Structure):
+    _fields_ = [("P", c_int32), ("S", c_int32), ("D", c_int32), ("M", c_int32), ("H", c_int32), ("W", c_int32),
+                ("tanfovx", c_float), ("tanfovy", c_float), ("scale_modifier", c_float), ("prefiltered", c_int32),
+                ("debug", c_int32)]
+
+
+class MrgsRasterInputs(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
+                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos")]
+
+
+class MrgsRasterGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dfeatures", "dL_dopacity", "dL_dmeans3D",
+                                        "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations")]
+
+
+class MrgsKernelTimes(ctypes.Structure):
+    _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
+                                       "preprocess_bwd_ms")]
+
+
+# every symbol include/mrgs.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mrgs_geom_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "mrgs_img_bytes": (c_size_t, [c_int32, c_int32]),
+    "mrgs_binning_bytes": (c_size_t, [c_int64]),
+    "mrgs_grad_bytes": (c_size_t, [c_int32, c_int32]),
+    "mrgs_rasterize_forward_geom": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p,
+                                                   c_size_t, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    "mrgs_rasterize_forward_render": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p,
+                                                     c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               ctypes.POINTER(MrgsRasterGrads), c_void_p]),
+    "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_debug_export": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                         c_void_p]),
+    "mrgs_set_profiling": (ctypes.c_int, [c_int32]),
+    "mrgs_get_kernel_times": (ctypes.c_int, [ctypes.POINTER(MrgsKernelTimes)]),
+    "mrgs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "mrgs_last_hip_error": (ctypes.c_char_p, []),
+    "mrgs_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libmrgs.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _CSRC, "-s", "-j8"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C materialrefgs_amd/csrc`). There is no CPU fallback for the rasterizer.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError here = the library does not export what mrgs.h declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        msg = L.mrgs_strerror(rc).decode()
+        if rc == 4:
+            msg += ": " + L.mrgs_last_hip_error().decode()
+        raise RuntimeError(f"libmrgs: {msg}")

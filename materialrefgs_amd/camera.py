@@ -1,0 +1,96 @@
+"""Camera matrices in the reference's conventions.
+
+Mirrors /root/reference/utils/graphics_utils.py:37-71 (getWorld2View2, getProjectionMatrix) and
+/root/reference/scene/cameras.py:65-86 (Camera: world_view_transform = W2V^T, full_proj_transform =
+world_view_transform @ projection^T, camera_center = inverse(world_view_transform)[3, :3]).  The
+rasterizer consumes these row-vector-convention tensors as-is (auxiliary.h:80-99 reads them column-major).
+"""
+import math
+from typing import NamedTuple
+
+import numpy as np
+import torch
+
+
+def get_world2view2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
+    """R is the camera-to-world rotation, t the world-to-camera translation (graphics_utils.py:37-49)."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = R.transpose()
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    C2W = np.linalg.inv(Rt)
+    cam_center = C2W[:3, 3]
+    cam_center = (cam_center + translate) * scale
+    C2W[:3, 3] = cam_center
+    Rt = np.linalg.inv(C2W)
+    return np.float32(Rt)
+
+
+def get_projection_matrix(znear, zfar, fovX, fovY):
+    """graphics_utils.py:51-71."""
+    tanHalfFovY = math.tan(fovY / 2)
+    tanHalfFovX = math.tan(fovX / 2)
+    top = tanHalfFovY * znear
+    bottom = -top
+    right = tanHalfFovX * znear
+    left = -right
+    P = torch.zeros(4, 4)
+    z_sign = 1.0
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = z_sign
+    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def fov2focal(fov, pixels):
+    return pixels / (2 * math.tan(fov / 2))
+
+
+class MiniCam(NamedTuple):
+    """The subset of scene/cameras.py:Camera that the render functions read."""
+    image_height: int
+    image_width: int
+    FoVx: float
+    FoVy: float
+    znear: float
+    zfar: float
+    world_view_transform: torch.Tensor   # [4,4], W2V transposed
+    full_proj_transform: torch.Tensor    # [4,4]
+    camera_center: torch.Tensor          # [3]
+    R: torch.Tensor                      # [3,3] c2w rotation (as stored by Camera.R)
+    T: torch.Tensor                      # [3]  w2c translation
+
+    def to(self, device):
+        return self._replace(world_view_transform=self.world_view_transform.to(device),
+                             full_proj_transform=self.full_proj_transform.to(device),
+                             camera_center=self.camera_center.to(device), R=self.R.to(device), T=self.T.to(device))
+
+
+def make_camera(R, T, FoVx, FoVy, height, width, znear=0.01, zfar=100.0):
+    """scene/cameras.py:70-86 without the image plumbing."""
+    wvt = torch.tensor(get_world2view2(np.asarray(R, dtype=np.float64), np.asarray(T, dtype=np.float64))).transpose(0, 1).contiguous()
+    proj = get_projection_matrix(znear=znear, zfar=zfar, fovX=FoVx, fovY=FoVy).transpose(0, 1)
+    full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
+    center = wvt.inverse()[3, :3].contiguous()
+    return MiniCam(int(height), int(width), float(FoVx), float(FoVy), znear, zfar, wvt, full, center,
+                   torch.tensor(np.asarray(R), dtype=torch.float32), torch.tensor(np.asarray(T), dtype=torch.float32))
+
+
+def look_at_camera(azimuth_deg, elevation_deg, distance, FoV, height, width, target=(0.0, 0.0, 0.0)):
+    """NeRF-synthetic style orbit camera: +z forward, +x right, +y down in view space."""
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    tgt = np.asarray(target, dtype=np.float64)
+    eye = tgt + distance * np.array([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az), math.sin(el)])
+    fwd = tgt - eye
+    fwd /= np.linalg.norm(fwd)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R_c2w = np.stack([right, down, fwd], axis=1)   # columns = camera axes in world space
+    T = -R_c2w.T @ eye                             # world-to-camera translation
+    return make_camera(R_c2w, T, FoV, FoV, height, width)

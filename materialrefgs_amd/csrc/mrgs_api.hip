@@ -1,0 +1,377 @@
+// mrgs_api.hip -- C-ABI entry points of libmrgs.so (see include/mrgs.h for the contract and the reference
+// interfaces each entry replaces).
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "mrgs_internal.h"
+
+static thread_local char g_hip_err[256] = "";
+static int g_profiling = 0;
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            snprintf(g_hip_err, sizeof(g_hip_err), "%s at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MRGS_E_HIP;                                                                              \
+        }                                                                                                   \
+    } while (0)
+
+// CHECK_CUDA(A, debug) of the reference (auxiliary.h:303-310): with cfg.debug every stage is synchronised.
+#define STAGE_CHECK(cfg, stream)                                 \
+    do {                                                         \
+        HIP_TRY(hipGetLastError());                              \
+        if ((cfg)->debug) HIP_TRY(hipStreamSynchronize(stream)); \
+    } while (0)
+
+namespace {
+// Non-blocking per-stage timing: while profiling is enabled every stage records a HIP event pair on the
+// launch stream (no host synchronisation inside the timed region); mrgs_get_kernel_times() synchronises the
+// recorded pairs afterwards and returns the mean duration of each stage since the last reset.
+enum { ST_PRE = 0, ST_SORT, ST_DUP, ST_FWD, ST_BWD, ST_PREB, ST_COUNT };
+struct EvPair { hipEvent_t a, b; int stage; };
+static std::vector<EvPair> g_pairs;
+static std::vector<EvPair> g_free;
+
+struct StageTimer {
+    EvPair p;
+    hipStream_t s;
+    bool on;
+    StageTimer(hipStream_t stream, int stage) : s(stream), on(g_profiling != 0)
+    {
+        if (on) {
+            if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+            else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+            p.stage = stage;
+            (void)hipEventRecord(p.a, s);
+        }
+    }
+    void stop()
+    {
+        if (on) {
+            (void)hipEventRecord(p.b, s);
+            g_pairs.push_back(p);
+            on = false;
+        }
+    }
+};
+
+struct Carver {
+    char* p;
+    size_t used = 0;
+    explicit Carver(void* base) : p((char*)base) {}
+    template <typename T>
+    T* take(size_t n)
+    {
+        used = mrgs_align_up(used, 256);
+        T* r = p ? (T*)(p + used) : nullptr;
+        used += sizeof(T) * n;
+        return r;
+    }
+};
+}   // namespace
+
+MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
+{
+    (void)H; (void)W;
+    Carver c(base);
+    MrgsGeomWs g;
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const size_t nblk = (n + MRGS_SORT_TILE - 1) / MRGS_SORT_TILE;
+    g.rec = c.take<float4>(n * MRGS_REC_F4);
+    g.depth_key[0] = c.take<uint32_t>(n);
+    g.depth_key[1] = c.take<uint32_t>(n);
+    g.order[0] = c.take<uint32_t>(n);
+    g.order[1] = c.take<uint32_t>(n);
+    g.rect = c.take<uint2>(n);
+    g.tiles_touched = c.take<uint32_t>(n);
+    g.offsets = c.take<uint32_t>(n);
+    g.clamped = c.take<uint8_t>(n);
+    g.sort_hist = c.take<uint32_t>(256 * nblk);
+    g.scan_tmp = c.take<uint32_t>((n + 2047) / 2048 + 1);
+    g.counters = c.take<uint32_t>(16);
+    g.total = mrgs_align_up(c.used, 256);
+    return g;
+}
+
+MrgsImgWs mrgs_carve_img(void* base, int H, int W)
+{
+    Carver c(base);
+    MrgsImgWs w;
+    const size_t hw = (size_t)H * W;
+    const size_t tiles = (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y);
+    w.ranges = c.take<uint2>(tiles > 0 ? tiles : 1);
+    w.final_T = c.take<float>(3 * hw);
+    w.n_contrib = c.take<uint32_t>(2 * hw);
+    w.total = mrgs_align_up(c.used, 256);
+    return w;
+}
+
+MrgsBinWs mrgs_carve_bin(void* base, int64_t R)
+{
+    Carver c(base);
+    MrgsBinWs b;
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    const size_t nblk = (n + MRGS_SORT_TILE - 1) / MRGS_SORT_TILE;
+    b.tile_key[0] = c.take<uint32_t>(n);
+    b.tile_key[1] = c.take<uint32_t>(n);
+    b.plist[0] = c.take<uint32_t>(n);
+    b.plist[1] = c.take<uint32_t>(n);
+    b.sort_hist = c.take<uint32_t>(256 * nblk);
+    b.total = mrgs_align_up(c.used, 256);
+    return b;
+}
+
+static int tile_bits(int ntiles)
+{
+    int bits = 1;
+    while ((1 << bits) < ntiles) bits++;
+    return bits;
+}
+
+// which of the two ping-pong buffers holds the final data after sorting `bits` bits in 8-bit passes
+static int sorted_buf(int bits) { return ((bits + 7) / 8) & 1; }
+
+static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
+{
+    if (!cfg || !in) return MRGS_E_BAD_ARG;
+    if (cfg->P < 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->S < 0 || cfg->M < 0) return MRGS_E_BAD_ARG;
+    if (cfg->S > MRGS_MAX_FEATURES) return MRGS_E_TOO_MANY_FEATURES;
+    if (cfg->P > 0) {
+        if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->campos || !in->bg) return MRGS_E_BAD_ARG;
+        if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) return MRGS_E_NEED_COLORS;
+        if (in->shs && cfg->M <= 0) return MRGS_E_BAD_ARG;
+        const bool have_sr = in->scales && in->rotations;
+        if (have_sr == (in->transMat_precomp != nullptr)) return MRGS_E_BAD_ARG;
+        if (cfg->S > 0 && !in->features) return MRGS_E_BAD_ARG;
+        if ((cfg->W + 15) / 16 > 65535 || (cfg->H + 15) / 16 > 65535) return MRGS_E_UNSUPPORTED;
+    }
+    return MRGS_OK;
+}
+
+extern "C" {
+
+size_t mrgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return mrgs_carve_geom(nullptr, P, H, W).total; }
+size_t mrgs_img_bytes(int32_t H, int32_t W) { return mrgs_carve_img(nullptr, H, W).total; }
+size_t mrgs_binning_bytes(int64_t R) { return mrgs_carve_bin(nullptr, R).total; }
+size_t mrgs_grad_bytes(int32_t P, int32_t S) { return mrgs_align_up((size_t)(P > 0 ? P : 1) * MRGS_GRAD_STRIDE(S) * sizeof(float), 256); }
+
+int mrgs_rasterize_forward_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                                int32_t* radii, int64_t* num_rendered_host, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg, in);
+    if (rc) return rc;
+    if (!num_rendered_host) return MRGS_E_BAD_ARG;
+    *num_rendered_host = 0;
+    if (cfg->P == 0) return MRGS_OK;
+    if (!geom_ws || !radii) return MRGS_E_BAD_ARG;
+    MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
+    if (geom_bytes < g.total) return MRGS_E_WORKSPACE;
+
+    StageTimer t0(stream, ST_PRE);
+    mrgs_launch_preprocess_fwd(*cfg, *in, g, radii, stream);
+    t0.stop();
+    STAGE_CHECK(cfg, stream);
+
+    StageTimer t1(stream, ST_SORT);
+    // depth sort of the gaussians (32 key bits, 4 passes -> result back in buffer 0)
+    const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_hist, cfg->P, 0, 32, stream);
+    STAGE_CHECK(cfg, stream);
+    mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_tmp, g.counters, cfg->P, stream);
+    t1.stop();
+    STAGE_CHECK(cfg, stream);
+
+    // blocking 4-byte read-back of num_rendered, as rasterizer_impl.cu:287
+    uint32_t R = 0;
+    HIP_TRY(hipMemcpyAsync(&R, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *num_rendered_host = (int64_t)R;
+    return MRGS_OK;
+}
+
+int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, void* binning_ws,
+                                  size_t binning_bytes, void* img_ws, int64_t R, float* out_color, float* out_feature,
+                                  float* out_others, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg, in);
+    if (rc) return rc;
+    if (!out_color || !out_others || (cfg->S > 0 && !out_feature) || !img_ws) return MRGS_E_BAD_ARG;
+    const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    const int ntiles = tiles_x * tiles_y;
+    MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
+    const size_t hw = (size_t)cfg->H * cfg->W;
+    if (cfg->P == 0) {
+        // the reference returns zero-filled outputs without touching the kernels (rasterize_points.cu:89-93,106)
+        HIP_TRY(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * hw, stream));
+        if (cfg->S > 0) HIP_TRY(hipMemsetAsync(out_feature, 0, sizeof(float) * cfg->S * hw, stream));
+        HIP_TRY(hipMemsetAsync(out_others, 0, sizeof(float) * MRGS_NUM_OTHERS * hw, stream));
+        return MRGS_OK;
+    }
+    if (!geom_ws || !binning_ws) return MRGS_E_BAD_ARG;
+    MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
+    MrgsBinWs b = mrgs_carve_bin(binning_ws, R);
+    if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
+    const int dcur = sorted_buf(32);
+
+    StageTimer t0(stream, ST_DUP);
+    if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], stream);
+    STAGE_CHECK(cfg, stream);
+    const int bits = tile_bits(ntiles);
+    const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_hist, R, 0, bits, stream);
+    STAGE_CHECK(cfg, stream);
+    mrgs_launch_tile_ranges(b.tile_key[cur], R, img.ranges, ntiles, stream);
+    t0.stop();
+    STAGE_CHECK(cfg, stream);
+
+    StageTimer t1(stream, ST_FWD);
+    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], img, out_color, out_feature, out_others, stream);
+    t1.stop();
+    STAGE_CHECK(cfg, stream);
+    return MRGS_OK;
+}
+
+int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                            const void* binning_ws, const void* img_ws, int64_t R, const float* dL_dout_color,
+                            const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws, const MrgsRasterGrads* grads,
+                            void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg, in);
+    if (rc) return rc;
+    if (!grads) return MRGS_E_BAD_ARG;
+    if (cfg->P == 0) return MRGS_OK;   // every gradient tensor has zero elements
+    if (!radii || !geom_ws || !binning_ws || !img_ws || !grad_ws || !dL_dout_color || !dL_dout_others) return MRGS_E_BAD_ARG;
+    if (cfg->S > 0 && !dL_dout_feature) return MRGS_E_BAD_ARG;
+    if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
+        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh))
+        return MRGS_E_BAD_ARG;
+    const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);
+    MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
+    MrgsImgWs img = mrgs_carve_img(const_cast<void*>(img_ws), cfg->H, cfg->W);
+    const int cur = sorted_buf(tile_bits(tiles_x * tiles_y));
+    float* grad_rec = (float*)grad_ws;
+
+    StageTimer t0(stream, ST_BWD);
+    HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
+    if (R > 0)
+        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
+    t0.stop();
+    STAGE_CHECK(cfg, stream);
+
+    StageTimer t1(stream, ST_PREB);
+    mrgs_launch_preprocess_bwd(*cfg, *in, g, radii, grad_rec, *grads, stream);
+    t1.stop();
+    STAGE_CHECK(cfg, stream);
+    return MRGS_OK;
+}
+
+int mrgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                      void* stream_)
+{
+    (void)projmatrix;
+    if (P < 0) return MRGS_E_BAD_ARG;
+    if (P == 0) return MRGS_OK;
+    if (!means3D || !viewmatrix || !present) return MRGS_E_BAD_ARG;
+    mrgs_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_);
+    HIP_TRY(hipGetLastError());
+    return MRGS_OK;
+}
+
+// ---- introspection for the parity tests --------------------------------------------------------------
+__global__ void export_rec_kernel(int P, int which, const float4* __restrict__ rec, const uint8_t* __restrict__ clamped, void* dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4* r = rec + (size_t)i * MRGS_REC_F4;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+    float* f = (float*)dst;
+    switch (which) {
+    case 0: f[i] = r4.z; break;
+    case 1: f[2 * i] = r2.y; f[2 * i + 1] = r2.z; break;
+    case 2: {
+        float* t = f + 9 * (size_t)i;
+        t[0] = r0.x; t[1] = r0.y; t[2] = r0.z; t[3] = r0.w; t[4] = r1.x; t[5] = r1.y; t[6] = r1.z; t[7] = r1.w; t[8] = r2.x;
+    } break;
+    case 3: f[4 * i] = r3.x; f[4 * i + 1] = r3.y; f[4 * i + 2] = r3.z; f[4 * i + 3] = r2.w; break;
+    case 4: f[3 * i] = r3.w; f[3 * i + 1] = r4.x; f[3 * i + 2] = r4.y; break;
+    case 6: {
+        uint8_t* c = (uint8_t*)dst;
+        const uint32_t cl = clamped[i];
+        c[3 * i] = cl & 1; c[3 * i + 1] = (cl >> 1) & 1; c[3 * i + 2] = (cl >> 2) & 1;
+    } break;
+    default: break;
+    }
+}
+
+int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const void* binning_ws, const void* img_ws, int64_t R,
+                      int32_t which, void* dst, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!cfg || !dst) return MRGS_E_BAD_ARG;
+    const int P = cfg->P;
+    const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    const size_t hw = (size_t)cfg->H * cfg->W;
+    MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), P, cfg->H, cfg->W);
+    MrgsImgWs img = mrgs_carve_img(const_cast<void*>(img_ws), cfg->H, cfg->W);
+    switch (which) {
+    case 0: case 1: case 2: case 3: case 4: case 6:
+        if (P > 0) hipLaunchKernelGGL(export_rec_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, which, g.rec, g.clamped, dst);
+        break;
+    case 5: HIP_TRY(hipMemcpyAsync(dst, g.tiles_touched, sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, stream)); break;
+    case 7: {
+        MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
+        const int cur = sorted_buf(tile_bits(tiles_x * tiles_y));
+        if (R > 0) HIP_TRY(hipMemcpyAsync(dst, b.plist[cur], sizeof(uint32_t) * R, hipMemcpyDeviceToDevice, stream));
+    } break;
+    case 8: HIP_TRY(hipMemcpyAsync(dst, img.ranges, sizeof(uint2) * tiles_x * tiles_y, hipMemcpyDeviceToDevice, stream)); break;
+    case 9: HIP_TRY(hipMemcpyAsync(dst, img.final_T, sizeof(float) * 3 * hw, hipMemcpyDeviceToDevice, stream)); break;
+    case 10: HIP_TRY(hipMemcpyAsync(dst, img.n_contrib, sizeof(uint32_t) * 2 * hw, hipMemcpyDeviceToDevice, stream)); break;
+    case 11: HIP_TRY(hipMemcpyAsync(dst, g.order[sorted_buf(32)], sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, stream)); break;
+    default: return MRGS_E_BAD_ARG;
+    }
+    HIP_TRY(hipGetLastError());
+    return MRGS_OK;
+}
+
+int mrgs_set_profiling(int32_t enabled)
+{
+    g_profiling = enabled;
+    for (auto& p : g_pairs) g_free.push_back(p);   // reset the statistics
+    g_pairs.clear();
+    return MRGS_OK;
+}
+int mrgs_get_kernel_times(MrgsKernelTimes* out)
+{
+    if (!out) return MRGS_E_BAD_ARG;
+    double sum[ST_COUNT] = {0};
+    int cnt[ST_COUNT] = {0};
+    for (auto& p : g_pairs) {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { sum[p.stage] += ms; cnt[p.stage]++; }
+    }
+    float* dst[ST_COUNT] = {&out->preprocess_ms, &out->sort_ms, &out->duplicate_ms, &out->render_fwd_ms, &out->render_bwd_ms,
+                            &out->preprocess_bwd_ms};
+    for (int i = 0; i < ST_COUNT; i++) *dst[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
+    return MRGS_OK;
+}
+
+const char* mrgs_strerror(int code)
+{
+    switch (code) {
+    case MRGS_OK: return "ok";
+    case MRGS_E_BAD_ARG: return "bad argument (shape / pointer contract violated)";
+    case MRGS_E_TOO_MANY_FEATURES: return "more than MRGS_MAX_FEATURES (24) feature channels";
+    case MRGS_E_NEED_COLORS: return "provide exactly one of SHs or precomputed colours";
+    case MRGS_E_HIP: return "HIP runtime error (see mrgs_last_hip_error)";
+    case MRGS_E_WORKSPACE: return "workspace too small";
+    case MRGS_E_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+    }
+}
+const char* mrgs_last_hip_error(void) { return g_hip_err; }
+const char* mrgs_version(void) { return "mrgs 0.1.0 (gfx950)"; }
+
+}   // extern "C"

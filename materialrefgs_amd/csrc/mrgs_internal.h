@@ -1,0 +1,87 @@
+// mrgs_internal.h -- shared declarations of the libmrgs.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mrgs.h"
+
+#define MRGS_BLOCK_X 16
+#define MRGS_BLOCK_Y 16
+#define MRGS_NEAR_N 0.2f             // auxiliary.h:39
+#define MRGS_FAR_N 100.0f            // auxiliary.h:40
+#define MRGS_FILTER_INV_SQUARE 2.0f  // auxiliary.h:41
+
+// Packed per-gaussian render record written by preprocess and gathered by the blend kernels:
+// 5 x float4 = 80 B, 16-byte aligned so that a record is fetched with five dwordx4 loads.
+//   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   [3] normal.xyz, rgb.r   [4] rgb.gb, 0, 0
+// (the reference keeps these in five separate arrays: transMat, means2D, normal_opacity, rgb; forward.cu:350-357,427)
+#define MRGS_REC_F4 5
+
+// Packed per-gaussian gradient accumulator of the blend backward (one row per gaussian so that the
+// atomics of one (tile, gaussian) pair land in one or two cache lines):
+//   [0..8] dL/dT (Tu,Tv,Tw)  [9..10] dL/dmean2D.xy  [11] dL/dopacity  [12..14] dL/dnormal  [15..17] dL/dcolor
+//   [18..18+S) dL/dfeature ; row stride = MRGS_GRAD_STRIDE(S) floats
+#define MRGS_GRAD_STRIDE(S) ((18 + (S) + 3) & ~3)
+
+static inline size_t mrgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
+    float4* rec;            // [P][5]
+    uint32_t* depth_key[2]; // [P] ping-pong radix keys (depth bits, 0xFFFFFFFF when culled)
+    uint32_t* order[2];     // [P] ping-pong payload: gaussian index
+    uint2* rect;            // [P] tile rect packed: x = min.x | min.y<<16, y = max.x | max.y<<16
+    uint32_t* tiles_touched;// [P]
+    uint32_t* offsets;      // [P] exclusive scan of tiles_touched in depth-sorted order
+    uint8_t* clamped;       // [P] bit c set when SH colour channel c was clamped
+    uint32_t* sort_hist;    // [256 * nblk_max] per-block digit histograms / offsets of the radix passes
+    uint32_t* scan_tmp;     // [nblk] block sums of the tiles_touched scan
+    uint32_t* counters;     // [16] 0: num_rendered, 1: which depth buffer holds the sorted order
+    size_t total;
+};
+
+struct MrgsImgWs {
+    uint2* ranges;       // [tiles]
+    float* final_T;      // [3][H*W]: T, M1, M2
+    uint32_t* n_contrib; // [2][H*W]: last, median
+    size_t total;
+};
+
+struct MrgsBinWs {
+    uint32_t* tile_key[2];  // [R] ping-pong: tile id of each pair
+    uint32_t* plist[2];     // [R] ping-pong: gaussian index of each pair
+    uint32_t* sort_hist;    // [256 * nblk]
+    size_t total;
+};
+
+MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W);
+MrgsImgWs mrgs_carve_img(void* base, int H, int W);
+MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
+
+// ---- kernel launchers (one per translation unit) ---------------------------------------------------
+// radix sort of (u32 key, u32 value) pairs on bits [bit_lo, bit_hi); returns index (0/1) of the buffer
+// that holds the sorted result.  hist must hold 256 * ceil(n / SORT_TILE) u32.
+#define MRGS_SORT_TILE 4096
+int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* hist, int64_t n, int bit_lo, int bit_hi,
+                          hipStream_t stream);
+// exclusive scan of tiles_touched[order[i]] -> offsets[i]; total -> *total_out (device)
+void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* block_sums,
+                     uint32_t* total_out, int n, hipStream_t stream);
+
+void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, int32_t* radii,
+                                hipStream_t stream);
+void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g,
+                                const int32_t* radii, const float* grad_rec, const MrgsRasterGrads& out, hipStream_t stream);
+void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
+
+void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
+                           uint32_t* plist, hipStream_t stream);
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, int ntiles, hipStream_t stream);
+
+void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
+                            const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);
+void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
+                            const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
+                            float* grad_rec, hipStream_t stream);
+
+#ifndef MRGS_EXP
+#define MRGS_EXP(x) __expf(x)
+#endif

@@ -1,0 +1,484 @@
+// mrgs_preprocess.hip -- per-gaussian kernels of the surfel rasterizer on gfx950 (one gaussian per lane).
+//
+//   preprocess_fwd_kernel : FORWARD::preprocess / preprocessCUDA (forward.cu:163-266) + compute_transmat (:77-125)
+//                           + compute_aabb (:129-159) + computeColorFromSH (:22-73) + getRect (auxiliary.h:68-78)
+//   preprocess_bwd_kernel : BACKWARD::preprocess / preprocessCUDA (backward.cu:614-669) + compute_transmat_aabb
+//                           (:471-612) + computeColorFromSH backward (:22-141) + quat_to_rotmat_vjp (auxiliary.h:245-289)
+//   mark_visible_kernel   : checkFrustum (rasterizer_impl.cu:56-68)
+//
+// This file is compiled with -ffp-contract=off: every discrete decision of the pipeline (cull, radius, tile
+// rect, sort key) is taken here, and keeping IEEE mul/add/div/sqrt un-fused makes the geometry state -- and
+// therefore the whole integer binning state -- reproducible bit for bit (tests/test_gpu_parity.py).  The
+// kernels are bandwidth-trivial (~320 B/gaussian), so the un-fused arithmetic costs nothing measurable.
+// The 35 camera floats are read from the caller's device tensors through wave-uniform (scalar) loads.
+#include "mrgs_internal.h"
+
+__device__ __constant__ float kSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float kSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f};
+
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// auxiliary.h:220-242, column-major R[c][r]; rsqrtf evaluated as 1/sqrt (IEEE)
+__device__ __forceinline__ void quat_to_rotmat(const float4 q, float R[3][3])
+{
+    const float s = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y + w * z);
+    R[0][2] = 2.f * (x * z - w * y);
+    R[1][0] = 2.f * (x * y - w * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z + w * x);
+    R[2][0] = 2.f * (x * z + w * y);
+    R[2][1] = 2.f * (y * z - w * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void row_times_proj(const float a[4], const float* pm, float out[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) out[c] = a[0] * pm[0 + c] + a[1] * pm[4 + c] + a[2] * pm[8 + c] + a[3] * pm[12 + c];
+}
+
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, int rmin[2], int rmax[2])
+{
+    const float r = (float)max_radius;
+    rmin[0] = min(gx, max(0, f2i_sat((px - r) / (float)MRGS_BLOCK_X)));
+    rmin[1] = min(gy, max(0, f2i_sat((py - r) / (float)MRGS_BLOCK_Y)));
+    rmax[0] = min(gx, max(0, f2i_sat((px + r + (float)MRGS_BLOCK_X - 1.0f) / (float)MRGS_BLOCK_X)));
+    rmax[1] = min(gy, max(0, f2i_sat((py + r + (float)MRGS_BLOCK_Y - 1.0f) / (float)MRGS_BLOCK_Y)));
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
+    int P, int D, int M, int W, int H, int tiles_x, int tiles_y, float scale_modifier, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order,
+    uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    float V[16], PM[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { V[i] = viewmatrix[i]; PM[i] = projmatrix[i]; }
+    int out_radius = 0;
+    uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
+    uint2 out_rect = make_uint2(0, 0);
+    do {
+        const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+        const float pvx = V[0] * p[0] + V[4] * p[1] + V[8] * p[2] + V[12];
+        const float pvy = V[1] * p[0] + V[5] * p[1] + V[9] * p[2] + V[13];
+        const float pvz = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+        if (pvz <= 0.2f) break;   // in_frustum, auxiliary.h:207 (the NDC test is commented out in the reference)
+
+        float T[9], nx, ny, nz;
+        if (scales != nullptr) {
+            float R[3][3];
+            quat_to_rotmat(reinterpret_cast<const float4*>(rotations)[idx], R);
+            const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
+            const float sx = scale_modifier * sc.x, sy = scale_modifier * sc.y;
+            float L0[3], L1[3], L2[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                L0[r] = R[0][r] * sx + R[1][r] * 0.0f + R[2][r] * 0.0f;
+                L1[r] = R[0][r] * 0.0f + R[1][r] * sy + R[2][r] * 0.0f;
+                L2[r] = R[0][r] * 0.0f + R[1][r] * 0.0f + R[2][r] * 1.0f;
+            }
+            const float a0[4] = {L0[0], L0[1], L0[2], 0.0f};
+            const float a1[4] = {L1[0], L1[1], L1[2], 0.0f};
+            const float a2[4] = {p[0], p[1], p[2], 1.0f};
+            float c[3][4];
+            row_times_proj(a0, PM, c[0]);
+            row_times_proj(a1, PM, c[1]);
+            row_times_proj(a2, PM, c[2]);
+            const float hw = (float)W / 2.0f, ow = (float)(W - 1) / 2.0f;
+            const float hh = (float)H / 2.0f, oh = (float)(H - 1) / 2.0f;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                T[0 + i] = c[i][0] * hw + c[i][1] * 0.0f + c[i][2] * 0.0f + c[i][3] * ow;
+                T[3 + i] = c[i][0] * 0.0f + c[i][1] * hh + c[i][2] * 0.0f + c[i][3] * oh;
+                T[6 + i] = c[i][0] * 0.0f + c[i][1] * 0.0f + c[i][2] * 0.0f + c[i][3] * 1.0f;
+            }
+            nx = V[0] * L2[0] + V[4] * L2[1] + V[8] * L2[2];
+            ny = V[1] * L2[0] + V[5] * L2[1] + V[9] * L2[2];
+            nz = V[2] * L2[0] + V[6] * L2[1] + V[10] * L2[2];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; i++) T[i] = transMat_precomp[9 * (size_t)idx + i];
+            nx = 0.0f; ny = 0.0f; nz = 1.0f;
+        }
+        // DUAL_VISIABLE, forward.cu:224-229
+        const float cosv = -((pvx * nx + pvy * ny) + pvz * nz);
+        if (cosv == 0) break;
+        const float mult = cosv > 0 ? 1.0f : -1.0f;
+        nx = mult * nx; ny = mult * ny; nz = mult * nz;
+
+        // compute_aabb with cutoff 3 (TIGHTBBOX 0), forward.cu:129-159,235
+        const float* T0 = T; const float* T1 = T + 3; const float* T3 = T + 6;
+        const float t[3] = {9.0f, 9.0f, -1.0f};
+        const float distance = ((T3[0] * T3[0]) * t[0] + (T3[1] * T3[1]) * t[1]) + (T3[2] * T3[2]) * t[2];
+        const float inv = 1 / distance;
+        const float f[3] = {inv * t[0], inv * t[1], inv * t[2]};
+        if (distance == 0.0f) break;
+        const float cx = ((f[0] * T0[0]) * T3[0] + (f[1] * T0[1]) * T3[1]) + (f[2] * T0[2]) * T3[2];
+        const float cy = ((f[0] * T1[0]) * T3[0] + (f[1] * T1[1]) * T3[1]) + (f[2] * T1[2]) * T3[2];
+        const float tmp0 = ((f[0] * T0[0]) * T0[0] + (f[1] * T0[1]) * T0[1]) + (f[2] * T0[2]) * T0[2];
+        const float tmp1 = ((f[0] * T1[0]) * T1[0] + (f[1] * T1[1]) * T1[1]) + (f[2] * T1[2]) * T1[2];
+        const float h0 = cx * cx - tmp0, h1 = cy * cy - tmp1;
+        const float floor_ = 1e-4f;
+        const float e0 = sqrtf((h0 != h0) ? floor_ : (floor_ > h0 ? floor_ : h0));
+        const float e1 = sqrtf((h1 != h1) ? floor_ : (floor_ > h1 ? floor_ : h1));
+        const float radius = ceilf(e0 > e1 ? e0 : e1);
+        const int iradius = f2i_sat(radius);
+        int rmin[2], rmax[2];
+        get_rect(cx, cy, iradius, tiles_x, tiles_y, rmin, rmax);
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) break;
+
+        float rgb[3];
+        if (colors_precomp == nullptr) {
+            // computeColorFromSH, forward.cu:22-73
+            const float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float x = dx / len, y = dy / len, z = dz / len;
+            const float* sh = shs + (size_t)idx * M * 3;
+            uint32_t cl = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+#define SH(i) sh[(i) * 3 + c]
+                float r = kSH_C0 * SH(0);
+                if (D > 0) {
+                    r = r - kSH_C1 * y * SH(1) + kSH_C1 * z * SH(2) - kSH_C1 * x * SH(3);
+                    if (D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        r = r + kSH_C2[0] * xy * SH(4) + kSH_C2[1] * yz * SH(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                            kSH_C2[3] * xz * SH(7) + kSH_C2[4] * (xx - yy) * SH(8);
+                        if (D > 2) {
+                            r = r + kSH_C3[0] * y * (3.0f * xx - yy) * SH(9) + kSH_C3[1] * xy * z * SH(10) +
+                                kSH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                                kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                                kSH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + kSH_C3[5] * z * (xx - yy) * SH(14) +
+                                kSH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                        }
+                    }
+                }
+#undef SH
+                r += 0.5f;
+                if (r < 0) cl |= 1u << c;
+                rgb[c] = r > 0.0f ? r : 0.0f;
+            }
+            clamped[idx] = (uint8_t)cl;
+        } else {
+            rgb[0] = colors_precomp[3 * (size_t)idx];
+            rgb[1] = colors_precomp[3 * (size_t)idx + 1];
+            rgb[2] = colors_precomp[3 * (size_t)idx + 2];
+        }
+        const float opa = opacities[idx];
+        float4* r4 = rec + (size_t)idx * MRGS_REC_F4;
+        r4[0] = make_float4(T[0], T[1], T[2], T[3]);
+        r4[1] = make_float4(T[4], T[5], T[6], T[7]);
+        r4[2] = make_float4(T[8], cx, cy, opa);
+        r4[3] = make_float4(nx, ny, nz, rgb[0]);
+        r4[4] = make_float4(rgb[1], rgb[2], pvz, 0.0f);
+        out_radius = iradius;
+        out_tiles = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
+        out_key = __float_as_uint(pvz);
+        out_rect = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
+    } while (0);
+    radii[idx] = out_radius;
+    tiles_touched[idx] = out_tiles;
+    depth_key[idx] = out_key;
+    order[idx] = (uint32_t)idx;
+    rect[idx] = out_rect;
+}
+
+void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, int32_t* radii,
+                                hipStream_t stream)
+{
+    const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H,
+                       tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
+                       in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec,
+                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+
+// auxiliary.h:129-139
+__device__ __forceinline__ f3 dnormvdv(f3 v, f3 dv)
+{
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    f3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(
+    int P, int D, int M, int S, int Wimg, int Himg, float tanfovx, float tanfovy, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
+    const float* __restrict__ transMat_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    const float* __restrict__ campos, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+    const float4* __restrict__ rec, const float* __restrict__ grad_rec, int gstride, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeatures, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drotations)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const bool live = radii[idx] > 0;   // backward.cu:643
+    const bool precomp = scales == nullptr;
+    const float* gr = grad_rec + (size_t)idx * gstride;
+
+    float dT[9], dm3[3] = {0, 0, 0}, dsc[2] = {0, 0}, drot[4] = {0, 0, 0, 0}, dm2[2] = {0, 0}, dcol[3] = {0, 0, 0}, dop = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) dT[i] = 0.0f;
+    float dT_out[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) dT_out[i] = 0.0f;
+
+    if (live) {
+        float V[16], PM[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { V[i] = viewmatrix[i]; PM[i] = projmatrix[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { dT[i] = gr[i]; dT_out[i] = dT[i]; }
+        const float m2x = gr[9], m2y = gr[10];
+        dop = gr[11];
+        const float dn[3] = {gr[12], gr[13], gr[14]};
+        dcol[0] = gr[15]; dcol[1] = gr[16]; dcol[2] = gr[17];
+
+        // rasterizer_impl.cu:398-399 and backward.cu:646-647: W,H are re-derived from the focal lengths
+        const float focal_y = Himg / (2.0f * tanfovy), focal_x = Wimg / (2.0f * tanfovx);
+        const int W = f2i_sat(focal_x * tanfovx * 2), H = f2i_sat(focal_y * tanfovy * 2);
+
+        float T[9], Pm[4][3], R[3][3];
+        float nx = 0, ny = 0, nz = 0, sx0 = 0, sy0 = 0;
+        const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+        if (precomp) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) T[i] = transMat_precomp[9 * (size_t)idx + i];
+        } else {
+            const float2 sc = reinterpret_cast<const float2*>(scales)[idx];
+            sx0 = sc.x; sy0 = sc.y;
+            quat_to_rotmat(reinterpret_cast<const float4*>(rotations)[idx], R);
+            const float sx = 1.0f * sx0, sy = 1.0f * sy0;   // scale_to_mat(scale, 1.0f), backward.cu:509
+            float L0[3], L1[3], L2[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                L0[r] = R[0][r] * sx + R[1][r] * 0.0f + R[2][r] * 0.0f;
+                L1[r] = R[0][r] * 0.0f + R[1][r] * sy + R[2][r] * 0.0f;
+                L2[r] = R[0][r] * 0.0f + R[1][r] * 0.0f + R[2][r] * 1.0f;
+            }
+            const float hw = (float)W / 2.0f, ow = (float)(W - 1) / 2.0f;
+            const float hh = (float)H / 2.0f, oh = (float)(H - 1) / 2.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {   // P = world2ndc * ndc2pix, backward.cu:531
+                Pm[r][0] = PM[4 * r + 0] * hw + PM[4 * r + 1] * 0.0f + PM[4 * r + 2] * 0.0f + PM[4 * r + 3] * ow;
+                Pm[r][1] = PM[4 * r + 0] * 0.0f + PM[4 * r + 1] * hh + PM[4 * r + 2] * 0.0f + PM[4 * r + 3] * oh;
+                Pm[r][2] = PM[4 * r + 0] * 0.0f + PM[4 * r + 1] * 0.0f + PM[4 * r + 2] * 0.0f + PM[4 * r + 3] * 1.0f;
+            }
+            const float a[3][4] = {{L0[0], L0[1], L0[2], 0.0f}, {L1[0], L1[1], L1[2], 0.0f}, {p[0], p[1], p[2], 1.0f}};
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    T[3 * j + i] = a[i][0] * Pm[0][j] + a[i][1] * Pm[1][j] + a[i][2] * Pm[2][j] + a[i][3] * Pm[3][j];
+            nx = V[0] * L2[0] + V[4] * L2[1] + V[8] * L2[2];
+            ny = V[1] * L2[0] + V[5] * L2[1] + V[9] * L2[2];
+            nz = V[2] * L2[0] + V[6] * L2[1] + V[10] * L2[2];
+        }
+        bool returned = false;
+        if (m2x != 0 || m2y != 0) {   // backward.cu:543-582
+            const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
+            const float distance = Tw[0] * Tw[0] + Tw[1] * Tw[1] - Tw[2] * Tw[2];
+            const float f = 1 / distance;
+            const float dpx_dT00 = f * Tw[0], dpx_dT01 = f * Tw[1], dpx_dT02 = -f * Tw[2];
+            const float dpy_dT10 = f * Tw[0], dpy_dT11 = f * Tw[1], dpy_dT12 = -f * Tw[2];
+            const float dpx_dT30 = Tu[0] * (f - 2 * f * f * Tw[0] * Tw[0]);
+            const float dpx_dT31 = Tu[1] * (f - 2 * f * f * Tw[1] * Tw[1]);
+            const float dpx_dT32 = -Tu[2] * (f + 2 * f * f * Tw[2] * Tw[2]);
+            const float dpy_dT30 = Tv[0] * (f - 2 * f * f * Tw[0] * Tw[0]);
+            const float dpy_dT31 = Tv[1] * (f - 2 * f * f * Tw[1] * Tw[1]);
+            const float dpy_dT32 = -Tv[2] * (f + 2 * f * f * Tw[2] * Tw[2]);
+            dT[0] += m2x * dpx_dT00; dT[1] += m2x * dpx_dT01; dT[2] += m2x * dpx_dT02;
+            dT[3] += m2y * dpy_dT10; dT[4] += m2y * dpy_dT11; dT[5] += m2y * dpy_dT12;
+            dT[6] += m2x * dpx_dT30 + m2y * dpy_dT30;
+            dT[7] += m2x * dpx_dT31 + m2y * dpy_dT31;
+            dT[8] += m2x * dpx_dT32 + m2y * dpy_dT32;
+            if (precomp) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) dT_out[i] = dT[i];
+                returned = true;
+            }
+        }
+        if (!precomp && !returned) {
+            float dM[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) dM[i][r] = Pm[r][0] * dT[0 + i] + Pm[r][1] * dT[3 + i] + Pm[r][2] * dT[6 + i];
+            float dtx = V[0] * dn[0] + V[1] * dn[1] + V[2] * dn[2];
+            float dty = V[4] * dn[0] + V[5] * dn[1] + V[6] * dn[2];
+            float dtz = V[8] * dn[0] + V[9] * dn[1] + V[10] * dn[2];
+            const float pvx = V[0] * p[0] + V[4] * p[1] + V[8] * p[2] + V[12];
+            const float pvy = V[1] * p[0] + V[5] * p[1] + V[9] * p[2] + V[13];
+            const float pvz = V[2] * p[0] + V[6] * p[1] + V[10] * p[2] + V[14];
+            const float cosv = -((pvx * nx + pvy * ny) + pvz * nz);
+            const float mult = cosv > 0 ? 1.0f : -1.0f;
+            dtx = mult * dtx; dty = mult * dty; dtz = mult * dtz;
+            const float dRS[3][3] = {{dM[0][0], dM[0][1], dM[0][2]}, {dM[1][0], dM[1][1], dM[1][2]}, {dtx, dty, dtz}};
+            float vR[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) { vR[0][r] = dRS[0][r] * sx0; vR[1][r] = dRS[1][r] * sy0; vR[2][r] = dRS[2][r]; }
+            {   // quat_to_rotmat_vjp, auxiliary.h:245-289
+                const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+                const float s = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+                const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+                drot[0] = 2.f * (x * (vR[1][2] - vR[2][1]) + y * (vR[2][0] - vR[0][2]) + z * (vR[0][1] - vR[1][0]));
+                drot[1] = 2.f * (-2.f * x * (vR[1][1] + vR[2][2]) + y * (vR[0][1] + vR[1][0]) + z * (vR[0][2] + vR[2][0]) +
+                                 w * (vR[1][2] - vR[2][1]));
+                drot[2] = 2.f * (x * (vR[0][1] + vR[1][0]) - 2.f * y * (vR[0][0] + vR[2][2]) + z * (vR[1][2] + vR[2][1]) +
+                                 w * (vR[2][0] - vR[0][2]));
+                drot[3] = 2.f * (x * (vR[0][2] + vR[2][0]) + y * (vR[1][2] + vR[2][1]) - 2.f * z * (vR[0][0] + vR[1][1]) +
+                                 w * (vR[0][1] - vR[1][0]));
+            }
+            dsc[0] = (dRS[0][0] * R[0][0] + dRS[0][1] * R[0][1]) + dRS[0][2] * R[0][2];
+            dsc[1] = (dRS[1][0] * R[1][0] + dRS[1][1] * R[1][1]) + dRS[1][2] * R[1][2];
+            dm3[0] = dM[2][0]; dm3[1] = dM[2][1]; dm3[2] = dM[2][2];
+        }
+        // densification proxy, backward.cu:665-668 (uses the raw accumulated dL_dtransMat unless precomp updated it)
+        const float depth = precomp ? transMat_precomp[9 * (size_t)idx + 8] : rec[(size_t)idx * MRGS_REC_F4 + 2].x;
+        dm2[0] = dT_out[2] * depth * 0.5f * (float)W;
+        dm2[1] = dT_out[5] * depth * 0.5f * (float)H;
+    }
+
+    // SH backward (backward.cu:22-141), also zero-fills dL_dsh for culled gaussians / unused degrees
+    if (M > 0) {
+        float* dsh = dL_dsh + (size_t)idx * M * 3;
+        if (live && shs != nullptr) {
+            const float* sh = shs + (size_t)idx * M * 3;
+            const f3 dir_orig = {means3D[3 * (size_t)idx] - campos[0], means3D[3 * (size_t)idx + 1] - campos[1],
+                                 means3D[3 * (size_t)idx + 2] - campos[2]};
+            const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+            const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+            const uint32_t cl = clamped[idx];
+            float dRGB[3], ddx[3], ddy[3], ddz[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f);
+            const int ncoef = (D + 1) * (D + 1);
+            for (int i = ncoef; i < M; i++) { dsh[i * 3] = 0.0f; dsh[i * 3 + 1] = 0.0f; dsh[i * 3 + 2] = 0.0f; }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+#define SH(i) sh[(i) * 3 + c]
+#define DSH(i) dsh[(i) * 3 + c]
+                float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
+                DSH(0) = kSH_C0 * dRGB[c];
+                if (D > 0) {
+                    DSH(1) = (-kSH_C1 * y) * dRGB[c];
+                    DSH(2) = (kSH_C1 * z) * dRGB[c];
+                    DSH(3) = (-kSH_C1 * x) * dRGB[c];
+                    dRGBdx = -kSH_C1 * SH(3);
+                    dRGBdy = -kSH_C1 * SH(1);
+                    dRGBdz = kSH_C1 * SH(2);
+                    if (D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        DSH(4) = (kSH_C2[0] * xy) * dRGB[c];
+                        DSH(5) = (kSH_C2[1] * yz) * dRGB[c];
+                        DSH(6) = (kSH_C2[2] * (2.f * zz - xx - yy)) * dRGB[c];
+                        DSH(7) = (kSH_C2[3] * xz) * dRGB[c];
+                        DSH(8) = (kSH_C2[4] * (xx - yy)) * dRGB[c];
+                        dRGBdx += kSH_C2[0] * y * SH(4) + kSH_C2[2] * 2.f * -x * SH(6) + kSH_C2[3] * z * SH(7) + kSH_C2[4] * 2.f * x * SH(8);
+                        dRGBdy += kSH_C2[0] * x * SH(4) + kSH_C2[1] * z * SH(5) + kSH_C2[2] * 2.f * -y * SH(6) + kSH_C2[4] * 2.f * -y * SH(8);
+                        dRGBdz += kSH_C2[1] * y * SH(5) + kSH_C2[2] * 2.f * 2.f * z * SH(6) + kSH_C2[3] * x * SH(7);
+                        if (D > 2) {
+                            DSH(9) = (kSH_C3[0] * y * (3.f * xx - yy)) * dRGB[c];
+                            DSH(10) = (kSH_C3[1] * xy * z) * dRGB[c];
+                            DSH(11) = (kSH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB[c];
+                            DSH(12) = (kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB[c];
+                            DSH(13) = (kSH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB[c];
+                            DSH(14) = (kSH_C3[5] * z * (xx - yy)) * dRGB[c];
+                            DSH(15) = (kSH_C3[6] * x * (xx - 3.f * yy)) * dRGB[c];
+                            dRGBdx += (kSH_C3[0] * SH(9) * 3.f * 2.f * xy + kSH_C3[1] * SH(10) * yz + kSH_C3[2] * SH(11) * -2.f * xy +
+                                       kSH_C3[3] * SH(12) * -3.f * 2.f * xz + kSH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                       kSH_C3[5] * SH(14) * 2.f * xz + kSH_C3[6] * SH(15) * 3.f * (xx - yy));
+                            dRGBdy += (kSH_C3[0] * SH(9) * 3.f * (xx - yy) + kSH_C3[1] * SH(10) * xz +
+                                       kSH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + kSH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                                       kSH_C3[4] * SH(13) * -2.f * xy + kSH_C3[5] * SH(14) * -2.f * yz +
+                                       kSH_C3[6] * SH(15) * -3.f * 2.f * xy);
+                            dRGBdz += (kSH_C3[1] * SH(10) * xy + kSH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                                       kSH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + kSH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                                       kSH_C3[5] * SH(14) * (xx - yy));
+                        }
+                    }
+                }
+#undef SH
+#undef DSH
+                ddx[c] = dRGBdx; ddy[c] = dRGBdy; ddz[c] = dRGBdz;
+            }
+            const f3 dd = {(ddx[0] * dRGB[0] + ddx[1] * dRGB[1]) + ddx[2] * dRGB[2],
+                           (ddy[0] * dRGB[0] + ddy[1] * dRGB[1]) + ddy[2] * dRGB[2],
+                           (ddz[0] * dRGB[0] + ddz[1] * dRGB[1]) + ddz[2] * dRGB[2]};
+            const f3 dm = dnormvdv(dir_orig, dd);
+            dm3[0] += dm.x; dm3[1] += dm.y; dm3[2] += dm.z;
+        } else {
+            for (int i = 0; i < M * 3; i++) dsh[i] = 0.0f;
+        }
+    }
+
+    dL_dmeans2D[3 * (size_t)idx] = dm2[0]; dL_dmeans2D[3 * (size_t)idx + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)idx + 2] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        dL_dcolors[3 * (size_t)idx + c] = dcol[c];
+        dL_dmeans3D[3 * (size_t)idx + c] = dm3[c];
+    }
+    for (int c = 0; c < S; c++) dL_dfeatures[(size_t)idx * S + c] = live ? gr[18 + c] : 0.0f;
+    dL_dopacity[idx] = dop;
+#pragma unroll
+    for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dT_out[i];
+    dL_dscales[2 * (size_t)idx] = dsc[0]; dL_dscales[2 * (size_t)idx + 1] = dsc[1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) dL_drotations[4 * (size_t)idx + i] = drot[i];
+}
+
+void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g,
+                                const int32_t* radii, const float* grad_rec, const MrgsRasterGrads& out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.S, cfg.W,
+                       cfg.H, cfg.tanfovx, cfg.tanfovy, in.means3D, in.scales, in.rotations, in.shs, in.transMat_precomp,
+                       in.viewmatrix, in.projmatrix, in.campos, radii, g.clamped, g.rec, grad_rec, MRGS_GRAD_STRIDE(cfg.S),
+                       out.dL_dmeans2D, out.dL_dcolors, out.dL_dfeatures, out.dL_dopacity, out.dL_dmeans3D, out.dL_dtransMat,
+                       out.dL_dsh, out.dL_dscales, out.dL_drotations);
+}
+
+// checkFrustum, rasterizer_impl.cu:56-68
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ viewmatrix,
+                                                           uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float z = viewmatrix[2] * means3D[3 * (size_t)idx] + viewmatrix[6] * means3D[3 * (size_t)idx + 1] +
+                    viewmatrix[10] * means3D[3 * (size_t)idx + 2] + viewmatrix[14];
+    present[idx] = !(z <= 0.2f);
+}
+
+void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+}

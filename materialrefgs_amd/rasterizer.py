@@ -1,0 +1,242 @@
+"""Drop-in replacement of the reference's `diff_surfel_rasterization` Python module on MI355X.
+
+Same public surface as /root/reference/submodules/diff-surfel-rasterization/diff_surfel_rasterization/__init__.py:
+`GaussianRasterizationSettings` (:167-179), `GaussianRasterizer` (:181-235, incl. `markVisible` :186-195),
+`rasterize_gaussians` (:20-45) and the autograd function `_RasterizeGaussians` (:47-165) -- same argument
+names and order, same return tuple `(contrib i32[1,H,W], color f32[3,H,W], feature f32[S,H,W], radii i32[P],
+allmap f32[7,H,W])`, same gradient routing.  The native side is libmrgs.so (include/mrgs.h) instead of the
+pybind `_C` module; there is no CPU or PyTorch fallback.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp):
+    P = means3D.shape[0]
+    S = features.shape[1] if features.dim() == 2 else 0
+    M = sh.shape[1] if sh.numel() != 0 else 0
+    cfg = MrgsRasterConfig(P, S, int(raster_settings.sh_degree), M, int(raster_settings.image_height),
+                           int(raster_settings.image_width), float(raster_settings.tanfovx), float(raster_settings.tanfovy),
+                           float(raster_settings.scale_modifier), int(bool(raster_settings.prefiltered)),
+                           int(bool(raster_settings.debug)))
+    inp = MrgsRasterInputs(_ptr(raster_settings.bg), _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(features),
+                           _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
+                           _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos))
+    return cfg, inp
+
+
+def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp):
+    """Counterpart of `_C.rasterize_gaussians` (rasterize_points.cu:41-144)."""
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA tensor")   # CHECK_INPUT, rasterize_points.cu:29-31
+    L = _lib.lib()
+    dev = means3D.device
+    H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp)
+    P, S = cfg.P, cfg.S
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        contrib = torch.zeros((1, H, W), dtype=torch.int32, device=dev)   # allocated, never written
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        feature = torch.empty((S, H, W), dtype=torch.float32, device=dev)
+        others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((L.mrgs_geom_bytes(P, H, W),), dtype=torch.uint8, device=dev)
+        img = torch.empty((L.mrgs_img_bytes(H, W),), dtype=torch.uint8, device=dev)
+        R = ctypes.c_int64(0)
+        _lib.check(L.mrgs_rasterize_forward_geom(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(radii),
+                                                 ctypes.byref(R), st))
+        num_rendered = int(R.value)
+        binning = torch.empty((L.mrgs_binning_bytes(num_rendered),), dtype=torch.uint8, device=dev)
+        _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
+                                                   _ptr(img), num_rendered, _ptr(color), _ptr(feature), _ptr(others), st))
+    return num_rendered, contrib, color, feature, others, radii, geom, binning, img
+
+
+def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp,
+                               grad_out_color, grad_out_feature, grad_out_others, sh, opacities, geom, num_rendered, binning, img):
+    """Counterpart of `_C.rasterize_gaussians_backward` (rasterize_points.cu:146-252)."""
+    L = _lib.lib()
+    dev = means3D.device
+    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp)
+    P, S, M = cfg.P, cfg.S, cfg.M
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        opts = dict(dtype=torch.float32, device=dev)
+        g = {"dL_dmeans2D": torch.empty((P, 3), **opts), "dL_dcolors": torch.empty((P, 3), **opts),
+             "dL_dfeatures": torch.empty((P, S), **opts), "dL_dopacity": torch.empty((P, 1), **opts),
+             "dL_dmeans3D": torch.empty((P, 3), **opts), "dL_dtransMat": torch.empty((P, 9), **opts),
+             "dL_dsh": torch.empty((P, M, 3), **opts), "dL_dscales": torch.empty((P, 2), **opts),
+             "dL_drotations": torch.empty((P, 4), **opts)}
+        grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_])
+        grad_ws = torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
+        _lib.check(L.mrgs_rasterize_backward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                             num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),
+                                             _ptr(grad_ws), ctypes.byref(grads), st))
+    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dfeatures"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dtransMat"],
+            g["dL_dsh"], g["dL_dscales"], g["dL_drotations"])
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        means3D, sh, colors_precomp, features = _f32c(means3D), _f32c(sh), _f32c(colors_precomp), _f32c(features)
+        opacities, scales, rotations, cov3Ds_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
+        rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_f32c(raster_settings.viewmatrix),
+                                      projmatrix=_f32c(raster_settings.projmatrix), campos=_f32c(raster_settings.campos))
+        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted
+            try:
+                out = _rasterize_forward_native(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            out = _rasterize_forward_native(*args)
+        num_rendered, contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer = out
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
+                              geomBuffer, binningBuffer, imgBuffer, contrib)
+        ctx.mark_non_differentiable(contrib, radii)
+        return contrib, color, feature, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_contrib, grad_out_color, grad_out_feature, grad_radii, grad_depth):
+        num_rendered = ctx.num_rendered
+        rs = ctx.raster_settings
+        (colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
+         imgBuffer, contrib) = ctx.saved_tensors
+        H, W = int(rs.image_height), int(rs.image_width)
+        S = features.shape[1] if features.dim() == 2 else 0
+        dev = means3D.device
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        if grad_out_feature is None:
+            grad_out_feature = torch.zeros((S, H, W), dtype=torch.float32, device=dev)
+        if grad_depth is None:
+            grad_depth = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
+        args = (rs, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp, _f32c(grad_out_color),
+                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args[1:])
+            try:
+                out = _rasterize_backward_native(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            out = _rasterize_backward_native(*args)
+        (grad_means2D, grad_colors_precomp, grad_features, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = out
+        # empty inputs (the `torch.Tensor([])` placeholders) get empty gradients of matching shape
+        if sh.numel() == 0:
+            grad_sh = None
+        if colors_precomp.numel() == 0:
+            grad_colors_precomp = None
+        if scales.numel() == 0:
+            grad_scales = None
+            grad_rotations = None
+        if cov3Ds_precomp.numel() == 0:
+            grad_cov3Ds_precomp = None
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_features, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points that pass the frustum test (`_C.mark_visible`, rasterize_points.cu:254-273)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            positions = _f32c(positions)
+            P = positions.shape[0]
+            present = torch.zeros((P,), dtype=torch.uint8, device=positions.device)
+            with torch.cuda.device(positions.device):
+                _lib.check(_lib.lib().mrgs_mark_visible(P, _ptr(positions), _ptr(_f32c(rs.viewmatrix)), _ptr(_f32c(rs.projmatrix)),
+                                                        _ptr(present), _stream(positions.device)))
+            visible = present.bool()
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, features=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        empty = torch.empty((0,), dtype=torch.float32, device=means3D.device)
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if features is None:
+            features = torch.empty_like(means3D[..., :0])
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
+                                   raster_settings)

@@ -1,0 +1,86 @@
+"""Synthetic "shell" scene of SURVEY.md section 8d / BASELINE.md section 3 (no datasets on the GPU box).
+
+P surfels with centres on a radius-1 sphere shell, disk normal = radial direction with a random in-plane
+spin, log-normal scales sized so that the mean projected 3-sigma radius is `radius_px` pixels at
+`image_size`^2 (=> about 6 tiles per surfel at 7 px / 800^2), opacity = sigmoid(N(1.5, 1)), degree-3 SH
+colours, S sigmoid feature channels.  Tensors are laid out exactly as scene/gaussian_model.py getters hand
+them to the rasterizer (xyz[P,3], scaling[P,2], rotation[P,4] wxyz, opacity[P,1], features[P,16,3]).
+"""
+import math
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from .camera import fov2focal, look_at_camera
+
+C0 = 0.28209479177387814
+FOV = 0.6911
+CAM_DISTANCE = 4.03
+
+
+class Scene(NamedTuple):
+    means3D: torch.Tensor      # [P,3]
+    scales: torch.Tensor       # [P,2]  (activated, i.e. exp(_scaling))
+    rotations: torch.Tensor    # [P,4]  (normalised, w x y z)
+    opacities: torch.Tensor    # [P,1]  (activated)
+    shs: torch.Tensor          # [P,16,3]
+    features: torch.Tensor     # [P,S]
+
+    def to(self, device):
+        return Scene(*[t.to(device) for t in self])
+
+
+def _quat_from_z_to(n, spin, rng):
+    """Unit quaternion (w,x,y,z) rotating +z onto n, composed with a spin about z."""
+    P = n.shape[0]
+    z = np.array([0.0, 0.0, 1.0])
+    axis = np.cross(np.broadcast_to(z, n.shape), n)
+    s = np.linalg.norm(axis, axis=1, keepdims=True)
+    c = n[:, 2:3]
+    axis = np.where(s > 1e-8, axis / np.maximum(s, 1e-8), np.array([[1.0, 0.0, 0.0]]))
+    ang = np.arctan2(s, c)
+    q1 = np.concatenate([np.cos(ang / 2), axis * np.sin(ang / 2)], axis=1)
+    q2 = np.concatenate([np.cos(spin / 2)[:, None], np.zeros((P, 2)), np.sin(spin / 2)[:, None]], axis=1)
+    w1, x1, y1, z1 = q1.T
+    w2, x2, y2, z2 = q2.T
+    q = np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                  w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], axis=1)
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def make_shell_scene(P: int, S: int = 0, seed: int = 0, radius_px: float = 7.0, image_size: int = 800,
+                     sh_degree_filled: int = 3, device: Optional[str] = None) -> Scene:
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(P, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = rng.uniform(0.95, 1.05, size=(P, 1))
+    xyz = d * r
+    q = _quat_from_z_to(d, rng.uniform(0, 2 * math.pi, size=P), rng)
+    focal = fov2focal(FOV, image_size)
+    s_bar = radius_px * CAM_DISTANCE / (3.0 * focal)
+    scales = np.exp(rng.normal(math.log(s_bar), 0.35, size=(P, 2)))
+    opac = 1.0 / (1.0 + np.exp(-rng.normal(1.5, 1.0, size=(P, 1))))
+    shs = np.zeros((P, 16, 3))
+    shs[:, 0, :] = (rng.uniform(0, 1, size=(P, 3)) - 0.5) / C0
+    ncoef = (sh_degree_filled + 1) ** 2
+    shs[:, 1:ncoef, :] = rng.normal(0, 0.05, size=(P, ncoef - 1, 3))
+    feats = 1.0 / (1.0 + np.exp(-rng.normal(0, 1, size=(P, S))))
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    sc = Scene(f32(xyz), f32(scales), f32(q), f32(opac), f32(shs), f32(feats))
+    return sc.to(device) if device is not None else sc
+
+
+def orbit_camera(view: int, height: int, width: int, n_views: int = 8, elevation: float = 30.0):
+    """View `view` of the 8-azimuth orbit."""
+    return look_at_camera(360.0 * (view % n_views) / n_views + 17.0, elevation, CAM_DISTANCE, FOV, height, width)
+
+
+def upstream_grads(S: int, H: int, W: int, device=None):
+    """Fixed upstream gradients of the benchmark: dL/dcolor = 1, dL/dfeature = 0.5, dL/dothers = 0.1 with the
+    median-depth channel zeroed."""
+    g_color = torch.ones(3, H, W, device=device)
+    g_feat = torch.full((S, H, W), 0.5, device=device)
+    g_others = torch.full((7, H, W), 0.1, device=device)
+    g_others[5] = 0.0
+    return g_color, g_feat, g_others
