@@ -83,5 +83,5 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
                             float* grad_rec, hipStream_t stream);
 
 #ifndef MRGS_EXP
-#define MRGS_EXP(x) __expf(x)
+#define MRGS_EXP(x) expf(x)
 #endif

@@ -341,7 +341,9 @@ static int intersect(const float *T, const float *xy, float opa, float px, float
     h->G = expf(power);
     float a = opa * h->G;
     h->alpha = a < 0.99f ? a : 0.99f;
+#ifndef MRGS_ORACLE_NO_ALPHA_CUTOFF   /* test-only build: see tests/test_oracle.py::test_smooth_part_is_exact_derivative */
     if (h->alpha < 1.0f / 255.0f) return 0;
+#endif
     return 1;
 }
 
@@ -832,6 +834,19 @@ int mrgs_oracle_backward(const mrgs_oracle_ctx *c, const float *dL_dpix, const f
     free(pool);
     preprocess_bwd(c, dL_dtransMat, dL_dnormal, dL_dmean2D, dL_dcolor, dL_dsh, dL_dmean3D, dL_dscale, dL_drot);
     return 0;
+}
+
+/* Test hook: BACKWARD::preprocess alone (backward.cu:614-669) on caller-supplied per-gaussian upstream gradients.
+ * dL_dtransMat [P,9] and dL_dmean2D [P,3] are updated in place exactly as the reference does; the outputs are
+ * zero-filled first.  Used by tests/oracle_derivative_probe.py to check the T -> (mean, scale, rotation) chain. */
+void mrgs_oracle_preprocess_backward_only(const mrgs_oracle_ctx *c, float *dL_dtransMat, const float *dL_dnormal,
+                                          float *dL_dmean2D, const float *dL_dcolors, float *dL_dsh, float *dL_dmean3D,
+                                          float *dL_dscale, float *dL_drot)
+{
+    const int P = c->P;
+    memset(dL_dsh, 0, sizeof(float) * 3 * (size_t)c->M * P); memset(dL_dmean3D, 0, sizeof(float) * 3 * (size_t)P);
+    memset(dL_dscale, 0, sizeof(float) * 2 * (size_t)P); memset(dL_drot, 0, sizeof(float) * 4 * (size_t)P);
+    preprocess_bwd(c, dL_dtransMat, dL_dnormal, dL_dmean2D, dL_dcolors, dL_dsh, dL_dmean3D, dL_dscale, dL_drot);
 }
 
 /* markVisible / checkFrustum, rasterizer_impl.cu:56-68,143-155 */

@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmrgs_oracle.so")
+if os.environ.get("MRGS_ORACLE_NOCUT") == "1":   # test-only smooth variant (oracle/Makefile)
+    _LIB_PATH = os.path.join(_HERE, "libmrgs_oracle_nocut.so")
 _lib = None
 
 FIELDS = {  # name -> (index in mrgs_oracle_field, dtype, shape builder)
@@ -54,6 +56,7 @@ def lib():
         L.mrgs_oracle_field.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mrgs_oracle_backward.restype = ctypes.c_int
         L.mrgs_oracle_backward.argtypes = [ctypes.c_void_p] + [fp] * 13
+        L.mrgs_oracle_preprocess_backward_only.argtypes = [ctypes.c_void_p] + [fp] * 8
         L.mrgs_oracle_mark_visible.argtypes = [ctypes.c_int, fp, fp, fp, fp]
         L.mrgs_oracle_num_threads.restype = ctypes.c_int
         _lib = L
@@ -152,6 +155,21 @@ class OracleRender:
         rc = lib().mrgs_oracle_backward(self._ctx, _ptr(g_c), _ptr(g_f), _ptr(g_o), *[_ptr(out[k]) for k in order])
         if rc != 0:
             raise RuntimeError("mrgs_oracle_backward failed")
+        return out
+
+    def preprocess_backward_only(self, dL_dtransMat, dL_dnormal, dL_dmean2D, dL_dcolors):
+        """Test hook: the per-gaussian backward alone, on caller-supplied upstream gradients."""
+        P, M = self.P, self.M
+        dT = _f32(dL_dtransMat, (P, 9)).copy()
+        dn = _f32(dL_dnormal, (P, 3))
+        dm2 = _f32(dL_dmean2D, (P, 3)).copy()
+        dc = _f32(dL_dcolors, (P, 3))
+        out = {"sh": np.zeros((P, M, 3), np.float32), "means3D": np.zeros((P, 3), np.float32),
+               "scales": np.zeros((P, 2), np.float32), "rotations": np.zeros((P, 4), np.float32)}
+        lib().mrgs_oracle_preprocess_backward_only(self._ctx, _ptr(dT), _ptr(dn), _ptr(dm2), _ptr(dc), _ptr(out["sh"]),
+                                                   _ptr(out["means3D"]), _ptr(out["scales"]), _ptr(out["rotations"]))
+        out["transMat"] = dT
+        out["means2D"] = dm2
         return out
 
     def close(self):

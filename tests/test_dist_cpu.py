@@ -1,0 +1,70 @@
+"""World-size-2 gloo test of the view-parallel gradient exchange (materialrefgs_amd/dist.py) on CPU."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from materialrefgs_amd import dist as mdist
+    env = mdist.init_from_env(backend="gloo")
+    assert env["world"] == world and env["rank"] == rank
+    P = 257
+    gen = torch.Generator().manual_seed(100 + rank)
+    shapes = [(P, 3), (P, 16, 3), (P, 1), (P, 2), (P, 4), (P, 3)]
+    grads = [torch.randn(*s, generator=gen) for s in shapes]
+    grads[3] = None   # a tensor that received no gradient on this rank
+    bucket = mdist.GradBucket([torch.Size(s) for s in shapes], "cpu")
+    red = mdist.allreduce_gradients(bucket, grads)
+    # densification statistics
+    norm = torch.rand(P, generator=gen)
+    vis = (torch.rand(P, generator=gen) > 0.5)
+    radii = torch.randint(0, 50, (P,), generator=gen, dtype=torch.int32)
+    s_norm, s_vis, m_radii = mdist.reduce_densification_stats(norm, vis, radii)
+    q.put((rank, [r.clone().numpy() for r in red], s_norm.numpy(), s_vis.numpy(), m_radii.numpy(),
+           [None if g is None else g.numpy() for g in grads], norm.numpy(), vis.numpy(), radii.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the sum over ranks equals the sum of the single-rank results, None counts as zero
+    for i in range(len(res[0][1])):
+        expect = sum((np.zeros_like(res[0][1][i]) if r[5][i] is None else r[5][i]) for r in res)
+        for r in res:
+            np.testing.assert_allclose(r[1][i], expect, rtol=1e-6, atol=1e-6)
+    for r in res:
+        np.testing.assert_allclose(r[2], res[0][6] + res[1][6], rtol=1e-6)
+        np.testing.assert_allclose(r[3], res[0][7].astype(np.float32) + res[1][7].astype(np.float32))
+        np.testing.assert_array_equal(r[4], np.maximum(res[0][8], res[1][8]))
+
+
+def test_bucket_roundtrip_single_process():
+    from materialrefgs_amd.dist import GradBucket, allreduce_gradients
+    shapes = [torch.Size((5, 3)), torch.Size((5, 1))]
+    b = GradBucket(shapes, "cpu")
+    g = [torch.arange(15.0).reshape(5, 3), None]
+    out = allreduce_gradients(b, g)
+    assert torch.equal(out[0], g[0]) and torch.count_nonzero(out[1]) == 0
