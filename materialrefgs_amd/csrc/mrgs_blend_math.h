@@ -1,0 +1,90 @@
+// mrgs_blend_math.h -- per-(pixel, surfel) arithmetic shared by the forward and the backward blend kernels.
+//
+// Both kernels must reproduce EXACTLY the same alpha for a pair (the backward rebuilds T by dividing the
+// forward's products back out), so the ray/splat intersection lives in one place.  The translation units that
+// include this header are compiled with -ffp-contract=off: every fused multiply-add below is written
+// explicitly, and oracle/mrgs_oracle.c mirrors the same fused expressions with fmaf(), which makes the
+// ill-conditioned part (cross product of the two pixel planes) bit-reproducible between CPU and GPU.
+// Two operations are NOT bit-reproducible and differ from the oracle by <= 1 ulp: the reciprocal
+// (v_rcp_f32 here, 1.0f/x there) and exp (v_exp_f32 with a compensated argument here, expf there).
+#pragma once
+#include "mrgs_internal.h"
+
+#define MRGS_ALPHA_MIN (1.0f / 255.0f)
+#define MRGS_T_MIN 0.0001f
+
+__device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// exp(x) for x <= 0 through v_exp_f32: 2^(x*log2e) with the rounding error of the product folded back in
+__device__ __forceinline__ float mrgs_exp(float x)
+{
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.693147182464599609375f;
+    const float t = x * L2E_HI;
+    float e = fmaf(x, L2E_HI, -t);
+    e = fmaf(x, L2E_LO, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return fmaf(r, e * LN2, r);
+}
+
+// geometry part of the packed record (first three float4 of MRGS_REC): Tu = g0.xyz, Tv = (g0.w, g1.x, g1.y),
+// Tw = (g1.z, g1.w, g2.x), mean2D = g2.yz, opacity = g2.w
+struct SurfelGeom { float4 g0, g1, g2; };
+
+struct Hit {
+    float kx, ky, kz, lx, ly, lz;   // the two pixel planes in splat space (forward.cu:371-372)
+    float inv_pz, sx, sy;           // intersection in splat coordinates, s = p.xy / p.z
+    float rho3d, rho2d, dx, dy;
+    float depth, G, alpha;
+};
+
+// forward.cu:366-398 / backward.cu:296-328.  Returns false when the pair is skipped.
+__device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, float py, Hit& h)
+{
+    const float Twx = s.g1.z, Twy = s.g1.w, Twz = s.g2.x;
+    h.kx = fmaf(px, Twx, -s.g0.x); h.ky = fmaf(px, Twy, -s.g0.y); h.kz = fmaf(px, Twz, -s.g0.z);
+    h.lx = fmaf(py, Twx, -s.g0.w); h.ly = fmaf(py, Twy, -s.g1.x); h.lz = fmaf(py, Twz, -s.g1.y);
+    const float ppx = fmaf(h.ky, h.lz, -(h.kz * h.ly));
+    const float ppy = fmaf(h.kz, h.lx, -(h.kx * h.lz));
+    const float ppz = fmaf(h.kx, h.ly, -(h.ky * h.lx));
+    if (ppz == 0.0f) return false;
+    h.inv_pz = mrgs_rcp(ppz);
+    h.sx = ppx * h.inv_pz;
+    h.sy = ppy * h.inv_pz;
+    h.rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);
+    h.dx = s.g2.y - px;
+    h.dy = s.g2.z - py;
+    h.rho2d = MRGS_FILTER_INV_SQUARE * fmaf(h.dx, h.dx, h.dy * h.dy);
+    const float rho = fminf(h.rho3d, h.rho2d);
+    h.depth = (h.rho3d <= h.rho2d) ? fmaf(h.sx, Twx, fmaf(h.sy, Twy, Twz)) : Twz;
+    if (h.depth < MRGS_NEAR_N) return false;
+    const float power = -0.5f * rho;
+    if (power > 0.0f) return false;
+    h.G = mrgs_exp(power);
+    h.alpha = fminf(0.99f, s.g2.w * h.G);
+    return h.alpha >= MRGS_ALPHA_MIN;
+}
+
+// 8x8 pixel block owned by a wave: lane -> pixel
+__device__ __forceinline__ void mrgs_block_pixel(int block_x, int block_y, int lane, int& pxi, int& pyi)
+{
+    pxi = block_x * 8 + (lane & 7);
+    pyi = block_y * 8 + (lane >> 3);
+}
+
+// Conservative screen-space bound of the region where a surfel can reach alpha >= 1/255 (record float4 #5 =
+// centre.xy, half-extent.xy, written by preprocess): the axis-aligned box that contains both the level set
+// rho3d <= tau and the low-pass disc rho2d <= tau, tau = 2 ln(255 opacity), padded for rounding.  A surfel is
+// skipped for a whole 8x8 block only when the block misses that box, i.e. when every lane would have failed the
+// alpha test anyway -- exact per-pixel results are unaffected.
+__device__ __forceinline__ bool mrgs_block_may_touch(const float4 bound, float bcx, float bcy)
+{
+    return (fabsf(bound.x - bcx) <= bound.z + 3.5f) && (fabsf(bound.y - bcy) <= bound.w + 3.5f);
+}
+
+// wave64 sum with DPP; every lane of the wave must be active.  Result valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float mrgs_dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}

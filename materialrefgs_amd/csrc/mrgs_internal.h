@@ -11,21 +11,25 @@
 #define MRGS_FILTER_INV_SQUARE 2.0f  // auxiliary.h:41
 
 // Packed per-gaussian render record written by preprocess and gathered by the blend kernels:
-// 5 x float4 = 80 B, 16-byte aligned so that a record is fetched with five dwordx4 loads.
-//   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   [3] normal.xyz, rgb.r   [4] rgb.gb, 0, 0
+// 6 x float4 = 96 B, 16-byte aligned so that a record is fetched with dwordx4 loads.
+//   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   (geometry: read for every list entry)
+//   [3] normal.xyz, rgb.r   [4] rgb.gb, depth, 0                          (appearance: read only when blended)
+//   [5] cull box: centre.xy, half-extent.xy (mrgs_blend_math.h)           (read for every list entry)
 // (the reference keeps these in five separate arrays: transMat, means2D, normal_opacity, rgb; forward.cu:350-357,427)
-#define MRGS_REC_F4 5
+#define MRGS_REC_F4 6
 
 // Packed per-gaussian gradient accumulator of the blend backward (one row per gaussian so that the
 // atomics of one (tile, gaussian) pair land in one or two cache lines):
 //   [0..8] dL/dT (Tu,Tv,Tw)  [9..10] dL/dmean2D.xy  [11] dL/dopacity  [12..14] dL/dnormal  [15..17] dL/dcolor
-//   [18..18+S) dL/dfeature ; row stride = MRGS_GRAD_STRIDE(S) floats
-#define MRGS_GRAD_STRIDE(S) ((18 + (S) + 3) & ~3)
+//   [18..18+S) dL/dfeature ; row stride = MRGS_GRAD_STRIDE(S) floats = the padded value count of the blend-backward
+//   kernel instance that serves S channels (instances exist for up to 0 / 8 / 12 / 24 channels)
+#define MRGS_SMAX(S) ((S) == 0 ? 0 : (S) <= 8 ? 8 : (S) <= 12 ? 12 : 24)
+#define MRGS_GRAD_STRIDE(S) ((18 + MRGS_SMAX(S) + 3) & ~3)
 
 static inline size_t mrgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
-    float4* rec;            // [P][5]
+    float4* rec;            // [P][MRGS_REC_F4]
     uint32_t* depth_key[2]; // [P] ping-pong radix keys (depth bits, 0xFFFFFFFF when culled)
     uint32_t* order[2];     // [P] ping-pong payload: gaussian index
     uint2* rect;            // [P] tile rect packed: x = min.x | min.y<<16, y = max.x | max.y<<16

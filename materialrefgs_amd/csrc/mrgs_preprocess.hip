@@ -185,12 +185,41 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             rgb[2] = colors_precomp[3 * (size_t)idx + 2];
         }
         const float opa = opacities[idx];
+        // Conservative cull box for the blend kernels (mrgs_blend_math.h): a pixel can reach alpha >= 1/255 only where
+        // min(rho3d, rho2d) <= tau = 2 ln(255 opacity).  {rho3d <= tau} is the image of a disc of the splat plane; its
+        // bounding box follows from the same dual-conic formula as compute_aabb, valid while the disc stays in front of
+        // the camera plane (tau (Twx^2 + Twy^2) < Twz^2).  {rho2d <= tau} is a disc of radius sqrt(tau/2) around mean2D.
+        float4 cull = make_float4(0.0f, 0.0f, -1e30f, -1e30f);   // never a candidate: opacity < 1/255 can never pass
+        const float oa = 255.0f * opa;
+        if (!(oa < 0.999f)) {
+            const float lg = logf(oa);
+            const float tau = 2.0f * (lg > 0.0f ? lg : 0.0f) * 1.0001f + 1e-3f;
+            const float dist = tau * (T3[0] * T3[0] + T3[1] * T3[1]) - T3[2] * T3[2];
+            float bx0 = 0.0f, by0 = 0.0f, bex = 1e30f, bey = 1e30f;
+            if (dist < -1e-6f * (T3[2] * T3[2])) {
+                const float fi = 1.0f / dist;
+                const float ccx = fi * (tau * (T0[0] * T3[0] + T0[1] * T3[1]) - T0[2] * T3[2]);
+                const float ccy = fi * (tau * (T1[0] * T3[0] + T1[1] * T3[1]) - T1[2] * T3[2]);
+                const float hx = ccx * ccx - fi * (tau * (T0[0] * T0[0] + T0[1] * T0[1]) - T0[2] * T0[2]);
+                const float hy = ccy * ccy - fi * (tau * (T1[0] * T1[0] + T1[1] * T1[1]) - T1[2] * T1[2]);
+                const float exx = sqrtf(hx > 0.0f ? hx : 0.0f), eyy = sqrtf(hy > 0.0f ? hy : 0.0f);
+                const float rr = sqrtf(0.5f * tau);
+                const float lox = fminf(ccx - exx, cx - rr) - 0.05f, hix = fmaxf(ccx + exx, cx + rr) + 0.05f;
+                const float loy = fminf(ccy - eyy, cy - rr) - 0.05f, hiy = fmaxf(ccy + eyy, cy + rr) + 0.05f;
+                bx0 = 0.5f * (lox + hix); by0 = 0.5f * (loy + hiy);
+                bex = 0.5f * (hix - lox) * 1.0001f + 0.01f; bey = 0.5f * (hiy - loy) * 1.0001f + 0.01f;
+                const float chk = bx0 + by0 + bex + bey;
+                if (!(chk - chk == 0.0f)) { bx0 = 0.0f; by0 = 0.0f; bex = 1e30f; bey = 1e30f; }   // inf / NaN: never cull
+            }
+            cull = make_float4(bx0, by0, bex, bey);
+        }
         float4* r4 = rec + (size_t)idx * MRGS_REC_F4;
         r4[0] = make_float4(T[0], T[1], T[2], T[3]);
         r4[1] = make_float4(T[4], T[5], T[6], T[7]);
         r4[2] = make_float4(T[8], cx, cy, opa);
         r4[3] = make_float4(nx, ny, nz, rgb[0]);
         r4[4] = make_float4(rgb[1], rgb[2], pvz, 0.0f);
+        r4[5] = cull;
         out_radius = iradius;
         out_tiles = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
         out_key = __float_as_uint(pvz);

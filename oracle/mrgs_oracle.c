@@ -13,9 +13,15 @@
  * the backward that ARE exact derivatives (opacity / colour / feature, tests/test_oracle.py) and on structural
  * invariants -- not on outputs of the reference itself.
  *
- * Arithmetic: IEEE fp32, evaluated in the operation order written in the reference, compiled with
- * -ffp-contract=off (the HIP preprocess kernel is compiled the same way so that the geometry state and the
- * integer binning state are bit-identical; the blend kernels contract FMAs and are compared with a tolerance).
+ * Arithmetic: IEEE fp32, compiled with -ffp-contract=off so that nothing fuses implicitly.
+ *   - per-gaussian code (preprocess, its backward): evaluated un-fused in the operation order written in the
+ *     reference; the HIP preprocess kernel is compiled the same way, so the geometry state and the whole integer
+ *     binning state are bit-identical.
+ *   - per-(pixel, surfel) blend code: the reference's expressions with the multiply-adds FUSED EXPLICITLY (fmaf)
+ *     exactly where materialrefgs_amd/csrc/mrgs_blend_math.h fuses them.  nvcc fuses the reference's own build too
+ *     (-fmad=true is its default), in a pattern that cannot be known here; choosing one fixed pattern on both sides
+ *     makes the ill-conditioned ray/splat cross product bit-reproducible.  The GPU's reciprocal (v_rcp_f32) and exp
+ *     (v_exp_f32) are 1-ulp approximations; here they are 1.0f/x and expf(x).
  * Deviations, all documented in DESIGN.md:
  *   - rsqrtf(x) is evaluated as 1.0f/sqrtf(x) (CUDA's rsqrtf is a 2-ulp approximation that cannot be restated);
  *   - per-gaussian gradient sums (the reference's fp32 atomicAdd, whose order is nondeterministic) are
@@ -320,29 +326,29 @@ static int binning(mrgs_oracle_ctx *c)
 
 /* ray-splat intersection shared by forward.cu:366-404 and backward.cu:296-328.
  * returns 0 when the pair is skipped before the alpha test */
-typedef struct { float sx, sy, pz, rho3d, rho2d, depth, dx, dy, G, alpha; f3 k, l; } hit_t;
+typedef struct { float sx, sy, inv_pz, rho3d, rho2d, depth, dx, dy, G, alpha; f3 k, l; } hit_t;
 static int intersect(const float *T, const float *xy, float opa, float px, float py, hit_t *h)
 {
     const float *Tu = T, *Tv = T + 3, *Tw = T + 6;
-    f3 k = {px * Tw[0] - Tu[0], px * Tw[1] - Tu[1], px * Tw[2] - Tu[2]};
-    f3 l = {py * Tw[0] - Tv[0], py * Tw[1] - Tv[1], py * Tw[2] - Tv[2]};
-    f3 p = {k.y * l.z - k.z * l.y, k.z * l.x - k.x * l.z, k.x * l.y - k.y * l.x};
+    f3 k = {fmaf(px, Tw[0], -Tu[0]), fmaf(px, Tw[1], -Tu[1]), fmaf(px, Tw[2], -Tu[2])};
+    f3 l = {fmaf(py, Tw[0], -Tv[0]), fmaf(py, Tw[1], -Tv[1]), fmaf(py, Tw[2], -Tv[2])};
+    f3 p = {fmaf(k.y, l.z, -(k.z * l.y)), fmaf(k.z, l.x, -(k.x * l.z)), fmaf(k.x, l.y, -(k.y * l.x))};   /* cross(k, l) */
     if (p.z == 0.0f) return 0;
-    h->k = k; h->l = l; h->pz = p.z;
-    h->sx = p.x / p.z; h->sy = p.y / p.z;
-    h->rho3d = h->sx * h->sx + h->sy * h->sy;
+    h->k = k; h->l = l;
+    h->inv_pz = 1.0f / p.z;
+    h->sx = p.x * h->inv_pz; h->sy = p.y * h->inv_pz;
+    h->rho3d = fmaf(h->sx, h->sx, h->sy * h->sy);
     h->dx = xy[0] - px; h->dy = xy[1] - py;
-    h->rho2d = FILTER_INV_SQUARE * (h->dx * h->dx + h->dy * h->dy);
+    h->rho2d = FILTER_INV_SQUARE * fmaf(h->dx, h->dx, h->dy * h->dy);
     float rho = fminf(h->rho3d, h->rho2d);   /* CUDA min(float,float) == fminf */
-    h->depth = (h->rho3d <= h->rho2d) ? (h->sx * Tw[0] + h->sy * Tw[1]) + Tw[2] : Tw[2];
+    h->depth = (h->rho3d <= h->rho2d) ? fmaf(h->sx, Tw[0], fmaf(h->sy, Tw[1], Tw[2])) : Tw[2];
     if (h->depth < NEAR_N) return 0;
     float power = -0.5f * rho;
     if (power > 0.0f) return 0;
     h->G = expf(power);
-    float a = opa * h->G;
-    h->alpha = a < 0.99f ? a : 0.99f;
+    h->alpha = fminf(0.99f, opa * h->G);
 #ifndef MRGS_ORACLE_NO_ALPHA_CUTOFF   /* test-only build: see tests/test_oracle.py::test_smooth_part_is_exact_derivative */
-    if (h->alpha < 1.0f / 255.0f) return 0;
+    if (!(h->alpha >= 1.0f / 255.0f)) return 0;
 #endif
     return 1;
 }
@@ -373,19 +379,20 @@ static void render_fwd(mrgs_oracle_ctx *c)
                     const float *no = c->normal_opacity + 4 * (size_t)g;
                     hit_t h;
                     if (!intersect(Ts + 9 * (size_t)g, c->means2D + 2 * (size_t)g, no[3], px, py, &h)) continue;
-                    float test_T = T * (1 - h.alpha);
+                    float test_T = T * (1.0f - h.alpha);
                     if (test_T < 0.0001f) break;   /* done = true */
                     float w = h.alpha * T;
-                    float A = 1 - T;
-                    float m = mscale * (1 - NEAR_N / h.depth);
-                    distortion += ((m * m) * A + M2 - (2 * m) * M1) * w;
-                    Dp += h.depth * w;
-                    M1 += m * w;
-                    M2 += (m * m) * w;
+                    float A = 1.0f - T;
+                    float m = mscale * (1.0f - NEAR_N * (1.0f / h.depth));
+                    float mm = m * m;
+                    distortion = fmaf(fmaf(-2.0f * m, M1, fmaf(mm, A, M2)), w, distortion);   /* (m*m*A + M2 - 2*m*M1) * w */
+                    Dp = fmaf(h.depth, w, Dp);
+                    M1 = fmaf(m, w, M1);
+                    M2 = fmaf(mm, w, M2);
                     if (T > 0.5f) { median_depth = h.depth; median_contributor = contributor; }
-                    for (int ch = 0; ch < 3; ch++) N[ch] += no[ch] * w;
-                    for (int ch = 0; ch < 3; ch++) C[ch] += colors[3 * (size_t)g + ch] * w;
-                    for (int ch = 0; ch < S; ch++) F[ch] += c->features[(size_t)g * S + ch] * w;
+                    for (int ch = 0; ch < 3; ch++) N[ch] = fmaf(no[ch], w, N[ch]);
+                    for (int ch = 0; ch < 3; ch++) C[ch] = fmaf(colors[3 * (size_t)g + ch], w, C[ch]);
+                    for (int ch = 0; ch < S; ch++) F[ch] = fmaf(c->features[(size_t)g * S + ch], w, F[ch]);
                     T = test_T;
                     last_contributor = contributor;
                 }
@@ -394,10 +401,10 @@ static void render_fwd(mrgs_oracle_ctx *c)
                 c->final_T[pix + 2 * HW] = M2;
                 c->n_contrib[pix] = last_contributor;
                 c->n_contrib[pix + HW] = median_contributor;   /* float -1 -> uint32 0 on the GPU (forward.cu:335,453) */
-                for (int ch = 0; ch < 3; ch++) c->out_color[ch * HW + pix] = C[ch] + T * c->bg[ch];
+                for (int ch = 0; ch < 3; ch++) c->out_color[ch * HW + pix] = fmaf(T, c->bg[ch], C[ch]);
                 for (int ch = 0; ch < S; ch++) c->out_feature[ch * HW + pix] = F[ch];
                 c->out_others[pix + 0 * HW] = Dp;
-                c->out_others[pix + 1 * HW] = 1 - T;
+                c->out_others[pix + 1 * HW] = 1.0f - T;
                 for (int ch = 0; ch < 3; ch++) c->out_others[pix + (2 + ch) * HW] = N[ch];
                 c->out_others[pix + 5 * HW] = median_depth;
                 c->out_others[pix + 6 * HW] = distortion;
@@ -489,6 +496,7 @@ static void render_bwd_pixel(const mrgs_oracle_ctx *c, int tile, int pxi, int py
     for (int i = 0; i < S; i++) dL_dpixel_f[i] = dL_dpix_f[i * HW + pix];
     float last_alpha = 0, last_color[3] = {0, 0, 0}, last_feature[MAX_FEATURES] = {0};
     const float mscale = FAR_N / (FAR_N - NEAR_N);
+    const float dmd_scale = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
     for (uint32_t ii = r1; ii > r0; ii--) {
         contributor--;
         if (contributor >= last_contributor) continue;
@@ -498,70 +506,71 @@ static void render_bwd_pixel(const mrgs_oracle_ctx *c, int tile, int pxi, int py
         hit_t h;
         if (!intersect(Tm, c->means2D + 2 * (size_t)g, no[3], px, py, &h)) continue;
         const float alpha = h.alpha, G = h.G, c_d = h.depth;
-        T = T / (1.f - alpha);
-        const float dchannel_dcolor = alpha * T;
+        const float inv_1ma = 1.0f / (1.0f - alpha);
+        T = T * inv_1ma;                                    /* T / (1 - alpha), backward.cu:330 */
+        const float w = alpha * T;                          /* dchannel_dcolor */
+        const float one_m_la = 1.0f - last_alpha;
         float dL_dalpha = 0.0f;
         for (int ch = 0; ch < 3; ch++) {
             const float col = colors[3 * (size_t)g + ch];
-            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+            accum_rec[ch] = fmaf(last_alpha, last_color[ch], one_m_la * accum_rec[ch]);
             last_color[ch] = col;
-            dL_dalpha += (col - accum_rec[ch]) * dL_dpixel[ch];
-            acc->color[3 * (size_t)g + ch] += (double)(dchannel_dcolor * dL_dpixel[ch]);
+            dL_dalpha = fmaf(col - accum_rec[ch], dL_dpixel[ch], dL_dalpha);
+            acc->color[3 * (size_t)g + ch] += (double)(w * dL_dpixel[ch]);
         }
         for (int ch = 0; ch < S; ch++) {
             const float f = c->features[(size_t)g * S + ch];
-            accum_rec_f[ch] = last_alpha * last_feature[ch] + (1.f - last_alpha) * accum_rec_f[ch];
+            accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
             last_feature[ch] = f;
-            dL_dalpha += (f - accum_rec_f[ch]) * dL_dpixel_f[ch];
-            acc->feature[(size_t)g * S + ch] += (double)(dchannel_dcolor * dL_dpixel_f[ch]);
+            dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
+            acc->feature[(size_t)g * S + ch] += (double)(w * dL_dpixel_f[ch]);
         }
-        float dL_dz = 0.0f, dL_dweight = 0;
-        const float m_d = mscale * (1 - NEAR_N / c_d);
-        const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
-        if (contributor == (uint32_t)(median_contributor - 1)) dL_dz += dL_dmedian_depth;
-        dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+        const float inv_cd = 1.0f / c_d;
+        const float m_d = mscale * (1.0f - NEAR_N * inv_cd);
+        const float dmd_dd = dmd_scale * inv_cd * inv_cd;   /* (far*near) / ((far-near) * c_d * c_d) */
+        float dL_dz = (contributor == (uint32_t)(median_contributor - 1)) ? dL_dmedian_depth : 0.0f;
+        const float dL_dweight = fmaf(-2.0f * m_d, final_D, fmaf(m_d * m_d, final_A, final_D2)) * dL_dreg;
         dL_dalpha += dL_dweight - last_dL_dT;
-        last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-        dL_dz += dL_dmd * dmd_dd;
-        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+        last_dL_dT = fmaf(dL_dweight, alpha, (1.0f - alpha) * last_dL_dT);
+        const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
+        dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
+        accum_depth_rec = fmaf(last_alpha, last_depth, one_m_la * accum_depth_rec);
         last_depth = c_d;
-        dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-        accum_alpha_rec = (float)((double)last_alpha * 1.0 + (double)((1.f - last_alpha) * accum_alpha_rec));
-        dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+        dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
+        accum_alpha_rec = fmaf(one_m_la, accum_alpha_rec, last_alpha);
+        dL_dalpha = fmaf(1.0f - accum_alpha_rec, dL_daccum, dL_dalpha);
         for (int ch = 0; ch < 3; ch++) {
-            accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+            accum_normal_rec[ch] = fmaf(last_alpha, last_normal[ch], one_m_la * accum_normal_rec[ch]);
             last_normal[ch] = no[ch];
-            dL_dalpha += (no[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
-            acc->normal[3 * (size_t)g + ch] += (double)(alpha * T * dL_dnormal2D[ch]);
+            dL_dalpha = fmaf(no[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
+            acc->normal[3 * (size_t)g + ch] += (double)(w * dL_dnormal2D[ch]);
         }
         dL_dalpha *= T;
         last_alpha = alpha;
-        float bg_dot_dpixel = 0;
-        for (int i = 0; i < 3; i++) bg_dot_dpixel += c->bg[i] * dL_dpixel[i];
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+        const float bg_dot_dpixel = fmaf(c->bg[2], dL_dpixel[2], fmaf(c->bg[1], dL_dpixel[1], c->bg[0] * dL_dpixel[0]));
+        dL_dalpha = fmaf(-T_final * inv_1ma, bg_dot_dpixel, dL_dalpha);
         const float dL_dG = no[3] * dL_dalpha;
-        dL_dz += alpha * T * dL_ddepth;
+        dL_dz = fmaf(w, dL_ddepth, dL_dz);
         double *dT = acc->transMat + 9 * (size_t)g;
         if (h.rho3d <= h.rho2d) {
             const float *Tw = Tm + 6;
-            const float dL_dsx = dL_dG * -G * h.sx + dL_dz * Tw[0];
-            const float dL_dsy = dL_dG * -G * h.sy + dL_dz * Tw[1];
-            const float dsx_pz = dL_dsx / h.pz, dsy_pz = dL_dsy / h.pz;
-            const f3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * h.sx + dsy_pz * h.sy)};
+            const float dGn = dL_dG * -G;
+            const float dL_dsx = fmaf(dGn, h.sx, dL_dz * Tw[0]);
+            const float dL_dsy = fmaf(dGn, h.sy, dL_dz * Tw[1]);
+            const float dpx = dL_dsx * h.inv_pz, dpy = dL_dsy * h.inv_pz;
+            const float dpz = -fmaf(dpx, h.sx, dpy * h.sy);
             const f3 k = h.k, l = h.l;
-            const f3 dL_dk = {l.y * dL_dp.z - l.z * dL_dp.y, l.z * dL_dp.x - l.x * dL_dp.z, l.x * dL_dp.y - l.y * dL_dp.x};
-            const f3 dL_dl = {dL_dp.y * k.z - dL_dp.z * k.y, dL_dp.z * k.x - dL_dp.x * k.z, dL_dp.x * k.y - dL_dp.y * k.x};
+            const f3 dL_dk = {fmaf(l.y, dpz, -(l.z * dpy)), fmaf(l.z, dpx, -(l.x * dpz)), fmaf(l.x, dpy, -(l.y * dpx))};
+            const f3 dL_dl = {fmaf(dpy, k.z, -(dpz * k.y)), fmaf(dpz, k.x, -(dpx * k.z)), fmaf(dpx, k.y, -(dpy * k.x))};
             dT[0] += (double)(-dL_dk.x); dT[1] += (double)(-dL_dk.y); dT[2] += (double)(-dL_dk.z);
             dT[3] += (double)(-dL_dl.x); dT[4] += (double)(-dL_dl.y); dT[5] += (double)(-dL_dl.z);
-            dT[6] += (double)(px * dL_dk.x + py * dL_dl.x + dL_dz * h.sx);
-            dT[7] += (double)(px * dL_dk.y + py * dL_dl.y + dL_dz * h.sy);
-            dT[8] += (double)(px * dL_dk.z + py * dL_dl.z + dL_dz * 1.0f);
+            dT[6] += (double)fmaf(px, dL_dk.x, fmaf(py, dL_dl.x, dL_dz * h.sx));
+            dT[7] += (double)fmaf(px, dL_dk.y, fmaf(py, dL_dl.y, dL_dz * h.sy));
+            dT[8] += (double)fmaf(px, dL_dk.z, fmaf(py, dL_dl.z, dL_dz));
         } else {
-            const float dG_ddelx = -G * FILTER_INV_SQUARE * h.dx;
-            const float dG_ddely = -G * FILTER_INV_SQUARE * h.dy;
-            acc->mean2D[2 * (size_t)g] += (double)(dL_dG * dG_ddelx);
-            acc->mean2D[2 * (size_t)g + 1] += (double)(dL_dG * dG_ddely);
+            const float dGf = -G * FILTER_INV_SQUARE;
+            acc->mean2D[2 * (size_t)g] += (double)(dL_dG * (dGf * h.dx));
+            acc->mean2D[2 * (size_t)g + 1] += (double)(dL_dG * (dGf * h.dy));
             dT[8] += (double)dL_dz;
         }
         acc->opacity[g] += (double)(G * dL_dalpha);
