@@ -15,6 +15,7 @@
 #define SORT_THREADS 256
 #define SORT_WAVES (SORT_THREADS / 64)
 #define SORT_ITERS (MRGS_SORT_TILE / SORT_THREADS)
+#define RADIX_FUSED_MAX_BLOCKS 1024
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t
         if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    hist[(size_t)tid * nblk + blockIdx.x] = h[tid];   // digit-major so that one scan yields global offsets
+    hist[(size_t)blockIdx.x * 256 + tid] = h[tid];   // block-major: digit d of consecutive blocks is read coalesced
 }
 
 // ---- block-wide exclusive scan helper (wave64 shuffles + one LDS hop) ----------------------------------
@@ -62,16 +63,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 }
 
 // ---- radix pass 2/3: exclusive scan of the digit-major histogram (single workgroup) ------------------
-__global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__ hist, int total)
+// (only used for very large inputs, nblk > RADIX_FUSED_MAX_BLOCKS; otherwise the scatter kernel derives its offsets itself)
+__global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk)
 {
     __shared__ uint32_t wave_sums[16];
     uint32_t carry = 0;
+    const int total = 256 * nblk;
     for (int base = 0; base < total; base += 1024) {
-        const int i = base + threadIdx.x;
-        uint32_t v = i < total ? hist[i] : 0u;
+        const int i = base + threadIdx.x;                       // digit-major scan order over the block-major matrix
+        const size_t at = i < total ? (size_t)(i % nblk) * 256 + (size_t)(i / nblk) : 0;
+        uint32_t v = i < total ? hist[at] : 0u;
         uint32_t tot;
         uint32_t ex = block_exclusive_scan<1024>(v, wave_sums, tot);
-        if (i < total) hist[i] = carry + ex;
+        if (i < total) hist[at] = carry + ex;
         carry += tot;
     }
 }
@@ -79,12 +83,29 @@ __global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__
 // ---- radix pass 3/3: stable scatter; in-wave ranks from 8 ballots (wave64 multi-split) ---------------
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                                      uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                                     const uint32_t* __restrict__ offs, int64_t n, int shift, int nblk)
+                                                                     const uint32_t* __restrict__ offs, int64_t n, int shift, int nblk,
+                                                                     int fused)
 {
     __shared__ uint32_t running[256];
     __shared__ uint32_t wcnt[SORT_WAVES][256];
+    __shared__ uint32_t scan_tmp[SORT_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    running[tid] = offs[(size_t)tid * nblk + blockIdx.x];
+    if (fused) {
+        // offs is the raw block-major histogram matrix: this block's start for digit d is
+        //   sum_{d' < d} total[d'] + sum_{b' < b} hist[b'][d]   -- nblk coalesced loads per thread, no separate scan launch
+        uint32_t below = 0, total = 0;
+        const int me = blockIdx.x;
+#pragma unroll 8
+        for (int bb = 0; bb < nblk; bb++) {
+            const uint32_t v = offs[(size_t)bb * 256 + tid];
+            total += v;
+            below += bb < me ? v : 0u;
+        }
+        uint32_t tot;
+        running[tid] = block_exclusive_scan<SORT_THREADS>(total, scan_tmp, tot) + below;
+    } else {
+        running[tid] = offs[(size_t)blockIdx.x * 256 + tid];
+    }
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; w++) wcnt[w][tid] = 0;
     __syncthreads();
@@ -132,9 +153,10 @@ int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* hist, in
     const int nblk = (int)((n + MRGS_SORT_TILE - 1) / MRGS_SORT_TILE);
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_THREADS), 0, stream, key[cur], hist, n, shift, nblk);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, 256 * nblk);
+        const int fused = nblk <= RADIX_FUSED_MAX_BLOCKS;
+        if (!fused) hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, nblk);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_THREADS), 0, stream, key[cur], val[cur], key[cur ^ 1],
-                           val[cur ^ 1], hist, n, shift, nblk);
+                           val[cur ^ 1], hist, n, shift, nblk, fused);
         cur ^= 1;
     }
     return cur;
