@@ -1,4 +1,5 @@
-// mrgs_blend_math.h -- per-(pixel, surfel) arithmetic shared by the forward and the backward blend kernels.
+// mrgs_blend_math.h -- per-(pixel, surfel) arithmetic and list staging shared by the forward and the backward
+// blend kernels.
 //
 // Both kernels must reproduce EXACTLY the same alpha for a pair (the backward rebuilds T by dividing the
 // forward's products back out), so the ray/splat intersection lives in one place.  The translation units that
@@ -12,6 +13,7 @@
 
 #define MRGS_ALPHA_MIN (1.0f / 255.0f)
 #define MRGS_T_MIN 0.0001f
+#define MRGS_CHUNK 64   // list entries staged per step = one per lane
 
 __device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -37,7 +39,9 @@ struct Hit {
     float depth, G, alpha;
 };
 
-// forward.cu:366-398 / backward.cu:296-328.  Returns false when the pair is skipped.
+// forward.cu:366-398 / backward.cu:296-328, branch-free: everything is evaluated and the reference's chain of
+// `continue`s collapses into the returned flag (a zero p.z gives inf/NaN operands, and every comparison with
+// NaN is false, so such pairs are rejected exactly as the reference rejects them).
 __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, float py, Hit& h)
 {
     const float Twx = s.g1.z, Twy = s.g1.w, Twz = s.g2.x;
@@ -46,7 +50,6 @@ __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, fl
     const float ppx = fmaf(h.ky, h.lz, -(h.kz * h.ly));
     const float ppy = fmaf(h.kz, h.lx, -(h.kx * h.lz));
     const float ppz = fmaf(h.kx, h.ly, -(h.ky * h.lx));
-    if (ppz == 0.0f) return false;
     h.inv_pz = mrgs_rcp(ppz);
     h.sx = ppx * h.inv_pz;
     h.sy = ppy * h.inv_pz;
@@ -56,12 +59,10 @@ __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, fl
     h.rho2d = MRGS_FILTER_INV_SQUARE * fmaf(h.dx, h.dx, h.dy * h.dy);
     const float rho = fminf(h.rho3d, h.rho2d);
     h.depth = (h.rho3d <= h.rho2d) ? fmaf(h.sx, Twx, fmaf(h.sy, Twy, Twz)) : Twz;
-    if (h.depth < MRGS_NEAR_N) return false;
     const float power = -0.5f * rho;
-    if (power > 0.0f) return false;
     h.G = mrgs_exp(power);
     h.alpha = fminf(0.99f, s.g2.w * h.G);
-    return h.alpha >= MRGS_ALPHA_MIN;
+    return (ppz != 0.0f) & !(h.depth < MRGS_NEAR_N) & !(power > 0.0f) & !(h.alpha < MRGS_ALPHA_MIN);
 }
 
 // 8x8 pixel block owned by a wave: lane -> pixel
@@ -81,7 +82,47 @@ __device__ __forceinline__ bool mrgs_block_may_touch(const float4 bound, float b
     return (fabsf(bound.x - bcx) <= bound.z + 3.5f) && (fabsf(bound.y - bcy) <= bound.w + 3.5f);
 }
 
-// wave64 sum with DPP; every lane of the wave must be active.  Result valid in lane 63.
+// ---- list staging: asynchronous global -> LDS gather ---------------------------------------------------
+// One stage = the records of up to 64 list entries, entry l in slot l.  The five float4 that the blend reads
+// (geometry 0..2, appearance 3..4) and the S feature floats are moved by LDS-DMA
+// (global_load_lds_dwordx4 / _dword: per-lane global address, destination = wave-uniform LDS base + lane*size),
+// so the staged data never occupies VGPRs and the copy for the next chunk is in flight while the current one is
+// blended.  Only lanes whose surfel can touch the block issue the copy (EXEC-masked DMA).
+template <int SF>
+struct StageBuf {
+    float4 rec[5][MRGS_CHUNK];
+    float feat[SF][MRGS_CHUNK];
+    uint32_t id[MRGS_CHUNK];
+};
+
+template <int S_MAX, int SF>
+__device__ __forceinline__ void mrgs_stage_async(StageBuf<SF>& dst, const float4* __restrict__ rec, const float* __restrict__ features,
+                                                 int S, uint32_t gid, bool pred)
+{
+    if (pred) {
+        const float4* src = rec + (size_t)gid * MRGS_REC_F4;
+        __builtin_amdgcn_global_load_lds(src + 0, &dst.rec[0][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 1, &dst.rec[1][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 2, &dst.rec[2][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 3, &dst.rec[3][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 4, &dst.rec[4][0], 16, 0, 0);
+        if (S_MAX > 0) {
+            const float* fsrc = features + (size_t)gid * S;
+#pragma unroll
+            for (int ch = 0; ch < S_MAX; ch++)
+                if (ch < S) __builtin_amdgcn_global_load_lds(fsrc + ch, &dst.feat[ch][0], 4, 0, 0);
+        }
+    }
+}
+
+// all LDS-DMA of this wave has landed (the DMA is tracked by vmcnt; nothing else orders a ds_read behind it)
+__device__ __forceinline__ void mrgs_stage_wait()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// wave64 sum with DPP; every lane of the wave must be active.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float mrgs_dpp_add(float v)
 {

@@ -14,7 +14,6 @@
 // floats of the surfel's packed gradient row, replace K single-lane atomics.
 #include "mrgs_blend_math.h"
 
-#define BWD_CHUNK 64
 
 __device__ __forceinline__ void swap32_add(float& a, float b)   // a <- [a.lo + a.hi | b.lo + b.hi]
 {
@@ -65,10 +64,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     constexpr int K = (18 + S_MAX + 3) & ~3;
-    __shared__ float4 s_geo[3][BWD_CHUNK];
-    __shared__ float4 s_app[2][BWD_CHUNK];
-    __shared__ float s_feat[SF * BWD_CHUNK];
-    __shared__ uint32_t s_id[BWD_CHUNK];
+    __shared__ StageBuf<SF> stage[2];
 
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
@@ -93,6 +89,10 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, d, 64));
     if (max_contrib == 0) return;
+    // longest waves first in line for issue slots (see mrgs_render_fwd.hip)
+    if (max_contrib > 768) __builtin_amdgcn_s_setprio(3);
+    else if (max_contrib > 384) __builtin_amdgcn_s_setprio(2);
+    else if (max_contrib > 192) __builtin_amdgcn_s_setprio(1);
     const int median_contributor = inside ? (int)n_contrib[pix + HW] : 0;
 
     const float T_final = inside ? final_Ts[pix] : 0.f;
@@ -128,76 +128,69 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
     const float dmd_scale = (MRGS_FAR_N * MRGS_NEAR_N) / (MRGS_FAR_N - MRGS_NEAR_N);
     const float bg_dot_dpixel = fmaf(bg[2], dL_dpixel[2], fmaf(bg[1], dL_dpixel[1], bg[0] * dL_dpixel[0]));
 
-    // chunks of 64 list entries, from the one holding position max_contrib-1 down to chunk 0; lane l <-> position 64c+l
+    // chunks of 64 list entries, from the one holding position max_contrib-1 down to chunk 0; lane l <-> position 64c+l.
+    // Same staging pipeline as the forward (LDS-DMA double buffer, boxes two chunks and ids three chunks ahead), walked
+    // towards the front of the list.
     const uint32_t* plist = point_list + range.x;
     const float4 kNever = make_float4(0.f, 0.f, -1e30f, -1e30f);
-    const int c_top = (max_contrib - 1) / BWD_CHUNK;
-    uint32_t id_cur = 0, id_nxt = 0;
-    float4 q0, q1, q2, q5 = kNever;
-    q0 = q1 = q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c_top * BWD_CHUNK + lane < max_contrib) {
-        id_cur = plist[c_top * BWD_CHUNK + lane];
-        const float4* src = rec + (size_t)id_cur * MRGS_REC_F4;
-        q0 = src[0]; q1 = src[1]; q2 = src[2]; q5 = src[5];
+    const int c_top = (max_contrib - 1) / MRGS_CHUNK;
+    uint32_t id1 = 0, id2 = 0;
+    float4 box1 = kNever;
+    uint64_t mask_cur;
+    {
+        uint32_t id0 = 0;
+        float4 box0 = kNever;
+        if (c_top * MRGS_CHUNK + lane < max_contrib) {
+            id0 = plist[c_top * MRGS_CHUNK + lane];
+            box0 = rec[(size_t)id0 * MRGS_REC_F4 + 5];
+        }
+        if (c_top >= 1) {
+            id1 = plist[(c_top - 1) * MRGS_CHUNK + lane];
+            box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+        }
+        if (c_top >= 2) id2 = plist[(c_top - 2) * MRGS_CHUNK + lane];
+        const bool cand0 = mrgs_block_may_touch(box0, bcx, bcy);
+        mask_cur = __ballot(cand0);
+        mrgs_stage_async<S_MAX, SF>(stage[c_top & 1], rec, features, S, id0, cand0);
+        if (cand0) stage[c_top & 1].id[lane] = id0;
     }
-    if (c_top >= 1) id_nxt = plist[(c_top - 1) * BWD_CHUNK + lane];
 
     for (int c = c_top; c >= 0; c--) {
-        const int base = c * BWD_CHUNK;
-        const uint32_t cur_id = id_cur;
-        const float4 c0 = q0, c1 = q1, c2 = q2;
-        const bool cand = mrgs_block_may_touch(q5, bcx, bcy);
-        uint64_t mask = __ballot(cand);
-        float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = a3;
-        float fch[SF];
-        if (cand) {
-            const float4* src = rec + (size_t)cur_id * MRGS_REC_F4;
-            a3 = src[3];
-            a4 = src[4];
-            if (S_MAX > 0) {
-                const float* fsrc = features + (size_t)cur_id * S;
-#pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) fch[ch] = fsrc[ch];
-            }
-        }
-        id_cur = id_nxt;
-        q5 = kNever;
-        if (c >= 1) {
-            const float4* src = rec + (size_t)id_cur * MRGS_REC_F4;
-            q0 = src[0]; q1 = src[1]; q2 = src[2]; q5 = src[5];
-        }
-        if (c >= 2) id_nxt = plist[(c - 2) * BWD_CHUNK + lane];
+        const int base = c * MRGS_CHUNK;
+        mrgs_stage_wait();                    // chunk c has landed in stage[c & 1]
+        const bool cand1 = mrgs_block_may_touch(box1, bcx, bcy);
+        const uint64_t mask_nxt = __ballot(cand1);
+        mrgs_stage_async<S_MAX, SF>(stage[(c + 1) & 1], rec, features, S, id1, cand1);
+        if (cand1) stage[(c + 1) & 1].id[lane] = id1;
+        id1 = id2;
+        box1 = kNever;
+        if (c >= 2) box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+        if (c >= 3) id2 = plist[(c - 3) * MRGS_CHUNK + lane];
+
+        uint64_t mask = mask_cur;
+        mask_cur = mask_nxt;
         if (mask == 0ull) continue;
-        if (cand) {
-            s_id[lane] = cur_id;
-            s_geo[0][lane] = c0; s_geo[1][lane] = c1; s_geo[2][lane] = c2;
-            s_app[0][lane] = a3;
-            s_app[1][lane] = a4;
-            if (S_MAX > 0) {
-#pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) s_feat[ch * BWD_CHUNK + lane] = fch[ch];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        while (mask) {
-            const int j = 63 - __builtin_clzll(mask);   // back to front
+        const StageBuf<SF>& sb = stage[c & 1];
+        int j = 63 - __builtin_clzll(mask);   // back to front
+        SurfelGeom sg;
+        sg.g0 = sb.rec[0][j]; sg.g1 = sb.rec[1][j]; sg.g2 = sb.rec[2][j];
+        while (true) {
             mask &= ~(1ull << j);
+            const bool more = mask != 0ull;
+            const int jn = more ? 63 - __builtin_clzll(mask) : j;
+            SurfelGeom nxt;
+            nxt.g0 = sb.rec[0][jn]; nxt.g1 = sb.rec[1][jn]; nxt.g2 = sb.rec[2][jn];
             const int contributor = base + j;           // 0-based list position; the forward's contributor is position+1
-            SurfelGeom sg;
-            sg.g0 = s_geo[0][j]; sg.g1 = s_geo[1][j]; sg.g2 = s_geo[2][j];
             Hit h;
-            bool active = inside && contributor < last_contributor;
-            if (active) active = mrgs_intersect(sg, px, py, h);
-            if (__ballot(active) == 0ull) continue;
+            const bool hit = mrgs_intersect(sg, px, py, h);
+            const bool active = hit && inside && contributor < last_contributor;
+            if (__ballot(active) != 0ull) {
 
             float g[K];
 #pragma unroll
             for (int i = 0; i < K; i++) g[i] = 0.f;
             if (active) {
-                const float4 a0 = s_app[0][j], a1 = s_app[1][j];
+                const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
                 const float normal[3] = {a0.x, a0.y, a0.z};
                 const float col[3] = {a0.w, a1.x, a1.y};
                 const float alpha = h.alpha, G = h.G, c_d = h.depth;
@@ -217,7 +210,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
 #pragma unroll
                     for (int ch = 0; ch < S_MAX; ch++)
                         if (ch < S) {
-                            const float f = s_feat[ch * BWD_CHUNK + j];
+                            const float f = sb.feat[ch][j];
                             accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
                             last_feature[ch] = f;
                             dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
@@ -276,9 +269,14 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
                 }
                 g[11] = G * dL_dalpha;
             }
-            wave_reduce_atomic_add<K>(g, grad_rec + (size_t)s_id[j] * gstride, lane);
+            wave_reduce_atomic_add<K>(g, grad_rec + (size_t)sb.id[j] * gstride, lane);
+            }
+            if (!more) break;
+            sg = nxt;
+            j = jn;
         }
     }
+    mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
 }
 
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,

@@ -4,17 +4,25 @@
 // MI355X-first design (the reference runs one 256-thread block per 16x16 tile with two barriers per batch):
 //   * one wave64 per 8x8 pixel block, each wave a workgroup of its own -> no barriers at all, 4x more (and 4x
 //     smaller) work items to balance over 256 CUs, and the 64 lanes of a wave see nearly the same surfels;
-//   * the tile's depth-sorted list is consumed 64 entries at a time: lane l fetches entry l's packed record
-//     (id + four dwordx4), tests its conservative screen bound against the wave's block, and a 64-bit
-//     __ballot gives the sub-list that can touch this block -- the wave then walks only the set bits
-//     (s_ff1) instead of all 64 entries.  Skipped entries could not have passed alpha >= 1/255 on any lane;
-//   * the surviving records are broadcast from LDS (ds_read_b128, same address on all lanes); colour, normal
-//     and feature channels are read only when some lane really blends the surfel;
+//   * the tile's depth-sorted list is consumed 64 entries at a time: lane l tests entry l's conservative screen
+//     box against the wave's block and a 64-bit __ballot gives the sub-list that can touch this block -- the
+//     wave then walks only the set bits (s_ff1) instead of all 64 entries.  Skipped entries could not have
+//     passed alpha >= 1/255 on any lane;
+//   * the records of the surviving entries are gathered by LDS-DMA (global_load_lds, per-lane source address,
+//     EXEC-masked to the candidates) into a double-buffered stage: the copy for chunk c+1 is in flight while
+//     chunk c is blended and the staged data never passes through VGPRs.  Ids run three chunks ahead and cull
+//     boxes two chunks ahead, so the dependent gather id -> box -> record is never waited for;
+//   * in the blend loop the stage is read with uniform-address ds_read_b128 (LDS broadcast), the next surfel's
+//     geometry being fetched while the current one is evaluated;
 //   * blockIdx -> (tile, quadrant) keeps the four quadrant-waves of a tile on one XCD (blocks are dealt
 //     round-robin to the 8 XCDs) so that the tile's records are fetched into one L2 only.
 #include "mrgs_blend_math.h"
 
-#define FWD_CHUNK 64
+// 1: single stage buffer, the copy of chunk c+1 is issued after chunk c has been blended (5.5 KB LDS per wave -> 7 waves
+//    per SIMD; the copy latency is covered by the other waves).  2: double buffer, copy overlapped inside the wave (11 KB).
+#ifndef MRGS_FWD_STAGES
+#define MRGS_FWD_STAGES 1
+#endif
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
@@ -23,9 +31,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
-    __shared__ float4 s_geo[3][FWD_CHUNK];
-    __shared__ float4 s_app[2][FWD_CHUNK];
-    __shared__ float s_feat[SF * FWD_CHUNK];
+    __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
 
     const int lane = threadIdx.x;
     // XCD-aware mapping: b % 8 selects the XCD; within an XCD consecutive blocks are the 4 quadrants of one tile
@@ -46,6 +52,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    // The launch lasts as long as its longest wave: every wave is resident from the start, and the waves of the densest
+    // tiles carry several times the average work.  Give them issue priority so that they run near their single-wave
+    // speed while the light waves fill the remaining issue slots.
+    if (total > 1024) __builtin_amdgcn_s_setprio(3);
+    else if (total > 512) __builtin_amdgcn_s_setprio(2);
+    else if (total > 256) __builtin_amdgcn_s_setprio(1);
 
     bool done = !inside;
     float T = 1.0f;
@@ -57,92 +69,96 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     uint32_t last_contributor = 0, median_contributor = 0;
     const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
 
-    // three-stage software pipeline over 64-entry chunks: ids are fetched two chunks ahead, packed geometry one
-    // chunk ahead, so that the dependent gather (id -> record) never stalls the blend loop
+    // ---- pipeline prologue: chunk 0 staged, box of chunk 1 and ids of chunks 1, 2 on their way ------------
     const uint32_t* plist = point_list + range.x;
     const float4 kNever = make_float4(0.f, 0.f, -1e30f, -1e30f);
-    uint32_t id_cur = 0, id_nxt = 0;
-    float4 q0, q1, q2, q5 = kNever;
-    q0 = q1 = q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < total) {
-        id_cur = plist[lane];
-        const float4* src = rec + (size_t)id_cur * MRGS_REC_F4;
-        q0 = src[0]; q1 = src[1]; q2 = src[2]; q5 = src[5];
+    uint32_t id1 = 0, id2 = 0;
+    float4 box1 = kNever;
+    uint64_t mask_cur;
+    {
+        uint32_t id0 = 0;
+        float4 box0 = kNever;
+        if (lane < total) {
+            id0 = plist[lane];
+            box0 = rec[(size_t)id0 * MRGS_REC_F4 + 5];
+        }
+        if (MRGS_CHUNK + lane < total) {
+            id1 = plist[MRGS_CHUNK + lane];
+            box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+        }
+        if (2 * MRGS_CHUNK + lane < total) id2 = plist[2 * MRGS_CHUNK + lane];
+        const bool cand0 = mrgs_block_may_touch(box0, bcx, bcy);
+        mask_cur = __ballot(cand0);
+        mrgs_stage_async<S_MAX, SF>(stage[0], rec, features, S, id0, cand0);
     }
-    if (FWD_CHUNK + lane < total) id_nxt = plist[FWD_CHUNK + lane];
 
-    for (int base = 0; base < total; base += FWD_CHUNK) {
+    for (int base = 0, c = 0; base < total; base += MRGS_CHUNK, c++) {
         if (__ballot(!done) == 0ull) break;   // every pixel of the block has terminated (forward.cu:342-344, per wave)
-        const uint32_t cur_id = id_cur;
-        const float4 c0 = q0, c1 = q1, c2 = q2;
-        const bool cand = mrgs_block_may_touch(q5, bcx, bcy);
-        uint64_t mask = __ballot(cand);
-        // appearance of the candidates (needed first), then the prefetches for the following chunks
-        float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = a3;
-        float fch[SF];
-        if (cand) {
-            const float4* src = rec + (size_t)cur_id * MRGS_REC_F4;
-            a3 = src[3];
-            a4 = src[4];
-            if (S_MAX > 0) {
-                const float* fsrc = features + (size_t)cur_id * S;
-#pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) fch[ch] = fsrc[ch];
-            }
-        }
-        id_cur = id_nxt;
-        q5 = kNever;
-        if (base + FWD_CHUNK + lane < total) {
-            const float4* src = rec + (size_t)id_cur * MRGS_REC_F4;
-            q0 = src[0]; q1 = src[1]; q2 = src[2]; q5 = src[5];
-        }
-        if (base + 2 * FWD_CHUNK + lane < total) id_nxt = plist[base + 2 * FWD_CHUNK + lane];
-        if (mask == 0ull) continue;
-        if (cand) {
-            s_geo[0][lane] = c0; s_geo[1][lane] = c1; s_geo[2][lane] = c2;
-            s_app[0][lane] = a3;
-            s_app[1][lane] = a4;
-            if (S_MAX > 0) {
-#pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) s_feat[ch * FWD_CHUNK + lane] = fch[ch];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // single-wave workgroup: LDS ops are ordered in issue order
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            if (done) continue;
-            SurfelGeom sg;
-            sg.g0 = s_geo[0][j]; sg.g1 = s_geo[1][j]; sg.g2 = s_geo[2][j];
+        mrgs_stage_wait();                    // chunk c has landed
+        uint64_t mask_nxt = 0ull;
+        auto stage_next = [&]() {
+            // stage chunk c+1 (its ids and boxes arrived during the previous iteration), prefetch box c+2 and ids c+3
+            const bool cand1 = mrgs_block_may_touch(box1, bcx, bcy);
+            mask_nxt = __ballot(cand1);
+            mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
+            id1 = id2;
+            box1 = kNever;
+            if (base + 2 * MRGS_CHUNK + lane < total) box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+            if (base + 3 * MRGS_CHUNK + lane < total) id2 = plist[base + 3 * MRGS_CHUNK + lane];
+        };
+        if (MRGS_FWD_STAGES == 2) stage_next();
+
+        uint64_t m = mask_cur;
+        const StageBuf<SF>& sb = stage[c % MRGS_FWD_STAGES];
+        if (m != 0ull) {
+        int j = __builtin_ctzll(m);
+        SurfelGeom cur;
+        cur.g0 = sb.rec[0][j]; cur.g1 = sb.rec[1][j]; cur.g2 = sb.rec[2][j];
+        while (true) {
+            m &= m - 1;
+            const bool more = m != 0ull;
+            const int jn = more ? __builtin_ctzll(m) : j;
+            SurfelGeom nxt;                               // next surfel's geometry is fetched while this one is evaluated
+            nxt.g0 = sb.rec[0][jn]; nxt.g1 = sb.rec[1][jn]; nxt.g2 = sb.rec[2][jn];
+            const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
             Hit h;
-            if (!mrgs_intersect(sg, px, py, h)) continue;
-            const float test_T = T * (1.0f - h.alpha);
-            if (test_T < MRGS_T_MIN) { done = true; continue; }
-            const float w = h.alpha * T;
-            const float A = 1.0f - T;
-            const float m = mscale * (1.0f - MRGS_NEAR_N * mrgs_rcp(h.depth));
-            const float mm = m * m;
-            // distortion += (m*m*A + M2 - 2*m*M1) * w   (forward.cu:412), fused as written here and in the oracle
-            distortion = fmaf(fmaf(-2.0f * m, M1, fmaf(mm, A, M2)), w, distortion);
-            Dp = fmaf(h.depth, w, Dp);
-            M1 = fmaf(m, w, M1);
-            M2 = fmaf(mm, w, M2);
-            const uint32_t contributor = (uint32_t)(base + j + 1);
-            if (T > 0.5f) { median_depth = h.depth; median_contributor = contributor; }
-            const float4 a0 = s_app[0][j], a1 = s_app[1][j];
-            N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
-            C0 = fmaf(a0.w, w, C0); C1 = fmaf(a1.x, w, C1); C2 = fmaf(a1.y, w, C2);
-            if (S_MAX > 0) {
+            const bool hit = mrgs_intersect(cur, px, py, h);
+            if (hit && !done) {
+                const float test_T = T * (1.0f - h.alpha);
+                if (test_T < MRGS_T_MIN) {
+                    done = true;
+                } else {
+                    const float w = h.alpha * T;
+                    const float A = 1.0f - T;
+                    const float m_ = mscale * (1.0f - MRGS_NEAR_N * mrgs_rcp(h.depth));
+                    const float mm = m_ * m_;
+                    // distortion += (m*m*A + M2 - 2*m*M1) * w   (forward.cu:412), fused as written here and in the oracle
+                    distortion = fmaf(fmaf(-2.0f * m_, M1, fmaf(mm, A, M2)), w, distortion);
+                    Dp = fmaf(h.depth, w, Dp);
+                    M1 = fmaf(m_, w, M1);
+                    M2 = fmaf(mm, w, M2);
+                    const uint32_t contributor = (uint32_t)(base + j + 1);
+                    if (T > 0.5f) { median_depth = h.depth; median_contributor = contributor; }
+                    N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
+                    C0 = fmaf(a0.w, w, C0); C1 = fmaf(a1.x, w, C1); C2 = fmaf(a1.y, w, C2);
+                    if (S_MAX > 0) {
 #pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) F[ch] = fmaf(s_feat[ch * FWD_CHUNK + j], w, F[ch]);
+                        for (int ch = 0; ch < S_MAX; ch++)
+                            if (ch < S) F[ch] = fmaf(sb.feat[ch][j], w, F[ch]);
+                    }
+                    T = test_T;
+                    last_contributor = contributor;
+                }
             }
-            T = test_T;
-            last_contributor = contributor;
+            if (!more) break;
+            cur = nxt;
+            j = jn;
         }
+        }
+        if (MRGS_FWD_STAGES == 1) stage_next();
+        mask_cur = mask_nxt;
     }
+    mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
 
     if (inside) {
         final_T[pix] = T;

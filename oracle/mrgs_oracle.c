@@ -348,7 +348,7 @@ static int intersect(const float *T, const float *xy, float opa, float px, float
     h->G = expf(power);
     h->alpha = fminf(0.99f, opa * h->G);
 #ifndef MRGS_ORACLE_NO_ALPHA_CUTOFF   /* test-only build: see tests/test_oracle.py::test_smooth_part_is_exact_derivative */
-    if (!(h->alpha >= 1.0f / 255.0f)) return 0;
+    if (h->alpha < 1.0f / 255.0f) return 0;
 #endif
     return 1;
 }
