@@ -117,6 +117,50 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
 int mrgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                       void* stream);
 
+/* ---- environment lookup and deferred specular shading ("second boundary") ----------------------
+ * The mip chain of scene/light.py:EnvLight: level i is a [6,res_i,res_i,3] fp32 cubemap holding PRE-sigmoid texels
+ * (light.py:129); face/orientation convention of cube_to_dir (scene/light_utils.py:24-31).  grad[i] (may be NULL) receives
+ * dL/dtexel by atomic accumulation -- the caller zero-fills it. */
+#define MRGS_MAX_MIPS 8
+typedef struct MrgsEnvMips {
+    int32_t n_levels;
+    int32_t res[MRGS_MAX_MIPS];
+    const float* tex[MRGS_MAX_MIPS];
+    float* grad[MRGS_MAX_MIPS];
+    float min_roughness, max_roughness;   /* EnvLight.min_roughness / max_roughness (0.08 / 0.5) */
+} MrgsEnvMips;
+
+/* Replaces EnvLight.__call__(l, roughness=...) (scene/light.py:99-129): out[N,3] = sigmoid(trilinear cube fetch at the mip
+ * level get_mip(roughness)).  roughness == NULL selects mode="pure_env" (level 0 only). */
+int mrgs_envmap_lookup_forward(const MrgsEnvMips* mips, int64_t N, const float* dirs, const float* roughness, float* out, void* stream);
+int mrgs_envmap_lookup_backward(const MrgsEnvMips* mips, int64_t N, const float* dirs, const float* roughness, const float* g_out,
+                                float* g_dirs /*[N,3] or NULL*/, float* g_roughness /*[N] or NULL*/, void* stream);
+
+typedef struct MrgsStridedMap { const float* ptr; int64_t stride_h, stride_w, stride_c; } MrgsStridedMap;   /* element strides */
+typedef struct MrgsShadeFrame {
+    int32_t H, W;
+    float Kinv[9];          /* inverse intrinsics, row-major, host values (np.linalg.inv(K), utils/refl_utils.py:64) */
+    const float* R;         /* device [3,3]: Camera.R (stored transposed, i.e. camera-to-world rotation) */
+    const float* T;         /* device [3]:   Camera.T (world-to-camera translation) */
+    MrgsStridedMap albedo;  /* [H,W,3] */
+    MrgsStridedMap normal;  /* [H,W,3] world-space shading normal (rend_normal / alpha) */
+    MrgsStridedMap alpha;   /* [H,W,1] */
+    MrgsStridedMap refl;    /* [H,W,1] refl_strength */
+    MrgsStridedMap roughness; /* [H,W,1] */
+    const float* lut;       /* device [lut_res, lut_res, 2] split-sum FG table (assets/bsdf_256_256.bin layout, refl_utils.py:9) */
+    int32_t lut_res;
+} MrgsShadeFrame;
+
+/* Replaces get_specular_color_surfel without visibility tracing (utils/refl_utils.py:364-419): per pixel, in one pass,
+ * specular[3,H,W] = direct_light * alpha * specular_weight, direct_light[3,H,W], specular_weight[H,W,3]. */
+int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, float* specular, float* direct_light,
+                                float* specular_weight, void* stream);
+/* Gradients w.r.t. the five maps (dense, fully written: g_albedo[H,W,3], g_normal[H,W,3], g_alpha[H,W], g_refl[H,W],
+ * g_roughness[H,W]) and, through mips->grad, w.r.t. the cubemap texels.  Any of the three upstream gradients may be NULL. */
+int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* g_specular, const float* g_direct_light,
+                                 const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
+                                 float* g_roughness, void* stream);
+
 /* Introspection used by the parity tests: copies of internal state in the reference's layouts.
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
  * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],

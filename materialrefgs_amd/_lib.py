@@ -32,6 +32,24 @@ class MrgsRasterGrads(ctypes.Structure):
                                         "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations")]
 
 
+MRGS_MAX_MIPS = 8
+
+
+class MrgsEnvMips(ctypes.Structure):
+    _fields_ = [("n_levels", c_int32), ("res", c_int32 * MRGS_MAX_MIPS), ("tex", c_void_p * MRGS_MAX_MIPS),
+                ("grad", c_void_p * MRGS_MAX_MIPS), ("min_roughness", c_float), ("max_roughness", c_float)]
+
+
+class MrgsStridedMap(ctypes.Structure):
+    _fields_ = [("ptr", c_void_p), ("stride_h", c_int64), ("stride_w", c_int64), ("stride_c", c_int64)]
+
+
+class MrgsShadeFrame(ctypes.Structure):
+    _fields_ = [("H", c_int32), ("W", c_int32), ("Kinv", c_float * 9), ("R", c_void_p), ("T", c_void_p),
+                ("albedo", MrgsStridedMap), ("normal", MrgsStridedMap), ("alpha", MrgsStridedMap), ("refl", MrgsStridedMap),
+                ("roughness", MrgsStridedMap), ("lut", c_void_p), ("lut_res", c_int32)]
+
+
 class MrgsKernelTimes(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
                                        "preprocess_bwd_ms")]
@@ -51,6 +69,13 @@ SYMBOLS = {
                                                c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                ctypes.POINTER(MrgsRasterGrads), c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_envmap_lookup_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p]),
+    "mrgs_shade_specular_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
+                                                   c_void_p, c_void_p]),
+    "mrgs_shade_specular_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_debug_export": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p]),
     "mrgs_set_profiling": (ctypes.c_int, [c_int32]),

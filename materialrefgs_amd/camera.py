@@ -64,6 +64,14 @@ class MiniCam(NamedTuple):
     R: torch.Tensor                      # [3,3] c2w rotation (as stored by Camera.R)
     T: torch.Tensor                      # [3]  w2c translation
 
+    @property
+    def HWK(self):
+        """(H, W, K) as the dataset readers hand it to Camera (scene/cameras.py:43-45): pinhole intrinsics with the
+        principal point at the image centre (Cx = 0.5 W, Cy = 0.5 H, cameras.py:63-66)."""
+        fx, fy = fov2focal(self.FoVx, self.image_width), fov2focal(self.FoVy, self.image_height)
+        K = np.array([[fx, 0.0, 0.5 * self.image_width], [0.0, fy, 0.5 * self.image_height], [0.0, 0.0, 1.0]], dtype=np.float32)
+        return (self.image_height, self.image_width, K)
+
     def to(self, device):
         return self._replace(world_view_transform=self.world_view_transform.to(device),
                              full_proj_transform=self.full_proj_transform.to(device),

@@ -1,0 +1,486 @@
+// mrgs_shade.hip -- environment-cubemap mip lookup and deferred split-sum specular shading on gfx950.
+//
+//   envmap_lookup_{fwd,bwd}_kernel : EnvLight.__call__ (scene/light.py:99-129): roughness -> mip level (get_mip, :88-96),
+//                                    seamless trilinear cubemap fetch over the mip chain, sigmoid.
+//   shade_specular_{fwd,bwd}_kernel: get_specular_color_surfel (utils/refl_utils.py:364-419) fused into one pass per pixel:
+//                                    camera ray (sample_camera_rays :54-73), mirror direction (reflection :95-98), split-sum
+//                                    FG LUT fetch (:373-374), environment lookup (:376), Fresnel-style weight (:377),
+//                                    specular = light * alpha * weight (:400-401).
+//
+// The reference does this with ~25 elementwise torch kernels plus two nvdiffrast `dr.texture` launches.  nvdiffrast is not
+// vendored (requirements.txt:57 pins a local path), so its sampling rules are RESTATED here and in oracle/shading_oracle.py
+// -- parity unpinned for the lookups: texel centres at (i + 0.5) / res, bilinear taps, `clamp` boundary for the 2D LUT,
+// seamless cube edges (a tap that falls off a face is taken from the face across the edge; the non-existent corner tap gets
+// zero weight and the other three are renormalised), mip level = mip_level_bias clamped to [0, levels-1] with linear
+// interpolation between the two nearest levels.  Face/orientation convention: cube_to_dir (scene/light_utils.py:24-31).
+//
+// Memory-bound by design: one pixel per lane, ~100 B/pixel in, 36 B/pixel out; the 1.6 MB mip chain and the 512 KB LUT stay
+// in L2.  Texel gradients are accumulated with fp32 atomics (mirror directions of neighbouring pixels hit the same texels).
+#include "mrgs_internal.h"
+
+struct EnvMips {   // by-value kernel argument
+    int n;
+    int res[MRGS_MAX_MIPS];
+    const float* tex[MRGS_MAX_MIPS];
+    float* grad[MRGS_MAX_MIPS];
+    float min_roughness, max_roughness;
+};
+
+struct Map {   // strided [H,W,C] view
+    const float* p;
+    long long sh, sw, sc;
+};
+struct MapOut {
+    float* p;
+    long long sh, sw, sc;
+};
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// direction -> (face, u, v) with u,v in [-1,1]; inverse of cube_to_dir (scene/light_utils.py:24-31)
+struct FaceUV { int face; float u, v, inv_ma; int axis; float sgn; };
+__device__ __forceinline__ FaceUV dir_to_face(f3 d)
+{
+    FaceUV r;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    if (ax >= ay && ax >= az) {
+        r.axis = 0; r.sgn = d.x >= 0.f ? 1.f : -1.f; r.inv_ma = 1.0f / ax;
+        r.face = d.x >= 0.f ? 0 : 1;
+        r.u = (d.x >= 0.f ? -d.z : d.z) * r.inv_ma;
+        r.v = -d.y * r.inv_ma;
+    } else if (ay >= az) {
+        r.axis = 1; r.sgn = d.y >= 0.f ? 1.f : -1.f; r.inv_ma = 1.0f / ay;
+        r.face = d.y >= 0.f ? 2 : 3;
+        r.u = d.x * r.inv_ma;
+        r.v = (d.y >= 0.f ? d.z : -d.z) * r.inv_ma;
+    } else {
+        r.axis = 2; r.sgn = d.z >= 0.f ? 1.f : -1.f; r.inv_ma = 1.0f / az;
+        r.face = d.z >= 0.f ? 4 : 5;
+        r.u = (d.z >= 0.f ? d.x : -d.x) * r.inv_ma;
+        r.v = -d.y * r.inv_ma;
+    }
+    return r;
+}
+__device__ __forceinline__ f3 face_to_dir(int s, float x, float y)
+{
+    switch (s) {
+    case 0: return mk(1.f, -y, -x);
+    case 1: return mk(-1.f, -y, x);
+    case 2: return mk(x, 1.f, y);
+    case 3: return mk(x, -1.f, -y);
+    case 4: return mk(x, -y, 1.f);
+    default: return mk(-x, -y, -1.f);
+    }
+}
+
+// the four bilinear taps of one mip level: linear texel indices (face*res*res + y*res + x) and weights
+struct Taps { int idx[4]; float w[4]; float wx, wy, norm; bool corner; };
+__device__ __forceinline__ int wrap_tap(int face, int x, int y, int res)
+{
+    if (x >= 0 && x < res && y >= 0 && y < res) return (face * res + y) * res + x;
+    // texel centre of the tap in the face's plane; the overshooting coordinate is pulled just across the edge so that the
+    // re-projection lands on the border texel of the adjacent face with the edge-parallel coordinate unchanged
+    const float eps = 1.0f / 4096.0f;
+    float u = ((float)x + 0.5f) / (float)res * 2.0f - 1.0f;
+    float v = ((float)y + 0.5f) / (float)res * 2.0f - 1.0f;
+    if (x < 0) u = -1.0f - eps; else if (x >= res) u = 1.0f + eps;
+    if (y < 0) v = -1.0f - eps; else if (y >= res) v = 1.0f + eps;
+    const FaceUV f = dir_to_face(face_to_dir(face, u, v));
+    int xi = (int)floorf((f.u * 0.5f + 0.5f) * (float)res);
+    int yi = (int)floorf((f.v * 0.5f + 0.5f) * (float)res);
+    xi = min(max(xi, 0), res - 1);
+    yi = min(max(yi, 0), res - 1);
+    return (f.face * res + yi) * res + xi;
+}
+__device__ __forceinline__ Taps cube_taps(const FaceUV& f, int res)
+{
+    Taps t;
+    const float fx = (f.u * 0.5f + 0.5f) * (float)res - 0.5f;
+    const float fy = (f.v * 0.5f + 0.5f) * (float)res - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    t.wx = fx - x0f; t.wy = fy - y0f;
+    const bool ox0 = x0 < 0, ox1 = x0 + 1 >= res, oy0 = y0 < 0, oy1 = y0 + 1 >= res;
+    t.w[0] = (1.f - t.wx) * (1.f - t.wy); t.w[1] = t.wx * (1.f - t.wy); t.w[2] = (1.f - t.wx) * t.wy; t.w[3] = t.wx * t.wy;
+    const bool c0 = ox0 && oy0, c1 = ox1 && oy0, c2 = ox0 && oy1, c3 = ox1 && oy1;
+    t.corner = c0 || c1 || c2 || c3;
+    t.norm = 1.0f;
+    if (t.corner) {   // three faces meet: the diagonal tap does not exist
+        if (c0) t.w[0] = 0.f; if (c1) t.w[1] = 0.f; if (c2) t.w[2] = 0.f; if (c3) t.w[3] = 0.f;
+        const float s = 1.0f / (t.w[0] + t.w[1] + t.w[2] + t.w[3]);
+        t.norm = s;
+        t.w[0] *= s; t.w[1] *= s; t.w[2] *= s; t.w[3] *= s;
+    }
+    t.idx[0] = c0 ? 0 : wrap_tap(f.face, x0, y0, res);
+    t.idx[1] = c1 ? 0 : wrap_tap(f.face, x0 + 1, y0, res);
+    t.idx[2] = c2 ? 0 : wrap_tap(f.face, x0, y0 + 1, res);
+    t.idx[3] = c3 ? 0 : wrap_tap(f.face, x0 + 1, y0 + 1, res);
+    return t;
+}
+
+// get_mip, scene/light.py:88-96 (n = number of specular levels); dlevel = d level / d roughness
+__device__ __forceinline__ float mip_level(const EnvMips& m, float r, float& dlevel)
+{
+    const float lo = m.min_roughness, hi = m.max_roughness;
+    const float n2 = (float)(m.n - 2);
+    if (r < hi) {
+        const float c = fminf(fmaxf(r, lo), hi);
+        dlevel = (r >= lo && r <= hi) ? n2 / (hi - lo) : 0.f;
+        return (c - lo) / (hi - lo) * n2;
+    }
+    const float c = fminf(fmaxf(r, hi), 1.0f);
+    dlevel = (r >= hi && r <= 1.0f) ? 1.0f / (1.0f - hi) : 0.f;
+    return (c - hi) / (1.0f - hi) + n2;
+}
+
+struct EnvSample { float L[3]; float dlev[3]; float du[2][3], dv[2][3]; int l0, l1; float f; bool lev_in; };
+
+// trilinear seamless cube fetch (pre-sigmoid); fills what the backward needs
+__device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, float level, bool use_mips, EnvSample& s, Taps tp[2])
+{
+    const int top = use_mips ? m.n - 1 : 0;
+    const float lc = fminf(fmaxf(level, 0.f), (float)top);
+    s.lev_in = level >= 0.f && level <= (float)top;
+    s.l0 = min((int)floorf(lc), top);
+    s.l1 = min(s.l0 + 1, top);
+    s.f = lc - (float)s.l0;
+    float v[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int l = k == 0 ? s.l0 : s.l1;
+        const int res = m.res[l];
+        tp[k] = cube_taps(fu, res);
+        const float* tex = m.tex[l];
+        float t[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) t[q][c] = tp[k].w[q] != 0.f ? tex[(size_t)tp[k].idx[q] * 3 + c] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            v[k][c] = tp[k].w[0] * t[0][c] + tp[k].w[1] * t[1][c] + tp[k].w[2] * t[2][c] + tp[k].w[3] * t[3][c];
+            // d value / d fx, d value / d fy (bilinear; the corner renormalisation is treated as constant)
+            s.du[k][c] = ((1.f - tp[k].wy) * (t[1][c] - t[0][c]) + tp[k].wy * (t[3][c] - t[2][c])) * 0.5f * (float)res * tp[k].norm;
+            s.dv[k][c] = ((1.f - tp[k].wx) * (t[2][c] - t[0][c]) + tp[k].wx * (t[3][c] - t[1][c])) * 0.5f * (float)res * tp[k].norm;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        s.L[c] = (1.f - s.f) * v[0][c] + s.f * v[1][c];
+        s.dlev[c] = (s.lev_in && s.l1 != s.l0) ? v[1][c] - v[0][c] : 0.f;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// gradient of the fetch: scatter to the texels, return d/d dir and d/d level
+__device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu, f3 dir, const EnvSample& s, const Taps tp[2],
+                                              const float gL[3], f3& g_dir, float& g_level)
+{
+    float gu = 0.f, gv = 0.f;
+    g_level = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float wk = k == 0 ? 1.f - s.f : s.f;
+        if (k == 1 && s.l1 == s.l0 && s.f == 0.f) continue;
+        float* gt = m.grad[k == 0 ? s.l0 : s.l1];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float g = gL[c] * wk;
+            gu += g * s.du[k][c];
+            gv += g * s.dv[k][c];
+            if (gt != nullptr && g != 0.f) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (tp[k].w[q] != 0.f) atomicAdd(gt + (size_t)tp[k].idx[q] * 3 + c, g * tp[k].w[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) g_level += gL[c] * s.dlev[c];
+    // (u, v) = (su * a, sv * b) / |major|  ->  d/d dir
+    float ga = gu * fu.inv_ma, gb = gv * fu.inv_ma;                       // w.r.t. the signed minor components
+    const float gm = -(gu * fu.u + gv * fu.v) * fu.sgn * fu.inv_ma;        // w.r.t. the major component
+    g_dir = mk(0.f, 0.f, 0.f);
+    switch (fu.face) {
+    case 0: g_dir = mk(gm, -gb, -ga); break;   // u = -z/|x|, v = -y/|x|
+    case 1: g_dir = mk(gm, -gb, ga); break;    // u = +z/|x|, v = -y/|x|
+    case 2: g_dir = mk(ga, gm, gb); break;     // u = +x/|y|, v = +z/|y|
+    case 3: g_dir = mk(ga, gm, -gb); break;    // u = +x/|y|, v = -z/|y|
+    case 4: g_dir = mk(ga, -gb, gm); break;    // u = +x/|z|, v = -y/|z|
+    default: g_dir = mk(-ga, -gb, gm); break;  // u = -x/|z|, v = -y/|z|
+    }
+    (void)dir;
+}
+
+// ---- standalone environment lookup ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) envmap_lookup_fwd_kernel(EnvMips m, long long N, const float* __restrict__ dirs,
+                                                                const float* __restrict__ roughness, float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const f3 d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    const FaceUV fu = dir_to_face(d);
+    float dl;
+    const bool use_mips = roughness != nullptr;
+    const float level = use_mips ? mip_level(m, roughness[i], dl) : 0.f;
+    EnvSample s;
+    Taps tp[2];
+    env_fetch(m, fu, level, use_mips, s, tp);
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[3 * i + c] = sigmoidf(s.L[c]);
+}
+
+__global__ void __launch_bounds__(256) envmap_lookup_bwd_kernel(EnvMips m, long long N, const float* __restrict__ dirs,
+                                                                const float* __restrict__ roughness, const float* __restrict__ g_out,
+                                                                float* __restrict__ g_dirs, float* __restrict__ g_rough)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const f3 d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    const FaceUV fu = dir_to_face(d);
+    float dl = 0.f;
+    const bool use_mips = roughness != nullptr;
+    const float level = use_mips ? mip_level(m, roughness[i], dl) : 0.f;
+    EnvSample s;
+    Taps tp[2];
+    env_fetch(m, fu, level, use_mips, s, tp);
+    float gL[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float y = sigmoidf(s.L[c]);
+        gL[c] = g_out[3 * i + c] * y * (1.f - y);
+    }
+    f3 gd;
+    float glev;
+    env_fetch_bwd(m, fu, d, s, tp, gL, gd, glev);
+    if (g_dirs) { g_dirs[3 * i] = gd.x; g_dirs[3 * i + 1] = gd.y; g_dirs[3 * i + 2] = gd.z; }
+    if (g_rough) g_rough[i] = use_mips ? glev * dl : 0.f;
+}
+
+// ---- fused deferred specular shading ---------------------------------------------------------------------
+struct ShadeCam { float Kinv[9]; const float* R; const float* T; };   // R: Camera.R (c2w rotation, [3,3]); T: w2c translation
+
+struct ShadePix {
+    f3 wo, n, r, rn;
+    float ndv, rlen, u, v, rough, refl, alpha;
+    float albedo[3], fg[2], dfg_du[2], dfg_dv[2];
+    bool u_in, v_in;
+};
+
+__device__ __forceinline__ void lut_fetch(const float* __restrict__ lut, int lres, float u, float v, float fg[2], float du[2], float dv[2])
+{
+    const float fx = u * (float)lres - 0.5f, fy = v * (float)lres - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int x0 = min(max((int)x0f, 0), lres - 1), x1 = min(max((int)x0f + 1, 0), lres - 1);
+    const int y0 = min(max((int)y0f, 0), lres - 1), y1 = min(max((int)y0f + 1, 0), lres - 1);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const float t00 = lut[((size_t)y0 * lres + x0) * 2 + c], t10 = lut[((size_t)y0 * lres + x1) * 2 + c];
+        const float t01 = lut[((size_t)y1 * lres + x0) * 2 + c], t11 = lut[((size_t)y1 * lres + x1) * 2 + c];
+        fg[c] = (1.f - wy) * ((1.f - wx) * t00 + wx * t10) + wy * ((1.f - wx) * t01 + wx * t11);
+        du[c] = ((1.f - wy) * (t10 - t00) + wy * (t11 - t01)) * (float)lres;
+        dv[c] = ((1.f - wx) * (t01 - t00) + wx * (t11 - t10)) * (float)lres;
+    }
+}
+
+__device__ __forceinline__ void shade_setup(const ShadeCam& cam, int x, int y, const Map& albedo, const Map& normal, const Map& alpha,
+                                            const Map& refl, const Map& rough, const float* __restrict__ lut, int lres, ShadePix& p)
+{
+    // sample_camera_rays (utils/refl_utils.py:54-73): pixel centres at integer coordinates
+    const float fx_ = (float)x, fy_ = (float)y;
+    const f3 pc = mk(cam.Kinv[0] * fx_ + cam.Kinv[1] * fy_ + cam.Kinv[2], cam.Kinv[3] * fx_ + cam.Kinv[4] * fy_ + cam.Kinv[5],
+                     cam.Kinv[6] * fx_ + cam.Kinv[7] * fy_ + cam.Kinv[8]);
+    // Camera.R is stored transposed (c2w); the reference re-transposes it: world = (pc - T) @ R^T^T ... = c2w * (pc - T)
+    const float* R = cam.R;
+    const f3 t = mk(cam.T[0], cam.T[1], cam.T[2]);
+    const f3 q = mk(pc.x - t.x, pc.y - t.y, pc.z - t.z);
+    const f3 pw = mk(R[0] * q.x + R[1] * q.y + R[2] * q.z, R[3] * q.x + R[4] * q.y + R[5] * q.z, R[6] * q.x + R[7] * q.y + R[8] * q.z);
+    const f3 ro = mk(-(R[0] * t.x + R[1] * t.y + R[2] * t.z), -(R[3] * t.x + R[4] * t.y + R[5] * t.z), -(R[6] * t.x + R[7] * t.y + R[8] * t.z));
+    f3 rd = mk(pw.x - ro.x, pw.y - ro.y, pw.z - ro.z);
+    const float inv = 1.0f / sqrtf(dot3(rd, rd));
+    rd = mk(rd.x * inv, rd.y * inv, rd.z * inv);
+    p.wo = mk(-rd.x, -rd.y, -rd.z);
+    const long long o = (long long)y * normal.sh + (long long)x * normal.sw;
+    p.n = mk(normal.p[o], normal.p[o + normal.sc], normal.p[o + 2 * normal.sc]);
+    p.ndv = dot3(p.wo, p.n);                                    // reflection(), :95-98
+    p.r = mk(2.f * p.n.x * p.ndv - p.wo.x, 2.f * p.n.y * p.ndv - p.wo.y, 2.f * p.n.z * p.ndv - p.wo.z);
+    p.rlen = fmaxf(sqrtf(dot3(p.r, p.r)), 1e-20f);              // safe_normalize
+    p.rn = mk(p.r.x / p.rlen, p.r.y / p.rlen, p.r.z / p.rlen);
+    p.rough = rough.p[(long long)y * rough.sh + (long long)x * rough.sw];
+    p.refl = refl.p[(long long)y * refl.sh + (long long)x * refl.sw];
+    p.alpha = alpha.p[(long long)y * alpha.sh + (long long)x * alpha.sw];
+    const long long oa = (long long)y * albedo.sh + (long long)x * albedo.sw;
+#pragma unroll
+    for (int c = 0; c < 3; c++) p.albedo[c] = albedo.p[oa + c * albedo.sc];
+    p.u_in = p.ndv >= 0.f && p.ndv <= 1.f;
+    p.v_in = p.rough >= 0.f && p.rough <= 1.f;
+    p.u = fminf(fmaxf(p.ndv, 0.f), 1.f);
+    p.v = fminf(fmaxf(p.rough, 0.f), 1.f);
+    lut_fetch(lut, lres, p.u, p.v, p.fg, p.dfg_du, p.dfg_dv);
+}
+
+__global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha,
+                                                                 Map refl, Map rough, const float* __restrict__ lut, int lres,
+                                                                 float* __restrict__ specular /*[3,H,W]*/, float* __restrict__ direct /*[3,H,W]*/,
+                                                                 float* __restrict__ weight /*[H,W,3]*/)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    ShadePix p;
+    shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
+    const FaceUV fu = dir_to_face(p.rn);
+    float dl;
+    const float level = mip_level(m, p.rough, dl);
+    EnvSample s;
+    Taps tp[2];
+    env_fetch(m, fu, level, true, s, tp);
+    const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float light = sigmoidf(s.L[c]);
+        const float wgt = (0.04f * (1.f - p.refl) + p.albedo[c] * p.refl) * p.fg[0] + p.fg[1];
+        direct[c * HW + pix] = light;
+        weight[pix * 3 + c] = wgt;
+        specular[c * HW + pix] = light * p.alpha * wgt;
+    }
+}
+
+__global__ void __launch_bounds__(256) shade_specular_bwd_kernel(EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha,
+                                                                 Map refl, Map rough, const float* __restrict__ lut, int lres,
+                                                                 const float* __restrict__ g_specular, const float* __restrict__ g_direct,
+                                                                 const float* __restrict__ g_weight, float* __restrict__ g_albedo /*[H,W,3]*/,
+                                                                 float* __restrict__ g_normal /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/,
+                                                                 float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    ShadePix p;
+    shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
+    const FaceUV fu = dir_to_face(p.rn);
+    float dl;
+    const float level = mip_level(m, p.rough, dl);
+    EnvSample s;
+    Taps tp[2];
+    env_fetch(m, fu, level, true, s, tp);
+    const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
+    float gL[3], ga = 0.f, gm = 0.f, gfg0 = 0.f, gfg1 = 0.f, galb[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float light = sigmoidf(s.L[c]);
+        const float base = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
+        const float wgt = base * p.fg[0] + p.fg[1];
+        const float gs = g_specular ? g_specular[c * HW + pix] : 0.f;
+        const float gd = (g_direct ? g_direct[c * HW + pix] : 0.f) + gs * p.alpha * wgt;
+        const float gw = (g_weight ? g_weight[pix * 3 + c] : 0.f) + gs * light * p.alpha;
+        ga += gs * light * wgt;
+        gL[c] = gd * light * (1.f - light);
+        galb[c] = gw * p.refl * p.fg[0];
+        gm += gw * (p.albedo[c] - 0.04f) * p.fg[0];
+        gfg0 += gw * base;
+        gfg1 += gw;
+    }
+    f3 g_rn;
+    float g_level;
+    env_fetch_bwd(m, fu, p.rn, s, tp, gL, g_rn, g_level);
+    // safe_normalize backward (the 1e-20 clamp never binds for finite normals)
+    const float rg = dot3(p.rn, g_rn);
+    const f3 g_r = mk((g_rn.x - p.rn.x * rg) / p.rlen, (g_rn.y - p.rn.y * rg) / p.rlen, (g_rn.z - p.rn.z * rg) / p.rlen);
+    // r = 2 n (n.wo) - wo ; NdotV = n.wo feeds the LUT's u coordinate
+    const float g_ndv = p.u_in ? gfg0 * p.dfg_du[0] + gfg1 * p.dfg_du[1] : 0.f;
+    const float grn = dot3(g_r, p.n);
+    const f3 gn = mk(2.f * p.ndv * g_r.x + (2.f * grn + g_ndv) * p.wo.x, 2.f * p.ndv * g_r.y + (2.f * grn + g_ndv) * p.wo.y,
+                     2.f * p.ndv * g_r.z + (2.f * grn + g_ndv) * p.wo.z);
+    const float g_rough_v = (p.v_in ? gfg0 * p.dfg_dv[0] + gfg1 * p.dfg_dv[1] : 0.f) + g_level * dl;
+    g_normal[pix * 3] = gn.x; g_normal[pix * 3 + 1] = gn.y; g_normal[pix * 3 + 2] = gn.z;
+#pragma unroll
+    for (int c = 0; c < 3; c++) g_albedo[pix * 3 + c] = galb[c];
+    g_alpha[pix] = ga;
+    g_refl[pix] = gm;
+    g_rough[pix] = g_rough_v;
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------
+static int make_mips(const MrgsEnvMips* in, EnvMips& m)
+{
+    if (!in || in->n_levels < 1 || in->n_levels > MRGS_MAX_MIPS) return MRGS_E_BAD_ARG;
+    m.n = in->n_levels;
+    for (int i = 0; i < MRGS_MAX_MIPS; i++) {
+        m.res[i] = i < m.n ? in->res[i] : 0;
+        m.tex[i] = i < m.n ? in->tex[i] : nullptr;
+        m.grad[i] = i < m.n ? in->grad[i] : nullptr;
+        if (i < m.n && (!m.tex[i] || m.res[i] < 1)) return MRGS_E_BAD_ARG;
+    }
+    m.min_roughness = in->min_roughness;
+    m.max_roughness = in->max_roughness;
+    return MRGS_OK;
+}
+static Map to_map(const MrgsStridedMap& s) { Map r = {s.ptr, s.stride_h, s.stride_w, s.stride_c}; return r; }
+
+extern "C" {
+
+int mrgs_envmap_lookup_forward(const MrgsEnvMips* mips, int64_t N, const float* dirs, const float* roughness, float* out, void* stream)
+{
+    EnvMips m;
+    int rc = make_mips(mips, m);
+    if (rc) return rc;
+    if (N < 0 || (N > 0 && (!dirs || !out))) return MRGS_E_BAD_ARG;
+    if (N == 0) return MRGS_OK;
+    hipLaunchKernelGGL(envmap_lookup_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m, (long long)N, dirs,
+                       roughness, out);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_envmap_lookup_backward(const MrgsEnvMips* mips, int64_t N, const float* dirs, const float* roughness, const float* g_out,
+                                float* g_dirs, float* g_roughness, void* stream)
+{
+    EnvMips m;
+    int rc = make_mips(mips, m);
+    if (rc) return rc;
+    if (N < 0 || (N > 0 && (!dirs || !g_out))) return MRGS_E_BAD_ARG;
+    if (N == 0) return MRGS_OK;
+    hipLaunchKernelGGL(envmap_lookup_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m, (long long)N, dirs,
+                       roughness, g_out, g_dirs, g_roughness);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, float* specular, float* direct_light, float* specular_weight,
+                                void* stream)
+{
+    EnvMips m;
+    int rc = make_mips(mips, m);
+    if (rc) return rc;
+    if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || fr->lut_res < 1 || !specular || !direct_light || !specular_weight)
+        return MRGS_E_BAD_ARG;
+    ShadeCam cam;
+    for (int i = 0; i < 9; i++) cam.Kinv[i] = fr->Kinv[i];
+    cam.R = fr->R; cam.T = fr->T;
+    const dim3 grid((fr->W + 63) / 64, (fr->H + 3) / 4), block(256);
+    hipLaunchKernelGGL(shade_specular_fwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
+                       to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, specular, direct_light, specular_weight);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
+                                 const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
+                                 float* g_roughness, void* stream)
+{
+    EnvMips m;
+    int rc = make_mips(mips, m);
+    if (rc) return rc;
+    if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || !g_albedo || !g_normal || !g_alpha || !g_refl || !g_roughness)
+        return MRGS_E_BAD_ARG;
+    ShadeCam cam;
+    for (int i = 0; i < 9; i++) cam.Kinv[i] = fr->Kinv[i];
+    cam.R = fr->R; cam.T = fr->T;
+    const dim3 grid((fr->W + 63) / 64, (fr->H + 3) / 4), block(256);
+    hipLaunchKernelGGL(shade_specular_bwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
+                       to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, g_specular, g_direct_light,
+                       g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+}   // extern "C"

@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's render functions for the hot path (appendix C).
+
+  compute_2dgs_normal_and_regularizations <-> gaussian_renderer/__init__.py:42-90 ("2dgs" flavour: 7-channel allmap)
+  depths_to_points / depth_to_normal      <-> utils/point_utils.py:9-37
+  render_initial                          <-> gaussian_renderer/__init__.py:94-220
+  render_surfel                           <-> gaussian_renderer/__init__.py:225-483 (SH-indirect branch, opt.indirect = False)
+
+Same arguments (`viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt, ...`) and the same output
+dictionary keys.  `pc` is anything exposing the GaussianModel getters the functions read (scene/gaussian_model.py:236-347);
+`SurfelModel` below is a minimal container with the reference's activations for tests and benchmarks -- the optimizer,
+densification and I/O of GaussianModel are out of scope.
+Rasterization and shading run in libmrgs.so; the per-gaussian and per-map glue stays in torch as in the reference.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .shading import EnvLight, get_specular_color_surfel
+
+
+class SurfelModel:
+    """The subset of scene/gaussian_model.py:GaussianModel that render_* reads: raw parameters + activated getters."""
+
+    def __init__(self, xyz, scaling, rotation, opacity, features_dc, features_rest, refl_strength=None, roughness=None,
+                 ori_color=None, indirect_dc=None, indirect_rest=None, envmap=None, active_sh_degree=3, max_sh_degree=3):
+        P, dev = xyz.shape[0], xyz.device
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self._xyz, self._scaling, self._rotation, self._opacity = xyz, scaling, rotation, opacity
+        self._features_dc, self._features_rest = features_dc, features_rest
+        self._refl_strength = refl_strength if refl_strength is not None else z(P, 1)
+        self._roughness = roughness if roughness is not None else z(P, 1)
+        self._ori_color = ori_color if ori_color is not None else z(P, 3)
+        self._indirect_dc = indirect_dc if indirect_dc is not None else z(P, 1, 3)
+        self._indirect_rest = indirect_rest if indirect_rest is not None else z(P, 15, 3)
+        self.env_map = envmap
+        self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
+        self.ray_tracer = None
+
+    def parameters(self):
+        return [self._xyz, self._scaling, self._rotation, self._opacity, self._features_dc, self._features_rest, self._refl_strength,
+                self._roughness, self._ori_color, self._indirect_dc, self._indirect_rest]
+
+    # activations: gaussian_model.py:56-78
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_refl = property(lambda s: torch.sigmoid(s._refl_strength))
+    get_rough = property(lambda s: torch.sigmoid(s._roughness))
+    get_ori_color = property(lambda s: torch.sigmoid(s._ori_color))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    get_indirect = property(lambda s: torch.cat((s._indirect_dc, s._indirect_rest), dim=1))
+    get_envmap = property(lambda s: s.env_map)
+
+    def get_normal(self, scaling_modifier, dir_pp_normalized):
+        """gaussian_model.py:269-285 (return_delta=False): third column of R(q), flipped to face the viewer."""
+        s3 = torch.cat([self.get_scaling * scaling_modifier, torch.ones_like(self.get_scaling[:, :1])], dim=-1)
+        RS = build_scaling_rotation(s3, self._rotation)          # [P,3,3]; columns = scaled axes
+        normals_raw = RS[:, :, 2]
+        normals_raw, _ = flip_align_view(normals_raw, dir_pp_normalized)
+        return safe_normalize(normals_raw)
+
+
+def depths_to_points(view, depthmap):
+    """utils/point_utils.py:9-24 (note: this back-projection uses W/2, H/2 pixel offsets, not (W-1)/2)."""
+    dev = depthmap.device
+    c2w = (view.world_view_transform.T).inverse()
+    W, H = view.image_width, view.image_height
+    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32, device=dev).T
+    projection_matrix = c2w.T @ view.full_proj_transform
+    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
+    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(), indexing="xy")
+    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
+    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3]
+    return depthmap.reshape(-1, 1) * rays_d + rays_o
+
+
+def depth_to_normal(view, depth):
+    """utils/point_utils.py:26-37: finite differences of the back-projected points; border pixels stay zero."""
+    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
+    output = torch.zeros_like(points)
+    dx = points[2:, 1:-1] - points[:-2, 1:-1]
+    dy = points[1:-1, 2:] - points[1:-1, :-2]
+    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return output
+
+
+def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=True):
+    """gaussian_renderer/__init__.py:42-90."""
+    render_alpha = allmap[1:2]
+    render_normal = allmap[2:5]
+    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
+    render_dist = allmap[6:7]
+    surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + pipe.depth_ratio * render_depth_median
+    if return_depth_normal:
+        surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
+        surf_normal = surf_normal * render_alpha.detach()
+    else:
+        surf_normal = None
+    return {"render_alpha": render_alpha, "render_normal": render_normal, "render_depth_median": render_depth_median,
+            "render_depth_expected": render_depth_expected, "render_dist": render_dist, "surf_depth": surf_depth,
+            "surf_normal": surf_normal}
+
+
+def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=torch.zeros_like(bg_color),                      # the rasterizer always composites over black (__init__.py:247)
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=getattr(pipe, "debug", False))
+
+
+def _screenspace_points(pc):
+    sp = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
+    try:
+        sp.retain_grad()
+    except Exception:
+        pass
+    return sp
+
+
+def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None):
+    """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour)."""
+    means2D = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
+    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
+        means3D=pc.get_xyz, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=None, opacities=pc.get_opacity,
+        scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe)
+    final_image = rendered_image
+    if srgb:
+        final_image = linear_to_srgb(final_image)
+    final_image = final_image + bg_color[:, None, None] * (1 - reg["render_alpha"])
+    return {"render": final_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+            "rend_alpha": reg["render_alpha"], "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"],
+            "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+
+
+def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None,
+                  wo_render_img=False, normal_img_map=None):
+    """gaussian_renderer/__init__.py:225-483: per-gaussian material channels (S = 8: refl 1, roughness 1, albedo 3, indirect 3)
+    blended by the rasterizer, then deferred split-sum shading."""
+    if opt is None:
+        opt = SimpleNamespace(indirect=False)
+    if getattr(opt, "indirect", False):
+        raise NotImplementedError("opt.indirect needs the mesh ray tracer (SURVEY.md section 8f-2)")
+    means2D = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
+    means3D = pc.get_xyz
+    refl, ori_color, roughness = pc.get_refl, pc.get_ori_color, pc.get_rough
+    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+
+    # per-gaussian indirect radiance along the mirror direction (__init__.py:338-346)
+    dir_pp = means3D - viewpoint_camera.camera_center
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
+    w_o = -dir_pp_normalized
+    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
+    shs_indirect = pc.get_indirect.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
+    features = torch.cat((refl, roughness, ori_color, indirect), dim=-1)          # "2dgs" flavour: S = 8
+
+    contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=pc.get_opacity,
+        scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
+
+    base_color = rendered_image
+    refl_strength, roughness_map = rendered_features[:1], rendered_features[1:2]
+    albedo, indirect_light = rendered_features[2:5], rendered_features[5:8]
+
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img))
+    render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
+    geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
+           "rend_normal": render_normal, "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if wo_render_img:
+        return {"refl_strength_map": refl_strength, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
+
+    normal_map = render_normal.permute(1, 2, 0)
+    normal_map = normal_map / render_alpha.permute(1, 2, 0).clamp_min(1e-6)
+    specular, extra_dict = get_specular_color_surfel(
+        pc.get_envmap, albedo.permute(1, 2, 0), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, normal_map,
+        render_alpha.permute(1, 2, 0), refl_strength=refl_strength.permute(1, 2, 0), roughness=roughness_map.permute(1, 2, 0), pc=pc,
+        surf_depth=reg["surf_depth"])
+    final_image = (1 - refl_strength) * base_color + specular
+    if srgb:
+        final_image = linear_to_srgb(final_image)
+        albedo = linear_to_srgb(albedo)
+        specular = linear_to_srgb(specular)
+    final_image = final_image + bg_color[:, None, None] * (1 - render_alpha)
+    return {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": (1 - refl_strength) * base_color,
+            "diffuse_map_ori": base_color, "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo}

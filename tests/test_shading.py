@@ -1,0 +1,228 @@
+"""Shading half of the hot path: oracle known-answer tests on CPU, HIP-vs-oracle parity on the GPU.
+The nvdiffrast sampling rules are restated (parity unpinned, see oracle/shading_oracle.py); the cube face convention is
+pinned by the reference's cube_to_dir through the texel-centre known-answer test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shading_oracle as so
+
+
+def make_mips(seed=0, max_res=32, min_res=4, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    mips = [torch.randn(6, max_res, max_res, 3, generator=g) * scale]
+    while mips[-1].shape[1] > min_res:
+        mips.append(torch.nn.functional.avg_pool2d(mips[-1].permute(0, 3, 1, 2), (2, 2)).permute(0, 2, 3, 1).contiguous())
+    return mips
+
+
+def texel_centre_dirs(res):
+    dirs, vals = [], []
+    lin = torch.linspace(-1.0 + 1.0 / res, 1.0 - 1.0 / res, res)
+    gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+    for s in range(6):
+        dirs.append(so.cube_to_dir(s, gx, gy).reshape(-1, 3))
+    return torch.cat(dirs, 0)
+
+
+def test_oracle_cube_lookup_known_answer_at_texel_centres():
+    """scene/light_utils.py:24-31 pins the convention: a lookup at cube_to_dir(texel centre) returns that texel exactly."""
+    tex = make_mips(1, 16, 16)[0]
+    d = texel_centre_dirs(16)
+    out = so.cube_fetch(tex, d)
+    np.testing.assert_allclose(out.numpy(), tex.reshape(-1, 3).numpy(), rtol=0, atol=1e-5)
+    out2 = so.cube_fetch(tex, d * 3.7)     # un-normalised directions address the same texel
+    np.testing.assert_allclose(out2.numpy(), tex.reshape(-1, 3).numpy(), rtol=0, atol=1e-5)
+
+
+def test_oracle_cube_lookup_is_seamless():
+    """Approaching a cube edge from both faces gives the same value (continuity across faces and at corners)."""
+    tex = make_mips(2, 8, 8)[0]
+    g = torch.Generator().manual_seed(5)
+    t = torch.rand(200, generator=g) * 1.8 - 0.9
+    eps = 1e-4
+    a = torch.stack([torch.ones_like(t), t, torch.full_like(t, 1.0 - eps)], -1)   # on face +x next to the +z edge
+    b = torch.stack([torch.full_like(t, 1.0 - eps), t, torch.ones_like(t)], -1)   # on face +z next to the +x edge
+    np.testing.assert_allclose(so.cube_fetch(tex, a).numpy(), so.cube_fetch(tex, b).numpy(), atol=5e-3)
+    c = torch.tensor([[1.0, 1.0 - eps, 1.0 - 2 * eps], [1.0 - eps, 1.0, 1.0 - 2 * eps], [1.0 - 2 * eps, 1.0 - eps, 1.0]])
+    v = so.cube_fetch(tex, c).numpy()
+    assert np.abs(v - v[0]).max() < 5e-3
+
+
+def test_oracle_get_mip_and_trilinear():
+    n = 4
+    r = torch.tensor([0.0, 0.08, 0.29, 0.5, 0.75, 1.0, 1.3])
+    expect = torch.tensor([0.0, 0.0, (0.29 - 0.08) / 0.42 * 2, 2.0, 2.5, 3.0, 3.0])
+    np.testing.assert_allclose(so.get_mip(r, n).numpy(), expect.numpy(), atol=1e-6)
+    mips = make_mips(3, 32, 4)
+    d = torch.nn.functional.normalize(torch.randn(50, 3, generator=torch.Generator().manual_seed(1)), dim=-1)
+    # roughness 0.08 -> level 0 exactly, 1.0 -> last level exactly
+    lo = so.env_lookup(mips, d, torch.full((50,), 0.08))
+    hi = so.env_lookup(mips, d, torch.full((50,), 1.0))
+    np.testing.assert_allclose(lo.numpy(), torch.sigmoid(so.cube_fetch(mips[0], d)).numpy(), atol=1e-6)
+    np.testing.assert_allclose(hi.numpy(), torch.sigmoid(so.cube_fetch(mips[-1], d)).numpy(), atol=1e-6)
+
+
+def test_oracle_lut_known_answer():
+    lut = torch.rand(16, 16, 2, generator=torch.Generator().manual_seed(2))
+    c = (torch.arange(16).float() + 0.5) / 16
+    uu, vv = torch.meshgrid(c, c, indexing="xy")
+    out = so.lut_fetch(lut, torch.stack([uu.reshape(-1), vv.reshape(-1)], -1)).reshape(16, 16, 2)
+    np.testing.assert_allclose(out.numpy(), lut.numpy(), atol=1e-6)
+    edge = so.lut_fetch(lut, torch.tensor([[0.0, 0.0], [1.0, 1.0]]))          # clamp boundary
+    np.testing.assert_allclose(edge.numpy(), torch.stack([lut[0, 0], lut[15, 15]]).numpy(), atol=1e-6)
+
+
+def test_fg_lut_asset_matches_schlick_row():
+    """Row v = 0 of the generated split-sum table is analytic: roughness -> 0 gives (1 - (1-c)^5, (1-c)^5)."""
+    import os
+    lut = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "materialrefgs_amd", "assets", "fg_lut_256.npy"))
+    assert lut.shape == (256, 256, 2) and lut.dtype == np.float32
+    c = (np.arange(256) + 0.5) / 256
+    np.testing.assert_allclose(lut[0, :, 1], (1 - c) ** 5, atol=2e-3)
+    np.testing.assert_allclose(lut[0, :, 0], 1 - (1 - c) ** 5, atol=2e-3)
+    # the two reference probe texels quoted in SURVEY.md (2a #23): [y=0,x=0] and [y=255,x=255]
+    np.testing.assert_allclose(lut[0, 0], [0.0097, 0.990], atol=2e-3)
+    np.testing.assert_allclose(lut[255, 255], [0.309, 3.5e-5], atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU parity
+# ---------------------------------------------------------------------------------------------------------------------
+def _frame(H=40, W=56, seed=0):
+    from materialrefgs_amd.synthetic import orbit_camera
+    g = torch.Generator().manual_seed(seed)
+    cam = orbit_camera(seed % 8, H, W)
+    albedo = torch.rand(H, W, 3, generator=g)
+    normal = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1) * (0.7 + 0.6 * torch.rand(H, W, 1, generator=g))
+    alpha = torch.rand(H, W, 1, generator=g)
+    refl = torch.rand(H, W, 1, generator=g)
+    rough = torch.rand(H, W, 1, generator=g) * 1.1 - 0.05       # a few values outside [0,1] exercise the clamps
+    return cam, albedo, normal, alpha, refl, rough
+
+
+@pytest.mark.gpu
+def test_envmap_lookup_parity(gpu_device):
+    from materialrefgs_amd.shading import EnvLight
+    mips = make_mips(4, 32, 4)
+    env = EnvLight(device=gpu_device, min_res=4, max_res=32, trainable=True)
+    with torch.no_grad():
+        env.base.copy_(mips[0])
+    env.build_mips()
+    g = torch.Generator().manual_seed(9)
+    N = 5000
+    d = torch.randn(N, 3, generator=g)
+    d[:384] = texel_centre_dirs(8) * 2.0                 # includes exact face-centre / edge-adjacent directions
+    d[600:650, 0] = 1.0; d[600:650, 2] = 0.999                 # near a cube edge
+    d[384:] = torch.nn.functional.normalize(d[384:], dim=-1)   # unit directions, as the shading code passes them
+    rough = torch.rand(N, generator=g) * 1.2 - 0.1
+    # forward + known answer on the GPU
+    kat = env(texel_centre_dirs(32).to(gpu_device), mode="pure_env")
+    np.testing.assert_allclose(kat.detach().cpu().numpy(), torch.sigmoid(mips[0].reshape(-1, 3)).numpy(), atol=2e-6)
+    for use_rough in (True, False):
+        base_o = mips[0].clone().requires_grad_(True)
+        mips_o = [base_o]
+        while mips_o[-1].shape[1] > 4:
+            mips_o.append(torch.nn.functional.avg_pool2d(mips_o[-1].permute(0, 3, 1, 2), (2, 2)).permute(0, 2, 3, 1))
+        d_o, r_o = d.clone().requires_grad_(True), rough.clone().requires_grad_(True)
+        out_o = so.env_lookup(mips_o, d_o, r_o if use_rough else None)
+        d_h, r_h = d.to(gpu_device).requires_grad_(True), rough.to(gpu_device).requires_grad_(True)
+        env.base.grad = None
+        env.build_mips()
+        out_h = env(d_h, roughness=r_h) if use_rough else env(d_h, mode="pure_env")
+        np.testing.assert_allclose(out_h.detach().cpu().numpy(), out_o.detach().numpy(), atol=3e-6)
+        gout = torch.randn(N, 3, generator=torch.Generator().manual_seed(3))
+        out_o.backward(gout)
+        out_h.backward(gout.to(gpu_device))
+        np.testing.assert_allclose(env.base.grad.cpu().numpy(), base_o.grad.numpy(), atol=2e-5 * float(base_o.grad.abs().max()))
+        # rows 0..383 sit exactly on texel centres, where the bilinear derivative is one-sided (left/right cell chosen by the
+        # last ulp of fx): compare the direction gradient on the generic directions only
+        gd_h, gd_o = d_h.grad.cpu().numpy()[384:], d_o.grad.numpy()[384:]
+        bad = np.abs(gd_h - gd_o).max(axis=1) > 1e-4 * np.abs(gd_o).max()
+        assert not bad.any(), (np.nonzero(bad)[0][:10] + 384, d[384:][bad][:5], gd_h[bad][:5], gd_o[bad][:5])
+        if use_rough:
+            assert np.abs(r_h.grad.cpu().numpy() - r_o.grad.numpy()).max() <= 1e-4 * float(r_o.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_shade_specular_parity(gpu_device):
+    from materialrefgs_amd.shading import EnvLight, get_specular_color_surfel, load_fg_lut
+    cam, albedo, normal, alpha, refl, rough = _frame(40, 56, 3)
+    H, W, K = cam.HWK
+    mips = make_mips(7, 32, 4)
+    lut = load_fg_lut("cpu")
+    # ---- oracle
+    leaves_o = [t.clone().requires_grad_(True) for t in (albedo, normal, alpha, refl, rough)]
+    base_o = mips[0].clone().requires_grad_(True)
+    mips_o = [base_o]
+    while mips_o[-1].shape[1] > 4:
+        mips_o.append(torch.nn.functional.avg_pool2d(mips_o[-1].permute(0, 3, 1, 2), (2, 2)).permute(0, 2, 3, 1))
+    spec_o, direct_o, weight_o = so.specular_color_surfel(mips_o, lut, leaves_o[0], H, W, K, cam.R, cam.T, leaves_o[1], leaves_o[2],
+                                                          leaves_o[3], leaves_o[4])
+    # ---- HIP (strided inputs: channel-first tensors permuted to HWC, as render_surfel passes them)
+    env = EnvLight(device=gpu_device, min_res=4, max_res=32, trainable=True)
+    with torch.no_grad():
+        env.base.copy_(mips[0])
+    env.build_mips()
+    chw = [t.permute(2, 0, 1).contiguous().to(gpu_device).requires_grad_(True) for t in (albedo, normal, alpha, refl, rough)]
+    hwc = [t.permute(1, 2, 0) for t in chw]
+    camd = cam.to(gpu_device)
+    spec_h, extra = get_specular_color_surfel(env, hwc[0], cam.HWK, camd.R, camd.T, hwc[1], hwc[2], refl_strength=hwc[3], roughness=hwc[4])
+    tol = lambda ref: 1e-5 * max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(spec_h.detach().cpu().numpy(), spec_o.detach().numpy(), atol=tol(spec_o))
+    np.testing.assert_allclose(extra["direct_light"].detach().cpu().numpy(), direct_o.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(extra["specular_weight"].detach().cpu().numpy(), weight_o.detach().numpy(), atol=tol(weight_o))
+    # ---- gradients (all three outputs feed the loss)
+    g = torch.Generator().manual_seed(11)
+    gs, gd, gw = torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g), torch.randn(H, W, 3, generator=g)
+    (spec_o * gs).sum().add((direct_o * gd).sum()).add((weight_o * gw).sum()).backward()
+    torch.autograd.backward([spec_h, extra["direct_light"], extra["specular_weight"]], [gs.to(gpu_device), gd.to(gpu_device), gw.to(gpu_device)])
+    for name, th, to in zip(("albedo", "normal", "alpha", "refl", "rough"), chw, leaves_o):
+        a, b = th.grad.permute(1, 2, 0).cpu().numpy(), to.grad.numpy()
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max(), (name, np.abs(a - b).max(), np.abs(b).max())
+    a, b = env.base.grad.cpu().numpy(), base_o.grad.numpy()
+    assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+
+
+@pytest.mark.gpu
+def test_render_surfel_end_to_end(gpu_device):
+    """The reference-shaped render functions run on the HIP path and produce the reference's dictionary keys; gradients reach
+    every parameter group including the environment cubemap."""
+    from types import SimpleNamespace
+    from materialrefgs_amd.renderer import SurfelModel, render_initial, render_surfel
+    from materialrefgs_amd.shading import EnvLight
+    from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera
+    P, H, W = 3000, 96, 128
+    sc = make_shell_scene(P, S=0, seed=1, radius_px=6.0, image_size=128).to(gpu_device)
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(gpu_device)
+    env = EnvLight(device=gpu_device, trainable=True)
+    with torch.no_grad():
+        env.base.copy_(rnd(6, 128, 128, 3))
+    env.build_mips()
+    inv_sig = lambda x: torch.log(x / (1 - x))
+    pc = SurfelModel(sc.means3D.clone(), torch.log(sc.scales), sc.rotations.clone(), inv_sig(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                     sc.shs[:, :1].clone(), sc.shs[:, 1:].clone(), refl_strength=rnd(P, 1), roughness=rnd(P, 1), ori_color=rnd(P, 3),
+                     indirect_dc=rnd(P, 1, 3) * 0.1, indirect_rest=rnd(P, 15, 3) * 0.01, envmap=env)
+    for t in pc.parameters():
+        t.requires_grad_(True)
+    cam = orbit_camera(1, H, W).to(gpu_device)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    out = render_surfel(cam, pc, pipe, bg, srgb=True, opt=SimpleNamespace(indirect=False))
+    for k in ("render", "refl_strength_map", "diffuse_map", "diffuse_map_ori", "specular_map", "base_color_map", "roughness_map",
+              "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal"):
+        assert k in out, k
+    assert out["render"].shape == (3, H, W) and torch.isfinite(out["render"]).all()
+    loss = out["render"].mean() + 0.1 * out["rend_dist"].mean() + 0.1 * (out["rend_normal"] * out["surf_normal"]).sum(0).mean()
+    loss.backward()
+    for t in pc.parameters():
+        assert t.grad is not None and torch.isfinite(t.grad).all()
+    assert env.base.grad is not None and float(env.base.grad.abs().sum()) > 0
+    assert out["viewspace_points"].grad is not None and out["viewspace_points"].grad.shape == (P, 3)
+    ini = render_initial(cam, pc, pipe, bg)
+    assert ini["render"].shape == (3, H, W) and set(("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal")) <= set(ini)
+    wo = render_surfel(cam, pc, pipe, bg, wo_render_img=True)
+    assert "render" not in wo and wo["surf_normal"] is None and "base_color_map" in wo
