@@ -28,6 +28,9 @@ WORKLOADS = {
     # name: (P, H, W, S, description)
     "C2": (300000, 800, 800, 0, "C2 shell scene: P=300000 surfels, 800x800, SH deg 3, S=0 (diffuse-only surfel raster), fwd+bwd"),
     "C3": (300000, 800, 800, 8, "C3 shell scene: P=300000 surfels, 800x800, SH deg 3, S=8 material channels, fwd+bwd"),
+    # BASELINE.json configs[2]: the full render_surfel path = per-gaussian material features -> rasterizer (S=8) -> 2DGS map
+    # post-processing -> deferred split-sum shading (FG LUT + 5-level 128^2 cubemap) -> compositing, forward and backward
+    "C3full": (300000, 800, 800, 8, "C3 shell scene through render_surfel: P=300000, 800x800, S=8 + deferred BRDF shading, fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
 }
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -64,6 +67,7 @@ def main():
 
     from materialrefgs_amd import _lib
     from materialrefgs_amd._lib import MrgsKernelTimes
+    from materialrefgs_amd import rasterizer as rasterizer_mod
     from materialrefgs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera, upstream_grads
     L = _lib.lib()
@@ -81,6 +85,27 @@ def main():
             debug=False))
     g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
 
+    surfel_mode = args.workload == "C3full"
+    if surfel_mode:
+        from types import SimpleNamespace
+        from materialrefgs_amd.renderer import SurfelModel, render_surfel
+        from materialrefgs_amd.shading import EnvLight
+        gen = torch.Generator().manual_seed(0)
+        rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
+        env = EnvLight(device=dev, trainable=True)
+        with torch.no_grad():
+            env.base.copy_(rnd(6, 128, 128, 3))
+        inv_sig = lambda x: torch.log(x / (1 - x))
+        pc = SurfelModel(scene.means3D.clone(), torch.log(scene.scales), scene.rotations.clone(),
+                         inv_sig(scene.opacities.clamp(1e-4, 1 - 1e-4)), scene.shs[:, :1].clone(), scene.shs[:, 1:].clone(),
+                         refl_strength=rnd(P, 1), roughness=rnd(P, 1), ori_color=rnd(P, 3), indirect_dc=rnd(P, 1, 3) * 0.1,
+                         indirect_rest=rnd(P, 15, 3) * 0.01, envmap=env)
+        surfel_params = pc.parameters() + [env.base]
+        for t_ in surfel_params:
+            t_.requires_grad_(True)
+        pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+        bg_color = torch.zeros(3, device=dev)
+        cams_dev = [c.to(dev) for c in cams]
     params = {"means3D": scene.means3D, "opacity": scene.opacities, "scales": scene.scales, "rotations": scene.rotations,
               "sh": scene.shs}
     if S > 0:
@@ -91,7 +116,24 @@ def main():
     bucket = mdist.GradBucket([params[k].shape for k in params] + [means2D.shape], dev) if world > 1 else None
     state = {"R": 0}
 
+    surfel_bucket = mdist.GradBucket([t_.shape for t_ in surfel_params], dev) if (surfel_mode and world > 1) else None
+
+    def step_surfel(i):
+        view = (i * world + rank) % len(settings)
+        for t_ in surfel_params:
+            t_.grad = None
+        env.build_mips()                                       # every iteration in the reference (train_refnerf.py:1157-1163)
+        out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
+        state["R"] = rasterizer_mod.LAST_NUM_RENDERED
+        # the maps calculate_loss consumes (utils/loss_utils.py:147-152,166), with fixed upstream gradients
+        outs = [out["render"], out["rend_alpha"], out["rend_normal"], out["rend_dist"], out["surf_depth"], out["surf_normal"]]
+        torch.autograd.backward(outs, [torch.ones_like(outs[0])] + [torch.full_like(o, 0.1) for o in outs[1:]])
+        if world > 1:
+            mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])
+
     def step(i):
+        if surfel_mode:
+            return step_surfel(i)
         view = (i * world + rank) % len(settings)
         for t in list(params.values()) + [means2D]:
             t.grad = None
@@ -161,7 +203,9 @@ def main():
                            "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(dom_ms, 4)}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
 
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and surfel_mode:
+            out["cpu_baseline"] = None   # the C oracle covers the rasterizer only; use --workload C3 for its CPU baseline
+        elif not args.no_cpu_baseline:
             from oracle import raster_oracle as ro
             cam = cams[0]
             t = time.perf_counter()

@@ -17,6 +17,9 @@ from . import _lib
 from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
 
 
+LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (bench.py reads it for the roofline figure)
+
+
 def cpu_deep_copy_tuple(input_tuple):
     copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
     return tuple(copied_tensors)
@@ -74,6 +77,8 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         _lib.check(L.mrgs_rasterize_forward_geom(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(radii),
                                                  ctypes.byref(R), st))
         num_rendered = int(R.value)
+        global LAST_NUM_RENDERED
+        LAST_NUM_RENDERED = num_rendered
         binning = torch.empty((L.mrgs_binning_bytes(num_rendered),), dtype=torch.uint8, device=dev)
         _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
                                                    _ptr(img), num_rendered, _ptr(color), _ptr(feature), _ptr(others), st))
