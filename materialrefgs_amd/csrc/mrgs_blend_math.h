@@ -72,14 +72,46 @@ __device__ __forceinline__ void mrgs_block_pixel(int block_x, int block_y, int l
     pyi = block_y * 8 + (lane >> 3);
 }
 
-// Conservative screen-space bound of the region where a surfel can reach alpha >= 1/255 (record float4 #5 =
-// centre.xy, half-extent.xy, written by preprocess): the axis-aligned box that contains both the level set
-// rho3d <= tau and the low-pass disc rho2d <= tau, tau = 2 ln(255 opacity), padded for rounding.  A surfel is
-// skipped for a whole 8x8 block only when the block misses that box, i.e. when every lane would have failed the
-// alpha test anyway -- exact per-pixel results are unaffected.
-__device__ __forceinline__ bool mrgs_block_may_touch(const float4 bound, float bcx, float bcy)
+// Block-level cull (record float4 #5, #6, written by preprocess).  A surfel can reach alpha >= 1/255 only inside the
+// ellipse d^T [[A,B],[B,C]] d <= 1 around (ex, ey) -- the exact pixel-space level set rho3d <= tau, tau = 2 ln(255 opacity)
+// -- or inside the low-pass disc of radius r around mean2D.  A surfel is skipped for a whole pixel block only when the
+// block's rectangle of pixel centres misses both, i.e. when every lane would have failed the alpha test anyway: exact
+// per-pixel results are unaffected.  The minimum of the (convex) quadratic over the rectangle is taken on its four edges
+// unless the centre lies inside; A = B = C = 0 encodes "not an ellipse, always a candidate".
+struct CullConic { float4 a, b; };
+__device__ __forceinline__ float mrgs_edge_min(float qa, float qb, float qc, float X, float lo, float hi)
+{   // min over t in [lo,hi] of qa X^2 + 2 qb X t + qc t^2
+    const float t = fminf(fmaxf(-qb * X * mrgs_rcp(qc), lo), hi);   // NaN (qc = 0) falls back to lo
+    return fmaf(qa * X, X, fmaf(2.0f * qb * X, t, qc * t * t));
+}
+__device__ __forceinline__ bool mrgs_block_may_touch(const CullConic& c, float x0, float y0, float w, float h)
 {
-    return (fabsf(bound.x - bcx) <= bound.z + 3.5f) && (fabsf(bound.y - bcy) <= bound.w + 3.5f);
+    const float dx0 = x0 - c.a.x, dx1 = dx0 + w, dy0 = y0 - c.a.y, dy1 = dy0 + h;
+    const float A = c.a.z, B = c.a.w, C = c.b.x;
+    const bool inside = (dx0 <= 0.0f) & (dx1 >= 0.0f) & (dy0 <= 0.0f) & (dy1 >= 0.0f);
+    float g = mrgs_edge_min(A, B, C, dx0, dy0, dy1);
+    g = fminf(g, mrgs_edge_min(A, B, C, dx1, dy0, dy1));
+    g = fminf(g, mrgs_edge_min(C, B, A, dy0, dx0, dx1));
+    g = fminf(g, mrgs_edge_min(C, B, A, dy1, dx0, dx1));
+    const bool ellipse = inside | (g <= 1.01f);
+    // disc: squared distance from mean2D to the rectangle
+    const float ex = fmaxf(fmaxf(x0 - c.b.y, c.b.y - (x0 + w)), 0.0f), ey = fmaxf(fmaxf(y0 - c.b.z, c.b.z - (y0 + h)), 0.0f);
+    const bool disc = fmaf(ex, ex, ey * ey) <= c.b.w;
+    return ellipse | disc;
+}
+__device__ __forceinline__ CullConic mrgs_cull_never()
+{
+    CullConic c;
+    c.a = make_float4(1e30f, 1e30f, 1e30f, 0.0f);
+    c.b = make_float4(1e30f, 0.0f, 0.0f, -1.0f);
+    return c;
+}
+__device__ __forceinline__ CullConic mrgs_cull_load(const float4* __restrict__ rec, uint32_t gid)
+{
+    CullConic c;
+    c.a = rec[(size_t)gid * MRGS_REC_F4 + 5];
+    c.b = rec[(size_t)gid * MRGS_REC_F4 + 6];
+    return c;
 }
 
 // ---- list staging: asynchronous global -> LDS gather ---------------------------------------------------

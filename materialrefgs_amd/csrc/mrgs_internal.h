@@ -11,12 +11,12 @@
 #define MRGS_FILTER_INV_SQUARE 2.0f  // auxiliary.h:41
 
 // Packed per-gaussian render record written by preprocess and gathered by the blend kernels:
-// 6 x float4 = 96 B, 16-byte aligned so that a record is fetched with dwordx4 loads.
+// 7 x float4 = 112 B, 16-byte aligned so that a record is fetched with dwordx4 loads.
 //   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   (geometry: read for every list entry)
 //   [3] normal.xyz, rgb.r   [4] rgb.gb, depth, 0                          (appearance: read only when blended)
-//   [5] cull box: centre.xy, half-extent.xy (mrgs_blend_math.h)           (read for every list entry)
+//   [5] cull conic: ellipse centre.xy, A, B   [6] C, mean2D.xy, disc r^2    (mrgs_blend_math.h; read for every list entry)
 // (the reference keeps these in five separate arrays: transMat, means2D, normal_opacity, rgb; forward.cu:350-357,427)
-#define MRGS_REC_F4 6
+#define MRGS_REC_F4 7
 
 // Packed per-gaussian gradient accumulator of the blend backward (one row per gaussian so that the
 // atomics of one (tile, gaussian) pair land in one or two cache lines):

@@ -185,33 +185,47 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             rgb[2] = colors_precomp[3 * (size_t)idx + 2];
         }
         const float opa = opacities[idx];
-        // Conservative cull box for the blend kernels (mrgs_blend_math.h): a pixel can reach alpha >= 1/255 only where
-        // min(rho3d, rho2d) <= tau = 2 ln(255 opacity).  {rho3d <= tau} is the image of a disc of the splat plane; its
-        // bounding box follows from the same dual-conic formula as compute_aabb, valid while the disc stays in front of
-        // the camera plane (tau (Twx^2 + Twy^2) < Twz^2).  {rho2d <= tau} is a disc of radius sqrt(tau/2) around mean2D.
-        float4 cull = make_float4(0.0f, 0.0f, -1e30f, -1e30f);   // never a candidate: opacity < 1/255 can never pass
+        // Cull conic for the blend kernels (mrgs_blend_math.h).  A pixel can reach alpha >= 1/255 only where
+        // min(rho3d, rho2d) <= tau = 2 ln(255 opacity).
+        //  * rho3d: the pixel -> splat map of the blend is p = M (x, y, 1) with M = [Tv x Tw | Tw x Tu | Tu x Tv]
+        //    (expand k x l of forward.cu:371-373), so {rho3d <= tau} = {(x,y,1) Q (x,y,1)^T <= 0}, Q = M^T diag(1,1,-tau) M:
+        //    an exact conic.  When it is an ellipse it is stored centred and normalised, d^T [[A,B],[B,C]] d <= 1; otherwise
+        //    (splat crossing the camera plane) A = B = C = 0, which every block passes.  Evaluated in fp64.
+        //  * rho2d: a disc of radius sqrt(tau/2) around mean2D.
+        float4 cull_a = make_float4(1e30f, 1e30f, 1e30f, 0.0f);   // never a candidate: opacity < 1/255 can never pass
+        float4 cull_b = make_float4(1e30f, 0.0f, 0.0f, -1.0f);
         const float oa = 255.0f * opa;
         if (!(oa < 0.999f)) {
             const float lg = logf(oa);
-            const float tau = 2.0f * (lg > 0.0f ? lg : 0.0f) * 1.0001f + 1e-3f;
-            const float dist = tau * (T3[0] * T3[0] + T3[1] * T3[1]) - T3[2] * T3[2];
-            float bx0 = 0.0f, by0 = 0.0f, bex = 1e30f, bey = 1e30f;
-            if (dist < -1e-6f * (T3[2] * T3[2])) {
-                const float fi = 1.0f / dist;
-                const float ccx = fi * (tau * (T0[0] * T3[0] + T0[1] * T3[1]) - T0[2] * T3[2]);
-                const float ccy = fi * (tau * (T1[0] * T3[0] + T1[1] * T3[1]) - T1[2] * T3[2]);
-                const float hx = ccx * ccx - fi * (tau * (T0[0] * T0[0] + T0[1] * T0[1]) - T0[2] * T0[2]);
-                const float hy = ccy * ccy - fi * (tau * (T1[0] * T1[0] + T1[1] * T1[1]) - T1[2] * T1[2]);
-                const float exx = sqrtf(hx > 0.0f ? hx : 0.0f), eyy = sqrtf(hy > 0.0f ? hy : 0.0f);
-                const float rr = sqrtf(0.5f * tau);
-                const float lox = fminf(ccx - exx, cx - rr) - 0.05f, hix = fmaxf(ccx + exx, cx + rr) + 0.05f;
-                const float loy = fminf(ccy - eyy, cy - rr) - 0.05f, hiy = fmaxf(ccy + eyy, cy + rr) + 0.05f;
-                bx0 = 0.5f * (lox + hix); by0 = 0.5f * (loy + hiy);
-                bex = 0.5f * (hix - lox) * 1.0001f + 0.01f; bey = 0.5f * (hiy - loy) * 1.0001f + 0.01f;
-                const float chk = bx0 + by0 + bex + bey;
-                if (!(chk - chk == 0.0f)) { bx0 = 0.0f; by0 = 0.0f; bex = 1e30f; bey = 1e30f; }   // inf / NaN: never cull
+            const double tau = (double)(2.0f * (lg > 0.0f ? lg : 0.0f) * 1.0001f + 1e-3f);
+            const double u[3] = {T0[0], T0[1], T0[2]}, v[3] = {T1[0], T1[1], T1[2]}, w[3] = {T3[0], T3[1], T3[2]};
+            const double c0[3] = {v[1] * w[2] - v[2] * w[1], v[2] * w[0] - v[0] * w[2], v[0] * w[1] - v[1] * w[0]};   // Tv x Tw
+            const double c1[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};   // Tw x Tu
+            const double c2[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};   // Tu x Tv
+            const double Qxx = c0[0] * c0[0] + c0[1] * c0[1] - tau * c0[2] * c0[2];
+            const double Qxy = c0[0] * c1[0] + c0[1] * c1[1] - tau * c0[2] * c1[2];
+            const double Qyy = c1[0] * c1[0] + c1[1] * c1[1] - tau * c1[2] * c1[2];
+            const double Qx1 = c0[0] * c2[0] + c0[1] * c2[1] - tau * c0[2] * c2[2];
+            const double Qy1 = c1[0] * c2[0] + c1[1] * c2[1] - tau * c1[2] * c2[2];
+            const double Q11 = c2[0] * c2[0] + c2[1] * c2[1] - tau * c2[2] * c2[2];
+            const double det = Qxx * Qyy - Qxy * Qxy;
+            float ea = 0.0f, eb = 0.0f, ec = 0.0f, ex0 = 0.0f, ey0 = 0.0f;   // default: not an ellipse -> always a candidate
+            if (Qxx > 0.0 && Qyy > 0.0 && det > 1e-9 * Qxx * Qyy) {
+                const double xc = -(Qyy * Qx1 - Qxy * Qy1) / det, yc = -(Qxx * Qy1 - Qxy * Qx1) / det;
+                const double fp = Q11 + Qx1 * xc + Qy1 * yc;
+                if (fp < 0.0) {
+                    const double sc_ = -1.0 / fp;
+                    ea = (float)(Qxx * sc_); eb = (float)(Qxy * sc_); ec = (float)(Qyy * sc_);
+                    ex0 = (float)xc; ey0 = (float)yc;
+                } else {   // empty level set (cannot happen for a visible splat; stay conservative)
+                    ea = 0.0f; eb = 0.0f; ec = 0.0f;
+                }
+                const float chk = ea + eb + ec + ex0 + ey0;
+                if (!(chk - chk == 0.0f)) { ea = 0.0f; eb = 0.0f; ec = 0.0f; ex0 = 0.0f; ey0 = 0.0f; }   // inf / NaN: never cull
             }
-            cull = make_float4(bx0, by0, bex, bey);
+            const float rr = sqrtf(0.5f * (float)tau) + 0.05f;
+            cull_a = make_float4(ex0, ey0, ea, eb);
+            cull_b = make_float4(ec, cx, cy, rr * rr);
         }
         float4* r4 = rec + (size_t)idx * MRGS_REC_F4;
         r4[0] = make_float4(T[0], T[1], T[2], T[3]);
@@ -219,7 +233,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         r4[2] = make_float4(T[8], cx, cy, opa);
         r4[3] = make_float4(nx, ny, nz, rgb[0]);
         r4[4] = make_float4(rgb[1], rgb[2], pvz, 0.0f);
-        r4[5] = cull;
+        r4[5] = cull_a;
+        r4[6] = cull_b;
         out_radius = iradius;
         out_tiles = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
         out_key = __float_as_uint(pvz);

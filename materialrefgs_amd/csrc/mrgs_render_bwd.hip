@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
     mrgs_block_pixel(bx, by, lane, pxi, pyi);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi, py = (float)pyi;
-    const float bcx = (float)(bx * 8) + 3.5f, bcy = (float)(by * 8) + 3.5f;
+    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8);   // rectangle of pixel centres [x0, x0+7] x [y0, y0+7]
     const int HW = H * W;
     const int pix = inside ? W * pyi + pxi : 0;
 
@@ -132,24 +132,24 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
     // Same staging pipeline as the forward (LDS-DMA double buffer, boxes two chunks and ids three chunks ahead), walked
     // towards the front of the list.
     const uint32_t* plist = point_list + range.x;
-    const float4 kNever = make_float4(0.f, 0.f, -1e30f, -1e30f);
+    const CullConic kNever = mrgs_cull_never();
     const int c_top = (max_contrib - 1) / MRGS_CHUNK;
     uint32_t id1 = 0, id2 = 0;
-    float4 box1 = kNever;
+    CullConic box1 = kNever;
     uint64_t mask_cur;
     {
         uint32_t id0 = 0;
-        float4 box0 = kNever;
+        CullConic box0 = kNever;
         if (c_top * MRGS_CHUNK + lane < max_contrib) {
             id0 = plist[c_top * MRGS_CHUNK + lane];
-            box0 = rec[(size_t)id0 * MRGS_REC_F4 + 5];
+            box0 = mrgs_cull_load(rec, id0);
         }
         if (c_top >= 1) {
             id1 = plist[(c_top - 1) * MRGS_CHUNK + lane];
-            box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+            box1 = mrgs_cull_load(rec, id1);
         }
         if (c_top >= 2) id2 = plist[(c_top - 2) * MRGS_CHUNK + lane];
-        const bool cand0 = mrgs_block_may_touch(box0, bcx, bcy);
+        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, 7.0f);
         mask_cur = __ballot(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[c_top & 1], rec, features, S, id0, cand0);
         if (cand0) stage[c_top & 1].id[lane] = id0;
@@ -158,13 +158,13 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
     for (int c = c_top; c >= 0; c--) {
         const int base = c * MRGS_CHUNK;
         mrgs_stage_wait();                    // chunk c has landed in stage[c & 1]
-        const bool cand1 = mrgs_block_may_touch(box1, bcx, bcy);
+        const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, 7.0f);
         const uint64_t mask_nxt = __ballot(cand1);
         mrgs_stage_async<S_MAX, SF>(stage[(c + 1) & 1], rec, features, S, id1, cand1);
         if (cand1) stage[(c + 1) & 1].id[lane] = id1;
         id1 = id2;
         box1 = kNever;
-        if (c >= 2) box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+        if (c >= 2) box1 = mrgs_cull_load(rec, id1);
         if (c >= 3) id2 = plist[(c - 3) * MRGS_CHUNK + lane];
 
         uint64_t mask = mask_cur;

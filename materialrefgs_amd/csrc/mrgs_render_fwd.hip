@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     mrgs_block_pixel(bx, by, lane, pxi, pyi);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi, py = (float)pyi;
-    const float bcx = (float)(bx * 8) + 3.5f, bcy = (float)(by * 8) + 3.5f;
+    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8);   // rectangle of pixel centres [x0, x0+7] x [y0, y0+7]
     const int HW = H * W;
     const int pix = W * pyi + pxi;
 
@@ -71,23 +71,23 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 
     // ---- pipeline prologue: chunk 0 staged, box of chunk 1 and ids of chunks 1, 2 on their way ------------
     const uint32_t* plist = point_list + range.x;
-    const float4 kNever = make_float4(0.f, 0.f, -1e30f, -1e30f);
+    const CullConic kNever = mrgs_cull_never();
     uint32_t id1 = 0, id2 = 0;
-    float4 box1 = kNever;
+    CullConic box1 = kNever;
     uint64_t mask_cur;
     {
         uint32_t id0 = 0;
-        float4 box0 = kNever;
+        CullConic box0 = kNever;
         if (lane < total) {
             id0 = plist[lane];
-            box0 = rec[(size_t)id0 * MRGS_REC_F4 + 5];
+            box0 = mrgs_cull_load(rec, id0);
         }
         if (MRGS_CHUNK + lane < total) {
             id1 = plist[MRGS_CHUNK + lane];
-            box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+            box1 = mrgs_cull_load(rec, id1);
         }
         if (2 * MRGS_CHUNK + lane < total) id2 = plist[2 * MRGS_CHUNK + lane];
-        const bool cand0 = mrgs_block_may_touch(box0, bcx, bcy);
+        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, 7.0f);
         mask_cur = __ballot(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[0], rec, features, S, id0, cand0);
     }
@@ -98,12 +98,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
             // stage chunk c+1 (its ids and boxes arrived during the previous iteration), prefetch box c+2 and ids c+3
-            const bool cand1 = mrgs_block_may_touch(box1, bcx, bcy);
+            const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, 7.0f);
             mask_nxt = __ballot(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
             id1 = id2;
             box1 = kNever;
-            if (base + 2 * MRGS_CHUNK + lane < total) box1 = rec[(size_t)id1 * MRGS_REC_F4 + 5];
+            if (base + 2 * MRGS_CHUNK + lane < total) box1 = mrgs_cull_load(rec, id1);
             if (base + 3 * MRGS_CHUNK + lane < total) id2 = plist[base + 3 * MRGS_CHUNK + lane];
         };
         if (MRGS_FWD_STAGES == 2) stage_next();
