@@ -120,13 +120,16 @@ int mrgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
 /* ---- environment lookup and deferred specular shading ("second boundary") ----------------------
  * The mip chain of scene/light.py:EnvLight: level i is a [6,res_i,res_i,3] fp32 cubemap holding PRE-sigmoid texels
  * (light.py:129); face/orientation convention of cube_to_dir (scene/light_utils.py:24-31).  grad[i] (may be NULL) receives
- * dL/dtexel by atomic accumulation -- the caller zero-fills it. */
+ * dL/dtexel by atomic accumulation into grad_copies[i] privatised copies -- the caller zero-fills them and sums them. */
 #define MRGS_MAX_MIPS 8
 typedef struct MrgsEnvMips {
     int32_t n_levels;
     int32_t res[MRGS_MAX_MIPS];
     const float* tex[MRGS_MAX_MIPS];
     float* grad[MRGS_MAX_MIPS];
+    int32_t grad_copies[MRGS_MAX_MIPS];   /* >= 1: grad[i] holds this many consecutive copies of the level; workgroups spread
+                                             their atomics over the copies (thousands of pixels mirror into each texel of the
+                                             coarse levels, and same-address atomics serialise in L2); the caller sums them */
     float min_roughness, max_roughness;   /* EnvLight.min_roughness / max_roughness (0.08 / 0.5) */
 } MrgsEnvMips;
 

@@ -37,7 +37,7 @@ MRGS_MAX_MIPS = 8
 
 class MrgsEnvMips(ctypes.Structure):
     _fields_ = [("n_levels", c_int32), ("res", c_int32 * MRGS_MAX_MIPS), ("tex", c_void_p * MRGS_MAX_MIPS),
-                ("grad", c_void_p * MRGS_MAX_MIPS), ("min_roughness", c_float), ("max_roughness", c_float)]
+                ("grad", c_void_p * MRGS_MAX_MIPS), ("grad_copies", c_int32 * MRGS_MAX_MIPS), ("min_roughness", c_float), ("max_roughness", c_float)]
 
 
 class MrgsStridedMap(ctypes.Structure):

@@ -23,6 +23,7 @@ struct EnvMips {   // by-value kernel argument
     int res[MRGS_MAX_MIPS];
     const float* tex[MRGS_MAX_MIPS];
     float* grad[MRGS_MAX_MIPS];
+    int copies[MRGS_MAX_MIPS];
     float min_roughness, max_roughness;
 };
 
@@ -175,6 +176,45 @@ __device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, fl
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// wave64 sum (DPP), result valid in every lane after the final readlane
+__device__ __forceinline__ float wave_sum_all(float v)
+{
+#define DPP_ADD(CTRL, RM) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xf, false))
+    DPP_ADD(0xb1, 0xf); DPP_ADD(0x4e, 0xf); DPP_ADD(0x124, 0xf); DPP_ADD(0x128, 0xf); DPP_ADD(0x142, 0xa); DPP_ADD(0x143, 0xc);
+#undef DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Add v[0..2] to the texel at `addr` (nullptr / all-zero v = nothing to add).  Neighbouring pixels mirror into the same few
+// texels (every lane of a wave into ONE texel of the coarse mip levels), and same-address atomics of one instruction
+// serialise in L2: combine the lanes that share a texel inside the wave first (leader election by ballot, DPP sums), for at
+// most MAX_ROUNDS distinct texels, and let the rest fall through to plain atomics.  Convergent: every lane of the wave calls it.
+__device__ __forceinline__ void texel_scatter(float* addr, const float v[3])
+{
+    const int MAX_ROUNDS = 4;
+    bool pending = addr != nullptr && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f);
+    const unsigned lo = (unsigned)(uintptr_t)addr, hi = (unsigned)((uintptr_t)addr >> 32);
+    for (int r = 0; r < MAX_ROUNDS; r++) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) return;
+        const int leader = __builtin_ctzll(pm);
+        const unsigned klo = __builtin_amdgcn_readlane(lo, leader), khi = __builtin_amdgcn_readlane(hi, leader);
+        const bool match = pending && lo == klo && hi == khi;
+        const float s0 = wave_sum_all(match ? v[0] : 0.f), s1 = wave_sum_all(match ? v[1] : 0.f), s2 = wave_sum_all(match ? v[2] : 0.f);
+        if ((int)(threadIdx.x & 63) == leader) {
+            atomicAdd(addr + 0, s0);
+            atomicAdd(addr + 1, s1);
+            atomicAdd(addr + 2, s2);
+        }
+        pending = pending && !match;
+    }
+    if (pending) {
+        atomicAdd(addr + 0, v[0]);
+        atomicAdd(addr + 1, v[1]);
+        atomicAdd(addr + 2, v[2]);
+    }
+}
+
 // gradient of the fetch: scatter to the texels, return d/d dir and d/d level
 __device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu, f3 dir, const EnvSample& s, const Taps tp[2],
                                               const float gL[3], f3& g_dir, float& g_level)
@@ -184,18 +224,23 @@ __device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const float wk = k == 0 ? 1.f - s.f : s.f;
-        if (k == 1 && s.l1 == s.l0 && s.f == 0.f) continue;
-        float* gt = m.grad[k == 0 ? s.l0 : s.l1];
+        const int lk = k == 0 ? s.l0 : s.l1;
+        float* gt = m.grad[lk];
+        if (gt != nullptr) {   // privatised copy of this workgroup
+            const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
+            gt += (size_t)(wg % (unsigned)m.copies[lk]) * (size_t)(6 * m.res[lk] * m.res[lk] * 3);
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float g = gL[c] * wk;
             gu += g * s.du[k][c];
             gv += g * s.dv[k][c];
-            if (gt != nullptr && g != 0.f) {
+        }
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (tp[k].w[q] != 0.f) atomicAdd(gt + (size_t)tp[k].idx[q] * 3 + c, g * tp[k].w[q]);
-            }
+        for (int q = 0; q < 4; q++) {
+            const float wq = wk * tp[k].w[q];
+            const float vq[3] = {gL[0] * wq, gL[1] * wq, gL[2] * wq};
+            texel_scatter((gt != nullptr && wq != 0.f) ? gt + (size_t)tp[k].idx[q] * 3 : nullptr, vq);
         }
     }
 #pragma unroll
@@ -237,8 +282,9 @@ __global__ void __launch_bounds__(256) envmap_lookup_bwd_kernel(EnvMips m, long 
                                                                 const float* __restrict__ roughness, const float* __restrict__ g_out,
                                                                 float* __restrict__ g_dirs, float* __restrict__ g_rough)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const long long i_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i_ < N;              // out-of-range lanes stay alive (the texel scatter is wave-convergent)
+    const long long i = valid ? i_ : N - 1;
     const f3 d = mk(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     const FaceUV fu = dir_to_face(d);
     float dl = 0.f;
@@ -251,13 +297,13 @@ __global__ void __launch_bounds__(256) envmap_lookup_bwd_kernel(EnvMips m, long 
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float y = sigmoidf(s.L[c]);
-        gL[c] = g_out[3 * i + c] * y * (1.f - y);
+        gL[c] = valid ? g_out[3 * i + c] * y * (1.f - y) : 0.f;
     }
     f3 gd;
     float glev;
     env_fetch_bwd(m, fu, d, s, tp, gL, gd, glev);
-    if (g_dirs) { g_dirs[3 * i] = gd.x; g_dirs[3 * i + 1] = gd.y; g_dirs[3 * i + 2] = gd.z; }
-    if (g_rough) g_rough[i] = use_mips ? glev * dl : 0.f;
+    if (valid && g_dirs) { g_dirs[3 * i] = gd.x; g_dirs[3 * i + 1] = gd.y; g_dirs[3 * i + 2] = gd.z; }
+    if (valid && g_rough) g_rough[i] = use_mips ? glev * dl : 0.f;
 }
 
 // ---- fused deferred specular shading ---------------------------------------------------------------------
@@ -356,8 +402,9 @@ __global__ void __launch_bounds__(256) shade_specular_bwd_kernel(EnvMips m, Shad
                                                                  float* __restrict__ g_normal /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/,
                                                                  float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    const int x_ = blockIdx.x * 64 + (threadIdx.x & 63), y_ = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool valid = x_ < W && y_ < H;    // out-of-image lanes stay alive (the texel scatter is wave-convergent)
+    const int x = min(x_, W - 1), y = min(y_, H - 1);
     ShadePix p;
     shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
     const FaceUV fu = dir_to_face(p.rn);
@@ -373,9 +420,9 @@ __global__ void __launch_bounds__(256) shade_specular_bwd_kernel(EnvMips m, Shad
         const float light = sigmoidf(s.L[c]);
         const float base = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
         const float wgt = base * p.fg[0] + p.fg[1];
-        const float gs = g_specular ? g_specular[c * HW + pix] : 0.f;
-        const float gd = (g_direct ? g_direct[c * HW + pix] : 0.f) + gs * p.alpha * wgt;
-        const float gw = (g_weight ? g_weight[pix * 3 + c] : 0.f) + gs * light * p.alpha;
+        const float gs = (valid && g_specular) ? g_specular[c * HW + pix] : 0.f;
+        const float gd = ((valid && g_direct) ? g_direct[c * HW + pix] : 0.f) + gs * p.alpha * wgt;
+        const float gw = ((valid && g_weight) ? g_weight[pix * 3 + c] : 0.f) + gs * light * p.alpha;
         ga += gs * light * wgt;
         gL[c] = gd * light * (1.f - light);
         galb[c] = gw * p.refl * p.fg[0];
@@ -395,6 +442,7 @@ __global__ void __launch_bounds__(256) shade_specular_bwd_kernel(EnvMips m, Shad
     const f3 gn = mk(2.f * p.ndv * g_r.x + (2.f * grn + g_ndv) * p.wo.x, 2.f * p.ndv * g_r.y + (2.f * grn + g_ndv) * p.wo.y,
                      2.f * p.ndv * g_r.z + (2.f * grn + g_ndv) * p.wo.z);
     const float g_rough_v = (p.v_in ? gfg0 * p.dfg_dv[0] + gfg1 * p.dfg_dv[1] : 0.f) + g_level * dl;
+    if (!valid) return;
     g_normal[pix * 3] = gn.x; g_normal[pix * 3 + 1] = gn.y; g_normal[pix * 3 + 2] = gn.z;
 #pragma unroll
     for (int c = 0; c < 3; c++) g_albedo[pix * 3 + c] = galb[c];
@@ -412,6 +460,7 @@ static int make_mips(const MrgsEnvMips* in, EnvMips& m)
         m.res[i] = i < m.n ? in->res[i] : 0;
         m.tex[i] = i < m.n ? in->tex[i] : nullptr;
         m.grad[i] = i < m.n ? in->grad[i] : nullptr;
+        m.copies[i] = (i < m.n && in->grad_copies[i] > 1) ? in->grad_copies[i] : 1;
         if (i < m.n && (!m.tex[i] || m.res[i] < 1)) return MRGS_E_BAD_ARG;
     }
     m.min_roughness = in->min_roughness;
