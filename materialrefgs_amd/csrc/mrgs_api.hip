@@ -101,6 +101,7 @@ MrgsImgWs mrgs_carve_img(void* base, int H, int W)
     const size_t hw = (size_t)H * W;
     const size_t tiles = (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y);
     w.ranges = c.take<uint2>(tiles > 0 ? tiles : 1);
+    w.tile_order = c.take<uint32_t>(tiles + 8);
     w.final_T = c.take<float>(3 * hw);
     w.n_contrib = c.take<uint32_t>(2 * hw);
     w.total = mrgs_align_up(c.used, 256);
@@ -221,7 +222,7 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
     const int bits = tile_bits(ntiles);
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_hist, R, 0, bits, stream);
     STAGE_CHECK(cfg, stream);
-    mrgs_launch_tile_ranges(b.tile_key[cur], R, img.ranges, ntiles, stream);
+    mrgs_launch_tile_ranges(b.tile_key[cur], R, img.ranges, img.tile_order, ntiles, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 

@@ -14,6 +14,9 @@
 #define MRGS_ALPHA_MIN (1.0f / 255.0f)
 #define MRGS_T_MIN 0.0001f
 #define MRGS_CHUNK 64   // list entries staged per step = one per lane
+#ifndef MRGS_SPLIT_THRESHOLD
+#define MRGS_SPLIT_THRESHOLD 1024   // tiles with more list entries are blended by 8 half-quadrant waves instead of 4
+#endif
 
 __device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

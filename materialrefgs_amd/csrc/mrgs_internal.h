@@ -44,6 +44,7 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
 
 struct MrgsImgWs {
     uint2* ranges;       // [tiles]
+    uint32_t* tile_order;// [tiles rounded up to 8] blend dispatch order: tile ids by decreasing list length
     float* final_T;      // [3][H*W]: T, M1, M2
     uint32_t* n_contrib; // [2][H*W]: last, median
     size_t total;
@@ -78,7 +79,7 @@ void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatr
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
                            uint32_t* plist, hipStream_t stream);
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, int ntiles, hipStream_t stream);
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, uint32_t* tile_order, int ntiles, hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);

@@ -48,16 +48,25 @@ __device__ __forceinline__ void wave_reduce_atomic_add(float (&v)[K], float* __r
     for (int i = 0; i < K / 4; i++) swap16_add(v[4 * i], v[4 * i + 2]);      // result in v[4i]
     const int row = lane >> 4;
     const int sub = ((row & 1) << 1) | (row >> 1);                             // rows 0,1,2,3 -> values +0,+2,+1,+3
+    // the four row rotates run as K/4 independent chains interleaved step by step (a DPP operand needs two wait states after
+    // the VALU write that produced it: back-to-back steps of ONE chain would each cost an s_nop)
 #pragma unroll
-    for (int i = 0; i < K / 4; i++) {
-        const float tot = row_sum(v[4 * i]);
-        if ((lane & 15) == 0 && tot != 0.0f) atomicAdd(dst + 4 * i + sub, tot);
+    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x128, 0xf>(v[4 * i]);   // row_ror:8
+#pragma unroll
+    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x124, 0xf>(v[4 * i]);   // row_ror:4
+#pragma unroll
+    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x122, 0xf>(v[4 * i]);   // row_ror:2
+#pragma unroll
+    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x121, 0xf>(v[4 * i]);   // row_ror:1
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < K / 4; i++) atomicAdd(dst + 4 * i + sub, v[4 * i]);
     }
 }
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride)
@@ -68,21 +77,32 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
 
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    const int xcd = b & 7, seq = b >> 3;
-    const int tile = (seq >> 2) * 8 + xcd;
+    // first half of the grid: one wave per quadrant; second half: the extra wave of each quadrant of a split tile (kept at the
+    // end of the grid so that the waves that exit at once do not alternate with working ones in the dispatch order)
+    const int nq = (int)(gridDim.x >> 1);
+    const int half = b >= nq ? 1 : 0;
+    const int bb = b - half * nq;
+    const int xcd = bb & 7, seq = bb >> 3;
+    const int tile = (int)tile_order[(seq >> 2) * 8 + xcd];   // longest lists first
     const int quad = seq & 3;
     if (tile >= ntiles) return;
+    const uint2 range = ranges[tile];
+    // Eight waves are launched per tile.  A tile with a short list is blended by four of them (one 8x8 quadrant each, the
+    // other four exit here).  The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split
+    // into two 8x4 halves: each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical
+    // path at the price of idle lanes in a few waves.
+    const bool split = (int)(range.y - range.x) > MRGS_SPLIT_THRESHOLD;
+    if (!split && half) return;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
-    int pxi, pyi;
-    mrgs_block_pixel(bx, by, lane, pxi, pyi);
-    const bool inside = pxi < W && pyi < H;
+    const int rows = split ? 4 : 8;
+    const int pxi = bx * 8 + (lane & 7), pyi = by * 8 + half * 4 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H && (lane >> 3) < rows;
     const float px = (float)pxi, py = (float)pyi;
-    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8);   // rectangle of pixel centres [x0, x0+7] x [y0, y0+7]
+    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8 + half * 4), blk_h = (float)(rows - 1);   // rectangle of pixel centres
     const int HW = H * W;
     const int pix = inside ? W * pyi + pxi : 0;
 
-    const uint2 range = ranges[tile];
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
     // deepest list position any pixel of this block blended: nothing behind it can receive a gradient
     int max_contrib = last_contributor;
@@ -149,7 +169,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
             box1 = mrgs_cull_load(rec, id1);
         }
         if (c_top >= 2) id2 = plist[(c_top - 2) * MRGS_CHUNK + lane];
-        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, 7.0f);
+        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
         mask_cur = __ballot(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[c_top & 1], rec, features, S, id0, cand0);
         if (cand0) stage[c_top & 1].id[lane] = id0;
@@ -158,7 +178,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
     for (int c = c_top; c >= 0; c--) {
         const int base = c * MRGS_CHUNK;
         mrgs_stage_wait();                    // chunk c has landed in stage[c & 1]
-        const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, 7.0f);
+        const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
         const uint64_t mask_nxt = __ballot(cand1);
         mrgs_stage_async<S_MAX, SF>(stage[(c + 1) & 1], rec, features, S, id1, cand1);
         if (cand1) stage[(c + 1) & 1].id[lane] = id1;
@@ -285,10 +305,10 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 4;
+    const int nblocks = ((ntiles + 7) / 8) * 8 * 8;   // 8 waves per tile (4 quadrants x 2 halves), tiles dealt to the 8 XCDs
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, GS)                                                                                                       \
-    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.tile_order, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS)
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);

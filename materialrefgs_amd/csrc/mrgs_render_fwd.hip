@@ -26,7 +26,7 @@
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others)
 {
@@ -36,21 +36,32 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const int lane = threadIdx.x;
     // XCD-aware mapping: b % 8 selects the XCD; within an XCD consecutive blocks are the 4 quadrants of one tile
     const int b = blockIdx.x;
-    const int xcd = b & 7, seq = b >> 3;
-    const int tile = (seq >> 2) * 8 + xcd;
+    // first half of the grid: one wave per quadrant; second half: the extra wave of each quadrant of a split tile (kept at the
+    // end of the grid so that the waves that exit at once do not alternate with working ones in the dispatch order)
+    const int nq = (int)(gridDim.x >> 1);
+    const int half = b >= nq ? 1 : 0;
+    const int bb = b - half * nq;
+    const int xcd = bb & 7, seq = bb >> 3;
+    const int tile = (int)tile_order[(seq >> 2) * 8 + xcd];   // longest lists first
     const int quad = seq & 3;
     if (tile >= ntiles) return;
+    const uint2 range = ranges[tile];
+    // Eight waves are launched per tile.  A tile with a short list is blended by four of them (one 8x8 quadrant each, the
+    // other four exit here).  The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split
+    // into two 8x4 halves: each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical
+    // path at the price of idle lanes in a few waves.
+    const bool split = (int)(range.y - range.x) > MRGS_SPLIT_THRESHOLD;
+    if (!split && half) return;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
-    int pxi, pyi;
-    mrgs_block_pixel(bx, by, lane, pxi, pyi);
-    const bool inside = pxi < W && pyi < H;
+    const int rows = split ? 4 : 8;
+    const int pxi = bx * 8 + (lane & 7), pyi = by * 8 + half * 4 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H && (lane >> 3) < rows;
     const float px = (float)pxi, py = (float)pyi;
-    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8);   // rectangle of pixel centres [x0, x0+7] x [y0, y0+7]
+    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8 + half * 4), blk_h = (float)(rows - 1);   // rectangle of pixel centres
     const int HW = H * W;
     const int pix = W * pyi + pxi;
 
-    const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     // The launch lasts as long as its longest wave: every wave is resident from the start, and the waves of the densest
     // tiles carry several times the average work.  Give them issue priority so that they run near their single-wave
@@ -87,7 +98,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             box1 = mrgs_cull_load(rec, id1);
         }
         if (2 * MRGS_CHUNK + lane < total) id2 = plist[2 * MRGS_CHUNK + lane];
-        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, 7.0f);
+        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
         mask_cur = __ballot(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[0], rec, features, S, id0, cand0);
     }
@@ -98,7 +109,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
             // stage chunk c+1 (its ids and boxes arrived during the previous iteration), prefetch box c+2 and ids c+3
-            const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, 7.0f);
+            const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
             mask_nxt = __ballot(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
             id1 = id2;
@@ -189,10 +200,10 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // 4 quadrant-waves per tile, tiles dealt to the 8 XCDs
+    const int nblocks = ((ntiles + 7) / 8) * 8 * 8;   // 8 waves per tile (4 quadrants x 2 halves), tiles dealt to the 8 XCDs   // 4 quadrant-waves per tile, tiles dealt to the 8 XCDs
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM)                                                                                                           \
-    hipLaunchKernelGGL(render_fwd_kernel<SM>, grid, block, 0, stream, img.ranges, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL(render_fwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.tile_order, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others)
     if (cfg.S == 0) LAUNCH(0);
     else if (cfg.S <= 8) LAUNCH(8);

@@ -274,9 +274,37 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
     if (idx == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, int ntiles, hipStream_t stream)
+// Blend-kernel dispatch order: tiles sorted by decreasing list length (counting sort on length / 16, one workgroup).  The
+// blend launches last as long as their longest wave, and not every wave is resident from the start: longest-first keeps the
+// heavy tiles off the tail of the launch.  Slots beyond ntiles (grid padding) get the id ntiles (= no tile).
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restrict__ ranges, int ntiles, int nslots, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wave_sums[16];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint2 r = ranges[t];
+        atomicAdd(&hist[255u - min((r.y - r.x) >> 4, 255u)], 1u);   // bucket 0 = longest lists
+    }
+    __syncthreads();
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<1024>(tid < 256 ? hist[tid] : 0u, wave_sums, tot);
+    if (tid < 256) hist[tid] = ex;
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint2 r = ranges[t];
+        const uint32_t pos = atomicAdd(&hist[255u - min((r.y - r.x) >> 4, 255u)], 1u);
+        order[pos] = (uint32_t)t;
+    }
+    for (int t = ntiles + tid; t < nslots; t += 1024) order[t] = (uint32_t)ntiles;
+}
+
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, uint32_t* tile_order, int ntiles, hipStream_t stream)
 {
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, stream);   // rasterizer_impl.cu:316
     if (R > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, R, ranges);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ranges, ntiles, ((ntiles + 7) / 8) * 8, tile_order);
 }
