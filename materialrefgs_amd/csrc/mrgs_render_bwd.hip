@@ -14,6 +14,10 @@
 // floats of the surfel's packed gradient row, replace K single-lane atomics.
 #include "mrgs_blend_math.h"
 
+#ifndef MRGS_BWD_STAGES
+#define MRGS_BWD_STAGES 1   // see MRGS_FWD_STAGES in mrgs_render_fwd.hip
+#endif
+
 
 __device__ __forceinline__ void swap32_add(float& a, float b)   // a <- [a.lo + a.hi | b.lo + b.hi]
 {
@@ -65,7 +69,7 @@ __device__ __forceinline__ void wave_reduce_atomic_add(float (&v)[K], float* __r
 }
 
 template <int S_MAX>
-__global__ void __launch_bounds__(64) render_bwd_kernel(
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 4 : S_MAX <= 8 ? 3 : 2, 8))) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     constexpr int K = (18 + S_MAX + 3) & ~3;
-    __shared__ StageBuf<SF> stage[2];
+    __shared__ StageBuf<SF> stage[MRGS_BWD_STAGES];
 
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
@@ -171,26 +175,29 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
         if (c_top >= 2) id2 = plist[(c_top - 2) * MRGS_CHUNK + lane];
         const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
         mask_cur = __ballot(cand0);
-        mrgs_stage_async<S_MAX, SF>(stage[c_top & 1], rec, features, S, id0, cand0);
-        if (cand0) stage[c_top & 1].id[lane] = id0;
+        mrgs_stage_async<S_MAX, SF>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
+        if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0;
     }
 
     for (int c = c_top; c >= 0; c--) {
         const int base = c * MRGS_CHUNK;
-        mrgs_stage_wait();                    // chunk c has landed in stage[c & 1]
-        const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
-        const uint64_t mask_nxt = __ballot(cand1);
-        mrgs_stage_async<S_MAX, SF>(stage[(c + 1) & 1], rec, features, S, id1, cand1);
-        if (cand1) stage[(c + 1) & 1].id[lane] = id1;
-        id1 = id2;
-        box1 = kNever;
-        if (c >= 2) box1 = mrgs_cull_load(rec, id1);
-        if (c >= 3) id2 = plist[(c - 3) * MRGS_CHUNK + lane];
+        mrgs_stage_wait();                    // chunk c has landed
+        uint64_t mask_nxt = 0ull;
+        auto stage_next = [&]() {
+            const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
+            mask_nxt = __ballot(cand1);
+            mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
+            if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1;
+            id1 = id2;
+            box1 = kNever;
+            if (c >= 2) box1 = mrgs_cull_load(rec, id1);
+            if (c >= 3) id2 = plist[(c - 3) * MRGS_CHUNK + lane];
+        };
+        if (MRGS_BWD_STAGES == 2) stage_next();
 
         uint64_t mask = mask_cur;
-        mask_cur = mask_nxt;
-        if (mask == 0ull) continue;
-        const StageBuf<SF>& sb = stage[c & 1];
+        const StageBuf<SF>& sb = stage[c % MRGS_BWD_STAGES];
+        if (mask != 0ull) {
         int j = 63 - __builtin_clzll(mask);   // back to front
         SurfelGeom sg;
         sg.g0 = sb.rec[0][j]; sg.g1 = sb.rec[1][j]; sg.g2 = sb.rec[2][j];
@@ -295,6 +302,9 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
             sg = nxt;
             j = jn;
         }
+        }
+        if (MRGS_BWD_STAGES == 1) stage_next();
+        mask_cur = mask_nxt;
     }
     mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
 }
