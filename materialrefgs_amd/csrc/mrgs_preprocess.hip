@@ -60,6 +60,35 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
     rmax[1] = min(gy, max(0, f2i_sat((py + r + (float)MRGS_BLOCK_Y - 1.0f) / (float)MRGS_BLOCK_Y)));
 }
 
+// Wave-cooperative transfer of 64 consecutive rows of L floats (the [P,M,3] SH tensors) between global memory and a
+// per-wave LDS tile with an odd row stride: one lane per gaussian would touch 64 rows 192 B apart with every load/store
+// instruction, whereas here every instruction moves 256 contiguous bytes and each lane then works on its own (bank
+// conflict-free) LDS row.
+#define SH_ROW_MAX 48
+#define SH_LDS_STRIDE 49
+__device__ __forceinline__ void wave_rows_load(float* __restrict__ tile, const float* __restrict__ src, int nrows, int L, int lane)
+{
+    const int total = nrows * L;
+    int r = 0, c = lane;
+    while (c >= L) { c -= L; r++; }
+    for (int t = lane; t < total; t += 64) {
+        tile[r * SH_LDS_STRIDE + c] = src[t];
+        c += 64;
+        while (c >= L) { c -= L; r++; }
+    }
+}
+__device__ __forceinline__ void wave_rows_store(const float* __restrict__ tile, float* __restrict__ dst, int nrows, int L, int lane)
+{
+    const int total = nrows * L;
+    int r = 0, c = lane;
+    while (c >= L) { c -= L; r++; }
+    for (int t = lane; t < total; t += 64) {
+        dst[t] = tile[r * SH_LDS_STRIDE + c];
+        c += 64;
+        while (c >= L) { c -= L; r++; }
+    }
+}
+
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, int W, int H, int tiles_x, int tiles_y, float scale_modifier, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -68,7 +97,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order,
     uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped)
 {
+    __shared__ float s_sh[4][64 * SH_LDS_STRIDE];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = M * 3;
+    const bool sh_staged = shs != nullptr && colors_precomp == nullptr && L <= SH_ROW_MAX;
+    if (sh_staged) {
+        const int row0 = blockIdx.x * blockDim.x + wave * 64;
+        const int nrows = min(64, P - row0);
+        if (nrows > 0) wave_rows_load(s_sh[wave], shs + (size_t)row0 * L, nrows, L, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     if (idx >= P) return;
     float V[16], PM[16];
 #pragma unroll
@@ -152,7 +192,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             const float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             const float x = dx / len, y = dy / len, z = dz / len;
-            const float* sh = shs + (size_t)idx * M * 3;
+            const float* sh = sh_staged ? &s_sh[wave][lane * SH_LDS_STRIDE] : shs + (size_t)idx * M * 3;
             uint32_t cl = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -284,9 +324,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const bool live = radii[idx] > 0;   // backward.cu:643
+    __shared__ float s_sh[4][64 * SH_LDS_STRIDE];
+    const int idx_ = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = M * 3;
+    // SH coefficients in, SH gradients out: staged through a per-wave LDS tile so that global traffic is coalesced
+    const bool sh_staged = M > 0 && L <= SH_ROW_MAX;
+    const int row0 = blockIdx.x * blockDim.x + wave * 64;
+    const int nrows = min(64, P - row0);
+    if (sh_staged && shs != nullptr && nrows > 0) {
+        wave_rows_load(s_sh[wave], shs + (size_t)row0 * L, nrows, L, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool in_range = idx_ < P;
+    const int idx = in_range ? idx_ : P - 1;   // out-of-range lanes stay alive for the cooperative tile store below
+    const bool live = in_range && radii[idx] > 0;   // backward.cu:643
     const bool precomp = scales == nullptr;
     const float* gr = grad_rec + (size_t)idx * gstride;
 
@@ -415,9 +468,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 
     // SH backward (backward.cu:22-141), also zero-fills dL_dsh for culled gaussians / unused degrees
     if (M > 0) {
-        float* dsh = dL_dsh + (size_t)idx * M * 3;
+        float* tile = &s_sh[wave][lane * SH_LDS_STRIDE];
+        float* dsh = sh_staged ? tile : dL_dsh + (size_t)idx * M * 3;
         if (live && shs != nullptr) {
-            const float* sh = shs + (size_t)idx * M * 3;
+            const float* sh = sh_staged ? tile : shs + (size_t)idx * M * 3;
             const f3 dir_orig = {means3D[3 * (size_t)idx] - campos[0], means3D[3 * (size_t)idx + 1] - campos[1],
                                  means3D[3 * (size_t)idx + 2] - campos[2]};
             const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
@@ -427,10 +481,13 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 #pragma unroll
             for (int c = 0; c < 3; c++) dRGB[c] = dcol[c] * (((cl >> c) & 1u) ? 0.0f : 1.0f);
             const int ncoef = (D + 1) * (D + 1);
-            for (int i = ncoef; i < M; i++) { dsh[i * 3] = 0.0f; dsh[i * 3 + 1] = 0.0f; dsh[i * 3 + 2] = 0.0f; }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-#define SH(i) sh[(i) * 3 + c]
+                // the coefficients of this channel are read before its gradients overwrite them (in-place tile)
+                float shv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) shv[i] = (i < ncoef && i < M) ? sh[i * 3 + c] : 0.0f;
+#define SH(i) shv[i]
 #define DSH(i) dsh[(i) * 3 + c]
                 float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
                 DSH(0) = kSH_C0 * dRGB[c];
@@ -476,15 +533,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 #undef DSH
                 ddx[c] = dRGBdx; ddy[c] = dRGBdy; ddz[c] = dRGBdz;
             }
+            for (int i = ncoef; i < M; i++) { dsh[i * 3] = 0.0f; dsh[i * 3 + 1] = 0.0f; dsh[i * 3 + 2] = 0.0f; }
             const f3 dd = {(ddx[0] * dRGB[0] + ddx[1] * dRGB[1]) + ddx[2] * dRGB[2],
                            (ddy[0] * dRGB[0] + ddy[1] * dRGB[1]) + ddy[2] * dRGB[2],
                            (ddz[0] * dRGB[0] + ddz[1] * dRGB[1]) + ddz[2] * dRGB[2]};
             const f3 dm = dnormvdv(dir_orig, dd);
             dm3[0] += dm.x; dm3[1] += dm.y; dm3[2] += dm.z;
-        } else {
+        } else if (in_range || sh_staged) {
             for (int i = 0; i < M * 3; i++) dsh[i] = 0.0f;
         }
+        if (sh_staged) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (nrows > 0) wave_rows_store(s_sh[wave], dL_dsh + (size_t)row0 * L, nrows, L, lane);
+        }
     }
+    if (!in_range) return;
 
     dL_dmeans2D[3 * (size_t)idx] = dm2[0]; dL_dmeans2D[3 * (size_t)idx + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)idx + 2] = 0.0f;
 #pragma unroll
