@@ -11,7 +11,8 @@ import subprocess
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libmrgs.so")
+# MRGS_LIB: developer override to load another build of the same library (kernel experiments); never a fallback
+LIB_PATH = os.environ.get("MRGS_LIB") or os.path.join(_CSRC, "libmrgs.so")
 
 c_int32, c_int64, c_float, c_void_p, c_size_t = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

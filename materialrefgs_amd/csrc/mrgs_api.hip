@@ -146,6 +146,8 @@ static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
         if (have_sr == (in->transMat_precomp != nullptr)) return MRGS_E_BAD_ARG;
         if (cfg->S > 0 && !in->features) return MRGS_E_BAD_ARG;
         if ((cfg->W + 15) / 16 > 65535 || (cfg->H + 15) / 16 > 65535) return MRGS_E_UNSUPPORTED;
+        // the blend backward addresses a surfel's gradient row with a 32-bit byte offset
+        if ((uint64_t)cfg->P * MRGS_GRAD_STRIDE(cfg->S) * sizeof(float) >= (1ull << 32)) return MRGS_E_UNSUPPORTED;
     }
     return MRGS_OK;
 }

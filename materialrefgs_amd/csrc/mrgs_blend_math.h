@@ -14,9 +14,29 @@
 #define MRGS_ALPHA_MIN (1.0f / 255.0f)
 #define MRGS_T_MIN 0.0001f
 #define MRGS_CHUNK 64   // list entries staged per step = one per lane
-#ifndef MRGS_SPLIT_THRESHOLD
-#define MRGS_SPLIT_THRESHOLD 1024   // tiles with more list entries are blended by 8 half-quadrant waves instead of 4
-#endif
+
+
+// Work-item decode shared by the two blend kernels.  tile_order[] lists the tile ids by decreasing list length and
+// tile_order[nslots] holds the number of leading "split" tiles (>= MRGS_SPLIT_THRESHOLD entries).  Tile p of the order is
+// dealt to XCD p % 8 (blockIdx % 8 selects the XCD, so all waves of a tile share one L2).  Inside an XCD the work items are
+// enumerated longest tile first: 8 items (4 quadrants x two 8x4 halves) per split tile, then 4 items (8x8 quadrants) per
+// ordinary tile -- so the dispatch order is also the order of decreasing work and contains no idle waves before its tail.
+struct BlendItem { int tile, quad, half; bool split; };
+__device__ __forceinline__ bool mrgs_decode_item(const uint32_t* __restrict__ tile_order, int ntiles, int b, BlendItem& it)
+{
+    const int nslots = ((ntiles + 7) >> 3) << 3;
+    const int xcd = b & 7, seq = b >> 3;
+    const int nsplit = (int)tile_order[nslots];
+    const int ns_x = (nsplit + 7 - xcd) >> 3;          // split tiles dealt to this XCD
+    int g;
+    if (seq < 8 * ns_x) { g = seq >> 3; it.quad = seq & 3; it.half = (seq >> 2) & 1; it.split = true; }
+    else { const int s2 = seq - 8 * ns_x; g = ns_x + (s2 >> 2); it.quad = s2 & 3; it.half = 0; it.split = false; }
+    const int p = g * 8 + xcd;
+    if (p >= nslots) return false;
+    it.tile = (int)tile_order[p];
+    return it.tile < ntiles;
+}
+
 
 __device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -20,10 +20,17 @@
 
 // Packed per-gaussian gradient accumulator of the blend backward (one row per gaussian so that the
 // atomics of one (tile, gaussian) pair land in one or two cache lines):
-//   [0..8] dL/dT (Tu,Tv,Tw)  [9..10] dL/dmean2D.xy  [11] dL/dopacity  [12..14] dL/dnormal  [15..17] dL/dcolor
-//   [18..18+S) dL/dfeature ; row stride = MRGS_GRAD_STRIDE(S) floats = the padded value count of the blend-backward
-//   kernel instance that serves S channels (instances exist for up to 0 / 8 / 12 / 24 channels)
+//   [0..8] dL/dT (Tu,Tv,Tw)  [9] dL/dopacity  [10..12] dL/dnormal  [13..15] dL/dcolor  [16..16+SMAX) dL/dfeature
+//   [16+SMAX, 17+SMAX] dL/dmean2D.xy ; SMAX = channel capacity of the blend-backward kernel instance that serves S
+//   channels (instances exist for 0 / 8 / 12 / 24); row stride = MRGS_GRAD_STRIDE(S) floats.  The first 16 (+SMAX)
+//   values are what one transposing wave reduction produces, 16 consecutive floats per atomic instruction.
 #define MRGS_SMAX(S) ((S) == 0 ? 0 : (S) <= 8 ? 8 : (S) <= 12 ? 12 : 24)
+#define MRGS_G_DT 0
+#define MRGS_G_OPA 9
+#define MRGS_G_NRM 10
+#define MRGS_G_COL 13
+#define MRGS_G_FEAT 16
+#define MRGS_G_M2(SMAX) (16 + (SMAX))
 #define MRGS_GRAD_STRIDE(S) ((18 + MRGS_SMAX(S) + 3) & ~3)
 
 static inline size_t mrgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -64,6 +71,9 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
 // ---- kernel launchers (one per translation unit) ---------------------------------------------------
 // radix sort of (u32 key, u32 value) pairs on bits [bit_lo, bit_hi); returns index (0/1) of the buffer
 // that holds the sorted result.  hist must hold 256 * ceil(n / SORT_TILE) u32.
+#ifndef MRGS_SPLIT_THRESHOLD
+#define MRGS_SPLIT_THRESHOLD 1024   // tiles with at least this many list entries are blended by 8 half-quadrant waves instead of 4 (multiple of 16)
+#endif
 #define MRGS_SORT_TILE 4096
 int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* hist, int64_t n, int bit_lo, int bit_hi,
                           hipStream_t stream);

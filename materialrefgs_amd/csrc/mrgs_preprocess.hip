@@ -356,10 +356,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
         for (int i = 0; i < 16; i++) { V[i] = viewmatrix[i]; PM[i] = projmatrix[i]; }
 #pragma unroll
         for (int i = 0; i < 9; i++) { dT[i] = gr[i]; dT_out[i] = dT[i]; }
-        const float m2x = gr[9], m2y = gr[10];
-        dop = gr[11];
-        const float dn[3] = {gr[12], gr[13], gr[14]};
-        dcol[0] = gr[15]; dcol[1] = gr[16]; dcol[2] = gr[17];
+        const int m2o = MRGS_G_M2(MRGS_SMAX(S));
+        const float m2x = gr[m2o], m2y = gr[m2o + 1];
+        dop = gr[MRGS_G_OPA];
+        const float dn[3] = {gr[MRGS_G_NRM], gr[MRGS_G_NRM + 1], gr[MRGS_G_NRM + 2]};
+        dcol[0] = gr[MRGS_G_COL]; dcol[1] = gr[MRGS_G_COL + 1]; dcol[2] = gr[MRGS_G_COL + 2];
 
         // rasterizer_impl.cu:398-399 and backward.cu:646-647: W,H are re-derived from the focal lengths
         const float focal_y = Himg / (2.0f * tanfovy), focal_x = Wimg / (2.0f * tanfovx);
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
         dL_dcolors[3 * (size_t)idx + c] = dcol[c];
         dL_dmeans3D[3 * (size_t)idx + c] = dm3[c];
     }
-    for (int c = 0; c < S; c++) dL_dfeatures[(size_t)idx * S + c] = live ? gr[18 + c] : 0.0f;
+    for (int c = 0; c < S; c++) dL_dfeatures[(size_t)idx * S + c] = live ? gr[MRGS_G_FEAT + c] : 0.0f;
     dL_dopacity[idx] = dop;
 #pragma unroll
     for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dT_out[i];

@@ -31,7 +31,59 @@ __device__ __forceinline__ void swap16_add(float& a, float b)   // rows: [a.r0+a
     const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-__device__ __forceinline__ float row_sum(float v)   // every lane of a 16-lane row gets the row total
+
+// ---- wave reduction of the per-lane gradient terms -------------------------------------------------------
+// K (multiple of 4) values per lane.  Two transposing swap stages (swap32_add, swap16_add) leave K/4 registers, each
+// holding in its rows 0..3 the 16-lane partial sums of values 4i, 4i+2, 4i+1, 4i+3.  The remaining 16 -> 1 reduction
+// inside the rows keeps transposing for two more steps: a DPP add whose bank_mask writes only half of the lanes
+// merges two registers into one while it halves the lane span (row_ror:8 into banks {0,1} | {2,3}, then
+// row_half_mirror into banks {0,2} | {1,3}), so that four registers (16 values) end up in ONE register in which
+// every quad of lanes holds the four partials of one value; two quad_perm adds finish.  8 DPP adds for 16 values
+// (the plain row reduction needs 16) and, more important, ONE atomic instruction whose 16 active lanes write 16
+// consecutive floats of the surfel's gradient row.
+//
+// The DPP steps are written as single asm blocks: the masked-write form (old lanes preserved) cannot be expressed
+// through __builtin_amdgcn_update_dpp + add, and inside a block the VALU-write -> DPP-read hazard (2 wait states)
+// is covered by the instruction order plus explicit s_nop (the compiler does not see hazards inside inline asm;
+// the leading s_nop covers the instruction that produced the inputs).
+__device__ __forceinline__ float rows_reduce4(float a0, float a1, float a2, float a3)
+{   // quad q = 4*row + bank of the result holds value 8*(bank&1) + 4*(bank>>1) + sub(row) of the 16
+    float t0, t1, u;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(t0), "=&v"(t1), "=&v"(u)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    return u;
+}
+__device__ __forceinline__ float rows_reduce2(float a0, float a1)
+{   // banks {0,1} of the result hold value 0 + sub(row), banks {2,3} value 4 + sub(row) of the 8
+    float t;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(t)
+        : "v"(a0), "v"(a1));
+    return t;
+}
+__device__ __forceinline__ float rows_reduce1(float v)   // every lane of a 16-lane row gets the row total
 {
     v = mrgs_dpp_add<0x128, 0xf>(v);   // row_ror:8
     v = mrgs_dpp_add<0x124, 0xf>(v);   // row_ror:4
@@ -40,33 +92,85 @@ __device__ __forceinline__ float row_sum(float v)   // every lane of a 16-lane r
     return v;
 }
 
-// Reduce K (multiple of 4) per-lane values over the wave and add them to dst[0..K).  After the two swap
-// stages register i holds, in its rows 0..3, the 16-lane partial sums of values 4i, 4i+2, 4i+1, 4i+3.
+// lane -> (float offset inside a 16-value group, writer flags) for the three block shapes above
+struct ReduceLane { uint32_t off16, off8, off4; bool w16, w8, w4; };   // offsets in bytes
+__device__ __forceinline__ ReduceLane mrgs_reduce_lane(int lane)
+{
+    const int row = lane >> 4, bank = (lane >> 2) & 3;
+    const int sub = ((row & 1) << 1) | (row >> 1);                  // rows 0,1,2,3 -> values +0,+2,+1,+3
+    ReduceLane r;
+    r.off16 = 4u * (uint32_t)(8 * (bank & 1) + 4 * (bank >> 1) + sub);
+    r.off8 = 4u * (uint32_t)(4 * (bank >> 1) + sub);
+    r.off4 = 4u * (uint32_t)sub;
+    r.w16 = (lane & 3) == 0;
+    r.w8 = (lane & 7) == 0;
+    r.w4 = (lane & 15) == 0;
+    return r;
+}
+
+// the per-lane address is formed as (wave-uniform base pointer) + (32-bit byte offset): one VALU add per atomic
+__device__ __forceinline__ void atomic_add_at(float* __restrict__ base, uint32_t byte_off, float v)
+{
+    atomicAdd((float*)((char*)base + byte_off), v);
+}
+
+// Reduce K per-lane values over the wave and add them to the K floats at base + row_off bytes (the surfel's gradient row).
 template <int K>
-__device__ __forceinline__ void wave_reduce_atomic_add(float (&v)[K], float* __restrict__ dst, int lane)
+__device__ __forceinline__ void wave_reduce_atomic_add(float (&v)[K], float* __restrict__ base, uint32_t row_off, const ReduceLane& rl)
 {
     static_assert(K % 4 == 0, "pad the value count to a multiple of 4");
 #pragma unroll
     for (int i = 0; i < K / 2; i++) swap32_add(v[2 * i], v[2 * i + 1]);      // result in v[2i]
 #pragma unroll
     for (int i = 0; i < K / 4; i++) swap16_add(v[4 * i], v[4 * i + 2]);      // result in v[4i]
-    const int row = lane >> 4;
-    const int sub = ((row & 1) << 1) | (row >> 1);                             // rows 0,1,2,3 -> values +0,+2,+1,+3
-    // the four row rotates run as K/4 independent chains interleaved step by step (a DPP operand needs two wait states after
-    // the VALU write that produced it: back-to-back steps of ONE chain would each cost an s_nop)
+    constexpr int N4 = K / 4;
+    constexpr int NB4 = N4 / 4;                 // blocks of four registers
+    constexpr int REM = N4 - 4 * NB4;           // 0..3 registers left
 #pragma unroll
-    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x128, 0xf>(v[4 * i]);   // row_ror:8
-#pragma unroll
-    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x124, 0xf>(v[4 * i]);   // row_ror:4
-#pragma unroll
-    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x122, 0xf>(v[4 * i]);   // row_ror:2
-#pragma unroll
-    for (int i = 0; i < K / 4; i++) v[4 * i] = mrgs_dpp_add<0x121, 0xf>(v[4 * i]);   // row_ror:1
-    if ((lane & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < K / 4; i++) atomicAdd(dst + 4 * i + sub, v[4 * i]);
+    for (int t = 0; t < NB4; t++) {
+        const float u = rows_reduce4(v[16 * t], v[16 * t + 4], v[16 * t + 8], v[16 * t + 12]);
+        if (rl.w16) atomic_add_at(base, row_off + (64u * t + rl.off16), u);
+    }
+    if (REM >= 2) {
+        const float u = rows_reduce2(v[16 * NB4], v[16 * NB4 + 4]);
+        if (rl.w8) atomic_add_at(base, row_off + (64u * NB4 + rl.off8), u);
+    }
+    if (REM == 1 || REM == 3) {
+        constexpr int vbase = 16 * NB4 + (REM == 3 ? 8 : 0);
+        const float u = rows_reduce1(v[vbase]);
+        if (rl.w4) atomic_add_at(base, row_off + (4u * vbase + rl.off4), u);
     }
 }
+
+// the dL/dmean2D pair of the low-pass-filter branch (backward.cu:407-413) is non-zero for few pairs: reduced apart,
+// and only when some lane of the wave took that branch
+__device__ __forceinline__ void wave_reduce_atomic_add2(float a, float b, float* __restrict__ base, uint32_t byte_off, int lane)
+{
+    swap32_add(a, b);                       // lanes 0..31: partials of a, lanes 32..63: partials of b
+    a = rows_reduce1(a);
+    // row_bcast:15 -- lane 15 of each row is added into the next row; rows 1 and 3 end up with the totals
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x142, 0xa, 0xf, false));
+    if ((lane & 31) == 16) atomic_add_at(base, byte_off + 4u * (uint32_t)(lane >> 5), a);
+}
+
+#ifdef MRGS_WAVE_STATS   // developer build only (tools/wave_stats.py): per-wave start/end time, iteration counts, placement
+__device__ unsigned long long g_wave_stats[6 * 65536];
+extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stats), sizeof(unsigned long long) * n);
+}
+#define WS_BEGIN() const unsigned long long ws_t0 = wall_clock64(), ws_c0 = __builtin_amdgcn_s_memtime(); unsigned ws_iters = 0, ws_act = 0, ws_chunks = 0;
+#define WS_ITER(a) { ws_iters++; ws_act += (a) ? 1 : 0; }
+#define WS_CHUNK() ws_chunks++;
+#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 6 * (size_t)b; w[0] = ws_t0; w[1] = wall_clock64(); \
+        w[2] = __builtin_amdgcn_s_memtime() - ws_c0; w[3] = ((unsigned long long)ws_iters << 32) | ws_act; w[4] = ((unsigned long long)ws_chunks << 32) | (unsigned)max_contrib; \
+        w[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+#else
+#define WS_BEGIN()
+#define WS_ITER(a)
+#define WS_CHUNK()
+#define WS_END()
+#endif
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 4 : S_MAX <= 8 ? 3 : 2, 8))) render_bwd_kernel(
@@ -76,27 +180,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
-    constexpr int K = (18 + S_MAX + 3) & ~3;
+    constexpr int K = 16 + S_MAX;   // values through the transposing reduction (the dL/dmean2D pair goes apart)
     __shared__ StageBuf<SF> stage[MRGS_BWD_STAGES];
 
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    // first half of the grid: one wave per quadrant; second half: the extra wave of each quadrant of a split tile (kept at the
-    // end of the grid so that the waves that exit at once do not alternate with working ones in the dispatch order)
-    const int nq = (int)(gridDim.x >> 1);
-    const int half = b >= nq ? 1 : 0;
-    const int bb = b - half * nq;
-    const int xcd = bb & 7, seq = bb >> 3;
-    const int tile = (int)tile_order[(seq >> 2) * 8 + xcd];   // longest lists first
-    const int quad = seq & 3;
-    if (tile >= ntiles) return;
+    BlendItem item;
+    if (!mrgs_decode_item(tile_order, ntiles, b, item)) return;
+    const int tile = item.tile, quad = item.quad, half = item.half;
+    const bool split = item.split;
     const uint2 range = ranges[tile];
-    // Eight waves are launched per tile.  A tile with a short list is blended by four of them (one 8x8 quadrant each, the
-    // other four exit here).  The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split
-    // into two 8x4 halves: each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical
-    // path at the price of idle lanes in a few waves.
-    const bool split = (int)(range.y - range.x) > MRGS_SPLIT_THRESHOLD;
-    if (!split && half) return;
+    // The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split into two 8x4 halves:
+    // each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical path at the price of
+    // idle lanes in a few waves.
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
     const int rows = split ? 4 : 8;
@@ -113,6 +209,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, d, 64));
     if (max_contrib == 0) return;
+    WS_BEGIN();
     // longest waves first in line for issue slots (see mrgs_render_fwd.hip)
     if (max_contrib > 768) __builtin_amdgcn_s_setprio(3);
     else if (max_contrib > 384) __builtin_amdgcn_s_setprio(2);
@@ -153,10 +250,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const float bg_dot_dpixel = fmaf(bg[2], dL_dpixel[2], fmaf(bg[1], dL_dpixel[1], bg[0] * dL_dpixel[0]));
 
     // chunks of 64 list entries, from the one holding position max_contrib-1 down to chunk 0; lane l <-> position 64c+l.
-    // Same staging pipeline as the forward (LDS-DMA double buffer, boxes two chunks and ids three chunks ahead), walked
-    // towards the front of the list.
+    // Same staging pipeline as the forward (LDS-DMA, cull conics two chunks and ids three chunks ahead), walked
+    // towards the front of the list.  The id slot of a staged entry holds the BYTE offset of the surfel's gradient row.
     const uint32_t* plist = point_list + range.x;
     const CullConic kNever = mrgs_cull_never();
+    const ReduceLane rl = mrgs_reduce_lane(lane);
+    const uint32_t row_bytes = (uint32_t)gstride * 4u;
     const int c_top = (max_contrib - 1) / MRGS_CHUNK;
     uint32_t id1 = 0, id2 = 0;
     CullConic box1 = kNever;
@@ -176,18 +275,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
         mask_cur = __ballot(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
-        if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0;
+        if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
     }
 
     for (int c = c_top; c >= 0; c--) {
         const int base = c * MRGS_CHUNK;
         mrgs_stage_wait();                    // chunk c has landed
+        WS_CHUNK();
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
             const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
             mask_nxt = __ballot(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
-            if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1;
+            if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
             id1 = id2;
             box1 = kNever;
             if (c >= 2) box1 = mrgs_cull_load(rec, id1);
@@ -197,116 +297,144 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 
         uint64_t mask = mask_cur;
         const StageBuf<SF>& sb = stage[c % MRGS_BWD_STAGES];
-        if (mask != 0ull) {
-        int j = 63 - __builtin_clzll(mask);   // back to front
-        SurfelGeom sg;
-        sg.g0 = sb.rec[0][j]; sg.g1 = sb.rec[1][j]; sg.g2 = sb.rec[2][j];
-        while (true) {
-            mask &= ~(1ull << j);
-            const bool more = mask != 0ull;
-            const int jn = more ? 63 - __builtin_clzll(mask) : j;
-            SurfelGeom nxt;
-            nxt.g0 = sb.rec[0][jn]; nxt.g1 = sb.rec[1][jn]; nxt.g2 = sb.rec[2][jn];
+
+        // One list entry.  The body is branch-free across lanes: a lane that does not contribute (no hit, outside the
+        // image, or behind the pixel's last contributor) runs it with alpha = 0, which leaves every running quantity
+        // bit-identical (T * rcp(1) = T; the accum_* recurrences absorb the pending term now and add 0 * x next time),
+        // and with the operands that could be non-finite for it (G, depth, 1/p.z, s) replaced, so that all of its
+        // gradient terms are exact zeros.  The 3D / low-pass-filter choice (backward.cu:380-413) is a select as well.
+        auto blend_entry = [&](const SurfelGeom& sg, int j) {
             const int contributor = base + j;           // 0-based list position; the forward's contributor is position+1
             Hit h;
             const bool hit = mrgs_intersect(sg, px, py, h);
-            const bool active = hit && inside && contributor < last_contributor;
-            if (__ballot(active) != 0ull) {
+            const bool active = hit & inside & (contributor < last_contributor);
+            const uint64_t amask = __builtin_amdgcn_ballot_w64(active);
+            WS_ITER(amask != 0ull);
+            if (amask == 0ull) return;
+            const bool use3d = h.rho3d <= h.rho2d;
+            const bool a3 = active & use3d;
+            const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
+            const float normal[3] = {a0.x, a0.y, a0.z};
+            const float col[3] = {a0.w, a1.x, a1.y};
+            const float alpha = active ? h.alpha : 0.0f;
+            const float G = active ? h.G : 0.0f;
+            const float c_d = active ? h.depth : 1.0f;
+            const float sx = a3 ? h.sx : 0.0f, sy = a3 ? h.sy : 0.0f;
+            const float inv_pz = a3 ? h.inv_pz : 0.0f;
 
             float g[K];
+            const float inv_1ma = mrgs_rcp(1.0f - alpha);
+            T = T * inv_1ma;                                   // backward.cu:330
+            const float w = alpha * T;
+            const float one_m_la = 1.0f - last_alpha;
+            float dL_dalpha = 0.0f;
 #pragma unroll
-            for (int i = 0; i < K; i++) g[i] = 0.f;
-            if (active) {
-                const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
-                const float normal[3] = {a0.x, a0.y, a0.z};
-                const float col[3] = {a0.w, a1.x, a1.y};
-                const float alpha = h.alpha, G = h.G, c_d = h.depth;
-                const float inv_1ma = mrgs_rcp(1.0f - alpha);
-                T = T * inv_1ma;                                   // backward.cu:330
-                const float w = alpha * T;
-                const float one_m_la = 1.0f - last_alpha;
-                float dL_dalpha = 0.0f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    accum_rec[ch] = fmaf(last_alpha, last_color[ch], one_m_la * accum_rec[ch]);
-                    last_color[ch] = col[ch];
-                    dL_dalpha = fmaf(col[ch] - accum_rec[ch], dL_dpixel[ch], dL_dalpha);
-                    g[15 + ch] = w * dL_dpixel[ch];
-                }
-                if (S_MAX > 0) {
-#pragma unroll
-                    for (int ch = 0; ch < S_MAX; ch++)
-                        if (ch < S) {
-                            const float f = sb.feat[ch][j];
-                            accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
-                            last_feature[ch] = f;
-                            dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
-                            g[18 + ch] = w * dL_dpixel_f[ch];
-                        }
-                }
-                const float inv_cd = mrgs_rcp(c_d);
-                const float m_d = mscale * (1.0f - MRGS_NEAR_N * inv_cd);
-                const float dmd_dd = dmd_scale * inv_cd * inv_cd;
-                float dL_dz = (contributor == median_contributor - 1) ? dL_dmedian_depth : 0.0f;
-                const float dL_dweight = fmaf(-2.0f * m_d, final_D, fmaf(m_d * m_d, final_A, final_D2)) * dL_dreg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = fmaf(dL_dweight, alpha, (1.0f - alpha) * last_dL_dT);
-                const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
-                dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
-                accum_depth_rec = fmaf(last_alpha, last_depth, one_m_la * accum_depth_rec);
-                last_depth = c_d;
-                dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
-                accum_alpha_rec = fmaf(one_m_la, accum_alpha_rec, last_alpha);
-                dL_dalpha = fmaf(1.0f - accum_alpha_rec, dL_daccum, dL_dalpha);
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    accum_normal_rec[ch] = fmaf(last_alpha, last_normal[ch], one_m_la * accum_normal_rec[ch]);
-                    last_normal[ch] = normal[ch];
-                    dL_dalpha = fmaf(normal[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
-                    g[12 + ch] = w * dL_dnormal2D[ch];
-                }
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha = fmaf(-T_final * inv_1ma, bg_dot_dpixel, dL_dalpha);
-                const float dL_dG = sg.g2.w * dL_dalpha;
-                dL_dz = fmaf(w, dL_ddepth, dL_dz);
-                if (h.rho3d <= h.rho2d) {
-                    const float Twx = sg.g1.z, Twy = sg.g1.w;
-                    const float dGn = dL_dG * -G;
-                    const float dL_dsx = fmaf(dGn, h.sx, dL_dz * Twx);
-                    const float dL_dsy = fmaf(dGn, h.sy, dL_dz * Twy);
-                    const float dpx = dL_dsx * h.inv_pz, dpy = dL_dsy * h.inv_pz;
-                    const float dpz = -fmaf(dpx, h.sx, dpy * h.sy);
-                    const float dkx = fmaf(h.ly, dpz, -(h.lz * dpy));   // cross(l, dL_dp)
-                    const float dky = fmaf(h.lz, dpx, -(h.lx * dpz));
-                    const float dkz = fmaf(h.lx, dpy, -(h.ly * dpx));
-                    const float dlx = fmaf(dpy, h.kz, -(dpz * h.ky));   // cross(dL_dp, k)
-                    const float dly = fmaf(dpz, h.kx, -(dpx * h.kz));
-                    const float dlz = fmaf(dpx, h.ky, -(dpy * h.kx));
-                    g[0] = -dkx; g[1] = -dky; g[2] = -dkz;
-                    g[3] = -dlx; g[4] = -dly; g[5] = -dlz;
-                    g[6] = fmaf(px, dkx, fmaf(py, dlx, dL_dz * h.sx));
-                    g[7] = fmaf(px, dky, fmaf(py, dly, dL_dz * h.sy));
-                    g[8] = fmaf(px, dkz, fmaf(py, dlz, dL_dz));
-                } else {
-                    const float dGf = -G * MRGS_FILTER_INV_SQUARE;
-                    g[9] = dL_dG * (dGf * h.dx);
-                    g[10] = dL_dG * (dGf * h.dy);
-                    g[8] = dL_dz;
-                }
-                g[11] = G * dL_dalpha;
+            for (int ch = 0; ch < 3; ch++) {
+                accum_rec[ch] = fmaf(last_alpha, last_color[ch], one_m_la * accum_rec[ch]);
+                last_color[ch] = col[ch];
+                dL_dalpha = fmaf(col[ch] - accum_rec[ch], dL_dpixel[ch], dL_dalpha);
+                g[MRGS_G_COL + ch] = w * dL_dpixel[ch];
             }
-            wave_reduce_atomic_add<K>(g, grad_rec + (size_t)sb.id[j] * gstride, lane);
+            if (S_MAX > 0) {
+#pragma unroll
+                for (int ch = 0; ch < S_MAX; ch++) {
+                    g[MRGS_G_FEAT + ch] = 0.0f;
+                    if (ch < S) {
+                        const float f = sb.feat[ch][j];
+                        accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
+                        last_feature[ch] = f;
+                        dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
+                        g[MRGS_G_FEAT + ch] = w * dL_dpixel_f[ch];
+                    }
+                }
             }
-            if (!more) break;
-            sg = nxt;
-            j = jn;
-        }
+            const float inv_cd = mrgs_rcp(c_d);
+            const float m_d = mscale * (1.0f - MRGS_NEAR_N * inv_cd);
+            const float dmd_dd = dmd_scale * inv_cd * inv_cd;
+            float dL_dz = (active & (contributor == median_contributor - 1)) ? dL_dmedian_depth : 0.0f;
+            const float dL_dweight = fmaf(-2.0f * m_d, final_D, fmaf(m_d * m_d, final_A, final_D2)) * dL_dreg;
+            dL_dalpha += dL_dweight - last_dL_dT;
+            last_dL_dT = fmaf(dL_dweight, alpha, (1.0f - alpha) * last_dL_dT);
+            const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
+            dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
+            accum_depth_rec = fmaf(last_alpha, last_depth, one_m_la * accum_depth_rec);
+            last_depth = c_d;
+            dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
+            accum_alpha_rec = fmaf(one_m_la, accum_alpha_rec, last_alpha);
+            dL_dalpha = fmaf(1.0f - accum_alpha_rec, dL_daccum, dL_dalpha);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                accum_normal_rec[ch] = fmaf(last_alpha, last_normal[ch], one_m_la * accum_normal_rec[ch]);
+                last_normal[ch] = normal[ch];
+                dL_dalpha = fmaf(normal[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
+                g[MRGS_G_NRM + ch] = w * dL_dnormal2D[ch];
+            }
+            dL_dalpha *= T;
+            last_alpha = alpha;
+            dL_dalpha = fmaf(-T_final * inv_1ma, bg_dot_dpixel, dL_dalpha);
+            dL_dalpha = active ? dL_dalpha : 0.0f;
+            const float dL_dG = sg.g2.w * dL_dalpha;
+            dL_dz = fmaf(w, dL_ddepth, dL_dz);
+            {   // ray/splat branch (zero for lanes in the low-pass branch: s = 0 and 1/p.z = 0 there)
+                const float Twx = sg.g1.z, Twy = sg.g1.w;
+                const float dGn = dL_dG * -G;
+                const float dL_dsx = fmaf(dGn, sx, dL_dz * Twx);
+                const float dL_dsy = fmaf(dGn, sy, dL_dz * Twy);
+                const float dpx = dL_dsx * inv_pz, dpy = dL_dsy * inv_pz;
+                const float dpz = -fmaf(dpx, sx, dpy * sy);
+                // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k); the rows of dL/dT need their negatives, which are
+                // formed directly (fma(-a, b, c*d) is the exact negative of fma(a, b, -(c*d)))
+                const float ndkx = fmaf(-h.ly, dpz, h.lz * dpy);
+                const float ndky = fmaf(-h.lz, dpx, h.lx * dpz);
+                const float ndkz = fmaf(-h.lx, dpy, h.ly * dpx);
+                const float ndlx = fmaf(-dpy, h.kz, dpz * h.ky);
+                const float ndly = fmaf(-dpz, h.kx, dpx * h.kz);
+                const float ndlz = fmaf(-dpx, h.ky, dpy * h.kx);
+                g[0] = ndkx; g[1] = ndky; g[2] = ndkz;
+                g[3] = ndlx; g[4] = ndly; g[5] = ndlz;
+                g[6] = fmaf(px, -ndkx, fmaf(py, -ndlx, dL_dz * sx));
+                g[7] = fmaf(px, -ndky, fmaf(py, -ndly, dL_dz * sy));
+                g[8] = fmaf(px, -ndkz, fmaf(py, -ndlz, dL_dz));
+            }
+            g[MRGS_G_OPA] = G * dL_dalpha;
+            const uint32_t row_off = sb.id[j];   // byte offset of the surfel's gradient row
+            wave_reduce_atomic_add<K>(g, grad_rec, row_off, rl);
+            const bool a2 = active & !use3d;
+            if (__builtin_amdgcn_ballot_w64(a2) != 0ull) {   // low-pass-filter branch: dL/dmean2D
+                const float dL_dG2 = a2 ? dL_dG : 0.0f;
+                const float dGf = -G * MRGS_FILTER_INV_SQUARE;
+                wave_reduce_atomic_add2(dL_dG2 * (dGf * h.dx), dL_dG2 * (dGf * h.dy), grad_rec, row_off + 4u * MRGS_G_M2(S_MAX), lane);
+            }
+        };
+
+        if (mask != 0ull) {
+            // back to front over the set bits; the geometry of the next entry is fetched from LDS while the current one
+            // is processed, in two alternating register sets (no copies at the loop edge)
+            int j = 63 - __builtin_clzll(mask);
+            SurfelGeom sA, sB;
+            sA.g0 = sb.rec[0][j]; sA.g1 = sb.rec[1][j]; sA.g2 = sb.rec[2][j];
+            while (true) {
+                mask &= ~(1ull << j);
+                bool more = mask != 0ull;
+                int jn = more ? 63 - __builtin_clzll(mask) : j;
+                sB.g0 = sb.rec[0][jn]; sB.g1 = sb.rec[1][jn]; sB.g2 = sb.rec[2][jn];
+                blend_entry(sA, j);
+                if (!more) break;
+                j = jn;
+                mask &= ~(1ull << j);
+                more = mask != 0ull;
+                jn = more ? 63 - __builtin_clzll(mask) : j;
+                sA.g0 = sb.rec[0][jn]; sA.g1 = sb.rec[1][jn]; sA.g2 = sb.rec[2][jn];
+                blend_entry(sB, j);
+                if (!more) break;
+                j = jn;
+            }
         }
         if (MRGS_BWD_STAGES == 1) stage_next();
         mask_cur = mask_nxt;
     }
     mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
+    WS_END();
 }
 
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,

@@ -36,22 +36,14 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const int lane = threadIdx.x;
     // XCD-aware mapping: b % 8 selects the XCD; within an XCD consecutive blocks are the 4 quadrants of one tile
     const int b = blockIdx.x;
-    // first half of the grid: one wave per quadrant; second half: the extra wave of each quadrant of a split tile (kept at the
-    // end of the grid so that the waves that exit at once do not alternate with working ones in the dispatch order)
-    const int nq = (int)(gridDim.x >> 1);
-    const int half = b >= nq ? 1 : 0;
-    const int bb = b - half * nq;
-    const int xcd = bb & 7, seq = bb >> 3;
-    const int tile = (int)tile_order[(seq >> 2) * 8 + xcd];   // longest lists first
-    const int quad = seq & 3;
-    if (tile >= ntiles) return;
+    BlendItem item;
+    if (!mrgs_decode_item(tile_order, ntiles, b, item)) return;
+    const int tile = item.tile, quad = item.quad, half = item.half;
+    const bool split = item.split;
     const uint2 range = ranges[tile];
-    // Eight waves are launched per tile.  A tile with a short list is blended by four of them (one 8x8 quadrant each, the
-    // other four exit here).  The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split
-    // into two 8x4 halves: each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical
-    // path at the price of idle lanes in a few waves.
-    const bool split = (int)(range.y - range.x) > MRGS_SPLIT_THRESHOLD;
-    if (!split && half) return;
+    // The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split into two 8x4 halves:
+    // each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical path at the price of
+    // idle lanes in a few waves.
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
     const int rows = split ? 4 : 8;

@@ -292,6 +292,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restric
     uint32_t tot;
     const uint32_t ex = block_exclusive_scan<1024>(tid < 256 ? hist[tid] : 0u, wave_sums, tot);
     if (tid < 256) hist[tid] = ex;
+    // number of leading tiles that the blend kernels split into half-quadrants (mrgs_decode_item)
+    if (tid == 256 - MRGS_SPLIT_THRESHOLD / 16) order[nslots] = ex;
     __syncthreads();
     for (int t = tid; t < ntiles; t += 1024) {
         const uint2 r = ranges[t];
