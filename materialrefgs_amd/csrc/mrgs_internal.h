@@ -72,7 +72,7 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
 // radix sort of (u32 key, u32 value) pairs on bits [bit_lo, bit_hi); returns index (0/1) of the buffer
 // that holds the sorted result.  hist must hold 256 * ceil(n / SORT_TILE) u32.
 #ifndef MRGS_SPLIT_THRESHOLD
-#define MRGS_SPLIT_THRESHOLD 1024   // tiles with at least this many list entries are blended by 8 half-quadrant waves instead of 4 (multiple of 16)
+#define MRGS_SPLIT_THRESHOLD 4080   // tiles with at least this many list entries are blended by 8 half-quadrant waves instead of 4 (multiple of 16, <= 4080)
 #endif
 #define MRGS_SORT_TILE 4096
 int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* hist, int64_t n, int bit_lo, int bit_hi,

@@ -223,7 +223,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 #pragma unroll
     for (int i = 0; i < SF; i++) { accum_rec_f[i] = 0.f; last_feature[i] = 0.f; dL_dpixel_f[i] = 0.f; }
     float dL_dreg = 0.f, dL_ddepth = 0.f, dL_daccum = 0.f, dL_dnormal2D[3] = {0.f, 0.f, 0.f}, dL_dmedian_depth = 0.f;
-    if (inside) {
+    // A pixel nothing was blended into takes no part in any sum; its upstream gradients are not even read (they may
+    // hold non-finite values, e.g. from a division by the zero accumulated alpha, and the entry body below multiplies
+    // the gradients of non-contributing lanes by exact zeros instead of branching around them).
+    if (inside && last_contributor > 0) {
         dL_ddepth = dL_dothers[0 * HW + pix];
         dL_daccum = dL_dothers[1 * HW + pix];
         dL_dnormal2D[0] = dL_dothers[2 * HW + pix];
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         }
         if (c_top >= 2) id2 = plist[(c_top - 2) * MRGS_CHUNK + lane];
         const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
-        mask_cur = __ballot(cand0);
+        mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
     }
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
             const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
-            mask_nxt = __ballot(cand1);
+            mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
             id1 = id2;

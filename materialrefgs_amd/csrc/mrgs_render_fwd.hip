@@ -91,18 +91,18 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         }
         if (2 * MRGS_CHUNK + lane < total) id2 = plist[2 * MRGS_CHUNK + lane];
         const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
-        mask_cur = __ballot(cand0);
+        mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[0], rec, features, S, id0, cand0);
     }
 
     for (int base = 0, c = 0; base < total; base += MRGS_CHUNK, c++) {
-        if (__ballot(!done) == 0ull) break;   // every pixel of the block has terminated (forward.cu:342-344, per wave)
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // every pixel of the block has terminated (forward.cu:342-344, per wave)
         mrgs_stage_wait();                    // chunk c has landed
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
             // stage chunk c+1 (its ids and boxes arrived during the previous iteration), prefetch box c+2 and ids c+3
             const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
-            mask_nxt = __ballot(cand1);
+            mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
             id1 = id2;
             box1 = kNever;
@@ -113,50 +113,69 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 
         uint64_t m = mask_cur;
         const StageBuf<SF>& sb = stage[c % MRGS_FWD_STAGES];
-        if (m != 0ull) {
-        int j = __builtin_ctzll(m);
-        SurfelGeom cur;
-        cur.g0 = sb.rec[0][j]; cur.g1 = sb.rec[1][j]; cur.g2 = sb.rec[2][j];
-        while (true) {
-            m &= m - 1;
-            const bool more = m != 0ull;
-            const int jn = more ? __builtin_ctzll(m) : j;
-            SurfelGeom nxt;                               // next surfel's geometry is fetched while this one is evaluated
-            nxt.g0 = sb.rec[0][jn]; nxt.g1 = sb.rec[1][jn]; nxt.g2 = sb.rec[2][jn];
-            const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
+
+        // One list entry (forward.cu:358-442).  Branch-free across lanes: a lane that does not blend this entry (no hit,
+        // pixel already terminated, or terminating right now) runs the accumulation with alpha = 0 -- every sum gets
+        // + x * 0 with a finite x, T gets * 1 -- and the depth, the only operand that can be non-finite for such a lane, is
+        // replaced.  The results are bit-identical to skipping the entry.
+        auto blend_entry = [&](const SurfelGeom& sg, int j) {
             Hit h;
-            const bool hit = mrgs_intersect(cur, px, py, h);
-            if (hit && !done) {
-                const float test_T = T * (1.0f - h.alpha);
-                if (test_T < MRGS_T_MIN) {
-                    done = true;
-                } else {
-                    const float w = h.alpha * T;
-                    const float A = 1.0f - T;
-                    const float m_ = mscale * (1.0f - MRGS_NEAR_N * mrgs_rcp(h.depth));
-                    const float mm = m_ * m_;
-                    // distortion += (m*m*A + M2 - 2*m*M1) * w   (forward.cu:412), fused as written here and in the oracle
-                    distortion = fmaf(fmaf(-2.0f * m_, M1, fmaf(mm, A, M2)), w, distortion);
-                    Dp = fmaf(h.depth, w, Dp);
-                    M1 = fmaf(m_, w, M1);
-                    M2 = fmaf(mm, w, M2);
-                    const uint32_t contributor = (uint32_t)(base + j + 1);
-                    if (T > 0.5f) { median_depth = h.depth; median_contributor = contributor; }
-                    N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
-                    C0 = fmaf(a0.w, w, C0); C1 = fmaf(a1.x, w, C1); C2 = fmaf(a1.y, w, C2);
-                    if (S_MAX > 0) {
+            const bool hit = mrgs_intersect(sg, px, py, h);
+            const bool ok = hit & !done;
+            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return;
+            const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
+            const float test_T = T * (1.0f - h.alpha);
+            const bool term = ok & (test_T < MRGS_T_MIN);     // forward.cu:400-404: the pixel stops BEFORE blending this entry
+            done |= term;
+            const bool upd = ok & !(test_T < MRGS_T_MIN);
+            const float alpha = upd ? h.alpha : 0.0f;
+            const float depth = upd ? h.depth : 1.0f;
+            const float w = alpha * T;
+            const float A = 1.0f - T;
+            const float m_ = mscale * (1.0f - MRGS_NEAR_N * mrgs_rcp(depth));
+            const float mm = m_ * m_;
+            // distortion += (m*m*A + M2 - 2*m*M1) * w   (forward.cu:412), fused as written here and in the oracle
+            distortion = fmaf(fmaf(-2.0f * m_, M1, fmaf(mm, A, M2)), w, distortion);
+            Dp = fmaf(depth, w, Dp);
+            M1 = fmaf(m_, w, M1);
+            M2 = fmaf(mm, w, M2);
+            const uint32_t contributor = (uint32_t)(base + j + 1);
+            const bool med = upd & (T > 0.5f);
+            median_depth = med ? depth : median_depth;
+            median_contributor = med ? contributor : median_contributor;
+            N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
+            C0 = fmaf(a0.w, w, C0); C1 = fmaf(a1.x, w, C1); C2 = fmaf(a1.y, w, C2);
+            if (S_MAX > 0) {
 #pragma unroll
-                        for (int ch = 0; ch < S_MAX; ch++)
-                            if (ch < S) F[ch] = fmaf(sb.feat[ch][j], w, F[ch]);
-                    }
-                    T = test_T;
-                    last_contributor = contributor;
-                }
+                for (int ch = 0; ch < S_MAX; ch++)
+                    if (ch < S) F[ch] = fmaf(sb.feat[ch][j], w, F[ch]);
             }
-            if (!more) break;
-            cur = nxt;
-            j = jn;
-        }
+            T = upd ? test_T : T;
+            last_contributor = upd ? contributor : last_contributor;
+        };
+
+        if (m != 0ull) {
+            // front to back over the set bits; the geometry of the next entry is fetched from LDS while the current one is
+            // evaluated, in two alternating register sets (no copies at the loop edge)
+            int j = __builtin_ctzll(m);
+            SurfelGeom sA, sB;
+            sA.g0 = sb.rec[0][j]; sA.g1 = sb.rec[1][j]; sA.g2 = sb.rec[2][j];
+            while (true) {
+                m &= m - 1;
+                bool more = m != 0ull;
+                int jn = more ? __builtin_ctzll(m) : j;
+                sB.g0 = sb.rec[0][jn]; sB.g1 = sb.rec[1][jn]; sB.g2 = sb.rec[2][jn];
+                blend_entry(sA, j);
+                if (!more) break;
+                j = jn;
+                m &= m - 1;
+                more = m != 0ull;
+                jn = more ? __builtin_ctzll(m) : j;
+                sA.g0 = sb.rec[0][jn]; sA.g1 = sb.rec[1][jn]; sA.g2 = sb.rec[2][jn];
+                blend_entry(sB, j);
+                if (!more) break;
+                j = jn;
+            }
         }
         if (MRGS_FWD_STAGES == 1) stage_next();
         mask_cur = mask_nxt;

@@ -129,6 +129,27 @@ def test_empty_scene_and_nothing_visible(gpu_device):
     assert all(float(np.abs(v).sum()) == 0 for v in g.values())
 
 
+def test_untouched_pixels_ignore_their_upstream_gradients(gpu_device):
+    """The reference never reads dL/dpixel of a pixel nothing was blended into (backward.cu:266 loops over contributors only), so
+    callers may leave NaN/inf there (e.g. depth / alpha with alpha = 0).  The blend backward must give the same gradients."""
+    S, H, W = 3, 96, 96
+    scene = make_shell_scene(400, S=S, seed=5, radius_px=4.0, image_size=96)
+    cam = orbit_camera(2, H, W)
+    hr = HipRender(scene, cam, gpu_device)
+    empty = torch.from_numpy(hr.export("n_contrib")[0] == 0)
+    assert 0.05 < float(empty.float().mean()) < 0.95
+    g_color, g_feat, g_others = upstream_grads(S, H, W)
+    clean = hr.backward(g_color, g_feat, g_others)
+    hr2 = HipRender(scene, cam, gpu_device)
+    bad = [g.clone() for g in (g_color, g_feat, g_others)]
+    for i, g in enumerate(bad):
+        g[:, empty] = float("nan") if i != 1 else float("inf")
+    poisoned = hr2.backward(*bad)
+    for k in clean:
+        assert np.isfinite(poisoned[k]).all(), k
+        assert rel_err(poisoned[k], clean[k]) <= 1e-5, k   # atomics: summation order differs between runs
+
+
 def test_mark_visible(gpu_device):
     from materialrefgs_amd.rasterizer import GaussianRasterizer
     from helpers import raster_settings
