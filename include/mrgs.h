@@ -33,7 +33,8 @@ enum {
     MRGS_E_NEED_COLORS = 3,   /* neither SH nor precomputed colours (rasterizer_impl.cu:248-251) */
     MRGS_E_HIP = 4,           /* a HIP runtime call failed; see mrgs_last_hip_error() */
     MRGS_E_WORKSPACE = 5,     /* workspace too small for this call */
-    MRGS_E_UNSUPPORTED = 6
+    MRGS_E_UNSUPPORTED = 6,
+    MRGS_E_INTERNAL = 7       /* a bounded device-side wait overran (binning look-back); results were not written */
 };
 
 /* Scalar arguments shared by forward and backward; mirrors GaussianRasterizationSettings

@@ -77,7 +77,6 @@ MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
     Carver c(base);
     MrgsGeomWs g;
     const size_t n = (size_t)(P > 0 ? P : 1);
-    const size_t nblk = (n + MRGS_SORT_TILE - 1) / MRGS_SORT_TILE;
     g.rec = c.take<float4>(n * MRGS_REC_F4);
     g.depth_key[0] = c.take<uint32_t>(n);
     g.depth_key[1] = c.take<uint32_t>(n);
@@ -87,9 +86,11 @@ MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
     g.tiles_touched = c.take<uint32_t>(n);
     g.offsets = c.take<uint32_t>(n);
     g.clamped = c.take<uint8_t>(n);
-    g.sort_hist = c.take<uint32_t>(256 * nblk);
-    g.scan_tmp = c.take<uint32_t>((n + 2047) / 2048 + 1);
     g.counters = c.take<uint32_t>(16);
+    const size_t clear_from = c.used - 16 * sizeof(uint32_t);
+    g.sort_ws = c.take<uint32_t>(mrgs_sort_ws_words((int64_t)n));
+    g.scan_ws = c.take<uint32_t>(mrgs_scan_ws_words((int)n));
+    g.clear_bytes = c.used - clear_from;
     g.total = mrgs_align_up(c.used, 256);
     return g;
 }
@@ -113,12 +114,12 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R)
     Carver c(base);
     MrgsBinWs b;
     const size_t n = (size_t)(R > 0 ? R : 1);
-    const size_t nblk = (n + MRGS_SORT_TILE - 1) / MRGS_SORT_TILE;
     b.tile_key[0] = c.take<uint32_t>(n);
     b.tile_key[1] = c.take<uint32_t>(n);
     b.plist[0] = c.take<uint32_t>(n);
     b.plist[1] = c.take<uint32_t>(n);
-    b.sort_hist = c.take<uint32_t>(256 * nblk);
+    b.sort_ws = c.take<uint32_t>(16 + mrgs_sort_ws_words((int64_t)n));
+    b.sort_ws_bytes = sizeof(uint32_t) * (16 + mrgs_sort_ws_words((int64_t)n));
     b.total = mrgs_align_up(c.used, 256);
     return b;
 }
@@ -173,23 +174,26 @@ int mrgs_rasterize_forward_geom(const MrgsRasterConfig* cfg, const MrgsRasterInp
     if (geom_bytes < g.total) return MRGS_E_WORKSPACE;
 
     StageTimer t0(stream, ST_PRE);
+    HIP_TRY(hipMemsetAsync(g.counters, 0, g.clear_bytes, stream));   // counters + look-back state of the sort and the scan
     mrgs_launch_preprocess_fwd(*cfg, *in, g, radii, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
     StageTimer t1(stream, ST_SORT);
     // depth sort of the gaussians (32 key bits, 4 passes -> result back in buffer 0)
-    const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_hist, cfg->P, 0, 32, stream);
+    const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_ws, g.counters + 1, cfg->P, 0, 32, stream);
     STAGE_CHECK(cfg, stream);
-    mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_tmp, g.counters, cfg->P, stream);
+    mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_ws, g.counters, g.counters + 1, cfg->P, stream);
     t1.stop();
     STAGE_CHECK(cfg, stream);
 
-    // blocking 4-byte read-back of num_rendered, as rasterizer_impl.cu:287
-    uint32_t R = 0;
-    HIP_TRY(hipMemcpyAsync(&R, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    // blocking read-back of num_rendered, as rasterizer_impl.cu:287 (plus the error flag of the look-back kernels)
+    uint32_t host[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host, g.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    *num_rendered_host = (int64_t)R;
+    if (host[1] != 0) return MRGS_E_INTERNAL;
+    if (host[0] >= (1u << 30)) return MRGS_E_UNSUPPORTED;   // pair counts are carried in 30 bits by the binning kernels
+    *num_rendered_host = (int64_t)host[0];
     return MRGS_OK;
 }
 
@@ -219,10 +223,11 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
     const int dcur = sorted_buf(32);
 
     StageTimer t0(stream, ST_DUP);
+    HIP_TRY(hipMemsetAsync(b.sort_ws, 0, b.sort_ws_bytes, stream));
     if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], stream);
     STAGE_CHECK(cfg, stream);
     const int bits = tile_bits(ntiles);
-    const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_hist, R, 0, bits, stream);
+    const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, 0, bits, stream);
     STAGE_CHECK(cfg, stream);
     mrgs_launch_tile_ranges(b.tile_key[cur], R, img.ranges, img.tile_order, ntiles, stream);
     t0.stop();
@@ -371,6 +376,7 @@ const char* mrgs_strerror(int code)
     case MRGS_E_HIP: return "HIP runtime error (see mrgs_last_hip_error)";
     case MRGS_E_WORKSPACE: return "workspace too small";
     case MRGS_E_UNSUPPORTED: return "unsupported configuration";
+    case MRGS_E_INTERNAL: return "device-side wait overran in the binning kernels";
     default: return "unknown error";
     }
 }

@@ -43,9 +43,11 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
     uint32_t* tiles_touched;// [P]
     uint32_t* offsets;      // [P] exclusive scan of tiles_touched in depth-sorted order
     uint8_t* clamped;       // [P] bit c set when SH colour channel c was clamped
-    uint32_t* sort_hist;    // [256 * nblk_max] per-block digit histograms / offsets of the radix passes
-    uint32_t* scan_tmp;     // [nblk] block sums of the tiles_touched scan
-    uint32_t* counters;     // [16] 0: num_rendered, 1: which depth buffer holds the sorted order
+    // cleared at the start of every forward (one memset over [counters, scan_ws end)):
+    uint32_t* counters;     // [16] 0: num_rendered, 1: error flag of the look-back kernels
+    uint32_t* sort_ws;      // tickets / digit totals / status words of the depth sort (mrgs_sort_ws_words)
+    uint32_t* scan_ws;      // ticket / status words of the tiles_touched scan (mrgs_scan_ws_words)
+    size_t clear_bytes;     // size of the region that starts at counters
     size_t total;
 };
 
@@ -60,7 +62,8 @@ struct MrgsImgWs {
 struct MrgsBinWs {
     uint32_t* tile_key[2];  // [R] ping-pong: tile id of each pair
     uint32_t* plist[2];     // [R] ping-pong: gaussian index of each pair
-    uint32_t* sort_hist;    // [256 * nblk]
+    uint32_t* sort_ws;      // [16] 0: error flag; then tickets / digit totals / status words of the tile-id sort; cleared per forward
+    size_t sort_ws_bytes;
     size_t total;
 };
 
@@ -74,12 +77,16 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
 #ifndef MRGS_SPLIT_THRESHOLD
 #define MRGS_SPLIT_THRESHOLD 4080   // tiles with at least this many list entries are blended by 8 half-quadrant waves instead of 4 (multiple of 16, <= 4080)
 #endif
-#define MRGS_SORT_TILE 4096
-int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* hist, int64_t n, int bit_lo, int bit_hi,
+#define MRGS_SORT_WS_HEADER 16
+// stable LSD radix sort of (key, value) pairs on key bits [bit_lo, bit_hi); returns the index of the buffer holding the
+// result.  ws: mrgs_sort_ws_words(n) zeroed words; *error_flag is set if a look-back spin overruns (never expected).
+size_t mrgs_sort_ws_words(int64_t n);
+int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint32_t* error_flag, int64_t n, int bit_lo, int bit_hi,
                           hipStream_t stream);
-// exclusive scan of tiles_touched[order[i]] -> offsets[i]; total -> *total_out (device)
-void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* block_sums,
-                     uint32_t* total_out, int n, hipStream_t stream);
+// exclusive scan of tiles_touched[order[i]] -> offsets[i]; total -> *total_out (device); ws: mrgs_scan_ws_words(n) zeroed words
+size_t mrgs_scan_ws_words(int n);
+void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* ws, uint32_t* total_out,
+                     uint32_t* error_flag, int n, hipStream_t stream);
 
 void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, int32_t* radii,
                                 hipStream_t stream);

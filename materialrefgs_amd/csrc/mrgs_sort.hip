@@ -14,27 +14,60 @@
 
 #define SORT_THREADS 256
 #define SORT_WAVES (SORT_THREADS / 64)
-#define SORT_ITERS (MRGS_SORT_TILE / SORT_THREADS)
-#define RADIX_FUSED_MAX_BLOCKS 1024
+
+// Each radix pass is ONE kernel ("onesweep" structure): a workgroup ranks its tile of keys locally, publishes its per-digit
+// counts, obtains the counts of all preceding tiles by a decoupled look-back over the published status words, and
+// scatters.  The only other launch is one kernel that histograms every digit position of all keys up front (digit totals
+// do not depend on the order of the keys).  Against a histogram + scatter pair per pass this halves the launches and
+// reads the keys once per pass; with 1024-key tiles a 300k-key pass fills the chip (293 workgroups) instead of 74.
+//
+// Look-back protocol (placement-independent, as the MI355X guide requires): a workgroup takes its tile index from an
+// atomic ticket, so "lower tile index" implies "started earlier"; status word = state << 30 | count, written and read with
+// agent-scope atomics (the word carries its own payload, no second location has to be ordered); tile 0 publishes an
+// inclusive prefix straight away, which ends every look-back.  Spins are bounded: on overrun the workgroup raises the
+// error flag of the sort workspace and leaves without writing.
+#define OS_STATE_AGG 1u
+#define OS_STATE_INC 2u
+#define OS_VALUE_MASK 0x3FFFFFFFu
+#define OS_SPIN_LIMIT (1 << 24)
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
-// ---- radix pass 1/3: per-block digit histogram ----------------------------------------------------
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist,
-                                                                  int64_t n, int shift, int nblk)
+__device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void os_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sum of the published counts of tiles [0, blk) for the caller's column; false on spin overrun.  The status words of
+// OS_WINDOW predecessors are fetched together (independent loads in flight) and consumed nearest-first: a walk that had
+// to take one dependent memory round trip per predecessor made the passes latency-bound.
+#define OS_WINDOW 8
+__device__ __forceinline__ bool os_look_back(const uint32_t* __restrict__ status, int stride, int column, int blk, uint32_t& excl)
 {
-    __shared__ uint32_t h[256];
-    const int tid = threadIdx.x;
-    h[tid] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * MRGS_SORT_TILE;
-#pragma unroll 4
-    for (int it = 0; it < SORT_ITERS; it++) {
-        const int64_t idx = base + it * SORT_THREADS + tid;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+    excl = 0;
+    int spins = 0;
+    int p = blk - 1;
+    while (p >= 0) {
+        uint32_t s[OS_WINDOW];
+#pragma unroll
+        for (int k = 0; k < OS_WINDOW; k++) s[k] = os_load(status + (size_t)max(p - k, 0) * stride + column);
+        bool stalled = false;
+#pragma unroll
+        for (int k = 0; k < OS_WINDOW; k++) {
+            if (!stalled && p >= 0) {
+                const uint32_t st = s[k] >> 30;
+                if (st == 0u) {
+                    stalled = true;             // not published yet: poll again from here
+                } else {
+                    excl += s[k] & OS_VALUE_MASK;
+                    p = (st == OS_STATE_INC) ? -1 : p - 1;
+                }
+            }
+        }
+        if (stalled) {
+            if (++spins > OS_SPIN_LIMIT) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
-    __syncthreads();
-    hist[(size_t)blockIdx.x * 256 + tid] = h[tid];   // block-major: digit d of consecutive blocks is read coalesced
+    return true;
 }
 
 // ---- block-wide exclusive scan helper (wave64 shuffles + one LDS hop) ----------------------------------
@@ -62,148 +95,180 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return wave_off + inc - v;
 }
 
-// ---- radix pass 2/3: exclusive scan of the digit-major histogram (single workgroup) ------------------
-// (only used for very large inputs, nblk > RADIX_FUSED_MAX_BLOCKS; otherwise the scatter kernel derives its offsets itself)
-__global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk)
+// ---- digit totals of every pass in one sweep over the keys ----------------------------------------------
+template <int NPASS>
+__global__ void __launch_bounds__(SORT_THREADS) radix_totals_kernel(const uint32_t* __restrict__ keys, int64_t n, int bit_lo,
+                                                                    uint32_t* __restrict__ totals /*[NPASS][256]*/)
 {
-    __shared__ uint32_t wave_sums[16];
-    uint32_t carry = 0;
-    const int total = 256 * nblk;
-    for (int base = 0; base < total; base += 1024) {
-        const int i = base + threadIdx.x;                       // digit-major scan order over the block-major matrix
-        const size_t at = i < total ? (size_t)(i % nblk) * 256 + (size_t)(i / nblk) : 0;
-        uint32_t v = i < total ? hist[at] : 0u;
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan<1024>(v, wave_sums, tot);
-        if (i < total) hist[at] = carry + ex;
-        carry += tot;
+    __shared__ uint32_t h[NPASS][256];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < NPASS; p++) h[p][tid] = 0;
+    __syncthreads();
+    for (int64_t idx = (int64_t)blockIdx.x * SORT_THREADS + tid; idx < n; idx += (int64_t)gridDim.x * SORT_THREADS) {
+        const uint32_t k = keys[idx];
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) atomicAdd(&h[p][(k >> (bit_lo + 8 * p)) & 255u], 1u);
     }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPASS; p++)
+        if (h[p][tid] != 0u) atomicAdd(&totals[p * 256 + tid], h[p][tid]);
 }
 
-// ---- radix pass 3/3: stable scatter; in-wave ranks from 8 ballots (wave64 multi-split) ---------------
-__global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                                     uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                                     const uint32_t* __restrict__ offs, int64_t n, int shift, int nblk,
-                                                                     int fused)
+// ---- one stable radix pass; in-wave ranks from 8 ballots (wave64 multi-split) -----------------------------
+// Wave w of the workgroup owns ITEMS consecutive runs of 64 keys; all counters it touches while ranking are its own
+// (whist[w]), so the ranking loop has no barrier: lanes of one wave execute LDS instructions in program order.
+template <int ITEMS>
+__global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                                      uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                                      const uint32_t* __restrict__ totals, uint32_t* __restrict__ status,
+                                                                      uint32_t* __restrict__ ticket, uint32_t* __restrict__ error_flag,
+                                                                      int64_t n, int shift)
 {
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t wcnt[SORT_WAVES][256];
+    __shared__ uint32_t whist[SORT_WAVES][256];
+    __shared__ uint32_t start[256];
     __shared__ uint32_t scan_tmp[SORT_WAVES];
+    __shared__ uint32_t s_blk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (fused) {
-        // offs is the raw block-major histogram matrix: this block's start for digit d is
-        //   sum_{d' < d} total[d'] + sum_{b' < b} hist[b'][d]   -- nblk coalesced loads per thread, no separate scan launch
-        uint32_t below = 0, total = 0;
-        const int me = blockIdx.x;
-#pragma unroll 8
-        for (int bb = 0; bb < nblk; bb++) {
-            const uint32_t v = offs[(size_t)bb * 256 + tid];
-            total += v;
-            below += bb < me ? v : 0u;
-        }
-        uint32_t tot;
-        running[tid] = block_exclusive_scan<SORT_THREADS>(total, scan_tmp, tot) + below;
-    } else {
-        running[tid] = offs[(size_t)blockIdx.x * 256 + tid];
+    if (tid == 0) s_blk = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; w++) whist[w][tid] = 0;
+    __syncthreads();
+    const int blk = (int)s_blk;
+    const int64_t wbase = (int64_t)blk * (SORT_THREADS * ITEMS) + (int64_t)wave * (64 * ITEMS) + lane;
+    const uint64_t lt = lanemask_lt();
+
+    uint32_t key[ITEMS], val[ITEMS], off[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int64_t idx = wbase + it * 64;
+        const bool valid = idx < n;
+        key[it] = valid ? kin[idx] : 0xFFFFFFFFu;
+        val[it] = valid ? vin[idx] : 0u;
     }
 #pragma unroll
-    for (int w = 0; w < SORT_WAVES; w++) wcnt[w][tid] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * MRGS_SORT_TILE;
-    const uint64_t lt = lanemask_lt();
-    for (int it = 0; it < SORT_ITERS; it++) {
-        const int64_t idx = base + it * SORT_THREADS + tid;
-        const bool valid = idx < n;
-        const uint32_t key = valid ? kin[idx] : 0xFFFFFFFFu;
-        const uint32_t val = valid ? vin[idx] : 0u;
-        const uint32_t d = (key >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
+    for (int it = 0; it < ITEMS; it++) {
+        const bool valid = wbase + it * 64 < n;
+        const uint32_t d = (key[it] >> shift) & 255u;
+        uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(bit);
             peers &= bit ? m : ~m;
         }
         const uint32_t rank = __popcll(peers & lt);
-        if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = running[d] + rank;
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; w++)
-                if (w < wave) pos += wcnt[w][d];
-            kout[pos] = key;
-            vout[pos] = val;
-        }
-        __syncthreads();
-        uint32_t s = 0;
-#pragma unroll
-        for (int w = 0; w < SORT_WAVES; w++) { s += wcnt[w][tid]; wcnt[w][tid] = 0; }
-        running[tid] += s;
-        __syncthreads();
+        const uint32_t prev = whist[wave][d];              // keys of this digit in the wave's earlier runs
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) whist[wave][d] = prev + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        off[it] = prev + rank;
     }
-    (void)lane;
+    __syncthreads();
+
+    // thread = digit: tile count, exclusive prefix over the waves (kept in whist), look-back over the preceding tiles
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; w++) {
+        const uint32_t c = whist[w][tid];
+        whist[w][tid] = cnt;
+        cnt += c;
+    }
+    uint32_t* mine = status + (size_t)blk * 256 + tid;
+    uint32_t excl = 0;
+    bool ok = true;
+    if (blk == 0) {
+        os_store(mine, (OS_STATE_INC << 30) | cnt);
+    } else {
+        os_store(mine, (OS_STATE_AGG << 30) | cnt);
+        ok = os_look_back(status, 256, tid, blk, excl);
+        if (ok) os_store(mine, (OS_STATE_INC << 30) | (excl + cnt));
+    }
+    uint32_t all;
+    const uint32_t digit_base = block_exclusive_scan<SORT_THREADS>(totals[tid], scan_tmp, all);
+    start[tid] = digit_base + excl;
+    if (__syncthreads_or(!ok)) {
+        if (tid == 0) atomicExch(error_flag, 1u);
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        if (wbase + it * 64 < n) {
+            const uint32_t d = (key[it] >> shift) & 255u;
+            const uint32_t pos = start[d] + whist[wave][d] + off[it];
+            kout[pos] = key[it];
+            vout[pos] = val[it];
+        }
+    }
 }
 
-int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* hist, int64_t n, int bit_lo, int bit_hi,
+// tile size of the passes for n keys: enough workgroups to fill 256 CUs for small inputs, longer tiles (shorter look-back
+// chains, fewer status words) for large ones
+static int sort_items(int64_t n) { return n <= (600 << 10) ? 4 : n <= (2400 << 10) ? 8 : 16; }
+
+size_t mrgs_sort_ws_words(int64_t n)
+{
+    const int64_t nblk = (n + 1023) / 1024 + 1;
+    return (size_t)(MRGS_SORT_WS_HEADER + 4 * 256 + 4 * 256 * nblk);
+}
+
+// ws must be zero on entry (the caller clears it together with its other per-call state); layout: [0..3] tickets of the
+// passes, then digit totals [4][256], then status words [passes][nblk][256]
+int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint32_t* error_flag, int64_t n, int bit_lo, int bit_hi,
                           hipStream_t stream)
 {
     int cur = 0;
-    if (n <= 0) return cur;
-    const int nblk = (int)((n + MRGS_SORT_TILE - 1) / MRGS_SORT_TILE);
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_THREADS), 0, stream, key[cur], hist, n, shift, nblk);
-        const int fused = nblk <= RADIX_FUSED_MAX_BLOCKS;
-        if (!fused) hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, nblk);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_THREADS), 0, stream, key[cur], val[cur], key[cur ^ 1],
-                           val[cur ^ 1], hist, n, shift, nblk, fused);
+    if (n <= 0 || bit_hi <= bit_lo) return cur;
+    const int npass = (bit_hi - bit_lo + 7) / 8;
+    const int items = sort_items(n);
+    const int tile = SORT_THREADS * items;
+    const int nblk = (int)((n + tile - 1) / tile);
+    uint32_t* tickets = ws;
+    uint32_t* totals = ws + MRGS_SORT_WS_HEADER;
+    uint32_t* status = totals + 4 * 256;
+    const int tblk = (int)((n + 4095) / 4096 < 1024 ? (n + 4095) / 4096 : 1024);
+    switch (npass) {
+    case 1: hipLaunchKernelGGL(radix_totals_kernel<1>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
+    case 2: hipLaunchKernelGGL(radix_totals_kernel<2>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
+    case 3: hipLaunchKernelGGL(radix_totals_kernel<3>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
+    default: hipLaunchKernelGGL(radix_totals_kernel<4>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
+    }
+    for (int p = 0; p < npass; p++) {
+        const int shift = bit_lo + 8 * p;
+        uint32_t* st = status + (size_t)p * nblk * 256;
+#define OS_LAUNCH(IT)                                                                                                        \
+    hipLaunchKernelGGL(radix_onesweep_kernel<IT>, dim3(nblk), dim3(SORT_THREADS), 0, stream, key[cur], val[cur], key[cur ^ 1], \
+                       val[cur ^ 1], totals + p * 256, st, tickets + p, error_flag, n, shift)
+        if (items == 4) OS_LAUNCH(4);
+        else if (items == 8) OS_LAUNCH(8);
+        else OS_LAUNCH(16);
+#undef OS_LAUNCH
         cur ^= 1;
     }
     return cur;
 }
 
 // ---- exclusive scan of tiles_touched in depth-sorted order (rasterizer_impl.cu:283, InclusiveSum) -----
+// One kernel, same look-back protocol with one status word per workgroup (64-bit: the total may need 31 bits).
 #define SCAN_THREADS 256
 #define SCAN_PER_THREAD 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_PER_THREAD)
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(const uint32_t* __restrict__ tiles_touched,
-                                                                       const uint32_t* __restrict__ order,
-                                                                       uint32_t* __restrict__ block_sums, int n)
-{
-    __shared__ uint32_t wave_sums[SCAN_THREADS / 64];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; k++)
-        if (base + k < n) s += tiles_touched[order[base + k]];
-    uint32_t tot;
-    block_exclusive_scan<SCAN_THREADS>(s, wave_sums, tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t* __restrict__ block_sums, int nblk, uint32_t* __restrict__ total_out)
-{
-    __shared__ uint32_t wave_sums[16];
-    uint32_t carry = 0;
-    for (int base = 0; base < nblk; base += 1024) {
-        const int i = base + threadIdx.x;
-        uint32_t v = i < nblk ? block_sums[i] : 0u;
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan<1024>(v, wave_sums, tot);
-        if (i < nblk) block_sums[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) *total_out = carry;
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) scan_final_kernel(const uint32_t* __restrict__ tiles_touched,
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(const uint32_t* __restrict__ tiles_touched,
                                                                   const uint32_t* __restrict__ order,
-                                                                  const uint32_t* __restrict__ block_sums,
-                                                                  uint32_t* __restrict__ offsets, int n)
+                                                                  uint32_t* __restrict__ offsets, unsigned long long* __restrict__ status,
+                                                                  uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out,
+                                                                  uint32_t* __restrict__ error_flag, int n, int nblk)
 {
     __shared__ uint32_t wave_sums[SCAN_THREADS / 64];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    __shared__ uint32_t s_blk;
+    __shared__ unsigned long long s_excl;
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) s_blk = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int blk = (int)s_blk;
+    const int base = blk * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
     uint32_t v[SCAN_PER_THREAD], s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; k++) {
@@ -211,7 +276,55 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_final_kernel(const uint32_t
         s += v[k];
     }
     uint32_t tot;
-    uint32_t ex = block_exclusive_scan<SCAN_THREADS>(s, wave_sums, tot) + block_sums[blockIdx.x];
+    uint32_t ex = block_exclusive_scan<SCAN_THREADS>(s, wave_sums, tot);
+    if (threadIdx.x < 64) {
+        // wave 0 looks back over 64 predecessors per step: lane l reads the status of tile p - l
+        const unsigned long long AGG = 1ull << 62, INC = 2ull << 62, MASK = (1ull << 62) - 1;
+        const int lane = threadIdx.x;
+        unsigned long long excl = 0;
+        bool ok = true;
+        if (blk == 0) {
+            if (lane == 0) __hip_atomic_store(status, INC | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(status + blk, AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            int p = blk - 1;
+            while (p >= 0) {
+                const int q = p - lane;
+                const unsigned long long w = q >= 0 ? __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INC;
+                const unsigned long long st = w >> 62;
+                const uint64_t m_inc = __builtin_amdgcn_ballot_w64(st == 2ull);
+                const uint64_t m_zero = __builtin_amdgcn_ballot_w64(st == 0ull);
+                // usable lanes: everything nearer than the first unpublished one, up to and including the first inclusive one
+                const int first_zero = m_zero ? __builtin_ctzll(m_zero) : 64;
+                const int first_inc = m_inc ? __builtin_ctzll(m_inc) : 64;
+                const int take = min(first_zero, first_inc + 1);       // lanes [0, take)
+                unsigned long long part = (lane < take && q >= 0) ? (w & MASK) : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (first_inc < first_zero) break;                      // reached an inclusive prefix
+                p -= take;
+                if (take == 0) {
+                    if (++spins > OS_SPIN_LIMIT) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (ok && lane == 0) __hip_atomic_store(status + blk, INC | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            s_ok = ok ? 1 : 0;
+            if (!ok) atomicExch(error_flag, 1u);
+            if (ok && blk == nblk - 1) {
+                const unsigned long long total = excl + tot;
+                *total_out = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;   // saturates; the host rejects >= 2^30
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    ex += (uint32_t)s_excl;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; k++) {
         if (base + k < n) offsets[base + k] = ex;
@@ -219,13 +332,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_final_kernel(const uint32_t
     }
 }
 
-void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* block_sums,
-                     uint32_t* total_out, int n, hipStream_t stream)
+size_t mrgs_scan_ws_words(int n) { return 2 * (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1) + 2; }
+
+// ws (zero on entry): [0] ticket, [1] pad, then 64-bit status words
+void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* ws, uint32_t* total_out,
+                     uint32_t* error_flag, int n, hipStream_t stream)
 {
     const int nblk = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, stream, tiles_touched, order, block_sums, n);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nblk, total_out);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, stream, tiles_touched, order, block_sums, offsets, n);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, stream, tiles_touched, order, offsets,
+                       (unsigned long long*)(ws + 2), ws, total_out, error_flag, n, nblk);
 }
 
 // ---- pair emission (duplicateWithKeys, rasterizer_impl.cu:72-113) in depth-sorted gaussian order -------
