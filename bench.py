@@ -158,7 +158,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    L.mrgs_set_profiling(1)
+    L.mrgs_set_profiling(2)      # HIP events around the two blend kernels only (the dominant one feeds `roofline`)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -166,6 +166,13 @@ def main():
     elapsed = time.perf_counter() - t0
     times = MrgsKernelTimes()
     L.mrgs_get_kernel_times(times)
+    # per-stage breakdown (diagnostic `stage_ms`): a few extra, untimed steps with an event pair around every stage
+    L.mrgs_set_profiling(1)
+    for i in range(min(args.steps, 10)):
+        step(args.warmup + args.steps + i)
+    fence()
+    stage_times = MrgsKernelTimes()
+    L.mrgs_get_kernel_times(stage_times)
     L.mrgs_set_profiling(0)
 
     if world > 1:
@@ -185,8 +192,9 @@ def main():
     }
     if rank == 0:
         R, HW = int(state["R"]), H * W
-        stage_ms = {"preprocess_fwd": times.preprocess_ms, "depth_sort_scan": times.sort_ms, "duplicate_tilesort_ranges": times.duplicate_ms,
-                    "render_fwd": times.render_fwd_ms, "render_bwd": times.render_bwd_ms, "preprocess_bwd": times.preprocess_bwd_ms}
+        stage_ms = {"preprocess_fwd": stage_times.preprocess_ms, "depth_sort_scan": stage_times.sort_ms,
+                    "duplicate_tilesort_ranges": stage_times.duplicate_ms, "render_fwd": times.render_fwd_ms,
+                    "render_bwd": times.render_bwd_ms, "preprocess_bwd": stage_times.preprocess_bwd_ms}
         dom = "render_bwd" if times.render_bwd_ms >= times.render_fwd_ms else "render_fwd"
         dom_ms = stage_ms[dom]
         nbytes = algorithmic_bytes(dom, P, R, HW, S)

@@ -91,6 +91,18 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
                                   size_t binning_bytes, void* img_ws, int64_t num_rendered, float* out_color,
                                   float* out_feature, float* out_others, void* stream);
 
+/* Both phases in one call, without a host round trip in the middle of the GPU work: the binning workspace is carved for
+ * `capacity_pairs` (a guess, e.g. the previous call's count plus a margin; binning_bytes >= mrgs_binning_bytes(capacity_pairs)),
+ * phase 2 is queued right behind phase 1 and takes the actual pair count from device memory, and the call returns once the
+ * count has reached the host (the GPU keeps working).  Returns MRGS_OK with *num_rendered_host set when the count fitted.
+ * Returns MRGS_E_WORKSPACE with *num_rendered_host set when it did not: the outputs are then undefined and the caller redoes
+ * phase 2 with mrgs_rasterize_forward_render on a workspace of mrgs_binning_bytes(*num_rendered_host).
+ * mrgs_rasterize_backward must be given the pair count the binning workspace was carved for (capacity_pairs here).
+ * Same reference interface as the two calls above (rasterize_points.cu:41-144). */
+int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                           void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
+                           float* out_color, float* out_feature, float* out_others, int64_t* num_rendered_host, void* stream);
+
 /* Gradient outputs of mrgs_rasterize_backward, the tuple returned by RasterizeGaussiansBackwardCUDA
  * (rasterize_points.cu:146-252): all fully written by the call (no pre-zeroing needed). */
 typedef struct MrgsRasterGrads {
@@ -176,7 +188,7 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
 typedef struct MrgsKernelTimes {
     float preprocess_ms, sort_ms, duplicate_ms, render_fwd_ms, render_bwd_ms, preprocess_bwd_ms;
 } MrgsKernelTimes;
-int mrgs_set_profiling(int32_t enabled);
+int mrgs_set_profiling(int32_t level);   /* 0 off, 1 every stage, 2 only the two blend kernels */
 int mrgs_get_kernel_times(MrgsKernelTimes* out);
 
 const char* mrgs_strerror(int code);

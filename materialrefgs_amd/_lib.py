@@ -66,6 +66,9 @@ SYMBOLS = {
                                                    c_size_t, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     "mrgs_rasterize_forward_render": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p,
                                                      c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_rasterize_forward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_size_t,
+                                              c_void_p, c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              ctypes.POINTER(c_int64), c_void_p]),
     "mrgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                ctypes.POINTER(MrgsRasterGrads), c_void_p]),
@@ -111,6 +114,9 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+MRGS_E_WORKSPACE = 5
 
 
 def check(rc):

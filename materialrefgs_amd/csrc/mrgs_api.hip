@@ -37,7 +37,8 @@ struct StageTimer {
     EvPair p;
     hipStream_t s;
     bool on;
-    StageTimer(hipStream_t stream, int stage) : s(stream), on(g_profiling != 0)
+    StageTimer(hipStream_t stream, int stage)
+        : s(stream), on(g_profiling == 1 || (g_profiling == 2 && (stage == ST_FWD || stage == ST_BWD)))
     {
         if (on) {
             if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
@@ -160,6 +161,71 @@ size_t mrgs_img_bytes(int32_t H, int32_t W) { return mrgs_carve_img(nullptr, H, 
 size_t mrgs_binning_bytes(int64_t R) { return mrgs_carve_bin(nullptr, R).total; }
 size_t mrgs_grad_bytes(int32_t P, int32_t S) { return mrgs_align_up((size_t)(P > 0 ? P : 1) * MRGS_GRAD_STRIDE(S) * sizeof(float), 256); }
 
+// phase 1: preprocess, depth sort, scan; leaves num_rendered and the look-back error flag in g.counters[0..1]
+static int enqueue_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, MrgsGeomWs g, int32_t* radii, hipStream_t stream)
+{
+    StageTimer t0(stream, ST_PRE);
+    HIP_TRY(hipMemsetAsync(g.counters, 0, g.clear_bytes, stream));   // counters + look-back state of the sort and the scan
+    mrgs_launch_preprocess_fwd(*cfg, *in, g, radii, stream);
+    t0.stop();
+    STAGE_CHECK(cfg, stream);
+
+    StageTimer t1(stream, ST_SORT);
+    // depth sort of the gaussians (32 key bits, 4 passes -> result back in buffer 0)
+    const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_ws, g.counters + 1, cfg->P, nullptr, 0, 32, stream);
+    STAGE_CHECK(cfg, stream);
+    mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_ws, g.counters, g.counters + 1, cfg->P, stream);
+    t1.stop();
+    STAGE_CHECK(cfg, stream);
+    return MRGS_OK;
+}
+
+// phase 2: pair emission, tile sort, ranges, blend.  R is the pair count the binning workspace was carved for; with
+// R_dev != nullptr it is a capacity and the kernels take the actual count from device memory.
+static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, MrgsGeomWs g, MrgsBinWs b,
+                          const MrgsImgWs& img, int64_t R, const uint32_t* R_dev, float* out_color, float* out_feature,
+                          float* out_others, hipStream_t stream)
+{
+    const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    const int ntiles = tiles_x * tiles_y;
+    const int dcur = sorted_buf(32);
+
+    StageTimer t0(stream, ST_DUP);
+    HIP_TRY(hipMemsetAsync(b.sort_ws, 0, b.sort_ws_bytes, stream));
+    if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, stream);
+    STAGE_CHECK(cfg, stream);
+    const int bits = tile_bits(ntiles);
+    const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
+    STAGE_CHECK(cfg, stream);
+    mrgs_launch_tile_ranges(b.tile_key[cur], R, R_dev, img.ranges, img.tile_order, ntiles, stream);
+    t0.stop();
+    STAGE_CHECK(cfg, stream);
+
+    StageTimer t1(stream, ST_FWD);
+    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], img, out_color, out_feature, out_others, stream);
+    t1.stop();
+    STAGE_CHECK(cfg, stream);
+    return MRGS_OK;
+}
+
+static int zero_outputs(const MrgsRasterConfig* cfg, float* out_color, float* out_feature, float* out_others, hipStream_t stream)
+{
+    // the reference returns zero-filled outputs without touching the kernels (rasterize_points.cu:89-93,106)
+    const size_t hw = (size_t)cfg->H * cfg->W;
+    HIP_TRY(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * hw, stream));
+    if (cfg->S > 0) HIP_TRY(hipMemsetAsync(out_feature, 0, sizeof(float) * cfg->S * hw, stream));
+    HIP_TRY(hipMemsetAsync(out_others, 0, sizeof(float) * MRGS_NUM_OTHERS * hw, stream));
+    return MRGS_OK;
+}
+
+static int check_counters(const uint32_t host[2], int64_t* num_rendered_host)
+{
+    if (host[1] != 0) return MRGS_E_INTERNAL;
+    if (host[0] >= (1u << 30)) return MRGS_E_UNSUPPORTED;   // pair counts are carried in 30 bits by the binning kernels
+    *num_rendered_host = (int64_t)host[0];
+    return MRGS_OK;
+}
+
 int mrgs_rasterize_forward_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
                                 int32_t* radii, int64_t* num_rendered_host, void* stream_)
 {
@@ -172,29 +238,13 @@ int mrgs_rasterize_forward_geom(const MrgsRasterConfig* cfg, const MrgsRasterInp
     if (!geom_ws || !radii) return MRGS_E_BAD_ARG;
     MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
     if (geom_bytes < g.total) return MRGS_E_WORKSPACE;
-
-    StageTimer t0(stream, ST_PRE);
-    HIP_TRY(hipMemsetAsync(g.counters, 0, g.clear_bytes, stream));   // counters + look-back state of the sort and the scan
-    mrgs_launch_preprocess_fwd(*cfg, *in, g, radii, stream);
-    t0.stop();
-    STAGE_CHECK(cfg, stream);
-
-    StageTimer t1(stream, ST_SORT);
-    // depth sort of the gaussians (32 key bits, 4 passes -> result back in buffer 0)
-    const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_ws, g.counters + 1, cfg->P, 0, 32, stream);
-    STAGE_CHECK(cfg, stream);
-    mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_ws, g.counters, g.counters + 1, cfg->P, stream);
-    t1.stop();
-    STAGE_CHECK(cfg, stream);
-
+    rc = enqueue_geom(cfg, in, g, radii, stream);
+    if (rc) return rc;
     // blocking read-back of num_rendered, as rasterizer_impl.cu:287 (plus the error flag of the look-back kernels)
     uint32_t host[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(host, g.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    if (host[1] != 0) return MRGS_E_INTERNAL;
-    if (host[0] >= (1u << 30)) return MRGS_E_UNSUPPORTED;   // pair counts are carried in 30 bits by the binning kernels
-    *num_rendered_host = (int64_t)host[0];
-    return MRGS_OK;
+    return check_counters(host, num_rendered_host);
 }
 
 int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, void* binning_ws,
@@ -205,39 +255,56 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
     int rc = check_cfg(cfg, in);
     if (rc) return rc;
     if (!out_color || !out_others || (cfg->S > 0 && !out_feature) || !img_ws) return MRGS_E_BAD_ARG;
-    const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
-    const int ntiles = tiles_x * tiles_y;
-    MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
-    const size_t hw = (size_t)cfg->H * cfg->W;
-    if (cfg->P == 0) {
-        // the reference returns zero-filled outputs without touching the kernels (rasterize_points.cu:89-93,106)
-        HIP_TRY(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * hw, stream));
-        if (cfg->S > 0) HIP_TRY(hipMemsetAsync(out_feature, 0, sizeof(float) * cfg->S * hw, stream));
-        HIP_TRY(hipMemsetAsync(out_others, 0, sizeof(float) * MRGS_NUM_OTHERS * hw, stream));
-        return MRGS_OK;
-    }
+    if (cfg->P == 0) return zero_outputs(cfg, out_color, out_feature, out_others, stream);
     if (!geom_ws || !binning_ws) return MRGS_E_BAD_ARG;
+    MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
     MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(binning_ws, R);
     if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
-    const int dcur = sorted_buf(32);
+    return enqueue_render(cfg, in, g, b, img, R, nullptr, out_color, out_feature, out_others, stream);
+}
 
-    StageTimer t0(stream, ST_DUP);
-    HIP_TRY(hipMemsetAsync(b.sort_ws, 0, b.sort_ws_bytes, stream));
-    if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], stream);
-    STAGE_CHECK(cfg, stream);
-    const int bits = tile_bits(ntiles);
-    const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, 0, bits, stream);
-    STAGE_CHECK(cfg, stream);
-    mrgs_launch_tile_ranges(b.tile_key[cur], R, img.ranges, img.tile_order, ntiles, stream);
-    t0.stop();
-    STAGE_CHECK(cfg, stream);
+namespace {
+// pinned landing slot + event for the asynchronous num_rendered read-back of mrgs_rasterize_forward (one per host thread:
+// the call waits for its own copy before it returns)
+struct ReadbackSlot {
+    uint32_t* host = nullptr;
+    hipEvent_t ev = nullptr;
+};
+static thread_local ReadbackSlot g_slot;
+}   // namespace
 
-    StageTimer t1(stream, ST_FWD);
-    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], img, out_color, out_feature, out_others, stream);
-    t1.stop();
-    STAGE_CHECK(cfg, stream);
-    return MRGS_OK;
+int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                           void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
+                           float* out_color, float* out_feature, float* out_others, int64_t* num_rendered_host, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg, in);
+    if (rc) return rc;
+    if (!num_rendered_host || !out_color || !out_others || (cfg->S > 0 && !out_feature) || !img_ws) return MRGS_E_BAD_ARG;
+    *num_rendered_host = 0;
+    if (cfg->P == 0) return zero_outputs(cfg, out_color, out_feature, out_others, stream);
+    if (!geom_ws || !radii || !binning_ws || capacity_pairs < 1 || capacity_pairs >= (1ll << 30)) return MRGS_E_BAD_ARG;
+    MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
+    if (geom_bytes < g.total) return MRGS_E_WORKSPACE;
+    MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
+    MrgsBinWs b = mrgs_carve_bin(binning_ws, capacity_pairs);
+    if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
+    if (!g_slot.host) {
+        HIP_TRY(hipHostMalloc((void**)&g_slot.host, 64, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming));
+    }
+    rc = enqueue_geom(cfg, in, g, radii, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(g_slot.host, g.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(g_slot.ev, stream));
+    // phase 2 is queued behind the copy without waiting for it: the kernels read the count from g.counters
+    rc = enqueue_render(cfg, in, g, b, img, capacity_pairs, g.counters, out_color, out_feature, out_others, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(g_slot.ev));
+    rc = check_counters(g_slot.host, num_rendered_host);
+    if (rc) return rc;
+    return *num_rendered_host > capacity_pairs ? MRGS_E_WORKSPACE : MRGS_OK;
 }
 
 int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,

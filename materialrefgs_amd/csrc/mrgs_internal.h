@@ -81,8 +81,9 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
 // stable LSD radix sort of (key, value) pairs on key bits [bit_lo, bit_hi); returns the index of the buffer holding the
 // result.  ws: mrgs_sort_ws_words(n) zeroed words; *error_flag is set if a look-back spin overruns (never expected).
 size_t mrgs_sort_ws_words(int64_t n);
-int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint32_t* error_flag, int64_t n, int bit_lo, int bit_hi,
-                          hipStream_t stream);
+// n_dev (nullable): device-resident element count; the launches are then sized for n (a capacity) and use min(*n_dev, n)
+int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint32_t* error_flag, int64_t n, const uint32_t* n_dev,
+                          int bit_lo, int bit_hi, hipStream_t stream);
 // exclusive scan of tiles_touched[order[i]] -> offsets[i]; total -> *total_out (device); ws: mrgs_scan_ws_words(n) zeroed words
 size_t mrgs_scan_ws_words(int n);
 void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* ws, uint32_t* total_out,
@@ -95,8 +96,9 @@ void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
 void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
-                           uint32_t* plist, hipStream_t stream);
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, uint32_t* tile_order, int ntiles, hipStream_t stream);
+                           uint32_t* plist, int64_t capacity, hipStream_t stream);
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, uint2* ranges, uint32_t* tile_order, int ntiles,
+                             hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);

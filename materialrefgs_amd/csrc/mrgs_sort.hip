@@ -31,6 +31,15 @@
 #define OS_VALUE_MASK 0x3FFFFFFFu
 #define OS_SPIN_LIMIT (1 << 24)
 
+// Element count of a binning kernel: the host value, or -- when the launch was sized for a capacity before the count was
+// known on the host (mrgs_rasterize_forward) -- the device-resident count clamped to that capacity.
+__device__ __forceinline__ int64_t mrgs_count(int64_t n_host, const uint32_t* __restrict__ n_dev)
+{
+    if (n_dev == nullptr) return n_host;
+    const int64_t v = (int64_t)*n_dev;
+    return v < n_host ? v : n_host;
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
 __device__ __forceinline__ uint32_t os_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -97,11 +106,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 
 // ---- digit totals of every pass in one sweep over the keys ----------------------------------------------
 template <int NPASS>
-__global__ void __launch_bounds__(SORT_THREADS) radix_totals_kernel(const uint32_t* __restrict__ keys, int64_t n, int bit_lo,
+__global__ void __launch_bounds__(SORT_THREADS) radix_totals_kernel(const uint32_t* __restrict__ keys, int64_t n_host,
+                                                                    const uint32_t* __restrict__ n_dev, int bit_lo,
                                                                     uint32_t* __restrict__ totals /*[NPASS][256]*/)
 {
     __shared__ uint32_t h[NPASS][256];
     const int tid = threadIdx.x;
+    const int64_t n = mrgs_count(n_host, n_dev);
 #pragma unroll
     for (int p = 0; p < NPASS; p++) h[p][tid] = 0;
     __syncthreads();
@@ -124,7 +135,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint
                                                                       uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                                       const uint32_t* __restrict__ totals, uint32_t* __restrict__ status,
                                                                       uint32_t* __restrict__ ticket, uint32_t* __restrict__ error_flag,
-                                                                      int64_t n, int shift)
+                                                                      int64_t n_host, const uint32_t* __restrict__ n_dev, int shift)
 {
     __shared__ uint32_t whist[SORT_WAVES][256];
     __shared__ uint32_t start[256];
@@ -136,6 +147,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint
     for (int w = 0; w < SORT_WAVES; w++) whist[w][tid] = 0;
     __syncthreads();
     const int blk = (int)s_blk;
+    const int64_t n = mrgs_count(n_host, n_dev);
+    if ((int64_t)blk * (SORT_THREADS * ITEMS) >= n) return;   // launched for the capacity, not needed for the actual count
     const int64_t wbase = (int64_t)blk * (SORT_THREADS * ITEMS) + (int64_t)wave * (64 * ITEMS) + lane;
     const uint64_t lt = lanemask_lt();
 
@@ -215,8 +228,8 @@ size_t mrgs_sort_ws_words(int64_t n)
 
 // ws must be zero on entry (the caller clears it together with its other per-call state); layout: [0..3] tickets of the
 // passes, then digit totals [4][256], then status words [passes][nblk][256]
-int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint32_t* error_flag, int64_t n, int bit_lo, int bit_hi,
-                          hipStream_t stream)
+int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint32_t* error_flag, int64_t n, const uint32_t* n_dev,
+                          int bit_lo, int bit_hi, hipStream_t stream)
 {
     int cur = 0;
     if (n <= 0 || bit_hi <= bit_lo) return cur;
@@ -229,17 +242,17 @@ int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint
     uint32_t* status = totals + 4 * 256;
     const int tblk = (int)((n + 4095) / 4096 < 1024 ? (n + 4095) / 4096 : 1024);
     switch (npass) {
-    case 1: hipLaunchKernelGGL(radix_totals_kernel<1>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
-    case 2: hipLaunchKernelGGL(radix_totals_kernel<2>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
-    case 3: hipLaunchKernelGGL(radix_totals_kernel<3>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
-    default: hipLaunchKernelGGL(radix_totals_kernel<4>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, bit_lo, totals); break;
+    case 1: hipLaunchKernelGGL(radix_totals_kernel<1>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, n_dev, bit_lo, totals); break;
+    case 2: hipLaunchKernelGGL(radix_totals_kernel<2>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, n_dev, bit_lo, totals); break;
+    case 3: hipLaunchKernelGGL(radix_totals_kernel<3>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, n_dev, bit_lo, totals); break;
+    default: hipLaunchKernelGGL(radix_totals_kernel<4>, dim3(tblk), dim3(SORT_THREADS), 0, stream, key[0], n, n_dev, bit_lo, totals); break;
     }
     for (int p = 0; p < npass; p++) {
         const int shift = bit_lo + 8 * p;
         uint32_t* st = status + (size_t)p * nblk * 256;
 #define OS_LAUNCH(IT)                                                                                                        \
     hipLaunchKernelGGL(radix_onesweep_kernel<IT>, dim3(nblk), dim3(SORT_THREADS), 0, stream, key[cur], val[cur], key[cur ^ 1], \
-                       val[cur ^ 1], totals + p * 256, st, tickets + p, error_flag, n, shift)
+                       val[cur ^ 1], totals + p * 256, st, tickets + p, error_flag, n, n_dev, shift)
         if (items == 4) OS_LAUNCH(4);
         else if (items == 8) OS_LAUNCH(8);
         else OS_LAUNCH(16);
@@ -346,13 +359,15 @@ void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint3
 // ---- pair emission (duplicateWithKeys, rasterizer_impl.cu:72-113) in depth-sorted gaussian order -------
 __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect,
-                                                        int tiles_x, uint32_t* __restrict__ tile_key, uint32_t* __restrict__ plist)
+                                                        int tiles_x, uint32_t* __restrict__ tile_key, uint32_t* __restrict__ plist,
+                                                        uint32_t capacity)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const uint32_t g = order[i];
     if (tiles_touched[g] == 0) return;
     uint32_t off = offsets[i];
+    if (off + tiles_touched[g] > capacity) return;   // only when the buffers were sized for a guess that proved too small
     const uint2 r = rect[g];
     const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
     for (int y = y0; y < y1; y++)
@@ -364,16 +379,18 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* _
 }
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
-                           uint32_t* plist, hipStream_t stream)
+                           uint32_t* plist, int64_t capacity, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X;
     hipLaunchKernelGGL(duplicate_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, order, g.tiles_touched, g.offsets,
-                       g.rect, tiles_x, tile_key, plist);
+                       g.rect, tiles_x, tile_key, plist, (uint32_t)capacity);
 }
 
 // ---- identifyTileRanges (rasterizer_impl.cu:118-140) on the sorted tile ids ---------------------------
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __restrict__ tile_key, int64_t R, uint2* __restrict__ ranges)
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __restrict__ tile_key, int64_t R_host,
+                                                          const uint32_t* __restrict__ R_dev, uint2* __restrict__ ranges)
 {
+    const int64_t R = mrgs_count(R_host, R_dev);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R) return;
     const uint32_t cur = tile_key[idx];
@@ -418,10 +435,11 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restric
     for (int t = ntiles + tid; t < nslots; t += 1024) order[t] = (uint32_t)ntiles;
 }
 
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, uint2* ranges, uint32_t* tile_order, int ntiles, hipStream_t stream)
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, uint2* ranges, uint32_t* tile_order, int ntiles,
+                             hipStream_t stream)
 {
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, stream);   // rasterizer_impl.cu:316
     if (R > 0)
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, R, ranges);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, R, R_dev, ranges);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ranges, ntiles, ((ntiles + 7) / 8) * 8, tile_order);
 }

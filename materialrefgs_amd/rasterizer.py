@@ -17,6 +17,7 @@ from . import _lib
 from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
 
 
+_PAIR_GUESS = {}   # device index -> pair capacity to try first (previous count + 25 %)
 LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (bench.py reads it for the roofline figure)
 
 
@@ -74,15 +75,33 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         geom = torch.empty((L.mrgs_geom_bytes(P, H, W),), dtype=torch.uint8, device=dev)
         img = torch.empty((L.mrgs_img_bytes(H, W),), dtype=torch.uint8, device=dev)
         R = ctypes.c_int64(0)
-        _lib.check(L.mrgs_rasterize_forward_geom(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(radii),
-                                                 ctypes.byref(R), st))
-        num_rendered = int(R.value)
         global LAST_NUM_RENDERED
+        guess = _PAIR_GUESS.get(dev.index)
+        pairs = None            # pair count the binning workspace is carved for (what the backward must be given)
+        if guess is not None and P > 0:
+            # one call, no host round trip in the middle of the GPU work: the workspace is sized from the previous call's
+            # count and the kernels take the actual count from device memory (include/mrgs.h, mrgs_rasterize_forward)
+            pairs = guess
+            binning = torch.empty((L.mrgs_binning_bytes(pairs),), dtype=torch.uint8, device=dev)
+            rc = L.mrgs_rasterize_forward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                          pairs, _ptr(img), _ptr(radii), _ptr(color), _ptr(feature), _ptr(others), ctypes.byref(R), st)
+            if rc == _lib.MRGS_E_WORKSPACE:
+                pairs = None    # the guess was too small: phase 2 is redone below on an exactly sized workspace
+            else:
+                _lib.check(rc)
+        else:
+            _lib.check(L.mrgs_rasterize_forward_geom(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(radii),
+                                                     ctypes.byref(R), st))
+        num_rendered = int(R.value)
         LAST_NUM_RENDERED = num_rendered
-        binning = torch.empty((L.mrgs_binning_bytes(num_rendered),), dtype=torch.uint8, device=dev)
-        _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
-                                                   _ptr(img), num_rendered, _ptr(color), _ptr(feature), _ptr(others), st))
-    return num_rendered, contrib, color, feature, others, radii, geom, binning, img
+        if pairs is None:
+            pairs = num_rendered
+            binning = torch.empty((L.mrgs_binning_bytes(pairs),), dtype=torch.uint8, device=dev)
+            _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
+                                                       _ptr(img), pairs, _ptr(color), _ptr(feature), _ptr(others), st))
+        if P > 0:
+            _PAIR_GUESS[dev.index] = max(int(num_rendered * 1.25) + 65536, 1)
+    return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img
 
 
 def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp,
@@ -134,9 +153,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ex
         else:
             out = _rasterize_forward_native(*args)
-        num_rendered, contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer = out
+        (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer = out
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.binning_pairs = binning_pairs   # pair count binningBuffer is carved for (>= num_rendered)
         ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer, contrib)
         ctx.mark_non_differentiable(contrib, radii)
@@ -144,7 +164,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_contrib, grad_out_color, grad_out_feature, grad_radii, grad_depth):
-        num_rendered = ctx.num_rendered
+        num_rendered = ctx.binning_pairs
         rs = ctx.raster_settings
         (colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
          imgBuffer, contrib) = ctx.saved_tensors

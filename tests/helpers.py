@@ -72,16 +72,18 @@ class HipRender:
         saved = self.fn.saved_tensors
         geom, binning, img = saved[9], saved[10], saved[11]
         R = self.num_rendered
+        pairs = self.fn.binning_pairs      # what the binning workspace is carved for (>= R when the forward ran on a guess)
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        shape = shp(self.P, R, T, self.H, self.W)
+        shape = shp(self.P, pairs if name == "point_list" else R, T, self.H, self.W)
         out = torch.zeros(shape, dtype=dtype, device=self.dev)
         cfg = MrgsRasterConfig(self.P, self.S, 0, 0, self.H, self.W, 0.0, 0.0, 1.0, 0, 0)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t.numel() else None
         if out.numel():
-            _lib.check(_lib.lib().mrgs_debug_export(ctypes.byref(cfg), p(geom), p(binning), p(img), R, which, p(out),
+            _lib.check(_lib.lib().mrgs_debug_export(ctypes.byref(cfg), p(geom), p(binning), p(img), pairs, which, p(out),
                                                     ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
         torch.cuda.synchronize(self.dev)
-        return out.cpu().numpy()
+        out = out.cpu().numpy()
+        return out[:R] if name == "point_list" else out
 
     def backward(self, g_color, g_feat, g_others):
         outs, grads = [self.color, self.others], [g_color.to(self.dev), g_others.to(self.dev)]

@@ -150,6 +150,34 @@ def test_untouched_pixels_ignore_their_upstream_gradients(gpu_device):
         assert rel_err(poisoned[k], clean[k]) <= 1e-5, k   # atomics: summation order differs between runs
 
 
+def test_forward_on_a_capacity_guess_matches_the_two_phase_forward(gpu_device):
+    """mrgs_rasterize_forward (no host round trip, binning workspace sized from a guess, pair count read on the device) against
+    the two-phase path; a guess that is too small must fall back transparently."""
+    from materialrefgs_amd import rasterizer as rz
+    S, H, W = 4, 160, 120
+    scene = make_shell_scene(3000, S=S, seed=9, radius_px=6.0, image_size=160)
+    cam = orbit_camera(3, H, W)
+    grads = upstream_grads(S, H, W)
+    results = []
+    for guess in (None, 10, 10_000_000, "exact"):
+        if guess is None:
+            rz._PAIR_GUESS.pop(gpu_device.index, None)
+        else:
+            rz._PAIR_GUESS[gpu_device.index] = results[0][0] if guess == "exact" else guess
+        hr = HipRender(scene, cam, gpu_device)
+        pl = hr.export("point_list")
+        rng = hr.export("ranges")
+        results.append((hr.num_rendered, pl, rng, hr.color.detach().cpu().numpy(), hr.others.detach().cpu().numpy(), hr.backward(*grads)))
+    ref = results[0]
+    assert ref[0] > 1000
+    for r in results[1:]:
+        assert r[0] == ref[0]
+        assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
+        assert np.array_equal(r[3], ref[3]) and np.array_equal(r[4], ref[4])
+        for k in ref[5]:
+            assert rel_err(r[5][k], ref[5][k]) <= 1e-5, k
+
+
 def test_mark_visible(gpu_device):
     from materialrefgs_amd.rasterizer import GaussianRasterizer
     from helpers import raster_settings
