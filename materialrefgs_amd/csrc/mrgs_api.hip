@@ -104,6 +104,12 @@ MrgsImgWs mrgs_carve_img(void* base, int H, int W)
     const size_t tiles = (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y);
     w.ranges = c.take<uint2>(tiles > 0 ? tiles : 1);
     w.tile_order = c.take<uint32_t>(tiles + 8);
+    const size_t nslots = (tiles + 7) / 8 * 8;
+    w.item_work = c.take<uint32_t>(8 * nslots + 8);
+    w.bwd_items = c.take<uint32_t>(8 * nslots + 8);
+    w.bwd_work = c.take<uint32_t>(8 * nslots + 8);
+    w.bwd_assign = c.take<uint32_t>(8 * (nslots + MRGS_MAX_SIMD_QUEUES) + 8);
+    w.bwd_state = c.take<uint32_t>(MRGS_BS_WORDS);
     w.final_T = c.take<float>(3 * hw);
     w.n_contrib = c.take<uint32_t>(2 * hw);
     w.total = mrgs_align_up(c.used, 256);
@@ -197,7 +203,7 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     const int bits = tile_bits(ntiles);
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
     STAGE_CHECK(cfg, stream);
-    mrgs_launch_tile_ranges(b.tile_key[cur], R, R_dev, img.ranges, img.tile_order, ntiles, stream);
+    mrgs_launch_tile_ranges(b.tile_key[cur], R, R_dev, img, ntiles, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
@@ -331,8 +337,10 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
 
     StageTimer t0(stream, ST_BWD);
     HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
-    if (R > 0)
+    if (R > 0) {
+        mrgs_launch_bwd_order(img, tiles_x * tiles_y, stream);
         mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
+    }
     t0.stop();
     STAGE_CHECK(cfg, stream);
 

@@ -54,6 +54,11 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
 struct MrgsImgWs {
     uint2* ranges;       // [tiles]
     uint32_t* tile_order;// [tiles rounded up to 8] blend dispatch order: tile ids by decreasing list length
+    uint32_t* item_work; // [8 * nslots] list entries each forward wave walked (item = tile * 8 + quadrant + 4 * half); 0 = idle
+    uint32_t* bwd_items; // [8][nslots] per XCD: work items of the blend backward by decreasing forward work
+    uint32_t* bwd_work;  // [8][nslots] their work
+    uint32_t* bwd_assign;// [8][nslots + 128] per XCD: item handed to ticket t of SIMD queue q at [t * NQ + q]
+    uint32_t* bwd_state; // MRGS_BS_* : item counts, per-CU queue tickets, CU census of the forward launch, dense CU numbering
     float* final_T;      // [3][H*W]: T, M1, M2
     uint32_t* n_contrib; // [2][H*W]: last, median
     size_t total;
@@ -78,6 +83,16 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
 #define MRGS_SPLIT_THRESHOLD 4080   // tiles with at least this many list entries are blended by 8 half-quadrant waves instead of 4 (multiple of 16, <= 4080)
 #endif
 #define MRGS_SORT_WS_HEADER 16
+// layout of MrgsImgWs::bwd_state (uint32 words); a CU is identified by (XCC_ID[2:0], HW_ID se[2:0] sh cu[3:0]) = 3 + 8 bits
+#define MRGS_MAX_SIMD_QUEUES 128             // 32 CUs x 4 SIMDs per XCD
+#define MRGS_BS_COUNT 0                      // [8]       work items of each XCD list
+#define MRGS_BS_PASSES 8                     // [8]       dealing passes of each XCD list
+#define MRGS_BS_TICKET 16                    // [8][128]  items handed out per (XCD list, SIMD queue)
+#define MRGS_BS_BITMAP (16 + 1024)           // [8][8]    CUs seen by the forward blend launch, one bit per CU key, per XCC
+#define MRGS_BS_NCU (16 + 1024 + 64)         // [8]       CUs per XCC
+#define MRGS_BS_DENSE (16 + 1024 + 64 + 8)   // [8][256]  CU key -> dense index inside its XCC
+#define MRGS_BS_WORDS (16 + 1024 + 64 + 8 + 2048)
+__device__ __forceinline__ uint32_t mrgs_cu_key(uint32_t hw_id) { return ((hw_id >> 8) & 0xFFu); }   // cu[3:0] sh se[2:0]
 // stable LSD radix sort of (key, value) pairs on key bits [bit_lo, bit_hi); returns the index of the buffer holding the
 // result.  ws: mrgs_sort_ws_words(n) zeroed words; *error_flag is set if a look-back spin overruns (never expected).
 size_t mrgs_sort_ws_words(int64_t n);
@@ -97,8 +112,8 @@ void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatr
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
                            uint32_t* plist, int64_t capacity, hipStream_t stream);
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, uint2* ranges, uint32_t* tile_order, int ntiles,
-                             hipStream_t stream);
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, const MrgsImgWs& img, int ntiles, hipStream_t stream);
+void mrgs_launch_bwd_order(const MrgsImgWs& img, int ntiles, hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);

@@ -154,7 +154,7 @@ __device__ __forceinline__ void wave_reduce_atomic_add2(float a, float b, float*
 }
 
 #ifdef MRGS_WAVE_STATS   // developer build only (tools/wave_stats.py): per-wave start/end time, iteration counts, placement
-__device__ unsigned long long g_wave_stats[6 * 65536];
+__device__ unsigned long long g_wave_stats[8 * 65536];
 extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stats), sizeof(unsigned long long) * n);
@@ -162,9 +162,9 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #define WS_BEGIN() const unsigned long long ws_t0 = wall_clock64(), ws_c0 = __builtin_amdgcn_s_memtime(); unsigned ws_iters = 0, ws_act = 0, ws_chunks = 0;
 #define WS_ITER(a) { ws_iters++; ws_act += (a) ? 1 : 0; }
 #define WS_CHUNK() ws_chunks++;
-#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 6 * (size_t)b; w[0] = ws_t0; w[1] = wall_clock64(); \
+#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 8 * (size_t)b; w[6] = 0; w[7] = (unsigned long long)n_items; w[0] = ws_t0; w[1] = wall_clock64(); \
         w[2] = __builtin_amdgcn_s_memtime() - ws_c0; w[3] = ((unsigned long long)ws_iters << 32) | ws_act; w[4] = ((unsigned long long)ws_chunks << 32) | (unsigned)max_contrib; \
-        w[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+        w[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); }
 #else
 #define WS_BEGIN()
 #define WS_ITER(a)
@@ -174,7 +174,7 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 4 : S_MAX <= 8 ? 3 : 2, 8))) render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ bwd_state, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride)
@@ -183,16 +183,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     constexpr int K = 16 + S_MAX;   // values through the transposing reduction (the dL/dmean2D pair goes apart)
     __shared__ StageBuf<SF> stage[MRGS_BWD_STAGES];
 
+    // Work-item pull (see bwd_order_kernel): this wave takes the next item from the queue of the SIMD it runs on and falls
+    // back to the other queues when its own is empty.  Exactly n_items waves of an XCD list take part and exactly n_items
+    // tickets are valid, so every participant ends up with one item.
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    BlendItem item;
-    if (!mrgs_decode_item(tile_order, ntiles, b, item)) return;
-    const int tile = item.tile, quad = item.quad, half = item.half;
-    const bool split = item.split;
+    const int xcd = b & 7, wv = b >> 3;
+    const int nslots = ((ntiles + 7) >> 3) << 3;
+    const int n_items = (int)bwd_state[MRGS_BS_COUNT + xcd];
+    if (wv >= n_items) return;
+    uint32_t item = 0xFFFFFFFFu;
+    {
+        const uint32_t pw = bwd_state[MRGS_BS_PASSES + xcd];
+        const int passes = (int)(pw & 0xFFFFu), NQ = (int)(pw >> 16);
+        const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));              // HW_REG_HW_ID
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;           // HW_REG_XCC_ID
+        const uint32_t dense = bwd_state[MRGS_BS_DENSE + xcc * 256 + mrgs_cu_key(hw_id)];
+        const int q0 = (int)((dense * 4u + ((hw_id >> 4) & 3u)) % (uint32_t)NQ);
+        const uint32_t* assign = bwd_assign + (size_t)xcd * (nslots + MRGS_MAX_SIMD_QUEUES);
+        uint32_t* tickets = bwd_state + MRGS_BS_TICKET + xcd * MRGS_MAX_SIMD_QUEUES;
+        if (lane == 0) {
+            for (int d = 0; d < NQ && item == 0xFFFFFFFFu; d++) {
+                const int q = q0 + d < NQ ? q0 + d : q0 + d - NQ;
+                if (d > 0 && __hip_atomic_load(&tickets[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)passes) continue;
+                const int t = (int)atomicAdd(&tickets[q], 1u);
+                if (t < passes) item = assign[t * NQ + q];
+            }
+        }
+        item = __builtin_amdgcn_readfirstlane(item);
+    }
+    if (item == 0xFFFFFFFFu) return;
+    const int tile = (int)((item & 0x1FFFFFFFu) >> 3), quad = (int)(item & 3u), half = (int)((item >> 2) & 1u);
+    const uint32_t prio = (item >> 29) & 3u;
     const uint2 range = ranges[tile];
-    // The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split into two 8x4 halves:
-    // each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical path at the price of
-    // idle lanes in a few waves.
+    const bool split = (range.y - range.x) >= (uint32_t)MRGS_SPLIT_THRESHOLD;   // as the forward decided (mrgs_decode_item)
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
     const int rows = split ? 4 : 8;
@@ -210,10 +234,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     for (int d = 32; d >= 1; d >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, d, 64));
     if (max_contrib == 0) return;
     WS_BEGIN();
-    // longest waves first in line for issue slots (see mrgs_render_fwd.hip)
-    if (max_contrib > 768) __builtin_amdgcn_s_setprio(3);
-    else if (max_contrib > 384) __builtin_amdgcn_s_setprio(2);
-    else if (max_contrib > 192) __builtin_amdgcn_s_setprio(1);
+    // heavy items first in line for issue slots (priority class chosen by bwd_order_kernel)
+    if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
     const int median_contributor = inside ? (int)n_contrib[pix + HW] : 0;
 
     const float T_final = inside ? final_Ts[pix] : 0.f;
@@ -446,10 +470,10 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 8;   // 8 waves per tile (4 quadrants x 2 halves), tiles dealt to the 8 XCDs
+    const int nblocks = ((ntiles + 7) / 8) * 8 * 8;   // at most 8 items per tile, one wave each; waves dealt to the 8 XCDs
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, GS)                                                                                                       \
-    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.tile_order, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.bwd_assign, img.bwd_state, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS)
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);

@@ -28,7 +28,8 @@ template <int S_MAX>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others)
+    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
+    uint32_t* __restrict__ item_work, uint32_t* __restrict__ bwd_state)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     else if (total > 256) __builtin_amdgcn_s_setprio(1);
 
     bool done = !inside;
+    uint32_t work = 0;
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float F[SF];
@@ -112,6 +114,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         if (MRGS_FWD_STAGES == 2) stage_next();
 
         uint64_t m = mask_cur;
+        work += (uint32_t)__builtin_popcountll(m);
         const StageBuf<SF>& sb = stage[c % MRGS_FWD_STAGES];
 
         // One list entry (forward.cu:358-442).  Branch-free across lanes: a lane that does not blend this entry (no hit,
@@ -123,6 +126,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             const bool hit = mrgs_intersect(sg, px, py, h);
             const bool ok = hit & !done;
             if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return;
+            work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
             const float test_T = T * (1.0f - h.alpha);
             const bool term = ok & (test_T < MRGS_T_MIN);     // forward.cu:400-404: the pixel stops BEFORE blending this entry
@@ -182,6 +186,16 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     }
     mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
 
+    // entries this wave tested + 3 x entries it blended: the cost of the backward wave of the same pixel block, which walks
+    // the same entries (bwd_order_kernel)
+    if (lane == 0) {
+        item_work[tile * 8 + quad + 4 * half] = work;
+        // CU census for the backward's per-CU work queues
+        const uint32_t key = mrgs_cu_key(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
+        uint32_t* word = bwd_state + MRGS_BS_BITMAP + xcc * 8 + (key >> 5);
+        if (!((*word >> (key & 31)) & 1u)) atomicOr(word, 1u << (key & 31));
+    }
     if (inside) {
         final_T[pix] = T;
         final_T[pix + HW] = M1;
@@ -215,7 +229,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM)                                                                                                           \
     hipLaunchKernelGGL(render_fwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.tile_order, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others)
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.bwd_state)
     if (cfg.S == 0) LAUNCH(0);
     else if (cfg.S <= 8) LAUNCH(8);
     else if (cfg.S <= 12) LAUNCH(12);

@@ -409,8 +409,11 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
 // Blend-kernel dispatch order: tiles sorted by decreasing list length (counting sort on length / 16, one workgroup).  The
 // blend launches last as long as their longest wave, and not every wave is resident from the start: longest-first keeps the
 // heavy tiles off the tail of the launch.  Slots beyond ntiles (grid padding) get the id ntiles (= no tile).
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restrict__ ranges, int ntiles, int nslots, uint32_t* __restrict__ order)
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restrict__ ranges, int ntiles, int nslots, uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ item_work, uint32_t* __restrict__ bwd_state)
 {
+    for (int t = threadIdx.x; t < 8 * nslots; t += 1024) item_work[t] = 0u;   // filled by the forward blend waves that do work
+    if (threadIdx.x < 64) bwd_state[MRGS_BS_BITMAP + threadIdx.x] = 0u;       // CU census, filled by the same waves
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wave_sums[16];
     const int tid = threadIdx.x;
@@ -435,11 +438,125 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restric
     for (int t = ntiles + tid; t < nslots; t += 1024) order[t] = (uint32_t)ntiles;
 }
 
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, uint2* ranges, uint32_t* tile_order, int ntiles,
-                             hipStream_t stream)
+// Dispatch order of the blend backward.  The forward waves leave the number of list entries they walked in item_work; the
+// backward walks (almost) the same entries, so this is its work per item.  Kernel time is set by the most loaded SIMD, and
+// a random mix of four or five waves per SIMD put 1.44x the mean load on the worst one.  Here, per XCD list (tile p of
+// tile_order belongs to list p % 8, as in the forward), the items with work are counting-sorted by decreasing work and
+// dealt to one queue per SIMD of the XCD in passes of NQ items: in every pass the heaviest item goes to the queue with the
+// smallest load so far (LPT per pass).  A backward wave pulls from the queue of the SIMD it finds itself on and steals
+// from the other queues when its own is empty (render_bwd_kernel); nothing depends on how the hardware places waves.
+// This kernel also turns the CU census of the forward launch into a dense CU numbering per XCC.
+#define BWD_ADAPTIVE_PASSES 64
+__global__ void __launch_bounds__(1024) bwd_order_kernel(const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ item_work,
+                                                         int ntiles, int nslots, uint32_t* __restrict__ bwd_items, uint32_t* __restrict__ bwd_work,
+                                                         uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ bwd_state)
 {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t load[MRGS_MAX_SIMD_QUEUES];
+    __shared__ unsigned long long s_total;
+    const int tid = threadIdx.x, x = blockIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) s_total = 0ull;
+    if (tid < MRGS_MAX_SIMD_QUEUES) { bwd_state[MRGS_BS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u; load[tid] = 0u; }
+    if (tid < 256) {   // block x numbers the CUs of XCC x
+        const uint32_t* bm = bwd_state + MRGS_BS_BITMAP + x * 8;
+        uint32_t below = 0;
+        for (int w = 0; w < (tid >> 5); w++) below += __popc(bm[w]);
+        below += __popc(bm[tid >> 5] & ((1u << (tid & 31)) - 1u));
+        bwd_state[MRGS_BS_DENSE + x * 256 + tid] = below;
+        if (tid == 255) bwd_state[MRGS_BS_NCU + x] = below + ((bm[7] >> 31) & 1u);
+    }
+    __syncthreads();
+    const int n = nslots;   // (nslots / 8 tiles) x 8 items
+    for (int idx = tid; idx < n; idx += 1024) {
+        const uint32_t tile = tile_order[(idx >> 3) * 8 + x];
+        const uint32_t w = tile < (uint32_t)ntiles ? item_work[tile * 8 + (idx & 7)] : 0u;
+        if (w > 0u) atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);   // bucket 0 = most work
+    }
+    __syncthreads();
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan<1024>(hist[tid], wave_sums, tot);
+    hist[tid] = ex;
+    __syncthreads();
+    uint32_t* items = bwd_items + (size_t)x * nslots;
+    uint32_t* work = bwd_work + (size_t)x * nslots;
+    for (int idx = tid; idx < n; idx += 1024) {
+        const uint32_t tile = tile_order[(idx >> 3) * 8 + x];
+        const uint32_t w = tile < (uint32_t)ntiles ? item_work[tile * 8 + (idx & 7)] : 0u;
+        if (w > 0u) {
+            const uint32_t pos = atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);
+            items[pos] = (tile << 3) | (uint32_t)(idx & 7);
+            work[pos] = w;
+            atomicAdd(&s_total, (unsigned long long)w);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // dealing: NQ queues (the SIMDs of the XCC this list runs on; all XCCs of a device have the same CU count)
+    int Q = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint32_t* bm = bwd_state + MRGS_BS_BITMAP + k * 8;
+        int c = 0;
+        for (int w = 0; w < 8; w++) c += __popc(bm[w]);
+        Q = max(Q, c);
+    }
+    const int NQ = 4 * min(max(Q, 1), MRGS_MAX_SIMD_QUEUES / 4);
+    const int n_items = (int)tot;
+    const int passes = (n_items + NQ - 1) / NQ;
+    const unsigned long long mean5 = n_items > 0 ? 5ull * s_total / (unsigned long long)n_items : 0ull;   // 5 x mean work
+    uint32_t* assign = bwd_assign + (size_t)x * (nslots + MRGS_MAX_SIMD_QUEUES);
+    for (int p = 0; p < passes; p++) {
+        int slot = tid;                                    // position in the pass (0 = heaviest item) this queue receives
+        if (tid < NQ) {
+            if (p > 0 && p < BWD_ADAPTIVE_PASSES) {
+                const uint32_t mine = load[tid];
+                int r = 0;
+                for (int q = 0; q < NQ; q++) {
+                    const uint32_t o = load[q];
+                    r += (o < mine || (o == mine && q < tid)) ? 1 : 0;
+                }
+                slot = r;                                  // lightest queue <- heaviest item
+            } else if (p & 1) {
+                slot = NQ - 1 - tid;                       // plain snake beyond the adaptive passes
+            }
+        }
+        __syncthreads();
+        if (tid < NQ) {
+            const int rank = p * NQ + slot;
+            const bool valid = rank < n_items;
+            uint32_t entry = 0xFFFFFFFFu;
+            if (valid) {
+                // issue priority of the wave (bits 29-30): the heavy items of a SIMD run ahead of its light ones, so that the
+                // SIMD keeps several waves in flight until its work runs out instead of finishing with one long straggler
+                const unsigned long long w25 = 25ull * work[rank];
+                const uint32_t prio = w25 > 8ull * mean5 ? 3u : w25 > 6ull * mean5 ? 2u : w25 > 4ull * mean5 ? 1u : 0u;
+                entry = items[rank] | (prio << 29);
+                load[tid] += work[rank];
+            }
+            assign[p * NQ + tid] = entry;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        bwd_state[MRGS_BS_COUNT + x] = tot;
+        bwd_state[MRGS_BS_PASSES + x] = (uint32_t)passes | ((uint32_t)NQ << 16);
+    }
+}
+
+void mrgs_launch_bwd_order(const MrgsImgWs& img, int ntiles, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bwd_order_kernel, dim3(8), dim3(1024), 0, stream, img.tile_order, img.item_work, ntiles, ((ntiles + 7) / 8) * 8,
+                       img.bwd_items, img.bwd_work, img.bwd_assign, img.bwd_state);
+}
+
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, const MrgsImgWs& img, int ntiles, hipStream_t stream)
+{
+    uint2* ranges = img.ranges;
+    uint32_t* tile_order = img.tile_order;
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, stream);   // rasterizer_impl.cu:316
     if (R > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, R, R_dev, ranges);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ranges, ntiles, ((ntiles + 7) / 8) * 8, tile_order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ranges, ntiles, ((ntiles + 7) / 8) * 8, tile_order, img.item_work, img.bwd_state);
 }

@@ -13,13 +13,13 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 sc = make_shell_scene(300000, S=S, seed=0, radius_px=7.0, image_size=800)
 cam = orbit_camera(0, 800, 800)
 L = _lib.lib()
-nb = 20032
-buf = (ctypes.c_ulonglong * (6 * nb))()
+nb = 65536
+buf = (ctypes.c_ulonglong * (8 * nb))()
 for rep in range(3):
     hr = HipRender(sc, cam, dev); torch.cuda.synchronize()
     hr.backward(*upstream_grads(S, 800, 800)); torch.cuda.synchronize()
-    L.mrgs_wave_stats(buf, ctypes.c_int(6 * nb))
-a = np.array(buf[:], dtype=np.uint64).reshape(-1, 6)
+    L.mrgs_wave_stats(buf, ctypes.c_int(8 * nb))
+a = np.array(buf[:], dtype=np.uint64).reshape(-1, 8)
 a = a[a[:, 1] > 0]
 a = a[a[:, 0] > a[:, 1].max() - np.uint64(500000)]   # records of the last launch only (5 ms window)
 t0 = a[:, 0].astype(np.float64); t1 = a[:, 1].astype(np.float64)
@@ -45,3 +45,37 @@ for i in late:
     print(f"  wave start {t0[i]:.1f} end {t1[i]:.1f} dur {dur[i]:.1f} active {act[i]:.0f} max_contrib {maxc[i]:.0f}")
 # start-time distribution
 print("start time percentiles (us):", [round(float(np.percentile(t0, p)), 1) for p in (10, 25, 50, 75, 90, 99, 100)])
+
+# per-SIMD load (HW_ID: wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13]; XCC_ID[3:0] in the high word)
+hwid = (hw & np.uint64(0xffffffff)).astype(np.int64); xcc = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64)
+simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 15; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 7
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+uk, inv = np.unique(key, return_inverse=True)
+load = np.bincount(inv, weights=act); cnt = np.bincount(inv); busy = np.bincount(inv, weights=dur)
+last = np.zeros(len(uk)); np.maximum.at(last, inv, t1)
+print(f"SIMDs used {len(uk)}; waves/SIMD mean {cnt.mean():.2f} max {cnt.max()}; active iters/SIMD mean {load.mean():.0f} p10 {np.percentile(load,10):.0f} p90 {np.percentile(load,90):.0f} max {load.max():.0f}")
+print(f"SIMD finish time (us): p10 {np.percentile(last,10):.0f} p50 {np.percentile(last,50):.0f} p90 {np.percentile(last,90):.0f} max {last.max():.0f}")
+cukey = key // 4
+ucu, invc = np.unique(cukey, return_inverse=True)
+loadc = np.bincount(invc, weights=act)
+print(f"CUs used {len(ucu)}; active iters/CU mean {loadc.mean():.0f} p10 {np.percentile(loadc,10):.0f} p90 {np.percentile(loadc,90):.0f} max {loadc.max():.0f}")
+xl = np.bincount(xcc, weights=act)
+print("active iters per XCC:", [int(v) for v in xl])
+
+w6 = a[:, 6]; rank = (w6 & np.uint64(0xffffffff)).astype(np.int64); kk = ((w6 >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64); dist = ((w6 >> np.uint64(48)) & np.uint64(1)).astype(np.int64)
+print(f"waves in workgroups with 4 distinct SIMDs: {dist.mean()*100:.1f}%")
+for c in range(4):
+    m = kk == c
+    print(f"  class {c}: waves {m.sum()} mean active {act[m].mean():.0f} mean iters {iters[m].mean():.0f}")
+print("corr(rank, active) = %.3f  corr(rank, iters) = %.3f" % (np.corrcoef(rank, act)[0,1], np.corrcoef(rank, iters)[0,1]))
+# SIMD composition by class
+comp = np.zeros((len(uk), 4)); np.add.at(comp, (inv, kk), 1)
+print("SIMDs whose first-round waves hold one of each class:", int(((comp >= 1).all(axis=1)).sum()), "of", len(uk))
+wcu = np.bincount(invc)
+print("waves per CU histogram:", dict(zip(*np.unique(wcu, return_counts=True))))
+grp = rank // 4
+for c in range(3):
+    m = invc == c
+    print(f"  CU {c}: xcc {xcc[m][0]} groups {sorted(set(grp[m].tolist()))} start {sorted(set(np.round(t0[m]).astype(int).tolist()))} active {act[m].sum():.0f}")
+gw = np.bincount(grp, weights=act)
+print("group weights (first 12, then every 16th):", [int(v) for v in gw[:12]], [int(v) for v in gw[::16]])
