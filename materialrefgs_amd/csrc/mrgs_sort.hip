@@ -218,7 +218,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint
 
 // tile size of the passes for n keys: enough workgroups to fill 256 CUs for small inputs, longer tiles (shorter look-back
 // chains, fewer status words) for large ones
-static int sort_items(int64_t n) { return n <= (600 << 10) ? 4 : n <= (2400 << 10) ? 8 : 16; }
+#ifdef MRGS_SORT_ITEMS_FORCE
+static int sort_items(int64_t) { return MRGS_SORT_ITEMS_FORCE; }
+#else
+static int sort_items(int64_t n) { return n <= (128 << 10) ? 4 : n <= (768 << 10) ? 8 : 16; }   // look-back chains of <= ~300 tiles
+#endif
 
 size_t mrgs_sort_ws_words(int64_t n)
 {
