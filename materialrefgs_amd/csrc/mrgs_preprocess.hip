@@ -66,8 +66,42 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 // conflict-free) LDS row.
 #define SH_ROW_MAX 48
 #define SH_LDS_STRIDE 49
+// Coalesced store of K floats per lane (row-major [row][K] destination, one row per lane): through the wave's LDS tile,
+// K dword stores each covering 64 consecutive floats instead of K stores that touch 64 cache lines each.
+template <int K>
+__device__ __forceinline__ void wave_store_rows(float* __restrict__ tile, const float (&v)[K], float* __restrict__ dst_rows, int nrows, int lane)
+{
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < K; j++) tile[lane * K + j] = v[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const int e = j * 64 + lane;
+        if (e < nrows * K) dst_rows[e] = tile[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void wave_rows_load(float* __restrict__ tile, const float* __restrict__ src, int nrows, int L, int lane)
 {
+    if (L == 48 && nrows == 64) {
+        // 3072 floats = 12 float4 per lane, all twelve loads in flight at once (a float4 never straddles a 48-float row)
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) v[k] = src4[k * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int e = 4 * (k * 64 + lane);
+            const int r = e / 48, c = e - 48 * r;
+            float* d = tile + r * SH_LDS_STRIDE + c;
+            d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        }
+        return;
+    }
     const int total = nrows * L;
     int r = 0, c = lane;
     while (c >= L) { c -= L; r++; }
@@ -79,6 +113,17 @@ __device__ __forceinline__ void wave_rows_load(float* __restrict__ tile, const f
 }
 __device__ __forceinline__ void wave_rows_store(const float* __restrict__ tile, float* __restrict__ dst, int nrows, int L, int lane)
 {
+    if (L == 48 && nrows == 64) {
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int e = 4 * (k * 64 + lane);
+            const int r = e / 48, c = e - 48 * r;
+            const float* q = tile + r * SH_LDS_STRIDE + c;
+            dst4[k * 64 + lane] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        return;
+    }
     const int total = nrows * L;
     int r = 0, c = lane;
     while (c >= L) { c -= L; r++; }
@@ -185,29 +230,46 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             const float x = dx / len, y = dy / len, z = dz / len;
             const float* sh = shs + (size_t)idx * M * 3;
             uint32_t cl = 0;
+            // sh_at(i, c) = coefficient i of channel c.  With the full 16-coefficient layout the 192-byte row is fetched with
+            // twelve 16-byte loads into registers (a 4-byte load per coefficient makes the texture path walk 64 cache lines
+            // 48 times per wave); other layouts take the plain path.
+            auto shade = [&](auto sh_at) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-#define SH(i) sh[(i) * 3 + c]
-                float r = kSH_C0 * SH(0);
-                if (D > 0) {
-                    r = r - kSH_C1 * y * SH(1) + kSH_C1 * z * SH(2) - kSH_C1 * x * SH(3);
-                    if (D > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        r = r + kSH_C2[0] * xy * SH(4) + kSH_C2[1] * yz * SH(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
-                            kSH_C2[3] * xz * SH(7) + kSH_C2[4] * (xx - yy) * SH(8);
-                        if (D > 2) {
-                            r = r + kSH_C3[0] * y * (3.0f * xx - yy) * SH(9) + kSH_C3[1] * xy * z * SH(10) +
-                                kSH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
-                                kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
-                                kSH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + kSH_C3[5] * z * (xx - yy) * SH(14) +
-                                kSH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                for (int c = 0; c < 3; c++) {
+#define SH(i) sh_at(i, c)
+                    float r = kSH_C0 * SH(0);
+                    if (D > 0) {
+                        r = r - kSH_C1 * y * SH(1) + kSH_C1 * z * SH(2) - kSH_C1 * x * SH(3);
+                        if (D > 1) {
+                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                            r = r + kSH_C2[0] * xy * SH(4) + kSH_C2[1] * yz * SH(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+                                kSH_C2[3] * xz * SH(7) + kSH_C2[4] * (xx - yy) * SH(8);
+                            if (D > 2) {
+                                r = r + kSH_C3[0] * y * (3.0f * xx - yy) * SH(9) + kSH_C3[1] * xy * z * SH(10) +
+                                    kSH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+                                    kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                                    kSH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + kSH_C3[5] * z * (xx - yy) * SH(14) +
+                                    kSH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+                            }
                         }
                     }
-                }
 #undef SH
-                r += 0.5f;
-                if (r < 0) cl |= 1u << c;
-                rgb[c] = r > 0.0f ? r : 0.0f;
+                    r += 0.5f;
+                    if (r < 0) cl |= 1u << c;
+                    rgb[c] = r > 0.0f ? r : 0.0f;
+                }
+            };
+            if (M == 16) {
+                float row[48];
+                const float4* sh4 = reinterpret_cast<const float4*>(sh);   // 192-byte rows of a 16-byte aligned tensor
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const float4 v = sh4[k];
+                    row[4 * k] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
+                }
+                shade([&](int i, int c) { return row[i * 3 + c]; });
+            } else {
+                shade([&](int i, int c) { return sh[i * 3 + c]; });
             }
             clamped[idx] = (uint8_t)cl;
         } else {
@@ -345,13 +407,24 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
         float V[16], PM[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) { V[i] = viewmatrix[i]; PM[i] = projmatrix[i]; }
+        // first 16 floats of the row with four 16-byte loads (rows are 16-byte aligned: the stride is a multiple of 4 floats)
+        float g16[16];
+        {
+            const float4* gr4 = reinterpret_cast<const float4*>(gr);
 #pragma unroll
-        for (int i = 0; i < 9; i++) { dT[i] = gr[i]; dT_out[i] = dT[i]; }
+            for (int k = 0; k < 4; k++) {
+                const float4 v = gr4[k];
+                g16[4 * k] = v.x; g16[4 * k + 1] = v.y; g16[4 * k + 2] = v.z; g16[4 * k + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { dT[i] = g16[MRGS_G_DT + i]; dT_out[i] = dT[i]; }
         const int m2o = MRGS_G_M2(MRGS_SMAX(S));
-        const float m2x = gr[m2o], m2y = gr[m2o + 1];
-        dop = gr[MRGS_G_OPA];
-        const float dn[3] = {gr[MRGS_G_NRM], gr[MRGS_G_NRM + 1], gr[MRGS_G_NRM + 2]};
-        dcol[0] = gr[MRGS_G_COL]; dcol[1] = gr[MRGS_G_COL + 1]; dcol[2] = gr[MRGS_G_COL + 2];
+        const float2 m2v = *reinterpret_cast<const float2*>(gr + m2o);
+        const float m2x = m2v.x, m2y = m2v.y;
+        dop = g16[MRGS_G_OPA];
+        const float dn[3] = {g16[MRGS_G_NRM], g16[MRGS_G_NRM + 1], g16[MRGS_G_NRM + 2]};
+        dcol[0] = g16[MRGS_G_COL]; dcol[1] = g16[MRGS_G_COL + 1]; dcol[2] = g16[MRGS_G_COL + 2];
 
         // rasterizer_impl.cu:398-399 and backward.cu:646-647: W,H are re-derived from the focal lengths
         const float focal_y = Himg / (2.0f * tanfovy), focal_x = Wimg / (2.0f * tanfovx);
@@ -540,21 +613,23 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
             if (nrows > 0) wave_rows_store(s_sh[wave], dL_dsh + (size_t)row0 * L, nrows, L, lane);
         }
     }
-    if (!in_range) return;
-
-    dL_dmeans2D[3 * (size_t)idx] = dm2[0]; dL_dmeans2D[3 * (size_t)idx + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)idx + 2] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        dL_dcolors[3 * (size_t)idx + c] = dcol[c];
-        dL_dmeans3D[3 * (size_t)idx + c] = dm3[c];
+    // the per-gaussian outputs leave through the wave's LDS tile as well (every lane of the wave is still here)
+    {
+        float* tile = s_sh[wave];
+        const size_t r0 = (size_t)row0;
+        if (nrows > 0) {
+            const float m2v[3] = {dm2[0], dm2[1], 0.0f};
+            wave_store_rows<3>(tile, m2v, dL_dmeans2D + 3 * r0, nrows, lane);
+            wave_store_rows<3>(tile, dcol, dL_dcolors + 3 * r0, nrows, lane);
+            wave_store_rows<3>(tile, dm3, dL_dmeans3D + 3 * r0, nrows, lane);
+            wave_store_rows<9>(tile, dT_out, dL_dtransMat + 9 * r0, nrows, lane);
+            wave_store_rows<2>(tile, dsc, dL_dscales + 2 * r0, nrows, lane);
+            wave_store_rows<4>(tile, drot, dL_drotations + 4 * r0, nrows, lane);
+        }
     }
+    if (!in_range) return;
     for (int c = 0; c < S; c++) dL_dfeatures[(size_t)idx * S + c] = live ? gr[MRGS_G_FEAT + c] : 0.0f;
     dL_dopacity[idx] = dop;
-#pragma unroll
-    for (int i = 0; i < 9; i++) dL_dtransMat[9 * (size_t)idx + i] = dT_out[i];
-    dL_dscales[2 * (size_t)idx] = dsc[0]; dL_dscales[2 * (size_t)idx + 1] = dsc[1];
-#pragma unroll
-    for (int i = 0; i < 4; i++) dL_drotations[4 * (size_t)idx + i] = drot[i];
 }
 
 void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g,
