@@ -79,6 +79,7 @@ MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
     MrgsGeomWs g;
     const size_t n = (size_t)(P > 0 ? P : 1);
     g.rec = c.take<float4>(n * MRGS_REC_F4);
+    g.cull = c.take<float4>(n * MRGS_CULL_F4);
     g.depth_key[0] = c.take<uint32_t>(n);
     g.depth_key[1] = c.take<uint32_t>(n);
     g.order[0] = c.take<uint32_t>(n);
@@ -87,8 +88,8 @@ MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
     g.tiles_touched = c.take<uint32_t>(n);
     g.offsets = c.take<uint32_t>(n);
     g.clamped = c.take<uint8_t>(n);
-    g.counters = c.take<uint32_t>(16);
-    const size_t clear_from = c.used - 16 * sizeof(uint32_t);
+    g.counters = c.take<uint32_t>(16 + MRGS_CENSUS_WORDS);
+    const size_t clear_from = c.used - (16 + MRGS_CENSUS_WORDS) * sizeof(uint32_t);
     g.sort_ws = c.take<uint32_t>(mrgs_sort_ws_words((int64_t)n));
     g.scan_ws = c.take<uint32_t>(mrgs_scan_ws_words((int)n));
     g.clear_bytes = c.used - clear_from;
@@ -102,14 +103,19 @@ MrgsImgWs mrgs_carve_img(void* base, int H, int W)
     MrgsImgWs w;
     const size_t hw = (size_t)H * W;
     const size_t tiles = (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y);
-    w.ranges = c.take<uint2>(tiles > 0 ? tiles : 1);
-    w.tile_order = c.take<uint32_t>(tiles + 8);
-    const size_t nslots = (tiles + 7) / 8 * 8;
-    w.item_work = c.take<uint32_t>(8 * nslots + 8);
-    w.bwd_items = c.take<uint32_t>(8 * nslots + 8);
-    w.bwd_work = c.take<uint32_t>(8 * nslots + 8);
-    w.bwd_assign = c.take<uint32_t>(8 * (nslots + MRGS_MAX_SIMD_QUEUES) + 8);
-    w.bwd_state = c.take<uint32_t>(MRGS_BS_WORDS);
+    const size_t nt = tiles > 0 ? tiles : 1;
+    w.ranges = c.take<uint2>(nt);
+    const size_t ranges_from = c.used - sizeof(uint2) * nt;
+    c.used = mrgs_align_up(c.used, 256);
+    w.item_est = c.take<uint32_t>(4 * nt);
+    w.ranges_est_bytes = c.used - ranges_from;
+    w.item_work = c.take<uint32_t>(4 * nt);
+    const size_t per_list = (nt + 7) / 8 * 4;
+    w.order_items = c.take<uint32_t>(8 * per_list);
+    w.order_work = c.take<uint32_t>(8 * per_list);
+    w.fwd_assign = c.take<uint32_t>(8 * (per_list + MRGS_MAX_SIMD_QUEUES));
+    w.bwd_assign = c.take<uint32_t>(8 * (per_list + MRGS_MAX_SIMD_QUEUES));
+    w.blend_state = c.take<uint32_t>(MRGS_BLEND_STATE_WORDS);
     w.final_T = c.take<float>(3 * hw);
     w.n_contrib = c.take<uint32_t>(2 * hw);
     w.total = mrgs_align_up(c.used, 256);
@@ -127,6 +133,7 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R)
     b.plist[1] = c.take<uint32_t>(n);
     b.sort_ws = c.take<uint32_t>(16 + mrgs_sort_ws_words((int64_t)n));
     b.sort_ws_bytes = sizeof(uint32_t) * (16 + mrgs_sort_ws_words((int64_t)n));
+    b.qmask = c.take<uint8_t>(n);
     b.total = mrgs_align_up(c.used, 256);
     return b;
 }
@@ -203,12 +210,13 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     const int bits = tile_bits(ntiles);
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
     STAGE_CHECK(cfg, stream);
-    mrgs_launch_tile_ranges(b.tile_key[cur], R, R_dev, img, ntiles, stream);
+    mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
+    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
     StageTimer t1(stream, ST_FWD);
-    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], img, out_color, out_feature, out_others, stream);
+    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], b.qmask, img, out_color, out_feature, out_others, stream);
     t1.stop();
     STAGE_CHECK(cfg, stream);
     return MRGS_OK;
@@ -338,8 +346,8 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     StageTimer t0(stream, ST_BWD);
     HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
     if (R > 0) {
-        mrgs_launch_bwd_order(img, tiles_x * tiles_y, stream);
-        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
+        mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, stream);
+        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.qmask, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
     }
     t0.stop();
     STAGE_CHECK(cfg, stream);

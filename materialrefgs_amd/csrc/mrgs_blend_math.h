@@ -16,27 +16,36 @@
 #define MRGS_CHUNK 64   // list entries staged per step = one per lane
 
 
-// Work-item decode shared by the two blend kernels.  tile_order[] lists the tile ids by decreasing list length and
-// tile_order[nslots] holds the number of leading "split" tiles (>= MRGS_SPLIT_THRESHOLD entries).  Tile p of the order is
-// dealt to XCD p % 8 (blockIdx % 8 selects the XCD, so all waves of a tile share one L2).  Inside an XCD the work items are
-// enumerated longest tile first: 8 items (4 quadrants x two 8x4 halves) per split tile, then 4 items (8x8 quadrants) per
-// ordinary tile -- so the dispatch order is also the order of decreasing work and contains no idle waves before its tail.
-struct BlendItem { int tile, quad, half; bool split; };
-__device__ __forceinline__ bool mrgs_decode_item(const uint32_t* __restrict__ tile_order, int ntiles, int b, BlendItem& it)
+// Work-item pull shared by the two blend kernels (queues built by blend_order_kernel, mrgs_sort.hip).  Wave `wv` of XCD
+// list `xcd` (blockIdx = wv * 8 + xcd: blockIdx % 8 selects the XCD) takes the next item from the queue of the SIMD it runs
+// on and falls back to the other queues of the list when its own is empty.  Exactly n_items waves of a list take part and
+// exactly n_items tickets are valid, so every participant ends up with one item.  Returns 0xFFFFFFFF for "no work",
+// otherwise tile << 2 | quadrant, with the wave's issue priority in bits 29-30.
+__device__ __forceinline__ uint32_t mrgs_pull_item(uint32_t* __restrict__ qstate, const uint32_t* __restrict__ cu_state,
+                                                   const uint32_t* __restrict__ assign_ws, int ntiles, int xcd, int wv, int lane)
 {
-    const int nslots = ((ntiles + 7) >> 3) << 3;
-    const int xcd = b & 7, seq = b >> 3;
-    const int nsplit = (int)tile_order[nslots];
-    const int ns_x = (nsplit + 7 - xcd) >> 3;          // split tiles dealt to this XCD
-    int g;
-    if (seq < 8 * ns_x) { g = seq >> 3; it.quad = seq & 3; it.half = (seq >> 2) & 1; it.split = true; }
-    else { const int s2 = seq - 8 * ns_x; g = ns_x + (s2 >> 2); it.quad = s2 & 3; it.half = 0; it.split = false; }
-    const int p = g * 8 + xcd;
-    if (p >= nslots) return false;
-    it.tile = (int)tile_order[p];
-    return it.tile < ntiles;
+    const int n_items = (int)qstate[MRGS_QS_COUNT + xcd];
+    if (wv >= n_items) return 0xFFFFFFFFu;
+    const int per_list = ((ntiles + 7) >> 3) * 4;
+    const uint32_t pw = qstate[MRGS_QS_PASSES + xcd];
+    const int passes = (int)(pw & 0xFFFFu), NQ = (int)(pw >> 16);
+    const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));              // HW_REG_HW_ID
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;           // HW_REG_XCC_ID
+    const uint32_t dense = cu_state[MRGS_CS_DENSE + xcc * 256 + mrgs_cu_key(hw_id)];
+    const int q0 = (int)((dense * 4u + ((hw_id >> 4) & 3u)) % (uint32_t)NQ);
+    const uint32_t* assign = assign_ws + (size_t)xcd * (per_list + MRGS_MAX_SIMD_QUEUES);
+    uint32_t* tickets = qstate + MRGS_QS_TICKET + xcd * MRGS_MAX_SIMD_QUEUES;
+    uint32_t item = 0xFFFFFFFFu;
+    if (lane == 0) {
+        for (int d = 0; d < NQ && item == 0xFFFFFFFFu; d++) {
+            const int q = q0 + d < NQ ? q0 + d : q0 + d - NQ;
+            if (d > 0 && __hip_atomic_load(&tickets[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)passes) continue;
+            const int t = (int)atomicAdd(&tickets[q], 1u);
+            if (t < passes) item = assign[t * NQ + q];
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(item);
 }
-
 
 __device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -129,11 +138,11 @@ __device__ __forceinline__ CullConic mrgs_cull_never()
     c.b = make_float4(1e30f, 0.0f, 0.0f, -1.0f);
     return c;
 }
-__device__ __forceinline__ CullConic mrgs_cull_load(const float4* __restrict__ rec, uint32_t gid)
+__device__ __forceinline__ CullConic mrgs_cull_load(const float4* __restrict__ rec /* MrgsGeomWs::cull */, uint32_t gid)
 {
     CullConic c;
-    c.a = rec[(size_t)gid * MRGS_REC_F4 + 5];
-    c.b = rec[(size_t)gid * MRGS_REC_F4 + 6];
+    c.a = rec[(size_t)gid * MRGS_CULL_F4];
+    c.b = rec[(size_t)gid * MRGS_CULL_F4 + 1];
     return c;
 }
 

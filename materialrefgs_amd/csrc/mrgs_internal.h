@@ -11,12 +11,15 @@
 #define MRGS_FILTER_INV_SQUARE 2.0f  // auxiliary.h:41
 
 // Packed per-gaussian render record written by preprocess and gathered by the blend kernels:
-// 7 x float4 = 112 B, 16-byte aligned so that a record is fetched with dwordx4 loads.
-//   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   (geometry: read for every list entry)
-//   [3] normal.xyz, rgb.r   [4] rgb.gb, depth, 0                          (appearance: read only when blended)
-//   [5] cull conic: ellipse centre.xy, A, B   [6] C, mean2D.xy, disc r^2    (mrgs_blend_math.h; read for every list entry)
+// 5 x float4 = 80 B, 16-byte aligned so that a record is fetched with dwordx4 loads.
+//   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   (geometry)
+//   [3] normal.xyz, rgb.r   [4] rgb.gb, depth, 0                          (appearance)
 // (the reference keeps these in five separate arrays: transMat, means2D, normal_opacity, rgb; forward.cu:350-357,427)
-#define MRGS_REC_F4 7
+// The cull conic (mrgs_blend_math.h) lives in its own array, 2 x float4 per gaussian: it is gathered once per list entry
+// by tile_ranges_kernel and never by the blend kernels.
+//   [0] ellipse centre.xy, A, B   [1] C, mean2D.xy, disc r^2
+#define MRGS_REC_F4 5
+#define MRGS_CULL_F4 2
 
 // Packed per-gaussian gradient accumulator of the blend backward (one row per gaussian so that the
 // atomics of one (tile, gaussian) pair land in one or two cache lines):
@@ -37,6 +40,7 @@ static inline size_t mrgs_align_up(size_t v, size_t a) { return (v + a - 1) / a 
 
 struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
     float4* rec;            // [P][MRGS_REC_F4]
+    float4* cull;           // [P][MRGS_CULL_F4]
     uint32_t* depth_key[2]; // [P] ping-pong radix keys (depth bits, 0xFFFFFFFF when culled)
     uint32_t* order[2];     // [P] ping-pong payload: gaussian index
     uint2* rect;            // [P] tile rect packed: x = min.x | min.y<<16, y = max.x | max.y<<16
@@ -44,7 +48,7 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
     uint32_t* offsets;      // [P] exclusive scan of tiles_touched in depth-sorted order
     uint8_t* clamped;       // [P] bit c set when SH colour channel c was clamped
     // cleared at the start of every forward (one memset over [counters, scan_ws end)):
-    uint32_t* counters;     // [16] 0: num_rendered, 1: error flag of the look-back kernels
+    uint32_t* counters;     // [16] 0: num_rendered, 1: error flag of the look-back kernels; then [MRGS_CENSUS_WORDS] CU census
     uint32_t* sort_ws;      // tickets / digit totals / status words of the depth sort (mrgs_sort_ws_words)
     uint32_t* scan_ws;      // ticket / status words of the tiles_touched scan (mrgs_scan_ws_words)
     size_t clear_bytes;     // size of the region that starts at counters
@@ -53,12 +57,12 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
 
 struct MrgsImgWs {
     uint2* ranges;       // [tiles]
-    uint32_t* tile_order;// [tiles rounded up to 8] blend dispatch order: tile ids by decreasing list length
-    uint32_t* item_work; // [8 * nslots] list entries each forward wave walked (item = tile * 8 + quadrant + 4 * half); 0 = idle
-    uint32_t* bwd_items; // [8][nslots] per XCD: work items of the blend backward by decreasing forward work
-    uint32_t* bwd_work;  // [8][nslots] their work
-    uint32_t* bwd_assign;// [8][nslots + 128] per XCD: item handed to ticket t of SIMD queue q at [t * NQ + q]
-    uint32_t* bwd_state; // MRGS_BS_* : item counts, per-CU queue tickets, CU census of the forward launch, dense CU numbering
+    uint32_t* item_est;  // [4 * tiles] directly behind ranges (cleared together): entries that pass the cull per (tile, quadrant)
+    size_t ranges_est_bytes;
+    uint32_t* item_work; // [4 * tiles] cost of each forward wave's walk (item = tile * 4 + quadrant) = work of its backward wave
+    uint32_t* order_items, *order_work;   // [8][per_list] scratch of blend_order_kernel (items of an XCD list by decreasing work)
+    uint32_t* fwd_assign, *bwd_assign;    // [8][per_list + 128] item handed to ticket t of SIMD queue q at [t * NQ + q]
+    uint32_t* blend_state;                // MRGS_BLEND_STATE_WORDS
     float* final_T;      // [3][H*W]: T, M1, M2
     uint32_t* n_contrib; // [2][H*W]: last, median
     size_t total;
@@ -69,6 +73,7 @@ struct MrgsBinWs {
     uint32_t* plist[2];     // [R] ping-pong: gaussian index of each pair
     uint32_t* sort_ws;      // [16] 0: error flag; then tickets / digit totals / status words of the tile-id sort; cleared per forward
     size_t sort_ws_bytes;
+    uint8_t* qmask;         // [R] bit q: the entry's surfel can touch quadrant q of its tile (tile_ranges_kernel)
     size_t total;
 };
 
@@ -79,20 +84,31 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
 // ---- kernel launchers (one per translation unit) ---------------------------------------------------
 // radix sort of (u32 key, u32 value) pairs on bits [bit_lo, bit_hi); returns index (0/1) of the buffer
 // that holds the sorted result.  hist must hold 256 * ceil(n / SORT_TILE) u32.
-#ifndef MRGS_SPLIT_THRESHOLD
-#define MRGS_SPLIT_THRESHOLD 4080   // tiles with at least this many list entries are blended by 8 half-quadrant waves instead of 4 (multiple of 16, <= 4080)
-#endif
+
 #define MRGS_SORT_WS_HEADER 16
-// layout of MrgsImgWs::bwd_state (uint32 words); a CU is identified by (XCC_ID[2:0], HW_ID se[2:0] sh cu[3:0]) = 3 + 8 bits
+// Work queues of the blend kernels (mrgs_sort.hip: blend_order_kernel; mrgs_blend_math.h: mrgs_pull_item).
+// MrgsImgWs::blend_state (uint32 words) = queue state of the forward | queue state of the backward | CU numbering.
+// A CU is identified by (XCC_ID[2:0], HW_ID se[2:0] sh cu[3:0]) = 3 + 8 bits.
 #define MRGS_MAX_SIMD_QUEUES 128             // 32 CUs x 4 SIMDs per XCD
-#define MRGS_BS_COUNT 0                      // [8]       work items of each XCD list
-#define MRGS_BS_PASSES 8                     // [8]       dealing passes of each XCD list
-#define MRGS_BS_TICKET 16                    // [8][128]  items handed out per (XCD list, SIMD queue)
-#define MRGS_BS_BITMAP (16 + 1024)           // [8][8]    CUs seen by the forward blend launch, one bit per CU key, per XCC
-#define MRGS_BS_NCU (16 + 1024 + 64)         // [8]       CUs per XCC
-#define MRGS_BS_DENSE (16 + 1024 + 64 + 8)   // [8][256]  CU key -> dense index inside its XCC
-#define MRGS_BS_WORDS (16 + 1024 + 64 + 8 + 2048)
+#define MRGS_QS_COUNT 0                      // [8]       work items of each XCD list
+#define MRGS_QS_PASSES 8                     // [8]       dealing passes | NQ << 16 of each XCD list
+#define MRGS_QS_TICKET 16                    // [8][128]  items handed out per (XCD list, SIMD queue)
+#define MRGS_QS_WORDS (16 + 8 * MRGS_MAX_SIMD_QUEUES)
+#define MRGS_QS_FWD 0
+#define MRGS_QS_BWD MRGS_QS_WORDS
+#define MRGS_CS_BASE (2 * MRGS_QS_WORDS)
+#define MRGS_CS_NCU 0                        // [8]       CUs per XCC
+#define MRGS_CS_DENSE 8                      // [8][256]  CU key -> dense index inside its XCC
+#define MRGS_BLEND_STATE_WORDS (2 * MRGS_QS_WORDS + 8 + 2048)
+#define MRGS_CENSUS_WORDS 2048               // [8][256] flag per CU key: a preprocess wave ran there; in MrgsGeomWs::counters + 16
 __device__ __forceinline__ uint32_t mrgs_cu_key(uint32_t hw_id) { return ((hw_id >> 8) & 0xFFu); }   // cu[3:0] sh se[2:0]
+// CU census bit of the calling wave (set by the preprocess waves, read by blend_order_kernel)
+__device__ __forceinline__ void mrgs_census_mark(uint32_t* __restrict__ census)
+{
+    const uint32_t key = mrgs_cu_key(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
+    census[xcc * 256 + key] = 1u;   // plain idempotent store, nothing in the wave waits for it
+}
 // stable LSD radix sort of (key, value) pairs on key bits [bit_lo, bit_hi); returns the index of the buffer holding the
 // result.  ws: mrgs_sort_ws_words(n) zeroed words; *error_flag is set if a look-back spin overruns (never expected).
 size_t mrgs_sort_ws_words(int64_t n);
@@ -112,13 +128,14 @@ void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatr
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
                            uint32_t* plist, int64_t capacity, hipStream_t stream);
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, const MrgsImgWs& img, int ntiles, hipStream_t stream);
-void mrgs_launch_bwd_order(const MrgsImgWs& img, int ntiles, hipStream_t stream);
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,
+                             uint8_t* qmask, const MrgsImgWs& img, int tiles_x, int ntiles, hipStream_t stream);
+void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);
+                            const uint8_t* qmask, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
+                            const uint8_t* qmask, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
                             float* grad_rec, hipStream_t stream);
 
 #ifndef MRGS_EXP

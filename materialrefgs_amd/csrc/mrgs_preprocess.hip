@@ -139,9 +139,11 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order,
-    uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped)
+    int32_t* __restrict__ radii, float4* __restrict__ rec, float4* __restrict__ cull, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order,
+    uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped, uint32_t* __restrict__ census)
 {
+    // which CUs exist (the blend kernels keep one work queue per SIMD): one bit per CU, set by the first wave that runs there
+    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
     // (the SH rows are read straight from global memory here: staging them through LDS as the backward does costs more in
     // occupancy -- 50 KB per workgroup -- than the coalescing gains; 0.060 ms staged vs 0.054 ms direct at P = 300k)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,8 +328,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         r4[2] = make_float4(T[8], cx, cy, opa);
         r4[3] = make_float4(nx, ny, nz, rgb[0]);
         r4[4] = make_float4(rgb[1], rgb[2], pvz, 0.0f);
-        r4[5] = cull_a;
-        r4[6] = cull_b;
+        cull[(size_t)idx * MRGS_CULL_F4] = cull_a;
+        cull[(size_t)idx * MRGS_CULL_F4 + 1] = cull_b;
         out_radius = iradius;
         out_tiles = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
         out_key = __float_as_uint(pvz);
@@ -346,8 +348,8 @@ void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H,
                        tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
-                       in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec,
-                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped);
+                       in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec, g.cull,
+                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters + 16);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -174,7 +174,8 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 4 : S_MAX <= 8 ? 3 : 2, 8))) render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ bwd_state, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
+    const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride)
@@ -183,47 +184,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     constexpr int K = 16 + S_MAX;   // values through the transposing reduction (the dL/dmean2D pair goes apart)
     __shared__ StageBuf<SF> stage[MRGS_BWD_STAGES];
 
-    // Work-item pull (see bwd_order_kernel): this wave takes the next item from the queue of the SIMD it runs on and falls
-    // back to the other queues when its own is empty.  Exactly n_items waves of an XCD list take part and exactly n_items
-    // tickets are valid, so every participant ends up with one item.
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    const int xcd = b & 7, wv = b >> 3;
-    const int nslots = ((ntiles + 7) >> 3) << 3;
-    const int n_items = (int)bwd_state[MRGS_BS_COUNT + xcd];
-    if (wv >= n_items) return;
-    uint32_t item = 0xFFFFFFFFu;
-    {
-        const uint32_t pw = bwd_state[MRGS_BS_PASSES + xcd];
-        const int passes = (int)(pw & 0xFFFFu), NQ = (int)(pw >> 16);
-        const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));              // HW_REG_HW_ID
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;           // HW_REG_XCC_ID
-        const uint32_t dense = bwd_state[MRGS_BS_DENSE + xcc * 256 + mrgs_cu_key(hw_id)];
-        const int q0 = (int)((dense * 4u + ((hw_id >> 4) & 3u)) % (uint32_t)NQ);
-        const uint32_t* assign = bwd_assign + (size_t)xcd * (nslots + MRGS_MAX_SIMD_QUEUES);
-        uint32_t* tickets = bwd_state + MRGS_BS_TICKET + xcd * MRGS_MAX_SIMD_QUEUES;
-        if (lane == 0) {
-            for (int d = 0; d < NQ && item == 0xFFFFFFFFu; d++) {
-                const int q = q0 + d < NQ ? q0 + d : q0 + d - NQ;
-                if (d > 0 && __hip_atomic_load(&tickets[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)passes) continue;
-                const int t = (int)atomicAdd(&tickets[q], 1u);
-                if (t < passes) item = assign[t * NQ + q];
-            }
-        }
-        item = __builtin_amdgcn_readfirstlane(item);
-    }
+    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_BWD, blend_state + MRGS_CS_BASE, bwd_assign, ntiles, b & 7, b >> 3, lane);
     if (item == 0xFFFFFFFFu) return;
-    const int tile = (int)((item & 0x1FFFFFFFu) >> 3), quad = (int)(item & 3u), half = (int)((item >> 2) & 1u);
+    const int tile = (int)((item & 0x1FFFFFFFu) >> 2), quad = (int)(item & 3u);
     const uint32_t prio = (item >> 29) & 3u;
     const uint2 range = ranges[tile];
-    const bool split = (range.y - range.x) >= (uint32_t)MRGS_SPLIT_THRESHOLD;   // as the forward decided (mrgs_decode_item)
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
-    const int rows = split ? 4 : 8;
-    const int pxi = bx * 8 + (lane & 7), pyi = by * 8 + half * 4 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H && (lane >> 3) < rows;
+    const int pxi = bx * 8 + (lane & 7), pyi = by * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi, py = (float)pyi;
-    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8 + half * 4), blk_h = (float)(rows - 1);   // rectangle of pixel centres
     const int HW = H * W;
     const int pix = inside ? W * pyi + pxi : 0;
 
@@ -280,26 +252,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     // Same staging pipeline as the forward (LDS-DMA, cull conics two chunks and ids three chunks ahead), walked
     // towards the front of the list.  The id slot of a staged entry holds the BYTE offset of the surfel's gradient row.
     const uint32_t* plist = point_list + range.x;
-    const CullConic kNever = mrgs_cull_never();
+    const uint8_t* qm = qmask + range.x;
     const ReduceLane rl = mrgs_reduce_lane(lane);
     const uint32_t row_bytes = (uint32_t)gstride * 4u;
     const int c_top = (max_contrib - 1) / MRGS_CHUNK;
-    uint32_t id1 = 0, id2 = 0;
-    CullConic box1 = kNever;
+    uint32_t id1 = 0, id2 = 0, q1 = 0, q2 = 0;
     uint64_t mask_cur;
     {
-        uint32_t id0 = 0;
-        CullConic box0 = kNever;
-        if (c_top * MRGS_CHUNK + lane < max_contrib) {
-            id0 = plist[c_top * MRGS_CHUNK + lane];
-            box0 = mrgs_cull_load(rec, id0);
-        }
-        if (c_top >= 1) {
-            id1 = plist[(c_top - 1) * MRGS_CHUNK + lane];
-            box1 = mrgs_cull_load(rec, id1);
-        }
-        if (c_top >= 2) id2 = plist[(c_top - 2) * MRGS_CHUNK + lane];
-        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
+        uint32_t id0 = 0, q0 = 0;
+        if (c_top * MRGS_CHUNK + lane < max_contrib) { id0 = plist[c_top * MRGS_CHUNK + lane]; q0 = qm[c_top * MRGS_CHUNK + lane]; }
+        if (c_top >= 1) { id1 = plist[(c_top - 1) * MRGS_CHUNK + lane]; q1 = qm[(c_top - 1) * MRGS_CHUNK + lane]; }
+        if (c_top >= 2) { id2 = plist[(c_top - 2) * MRGS_CHUNK + lane]; q2 = qm[(c_top - 2) * MRGS_CHUNK + lane]; }
+        const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
@@ -311,14 +275,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         WS_CHUNK();
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
-            const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
+            const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
-            id1 = id2;
-            box1 = kNever;
-            if (c >= 2) box1 = mrgs_cull_load(rec, id1);
-            if (c >= 3) id2 = plist[(c - 3) * MRGS_CHUNK + lane];
+            id1 = id2; q1 = q2;
+            id2 = 0; q2 = 0;
+            if (c >= 3) { id2 = plist[(c - 3) * MRGS_CHUNK + lane]; q2 = qm[(c - 3) * MRGS_CHUNK + lane]; }
         };
         if (MRGS_BWD_STAGES == 2) stage_next();
 
@@ -465,15 +428,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 }
 
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
+                            const uint8_t* qmask, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
                             float* grad_rec, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 8;   // at most 8 items per tile, one wave each; waves dealt to the 8 XCDs
+    const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // one wave per (tile, quadrant); blockIdx % 8 = XCD list
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, GS)                                                                                                       \
-    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.bwd_assign, img.bwd_state, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.bwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS)
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);

@@ -26,10 +26,11 @@
 
 template <int S_MAX>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int S, int W, int H, int tiles_x, int ntiles,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
+    const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
-    uint32_t* __restrict__ item_work, uint32_t* __restrict__ bwd_state)
+    uint32_t* __restrict__ item_work)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
@@ -37,31 +38,24 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const int lane = threadIdx.x;
     // XCD-aware mapping: b % 8 selects the XCD; within an XCD consecutive blocks are the 4 quadrants of one tile
     const int b = blockIdx.x;
-    BlendItem item;
-    if (!mrgs_decode_item(tile_order, ntiles, b, item)) return;
-    const int tile = item.tile, quad = item.quad, half = item.half;
-    const bool split = item.split;
+    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_FWD, blend_state + MRGS_CS_BASE, fwd_assign, ntiles, b & 7, b >> 3, lane);
+    if (item == 0xFFFFFFFFu) return;
+    const int tile = (int)((item & 0x1FFFFFFFu) >> 2), quad = (int)(item & 3u);
+    const uint32_t prio = (item >> 29) & 3u;
     const uint2 range = ranges[tile];
-    // The launch lasts as long as its longest wave, so the quadrants of the DENSEST tiles are split into two 8x4 halves:
-    // each half sees fewer surfels (the cull rectangle is half as tall), which shortens the critical path at the price of
-    // idle lanes in a few waves.
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int bx = tx * 2 + (quad & 1), by = ty * 2 + (quad >> 1);
-    const int rows = split ? 4 : 8;
-    const int pxi = bx * 8 + (lane & 7), pyi = by * 8 + half * 4 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H && (lane >> 3) < rows;
+    const int pxi = bx * 8 + (lane & 7), pyi = by * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi, py = (float)pyi;
-    const float blk_x0 = (float)(bx * 8), blk_y0 = (float)(by * 8 + half * 4), blk_h = (float)(rows - 1);   // rectangle of pixel centres
     const int HW = H * W;
     const int pix = W * pyi + pxi;
 
     const int total = (int)(range.y - range.x);
-    // The launch lasts as long as its longest wave: every wave is resident from the start, and the waves of the densest
-    // tiles carry several times the average work.  Give them issue priority so that they run near their single-wave
-    // speed while the light waves fill the remaining issue slots.
-    if (total > 1024) __builtin_amdgcn_s_setprio(3);
-    else if (total > 512) __builtin_amdgcn_s_setprio(2);
-    else if (total > 256) __builtin_amdgcn_s_setprio(1);
+    // heavy items first in line for issue slots (priority class chosen by blend_order_kernel)
+    if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
 
     bool done = !inside;
     uint32_t work = 0;
@@ -74,25 +68,18 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     uint32_t last_contributor = 0, median_contributor = 0;
     const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
 
-    // ---- pipeline prologue: chunk 0 staged, box of chunk 1 and ids of chunks 1, 2 on their way ------------
+    // ---- pipeline prologue: chunk 0 staged, ids and cull bits of chunks 1, 2 on their way ----------------------
+    // (the block-level cull was evaluated once per entry and quadrant by tile_ranges_kernel: bit `quad` of qmask)
     const uint32_t* plist = point_list + range.x;
-    const CullConic kNever = mrgs_cull_never();
-    uint32_t id1 = 0, id2 = 0;
-    CullConic box1 = kNever;
+    const uint8_t* qm = qmask + range.x;
+    uint32_t id1 = 0, id2 = 0, q1 = 0, q2 = 0;
     uint64_t mask_cur;
     {
-        uint32_t id0 = 0;
-        CullConic box0 = kNever;
-        if (lane < total) {
-            id0 = plist[lane];
-            box0 = mrgs_cull_load(rec, id0);
-        }
-        if (MRGS_CHUNK + lane < total) {
-            id1 = plist[MRGS_CHUNK + lane];
-            box1 = mrgs_cull_load(rec, id1);
-        }
-        if (2 * MRGS_CHUNK + lane < total) id2 = plist[2 * MRGS_CHUNK + lane];
-        const bool cand0 = mrgs_block_may_touch(box0, blk_x0, blk_y0, 7.0f, blk_h);
+        uint32_t id0 = 0, q0 = 0;
+        if (lane < total) { id0 = plist[lane]; q0 = qm[lane]; }
+        if (MRGS_CHUNK + lane < total) { id1 = plist[MRGS_CHUNK + lane]; q1 = qm[MRGS_CHUNK + lane]; }
+        if (2 * MRGS_CHUNK + lane < total) { id2 = plist[2 * MRGS_CHUNK + lane]; q2 = qm[2 * MRGS_CHUNK + lane]; }
+        const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         mrgs_stage_async<S_MAX, SF>(stage[0], rec, features, S, id0, cand0);
     }
@@ -102,14 +89,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         mrgs_stage_wait();                    // chunk c has landed
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
-            // stage chunk c+1 (its ids and boxes arrived during the previous iteration), prefetch box c+2 and ids c+3
-            const bool cand1 = mrgs_block_may_touch(box1, blk_x0, blk_y0, 7.0f, blk_h);
+            // stage chunk c+1 (its ids and cull bits arrived during the previous iterations), prefetch those of chunk c+3
+            const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
-            id1 = id2;
-            box1 = kNever;
-            if (base + 2 * MRGS_CHUNK + lane < total) box1 = mrgs_cull_load(rec, id1);
-            if (base + 3 * MRGS_CHUNK + lane < total) id2 = plist[base + 3 * MRGS_CHUNK + lane];
+            id1 = id2; q1 = q2;
+            id2 = 0; q2 = 0;
+            if (base + 3 * MRGS_CHUNK + lane < total) { id2 = plist[base + 3 * MRGS_CHUNK + lane]; q2 = qm[base + 3 * MRGS_CHUNK + lane]; }
         };
         if (MRGS_FWD_STAGES == 2) stage_next();
 
@@ -188,14 +174,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 
     // entries this wave tested + 3 x entries it blended: the cost of the backward wave of the same pixel block, which walks
     // the same entries (bwd_order_kernel)
-    if (lane == 0) {
-        item_work[tile * 8 + quad + 4 * half] = work;
-        // CU census for the backward's per-CU work queues
-        const uint32_t key = mrgs_cu_key(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
-        uint32_t* word = bwd_state + MRGS_BS_BITMAP + xcc * 8 + (key >> 5);
-        if (!((*word >> (key & 31)) & 1u)) atomicOr(word, 1u << (key & 31));
-    }
+    if (lane == 0) item_work[tile * 4 + quad] = work;
     if (inside) {
         final_T[pix] = T;
         final_T[pix + HW] = M1;
@@ -221,15 +200,15 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 }
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream)
+                            const uint8_t* qmask, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 8;   // 8 waves per tile (4 quadrants x 2 halves), tiles dealt to the 8 XCDs   // 4 quadrant-waves per tile, tiles dealt to the 8 XCDs
+    const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // one wave per (tile, quadrant); blockIdx % 8 = XCD list
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM)                                                                                                           \
-    hipLaunchKernelGGL(render_fwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.tile_order, plist, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.bwd_state)
+    hipLaunchKernelGGL(render_fwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work)
     if (cfg.S == 0) LAUNCH(0);
     else if (cfg.S <= 8) LAUNCH(8);
     else if (cfg.S <= 12) LAUNCH(12);

@@ -10,7 +10,7 @@
 //   (3) a stable sort of the R pairs on the tile id only (2 passes for <= 65536 tiles).
 // LSD radix passes are stable, so within a tile the pairs stay in (depth bits, gaussian index) order --
 // exactly the reference's order -- while moving ~3.4x fewer bytes than the 64-bit-key sort.
-#include "mrgs_internal.h"
+#include "mrgs_blend_math.h"
 
 #define SORT_THREADS 256
 #define SORT_WAVES (SORT_THREADS / 64)
@@ -390,150 +390,191 @@ void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, con
                        g.rect, tiles_x, tile_key, plist, (uint32_t)capacity);
 }
 
-// ---- identifyTileRanges (rasterizer_impl.cu:118-140) on the sorted tile ids ---------------------------
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __restrict__ tile_key, int64_t R_host,
-                                                          const uint32_t* __restrict__ R_dev, uint2* __restrict__ ranges)
+// ---- identifyTileRanges (rasterizer_impl.cu:118-140) on the sorted tile ids + quadrant cull ------------------
+// One thread per list entry.  Besides the tile ranges it evaluates the block-level cull (mrgs_block_may_touch) of the
+// entry's surfel against the four 8x8 quadrants of its tile ONCE -- the blend kernels' four quadrant waves used to fetch
+// the 32-byte cull conic and run the test each, in the forward and again in the backward -- and leaves
+//   qmask[idx]            bit q set when the surfel can touch quadrant q (the blend waves read 1 byte per entry),
+//   item_est[tile*4 + q]  number of such entries = the forward's work estimate for that quadrant wave (blend_order_kernel).
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __restrict__ tile_key, const uint32_t* __restrict__ plist,
+                                                          int64_t R_host, const uint32_t* __restrict__ R_dev, const float4* __restrict__ cull,
+                                                          int tiles_x, uint2* __restrict__ ranges, uint8_t* __restrict__ qmask,
+                                                          uint32_t* __restrict__ item_est)
 {
     const int64_t R = mrgs_count(R_host, R_dev);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R) return;
-    const uint32_t cur = tile_key[idx];
-    if (idx == 0)
-        ranges[cur].x = 0;
-    else {
-        const uint32_t prev = tile_key[idx - 1];
-        if (cur != prev) {
-            ranges[prev].y = (uint32_t)idx;
-            ranges[cur].x = (uint32_t)idx;
+    const bool valid = idx < R;
+    uint32_t cur = 0xFFFFFFFFu;
+    uint32_t m = 0;
+    if (valid) {
+        cur = tile_key[idx];
+        if (idx == 0)
+            ranges[cur].x = 0;
+        else {
+            const uint32_t prev = tile_key[idx - 1];
+            if (cur != prev) {
+                ranges[prev].y = (uint32_t)idx;
+                ranges[cur].x = (uint32_t)idx;
+            }
+        }
+        if (idx == R - 1) ranges[cur].y = (uint32_t)R;
+        const CullConic c = mrgs_cull_load(cull, plist[idx]);
+        const int tx = (int)(cur % (uint32_t)tiles_x), ty = (int)(cur / (uint32_t)tiles_x);
+        const float x0 = (float)(tx * MRGS_BLOCK_X), y0 = (float)(ty * MRGS_BLOCK_Y);
+#ifdef TR_NO_CULL
+        m = (c.a.x + x0 + y0 > 1e20f) ? 3u : 15u;
+#else
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            m |= mrgs_block_may_touch(c, x0 + (float)(8 * (q & 1)), y0 + (float)(8 * (q >> 1)), 7.0f, 7.0f) ? (1u << q) : 0u;
+#endif
+        qmask[idx] = (uint8_t)m;
+    }
+    // per-quadrant counts: one atomic per (wave, tile, quadrant) -- a wave spans one tile, or a few at segment boundaries
+#ifdef TR_NO_ATOMICS
+    uint64_t todo = 0;
+#else
+    uint64_t todo = __builtin_amdgcn_ballot_w64(valid);
+#endif
+    while (todo != 0ull) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)cur, __builtin_ctzll(todo));
+        const bool mine = valid && cur == t;
+        todo &= ~__builtin_amdgcn_ballot_w64(mine);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int n = __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && ((m >> q) & 1u)));
+            if ((threadIdx.x & 63) == 0 && n > 0) atomicAdd(&item_est[t * 4 + q], (uint32_t)n);
         }
     }
-    if (idx == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-// Blend-kernel dispatch order: tiles sorted by decreasing list length (counting sort on length / 16, one workgroup).  The
-// blend launches last as long as their longest wave, and not every wave is resident from the start: longest-first keeps the
-// heavy tiles off the tail of the launch.  Slots beyond ntiles (grid padding) get the id ntiles (= no tile).
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restrict__ ranges, int ntiles, int nslots, uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ item_work, uint32_t* __restrict__ bwd_state)
-{
-    for (int t = threadIdx.x; t < 8 * nslots; t += 1024) item_work[t] = 0u;   // filled by the forward blend waves that do work
-    if (threadIdx.x < 64) bwd_state[MRGS_BS_BITMAP + threadIdx.x] = 0u;       // CU census, filled by the same waves
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wave_sums[16];
-    const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint2 r = ranges[t];
-        atomicAdd(&hist[255u - min((r.y - r.x) >> 4, 255u)], 1u);   // bucket 0 = longest lists
-    }
-    __syncthreads();
-    uint32_t tot;
-    const uint32_t ex = block_exclusive_scan<1024>(tid < 256 ? hist[tid] : 0u, wave_sums, tot);
-    if (tid < 256) hist[tid] = ex;
-    // number of leading tiles that the blend kernels split into half-quadrants (mrgs_decode_item)
-    if (tid == 256 - MRGS_SPLIT_THRESHOLD / 16) order[nslots] = ex;
-    __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint2 r = ranges[t];
-        const uint32_t pos = atomicAdd(&hist[255u - min((r.y - r.x) >> 4, 255u)], 1u);
-        order[pos] = (uint32_t)t;
-    }
-    for (int t = ntiles + tid; t < nslots; t += 1024) order[t] = (uint32_t)ntiles;
-}
-
-// Dispatch order of the blend backward.  The forward waves leave the number of list entries they walked in item_work; the
-// backward walks (almost) the same entries, so this is its work per item.  Kernel time is set by the most loaded SIMD, and
-// a random mix of four or five waves per SIMD put 1.44x the mean load on the worst one.  Here, per XCD list (tile p of
-// tile_order belongs to list p % 8, as in the forward), the items with work are counting-sorted by decreasing work and
-// dealt to one queue per SIMD of the XCD in passes of NQ items: in every pass the heaviest item goes to the queue with the
-// smallest load so far (LPT per pass).  A backward wave pulls from the queue of the SIMD it finds itself on and steals
-// from the other queues when its own is empty (render_bwd_kernel); nothing depends on how the hardware places waves.
-// This kernel also turns the CU census of the forward launch into a dense CU numbering per XCC.
-#define BWD_ADAPTIVE_PASSES 64
-__global__ void __launch_bounds__(1024) bwd_order_kernel(const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ item_work,
-                                                         int ntiles, int nslots, uint32_t* __restrict__ bwd_items, uint32_t* __restrict__ bwd_work,
-                                                         uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ bwd_state)
+// ---- dispatch order of the blend kernels ---------------------------------------------------------------------
+// Kernel time of a blend launch is set by its most loaded SIMD: a wave lasts as long as its list is long, the lists differ
+// by an order of magnitude, and a random mix of four to six waves per SIMD put 1.44x the mean load on the worst SIMD.
+// This kernel (one workgroup per XCD list; list x = the tiles t with t % 8 == x, so that the four quadrant waves of a tile
+// share one L2) counting-sorts the work items (tile, quadrant) with work > 0 by decreasing work and deals them to one
+// queue per SIMD of an XCD in passes of NQ items; in every pass the heaviest item goes to the queue with the smallest load
+// so far (LPT per pass).  A blend wave pulls from the queue of the SIMD it finds itself on and steals from the other queues
+// when its own is empty (mrgs_pull_item): nothing depends on how the hardware places waves.
+// Work per item: the forward uses the cull counts of tile_ranges_kernel, the backward what the forward waves actually walked.
+// The first call of a forward also turns the CU census (bits set by the preprocess waves) into a dense CU numbering.
+#define ORDER_ADAPTIVE_PASSES 16
+__global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __restrict__ item_src, int ntiles, uint32_t* __restrict__ items_ws,
+                                                           uint32_t* __restrict__ work_ws, uint32_t* __restrict__ assign_ws,
+                                                           uint32_t* __restrict__ qstate, const uint32_t* __restrict__ census,
+                                                           uint32_t* __restrict__ cu_state, int forward, uint32_t* __restrict__ zero_this)
 {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t load[MRGS_MAX_SIMD_QUEUES];
     __shared__ unsigned long long s_total;
     const int tid = threadIdx.x, x = blockIdx.x;
+    const int per_list = ((ntiles + 7) >> 3) * 4;           // items of one XCD list (upper bound)
     hist[tid] = 0;
     if (tid == 0) s_total = 0ull;
-    if (tid < MRGS_MAX_SIMD_QUEUES) { bwd_state[MRGS_BS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u; load[tid] = 0u; }
-    if (tid < 256) {   // block x numbers the CUs of XCC x
-        const uint32_t* bm = bwd_state + MRGS_BS_BITMAP + x * 8;
-        uint32_t below = 0;
-        for (int w = 0; w < (tid >> 5); w++) below += __popc(bm[w]);
-        below += __popc(bm[tid >> 5] & ((1u << (tid & 31)) - 1u));
-        bwd_state[MRGS_BS_DENSE + x * 256 + tid] = below;
-        if (tid == 255) bwd_state[MRGS_BS_NCU + x] = below + ((bm[7] >> 31) & 1u);
+    if (tid < MRGS_MAX_SIMD_QUEUES) { qstate[MRGS_QS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u; load[tid] = 0u; }
+    if (zero_this != nullptr)
+        for (int i = tid + 1024 * x; i < 4 * ntiles; i += 8 * 1024) zero_this[i] = 0u;
+    // forward: every (tile, quadrant) is an item (idle ones still write their pixels: key = work + 1); backward: only those
+    // with work
+    const uint32_t idle = forward ? 1u : 0u;
+    if (forward && tid < 256) {   // block x numbers the CUs of XCC x (tid = CU key)
+        const bool seen = census[x * 256 + tid] != 0u;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(seen);
+        if ((tid & 63) == 0) wave_sums[tid >> 6] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t below = (uint32_t)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < (tid >> 6); w++) below += wave_sums[w];
+        cu_state[MRGS_CS_DENSE + x * 256 + tid] = below;
+        if (tid == 255) cu_state[MRGS_CS_NCU + x] = below + (seen ? 1u : 0u);
+    } else if (forward) {
+        __syncthreads();
     }
     __syncthreads();
-    const int n = nslots;   // (nslots / 8 tiles) x 8 items
-    for (int idx = tid; idx < n; idx += 1024) {
-        const uint32_t tile = tile_order[(idx >> 3) * 8 + x];
-        const uint32_t w = tile < (uint32_t)ntiles ? item_work[tile * 8 + (idx & 7)] : 0u;
-        if (w > 0u) atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);   // bucket 0 = most work
+    // (items without work -- all of them in bucket 1023 of the forward -- are counted per wave: several hundred LDS
+    // atomics on one address would dominate this kernel)
+    for (int i0 = 0; i0 < per_list; i0 += 1024) {
+        const int i = i0 + tid;
+        const int tile = (i >> 2) * 8 + x;
+        const uint32_t w = (i < per_list && tile < ntiles) ? item_src[tile * 4 + (i & 3)] + idle : 0u;
+        const bool lightest = w > 0u && (w >> 2) == 0u;
+        const uint64_t lm = __builtin_amdgcn_ballot_w64(lightest);
+        if (lightest) { if ((tid & 63) == __builtin_ctzll(lm)) atomicAdd(&hist[1023], (uint32_t)__builtin_popcountll(lm)); }
+        else if (w > 0u) atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);   // bucket 0 = most work
     }
     __syncthreads();
     uint32_t tot;
     const uint32_t ex = block_exclusive_scan<1024>(hist[tid], wave_sums, tot);
     hist[tid] = ex;
     __syncthreads();
-    uint32_t* items = bwd_items + (size_t)x * nslots;
-    uint32_t* work = bwd_work + (size_t)x * nslots;
-    for (int idx = tid; idx < n; idx += 1024) {
-        const uint32_t tile = tile_order[(idx >> 3) * 8 + x];
-        const uint32_t w = tile < (uint32_t)ntiles ? item_work[tile * 8 + (idx & 7)] : 0u;
-        if (w > 0u) {
-            const uint32_t pos = atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);
-            items[pos] = (tile << 3) | (uint32_t)(idx & 7);
-            work[pos] = w;
-            atomicAdd(&s_total, (unsigned long long)w);
+    uint32_t* items = items_ws + (size_t)x * per_list;
+    uint32_t* work = work_ws + (size_t)x * per_list;
+    for (int i0 = 0; i0 < per_list; i0 += 1024) {
+        const int i = i0 + tid;
+        const int tile = (i >> 2) * 8 + x;
+        const uint32_t w = (i < per_list && tile < ntiles) ? item_src[tile * 4 + (i & 3)] + idle : 0u;
+        const bool lightest = w > 0u && (w >> 2) == 0u;
+        const uint64_t lm = __builtin_amdgcn_ballot_w64(lightest);
+        uint32_t pos = 0;
+        if (lightest) {
+            const int leader = __builtin_ctzll(lm);
+            uint32_t base = 0;
+            if ((tid & 63) == leader) base = atomicAdd(&hist[1023], (uint32_t)__builtin_popcountll(lm));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            pos = base + (uint32_t)__builtin_popcountll(lm & ((1ull << (tid & 63)) - 1ull));
+        } else if (w > 0u) {
+            pos = atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);
         }
+        if (w > 0u) {
+            items[pos] = ((uint32_t)tile << 2) | (uint32_t)(i & 3);
+            work[pos] = w;
+        }
+        // total work of the list (for the priority classes): wave sum, one atomic per wave
+        unsigned long long ws = w;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ws += __shfl_xor(ws, d, 64);
+        if ((tid & 63) == 0 && ws != 0ull) atomicAdd(&s_total, ws);
     }
     __threadfence_block();
     __syncthreads();
 
-    // dealing: NQ queues (the SIMDs of the XCC this list runs on; all XCCs of a device have the same CU count)
-    int Q = 0;
-    for (int k = 0; k < 8; k++) {
-        const uint32_t* bm = bwd_state + MRGS_BS_BITMAP + k * 8;
-        int c = 0;
-        for (int w = 0; w < 8; w++) c += __popc(bm[w]);
-        Q = max(Q, c);
-    }
+    // NQ queues = the SIMDs of an XCC (all XCCs of a device have the same CU count; XCC x was counted above or, for the
+    // backward, by the forward's call)
+    __syncthreads();
+    const int Q = (int)cu_state[MRGS_CS_NCU + x];
     const int NQ = 4 * min(max(Q, 1), MRGS_MAX_SIMD_QUEUES / 4);
     const int n_items = (int)tot;
     const int passes = (n_items + NQ - 1) / NQ;
     const unsigned long long mean5 = n_items > 0 ? 5ull * s_total / (unsigned long long)n_items : 0ull;   // 5 x mean work
-    uint32_t* assign = bwd_assign + (size_t)x * (nslots + MRGS_MAX_SIMD_QUEUES);
+    uint32_t* assign = assign_ws + (size_t)x * (per_list + MRGS_MAX_SIMD_QUEUES);
+    __shared__ uint32_t qrank[MRGS_MAX_SIMD_QUEUES];
     for (int p = 0; p < passes; p++) {
-        int slot = tid;                                    // position in the pass (0 = heaviest item) this queue receives
-        if (tid < NQ) {
-            if (p > 0 && p < BWD_ADAPTIVE_PASSES) {
-                const uint32_t mine = load[tid];
-                int r = 0;
-                for (int q = 0; q < NQ; q++) {
-                    const uint32_t o = load[q];
-                    r += (o < mine || (o == mine && q < tid)) ? 1 : 0;
+        const bool adaptive = p > 0 && p < ORDER_ADAPTIVE_PASSES;
+        if (adaptive) {
+            // rank of every queue by load so far (ascending, ties by index): thread (part, q) counts the queues of its
+            // eighth that come before q
+            if (tid < NQ) qrank[tid] = 0u;
+            __syncthreads();
+            const int q = tid & (MRGS_MAX_SIMD_QUEUES - 1), part = tid >> 7;
+            if (q < NQ) {
+                const uint32_t mine = load[q];
+                uint32_t r = 0;
+                for (int o = part; o < NQ; o += 8) {
+                    const uint32_t lo = load[o];
+                    r += (lo < mine || (lo == mine && o < q)) ? 1u : 0u;
                 }
-                slot = r;                                  // lightest queue <- heaviest item
-            } else if (p & 1) {
-                slot = NQ - 1 - tid;                       // plain snake beyond the adaptive passes
+                if (r) atomicAdd(&qrank[q], r);
             }
+            __syncthreads();
         }
-        __syncthreads();
         if (tid < NQ) {
+            // position in the pass (0 = heaviest item) this queue receives: lightest queue <- heaviest item; plain snake
+            // beyond the adaptive passes
+            const int slot = adaptive ? (int)qrank[tid] : (p & 1) ? NQ - 1 - tid : tid;
             const int rank = p * NQ + slot;
-            const bool valid = rank < n_items;
             uint32_t entry = 0xFFFFFFFFu;
-            if (valid) {
-                // issue priority of the wave (bits 29-30): the heavy items of a SIMD run ahead of its light ones, so that the
-                // SIMD keeps several waves in flight until its work runs out instead of finishing with one long straggler
+            if (rank < n_items) {
+                // issue priority of the wave (bits 29-30): the heavy items of a SIMD run ahead of its light ones
                 const unsigned long long w25 = 25ull * work[rank];
                 const uint32_t prio = w25 > 8ull * mean5 ? 3u : w25 > 6ull * mean5 ? 2u : w25 > 4ull * mean5 ? 1u : 0u;
                 entry = items[rank] | (prio << 29);
@@ -544,23 +585,27 @@ __global__ void __launch_bounds__(1024) bwd_order_kernel(const uint32_t* __restr
         __syncthreads();
     }
     if (tid == 0) {
-        bwd_state[MRGS_BS_COUNT + x] = tot;
-        bwd_state[MRGS_BS_PASSES + x] = (uint32_t)passes | ((uint32_t)NQ << 16);
+        qstate[MRGS_QS_COUNT + x] = tot;
+        qstate[MRGS_QS_PASSES + x] = (uint32_t)passes | ((uint32_t)NQ << 16);
     }
 }
 
-void mrgs_launch_bwd_order(const MrgsImgWs& img, int ntiles, hipStream_t stream)
+void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bwd_order_kernel, dim3(8), dim3(1024), 0, stream, img.tile_order, img.item_work, ntiles, ((ntiles + 7) / 8) * 8,
-                       img.bwd_items, img.bwd_work, img.bwd_assign, img.bwd_state);
+    if (backward)
+        hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
+                           img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
+                           img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work);
 }
 
-void mrgs_launch_tile_ranges(const uint32_t* tile_key, int64_t R, const uint32_t* R_dev, const MrgsImgWs& img, int ntiles, hipStream_t stream)
+void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,
+                             uint8_t* qmask, const MrgsImgWs& img, int tiles_x, int ntiles, hipStream_t stream)
 {
-    uint2* ranges = img.ranges;
-    uint32_t* tile_order = img.tile_order;
-    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, stream);   // rasterizer_impl.cu:316
+    // ranges and item_est are adjacent: one clear (rasterizer_impl.cu:316 clears the ranges)
+    (void)hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream);
     if (R > 0)
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, R, R_dev, ranges);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ranges, ntiles, ((ntiles + 7) / 8) * 8, tile_order, img.item_work, img.bwd_state);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, plist, R, R_dev, rec,
+                           tiles_x, img.ranges, qmask, img.item_est);
 }
