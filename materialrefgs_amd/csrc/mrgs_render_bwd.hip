@@ -162,7 +162,7 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #define WS_BEGIN() const unsigned long long ws_t0 = wall_clock64(), ws_c0 = __builtin_amdgcn_s_memtime(); unsigned ws_iters = 0, ws_act = 0, ws_chunks = 0;
 #define WS_ITER(a) { ws_iters++; ws_act += (a) ? 1 : 0; }
 #define WS_CHUNK() ws_chunks++;
-#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 8 * (size_t)b; w[6] = 0; w[7] = (unsigned long long)n_items; w[0] = ws_t0; w[1] = wall_clock64(); \
+#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 8 * (size_t)b; w[6] = 0; w[7] = 0; w[0] = ws_t0; w[1] = wall_clock64(); \
         w[2] = __builtin_amdgcn_s_memtime() - ws_c0; w[3] = ((unsigned long long)ws_iters << 32) | ws_act; w[4] = ((unsigned long long)ws_chunks << 32) | (unsigned)max_contrib; \
         w[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); }
 #else

@@ -468,10 +468,11 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t load[MRGS_MAX_SIMD_QUEUES];
     __shared__ unsigned long long s_total;
+    __shared__ uint32_t s_busy;
     const int tid = threadIdx.x, x = blockIdx.x;
     const int per_list = ((ntiles + 7) >> 3) * 4;           // items of one XCD list (upper bound)
     hist[tid] = 0;
-    if (tid == 0) s_total = 0ull;
+    if (tid == 0) { s_total = 0ull; s_busy = 0u; }
     if (tid < MRGS_MAX_SIMD_QUEUES) { qstate[MRGS_QS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u; load[tid] = 0u; }
     if (zero_this != nullptr)
         for (int i = tid + 1024 * x; i < 4 * ntiles; i += 8 * 1024) zero_this[i] = 0u;
@@ -501,6 +502,8 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
         const uint64_t lm = __builtin_amdgcn_ballot_w64(lightest);
         if (lightest) { if ((tid & 63) == __builtin_ctzll(lm)) atomicAdd(&hist[1023], (uint32_t)__builtin_popcountll(lm)); }
         else if (w > 0u) atomicAdd(&hist[1023u - min(w >> 2, 1023u)], 1u);   // bucket 0 = most work
+        const uint64_t bm = __builtin_amdgcn_ballot_w64(w > idle);
+        if ((tid & 63) == 0 && bm != 0ull) atomicAdd(&s_busy, (uint32_t)__builtin_popcountll(bm));
     }
     __syncthreads();
     uint32_t tot;
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     uint32_t* assign = assign_ws + (size_t)x * (per_list + MRGS_MAX_SIMD_QUEUES);
     __shared__ uint32_t qrank[MRGS_MAX_SIMD_QUEUES];
     for (int p = 0; p < passes; p++) {
-        const bool adaptive = p > 0 && p < ORDER_ADAPTIVE_PASSES;
+        const bool adaptive = p > 0 && p < ORDER_ADAPTIVE_PASSES && p * NQ < (int)s_busy;   // idle items need no balancing
         if (adaptive) {
             // rank of every queue by load so far (ascending, ties by index): thread (part, q) counts the queues of its
             // eighth that come before q
