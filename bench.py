@@ -39,12 +39,13 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def algorithmic_bytes(kernel, P, R, HW, S):
     """Algorithmic HBM bytes of ONE launch (DESIGN.md section 'Kernels'); each datum moved once per kernel."""
     if kernel == "render_bwd":
-        # staged records + ids, per-pixel inputs (dL_dpix 3+S, dL_dothers 7, final_T 3, n_contrib 2), one RMW of the
-        # (18+S)-float gradient row per (tile, gaussian) pair
-        return (4 + 80 + 4 * S) * R + (60 + 4 * S) * HW + 8 * (18 + S) * R
+        # list ids + cull bits (5 B), staged records (80 B + features), per-pixel inputs (dL_dpix 3+S, dL_dothers 7, final_T 3,
+        # n_contrib 2), one RMW of the (18+S)-float gradient row per (tile, gaussian) pair
+        return (5 + 80 + 4 * S) * R + (60 + 4 * S) * HW + 8 * (18 + S) * R
     if kernel == "render_fwd":
-        # staged records + ids, per-pixel outputs (color 3, feature S, others 7, final_T 3, n_contrib 2)
-        return (4 + 80 + 4 * S) * R + (60 + 4 * S) * HW
+        # list ids + cull bits (5 B), staged records (80 B + features), per-pixel outputs (color 3, feature S, others 7,
+        # final_T 3, n_contrib 2)
+        return (5 + 80 + 4 * S) * R + (60 + 4 * S) * HW
     raise KeyError(kernel)
 
 
