@@ -177,6 +177,30 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
                                  const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
                                  float* g_roughness, void* stream);
 
+/* ---- per-gaussian inputs of the surfel renderer (fused glue) -----------------------------------------------------
+ * One kernel instead of the ~50 torch kernels the reference runs per view before the rasterizer call: GaussianModel getters
+ * (scene/gaussian_model.py:236-311: sigmoid / exp / normalize activations), get_normal (:269-285) and the feature assembly of
+ * render_surfel (gaussian_renderer/__init__.py:338-355): view direction, facing unit normal (third column of R(q)), mirror
+ * direction r = 2 (n.w_o) n - w_o, indirect = clamp_min(eval_sh(3, cat(indirect_dc, indirect_rest), r), 0),
+ * features[P,8] = (sigmoid refl, sigmoid roughness, sigmoid ori_color[3], indirect[3]).  All pointers are device pointers to
+ * contiguous fp32 tensors in the GaussianModel layout: xyz[P,3], scaling_raw[P,2], rotation_raw[P,4] (w,x,y,z), opacity_raw[P,1],
+ * refl_raw[P,1], rough_raw[P,1], ori_color_raw[P,3], indirect_dc[P,1,3], indirect_rest[P,15,3], campos[3]. */
+typedef struct MrgsSurfelParams {
+    int32_t P;
+    const float *xyz, *scaling_raw, *rotation_raw, *opacity_raw, *refl_raw, *rough_raw, *ori_color_raw, *indirect_dc, *indirect_rest,
+        *campos;
+} MrgsSurfelParams;
+typedef struct MrgsSurfelGrads {   /* gradients w.r.t. the raw parameters, same shapes, fully written */
+    float *d_xyz, *d_scaling, *d_rotation, *d_opacity, *d_refl, *d_rough, *d_ori_color, *d_indirect_dc, *d_indirect_rest;
+} MrgsSurfelGrads;
+/* outputs: opacity[P,1], scales[P,2], rotations[P,4] (unit), features[P,8] -- exactly what GaussianRasterizer is fed */
+int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, float* scales, float* rotations, float* features,
+                                 void* stream);
+/* upstream gradients of the four outputs (any may be NULL = zero); d_xyz holds only the part that flows through the view and
+ * mirror directions (the rasterizer's own dL/dmeans3D is added by the caller / autograd) */
+int mrgs_surfel_features_backward(const MrgsSurfelParams* p, const float* g_opacity, const float* g_scales, const float* g_rotations,
+                                  const float* g_features, const MrgsSurfelGrads* grads, void* stream);
+
 /* Introspection used by the parity tests: copies of internal state in the reference's layouts.
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
  * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],

@@ -51,6 +51,16 @@ class MrgsShadeFrame(ctypes.Structure):
                 ("roughness", MrgsStridedMap), ("lut", c_void_p), ("lut_res", c_int32)]
 
 
+class MrgsSurfelParams(ctypes.Structure):
+    _fields_ = [("P", c_int32)] + [(n, c_void_p) for n in ("xyz", "scaling_raw", "rotation_raw", "opacity_raw", "refl_raw", "rough_raw",
+                                                             "ori_color_raw", "indirect_dc", "indirect_rest", "campos")]
+
+
+class MrgsSurfelGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("d_xyz", "d_scaling", "d_rotation", "d_opacity", "d_refl", "d_rough", "d_ori_color",
+                                        "d_indirect_dc", "d_indirect_rest")]
+
+
 class MrgsKernelTimes(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
                                        "preprocess_bwd_ms")]
@@ -72,6 +82,9 @@ SYMBOLS = {
     "mrgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                ctypes.POINTER(MrgsRasterGrads), c_void_p]),
+    "mrgs_surfel_features_forward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_surfel_features_backward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     ctypes.POINTER(MrgsSurfelGrads), c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -9,12 +9,17 @@ Same arguments (`viewpoint_camera, pc, pipe, bg_color, scaling_modifier, overrid
 dictionary keys.  `pc` is anything exposing the GaussianModel getters the functions read (scene/gaussian_model.py:236-347);
 `SurfelModel` below is a minimal container with the reference's activations for tests and benchmarks -- the optimizer,
 densification and I/O of GaussianModel are out of scope.
-Rasterization and shading run in libmrgs.so; the per-gaussian and per-map glue stays in torch as in the reference.
+Rasterization, shading and the per-gaussian glue (activations, normals, mirror direction, indirect SH, feature assembly:
+`surfel_features`) run in libmrgs.so; the per-map glue stays in torch as in the reference.
 """
+import ctypes
 import math
 from types import SimpleNamespace
 
 import torch
+
+from . import _lib
+from ._lib import MrgsSurfelGrads, MrgsSurfelParams
 
 from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -62,6 +67,70 @@ class SurfelModel:
         normals_raw = RS[:, :, 2]
         normals_raw, _ = flip_align_view(normals_raw, dir_pp_normalized)
         return safe_normalize(normals_raw)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _SurfelFeatures(torch.autograd.Function):
+    """mrgs_surfel_features_forward/backward (include/mrgs.h): raw GaussianModel parameters -> (opacity, scales, rotations,
+    features[P,8]) in one kernel each way.  Torch restatement = `surfel_features_reference` below (the reference's own ops)."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos):
+        if not xyz.is_cuda:
+            raise RuntimeError("surfel_features needs CUDA(HIP) tensors: the per-gaussian glue runs in libmrgs.so, there is no CPU path")
+        ts = [_c(t) for t in (xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos)]
+        P, dev = ts[0].shape[0], ts[0].device
+        L = _lib.lib()
+        prm = MrgsSurfelParams(P, *[_p(t) for t in ts])
+        o = dict(dtype=torch.float32, device=dev)
+        op, sc, rot, feat = torch.empty((P, 1), **o), torch.empty((P, 2), **o), torch.empty((P, 4), **o), torch.empty((P, 8), **o)
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(L.mrgs_surfel_features_forward(ctypes.byref(prm), _p(op), _p(sc), _p(rot), _p(feat), st))
+        ctx.save_for_backward(*ts)
+        return op, sc, rot, feat
+
+    @staticmethod
+    def backward(ctx, g_op, g_sc, g_rot, g_feat):
+        ts = ctx.saved_tensors
+        P, dev = ts[0].shape[0], ts[0].device
+        L = _lib.lib()
+        prm = MrgsSurfelParams(P, *[_p(t) for t in ts])
+        outs = [torch.empty_like(t) for t in ts[:9]]
+        grads = MrgsSurfelGrads(*[_p(t) for t in outs])
+        gs = [None if g is None else _c(g) for g in (g_op, g_sc, g_rot, g_feat)]
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads), st))
+        return (*outs, None)
+
+
+def surfel_features(pc, camera_center):
+    """(opacity[P,1], scales[P,2], rotations[P,4], features[P,8]) for `render_surfel` from the raw parameters of `pc`."""
+    return _SurfelFeatures.apply(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._refl_strength, pc._roughness, pc._ori_color,
+                                 pc._indirect_dc, pc._indirect_rest, camera_center)
+
+
+def surfel_features_reference(pc, camera_center, scaling_modifier=1.0):
+    """The same quantities with the reference's torch ops (gaussian_renderer/__init__.py:338-355 + the GaussianModel getters);
+    runs on any device -- the parity tests use it as the checker of `surfel_features`."""
+    means3D = pc.get_xyz
+    dir_pp = means3D - camera_center
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
+    w_o = -dir_pp_normalized
+    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
+    shs_indirect = pc.get_indirect.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
+    features = torch.cat((pc.get_refl, pc.get_rough, pc.get_ori_color, indirect), dim=-1)          # "2dgs" flavour: S = 8
+    return pc.get_opacity, pc.get_scaling, pc.get_rotation, features
 
 
 def depths_to_points(view, depthmap):
@@ -156,22 +225,15 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     means2D = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
     means3D = pc.get_xyz
-    refl, ori_color, roughness = pc.get_refl, pc.get_ori_color, pc.get_rough
     shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
 
-    # per-gaussian indirect radiance along the mirror direction (__init__.py:338-346)
-    dir_pp = means3D - viewpoint_camera.camera_center
-    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-    normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
-    w_o = -dir_pp_normalized
-    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
-    shs_indirect = pc.get_indirect.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-    indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
-    features = torch.cat((refl, roughness, ori_color, indirect), dim=-1)          # "2dgs" flavour: S = 8
+    # activations, facing normal, mirror direction, indirect radiance along it and the feature concat (__init__.py:338-355):
+    # one HIP kernel each way
+    opacities, scales, rotations, features = surfel_features(pc, viewpoint_camera.camera_center)
 
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=pc.get_opacity,
-        scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
+        scales=scales, rotations=rotations, cov3D_precomp=None)
 
     base_color = rendered_image
     refl_strength, roughness_map = rendered_features[:1], rendered_features[1:2]
