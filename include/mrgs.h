@@ -201,6 +201,36 @@ int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, floa
 int mrgs_surfel_features_backward(const MrgsSurfelParams* p, const float* g_opacity, const float* g_scales, const float* g_rotations,
                                   const float* g_features, const MrgsSurfelGrads* grads, void* stream);
 
+/* ---- per-pixel maps of the surfel renderer (fused glue) ------------------------------------------------------------
+ * compute_2dgs_normal_and_regularizations (gaussian_renderer/__init__.py:42-90) + depths_to_points / depth_to_normal
+ * (utils/point_utils.py:9-37) + the normal_map of render_surfel (:419-421) in one kernel each way.
+ *   view_rot   = world_view_transform[:3,:3] as stored (row-major): rend_normal = view_rot * allmap[2:5]
+ *   ray_matrix = c2w[:3,:3] * intrins^-1, ray_origin = c2w[:3,3] with c2w, intrins exactly as depths_to_points builds them:
+ *                point(x, y) = surf_depth * (ray_matrix * (x, y, 1)) + ray_origin
+ * allmap is the rasterizer's [7,H,W] output.  Outputs: rend_normal[3,H,W], surf_depth[1,H,W], surf_normal[3,H,W] (already
+ * multiplied by the detached alpha; NULL = skip, render_surfel(wo_render_img)), normal_map[H,W,3] = rend_normal / max(alpha,
+ * 1e-6) (NULL = skip). */
+typedef struct MrgsMapsFrame {
+    int32_t H, W;
+    float view_rot[9], ray_matrix[9], ray_origin[3];
+    float depth_ratio;
+} MrgsMapsFrame;
+int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
+                             float* normal_map, void* stream);
+/* g_allmap[7,H,W] (fully written; channel 6 = 0) from the upstream gradients of the four outputs (any may be NULL = zero).
+ * rend_alpha / rend_dist are plain views of allmap in the reference: their gradients are added by the caller. */
+int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
+                              const float* g_surf_normal, const float* g_normal_map, float* g_allmap, void* stream);
+
+/* render_surfel compositing (gaussian_renderer/__init__.py:436-445): diffuse = (1 - refl) * base, render =
+ * [linear_to_srgb]((diffuse + specular)) + bg * (1 - alpha).  base_color / specular / render / diffuse [3,H,W],
+ * refl_strength / alpha [1,H,W], bg[3]; all contiguous fp32 device tensors. */
+int mrgs_surfel_composite_forward(int32_t H, int32_t W, int32_t srgb, const float* base_color, const float* refl_strength, const float* specular,
+                                  const float* alpha, const float* bg, float* render, float* diffuse, void* stream);
+int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const float* base_color, const float* refl_strength,
+                                   const float* specular, const float* bg, const float* g_render, const float* g_diffuse, float* g_base,
+                                   float* g_refl, float* g_specular, float* g_alpha, void* stream);
+
 /* Introspection used by the parity tests: copies of internal state in the reference's layouts.
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
  * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],

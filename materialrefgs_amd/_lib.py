@@ -61,6 +61,11 @@ class MrgsSurfelGrads(ctypes.Structure):
                                         "d_indirect_dc", "d_indirect_rest")]
 
 
+class MrgsMapsFrame(ctypes.Structure):
+    _fields_ = [("H", c_int32), ("W", c_int32), ("view_rot", c_float * 9), ("ray_matrix", c_float * 9), ("ray_origin", c_float * 3),
+                ("depth_ratio", c_float)]
+
+
 class MrgsKernelTimes(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
                                        "preprocess_bwd_ms")]
@@ -85,6 +90,13 @@ SYMBOLS = {
     "mrgs_surfel_features_forward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_features_backward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p,
                                                      ctypes.POINTER(MrgsSurfelGrads), c_void_p]),
+    "mrgs_surfel_maps_forward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_surfel_maps_backward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p]),
+    "mrgs_surfel_composite_forward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_void_p]),
+    "mrgs_surfel_composite_backward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,323 @@
+// mrgs_maps.hip -- per-pixel glue of the surfel renderer as fused kernels.
+//
+//  surfel_maps_*      <-> compute_2dgs_normal_and_regularizations (gaussian_renderer/__init__.py:42-90) with
+//                         depths_to_points / depth_to_normal (utils/point_utils.py:9-37) and the normal_map of render_surfel
+//                         (gaussian_renderer/__init__.py:419-421): view->world normals, expected / median depth with
+//                         nan_to_num, surf_depth, finite-difference normals of the back-projected depth, normal / alpha.
+//  surfel_composite_* <-> the compositing lines of render_surfel (:436-445): (1 - refl) * base + specular, optional
+//                         linear_to_srgb (utils/graphics_utils.py:102-110), background.
+// The reference runs ~40 torch kernels forward and ~80 backward for these on 800x800 maps; here it is one kernel each way,
+// one pixel per lane, channel-first maps read and written coalesced.  The backward of the finite-difference normals is a
+// gather (each pixel recomputes the four neighbouring normals it contributed to): deterministic, no atomics.
+#include "mrgs_internal.h"
+
+namespace {
+
+struct MapsFrameDev {
+    int H, W;
+    float V[9];      // world_view_transform[:3,:3] as stored: n_world = V * n_view
+    float M[9];      // rays_d(x, y) = M * (x, y, 1)
+    float o[3];      // rays_o
+    float depth_ratio;
+};
+
+__device__ __forceinline__ float nan_to_num0(float x)
+{   // torch.nan_to_num(x, 0, 0): nan -> 0, +inf -> 0, -inf -> lowest finite
+    if (x != x) return 0.0f;
+    if (x == __builtin_inff()) return 0.0f;
+    if (x == -__builtin_inff()) return -3.4028234663852886e38f;
+    return x;
+}
+__device__ __forceinline__ bool is_finite(float x) { return (x - x) == 0.0f; }
+
+__device__ __forceinline__ float surf_depth_at(const MapsFrameDev& f, const float* __restrict__ allmap, int HW, int pix)
+{
+    const float a = allmap[HW + pix];
+    const float de = nan_to_num0(allmap[pix] / a);
+    float sd = de * (1.0f - f.depth_ratio);
+    if (f.depth_ratio != 0.0f) sd += f.depth_ratio * nan_to_num0(allmap[5 * HW + pix]);
+    else sd += f.depth_ratio * 0.0f;
+    return sd;
+}
+__device__ __forceinline__ void ray_dir(const MapsFrameDev& f, int x, int y, float (&d)[3])
+{
+    const float fx = (float)x, fy = (float)y;
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = f.M[3 * i] * fx + f.M[3 * i + 1] * fy + f.M[3 * i + 2];
+}
+__device__ __forceinline__ void point_at(const MapsFrameDev& f, const float* __restrict__ allmap, int HW, int x, int y, float (&p)[3])
+{
+    float d[3];
+    ray_dir(f, x, y, d);
+    const float sd = surf_depth_at(f, allmap, HW, y * f.W + x);
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = sd * d[i] + f.o[i];
+}
+__device__ __forceinline__ void cross3(const float (&a)[3], const float (&b)[3], float (&c)[3])
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// finite-difference normal at an interior pixel: "dx" = rows difference, "dy" = columns difference (point_utils.py:33-35)
+struct FdNormal { float dx[3], dy[3], n[3], len, nn[3]; };
+__device__ __forceinline__ FdNormal fd_normal(const MapsFrameDev& f, const float* __restrict__ allmap, int HW, int x, int y)
+{
+    FdNormal r;
+    float pa[3], pb[3];
+    point_at(f, allmap, HW, x, y + 1, pa);
+    point_at(f, allmap, HW, x, y - 1, pb);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.dx[i] = pa[i] - pb[i];
+    point_at(f, allmap, HW, x + 1, y, pa);
+    point_at(f, allmap, HW, x - 1, y, pb);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.dy[i] = pa[i] - pb[i];
+    cross3(r.dx, r.dy, r.n);
+    r.len = fmaxf(sqrtf(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2]), 1e-12f);   // F.normalize eps
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.nn[i] = r.n[i] / r.len;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) surfel_maps_fwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, float* __restrict__ rend_normal,
+                                                              float* __restrict__ surf_depth, float* __restrict__ surf_normal,
+                                                              float* __restrict__ normal_map)
+{
+    const int HW = f.H * f.W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / f.W, x = pix - y * f.W;
+    const float a = allmap[HW + pix];
+    const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
+    float nw[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) nw[j] = f.V[3 * j] * nv[0] + f.V[3 * j + 1] * nv[1] + f.V[3 * j + 2] * nv[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) rend_normal[j * HW + pix] = nw[j];
+    surf_depth[pix] = surf_depth_at(f, allmap, HW, pix);
+    if (normal_map != nullptr) {
+        const float inv = 1.0f / fmaxf(a, 1e-6f);
+#pragma unroll
+        for (int j = 0; j < 3; j++) normal_map[3 * (size_t)pix + j] = nw[j] * inv;
+    }
+    if (surf_normal != nullptr) {
+        float sn[3] = {0.0f, 0.0f, 0.0f};
+        if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1) {
+            const FdNormal r = fd_normal(f, allmap, HW, x, y);
+#pragma unroll
+            for (int i = 0; i < 3; i++) sn[i] = r.nn[i] * a;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) surf_normal[j * HW + pix] = sn[j];
+    }
+}
+
+// gradient of the loss w.r.t. the finite-difference operands of the normal at interior pixel (cx, cy)
+__device__ __forceinline__ void fd_normal_bwd(const MapsFrameDev& f, const float* __restrict__ allmap, const float* __restrict__ g_sn, int HW,
+                                              int cx, int cy, float (&g_dx)[3], float (&g_dy)[3])
+{
+    const int c = cy * f.W + cx;
+    const FdNormal r = fd_normal(f, allmap, HW, cx, cy);
+    const float a = allmap[HW + c];
+    const float g_nn[3] = {g_sn[c] * a, g_sn[HW + c] * a, g_sn[2 * HW + c] * a};
+    const float dot = r.nn[0] * g_nn[0] + r.nn[1] * g_nn[1] + r.nn[2] * g_nn[2];
+    float g_n[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) g_n[i] = (g_nn[i] - r.nn[i] * dot) / r.len;
+    cross3(r.dy, g_n, g_dx);      // n = dx x dy
+    cross3(g_n, r.dx, g_dy);
+}
+
+__global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, const float* __restrict__ g_rn,
+                                                              const float* __restrict__ g_sd, const float* __restrict__ g_sn,
+                                                              const float* __restrict__ g_nm, float* __restrict__ g_allmap)
+{
+    const int HW = f.H * f.W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / f.W, x = pix - y * f.W;
+    const float a = allmap[HW + pix];
+    const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
+    float g_nw[3] = {0.0f, 0.0f, 0.0f};
+    float g_a = 0.0f;
+    if (g_rn != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) g_nw[j] = g_rn[j * HW + pix];
+    }
+    if (g_nm != nullptr) {
+        const float ac = fmaxf(a, 1e-6f), inv = 1.0f / ac;
+        float nw[3], s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            nw[j] = f.V[3 * j] * nv[0] + f.V[3 * j + 1] * nv[1] + f.V[3 * j + 2] * nv[2];
+            const float g = g_nm[3 * (size_t)pix + j];
+            g_nw[j] += g * inv;
+            s += nw[j] * g;
+        }
+        if (a >= 1e-6f) g_a -= s * inv * inv;            // clamp_min passes the gradient where x >= min
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) g_allmap[(2 + i) * HW + pix] = f.V[i] * g_nw[0] + f.V[3 + i] * g_nw[1] + f.V[6 + i] * g_nw[2];
+
+    // surf_depth: own upstream gradient + the finite-difference normals of the four neighbours this pixel's point feeds
+    float g_depth = g_sd != nullptr ? g_sd[pix] : 0.0f;
+    if (g_sn != nullptr) {
+        float gp[3] = {0.0f, 0.0f, 0.0f};
+        float gdx[3], gdy[3];
+        const bool xin = x >= 1 && x < f.W - 1;
+        if (xin && y - 1 >= 1 && y - 1 < f.H - 1) {            // c = p - e_y: p is c's "row below" point (+dx)
+            fd_normal_bwd(f, allmap, g_sn, HW, x, y - 1, gdx, gdy);
+#pragma unroll
+            for (int i = 0; i < 3; i++) gp[i] += gdx[i];
+        }
+        if (xin && y + 1 >= 1 && y + 1 < f.H - 1) {            // c = p + e_y: -dx
+            fd_normal_bwd(f, allmap, g_sn, HW, x, y + 1, gdx, gdy);
+#pragma unroll
+            for (int i = 0; i < 3; i++) gp[i] -= gdx[i];
+        }
+        const bool yin = y >= 1 && y < f.H - 1;
+        if (yin && x - 1 >= 1 && x - 1 < f.W - 1) {            // c = p - e_x: +dy
+            fd_normal_bwd(f, allmap, g_sn, HW, x - 1, y, gdx, gdy);
+#pragma unroll
+            for (int i = 0; i < 3; i++) gp[i] += gdy[i];
+        }
+        if (yin && x + 1 >= 1 && x + 1 < f.W - 1) {            // c = p + e_x: -dy
+            fd_normal_bwd(f, allmap, g_sn, HW, x + 1, y, gdx, gdy);
+#pragma unroll
+            for (int i = 0; i < 3; i++) gp[i] -= gdy[i];
+        }
+        float d[3];
+        ray_dir(f, x, y, d);
+        g_depth += gp[0] * d[0] + gp[1] * d[1] + gp[2] * d[2];
+    }
+    const float d0 = allmap[pix];
+    const float q = d0 / a;
+    float g0 = 0.0f;
+    if (is_finite(q)) {                                        // nan_to_num passes the gradient only where its input is finite
+        const float g_de = g_depth * (1.0f - f.depth_ratio);
+        g0 = g_de / a;
+        g_a -= g_de * d0 / (a * a);
+    }
+    g_allmap[pix] = g0;
+    g_allmap[HW + pix] = g_a;
+    const float dmed = allmap[5 * HW + pix];
+    g_allmap[5 * HW + pix] = is_finite(dmed) ? g_depth * f.depth_ratio : 0.0f;
+    g_allmap[6 * HW + pix] = 0.0f;
+}
+
+// ---- compositing ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lin2srgb(float x)
+{
+    const float eps = 1.1920928955078125e-07f;
+    return x <= 0.0031308f ? (323.0f / 25.0f) * x : (211.0f * powf(fmaxf(x, eps), 5.0f / 12.0f) - 11.0f) / 200.0f;
+}
+__device__ __forceinline__ float lin2srgb_grad(float x)
+{
+    const float eps = 1.1920928955078125e-07f;
+    if (x <= 0.0031308f) return 323.0f / 25.0f;
+    return x >= eps ? (211.0f / 200.0f) * (5.0f / 12.0f) * powf(x, -7.0f / 12.0f) : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) surfel_composite_fwd_kernel(int HW, int srgb, const float* __restrict__ base, const float* __restrict__ refl,
+                                                                   const float* __restrict__ spec, const float* __restrict__ alpha,
+                                                                   const float* __restrict__ bg, float* __restrict__ render,
+                                                                   float* __restrict__ diffuse)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const float k = 1.0f - refl[pix], oma = 1.0f - alpha[pix];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float d = k * base[c * HW + pix];
+        float v = d + spec[c * HW + pix];
+        if (srgb) v = lin2srgb(v);
+        render[c * HW + pix] = v + bg[c] * oma;
+        diffuse[c * HW + pix] = d;
+    }
+}
+
+__global__ void __launch_bounds__(256) surfel_composite_bwd_kernel(int HW, int srgb, const float* __restrict__ base, const float* __restrict__ refl,
+                                                                   const float* __restrict__ spec, const float* __restrict__ bg,
+                                                                   const float* __restrict__ g_render, const float* __restrict__ g_diffuse,
+                                                                   float* __restrict__ g_base, float* __restrict__ g_refl,
+                                                                   float* __restrict__ g_spec, float* __restrict__ g_alpha)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const float k = 1.0f - refl[pix];
+    float ga = 0.0f, gr = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float b = base[c * HW + pix];
+        const float gR = g_render != nullptr ? g_render[c * HW + pix] : 0.0f;
+        ga -= bg[c] * gR;
+        float gl = gR;
+        if (srgb) gl *= lin2srgb_grad(k * b + spec[c * HW + pix]);
+        const float gd = gl + (g_diffuse != nullptr ? g_diffuse[c * HW + pix] : 0.0f);
+        g_base[c * HW + pix] = k * gd;
+        gr -= b * gd;
+        g_spec[c * HW + pix] = gl;
+    }
+    g_refl[pix] = gr;
+    g_alpha[pix] = ga;
+}
+
+MapsFrameDev to_dev(const MrgsMapsFrame* fr)
+{
+    MapsFrameDev f;
+    f.H = fr->H; f.W = fr->W;
+    for (int i = 0; i < 9; i++) { f.V[i] = fr->view_rot[i]; f.M[i] = fr->ray_matrix[i]; }
+    for (int i = 0; i < 3; i++) f.o[i] = fr->ray_origin[i];
+    f.depth_ratio = fr->depth_ratio;
+    return f;
+}
+
+}   // namespace
+
+extern "C" {
+
+int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
+                             float* normal_map, void* stream)
+{
+    if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !rend_normal || !surf_depth) return MRGS_E_BAD_ARG;
+    const int HW = fr->H * fr->W;
+    hipLaunchKernelGGL(surfel_maps_fwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, to_dev(fr), allmap, rend_normal,
+                       surf_depth, surf_normal, normal_map);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
+                              const float* g_surf_normal, const float* g_normal_map, float* g_allmap, void* stream)
+{
+    if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !g_allmap) return MRGS_E_BAD_ARG;
+    const int HW = fr->H * fr->W;
+    hipLaunchKernelGGL(surfel_maps_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, to_dev(fr), allmap, g_rend_normal,
+                       g_surf_depth, g_surf_normal, g_normal_map, g_allmap);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_surfel_composite_forward(int32_t H, int32_t W, int32_t srgb, const float* base_color, const float* refl_strength, const float* specular,
+                                  const float* alpha, const float* bg, float* render, float* diffuse, void* stream)
+{
+    if (H <= 0 || W <= 0 || !base_color || !refl_strength || !specular || !alpha || !bg || !render || !diffuse) return MRGS_E_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(surfel_composite_fwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, srgb, base_color,
+                       refl_strength, specular, alpha, bg, render, diffuse);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const float* base_color, const float* refl_strength,
+                                   const float* specular, const float* bg, const float* g_render, const float* g_diffuse, float* g_base,
+                                   float* g_refl, float* g_specular, float* g_alpha, void* stream)
+{
+    if (H <= 0 || W <= 0 || !base_color || !refl_strength || !specular || !bg || !g_base || !g_refl || !g_specular || !g_alpha)
+        return MRGS_E_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(surfel_composite_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, srgb, base_color,
+                       refl_strength, specular, bg, g_render, g_diffuse, g_base, g_refl, g_specular, g_alpha);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+}   // extern "C"

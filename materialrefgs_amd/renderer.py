@@ -19,7 +19,7 @@ from types import SimpleNamespace
 import torch
 
 from . import _lib
-from ._lib import MrgsSurfelGrads, MrgsSurfelParams
+from ._lib import MrgsMapsFrame, MrgsSurfelGrads, MrgsSurfelParams
 
 from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -138,10 +138,10 @@ def depths_to_points(view, depthmap):
     dev = depthmap.device
     c2w = (view.world_view_transform.T).inverse()
     W, H = view.image_width, view.image_height
-    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32, device=dev).T
+    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=depthmap.dtype, device=dev).T
     projection_matrix = c2w.T @ view.full_proj_transform
     intrins = (projection_matrix @ ndc2pix)[:3, :3].T
-    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(), indexing="xy")
+    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).to(depthmap.dtype), torch.arange(H, device=dev).to(depthmap.dtype), indexing="xy")
     points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
     rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
     rays_o = c2w[:3, 3]
@@ -158,8 +158,8 @@ def depth_to_normal(view, depth):
     return output
 
 
-def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=True):
-    """gaussian_renderer/__init__.py:42-90."""
+def compute_2dgs_normal_and_regularizations_reference(allmap, viewpoint_camera, pipe, return_depth_normal=True):
+    """gaussian_renderer/__init__.py:42-90 with the reference's torch ops (any device); the checker of the fused version below."""
     render_alpha = allmap[1:2]
     render_normal = allmap[2:5]
     render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
@@ -175,6 +175,116 @@ def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, retu
     return {"render_alpha": render_alpha, "render_normal": render_normal, "render_depth_median": render_depth_median,
             "render_depth_expected": render_depth_expected, "render_dist": render_dist, "surf_depth": surf_depth,
             "surf_normal": surf_normal}
+
+
+_MAPS_FRAME_CACHE = {}
+
+
+def _maps_frame(view, depth_ratio):
+    """Camera constants of depths_to_points (utils/point_utils.py:9-24) for the fused kernels.  Built once per camera on the
+    host (float64) from the camera's matrices and cached: the reference rebuilds them with ~10 small GPU kernels per view."""
+    wvt, fpt = view.world_view_transform, view.full_proj_transform
+    key = (wvt.data_ptr(), fpt.data_ptr(), wvt._version, fpt._version, int(view.image_width), int(view.image_height))
+    ent = _MAPS_FRAME_CACHE.get(key)
+    if ent is None:
+        import numpy as np
+        wv = wvt.detach().cpu().double().numpy()
+        fp = fpt.detach().cpu().double().numpy()
+        W, H = int(view.image_width), int(view.image_height)
+        c2w = np.linalg.inv(wv.T)
+        ndc2pix = np.array([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=np.float64).T
+        intrins = ((c2w.T @ fp) @ ndc2pix)[:3, :3].T
+        M = c2w[:3, :3] @ np.linalg.inv(intrins)
+        ent = (wv[:3, :3].reshape(-1).tolist(), M.reshape(-1).tolist(), c2w[:3, 3].tolist())
+        if len(_MAPS_FRAME_CACHE) > 4096:
+            _MAPS_FRAME_CACHE.clear()
+        _MAPS_FRAME_CACHE[key] = ent
+    fr = MrgsMapsFrame()
+    fr.H, fr.W = int(view.image_height), int(view.image_width)
+    for i in range(9):
+        fr.view_rot[i] = ent[0][i]
+        fr.ray_matrix[i] = ent[1][i]
+    for i in range(3):
+        fr.ray_origin[i] = ent[2][i]
+    fr.depth_ratio = float(depth_ratio)
+    return fr
+
+
+class _SurfelMaps(torch.autograd.Function):
+    """mrgs_surfel_maps_forward/backward: allmap -> (rend_normal, surf_depth, surf_normal, normal_map)."""
+
+    @staticmethod
+    def forward(ctx, allmap, fr, want_surf_normal, want_normal_map):
+        if not allmap.is_cuda:
+            raise RuntimeError("the fused map kernels need CUDA(HIP) tensors; use compute_2dgs_normal_and_regularizations_reference on the CPU")
+        allmap = _c(allmap)
+        H, W, dev = fr.H, fr.W, allmap.device
+        o = dict(dtype=torch.float32, device=dev)
+        rn, sd = torch.empty((3, H, W), **o), torch.empty((1, H, W), **o)
+        sn = torch.empty((3, H, W), **o) if want_surf_normal else None
+        nm = torch.empty((H, W, 3), **o) if want_normal_map else None
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), st))
+        ctx.save_for_backward(allmap)
+        ctx.fr = fr
+        outs = (rn, sd, sn if sn is not None else rn.new_empty(0), nm if nm is not None else rn.new_empty(0))
+        ctx.mark_non_differentiable(*[t for t in outs[2:] if t.numel() == 0])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rn, g_sd, g_sn, g_nm):
+        (allmap,) = ctx.saved_tensors
+        dev = allmap.device
+        g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm)]
+        g_allmap = torch.empty_like(allmap)
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(ctx.fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g_allmap), st))
+        return g_allmap, None, None, None
+
+
+class _SurfelComposite(torch.autograd.Function):
+    """mrgs_surfel_composite_forward/backward: (base, refl, specular, alpha, bg) -> (render, diffuse)."""
+
+    @staticmethod
+    def forward(ctx, base, refl, spec, alpha, bg, srgb):
+        base, refl, spec, alpha, bg = _c(base), _c(refl), _c(spec), _c(alpha), _c(bg)
+        H, W, dev = base.shape[1], base.shape[2], base.device
+        render, diffuse = torch.empty_like(base), torch.empty_like(base)
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib().mrgs_surfel_composite_forward(H, W, int(bool(srgb)), _p(base), _p(refl), _p(spec), _p(alpha), _p(bg),
+                                                                _p(render), _p(diffuse), st))
+        ctx.save_for_backward(base, refl, spec, bg)
+        ctx.srgb = int(bool(srgb))
+        return render, diffuse
+
+    @staticmethod
+    def backward(ctx, g_render, g_diffuse):
+        base, refl, spec, bg = ctx.saved_tensors
+        H, W, dev = base.shape[1], base.shape[2], base.device
+        g_render = None if g_render is None else _c(g_render)
+        g_diffuse = None if g_diffuse is None else _c(g_diffuse)
+        g_base, g_spec = torch.empty_like(base), torch.empty_like(spec)
+        g_refl, g_alpha = torch.empty_like(refl), torch.empty_like(refl)
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib().mrgs_surfel_composite_backward(H, W, ctx.srgb, _p(base), _p(refl), _p(spec), _p(bg), _p(g_render), _p(g_diffuse),
+                                                                 _p(g_base), _p(g_refl), _p(g_spec), _p(g_alpha), st))
+        return g_base, g_refl, g_spec, g_alpha, None, None
+
+
+def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=True, return_normal_map=False):
+    """gaussian_renderer/__init__.py:42-90, one HIP kernel each way (`mrgs_surfel_maps_*`).  With `return_normal_map` the
+    dictionary also holds render_surfel's `normal_map` [H,W,3] = render_normal / max(alpha, 1e-6) (:419-421)."""
+    fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
+    rn, sd, sn, nm = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map))
+    out = {"render_alpha": allmap[1:2], "render_normal": rn, "render_depth_median": None, "render_depth_expected": None,
+           "render_dist": allmap[6:7], "surf_depth": sd, "surf_normal": sn if return_depth_normal else None}
+    if return_normal_map:
+        out["normal_map"] = nm
+    return out
 
 
 def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
@@ -239,24 +349,22 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     refl_strength, roughness_map = rendered_features[:1], rendered_features[1:2]
     albedo, indirect_light = rendered_features[2:5], rendered_features[5:8]
 
-    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img))
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img),
+                                                  return_normal_map=(not wo_render_img))
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
     geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": render_normal, "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
     if wo_render_img:
         return {"refl_strength_map": refl_strength, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
 
-    normal_map = render_normal.permute(1, 2, 0)
-    normal_map = normal_map / render_alpha.permute(1, 2, 0).clamp_min(1e-6)
     specular, extra_dict = get_specular_color_surfel(
-        pc.get_envmap, albedo.permute(1, 2, 0), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, normal_map,
+        pc.get_envmap, albedo.permute(1, 2, 0), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, reg["normal_map"],
         render_alpha.permute(1, 2, 0), refl_strength=refl_strength.permute(1, 2, 0), roughness=roughness_map.permute(1, 2, 0), pc=pc,
         surf_depth=reg["surf_depth"])
-    final_image = (1 - refl_strength) * base_color + specular
+    # (1 - refl) * base + specular, optional sRGB, background: one kernel each way (__init__.py:436-445)
+    final_image, diffuse_map = _SurfelComposite.apply(base_color, refl_strength, specular, render_alpha, bg_color, srgb)
     if srgb:
-        final_image = linear_to_srgb(final_image)
         albedo = linear_to_srgb(albedo)
         specular = linear_to_srgb(specular)
-    final_image = final_image + bg_color[:, None, None] * (1 - render_alpha)
-    return {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": (1 - refl_strength) * base_color,
+    return {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": diffuse_map,
             "diffuse_map_ori": base_color, "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
