@@ -128,7 +128,9 @@ def main():
         state["R"] = rasterizer_mod.LAST_NUM_RENDERED
         # the maps calculate_loss consumes (utils/loss_utils.py:147-152,166), with fixed upstream gradients
         outs = [out["render"], out["rend_alpha"], out["rend_normal"], out["rend_dist"], out["surf_depth"], out["surf_normal"]]
-        torch.autograd.backward(outs, [torch.ones_like(outs[0])] + [torch.full_like(o, 0.1) for o in outs[1:]])
+        if "g" not in state:   # constant upstream gradients, built once (a loss would produce them in training)
+            state["g"] = [torch.ones_like(outs[0])] + [torch.full_like(o, 0.1) for o in outs[1:]]
+        torch.autograd.backward(outs, state["g"])
         if world > 1:
             mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])
 

@@ -217,10 +217,11 @@ typedef struct MrgsMapsFrame {
 } MrgsMapsFrame;
 int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
                              float* normal_map, void* stream);
-/* g_allmap[7,H,W] (fully written; channel 6 = 0) from the upstream gradients of the four outputs (any may be NULL = zero).
- * rend_alpha / rend_dist are plain views of allmap in the reference: their gradients are added by the caller. */
+/* g_allmap[7,H,W] (fully written) from the upstream gradients of the four outputs and of rend_alpha = allmap[1:2] and
+ * rend_dist = allmap[6:7], which are plain views in the reference ([1,H,W] each; any of the six may be NULL = zero). */
 int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
-                              const float* g_surf_normal, const float* g_normal_map, float* g_allmap, void* stream);
+                              const float* g_surf_normal, const float* g_normal_map, const float* g_rend_alpha, const float* g_rend_dist,
+                              float* g_allmap, void* stream);
 
 /* render_surfel compositing (gaussian_renderer/__init__.py:436-445): diffuse = (1 - refl) * base, render =
  * [linear_to_srgb]((diffuse + specular)) + bg * (1 - alpha).  base_color / specular / render / diffuse [3,H,W],

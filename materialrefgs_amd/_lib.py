@@ -92,7 +92,7 @@ SYMBOLS = {
                                                      ctypes.POINTER(MrgsSurfelGrads), c_void_p]),
     "mrgs_surfel_maps_forward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_maps_backward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                 c_void_p]),
+                                                 c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_composite_forward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                      c_void_p, c_void_p]),
     "mrgs_surfel_composite_backward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

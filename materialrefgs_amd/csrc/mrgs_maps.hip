@@ -132,7 +132,8 @@ __device__ __forceinline__ void fd_normal_bwd(const MapsFrameDev& f, const float
 
 __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, const float* __restrict__ g_rn,
                                                               const float* __restrict__ g_sd, const float* __restrict__ g_sn,
-                                                              const float* __restrict__ g_nm, float* __restrict__ g_allmap)
+                                                              const float* __restrict__ g_nm, const float* __restrict__ g_alpha,
+                                                              const float* __restrict__ g_dist, float* __restrict__ g_allmap)
 {
     const int HW = f.H * f.W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, co
     const float a = allmap[HW + pix];
     const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
     float g_nw[3] = {0.0f, 0.0f, 0.0f};
-    float g_a = 0.0f;
+    float g_a = g_alpha != nullptr ? g_alpha[pix] : 0.0f;      // rend_alpha is a plain view of allmap[1]
     if (g_rn != nullptr) {
 #pragma unroll
         for (int j = 0; j < 3; j++) g_nw[j] = g_rn[j * HW + pix];
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, co
     g_allmap[HW + pix] = g_a;
     const float dmed = allmap[5 * HW + pix];
     g_allmap[5 * HW + pix] = is_finite(dmed) ? g_depth * f.depth_ratio : 0.0f;
-    g_allmap[6 * HW + pix] = 0.0f;
+    g_allmap[6 * HW + pix] = g_dist != nullptr ? g_dist[pix] : 0.0f;   // rend_dist is a plain view of allmap[6]
 }
 
 // ---- compositing ----------------------------------------------------------------------------------------------
@@ -289,12 +290,13 @@ int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float
 }
 
 int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
-                              const float* g_surf_normal, const float* g_normal_map, float* g_allmap, void* stream)
+                              const float* g_surf_normal, const float* g_normal_map, const float* g_rend_alpha, const float* g_rend_dist,
+                              float* g_allmap, void* stream)
 {
     if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !g_allmap) return MRGS_E_BAD_ARG;
     const int HW = fr->H * fr->W;
     hipLaunchKernelGGL(surfel_maps_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, to_dev(fr), allmap, g_rend_normal,
-                       g_surf_depth, g_surf_normal, g_normal_map, g_allmap);
+                       g_surf_depth, g_surf_normal, g_normal_map, g_rend_alpha, g_rend_dist, g_allmap);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

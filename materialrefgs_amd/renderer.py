@@ -211,7 +211,9 @@ def _maps_frame(view, depth_ratio):
 
 
 class _SurfelMaps(torch.autograd.Function):
-    """mrgs_surfel_maps_forward/backward: allmap -> (rend_normal, surf_depth, surf_normal, normal_map)."""
+    """mrgs_surfel_maps_forward/backward: allmap -> (rend_normal, surf_depth, surf_normal, normal_map, rend_alpha, rend_dist);
+    the last two are the reference's plain slices of allmap, routed through here so that their gradients enter the one
+    backward kernel instead of two extra [7,H,W] accumulation kernels."""
 
     @staticmethod
     def forward(ctx, allmap, fr, want_surf_normal, want_normal_map):
@@ -230,17 +232,18 @@ class _SurfelMaps(torch.autograd.Function):
         ctx.fr = fr
         outs = (rn, sd, sn if sn is not None else rn.new_empty(0), nm if nm is not None else rn.new_empty(0))
         ctx.mark_non_differentiable(*[t for t in outs[2:] if t.numel() == 0])
-        return outs
+        return (*outs, allmap[1:2].clone(), allmap[6:7].clone())
 
     @staticmethod
-    def backward(ctx, g_rn, g_sd, g_sn, g_nm):
+    def backward(ctx, g_rn, g_sd, g_sn, g_nm, g_ra, g_rd):
         (allmap,) = ctx.saved_tensors
         dev = allmap.device
-        g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm)]
+        g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm, g_ra, g_rd)]
         g_allmap = torch.empty_like(allmap)
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(ctx.fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g_allmap), st))
+            _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(ctx.fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]),
+                                                            _p(g_allmap), st))
         return g_allmap, None, None, None
 
 
@@ -279,9 +282,9 @@ def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, retu
     """gaussian_renderer/__init__.py:42-90, one HIP kernel each way (`mrgs_surfel_maps_*`).  With `return_normal_map` the
     dictionary also holds render_surfel's `normal_map` [H,W,3] = render_normal / max(alpha, 1e-6) (:419-421)."""
     fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
-    rn, sd, sn, nm = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map))
-    out = {"render_alpha": allmap[1:2], "render_normal": rn, "render_depth_median": None, "render_depth_expected": None,
-           "render_dist": allmap[6:7], "surf_depth": sd, "surf_normal": sn if return_depth_normal else None}
+    rn, sd, sn, nm, ra, rd = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map))
+    out = {"render_alpha": ra, "render_normal": rn, "render_depth_median": None, "render_depth_expected": None,
+           "render_dist": rd, "surf_depth": sd, "surf_normal": sn if return_depth_normal else None}
     if return_normal_map:
         out["normal_map"] = nm
     return out
