@@ -24,6 +24,7 @@ struct EnvMips {   // by-value kernel argument
     const float* tex[MRGS_MAX_MIPS];
     float* grad[MRGS_MAX_MIPS];
     int copies[MRGS_MAX_MIPS];
+    int lds_off[MRGS_MAX_MIPS];   // backward of the deferred shading: float offset of the level's LDS accumulator, -1 = global only
     float min_roughness, max_roughness;
 };
 
@@ -217,7 +218,7 @@ __device__ __forceinline__ void texel_scatter(float* addr, const float v[3])
 
 // gradient of the fetch: scatter to the texels, return d/d dir and d/d level
 __device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu, f3 dir, const EnvSample& s, const Taps tp[2],
-                                              const float gL[3], f3& g_dir, float& g_level)
+                                              const float gL[3], f3& g_dir, float& g_level, float* __restrict__ lds_grad = nullptr)
 {
     float gu = 0.f, gv = 0.f;
     g_level = 0.f;
@@ -236,11 +237,21 @@ __device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu
             gu += g * s.du[k][c];
             gv += g * s.dv[k][c];
         }
+        // coarse levels: thousands of pixels land on each texel -> accumulate in the workgroup's LDS copy of the level (LDS
+        // float atomics), flushed once per workgroup; fine levels: global atomics, lanes sharing a texel combined in the wave
+        const int loff = lds_grad != nullptr ? m.lds_off[lk] : -1;
+        const bool in_lds = __builtin_amdgcn_readfirstlane(loff) >= 0 && __builtin_amdgcn_ballot_w64(loff < 0) == 0ull;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float wq = wk * tp[k].w[q];
             const float vq[3] = {gL[0] * wq, gL[1] * wq, gL[2] * wq};
-            texel_scatter((gt != nullptr && wq != 0.f) ? gt + (size_t)tp[k].idx[q] * 3 : nullptr, vq);
+            const bool live = gt != nullptr && wq != 0.f;
+            if (live && loff >= 0) {                       // this lane's level is LDS-resident
+                float* a = lds_grad + loff + tp[k].idx[q] * 3;
+                atomicAdd(a, vq[0]); atomicAdd(a + 1, vq[1]); atomicAdd(a + 2, vq[2]);
+            }
+            // wave-convergent: skipped only when no lane of the wave needs the global path
+            if (!in_lds) texel_scatter((live && loff < 0) ? gt + (size_t)tp[k].idx[q] * 3 : nullptr, vq);
         }
     }
 #pragma unroll
@@ -395,60 +406,83 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
     }
 }
 
-__global__ void __launch_bounds__(256) shade_specular_bwd_kernel(EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha,
-                                                                 Map refl, Map rough, const float* __restrict__ lut, int lres,
-                                                                 const float* __restrict__ g_specular, const float* __restrict__ g_direct,
-                                                                 const float* __restrict__ g_weight, float* __restrict__ g_albedo /*[H,W,3]*/,
-                                                                 float* __restrict__ g_normal /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/,
-                                                                 float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/)
+// Persistent workgroups (one per CU, 12 waves): each keeps an LDS copy of the texel gradients of the coarse mip levels
+// (<= MRGS_SHADE_LDS_FLOATS floats: 32x32 and 16x16 cubemap levels = 90 KB), walks 64x12-pixel tiles of the image and flushes
+// the copy once at the end.  On those levels thousands of pixels hit every texel; global float atomics there ran at
+// ~40 G/s and bounded the kernel.
+#define MRGS_SHADE_BWD_THREADS 768
+#define MRGS_SHADE_LDS_FLOATS 23552
+__global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_kernel(
+    EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha, Map refl, Map rough, const float* __restrict__ lut, int lres,
+    const float* __restrict__ g_specular, const float* __restrict__ g_direct, const float* __restrict__ g_weight,
+    float* __restrict__ g_albedo /*[H,W,3]*/, float* __restrict__ g_normal /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/,
+    float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/, int tiles_x, int ntiles, int lds_floats)
 {
-    const int x_ = blockIdx.x * 64 + (threadIdx.x & 63), y_ = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const bool valid = x_ < W && y_ < H;    // out-of-image lanes stay alive (the texel scatter is wave-convergent)
-    const int x = min(x_, W - 1), y = min(y_, H - 1);
-    ShadePix p;
-    shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
-    const FaceUV fu = dir_to_face(p.rn);
-    float dl;
-    const float level = mip_level(m, p.rough, dl);
-    EnvSample s;
-    Taps tp[2];
-    env_fetch(m, fu, level, true, s, tp);
-    const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
-    float gL[3], ga = 0.f, gm = 0.f, gfg0 = 0.f, gfg1 = 0.f, galb[3];
+    __shared__ float s_grad[MRGS_SHADE_LDS_FLOATS];
+    for (int i = threadIdx.x; i < lds_floats; i += MRGS_SHADE_BWD_THREADS) s_grad[i] = 0.f;
+    __syncthreads();
+    const size_t HW = (size_t)H * W;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int x_ = (t % tiles_x) * 64 + (threadIdx.x & 63), y_ = (t / tiles_x) * (MRGS_SHADE_BWD_THREADS / 64) + (threadIdx.x >> 6);
+        const bool valid = x_ < W && y_ < H;    // out-of-image lanes stay alive (the texel scatter is wave-convergent)
+        const int x = min(x_, W - 1), y = min(y_, H - 1);
+        ShadePix p;
+        shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
+        const FaceUV fu = dir_to_face(p.rn);
+        float dl;
+        const float level = mip_level(m, p.rough, dl);
+        EnvSample s;
+        Taps tp[2];
+        env_fetch(m, fu, level, true, s, tp);
+        const size_t pix = (size_t)y * W + x;
+        float gL[3], ga = 0.f, gm = 0.f, gfg0 = 0.f, gfg1 = 0.f, galb[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float light = sigmoidf(s.L[c]);
-        const float base = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
-        const float wgt = base * p.fg[0] + p.fg[1];
-        const float gs = (valid && g_specular) ? g_specular[c * HW + pix] : 0.f;
-        const float gd = ((valid && g_direct) ? g_direct[c * HW + pix] : 0.f) + gs * p.alpha * wgt;
-        const float gw = ((valid && g_weight) ? g_weight[pix * 3 + c] : 0.f) + gs * light * p.alpha;
-        ga += gs * light * wgt;
-        gL[c] = gd * light * (1.f - light);
-        galb[c] = gw * p.refl * p.fg[0];
-        gm += gw * (p.albedo[c] - 0.04f) * p.fg[0];
-        gfg0 += gw * base;
-        gfg1 += gw;
+        for (int c = 0; c < 3; c++) {
+            const float light = sigmoidf(s.L[c]);
+            const float base = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
+            const float wgt = base * p.fg[0] + p.fg[1];
+            const float gs = (valid && g_specular) ? g_specular[c * HW + pix] : 0.f;
+            const float gd = ((valid && g_direct) ? g_direct[c * HW + pix] : 0.f) + gs * p.alpha * wgt;
+            const float gw = ((valid && g_weight) ? g_weight[pix * 3 + c] : 0.f) + gs * light * p.alpha;
+            ga += gs * light * wgt;
+            gL[c] = gd * light * (1.f - light);
+            galb[c] = gw * p.refl * p.fg[0];
+            gm += gw * (p.albedo[c] - 0.04f) * p.fg[0];
+            gfg0 += gw * base;
+            gfg1 += gw;
+        }
+        f3 g_rn;
+        float g_level;
+        env_fetch_bwd(m, fu, p.rn, s, tp, gL, g_rn, g_level, s_grad);
+        // safe_normalize backward (the 1e-20 clamp never binds for finite normals)
+        const float rg = dot3(p.rn, g_rn);
+        const f3 g_r = mk((g_rn.x - p.rn.x * rg) / p.rlen, (g_rn.y - p.rn.y * rg) / p.rlen, (g_rn.z - p.rn.z * rg) / p.rlen);
+        // r = 2 n (n.wo) - wo ; NdotV = n.wo feeds the LUT's u coordinate
+        const float g_ndv = p.u_in ? gfg0 * p.dfg_du[0] + gfg1 * p.dfg_du[1] : 0.f;
+        const float grn = dot3(g_r, p.n);
+        const f3 gn = mk(2.f * p.ndv * g_r.x + (2.f * grn + g_ndv) * p.wo.x, 2.f * p.ndv * g_r.y + (2.f * grn + g_ndv) * p.wo.y,
+                         2.f * p.ndv * g_r.z + (2.f * grn + g_ndv) * p.wo.z);
+        const float g_rough_v = (p.v_in ? gfg0 * p.dfg_dv[0] + gfg1 * p.dfg_dv[1] : 0.f) + g_level * dl;
+        if (valid) {
+            g_normal[pix * 3] = gn.x; g_normal[pix * 3 + 1] = gn.y; g_normal[pix * 3 + 2] = gn.z;
+#pragma unroll
+            for (int c = 0; c < 3; c++) g_albedo[pix * 3 + c] = galb[c];
+            g_alpha[pix] = ga;
+            g_refl[pix] = gm;
+            g_rough[pix] = g_rough_v;
+        }
     }
-    f3 g_rn;
-    float g_level;
-    env_fetch_bwd(m, fu, p.rn, s, tp, gL, g_rn, g_level);
-    // safe_normalize backward (the 1e-20 clamp never binds for finite normals)
-    const float rg = dot3(p.rn, g_rn);
-    const f3 g_r = mk((g_rn.x - p.rn.x * rg) / p.rlen, (g_rn.y - p.rn.y * rg) / p.rlen, (g_rn.z - p.rn.z * rg) / p.rlen);
-    // r = 2 n (n.wo) - wo ; NdotV = n.wo feeds the LUT's u coordinate
-    const float g_ndv = p.u_in ? gfg0 * p.dfg_du[0] + gfg1 * p.dfg_du[1] : 0.f;
-    const float grn = dot3(g_r, p.n);
-    const f3 gn = mk(2.f * p.ndv * g_r.x + (2.f * grn + g_ndv) * p.wo.x, 2.f * p.ndv * g_r.y + (2.f * grn + g_ndv) * p.wo.y,
-                     2.f * p.ndv * g_r.z + (2.f * grn + g_ndv) * p.wo.z);
-    const float g_rough_v = (p.v_in ? gfg0 * p.dfg_dv[0] + gfg1 * p.dfg_dv[1] : 0.f) + g_level * dl;
-    if (!valid) return;
-    g_normal[pix * 3] = gn.x; g_normal[pix * 3 + 1] = gn.y; g_normal[pix * 3 + 2] = gn.z;
-#pragma unroll
-    for (int c = 0; c < 3; c++) g_albedo[pix * 3 + c] = galb[c];
-    g_alpha[pix] = ga;
-    g_refl[pix] = gm;
-    g_rough[pix] = g_rough_v;
+    __syncthreads();
+    // flush the LDS-resident levels into one of the level's global copies (untouched texels are skipped)
+    for (int l = 0; l < m.n; l++) {
+        if (m.lds_off[l] < 0 || m.grad[l] == nullptr) continue;
+        const int n = 6 * m.res[l] * m.res[l] * 3;
+        float* dst = m.grad[l] + (size_t)(blockIdx.x % (unsigned)m.copies[l]) * (size_t)n;
+        for (int i = threadIdx.x; i < n; i += MRGS_SHADE_BWD_THREADS) {
+            const float v = s_grad[m.lds_off[l] + i];
+            if (v != 0.f) atomicAdd(dst + i, v);
+        }
+    }
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------
@@ -461,6 +495,7 @@ static int make_mips(const MrgsEnvMips* in, EnvMips& m)
         m.tex[i] = i < m.n ? in->tex[i] : nullptr;
         m.grad[i] = i < m.n ? in->grad[i] : nullptr;
         m.copies[i] = (i < m.n && in->grad_copies[i] > 1) ? in->grad_copies[i] : 1;
+        m.lds_off[i] = -1;
         if (i < m.n && (!m.tex[i] || m.res[i] < 1)) return MRGS_E_BAD_ARG;
     }
     m.min_roughness = in->min_roughness;
@@ -525,10 +560,26 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
     ShadeCam cam;
     for (int i = 0; i < 9; i++) cam.Kinv[i] = fr->Kinv[i];
     cam.R = fr->R; cam.T = fr->T;
-    const dim3 grid((fr->W + 63) / 64, (fr->H + 3) / 4), block(256);
+    // LDS-resident levels: from the coarsest up while they fit
+    int lds_floats = 0;
+    for (int l = m.n - 1; l >= 0; l--) {
+        const int n = 6 * m.res[l] * m.res[l] * 3;
+        if (m.grad[l] == nullptr || lds_floats + n > MRGS_SHADE_LDS_FLOATS) break;
+        m.lds_off[l] = lds_floats;
+        lds_floats += n;
+    }
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+        else n_cu = 256;
+    }
+    const int rows = MRGS_SHADE_BWD_THREADS / 64;
+    const int tiles_x = (fr->W + 63) / 64, ntiles = tiles_x * ((fr->H + rows - 1) / rows);
+    const dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(MRGS_SHADE_BWD_THREADS);
     hipLaunchKernelGGL(shade_specular_bwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
                        to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, g_specular, g_direct_light,
-                       g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness);
+                       g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness, tiles_x, ntiles, lds_floats);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
