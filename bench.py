@@ -31,6 +31,8 @@ WORKLOADS = {
     # BASELINE.json configs[2]: the full render_surfel path = per-gaussian material features -> rasterizer (S=8) -> 2DGS map
     # post-processing -> deferred split-sum shading (FG LUT + 5-level 128^2 cubemap) -> compositing, forward and backward
     "C3full": (300000, 800, 800, 8, "C3 shell scene through render_surfel: P=300000, 800x800, S=8 + deferred BRDF shading, fwd+bwd"),
+    # raster part of BASELINE.json configs[3] (the traced reflection integral needs the BVH tracer)
+    "C4raster": (1000000, 1600, 1600, 8, "C4-size shell scene: P=1000000 surfels, 1600x1600, SH deg 3, S=8 material channels, raster fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
 }
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

@@ -205,7 +205,7 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
 
     StageTimer t0(stream, ST_DUP);
     HIP_TRY(hipMemsetAsync(b.sort_ws, 0, b.sort_ws_bytes, stream));
-    if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, stream);
+    if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, stream);
     STAGE_CHECK(cfg, stream);
     const int bits = tile_bits(ntiles);
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);

@@ -32,12 +32,14 @@
 #define OS_SPIN_LIMIT (1 << 24)
 
 // Element count of a binning kernel: the host value, or -- when the launch was sized for a capacity before the count was
-// known on the host (mrgs_rasterize_forward) -- the device-resident count clamped to that capacity.
+// known on the host (mrgs_rasterize_forward) -- the device-resident count.  If that count exceeds the capacity the whole
+// second phase degenerates to "nothing to do" (0): the pair buffers would hold holes with arbitrary tile / gaussian ids, and
+// the host redoes the phase on an exactly sized workspace anyway.
 __device__ __forceinline__ int64_t mrgs_count(int64_t n_host, const uint32_t* __restrict__ n_dev)
 {
     if (n_dev == nullptr) return n_host;
     const int64_t v = (int64_t)*n_dev;
-    return v < n_host ? v : n_host;
+    return v <= n_host ? v : 0;
 }
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
@@ -364,14 +366,14 @@ void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint3
 __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect,
                                                         int tiles_x, uint32_t* __restrict__ tile_key, uint32_t* __restrict__ plist,
-                                                        uint32_t capacity)
+                                                        uint32_t capacity, const uint32_t* __restrict__ R_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    if (R_dev != nullptr && *R_dev > capacity) return;   // capacity guess too small: see mrgs_count
     const uint32_t g = order[i];
     if (tiles_touched[g] == 0) return;
     uint32_t off = offsets[i];
-    if (off + tiles_touched[g] > capacity) return;   // only when the buffers were sized for a guess that proved too small
     const uint2 r = rect[g];
     const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
     for (int y = y0; y < y1; y++)
@@ -383,11 +385,11 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* _
 }
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
-                           uint32_t* plist, int64_t capacity, hipStream_t stream)
+                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X;
     hipLaunchKernelGGL(duplicate_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, order, g.tiles_touched, g.offsets,
-                       g.rect, tiles_x, tile_key, plist, (uint32_t)capacity);
+                       g.rect, tiles_x, tile_key, plist, (uint32_t)capacity, R_dev);
 }
 
 // ---- identifyTileRanges (rasterizer_impl.cu:118-140) on the sorted tile ids + quadrant cull ------------------

@@ -159,11 +159,11 @@ def test_forward_on_a_capacity_guess_matches_the_two_phase_forward(gpu_device):
     cam = orbit_camera(3, H, W)
     grads = upstream_grads(S, H, W)
     results = []
-    for guess in (None, 10, 10_000_000, "exact"):
+    for guess in (None, 10, "half", 10_000_000, "exact"):      # too small (twice), far too large, exact
         if guess is None:
             rz._PAIR_GUESS.pop(gpu_device.index, None)
         else:
-            rz._PAIR_GUESS[gpu_device.index] = results[0][0] if guess == "exact" else guess
+            rz._PAIR_GUESS[gpu_device.index] = results[0][0] if guess == "exact" else results[0][0] // 2 if guess == "half" else guess
         hr = HipRender(scene, cam, gpu_device)
         pl = hr.export("point_list")
         rng = hr.export("ranges")
@@ -190,10 +190,11 @@ def test_mark_visible(gpu_device):
     np.testing.assert_array_equal(vis.cpu().numpy(), ro.mark_visible(pts, cam.world_view_transform, cam.full_proj_transform))
 
 
-def test_full_size_properties(gpu_device):
-    """BASELINE.json's C3 size (300k surfels, 800x800, S=8): size-independent properties, no oracle needed."""
-    P, S, H, W = 300000, 8, 800, 800
-    scene = make_shell_scene(P, S=S, seed=0, radius_px=7.0, image_size=800)
+@pytest.mark.parametrize("P,S,H,W", [(300000, 8, 800, 800), (1000000, 8, 1600, 1600)])
+def test_full_size_properties(gpu_device, P, S, H, W):
+    """BASELINE.json's C3 size (300k surfels, 800x800, S=8) and the raster part of C4 (1M surfels, 1600x1600): size-independent
+    properties, no oracle needed."""
+    scene = make_shell_scene(P, S=S, seed=0, radius_px=7.0, image_size=max(H, W))
     cam = orbit_camera(0, H, W)
     hr = HipRender(scene, cam, gpu_device)
     R = hr.num_rendered
