@@ -177,6 +177,26 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
                                  const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
                                  float* g_roughness, void* stream);
 
+/* ---- environment prefilter: EnvLight.build_mips (scene/light.py:72-86) ------------------------------------------------
+ * renderutils' specular_cubemap / diffuse_cubemap (scene/renderutils/c_src/cubemap.cu:110-354, ops.py:390-459) are fixed linear
+ * operators for a given (resolution, roughness, cos_cutoff): out[t] = sum_s w(t,s) cube[s] / sum_s w(t,s).  They are built
+ * once as CSR matrices with normalised weights and applied every iteration as 3-channel SpMVs (forward with the matrix,
+ * backward with its transpose, which the caller builds from the CSR).  kind: 0 specular GGX lobe, 1 diffuse cosine.
+ * Texel index = (face * res + y) * res + x; cubemaps are [6,res,res,3] fp32.
+ *   count: row_count[6 res^2] non-zeros per output texel, row_wsum[6 res^2] = sum of its un-normalised weights
+ *   fill:  col / val for row_ptr = exclusive prefix sum of row_count (val = weight / row_wsum for kind 0, the plain weight for kind 1:
+ *          diffuse_cubemap is not normalised) */
+int mrgs_cubemap_filter_count(int32_t res, int32_t kind, float roughness, float cos_cutoff, uint32_t* row_count, float* row_wsum, void* stream);
+int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float cos_cutoff, const uint32_t* row_ptr, const float* row_wsum,
+                             uint32_t* col, float* val, void* stream);
+/* y[nrows,3] = A x for a CSR matrix A (row_ptr[nrows+1]); lanes_per_row: 4 for short rows, 64 for rows of hundreds of non-zeros */
+int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const uint32_t* col, const float* val, const float* x, float* y, int32_t lanes_per_row,
+                   void* stream);
+/* cubemap_mip (scene/light_utils.py:66-81): forward = 2x2 box filter [6,2r,2r,3] -> [6,r,r,3]; backward = the reference's own
+ * rule (seamless bilinear cube fetch of 0.25 * dout at the finer level's texel-centre directions), ACCUMULATED into g_fine. */
+int mrgs_cubemap_mip_forward(int32_t res_out, const float* in, float* out, void* stream);
+int mrgs_cubemap_mip_backward(int32_t res_fine, const float* dout, float* g_fine, void* stream);
+
 /* ---- per-gaussian inputs of the surfel renderer (fused glue) -----------------------------------------------------
  * One kernel instead of the ~50 torch kernels the reference runs per view before the rasterizer call: GaussianModel getters
  * (scene/gaussian_model.py:236-311: sigmoid / exp / normalize activations), get_normal (:269-285) and the feature assembly of

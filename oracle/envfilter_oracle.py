@@ -1,0 +1,119 @@
+"""Dense CPU restatement of EnvLight.build_mips -- TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench cpu_baseline).
+
+Restates, literally and densely (one weight for every (output texel, source texel) pair, float64):
+  * cube_to_dir / pixel_area / ndfGGX                       scene/renderutils/c_src/cubemap.cu:17-46,171-176
+  * SpecularCubemapFwdKernel + `out[..., 0:3] / out[..., 3:]` scene/renderutils/c_src/cubemap.cu:238-290, ops.py:459
+  * DiffuseCubemapFwdKernel                                  scene/renderutils/c_src/cubemap.cu:110-137
+  * __ndfBounds cut-off angle                                scene/renderutils/ops.py:426-437
+  * cubemap_mip forward (box) and backward (bilinear cube fetch of 0.25 * dout)   scene/light_utils.py:66-81
+  * EnvLight.build_mips                                      scene/light.py:72-86
+PARITY UNPINNED: renderutils is a CUDA extension (cannot be built here) and the reference has no test or fixture for it; the
+cube fetch of the mip backward is nvdiffrast's `dr.texture` (not vendored), restated in shading_oracle.cube_fetch.  The
+specular filter's window is the set {dot(L, V) >= cos_cutoff}: the reference walks a per-face bounding box of exactly that
+set (SpecularBoundsKernel, cubemap.cu:178-236) and re-tests the dot product per texel.
+Usable for cubemaps up to ~32x32 (6144^2 weights).
+"""
+import numpy as np
+import torch
+
+from . import shading_oracle as so
+
+
+def cube_to_dir(N):
+    """[6*N*N, 3] unit directions of the texel centres, index (s*N + y)*N + x (cubemap.cu:32-46)."""
+    x = (2.0 * ((np.arange(N) + 0.5) / N) - 1.0)
+    fx, fy = np.meshgrid(x, x, indexing="xy")          # fx varies along x (columns), fy along y (rows)
+    one = np.ones_like(fx)
+    faces = [(one, -fy, -fx), (-one, -fy, fx), (fx, one, fy), (fx, -one, -fy), (fx, -fy, one), (-fx, -fy, -one)]
+    d = np.stack([np.stack(f, -1) for f in faces], 0).reshape(-1, 3)
+    return d / np.sqrt(np.maximum((d * d).sum(-1, keepdims=True), 1e-20))
+
+
+def pixel_area(N):
+    """[6*N*N] (cubemap.cu:17-30)."""
+    if N <= 1:
+        return np.ones(6)
+    H = N // 2
+    i = np.abs(np.arange(N) - H)
+    d = np.arctan((i + 1) / H) - np.arctan(i / H)
+    a = d[None, :] * d[:, None]                          # [y, x]
+    return np.tile(a.reshape(-1), 6)
+
+
+def cos_cutoff(roughness, cutoff=0.99):
+    def ndf(a2, c):
+        c = np.clip(c, 0.0, 1.0)
+        d = (c * a2 - c) * c + 1.0
+        return a2 / (d * d * np.pi)
+    costheta = np.cos(np.linspace(0, np.pi / 2.0, 1000000))
+    D = np.cumsum(ndf(roughness ** 4, costheta))
+    return float(costheta[np.argmax(D >= D[..., -1] * cutoff)])
+
+
+def specular_matrix(N, roughness, cutoff=0.99):
+    """Row-normalised dense operator [6N^2, 6N^2] of specular_cubemap."""
+    D = cube_to_dir(N)
+    dots = D @ D.T                                        # [out t, src s] = dot(L_s, VNR_t)
+    a2 = (roughness * roughness) ** 2
+    Hh = D[None, :, :] + D[:, None, :]                   # L + VNR
+    Hh = Hh / np.sqrt(np.maximum((Hh * Hh).sum(-1, keepdims=True), 1e-20))
+    vh = np.maximum((Hh * D[:, None, :]).sum(-1), 0.0)
+    c = np.clip(vh, 0.0, 1.0)
+    dd = (c * a2 - c) * c + 1.0
+    ndf = a2 / (dd * dd * np.pi)
+    W = np.maximum(dots, 0.0) * ndf * pixel_area(N)[None, :] / 4.0
+    W = np.where(dots >= np.float32(cos_cutoff(roughness, cutoff)), W, 0.0)
+    return W / W.sum(1, keepdims=True)
+
+
+def diffuse_matrix(N):
+    D = cube_to_dir(N)
+    ct = np.minimum(np.maximum(D @ D.T, 0.0), 0.999)
+    return ct * pixel_area(N)[None, :] / 3.141592       # diffuse_cubemap is NOT normalised by the weight sum
+
+
+def mip_forward(cube):
+    """[6,N,N,3] -> [6,N/2,N/2,3] (avg_pool2d 2x2)."""
+    N = cube.shape[1]
+    return cube.reshape(6, N // 2, 2, N // 2, 2, 3).mean(axis=(2, 4))
+
+
+def mip_backward(dout):
+    """The reference's rule (light_utils.py:71-80): bilinear cube fetch of 0.25 * dout at the finer level's texel centres."""
+    r = dout.shape[1] * 2
+    lin = torch.linspace(-1.0 + 1.0 / r, 1.0 - 1.0 / r, r, dtype=torch.float64)
+    gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+    out = np.zeros((6, r, r, 3))
+    t = torch.from_numpy(np.ascontiguousarray(dout * 0.25))
+    for s in range(6):
+        v = so.cube_to_dir(s, gx, gy)
+        v = v / torch.sqrt(torch.clamp((v * v).sum(-1, keepdim=True), min=1e-20))
+        out[s] = so.cube_fetch(t, v.reshape(-1, 3)).reshape(r, r, 3).numpy()
+    return out
+
+
+def build_mips(base, min_res, min_roughness=0.08, max_roughness=0.5, cutoff=0.99):
+    """EnvLight.build_mips forward: returns (specular levels, diffuse, per-level operators)."""
+    raw = [np.asarray(base, dtype=np.float64)]
+    while raw[-1].shape[1] > min_res:
+        raw.append(mip_forward(raw[-1]))
+    n = len(raw)
+    ops = []
+    for idx in range(n - 1):
+        rough = (idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness
+        ops.append(specular_matrix(raw[idx].shape[1], rough, cutoff))
+    ops.append(specular_matrix(raw[-1].shape[1], 1.0, cutoff))
+    spec = [(P @ r.reshape(-1, 3)).reshape(r.shape) for P, r in zip(ops, raw)]
+    diffuse = (diffuse_matrix(raw[-1].shape[1]) @ raw[-1].reshape(-1, 3)).reshape(raw[-1].shape)
+    return spec, diffuse, ops
+
+
+def build_mips_backward(ops, g_spec):
+    """Gradient w.r.t. base of sum_l <g_spec[l], specular[l]> under the reference's autograd rules."""
+    g = None
+    for l in range(len(ops) - 1, -1, -1):
+        gl = (ops[l].T @ np.asarray(g_spec[l], dtype=np.float64).reshape(-1, 3)).reshape(g_spec[l].shape)
+        if g is not None:
+            gl = gl + mip_backward(g)
+        g = gl
+    return g

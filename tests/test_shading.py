@@ -110,7 +110,12 @@ def test_envmap_lookup_parity(gpu_device):
     env = EnvLight(device=gpu_device, min_res=4, max_res=32, trainable=True)
     with torch.no_grad():
         env.base.copy_(mips[0])
-    env.build_mips()
+
+    def box_chain():   # this test is about the lookup kernels: plain box mips with torch's own autograd (build_mips has its own test)
+        env.specular = [env.base]
+        while env.specular[-1].shape[1] > 4:
+            env.specular.append(torch.nn.functional.avg_pool2d(env.specular[-1].permute(0, 3, 1, 2), (2, 2)).permute(0, 2, 3, 1).contiguous())
+    box_chain()
     g = torch.Generator().manual_seed(9)
     N = 5000
     d = torch.randn(N, 3, generator=g)
@@ -130,7 +135,7 @@ def test_envmap_lookup_parity(gpu_device):
         out_o = so.env_lookup(mips_o, d_o, r_o if use_rough else None)
         d_h, r_h = d.to(gpu_device).requires_grad_(True), rough.to(gpu_device).requires_grad_(True)
         env.base.grad = None
-        env.build_mips()
+        box_chain()
         out_h = env(d_h, roughness=r_h) if use_rough else env(d_h, mode="pure_env")
         np.testing.assert_allclose(out_h.detach().cpu().numpy(), out_o.detach().numpy(), atol=3e-6)
         gout = torch.randn(N, 3, generator=torch.Generator().manual_seed(3))
@@ -165,7 +170,9 @@ def test_shade_specular_parity(gpu_device):
     env = EnvLight(device=gpu_device, min_res=4, max_res=32, trainable=True)
     with torch.no_grad():
         env.base.copy_(mips[0])
-    env.build_mips()
+    env.specular = [env.base]          # plain box mips, as the oracle side of this test (build_mips has its own test)
+    while env.specular[-1].shape[1] > 4:
+        env.specular.append(torch.nn.functional.avg_pool2d(env.specular[-1].permute(0, 3, 1, 2), (2, 2)).permute(0, 2, 3, 1).contiguous())
     chw = [t.permute(2, 0, 1).contiguous().to(gpu_device).requires_grad_(True) for t in (albedo, normal, alpha, refl, rough)]
     hwc = [t.permute(1, 2, 0) for t in chw]
     camd = cam.to(gpu_device)
@@ -329,3 +336,26 @@ def test_fused_composite_matches_the_reference_ops(gpu_device, srgb):
     torch.autograd.backward([render_g, diffuse_g], [u1.float().to(gpu_device), u2.float().to(gpu_device)])
     for a, b in zip(tg, tc):
         assert float((a.grad.detach().cpu().double() - b.grad).abs().max()) <= 2e-5 * max(1.0, float(b.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_build_mips_prefilter_matches_dense_oracle(gpu_device):
+    """EnvLight.build_mips (box mips + GGX prefilter as sparse operators + the reference's mip backward rule) against the dense
+    float64 restatement of renderutils' cubemap kernels, forward and backward, on a 32 -> 16 -> 8 chain; plus the diffuse map."""
+    from oracle import envfilter_oracle as eo
+    from materialrefgs_amd.shading import EnvLight
+    g = torch.Generator().manual_seed(3)
+    env = EnvLight(device=gpu_device, min_res=8, max_res=32, trainable=True)
+    base = torch.randn(6, 32, 32, 3, generator=g)
+    with torch.no_grad():
+        env.base.copy_(base.to(gpu_device))
+    env.build_mips()
+    spec_o, diff_o, ops = eo.build_mips(base.double().numpy(), 8)
+    assert [tuple(m.shape) for m in env.specular] == [(6, 32, 32, 3), (6, 16, 16, 3), (6, 8, 8, 3)]
+    for a, b in zip(env.specular, spec_o):
+        assert float(np.abs(a.detach().cpu().double().numpy() - b).max()) <= 2e-5 * max(1.0, float(np.abs(b).max()))
+    assert float(np.abs(env.diffuse.detach().cpu().double().numpy() - diff_o).max()) <= 2e-5 * max(1.0, float(np.abs(diff_o).max()))
+    ups = [torch.randn(m.shape, generator=g) for m in env.specular]
+    torch.autograd.backward(env.specular, [u.to(gpu_device) for u in ups])
+    g_o = eo.build_mips_backward(ops, [u.double().numpy() for u in ups])
+    assert float(np.abs(env.base.grad.detach().cpu().double().numpy() - g_o).max()) <= 2e-5 * float(np.abs(g_o).max())
