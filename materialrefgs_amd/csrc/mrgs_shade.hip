@@ -580,8 +580,8 @@ __global__ void __launch_bounds__(256) cubemap_filter_build_kernel(int N, int ki
 }
 
 // y[r, 0..2] = sum_k val[k] x[col[k], 0..2] over the non-zeros of row r; G lanes per row (4: short rows, 64: long rows)
-template <int G>
-__global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+template <int G, typename IDX>
+__global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
                                                         const float* __restrict__ val, const float* __restrict__ x, float* __restrict__ y)
 {
     const int gid = (blockIdx.x * 256 + threadIdx.x) / G, sub = threadIdx.x % G;
@@ -750,14 +750,19 @@ int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float c
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
-int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const uint32_t* col, const float* val, const float* x, float* y, int32_t lanes_per_row,
-                   void* stream)
+int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const float* val, const float* x, float* y,
+                   int32_t lanes_per_row, void* stream)
 {
-    if (nrows < 1 || !row_ptr || !col || !val || !x || !y) return MRGS_E_BAD_ARG;
-    if (lanes_per_row >= 64)
-        hipLaunchKernelGGL(csr_spmv3_kernel<64>, dim3((unsigned)(((size_t)nrows * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nrows, row_ptr, col, val, x, y);
-    else
-        hipLaunchKernelGGL(csr_spmv3_kernel<4>, dim3((unsigned)(((size_t)nrows * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nrows, row_ptr, col, val, x, y);
+    if (nrows < 1 || !row_ptr || !col || !val || !x || !y || (col_bytes != 2 && col_bytes != 4)) return MRGS_E_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g64((unsigned)(((size_t)nrows * 64 + 255) / 256)), g4((unsigned)(((size_t)nrows * 4 + 255) / 256)), b(256);
+    if (lanes_per_row >= 64) {
+        if (col_bytes == 2) hipLaunchKernelGGL((csr_spmv3_kernel<64, uint16_t>), g64, b, 0, st, nrows, row_ptr, (const uint16_t*)col, val, x, y);
+        else hipLaunchKernelGGL((csr_spmv3_kernel<64, uint32_t>), g64, b, 0, st, nrows, row_ptr, (const uint32_t*)col, val, x, y);
+    } else {
+        if (col_bytes == 2) hipLaunchKernelGGL((csr_spmv3_kernel<4, uint16_t>), g4, b, 0, st, nrows, row_ptr, (const uint16_t*)col, val, x, y);
+        else hipLaunchKernelGGL((csr_spmv3_kernel<4, uint32_t>), g4, b, 0, st, nrows, row_ptr, (const uint32_t*)col, val, x, y);
+    }
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
