@@ -359,3 +359,24 @@ def test_build_mips_prefilter_matches_dense_oracle(gpu_device):
     torch.autograd.backward(env.specular, [u.to(gpu_device) for u in ups])
     g_o = eo.build_mips_backward(ops, [u.double().numpy() for u in ups])
     assert float(np.abs(env.base.grad.detach().cpu().double().numpy() - g_o).max()) <= 2e-5 * float(np.abs(g_o).max())
+
+
+def test_envfilter_oracle_known_answers():
+    """CPU: the dense restatement of renderutils' cubemap filters -- rows of the specular operator are normalised (a constant
+    cubemap stays constant), the diffuse operator integrates cos / pi over the hemisphere (~1 for a constant map), the mip
+    backward rule conserves the mass of the gradient (bilinear weights sum to 1, times 4 fine texels * 0.25), cut-off angles grow
+    with roughness."""
+    from oracle import envfilter_oracle as eo
+    N = 8
+    P = eo.specular_matrix(N, 0.5)
+    assert np.allclose(P.sum(1), 1.0) and (P >= 0).all()
+    const = np.full((6, 16, 16, 3), 0.7)
+    spec, diffuse, ops = eo.build_mips(const, 4)           # 16 -> 8 -> 4 (the reference's roughness schedule needs >= 3 levels)
+    for s in spec:
+        assert np.allclose(s, 0.7)
+    assert 0.7 < float(diffuse.mean()) / 0.7 < 1.1      # atan-product texel areas are coarse at 4x4 (the reference's formula)
+    assert eo.cos_cutoff(0.08) > eo.cos_cutoff(0.29) > eo.cos_cutoff(0.5) > eo.cos_cutoff(1.0) > 0.0
+    g = np.random.default_rng(0).normal(size=(6, 4, 4, 3))
+    assert np.allclose(eo.mip_backward(g).sum(axis=(0, 1, 2)), g.sum(axis=(0, 1, 2)), rtol=1e-6, atol=1e-9)
+    d = eo.cube_to_dir(N)
+    assert np.allclose((d * d).sum(-1), 1.0) and abs(float(eo.pixel_area(N).sum()) - 4 * np.pi) < 0.25 * 4 * np.pi
