@@ -380,3 +380,25 @@ def test_envfilter_oracle_known_answers():
     assert np.allclose(eo.mip_backward(g).sum(axis=(0, 1, 2)), g.sum(axis=(0, 1, 2)), rtol=1e-6, atol=1e-9)
     d = eo.cube_to_dir(N)
     assert np.allclose((d * d).sum(-1), 1.0) and abs(float(eo.pixel_area(N).sum()) - 4 * np.pi) < 0.25 * 4 * np.pi
+
+
+def test_maps_frame_matches_depths_to_points():
+    """CPU: the camera constants handed to the fused map kernels (built on the host in float64) reproduce the reference's
+    depths_to_points (utils/point_utils.py:9-24): point(x, y) = depth * (M (x, y, 1)) + o."""
+    from materialrefgs_amd.renderer import _maps_frame, depths_to_points
+    from materialrefgs_amd.synthetic import orbit_camera
+    H, W = 21, 34
+    cam = orbit_camera(5, H, W)
+    fr = _maps_frame(cam, 0.25)
+    assert (fr.H, fr.W) == (H, W) and abs(fr.depth_ratio - 0.25) < 1e-7
+    depth = torch.rand(1, H, W, dtype=torch.float64) * 3 + 1
+    cam64 = cam._replace(world_view_transform=cam.world_view_transform.double(), full_proj_transform=cam.full_proj_transform.double())
+    ref = depths_to_points(cam64, depth).reshape(H, W, 3).numpy()
+    M = np.array(list(fr.ray_matrix), dtype=np.float64).reshape(3, 3)
+    o = np.array(list(fr.ray_origin), dtype=np.float64)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rays = np.stack([xs, ys, np.ones_like(xs)], -1).astype(np.float64) @ M.T
+    mine = depth[0].numpy()[..., None] * rays + o
+    assert np.abs(mine - ref).max() <= 1e-5 * np.abs(ref).max()
+    V = np.array(list(fr.view_rot), dtype=np.float64).reshape(3, 3)
+    assert np.allclose(V, cam.world_view_transform[:3, :3].double().numpy(), atol=1e-7)
