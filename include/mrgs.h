@@ -199,6 +199,11 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
 int mrgs_cubemap_mip_forward(int32_t res_out, const float* in, float* out, void* stream);
 int mrgs_cubemap_mip_backward(int32_t res_fine, const float* dout, float* g_fine, void* stream);
 
+/* g_features[8,H,W] of render_surfel's material map (refl, roughness, albedo[3], indirect[3] = 0) assembled from the outputs of
+ * mrgs_surfel_composite_backward (g_refl) and mrgs_shade_specular_backward (g_refl, g_roughness [H,W]; g_albedo [H,W,3]). */
+int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,
+                              const float* g_albedo_hwc, float* g_features, void* stream);
+
 /* ---- per-gaussian inputs of the surfel renderer (fused glue) -----------------------------------------------------
  * One kernel instead of the ~50 torch kernels the reference runs per view before the rasterizer call: GaussianModel getters
  * (scene/gaussian_model.py:236-311: sigmoid / exp / normalize activations), get_normal (:269-285) and the feature assembly of

@@ -265,6 +265,24 @@ __global__ void __launch_bounds__(256) surfel_composite_bwd_kernel(int HW, int s
     g_alpha[pix] = ga;
 }
 
+// gradient of the rasterizer's [8,H,W] feature map of render_surfel (channels: refl, roughness, albedo[3], indirect[3]) from
+// the pieces the shading and compositing backward kernels produce -- one tensor instead of four slice gradients that autograd
+// would each pad to [8,H,W] and add up
+__global__ void __launch_bounds__(256) surfel_feature_grads_kernel(int HW, const float* __restrict__ g_refl_composite, const float* __restrict__ g_refl_shade,
+                                                                   const float* __restrict__ g_rough, const float* __restrict__ g_albedo_hwc,
+                                                                   float* __restrict__ g_features)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    g_features[pix] = g_refl_composite[pix] + g_refl_shade[pix];
+    g_features[HW + pix] = g_rough[pix];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        g_features[(2 + c) * HW + pix] = g_albedo_hwc[3 * (size_t)pix + c];
+        g_features[(5 + c) * HW + pix] = 0.0f;       // the indirect radiance map is not used without the visibility tracer
+    }
+}
+
 MapsFrameDev to_dev(const MrgsMapsFrame* fr)
 {
     MapsFrameDev f;
@@ -319,6 +337,16 @@ int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const flo
     const int HW = H * W;
     hipLaunchKernelGGL(surfel_composite_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, srgb, base_color,
                        refl_strength, specular, bg, g_render, g_diffuse, g_base, g_refl, g_specular, g_alpha);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,
+                              const float* g_albedo_hwc, float* g_features, void* stream)
+{
+    if (H <= 0 || W <= 0 || !g_refl_composite || !g_refl_shade || !g_roughness || !g_albedo_hwc || !g_features) return MRGS_E_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(surfel_feature_grads_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, g_refl_composite, g_refl_shade,
+                       g_roughness, g_albedo_hwc, g_features);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

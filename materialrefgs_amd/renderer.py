@@ -23,7 +23,7 @@ from ._lib import MrgsMapsFrame, MrgsSurfelGrads, MrgsSurfelParams
 
 from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
-from .shading import EnvLight, get_specular_color_surfel
+from .shading import EnvLight, get_specular_color_surfel, shade_and_composite_surfel
 
 
 class SurfelModel:
@@ -360,12 +360,13 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     if wo_render_img:
         return {"refl_strength_map": refl_strength, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
 
-    specular, extra_dict = get_specular_color_surfel(
-        pc.get_envmap, albedo.permute(1, 2, 0), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, reg["normal_map"],
-        render_alpha.permute(1, 2, 0), refl_strength=refl_strength.permute(1, 2, 0), roughness=roughness_map.permute(1, 2, 0), pc=pc,
-        surf_depth=reg["surf_depth"])
-    # (1 - refl) * base + specular, optional sRGB, background: one kernel each way (__init__.py:436-445)
-    final_image, diffuse_map = _SurfelComposite.apply(base_color, refl_strength, specular, render_alpha, bg_color, srgb)
+    # get_specular_color_surfel (utils/refl_utils.py:364-419) + (1 - refl) * base + specular, optional sRGB, background
+    # (__init__.py:436-445) as one autograd node on the whole material map
+    if getattr(pc, "ray_tracer", None) is not None:
+        raise NotImplementedError("visibility ray tracing is not part of this build (SURVEY.md section 8f-2)")
+    final_image, diffuse_map, specular, extra_dict = shade_and_composite_surfel(
+        pc.get_envmap, base_color, rendered_features, viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, reg["normal_map"],
+        render_alpha, bg_color, srgb)
     if srgb:
         albedo = linear_to_srgb(albedo)
         specular = linear_to_srgb(specular)

@@ -402,3 +402,41 @@ def test_maps_frame_matches_depths_to_points():
     assert np.abs(mine - ref).max() <= 1e-5 * np.abs(ref).max()
     V = np.array(list(fr.view_rot), dtype=np.float64).reshape(3, 3)
     assert np.allclose(V, cam.world_view_transform[:3, :3].double().numpy(), atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("srgb", [False, True])
+def test_shade_and_composite_node_matches_the_separate_ops(gpu_device, srgb):
+    """The single autograd node render_surfel uses (whole [8,H,W] material map in, one gradient tensor out) against the
+    reference-shaped sequence get_specular_color_surfel -> compositing on channel slices, which the other tests check."""
+    from materialrefgs_amd.renderer import _SurfelComposite
+    from materialrefgs_amd.shading import EnvLight, get_specular_color_surfel, shade_and_composite_surfel
+    from materialrefgs_amd.synthetic import orbit_camera
+    H, W = 40, 56
+    g = torch.Generator().manual_seed(21)
+    cam = orbit_camera(3, H, W).to(gpu_device)
+    env = EnvLight(device=gpu_device, min_res=4, max_res=16, trainable=True)
+    with torch.no_grad():
+        env.base.copy_(torch.randn(6, 16, 16, 3, generator=g).to(gpu_device))
+    vals = dict(base=torch.rand(3, H, W, generator=g), feat=torch.rand(8, H, W, generator=g),
+                nmap=torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1), alpha=torch.rand(1, H, W, generator=g))
+    bg = torch.tensor([0.2, 0.4, 0.6], device=gpu_device)
+    ups = [torch.randn(3, H, W, generator=g).to(gpu_device) for _ in range(3)]
+    res = []
+    for fused in (True, False):
+        t = {k: v.to(gpu_device).clone().requires_grad_(True) for k, v in vals.items()}
+        env.base.grad = None
+        env.build_mips()
+        if fused:
+            render, diffuse, spec, _ = shade_and_composite_surfel(env, t["base"], t["feat"], cam.HWK, cam.R, cam.T, t["nmap"], t["alpha"], bg, srgb)
+        else:
+            f = t["feat"]
+            spec, _ = get_specular_color_surfel(env, f[2:5].permute(1, 2, 0), cam.HWK, cam.R, cam.T, t["nmap"], t["alpha"].permute(1, 2, 0),
+                                                refl_strength=f[0:1].permute(1, 2, 0), roughness=f[1:2].permute(1, 2, 0))
+            render, diffuse = _SurfelComposite.apply(t["base"], f[0:1], spec, t["alpha"], bg, srgb)
+        torch.autograd.backward([render, diffuse, spec], ups)
+        res.append(([render, diffuse, spec], [t[k].grad for k in ("base", "feat", "nmap", "alpha")] + [env.base.grad.clone()]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(b.abs().max()))
