@@ -155,11 +155,22 @@ __device__ __forceinline__ CullConic mrgs_cull_load(const float4* __restrict__ r
 template <int SF>
 struct StageBuf {
     float4 rec[5][MRGS_CHUNK];
-    float feat[SF][MRGS_CHUNK];
+    float feat[SF][MRGS_CHUNK];   // FV = false: [channel][slot]; FV = true: the same bytes hold float4 [channel / 4][slot]
     uint32_t id[MRGS_CHUNK];
 };
 
-template <int S_MAX, int SF>
+// feature channel ch of staged entry j
+template <bool FV, int SF>
+__device__ __forceinline__ float mrgs_staged_feature(const StageBuf<SF>& sb, int ch, int j)
+{
+    if (FV) return reinterpret_cast<const float*>(&sb.feat[0][0])[((ch >> 2) * MRGS_CHUNK + j) * 4 + (ch & 3)];
+    return sb.feat[ch][j];
+}
+
+// FV ("feature vectors"): the feature row of a gaussian is S = S_MAX floats with S % 4 == 0, i.e. 16-byte aligned 16-byte
+// pieces: S/4 DMA instructions of 16 bytes per lane instead of S of 4 bytes (each DMA instruction of a wave gathers from up
+// to 64 different cache lines, which is what it costs), and the blend reads four channels with one ds_read_b128.
+template <int S_MAX, int SF, bool FV>
 __device__ __forceinline__ void mrgs_stage_async(StageBuf<SF>& dst, const float4* __restrict__ rec, const float* __restrict__ features,
                                                  int S, uint32_t gid, bool pred)
 {
@@ -171,10 +182,17 @@ __device__ __forceinline__ void mrgs_stage_async(StageBuf<SF>& dst, const float4
         __builtin_amdgcn_global_load_lds(src + 3, &dst.rec[3][0], 16, 0, 0);
         __builtin_amdgcn_global_load_lds(src + 4, &dst.rec[4][0], 16, 0, 0);
         if (S_MAX > 0) {
-            const float* fsrc = features + (size_t)gid * S;
+            if (FV) {
+                const float4* fsrc = reinterpret_cast<const float4*>(features + (size_t)gid * S_MAX);
+                float4* fdst = reinterpret_cast<float4*>(&dst.feat[0][0]);
 #pragma unroll
-            for (int ch = 0; ch < S_MAX; ch++)
-                if (ch < S) __builtin_amdgcn_global_load_lds(fsrc + ch, &dst.feat[ch][0], 4, 0, 0);
+                for (int q = 0; q < S_MAX / 4; q++) __builtin_amdgcn_global_load_lds(fsrc + q, fdst + q * MRGS_CHUNK, 16, 0, 0);
+            } else {
+                const float* fsrc = features + (size_t)gid * S;
+#pragma unroll
+                for (int ch = 0; ch < S_MAX; ch++)
+                    if (ch < S) __builtin_amdgcn_global_load_lds(fsrc + ch, &dst.feat[ch][0], 4, 0, 0);
+            }
         }
     }
 }

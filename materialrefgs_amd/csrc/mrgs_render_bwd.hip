@@ -172,7 +172,7 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #define WS_END()
 #endif
 
-template <int S_MAX>
+template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 4 : S_MAX <= 8 ? 3 : 2, 8))) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (c_top >= 2) { id2 = plist[(c_top - 2) * MRGS_CHUNK + lane]; q2 = qm[(c_top - 2) * MRGS_CHUNK + lane]; }
         const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
-        mrgs_stage_async<S_MAX, SF>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
+        mrgs_stage_async<S_MAX, SF, FV>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
     }
 
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         auto stage_next = [&]() {
             const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
-            mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
+            mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
             id1 = id2; q1 = q2;
             id2 = 0; q2 = 0;
@@ -328,14 +328,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             if (S_MAX > 0) {
 #pragma unroll
                 for (int ch = 0; ch < S_MAX; ch++) {
-                    g[MRGS_G_FEAT + ch] = 0.0f;
-                    if (ch < S) {
-                        const float f = sb.feat[ch][j];
-                        accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
-                        last_feature[ch] = f;
-                        dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
-                        g[MRGS_G_FEAT + ch] = w * dL_dpixel_f[ch];
-                    }
+                    // no branch on the runtime S (see the forward): slots beyond S read as 0 and have dL_dpixel_f = 0
+                    const float f = (FV || ch < S) ? mrgs_staged_feature<FV>(sb, ch, j) : 0.0f;
+                    accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
+                    last_feature[ch] = f;
+                    dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
+                    g[MRGS_G_FEAT + ch] = w * dL_dpixel_f[ch];
                 }
             }
             const float inv_cd = mrgs_rcp(c_d);
@@ -435,14 +433,18 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int ntiles = tiles_x * tiles_y;
     const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // one wave per (tile, quadrant); blockIdx % 8 = XCD list
     const dim3 grid(nblocks), block(64);
-#define LAUNCH(SM, GS)                                                                                                       \
-    hipLaunchKernelGGL(render_bwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.bwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+#define LAUNCH(SM, FVV, GS)                                                                                                       \
+    hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.bwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS)
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);
-    if (cfg.S == 0) LAUNCH(0, gs);
-    else if (cfg.S <= 8) LAUNCH(8, gs);
-    else if (cfg.S <= 12) LAUNCH(12, gs);
-    else LAUNCH(24, gs);
+    const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
+    if (cfg.S == 0) LAUNCH(0, false, gs);
+    else if (cfg.S == 8 && fv_ok) LAUNCH(8, true, gs);
+    else if (cfg.S <= 8) LAUNCH(8, false, gs);
+    else if (cfg.S == 12 && fv_ok) LAUNCH(12, true, gs);
+    else if (cfg.S <= 12) LAUNCH(12, false, gs);
+    else if (cfg.S == 24 && fv_ok) LAUNCH(24, true, gs);
+    else LAUNCH(24, false, gs);
 #undef LAUNCH
 }

@@ -24,7 +24,7 @@
 #define MRGS_FWD_STAGES 1
 #endif
 
-template <int S_MAX>
+template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         if (2 * MRGS_CHUNK + lane < total) { id2 = plist[2 * MRGS_CHUNK + lane]; q2 = qm[2 * MRGS_CHUNK + lane]; }
         const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
-        mrgs_stage_async<S_MAX, SF>(stage[0], rec, features, S, id0, cand0);
+        mrgs_stage_async<S_MAX, SF, FV>(stage[0], rec, features, S, id0, cand0);
     }
 
     for (int base = 0, c = 0; base < total; base += MRGS_CHUNK, c++) {
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             // stage chunk c+1 (its ids and cull bits arrived during the previous iterations), prefetch those of chunk c+3
             const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
-            mrgs_stage_async<S_MAX, SF>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
+            mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
             id1 = id2; q1 = q2;
             id2 = 0; q2 = 0;
             if (base + 3 * MRGS_CHUNK + lane < total) { id2 = plist[base + 3 * MRGS_CHUNK + lane]; q2 = qm[base + 3 * MRGS_CHUNK + lane]; }
@@ -136,9 +136,11 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
             C0 = fmaf(a0.w, w, C0); C1 = fmaf(a1.x, w, C1); C2 = fmaf(a1.y, w, C2);
             if (S_MAX > 0) {
+                // every channel slot of the kernel instance, no per-channel branch on the runtime S: a branch per channel puts
+                // each LDS read and its wait into a basic block of its own (measured: +110 us for 8 channels); the slots
+                // beyond S accumulate whatever the stage buffer holds and are never written out
 #pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) F[ch] = fmaf(sb.feat[ch][j], w, F[ch]);
+                for (int ch = 0; ch < S_MAX; ch++) F[ch] = fmaf(mrgs_staged_feature<FV>(sb, ch, j), w, F[ch]);
             }
             T = upd ? test_T : T;
             last_contributor = upd ? contributor : last_contributor;
@@ -206,12 +208,17 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int ntiles = tiles_x * tiles_y;
     const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // one wave per (tile, quadrant); blockIdx % 8 = XCD list
     const dim3 grid(nblocks), block(64);
-#define LAUNCH(SM)                                                                                                           \
-    hipLaunchKernelGGL(render_fwd_kernel<SM>, grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+#define LAUNCH(SM, FVV)                                                                                                           \
+    hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work)
-    if (cfg.S == 0) LAUNCH(0);
-    else if (cfg.S <= 8) LAUNCH(8);
-    else if (cfg.S <= 12) LAUNCH(12);
-    else LAUNCH(24);
+    // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
+    const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
+    if (cfg.S == 0) LAUNCH(0, false);
+    else if (cfg.S == 8 && fv_ok) LAUNCH(8, true);
+    else if (cfg.S <= 8) LAUNCH(8, false);
+    else if (cfg.S == 12 && fv_ok) LAUNCH(12, true);
+    else if (cfg.S <= 12) LAUNCH(12, false);
+    else if (cfg.S == 24 && fv_ok) LAUNCH(24, true);
+    else LAUNCH(24, false);
 #undef LAUNCH
 }
