@@ -61,11 +61,11 @@ def main():
     args = ap.parse_args()
 
     from materialrefgs_amd import dist as mdist
-    env = mdist.init_from_env()
+    env = mdist.init_from_env(backend=os.environ.get("MRGS_DIST_BACKEND"))   # default: RCCL ("nccl"); "gloo" for plumbing checks on one GPU
     world, rank, local = env["world"], env["rank"], env["local"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
     from materialrefgs_amd import _lib
@@ -116,7 +116,10 @@ def main():
     params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     means2D = torch.zeros_like(scene.means3D, requires_grad=True)   # screenspace_points (gaussian_renderer/__init__.py:229)
     grad_names = list(params.keys()) + ["means2D"]
-    bucket = mdist.GradBucket([params[k].shape for k in params] + [means2D.shape], dev) if world > 1 else None
+    # view-parallel exchange: dense all-reduce of 13 gradient floats per gaussian + factored exchange of the SH gradient
+    # (materialrefgs_amd/dist.py: FactoredGradReducer)
+    reducer = mdist.FactoredGradReducer([params[k].shape for k in params] + [means2D.shape], list(params.keys()).index("sh"), dev) \
+        if world > 1 else None
     state = {"R": 0}
 
     surfel_bucket = mdist.GradBucket([t_.shape for t_ in surfel_params], dev) if (surfel_mode and world > 1) else None
@@ -153,7 +156,7 @@ def main():
             grads.append(g_feat)
         torch.autograd.backward(outs, grads)
         if world > 1:
-            mdist.allreduce_gradients(bucket, [params[k].grad for k in params] + [means2D.grad])
+            reducer.reduce([params[k].grad for k in params] + [means2D.grad], params["means3D"], settings[view].campos, 3)
 
     def fence():
         if world > 1:

@@ -259,6 +259,13 @@ int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const flo
                                    const float* specular, const float* bg, const float* g_render, const float* g_diffuse, float* g_base,
                                    float* g_refl, float* g_specular, float* g_alpha, void* stream);
 
+/* View-parallel training (materialrefgs_amd/dist.py): sum over V views of the SH colour gradients from each view's masked colour
+ * gradient dRGB_v = dL/dsh_v[:,0,:] / SH_C0 and camera centre: dL_dsh[p][k][c] = sum_v B_k(normalize(means3D[p] - campos_v)) dRGB_v[p][c]
+ * for k < (D+1)^2, 0 beyond (backward.cu:22-141).  gathered = V rows of row_stride floats, row v = [dRGB_v (P x 3) | campos_v (3)]
+ * -- the layout an all-gather of the per-rank rows produces.  Replaces the all-reduce of the [P,M,3] gradient (16x the bytes). */
+int mrgs_sh_grad_expand(int32_t P, int32_t M, int32_t D, int32_t V, const float* means3D, const float* gathered, int64_t row_stride,
+                        float* dL_dsh, void* stream);
+
 /* Introspection used by the parity tests: copies of internal state in the reference's layouts.
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
  * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],

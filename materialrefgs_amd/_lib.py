@@ -103,6 +103,7 @@ SYMBOLS = {
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_mip_backward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -291,9 +291,58 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
     }
 }
 
+// Sum over views of the SH colour gradients, rebuilt from each view's masked colour gradient (materialrefgs_amd/dist.py):
+// dL/dsh[k][c] of view v = B_k(dir_v) * dRGB_v[c] (backward.cu:22-141), so instead of all-reducing 48 floats per gaussian the
+// ranks all-gather 3 and every rank evaluates sum_v B_k(dir_v(p)) dRGB_v[p][c] itself.  gathered: V rows of `row_stride` floats,
+// row v = [dRGB_v (P x 3) | campos_v (3)].
+__global__ void __launch_bounds__(256) sh_grad_expand_kernel(int P, int M, int D, int V, const float* __restrict__ means3D,
+                                                             const float* __restrict__ gathered, long long row_stride,
+                                                             float* __restrict__ out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+    float acc[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { acc[k][0] = 0.0f; acc[k][1] = 0.0f; acc[k][2] = 0.0f; }
+    const int ncoef = (D + 1) * (D + 1);
+    for (int v = 0; v < V; v++) {
+        const float* row = gathered + (size_t)v * row_stride;
+        const float* cam = row + 3 * (size_t)P;
+        const float g[3] = {row[3 * (size_t)idx], row[3 * (size_t)idx + 1], row[3 * (size_t)idx + 2]};
+        if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) continue;     // not visible in that view
+        const float d[3] = {p[0] - cam[0], p[1] - cam[1], p[2] - cam[2]};
+        const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        float B[16];
+        sh_basis16(d[0] / len, d[1] / len, d[2] / len, B);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float b = k < ncoef ? B[k] : 0.0f;
+            acc[k][0] += b * g[0]; acc[k][1] += b * g[1]; acc[k][2] += b * g[2];
+        }
+    }
+    float* o = out + (size_t)idx * M * 3;
+    for (int k = 0; k < M; k++) {
+        const bool in16 = k < 16;
+        o[3 * k] = in16 ? acc[k & 15][0] : 0.0f; o[3 * k + 1] = in16 ? acc[k & 15][1] : 0.0f; o[3 * k + 2] = in16 ? acc[k & 15][2] : 0.0f;
+    }
+}
+
 }   // namespace
 
 extern "C" {
+
+int mrgs_sh_grad_expand(int32_t P, int32_t M, int32_t D, int32_t V, const float* means3D, const float* gathered, int64_t row_stride,
+                        float* dL_dsh, void* stream)
+{
+    if (P < 0 || M < 1 || D < 0 || D > 3 || V < 1 || row_stride < 3 * (int64_t)P + 3) return MRGS_E_BAD_ARG;
+    if (P == 0) return MRGS_OK;
+    if (!means3D || !gathered || !dL_dsh) return MRGS_E_BAD_ARG;
+    hipLaunchKernelGGL(sh_grad_expand_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, D, V, means3D, gathered,
+                       (long long)row_stride, dL_dsh);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
 
 int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, float* scales, float* rotations, float* features, void* stream)
 {

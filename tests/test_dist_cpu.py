@@ -68,3 +68,45 @@ def test_bucket_roundtrip_single_process():
     g = [torch.arange(15.0).reshape(5, 3), None]
     out = allreduce_gradients(b, g)
     assert torch.equal(out[0], g[0]) and torch.count_nonzero(out[1]) == 0
+
+
+def _worker_factored(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from materialrefgs_amd import dist as mdist
+    from materialrefgs_amd.gs_utils import sh_basis
+    mdist.init_from_env(backend="gloo")
+    P, M, deg = 301, 16, 3
+    shared = torch.Generator().manual_seed(7)
+    means3D = torch.randn(P, 3, generator=shared) * 2          # replicated parameters: identical on every rank
+    gen = torch.Generator().manual_seed(200 + rank)
+    campos = torch.randn(3, generator=gen) * 5                  # this rank's view
+    drgb = torch.randn(P, 3, generator=gen)
+    drgb[torch.rand(P, generator=gen) < 0.3] = 0.0             # gaussians not visible in this view
+    d = means3D - campos
+    sh_grad = sh_basis(deg, d / d.norm(dim=1, keepdim=True)).unsqueeze(-1) * drgb.unsqueeze(1)       # what the rasterizer backward yields
+    shapes = [(P, 3), (P, M, 3), (P, 1), (P, 4)]
+    grads = [torch.randn(P, 3, generator=gen), sh_grad, torch.randn(P, 1, generator=gen), None]
+    red = mdist.FactoredGradReducer([torch.Size(s) for s in shapes], 1, "cpu")
+    out = red.reduce(grads, means3D, campos, deg)
+    q.put((rank, [o.clone().numpy() for o in out], [None if g is None else g.numpy() for g in grads]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factored_sh_gradient_exchange_world2():
+    """FactoredGradReducer (all-gather of dRGB + camera centres, local SH expansion, all-reduce of the rest) gives the same sums as
+    a dense all-reduce of every gradient tensor."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(4):
+        expect = sum((np.zeros_like(res[0][1][i]) if r[2][i] is None else r[2][i]) for r in res)
+        for r in res:
+            np.testing.assert_allclose(r[1][i], expect, rtol=2e-5, atol=2e-6)
