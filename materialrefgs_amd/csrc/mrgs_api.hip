@@ -178,7 +178,6 @@ size_t mrgs_grad_bytes(int32_t P, int32_t S) { return mrgs_align_up((size_t)(P >
 static int enqueue_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, MrgsGeomWs g, int32_t* radii, hipStream_t stream)
 {
     StageTimer t0(stream, ST_PRE);
-    HIP_TRY(hipMemsetAsync(g.counters, 0, g.clear_bytes, stream));   // counters + look-back state of the sort and the scan
     mrgs_launch_preprocess_fwd(*cfg, *in, g, radii, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
@@ -204,8 +203,11 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     const int dcur = sorted_buf(32);
 
     StageTimer t0(stream, ST_DUP);
-    HIP_TRY(hipMemsetAsync(b.sort_ws, 0, b.sort_ws_bytes, stream));
-    if (R > 0) mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, stream);
+    if (R > 0) {
+        mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, b, img, stream);
+    } else {   // nothing visible: no kernel touches the pair buffers, only the ranges have to read as empty
+        HIP_TRY(hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream));
+    }
     STAGE_CHECK(cfg, stream);
     const int bits = tile_bits(ntiles);
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);

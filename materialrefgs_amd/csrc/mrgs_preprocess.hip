@@ -140,10 +140,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ shs, const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     int32_t* __restrict__ radii, float4* __restrict__ rec, float4* __restrict__ cull, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order,
-    uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped, uint32_t* __restrict__ census)
+    uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped, uint32_t* __restrict__ clear_ptr,
+    unsigned clear_words)
 {
-    // which CUs exist (the blend kernels keep one work queue per SIMD): one bit per CU, set by the first wave that runs there
-    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
+    // first kernel of a forward: clears the per-call state of the later binning kernels (num_rendered, error flag, CU census,
+    // tickets / totals / look-back words of the depth sort and the scan) instead of a separate memset launch
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < clear_words; i += gridDim.x * blockDim.x) clear_ptr[i] = 0u;
     // (the SH rows are read straight from global memory here: staging them through LDS as the backward does costs more in
     // occupancy -- 50 KB per workgroup -- than the coalescing gains; 0.060 ms staged vs 0.054 ms direct at P = 300k)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,7 +351,7 @@ void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H,
                        tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
                        in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec, g.cull,
-                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters + 16);
+                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters, (unsigned)(g.clear_bytes / sizeof(uint32_t)));
 }
 
 // ------------------------------------------------------------------------------------------------------

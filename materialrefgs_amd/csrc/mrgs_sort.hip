@@ -366,8 +366,16 @@ void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint3
 __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect,
                                                         int tiles_x, uint32_t* __restrict__ tile_key, uint32_t* __restrict__ plist,
-                                                        uint32_t capacity, const uint32_t* __restrict__ R_dev)
+                                                        uint32_t capacity, const uint32_t* __restrict__ R_dev, uint32_t* __restrict__ census,
+                                                        uint32_t* __restrict__ clear_a, unsigned words_a, uint32_t* __restrict__ clear_b,
+                                                        unsigned words_b)
 {
+    // first kernel of the second phase: clears the look-back state of the tile sort (clear_a) and the tile ranges + cull counts
+    // (clear_b; rasterizer_impl.cu:316 clears the ranges) instead of two memset launches, and takes the CU census for the
+    // work queues of the blend kernels (one flag per CU some wave of this launch runs on)
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < words_a; k += gridDim.x * blockDim.x) clear_a[k] = 0u;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < words_b; k += gridDim.x * blockDim.x) clear_b[k] = 0u;
+    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     if (R_dev != nullptr && *R_dev > capacity) return;   // capacity guess too small: see mrgs_count
@@ -385,11 +393,12 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* _
 }
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
-                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, hipStream_t stream)
+                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, const MrgsBinWs& b, const MrgsImgWs& img, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X;
     hipLaunchKernelGGL(duplicate_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, order, g.tiles_touched, g.offsets,
-                       g.rect, tiles_x, tile_key, plist, (uint32_t)capacity, R_dev);
+                       g.rect, tiles_x, tile_key, plist, (uint32_t)capacity, R_dev, g.counters + 16, b.sort_ws,
+                       (unsigned)(b.sort_ws_bytes / sizeof(uint32_t)), (uint32_t*)img.ranges, (unsigned)(img.ranges_est_bytes / sizeof(uint32_t)));
 }
 
 // ---- identifyTileRanges (rasterizer_impl.cu:118-140) on the sorted tile ids + quadrant cull ------------------
@@ -608,8 +617,7 @@ void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int n
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,
                              uint8_t* qmask, const MrgsImgWs& img, int tiles_x, int ntiles, hipStream_t stream)
 {
-    // ranges and item_est are adjacent: one clear (rasterizer_impl.cu:316 clears the ranges)
-    (void)hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream);
+    // (ranges and item_est were cleared by duplicate_kernel)
     if (R > 0)
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, tile_key, plist, R, R_dev, rec,
                            tiles_x, img.ranges, qmask, img.item_est);
