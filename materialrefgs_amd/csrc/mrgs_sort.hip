@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
 // Work per item: the forward uses the cull counts of tile_ranges_kernel, the backward what the forward waves actually walked.
 // The first call of a forward also turns the CU census (bits set by the preprocess waves) into a dense CU numbering.
 #define ORDER_ADAPTIVE_PASSES 16
+#define ORDER_LDS_ITEMS 4096
 __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __restrict__ item_src, int ntiles, uint32_t* __restrict__ items_ws,
                                                            uint32_t* __restrict__ work_ws, uint32_t* __restrict__ assign_ws,
                                                            uint32_t* __restrict__ qstate, const uint32_t* __restrict__ census,
@@ -521,8 +522,12 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     const uint32_t ex = block_exclusive_scan<1024>(hist[tid], wave_sums, tot);
     hist[tid] = ex;
     __syncthreads();
-    uint32_t* items = items_ws + (size_t)x * per_list;
-    uint32_t* work = work_ws + (size_t)x * per_list;
+    // sorted items and their work: in LDS when the list is short enough (the dealing passes below read them back one pass
+    // after the other: from global memory every pass costs a round trip)
+    __shared__ uint32_t s_items[ORDER_LDS_ITEMS], s_work[ORDER_LDS_ITEMS];
+    const bool in_lds = per_list <= ORDER_LDS_ITEMS;
+    uint32_t* items = in_lds ? s_items : items_ws + (size_t)x * per_list;
+    uint32_t* work = in_lds ? s_work : work_ws + (size_t)x * per_list;
     for (int i0 = 0; i0 < per_list; i0 += 1024) {
         const int i = i0 + tid;
         const int tile = (i >> 2) * 8 + x;
@@ -562,11 +567,12 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     const unsigned long long mean5 = n_items > 0 ? 5ull * s_total / (unsigned long long)n_items : 0ull;   // 5 x mean work
     uint32_t* assign = assign_ws + (size_t)x * (per_list + MRGS_MAX_SIMD_QUEUES);
     __shared__ uint32_t qrank[MRGS_MAX_SIMD_QUEUES];
-    for (int p = 0; p < passes; p++) {
-        const bool adaptive = p > 0 && p < ORDER_ADAPTIVE_PASSES && p * NQ < (int)s_busy;   // idle items need no balancing
-        if (adaptive) {
-            // rank of every queue by load so far (ascending, ties by index): thread (part, q) counts the queues of its
-            // eighth that come before q
+    // items with work: sequential passes, the heaviest item of a pass to the queue with the least load so far
+    const int n_adapt = min(min(passes, ORDER_ADAPTIVE_PASSES), ((int)s_busy + NQ - 1) / NQ);
+    for (int p = 0; p < n_adapt; p++) {
+        if (p > 0) {
+            // rank of every queue by load (ascending, ties by index): thread (part, q) counts the queues of its eighth that
+            // come before q
             if (tid < NQ) qrank[tid] = 0u;
             __syncthreads();
             const int q = tid & (MRGS_MAX_SIMD_QUEUES - 1), part = tid >> 7;
@@ -582,10 +588,7 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
             __syncthreads();
         }
         if (tid < NQ) {
-            // position in the pass (0 = heaviest item) this queue receives: lightest queue <- heaviest item; plain snake
-            // beyond the adaptive passes
-            const int slot = adaptive ? (int)qrank[tid] : (p & 1) ? NQ - 1 - tid : tid;
-            const int rank = p * NQ + slot;
+            const int rank = p * NQ + (p > 0 ? (int)qrank[tid] : tid);
             uint32_t entry = 0xFFFFFFFFu;
             if (rank < n_items) {
                 // issue priority of the wave (bits 29-30): the heavy items of a SIMD run ahead of its light ones
@@ -597,6 +600,12 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
             assign[p * NQ + tid] = entry;
         }
         __syncthreads();
+    }
+    // the rest (idle items of the forward, very long lists): plain snake dealing, all passes at once
+    for (int e = n_adapt * NQ + tid; e < passes * NQ; e += 1024) {
+        const int p = e / NQ, q = e - p * NQ;
+        const int rank = p * NQ + ((p & 1) ? NQ - 1 - q : q);
+        assign[e] = rank < n_items ? items[rank] : 0xFFFFFFFFu;
     }
     if (tid == 0) {
         qstate[MRGS_QS_COUNT + x] = tot;
