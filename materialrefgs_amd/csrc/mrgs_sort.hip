@@ -441,7 +441,14 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
 #endif
         qmask[idx] = (uint8_t)m;
     }
-    // per-quadrant counts: one atomic per (wave, tile, quadrant) -- a wave spans one tile, or a few at segment boundaries
+    // per-quadrant counts: summed per wave with ballots, per workgroup in LDS (the 256 sorted entries of a workgroup span one or
+    // two tiles, rarely more than 64), then one global atomic per (workgroup, tile, quadrant)
+    __shared__ uint32_t s_cnt[64 * 4];
+    __shared__ uint32_t s_first;
+    s_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_first = cur;          // entry 0 of the workgroup is valid whenever any entry is
+    __syncthreads();
+    const uint32_t first_tile = s_first;
 #ifdef TR_NO_ATOMICS
     uint64_t todo = 0;
 #else
@@ -451,12 +458,19 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
         const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)cur, __builtin_ctzll(todo));
         const bool mine = valid && cur == t;
         todo &= ~__builtin_amdgcn_ballot_w64(mine);
+        const uint32_t rel = t - first_tile;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int n = __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine && ((m >> q) & 1u)));
-            if ((threadIdx.x & 63) == 0 && n > 0) atomicAdd(&item_est[t * 4 + q], (uint32_t)n);
+            if ((threadIdx.x & 63) == 0 && n > 0) {
+                if (rel < 64u) atomicAdd(&s_cnt[rel * 4 + q], (uint32_t)n);
+                else atomicAdd(&item_est[t * 4 + q], (uint32_t)n);
+            }
         }
     }
+    __syncthreads();
+    const uint32_t c = s_cnt[threadIdx.x];
+    if (c != 0u) atomicAdd(&item_est[(first_tile + (threadIdx.x >> 2)) * 4 + (threadIdx.x & 3)], c);
 }
 
 // ---- dispatch order of the blend kernels ---------------------------------------------------------------------
