@@ -213,7 +213,7 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
     STAGE_CHECK(cfg, stream);
     mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
-    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, stream);
+    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, nullptr, 0, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
@@ -346,10 +346,12 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     float* grad_rec = (float*)grad_ws;
 
     StageTimer t0(stream, ST_BWD);
-    HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
     if (R > 0) {
-        mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, stream);
+        // (the gradient rows are cleared by spare workgroups of the ordering launch; mrgs_grad_bytes is a multiple of 256)
+        mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, grad_rec, mrgs_grad_bytes(cfg->P, cfg->S), stream);
         mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.qmask, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
+    } else {
+        HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
     }
     t0.stop();
     STAGE_CHECK(cfg, stream);

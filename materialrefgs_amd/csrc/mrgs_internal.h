@@ -130,7 +130,9 @@ void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, con
                            uint32_t* plist, int64_t capacity, const uint32_t* R_dev, const MrgsBinWs& b, const MrgsImgWs& img, hipStream_t stream);
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,
                              uint8_t* qmask, const MrgsImgWs& img, int tiles_x, int ntiles, hipStream_t stream);
-void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, hipStream_t stream);
+// bulk_zero (nullable, 16-byte aligned, size a multiple of 16): cleared by extra workgroups of the same launch
+void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, void* bulk_zero, size_t bulk_zero_bytes,
+                             hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const uint8_t* qmask, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);

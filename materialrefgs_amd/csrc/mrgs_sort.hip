@@ -488,8 +488,16 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
 __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __restrict__ item_src, int ntiles, uint32_t* __restrict__ items_ws,
                                                            uint32_t* __restrict__ work_ws, uint32_t* __restrict__ assign_ws,
                                                            uint32_t* __restrict__ qstate, const uint32_t* __restrict__ census,
-                                                           uint32_t* __restrict__ cu_state, int forward, uint32_t* __restrict__ zero_this)
+                                                           uint32_t* __restrict__ cu_state, int forward, uint32_t* __restrict__ zero_this,
+                                                           float4* __restrict__ bulk_zero, size_t bulk_zero_f4)
 {
+    // workgroups beyond the eight that order the lists only clear a buffer for the kernel that follows (the gradient rows of
+    // the blend backward, 24 MB at P = 300k): the ordering occupies 8 CUs for ~10 us, the clear runs beside it on the others
+    if (blockIdx.x >= 8) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = (size_t)(blockIdx.x - 8) * 1024 + threadIdx.x; i < bulk_zero_f4; i += (size_t)(gridDim.x - 8) * 1024) bulk_zero[i] = z;
+        return;
+    }
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t load[MRGS_MAX_SIMD_QUEUES];
@@ -627,14 +635,19 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     }
 }
 
-void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, hipStream_t stream)
+void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, void* bulk_zero, size_t bulk_zero_bytes,
+                             hipStream_t stream)
 {
+    const size_t f4 = bulk_zero ? bulk_zero_bytes / sizeof(float4) : 0;   // callers pass multiples of 16 bytes
+    const unsigned extra = f4 ? (unsigned)((f4 + 8191) / 8192 < 504 ? (f4 + 8191) / 8192 : 504) : 0u;
     if (backward)
-        hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
-                           img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
+                           img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr,
+                           (float4*)bulk_zero, f4);
     else
-        hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
-                           img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work);
+        hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
+                           img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work,
+                           (float4*)bulk_zero, f4);
 }
 
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,
