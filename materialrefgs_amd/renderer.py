@@ -301,12 +301,9 @@ def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
 
 
 def _screenspace_points(pc):
-    sp = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        sp.retain_grad()
-    except Exception:
-        pass
-    return sp
+    """screenspace_points of the reference (gaussian_renderer/__init__.py:229-233): a zero tensor whose .grad receives the
+    2D-mean gradients.  A leaf here (the reference adds 0 and calls retain_grad(): same .grad, one kernel more)."""
+    return torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True)
 
 
 def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None):
