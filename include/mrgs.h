@@ -189,11 +189,12 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
 int mrgs_cubemap_filter_count(int32_t res, int32_t kind, float roughness, float cos_cutoff, uint32_t* row_count, float* row_wsum, void* stream);
 int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float cos_cutoff, const uint32_t* row_ptr, const float* row_wsum,
                              uint32_t* col, float* val, void* stream);
-/* y[nrows,3] = A x for a CSR matrix A (row_ptr[nrows+1]); col holds uint16 (col_bytes 2, matrices with <= 65536 columns: the
- * kernel streams 6 instead of 8 bytes per non-zero) or uint32 (col_bytes 4) column indices; lanes_per_row: 4 for short rows, 64 for
- * rows of hundreds of non-zeros */
-int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const float* val, const float* x, float* y,
-                   int32_t lanes_per_row, void* stream);
+/* y[nrows,3] = A x for a CSR matrix A (row_ptr[nrows+1]).  The kernel is bound by streaming A from HBM, so A may be stored
+ * compactly: col holds uint16 (col_bytes 2, <= 65536 columns) or uint32 (4) column indices; val holds fp32 weights (val_bytes 4,
+ * row_scale may be NULL) or 16-bit fixed-point weights q (val_bytes 2) with weight = q * row_scale[row].  lanes_per_row: 4 for
+ * short rows, 64 for rows of hundreds of non-zeros. */
+int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const void* val, int32_t val_bytes,
+                   const float* row_scale, const float* x, float* y, int32_t lanes_per_row, void* stream);
 /* cubemap_mip (scene/light_utils.py:66-81): forward = 2x2 box filter [6,2r,2r,3] -> [6,r,r,3]; backward = the reference's own
  * rule (seamless bilinear cube fetch of 0.25 * dout at the finer level's texel-centre directions), ACCUMULATED into g_fine. */
 int mrgs_cubemap_mip_forward(int32_t res_out, const float* in, float* out, void* stream);

@@ -99,7 +99,7 @@ SYMBOLS = {
                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_filter_count": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_filter_fill": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_mip_backward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

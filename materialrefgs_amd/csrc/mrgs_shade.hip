@@ -579,17 +579,21 @@ __global__ void __launch_bounds__(256) cubemap_filter_build_kernel(int N, int ki
     if (PASS == 0) { row_count[t] = cnt; row_wsum[t] = wsum; }
 }
 
-// y[r, 0..2] = sum_k val[k] x[col[k], 0..2] over the non-zeros of row r; G lanes per row (4: short rows, 64: long rows)
-template <int G, typename IDX>
+// y[r, 0..2] = sum_k val[k] x[col[k], 0..2] over the non-zeros of row r; G lanes per row (4: short rows, 64: long rows).
+// The kernel streams its matrix from HBM once per call, so the matrix is kept small: 16-bit column indices when they fit and
+// 16-bit fixed-point weights with one fp32 scale per row (weight = q * scale[r], q in [0, 65535]: absolute error <= row
+// maximum / 131070 per weight, ~1e-6 of the result for the rows of hundreds of similar weights these filters have).
+template <int G, typename IDX, typename WT>
 __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
-                                                        const float* __restrict__ val, const float* __restrict__ x, float* __restrict__ y)
+                                                        const WT* __restrict__ val, const float* __restrict__ row_scale,
+                                                        const float* __restrict__ x, float* __restrict__ y)
 {
     const int gid = (blockIdx.x * 256 + threadIdx.x) / G, sub = threadIdx.x % G;
     const int r = min(gid, nrows - 1);
     const uint32_t a = row_ptr[r], b = gid < nrows ? row_ptr[r + 1] : a;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     for (uint32_t k = a + sub; k < b; k += G) {
-        const float w = val[k];
+        const float w = (float)val[k];
         const float* xv = x + 3 * (size_t)col[k];
         s0 += w * xv[0]; s1 += w * xv[1]; s2 += w * xv[2];
     }
@@ -597,7 +601,10 @@ __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_
     for (int d = G / 2; d >= 1; d >>= 1) {
         s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64);
     }
-    if (sub == 0 && gid < nrows) { y[3 * (size_t)r] = s0; y[3 * (size_t)r + 1] = s1; y[3 * (size_t)r + 2] = s2; }
+    if (sub == 0 && gid < nrows) {
+        const float sc = row_scale != nullptr ? row_scale[r] : 1.0f;
+        y[3 * (size_t)r] = s0 * sc; y[3 * (size_t)r + 1] = s1 * sc; y[3 * (size_t)r + 2] = s2 * sc;
+    }
 }
 
 // 2x2 box mip of a [6, N, N, 3] cubemap (cubemap_mip.forward, scene/light_utils.py:68-69)
@@ -750,19 +757,23 @@ int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float c
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
-int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const float* val, const float* x, float* y,
-                   int32_t lanes_per_row, void* stream)
+int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const void* val, int32_t val_bytes,
+                   const float* row_scale, const float* x, float* y, int32_t lanes_per_row, void* stream)
 {
-    if (nrows < 1 || !row_ptr || !col || !val || !x || !y || (col_bytes != 2 && col_bytes != 4)) return MRGS_E_BAD_ARG;
+    if (nrows < 1 || !row_ptr || !col || !val || !x || !y || (col_bytes != 2 && col_bytes != 4) || (val_bytes != 2 && val_bytes != 4)) return MRGS_E_BAD_ARG;
+    if (val_bytes == 2 && !row_scale) return MRGS_E_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 g64((unsigned)(((size_t)nrows * 64 + 255) / 256)), g4((unsigned)(((size_t)nrows * 4 + 255) / 256)), b(256);
-    if (lanes_per_row >= 64) {
-        if (col_bytes == 2) hipLaunchKernelGGL((csr_spmv3_kernel<64, uint16_t>), g64, b, 0, st, nrows, row_ptr, (const uint16_t*)col, val, x, y);
-        else hipLaunchKernelGGL((csr_spmv3_kernel<64, uint32_t>), g64, b, 0, st, nrows, row_ptr, (const uint32_t*)col, val, x, y);
+    const bool wide = lanes_per_row >= 64;
+    const dim3 g(wide ? (unsigned)(((size_t)nrows * 64 + 255) / 256) : (unsigned)(((size_t)nrows * 4 + 255) / 256)), b(256);
+#define SPMV(G_, IDX_, WT_) hipLaunchKernelGGL((csr_spmv3_kernel<G_, IDX_, WT_>), g, b, 0, st, nrows, row_ptr, (const IDX_*)col, (const WT_*)val, row_scale, x, y)
+    if (wide) {
+        if (col_bytes == 2) { if (val_bytes == 2) SPMV(64, uint16_t, uint16_t); else SPMV(64, uint16_t, float); }
+        else { if (val_bytes == 2) SPMV(64, uint32_t, uint16_t); else SPMV(64, uint32_t, float); }
     } else {
-        if (col_bytes == 2) hipLaunchKernelGGL((csr_spmv3_kernel<4, uint16_t>), g4, b, 0, st, nrows, row_ptr, (const uint16_t*)col, val, x, y);
-        else hipLaunchKernelGGL((csr_spmv3_kernel<4, uint32_t>), g4, b, 0, st, nrows, row_ptr, (const uint32_t*)col, val, x, y);
+        if (col_bytes == 2) { if (val_bytes == 2) SPMV(4, uint16_t, uint16_t); else SPMV(4, uint16_t, float); }
+        else { if (val_bytes == 2) SPMV(4, uint32_t, uint16_t); else SPMV(4, uint32_t, float); }
     }
+#undef SPMV
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
