@@ -24,6 +24,14 @@
 #define MRGS_FWD_STAGES 1
 #endif
 
+#ifdef MRGS_WAVE_STATS   // developer build only (tools/wave_stats.py fwd)
+__device__ unsigned long long g_wave_stats_fwd[8 * 65536];
+extern "C" int mrgs_wave_stats_fwd(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stats_fwd), sizeof(unsigned long long) * n);
+}
+#endif
+
 template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
@@ -52,6 +60,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const int pix = W * pyi + pxi;
 
     const int total = (int)(range.y - range.x);
+#ifdef MRGS_WAVE_STATS
+    const unsigned long long ws_t0 = wall_clock64(), ws_c0 = __builtin_amdgcn_s_memtime();
+    unsigned ws_blend = 0;
+#endif
     // heavy items first in line for issue slots (priority class chosen by blend_order_kernel)
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
@@ -112,6 +124,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             const bool hit = mrgs_intersect(sg, px, py, h);
             const bool ok = hit & !done;
             if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return;
+#ifdef MRGS_WAVE_STATS
+            ws_blend++;
+#endif
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
             const float test_T = T * (1.0f - h.alpha);
@@ -177,6 +192,15 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     // entries this wave tested + 3 x entries it blended: the cost of the backward wave of the same pixel block, which walks
     // the same entries (bwd_order_kernel)
     if (lane == 0) item_work[tile * 4 + quad] = work;
+#ifdef MRGS_WAVE_STATS
+    if (lane == 0 && b < 65536) {
+        unsigned long long* w = g_wave_stats_fwd + 8 * (size_t)b;
+        w[0] = ws_t0; w[1] = wall_clock64(); w[2] = __builtin_amdgcn_s_memtime() - ws_c0;
+        w[3] = ((unsigned long long)(work - 3u * ws_blend) << 32) | ws_blend; w[4] = ((unsigned long long)0 << 32) | (unsigned)total;
+        w[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+        w[6] = 0; w[7] = 0;
+    }
+#endif
     if (inside) {
         final_T[pix] = T;
         final_T[pix + HW] = M1;

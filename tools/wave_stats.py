@@ -10,6 +10,7 @@ from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera, upstream
 
 dev = torch.device('cuda:0')
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+FWD = len(sys.argv) > 2 and sys.argv[2] == 'fwd'
 sc = make_shell_scene(300000, S=S, seed=0, radius_px=7.0, image_size=800)
 cam = orbit_camera(0, 800, 800)
 L = _lib.lib()
@@ -18,7 +19,7 @@ buf = (ctypes.c_ulonglong * (8 * nb))()
 for rep in range(3):
     hr = HipRender(sc, cam, dev); torch.cuda.synchronize()
     hr.backward(*upstream_grads(S, 800, 800)); torch.cuda.synchronize()
-    L.mrgs_wave_stats(buf, ctypes.c_int(8 * nb))
+    (L.mrgs_wave_stats_fwd if FWD else L.mrgs_wave_stats)(buf, ctypes.c_int(8 * nb))
 a = np.array(buf[:], dtype=np.uint64).reshape(-1, 8)
 a = a[a[:, 1] > 0]
 a = a[a[:, 0] > a[:, 1].max() - np.uint64(500000)]   # records of the last launch only (5 ms window)
