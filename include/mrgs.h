@@ -260,6 +260,28 @@ int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const flo
                                    const float* specular, const float* bg, const float* g_render, const float* g_diffuse, float* g_base,
                                    float* g_refl, float* g_specular, float* g_alpha, void* stream);
 
+/* ---- training loss of one view (fused) ---------------------------------------------------
+ * Replaces calculate_loss (utils/loss_utils.py:142-228) = (1 - lambda_dssim) * l1_loss (:22-23) + lambda_dssim * (1 - ssim)
+ * (ssim/_ssim, 11x11 gaussian window sigma 1.5, zero padding, :83-119) + lambda_normal * normal consistency (:166-175) +
+ * lambda_dist * mean(rend_dist) (:180-182), and its autograd backward.  image / gt: [C,H,W] (C <= 4), rend_normal /
+ * surf_normal: [3,H,W], rend_dist: [H,W], image_weight: [H,W] or NULL.  With image_weight the normal term is
+ * mean(image_weight * sum_c |surf - rend|), without it mean(1 - sum_c rend * surf); lambda_normal <= 0 / lambda_dist <= 0
+ * switch the terms off (the iteration gates of the reference are the caller's business; the pointers may then be NULL).
+ * ws (mrgs_loss_ws_bytes) carries the SSIM derivative maps from forward to backward.
+ * out_terms[16] (device): [0] loss, [1] Ll1, [2] ssim, [3] loss0, [4] normal term (unscaled mean), [5] lambda_dist * mean(dist),
+ * [6] psnr (utils/image_utils.py psnr, mean over channels), [7..7+C) per-channel mse.  Sums are reduced in a fixed order.
+ * g_loss: device scalar dL/dloss (NULL = 1).  Gradients are written in full (no pre-zeroing by the caller). */
+typedef struct MrgsLossConfig {
+    int32_t H, W, C;
+    float lambda_dssim, lambda_normal, lambda_dist;
+} MrgsLossConfig;
+size_t mrgs_loss_ws_bytes(int32_t H, int32_t W, int32_t C);
+int mrgs_loss_forward(const MrgsLossConfig* cfg, const float* image, const float* gt, const float* rend_normal, const float* surf_normal,
+                      const float* rend_dist, const float* image_weight, void* ws, size_t ws_bytes, float* out_terms, void* stream);
+int mrgs_loss_backward(const MrgsLossConfig* cfg, const float* image, const float* gt, const float* rend_normal, const float* surf_normal,
+                       const float* image_weight, const void* ws, const float* g_loss, float* g_image, float* g_rend_normal,
+                       float* g_surf_normal, float* g_rend_dist, void* stream);
+
 /* View-parallel training (materialrefgs_amd/dist.py): sum over V views of the SH colour gradients from each view's masked colour
  * gradient dRGB_v = dL/dsh_v[:,0,:] / SH_C0 and camera centre: dL_dsh[p][k][c] = sum_v B_k(normalize(means3D[p] - campos_v)) dRGB_v[p][c]
  * for k < (D+1)^2, 0 beyond (backward.cu:22-141).  gathered = V rows of row_stride floats, row v = [dRGB_v (P x 3) | campos_v (3)]

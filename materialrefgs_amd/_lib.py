@@ -66,6 +66,11 @@ class MrgsMapsFrame(ctypes.Structure):
                 ("depth_ratio", c_float)]
 
 
+class MrgsLossConfig(ctypes.Structure):
+    _fields_ = [("H", c_int32), ("W", c_int32), ("C", c_int32), ("lambda_dssim", c_float), ("lambda_normal", c_float),
+                ("lambda_dist", c_float)]
+
+
 class MrgsKernelTimes(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
                                        "preprocess_bwd_ms")]
@@ -103,6 +108,11 @@ SYMBOLS = {
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_mip_backward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_loss_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "mrgs_loss_forward": (ctypes.c_int, [ctypes.POINTER(MrgsLossConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mrgs_loss_backward": (ctypes.c_int, [ctypes.POINTER(MrgsLossConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
