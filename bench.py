@@ -31,7 +31,12 @@ WORKLOADS = {
     # BASELINE.json configs[2]: the full render_surfel path = per-gaussian material features -> rasterizer (S=8) -> 2DGS map
     # post-processing -> deferred split-sum shading (FG LUT + 5-level 128^2 cubemap) -> compositing, forward and backward
     "C3full": (300000, 800, 800, 8, "C3 shell scene through render_surfel: P=300000, 800x800, S=8 + deferred BRDF shading, fwd+bwd"),
-    # raster part of BASELINE.json configs[3] (the traced reflection integral needs the BVH tracer)
+    # C3full with the reference's per-view loss (calculate_loss: L1 + SSIM + normal consistency + distortion) producing the upstream
+    # gradients instead of constants: one training view without the optimizer step
+    "C3train": (300000, 800, 800, 8, "C3 shell scene: render_surfel + calculate_loss, P=300000, 800x800, S=8, fwd+bwd"),
+    # BASELINE.json configs[3]: render_surfel with opt.indirect: visibility (mirror) rays of all H*W pixels against a ~1 M triangle mesh
+    "C4full": (1000000, 1600, 1600, 8, "C4 shell scene: render_surfel + visibility rays vs a 1 M triangle mesh + calculate_loss, P=1000000, 1600x1600, S=8, fwd+bwd"),
+    # raster part of BASELINE.json configs[3]
     "C4raster": (1000000, 1600, 1600, 8, "C4-size shell scene: P=1000000 surfels, 1600x1600, SH deg 3, S=8 material channels, raster fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
 }
@@ -88,7 +93,9 @@ def main():
             debug=False))
     g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
 
-    surfel_mode = args.workload == "C3full"
+    surfel_mode = args.workload in ("C3full", "C3train", "C4full")
+    use_loss = args.workload in ("C3train", "C4full")
+    indirect = args.workload == "C4full"
     if surfel_mode:
         from types import SimpleNamespace
         from materialrefgs_amd.renderer import SurfelModel, render_surfel
@@ -109,6 +116,19 @@ def main():
         pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
         bg_color = torch.zeros(3, device=dev)
         cams_dev = [c.to(dev) for c in cams]
+        if indirect:
+            from materialrefgs_amd.raytracing import RayTracer
+            from materialrefgs_amd.synthetic import make_occluder_mesh
+            pc.ray_tracer = RayTracer(*make_occluder_mesh(1_000_000), device=dev)
+        if use_loss:
+            from materialrefgs_amd import losses
+            gt_cams = []            # synthetic ground truth + its edge weight, once per camera (train_refnerf.py:1176-1179)
+            for _c in cams_dev:
+                gt = torch.rand(3, H, W, generator=gen).to(dev)
+                gt_cams.append(SimpleNamespace(original_image=gt, image_weight=losses.image_weight(gt)))
+            loss_opt = SimpleNamespace(lambda_dssim=0.2, lambda_normal_render_depth=0.05, normal_loss_start=0, lambda_dist=100.0,
+                                       dist_loss_start=3000, lambda_normal_smooth=0.0, lambda_depth_smooth=0.0,
+                                       normal_smooth_from_iter=0, normal_smooth_until_iter=18000, use_perceptual_loss=False)
     params = {"means3D": scene.means3D, "opacity": scene.opacities, "scales": scene.scales, "rotations": scene.rotations,
               "sh": scene.shs}
     if S > 0:
@@ -129,8 +149,14 @@ def main():
         for t_ in surfel_params:
             t_.grad = None
         env.build_mips()                                       # every iteration in the reference (train_refnerf.py:1157-1163)
-        out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
+        out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect))
         state["R"] = rasterizer_mod.LAST_NUM_RENDERED
+        if use_loss:
+            loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)
+            loss.backward()
+            if world > 1:
+                mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])
+            return
         # the maps calculate_loss consumes (utils/loss_utils.py:147-152,166), with fixed upstream gradients
         outs = [out["render"], out["rend_alpha"], out["rend_normal"], out["rend_dist"], out["surf_depth"], out["surf_normal"]]
         if "g" not in state:   # constant upstream gradients, built once (a loss would produce them in training)
@@ -166,6 +192,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    # Host-loop hygiene: after `import torch` the interpreter tracks ~170k container objects, and a full cyclic-GC pass over them
+    # costs ~40 ms; the per-view Python glue allocates enough containers to trigger one every few dozen views.  Moving the
+    # start-up objects to the permanent generation keeps collections proportional to what a view allocates.
+    import gc
+    gc.collect()
+    gc.freeze()
     L.mrgs_set_profiling(2)      # HIP events around the two blend kernels only (the dominant one feeds `roofline`)
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -270,6 +270,7 @@ int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const flo
  * ws (mrgs_loss_ws_bytes) carries the SSIM derivative maps from forward to backward.
  * out_terms[16] (device): [0] loss, [1] Ll1, [2] ssim, [3] loss0, [4] normal term (unscaled mean), [5] lambda_dist * mean(dist),
  * [6] psnr (utils/image_utils.py psnr, mean over channels), [7..7+C) per-channel mse.  Sums are reduced in a fixed order.
+ * out_loss (device scalar, may be NULL) receives the loss as well: a host binding can hand it out as its own tensor.
  * g_loss: device scalar dL/dloss (NULL = 1).  Gradients are written in full (no pre-zeroing by the caller). */
 typedef struct MrgsLossConfig {
     int32_t H, W, C;
@@ -277,10 +278,33 @@ typedef struct MrgsLossConfig {
 } MrgsLossConfig;
 size_t mrgs_loss_ws_bytes(int32_t H, int32_t W, int32_t C);
 int mrgs_loss_forward(const MrgsLossConfig* cfg, const float* image, const float* gt, const float* rend_normal, const float* surf_normal,
-                      const float* rend_dist, const float* image_weight, void* ws, size_t ws_bytes, float* out_terms, void* stream);
+                      const float* rend_dist, const float* image_weight, void* ws, size_t ws_bytes, float* out_terms, float* out_loss,
+                      void* stream);
 int mrgs_loss_backward(const MrgsLossConfig* cfg, const float* image, const float* gt, const float* rend_normal, const float* surf_normal,
                        const float* image_weight, const void* ws, const float* g_loss, float* g_image, float* g_rend_normal,
                        float* g_surf_normal, float* g_rend_dist, void* stream);
+
+/* ---- closest-hit ray queries against a triangle mesh (visibility rays) --------------------
+ * Replaces RayTracer(vertices, triangles).trace (submodules/raytracing/raytracing/raytracer.py:8-56,
+ * raytracing_brdf/raytracer.py:18-123) = create_raytracer + TriangleBvh4::build / ray_trace_gpu
+ * (submodules/raytracing/src/raytracer.cu:20-53, bvh.cu:259-302,526-609,694-720) with Triangle::ray_intersect
+ * (include/raytracing/triangle.cuh:27-45): back faces are ignored, hits need 0 <= t < 10, depth = 10 marks a miss.
+ * mrgs_bvh_build runs on the HOST (as the reference's build does): vertices [n_vertices,3] f32 and triangles [n_triangles,3] i32
+ * are host arrays, the hierarchy is written into blob_host (mrgs_bvh_bytes, position independent); the caller copies the blob
+ * to the device once per mesh.  mrgs_bvh_trace: all pointers are device pointers; rays_o / rays_d [n_rays,3], outputs
+ * positions / normals [n_rays,3] (may alias rays_o / rays_d: the reference's inplace mode), depth [n_rays], face_ids [n_rays]
+ * (index into `triangles`, -1 for a miss; may be NULL). */
+size_t mrgs_bvh_bytes(int64_t n_triangles);
+int mrgs_bvh_build(const float* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles, void* blob_host,
+                   size_t blob_bytes);
+int mrgs_bvh_trace(const void* blob_dev, int64_t n_triangles, int64_t n_rays, const float* rays_o, const float* rays_d, float* positions,
+                   float* normals, float* depth, int32_t* face_ids, void* stream);
+/* The visibility block of get_specular_color_surfel (utils/refl_utils.py:379-391) in one launch: per pixel with alpha > 0 the mirror
+ * ray of the view direction about `normal` ([H,W,3]) is started at rays_o + surf_depth * rays_cam (un-normalised pixel ray,
+ * sample_camera_rays_unnormalize :75-93; Kinv = host inverse intrinsics, R / T = device Camera.R / Camera.T as in MrgsShadeFrame)
+ * and visibility[H,W] = 1 if nothing is hit within 10 units (or alpha <= 0), else 0.  No ray buffers, no mask compaction. */
+int mrgs_bvh_visibility(const void* blob_dev, int64_t n_triangles, int32_t H, int32_t W, const float* Kinv, const float* R, const float* T,
+                        const MrgsStridedMap* normal, const MrgsStridedMap* alpha, const float* surf_depth, float* visibility, void* stream);
 
 /* View-parallel training (materialrefgs_amd/dist.py): sum over V views of the SH colour gradients from each view's masked colour
  * gradient dRGB_v = dL/dsh_v[:,0,:] / SH_C0 and camera centre: dL_dsh[p][k][c] = sum_v B_k(normalize(means3D[p] - campos_v)) dRGB_v[p][c]

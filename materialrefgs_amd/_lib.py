@@ -110,9 +110,14 @@ SYMBOLS = {
     "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_loss_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mrgs_loss_forward": (ctypes.c_int, [ctypes.POINTER(MrgsLossConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_size_t, c_void_p, c_void_p]),
+                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mrgs_loss_backward": (ctypes.c_int, [ctypes.POINTER(MrgsLossConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_bvh_bytes": (c_size_t, [c_int64]),
+    "mrgs_bvh_build": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_size_t]),
+    "mrgs_bvh_trace": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_bvh_visibility": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p,
+                                           ctypes.POINTER(MrgsStridedMap), ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p]),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, const float* 
 // out[0] loss, [1] Ll1, [2] ssim, [3] loss0, [4] normal term (mean, unscaled), [5] lambda_dist * mean(rend_dist), [6] psnr,
 // [7..7+C) per-channel mse
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(LossArgs a, const float* __restrict__ partials, int blocks_per_channel,
-                                                             float* __restrict__ out)
+                                                             float* __restrict__ out, float* __restrict__ out_loss)
 {
     __shared__ double red[16][8];
     const int tid = threadIdx.x, C = a.C < 4 ? a.C : 4;
@@ -162,6 +162,8 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(LossArgs a, const f
             out[7 + k] = mse;
             ps += 20.f * log10f(1.f / sqrtf(mse));
         }
+        for (int k = 7 + C; k < 16; ++k) out[k] = 0.f;
+        if (out_loss) out_loss[0] = loss;
         out[0] = loss; out[1] = Ll1; out[2] = ssim; out[3] = loss0; out[4] = nrm; out[5] = dst; out[6] = ps / (float)C;
     }
 }
@@ -278,7 +280,7 @@ extern "C" size_t mrgs_loss_ws_bytes(int32_t H, int32_t W, int32_t C)
 
 extern "C" int mrgs_loss_forward(const MrgsLossConfig* cfg, const float* image, const float* gt, const float* rend_normal,
                                  const float* surf_normal, const float* rend_dist, const float* image_weight, void* ws,
-                                 size_t ws_bytes, float* out_terms, void* stream)
+                                 size_t ws_bytes, float* out_terms, float* out_loss, void* stream)
 {
     LossArgs a;
     const int rc = make_args(cfg, image_weight != nullptr, a);
@@ -292,7 +294,7 @@ extern "C" int mrgs_loss_forward(const MrgsLossConfig* cfg, const float* image, 
     const dim3 grid = loss_grid(a);
     hipStream_t st = (hipStream_t)stream;
     loss_fwd_kernel<<<grid, 256, 0, st>>>(a, image, gt, rend_normal, surf_normal, rend_dist, image_weight, dmaps, partials);
-    loss_finalize_kernel<<<1, 1024, 0, st>>>(a, partials, (int)(grid.x * grid.y), out_terms);
+    loss_finalize_kernel<<<1, 1024, 0, st>>>(a, partials, (int)(grid.x * grid.y), out_terms, out_loss);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -47,16 +47,18 @@ class _FusedLoss(torch.autograd.Function):
         with torch.cuda.device(image.device):
             ws = torch.empty(lib.mrgs_loss_ws_bytes(H, W, C), dtype=torch.uint8, device=image.device)
             terms = torch.empty(16, dtype=torch.float32, device=image.device)
+            loss = torch.empty((), dtype=torch.float32, device=image.device)   # its own tensor: a view of `terms` as a second output
+            #                                                                    ties both outputs into a cycle only the GC can free
             st = ctypes.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)
             _lib.check(lib.mrgs_loss_forward(ctypes.byref(cfg), _p(img), _p(g), _p(rn), _p(sn), _p(rd), _p(wt), _p(ws), ws.numel(),
-                                             _p(terms), st))
+                                             _p(terms), _p(loss), st))
         ctx.cfg = cfg
         ctx.shapes = (image.shape, None if rend_normal is None else rend_normal.shape, None if surf_normal is None else surf_normal.shape,
                       None if rend_dist is None else rend_dist.shape)
         ctx.use = (use_n, use_d)
         ctx.save_for_backward(img, g, rn, sn, wt, ws)
         ctx.mark_non_differentiable(terms)
-        return terms[0], terms
+        return loss, terms
 
     @staticmethod
     def backward(ctx, g_loss, _g_terms):

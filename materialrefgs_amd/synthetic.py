@@ -84,3 +84,36 @@ def upstream_grads(S: int, H: int, W: int, device=None):
     g_others = torch.full((7, H, W), 0.1, device=device)
     g_others[5] = 0.0
     return g_color, g_feat, g_others
+
+
+def sphere_mesh(n_lat: int, n_lon: int, radius: float = 1.0, bumps: float = 0.0, seed: int = 0, centre=(0.0, 0.0, 0.0)):
+    """Outward-facing triangulated sphere (open at the poles), optional radial noise: (vertices f32 [V,3], triangles i32 [2 n_lat n_lon, 3])."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0.02, np.pi - 0.02, n_lat + 1)
+    ph = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
+    T, Ph = np.meshgrid(th, ph, indexing="ij")
+    r = radius * (1 + bumps * rng.standard_normal(T.shape))
+    v = np.stack([r * np.sin(T) * np.cos(Ph), r * np.sin(T) * np.sin(Ph), r * np.cos(T)], -1).reshape(-1, 3)
+    v = (v + np.asarray(centre)[None]).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n_lat), np.arange(n_lon), indexing="ij")
+    a, b = i * n_lon + j, i * n_lon + (j + 1) % n_lon
+    c, d = (i + 1) * n_lon + j, (i + 1) * n_lon + (j + 1) % n_lon
+    tri = np.stack([np.stack([a, c, b], -1), np.stack([b, c, d], -1)], axis=2).reshape(-1, 3)
+    return v, tri.astype(np.int32)
+
+
+def make_occluder_mesh(n_triangles: int = 1_000_000, seed: int = 0):
+    """Mesh for the visibility rays of the shell scene (BASELINE config 4: ~1 M triangles): a sphere just inside the surfel shell
+    (60 % of the triangles) and six satellite spheres that block part of the mirror directions."""
+    n_main = int(0.6 * n_triangles)
+    lat = max(3, int(round(math.sqrt(n_main / 4.0))))
+    vs, ts = [], []
+    v, t = sphere_mesh(lat, 2 * lat, 0.93, 0.005, seed)
+    vs.append(v); ts.append(t)
+    lat_s = max(3, int(round(math.sqrt((n_triangles - len(t)) / 6.0 / 4.0))))
+    off = len(v)
+    for k, c in enumerate([(2.2, 0, 0), (-2.2, 0, 0), (0, 2.2, 0), (0, -2.2, 0), (0, 0, 2.2), (0, 0, -2.2)]):
+        v, t = sphere_mesh(lat_s, 2 * lat_s, 0.8, 0.005, seed + 1 + k, centre=c)
+        vs.append(v); ts.append(t + off)
+        off += len(v)
+    return np.concatenate(vs), np.concatenate(ts)
