@@ -33,9 +33,9 @@ WORKLOADS = {
     "C3full": (300000, 800, 800, 8, "C3 shell scene through render_surfel: P=300000, 800x800, S=8 + deferred BRDF shading, fwd+bwd"),
     # C3full with the reference's per-view loss (calculate_loss: L1 + SSIM + normal consistency + distortion) producing the upstream
     # gradients instead of constants: one training view without the optimizer step
-    "C3train": (300000, 800, 800, 8, "C3 shell scene: render_surfel + calculate_loss, P=300000, 800x800, S=8, fwd+bwd"),
+    "C3train": (300000, 800, 800, 8, "C3 shell scene: render_surfel + calculate_loss + Adam step, P=300000, 800x800, S=8, one full training view"),
     # BASELINE.json configs[3]: render_surfel with opt.indirect: visibility (mirror) rays of all H*W pixels against a ~1 M triangle mesh
-    "C4full": (1000000, 1600, 1600, 8, "C4 shell scene: render_surfel + visibility rays vs a 1 M triangle mesh + calculate_loss, P=1000000, 1600x1600, S=8, fwd+bwd"),
+    "C4full": (1000000, 1600, 1600, 8, "C4 shell scene: render_surfel + visibility rays vs a 1 M triangle mesh + calculate_loss + Adam step, P=1000000, 1600x1600, S=8, one full training view"),
     # raster part of BASELINE.json configs[3]
     "C4raster": (1000000, 1600, 1600, 8, "C4-size shell scene: P=1000000 surfels, 1600x1600, SH deg 3, S=8 material channels, raster fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
@@ -126,6 +126,11 @@ def main():
             for _c in cams_dev:
                 gt = torch.rand(3, H, W, generator=gen).to(dev)
                 gt_cams.append(SimpleNamespace(original_image=gt, image_weight=losses.image_weight(gt)))
+            from materialrefgs_amd.optim import Adam
+            # learning rates of GaussianModel.training_setup (scene/gaussian_model.py:422-443, arguments/__init__.py defaults)
+            # (one group per tensor as there; the rate is kept tiny so that the synthetic scene stays the benchmark's scene --
+            # the work of an Adam step does not depend on it)
+            optimizer = Adam([{"params": [t_], "lr": 1e-6} for t_ in surfel_params], lr=0.0, eps=1e-15)
             loss_opt = SimpleNamespace(lambda_dssim=0.2, lambda_normal_render_depth=0.05, normal_loss_start=0, lambda_dist=100.0,
                                        dist_loss_start=3000, lambda_normal_smooth=0.0, lambda_depth_smooth=0.0,
                                        normal_smooth_from_iter=0, normal_smooth_until_iter=18000, use_perceptual_loss=False)
@@ -155,7 +160,9 @@ def main():
             loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)
             loss.backward()
             if world > 1:
-                mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])
+                for t_, g_ in zip(surfel_params, mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])):
+                    t_.grad = g_
+            optimizer.step()
             return
         # the maps calculate_loss consumes (utils/loss_utils.py:147-152,166), with fixed upstream gradients
         outs = [out["render"], out["rend_alpha"], out["rend_normal"], out["rend_dist"], out["surf_depth"], out["surf_normal"]]

@@ -306,6 +306,25 @@ int mrgs_bvh_trace(const void* blob_dev, int64_t n_triangles, int64_t n_rays, co
 int mrgs_bvh_visibility(const void* blob_dev, int64_t n_triangles, int32_t H, int32_t W, const float* Kinv, const float* R, const float* T,
                         const MrgsStridedMap* normal, const MrgsStridedMap* alpha, const float* surf_depth, float* visibility, void* stream);
 
+/* ---- optimizer step -------------------------------------------------------------------------
+ * torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of GaussianModel.training_setup (scene/gaussian_model.py:417-453) for every
+ * parameter tensor in one launch (per MRGS_ADAM_MAX_TENSORS tensors): amsgrad off, no weight decay.  `tensors` is a HOST array;
+ * param / grad / exp_avg / exp_avg_sq are device pointers to `numel` contiguous fp32 values (updated in place, grad read only),
+ * lr the group's learning rate, step the 1-based count of this update for this tensor (torch keeps one per parameter).
+ * beta1 / beta2 / eps are doubles like torch's python scalars: 1 - beta and the bias corrections are formed in double and
+ * rounded to fp32 where torch rounds them. */
+#define MRGS_ADAM_MAX_TENSORS 32
+typedef struct MrgsAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    float lr;
+    int32_t step;
+} MrgsAdamTensor;
+int mrgs_adam_step(const MrgsAdamTensor* tensors, int32_t n_tensors, double beta1, double beta2, double eps, void* stream);
+
 /* View-parallel training (materialrefgs_amd/dist.py): sum over V views of the SH colour gradients from each view's masked colour
  * gradient dRGB_v = dL/dsh_v[:,0,:] / SH_C0 and camera centre: dL_dsh[p][k][c] = sum_v B_k(normalize(means3D[p] - campos_v)) dRGB_v[p][c]
  * for k < (D+1)^2, 0 beyond (backward.cu:22-141).  gathered = V rows of row_stride floats, row v = [dRGB_v (P x 3) | campos_v (3)]

@@ -71,6 +71,11 @@ class MrgsLossConfig(ctypes.Structure):
                 ("lambda_dist", c_float)]
 
 
+class MrgsAdamTensor(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("numel", c_int64),
+                ("lr", c_float), ("step", c_int32)]
+
+
 class MrgsKernelTimes(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
                                        "preprocess_bwd_ms")]
@@ -118,6 +123,7 @@ SYMBOLS = {
     "mrgs_bvh_trace": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_bvh_visibility": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p,
                                            ctypes.POINTER(MrgsStridedMap), ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p]),
+    "mrgs_adam_step": (ctypes.c_int, [ctypes.POINTER(MrgsAdamTensor), c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
