@@ -1,0 +1,65 @@
+"""PLY layout of GaussianModel.save_ply / load_ply (scene/gaussian_model.py:462-529, 725-838)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from materialrefgs_amd import io as mio  # noqa: E402
+
+
+def _model(P=7, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)   # noqa: E731
+    return {"xyz": r(P, 3), "normal1": r(P, 3), "normal2": r(P, 3), "features_dc": r(P, 1, 3), "features_rest": r(P, 15, 3),
+            "indirect_dc": r(P, 1, 3), "indirect_rest": r(P, 15, 3), "indirect_asg": r(P, 32, 5), "opacity": r(P, 1),
+            "refl_strength": r(P, 1), "metalness": r(P, 1), "roughness": r(P, 1), "ori_color": r(P, 3), "diffuse_color": r(P, 3),
+            "scaling": r(P, 2), "rotation": r(P, 4)}
+
+
+def test_attribute_order_is_the_reference_order():
+    m = _model()
+    names = mio.attribute_names({k: tuple(v.shape) for k, v in m.items()})
+    want = (["x", "y", "z", "nx", "ny", "nz", "nx2", "ny2", "nz2"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)] +
+            [f"ind_dc_{i}" for i in range(3)] + [f"ind_rest_{i}" for i in range(45)] + [f"ind_asg_{i}" for i in range(160)] +
+            ["opacity", "refl_strength", "metalness", "roughness"] + [f"ori_color_{i}" for i in range(3)] +
+            [f"diffuse_color_{i}" for i in range(3)] + [f"scale_{i}" for i in range(2)] + [f"rot_{i}" for i in range(4)])
+    assert names == want and len(names) == 281
+
+
+def test_ply_round_trip_and_byte_layout(tmp_path):
+    m = _model(11, 3)
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    mio.save_ply(path, m)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().split("\n")
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0" and lines[2] == "element vertex 11"
+    assert lines[3] == "property float x" and lines[-2] == "property float rot_3"
+    rows = np.frombuffer(body, dtype="<f4").reshape(11, 281)
+    np.testing.assert_array_equal(rows[:, 0:3], m["xyz"].numpy())
+    # SH coefficients are written channel-major: f_rest_k = features_rest[:, k % 15, k // 15]  (transpose(1, 2).flatten, :494)
+    np.testing.assert_array_equal(rows[:, 12 + 16], m["features_rest"][:, 1, 1].numpy())
+    np.testing.assert_array_equal(rows[:, 9 + 3 + 45 + 3 + 45 + 7], m["indirect_asg"][:, 7, 0].numpy())
+    back = mio.load_ply(path)
+    assert set(back) == set(m)
+    for k in m:
+        assert back[k].shape == m[k].shape, k
+        torch.testing.assert_close(back[k], m[k], rtol=0, atol=0)
+
+
+def test_env_map_files_round_trip(tmp_path):
+    class Env(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.base = torch.nn.Parameter(torch.randn(6, 8, 8, 3))
+    e1, e2 = Env(), Env()
+    path = str(tmp_path / "point_cloud.ply")
+    mio.save_ply(path, _model(), env_map=e1, env_map_2=e2)
+    assert os.path.exists(str(tmp_path / "point_cloud1.map")) and os.path.exists(str(tmp_path / "point_cloud2.map"))
+    f1, f2 = Env(), Env()
+    mio.load_env_maps(path, f1, f2)
+    torch.testing.assert_close(f1.base, e1.base, rtol=0, atol=0)
+    torch.testing.assert_close(f2.base, e2.base, rtol=0, atol=0)
