@@ -200,6 +200,17 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
 int mrgs_cubemap_mip_forward(int32_t res_out, const float* in, float* out, void* stream);
 int mrgs_cubemap_mip_backward(int32_t res_fine, const float* dout, float* g_fine, void* stream);
 
+/* Visibility blend of get_specular_color_surfel (utils/refl_utils.py:393-401), one pass each way:
+ * specular = (direct * vis + (1 - vis) * indirect) * alpha * weight, indirect_color = (1 - vis) * indirect * alpha * weight.
+ * direct / specular / indirect_color [3,H,W], weight [H,W,3] (layouts of mrgs_shade_specular_forward), indirect [H,W,3] and alpha
+ * [H,W,1] strided maps, visibility [H,W] (constant).  Backward writes g_direct [3,H,W], g_weight [H,W,3], g_indirect [H,W,3],
+ * g_alpha [H,W] in full; either upstream gradient may be NULL. */
+int mrgs_indirect_blend_forward(int32_t H, int32_t W, const float* direct, const float* weight, const MrgsStridedMap* indirect,
+                                const MrgsStridedMap* alpha, const float* visibility, float* specular, float* indirect_color, void* stream);
+int mrgs_indirect_blend_backward(int32_t H, int32_t W, const float* direct, const float* weight, const MrgsStridedMap* indirect,
+                                 const MrgsStridedMap* alpha, const float* visibility, const float* g_specular, const float* g_indirect_color,
+                                 float* g_direct, float* g_weight, float* g_indirect, float* g_alpha, void* stream);
+
 /* g_features[8,H,W] of render_surfel's material map (refl, roughness, albedo[3], indirect[3] = 0) assembled from the outputs of
  * mrgs_surfel_composite_backward (g_refl) and mrgs_shade_specular_backward (g_refl, g_roughness [H,W]; g_albedo [H,W,3]). */
 int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,

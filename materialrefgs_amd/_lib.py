@@ -124,6 +124,11 @@ SYMBOLS = {
     "mrgs_bvh_visibility": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p,
                                            ctypes.POINTER(MrgsStridedMap), ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p]),
     "mrgs_adam_step": (ctypes.c_int, [ctypes.POINTER(MrgsAdamTensor), c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
+    "mrgs_indirect_blend_forward": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap),
+                                                   ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_indirect_blend_backward": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap),
+                                                    ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p]),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

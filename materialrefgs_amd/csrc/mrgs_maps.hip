@@ -293,6 +293,54 @@ MapsFrameDev to_dev(const MrgsMapsFrame* fr)
     return f;
 }
 
+// Visibility blend of get_specular_color_surfel (utils/refl_utils.py:393-401): specular_light = direct * vis + (1 - vis) * indirect,
+// specular = specular_light * alpha * weight, indirect_color = (1 - vis) * indirect * alpha * weight.  direct / specular /
+// indirect_color are [3,H,W], weight [H,W,3] (the shading kernel's layouts), indirect and alpha arbitrary-stride maps, vis [H,W].
+struct BlendMap { const float* p; long long sh, sw, sc; };
+__global__ void __launch_bounds__(256) indirect_blend_fwd_kernel(int H, int W, const float* __restrict__ direct, const float* __restrict__ weight,
+                                                                 BlendMap indirect, BlendMap alpha, const float* __restrict__ vis,
+                                                                 float* __restrict__ specular, float* __restrict__ indirect_color)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x, HW = H * W;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix - y * W;
+    const float v = vis[pix], a = alpha.p[y * alpha.sh + x * alpha.sw];
+    const long long oi = y * indirect.sh + x * indirect.sw;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float i = indirect.p[oi + c * indirect.sc], w = weight[pix * 3 + c];
+        const float L = direct[c * HW + pix] * v + (1.0f - v) * i;
+        specular[c * HW + pix] = L * a * w;
+        indirect_color[c * HW + pix] = (1.0f - v) * i * a * w;
+    }
+}
+
+__global__ void __launch_bounds__(256) indirect_blend_bwd_kernel(int H, int W, const float* __restrict__ direct, const float* __restrict__ weight,
+                                                                 BlendMap indirect, BlendMap alpha, const float* __restrict__ vis,
+                                                                 const float* __restrict__ g_spec, const float* __restrict__ g_ic,
+                                                                 float* __restrict__ g_direct /*[3,H,W]*/, float* __restrict__ g_weight /*[H,W,3]*/,
+                                                                 float* __restrict__ g_indirect /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x, HW = H * W;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix - y * W;
+    const float v = vis[pix], a = alpha.p[y * alpha.sh + x * alpha.sw];
+    const long long oi = y * indirect.sh + x * indirect.sw;
+    float ga = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float i = indirect.p[oi + c * indirect.sc], w = weight[pix * 3 + c];
+        const float L = direct[c * HW + pix] * v + (1.0f - v) * i;
+        const float gs = g_spec ? g_spec[c * HW + pix] : 0.0f, gi = g_ic ? g_ic[c * HW + pix] : 0.0f;
+        const float ic_aw = (1.0f - v) * i;                       // indirect_color / (a w)
+        g_direct[c * HW + pix] = gs * a * w * v;
+        g_indirect[pix * 3 + c] = (gs + gi) * (1.0f - v) * a * w;
+        g_weight[pix * 3 + c] = gs * L * a + gi * ic_aw * a;
+        ga += gs * L * w + gi * ic_aw * w;
+    }
+    g_alpha[pix] = ga;
+}
+
 }   // namespace
 
 extern "C" {
@@ -337,6 +385,32 @@ int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const flo
     const int HW = H * W;
     hipLaunchKernelGGL(surfel_composite_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, srgb, base_color,
                        refl_strength, specular, bg, g_render, g_diffuse, g_base, g_refl, g_specular, g_alpha);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_indirect_blend_forward(int32_t H, int32_t W, const float* direct, const float* weight, const MrgsStridedMap* indirect,
+                                const MrgsStridedMap* alpha, const float* visibility, float* specular, float* indirect_color, void* stream)
+{
+    if (H <= 0 || W <= 0 || !direct || !weight || !indirect || !alpha || !indirect->ptr || !alpha->ptr || !visibility || !specular || !indirect_color)
+        return MRGS_E_BAD_ARG;
+    const BlendMap mi = {indirect->ptr, (long long)indirect->stride_h, (long long)indirect->stride_w, (long long)indirect->stride_c};
+    const BlendMap ma = {alpha->ptr, (long long)alpha->stride_h, (long long)alpha->stride_w, (long long)alpha->stride_c};
+    hipLaunchKernelGGL(indirect_blend_fwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, direct, weight, mi, ma,
+                       visibility, specular, indirect_color);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_indirect_blend_backward(int32_t H, int32_t W, const float* direct, const float* weight, const MrgsStridedMap* indirect,
+                                 const MrgsStridedMap* alpha, const float* visibility, const float* g_specular, const float* g_indirect_color,
+                                 float* g_direct, float* g_weight, float* g_indirect, float* g_alpha, void* stream)
+{
+    if (H <= 0 || W <= 0 || !direct || !weight || !indirect || !alpha || !indirect->ptr || !alpha->ptr || !visibility || !g_direct || !g_weight ||
+        !g_indirect || !g_alpha)
+        return MRGS_E_BAD_ARG;
+    const BlendMap mi = {indirect->ptr, (long long)indirect->stride_h, (long long)indirect->stride_w, (long long)indirect->stride_c};
+    const BlendMap ma = {alpha->ptr, (long long)alpha->stride_h, (long long)alpha->stride_w, (long long)alpha->stride_c};
+    hipLaunchKernelGGL(indirect_blend_bwd_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, direct, weight, mi, ma,
+                       visibility, g_specular, g_indirect_color, g_direct, g_weight, g_indirect, g_alpha);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -332,14 +332,12 @@ def _render_surfel_indirect(viewpoint_camera, pc, bg_color, srgb, base_color, re
         pc.get_envmap, albedo.permute(1, 2, 0), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, normal_map,
         render_alpha.permute(1, 2, 0), refl_strength=refl_strength.permute(1, 2, 0), roughness=roughness_map.permute(1, 2, 0), pc=pc,
         surf_depth=surf_depth, indirect_light=indirect_light.permute(1, 2, 0))
-    diffuse_map = (1 - refl_strength) * base_color
-    final_image = diffuse_map + specular
+    # (1 - refl) * base + specular, optional sRGB, background (:436-445): the composite kernel of the direct branch
+    final_image, diffuse_map = _SurfelComposite.apply(base_color, refl_strength, specular, render_alpha, bg_color, srgb)
     if srgb:
-        final_image, albedo, specular = linear_to_srgb(final_image), linear_to_srgb(albedo), linear_to_srgb(specular)
-    background = bg_color[:, None, None] * (1 - render_alpha)
-    final_image = final_image + background
+        albedo, specular = linear_to_srgb(albedo), linear_to_srgb(specular)
     extra = dict(extra)
-    extra["indirect_color"] = diffuse_map + extra["indirect_color"] + background
+    extra["indirect_color"] = diffuse_map + extra["indirect_color"] + bg_color[:, None, None] * (1 - render_alpha)
     return {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": diffuse_map, "diffuse_map_ori": base_color,
             "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo, **extra}
 

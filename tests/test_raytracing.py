@@ -313,3 +313,28 @@ def test_render_surfel_indirect_branch():
     out["render"].mean().backward()
     assert pc._indirect_dc.grad is not None and float(pc._indirect_dc.grad.abs().sum()) > 0
     assert env.base.grad is not None and torch.isfinite(env.base.grad).all()
+
+
+@pytest.mark.gpu
+def test_indirect_blend_kernel_matches_torch_ops():
+    """mrgs_indirect_blend_* against the reference's expressions (utils/refl_utils.py:393-401) evaluated with torch autograd."""
+    from materialrefgs_amd.shading import _IndirectBlend
+    H, W = 37, 53
+    g = torch.Generator(device="cuda").manual_seed(4)
+    r = lambda *s: torch.rand(*s, device="cuda", generator=g)   # noqa: E731
+    direct, weight = r(3, H, W).requires_grad_(True), r(H, W, 3).requires_grad_(True)
+    feat = r(8, H, W).requires_grad_(True)
+    alpha_chw = r(1, H, W).requires_grad_(True)
+    vis = (r(H, W, 1) > 0.4).float()
+    indirect, alpha = feat[5:8].permute(1, 2, 0), alpha_chw.permute(1, 2, 0)            # strided views, as render_surfel passes them
+    spec, ic = _IndirectBlend.apply(direct, weight, indirect, alpha, vis)
+    light = direct.permute(1, 2, 0) * vis + (1 - vis) * indirect
+    spec_ref = (light * alpha * weight).permute(2, 0, 1)
+    ic_ref = ((1 - vis) * indirect * alpha * weight).permute(2, 0, 1)
+    torch.testing.assert_close(spec, spec_ref, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ic, ic_ref, rtol=1e-6, atol=1e-7)
+    gs, gi = r(3, H, W), r(3, H, W)
+    got = torch.autograd.grad([spec, ic], [direct, weight, feat, alpha_chw], [gs, gi])
+    want = torch.autograd.grad([spec_ref, ic_ref], [direct, weight, feat, alpha_chw], [gs, gi])
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
