@@ -211,10 +211,11 @@ int mrgs_indirect_blend_backward(int32_t H, int32_t W, const float* direct, cons
                                  const MrgsStridedMap* alpha, const float* visibility, const float* g_specular, const float* g_indirect_color,
                                  float* g_direct, float* g_weight, float* g_indirect, float* g_alpha, void* stream);
 
-/* g_features[8,H,W] of render_surfel's material map (refl, roughness, albedo[3], indirect[3] = 0) assembled from the outputs of
- * mrgs_surfel_composite_backward (g_refl) and mrgs_shade_specular_backward (g_refl, g_roughness [H,W]; g_albedo [H,W,3]). */
+/* g_features[8,H,W] of render_surfel's material map (refl, roughness, albedo[3], indirect[3]) assembled from the outputs of
+ * mrgs_surfel_composite_backward (g_refl), mrgs_shade_specular_backward (g_refl, g_roughness [H,W]; g_albedo [H,W,3]) and, with the
+ * visibility tracer, mrgs_indirect_blend_backward (g_indirect [H,W,3]; NULL = zeros). */
 int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,
-                              const float* g_albedo_hwc, float* g_features, void* stream);
+                              const float* g_albedo_hwc, const float* g_indirect_hwc, float* g_features, void* stream);
 
 /* ---- per-gaussian inputs of the surfel renderer (fused glue) -----------------------------------------------------
  * One kernel instead of the ~50 torch kernels the reference runs per view before the rasterizer call: GaussianModel getters

@@ -112,7 +112,7 @@ SYMBOLS = {
     "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_mip_backward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
-    "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_loss_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mrgs_loss_forward": (ctypes.c_int, [ctypes.POINTER(MrgsLossConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

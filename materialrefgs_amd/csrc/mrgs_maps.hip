@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) surfel_composite_bwd_kernel(int HW, int s
 // would each pad to [8,H,W] and add up
 __global__ void __launch_bounds__(256) surfel_feature_grads_kernel(int HW, const float* __restrict__ g_refl_composite, const float* __restrict__ g_refl_shade,
                                                                    const float* __restrict__ g_rough, const float* __restrict__ g_albedo_hwc,
-                                                                   float* __restrict__ g_features)
+                                                                   const float* __restrict__ g_indirect_hwc, float* __restrict__ g_features)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
@@ -279,7 +279,8 @@ __global__ void __launch_bounds__(256) surfel_feature_grads_kernel(int HW, const
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         g_features[(2 + c) * HW + pix] = g_albedo_hwc[3 * (size_t)pix + c];
-        g_features[(5 + c) * HW + pix] = 0.0f;       // the indirect radiance map is not used without the visibility tracer
+        // the indirect radiance map only matters with the visibility tracer (mrgs_indirect_blend_backward)
+        g_features[(5 + c) * HW + pix] = g_indirect_hwc ? g_indirect_hwc[3 * (size_t)pix + c] : 0.0f;
     }
 }
 
@@ -415,12 +416,12 @@ int mrgs_indirect_blend_backward(int32_t H, int32_t W, const float* direct, cons
 }
 
 int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,
-                              const float* g_albedo_hwc, float* g_features, void* stream)
+                              const float* g_albedo_hwc, const float* g_indirect_hwc, float* g_features, void* stream)
 {
     if (H <= 0 || W <= 0 || !g_refl_composite || !g_refl_shade || !g_roughness || !g_albedo_hwc || !g_features) return MRGS_E_BAD_ARG;
     const int HW = H * W;
     hipLaunchKernelGGL(surfel_feature_grads_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, g_refl_composite, g_refl_shade,
-                       g_roughness, g_albedo_hwc, g_features);
+                       g_roughness, g_albedo_hwc, g_indirect_hwc, g_features);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

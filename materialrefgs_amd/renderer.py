@@ -324,24 +324,6 @@ def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, o
             "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
 
 
-def _render_surfel_indirect(viewpoint_camera, pc, bg_color, srgb, base_color, refl_strength, roughness_map, albedo, indirect_light, normal_map,
-                            render_alpha, surf_depth, geo):
-    """opt.indirect branch of render_surfel (gaussian_renderer/__init__.py:421-479, INDIRECT_TYPE other than "raytracing_residual"):
-    the blended indirect radiance replaces the environment where the mirror ray hits the mesh (`pc.ray_tracer`)."""
-    specular, extra = get_specular_color_surfel(
-        pc.get_envmap, albedo.permute(1, 2, 0), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, normal_map,
-        render_alpha.permute(1, 2, 0), refl_strength=refl_strength.permute(1, 2, 0), roughness=roughness_map.permute(1, 2, 0), pc=pc,
-        surf_depth=surf_depth, indirect_light=indirect_light.permute(1, 2, 0))
-    # (1 - refl) * base + specular, optional sRGB, background (:436-445): the composite kernel of the direct branch
-    final_image, diffuse_map = _SurfelComposite.apply(base_color, refl_strength, specular, render_alpha, bg_color, srgb)
-    if srgb:
-        albedo, specular = linear_to_srgb(albedo), linear_to_srgb(specular)
-    extra = dict(extra)
-    extra["indirect_color"] = diffuse_map + extra["indirect_color"] + bg_color[:, None, None] * (1 - render_alpha)
-    return {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": diffuse_map, "diffuse_map_ori": base_color,
-            "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo, **extra}
-
-
 def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None,
                   wo_render_img=False, normal_img_map=None):
     """gaussian_renderer/__init__.py:225-483: per-gaussian material channels (S = 8: refl 1, roughness 1, albedo 3, indirect 3)
@@ -375,14 +357,23 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
 
     # get_specular_color_surfel (utils/refl_utils.py:364-419) + (1 - refl) * base + specular, optional sRGB, background
     # (__init__.py:436-445) as one autograd node on the whole material map
-    if getattr(opt, "indirect", False):
-        return _render_surfel_indirect(viewpoint_camera, pc, bg_color, srgb, base_color, refl_strength, roughness_map, albedo, indirect_light,
-                                       reg["normal_map"], render_alpha, reg["surf_depth"], geo)
+    # opt.indirect (:421-431, INDIRECT_TYPE other than "raytracing_residual"): where the mirror ray hits the mesh of `pc.ray_tracer`
+    # the blended indirect radiance replaces the environment; same node, plus the visibility and blend kernels
+    indirect = bool(getattr(opt, "indirect", False))
+    tracer = getattr(pc, "ray_tracer", None) if indirect else None
     final_image, diffuse_map, specular, extra_dict = shade_and_composite_surfel(
         pc.get_envmap, base_color, rendered_features, viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, reg["normal_map"],
-        render_alpha, bg_color, srgb)
+        render_alpha, bg_color, srgb, ray_tracer=tracer, surf_depth=reg["surf_depth"])
     if srgb:
         albedo = linear_to_srgb(albedo)
         specular = linear_to_srgb(specular)
-    return {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": diffuse_map,
-            "diffuse_map_ori": base_color, "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
+    out = {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": diffuse_map,
+           "diffuse_map_ori": base_color, "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
+    if indirect:
+        if tracer is None:      # :379-406 without a tracer: everything is visible
+            extra_dict = {**extra_dict, "visibility": torch.ones_like(render_alpha), "indirect_light": indirect_light,
+                          "indirect_color": torch.zeros_like(base_color)}
+        background = bg_color[:, None, None] * (1 - render_alpha)
+        out.update(extra_dict)
+        out["indirect_color"] = diffuse_map + extra_dict["indirect_color"] + background          # :446-449
+    return out
