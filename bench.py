@@ -147,7 +147,15 @@ def main():
         if world > 1 else None
     state = {"R": 0}
 
-    surfel_bucket = mdist.GradBucket([t_.shape for t_ in surfel_params], dev) if (surfel_mode and world > 1) else None
+    # render_surfel's parameter set: both SH families (96 of 111 floats per gaussian) travel factored (dist.SurfelGradReducer)
+    surfel_names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color",
+                    "indirect_dc", "indirect_rest", "env_base"]
+    surfel_reducer = mdist.SurfelGradReducer([t_.shape for t_ in surfel_params], surfel_names, dev) if (surfel_mode and world > 1) else None
+
+    def reduce_surfel(view):
+        summed = surfel_reducer.reduce([t_.grad for t_ in surfel_params], pc._xyz, pc._rotation, cams_dev[view].camera_center, pc.active_sh_degree)
+        for t_, g_ in zip(surfel_params, summed):
+            t_.grad = g_
 
     def step_surfel(i):
         view = (i * world + rank) % len(settings)
@@ -160,8 +168,7 @@ def main():
             loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)
             loss.backward()
             if world > 1:
-                for t_, g_ in zip(surfel_params, mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])):
-                    t_.grad = g_
+                reduce_surfel(view)
             optimizer.step()
             return
         # the maps calculate_loss consumes (utils/loss_utils.py:147-152,166), with fixed upstream gradients
@@ -170,7 +177,7 @@ def main():
             state["g"] = [torch.ones_like(outs[0])] + [torch.full_like(o, 0.1) for o in outs[1:]]
         torch.autograd.backward(outs, state["g"])
         if world > 1:
-            mdist.allreduce_gradients(surfel_bucket, [t_.grad for t_ in surfel_params])
+            reduce_surfel(view)
 
     def step(i):
         if surfel_mode:

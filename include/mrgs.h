@@ -344,6 +344,16 @@ int mrgs_adam_step(const MrgsAdamTensor* tensors, int32_t n_tensors, double beta
 int mrgs_sh_grad_expand(int32_t P, int32_t M, int32_t D, int32_t V, const float* means3D, const float* gathered, int64_t row_stride,
                         float* dL_dsh, void* stream);
 
+/* The same exchange for render_surfel's parameter set (BASELINE config 5): colour SH along the view direction and indirect-radiance SH
+ * (eval_sh(3, .) along the mirror direction of the facing normal, gaussian_renderer/__init__.py:338-352) are both rank one per view.
+ * gathered row v = [dRGB_v (P x 3) | dIND_v (P x 3) | campos_v (3)] with dRGB_v = d features_dc_v / SH_C0 and
+ * dIND_v = d indirect_dc_v / SH_C0; xyz [P,3] and rotation_raw [P,4] (w,x,y,z, un-normalised) are the replicated parameters the
+ * directions are rebuilt from.  Writes the summed gradients of features_dc [P,1,3], features_rest [P,15,3] (coefficients beyond
+ * (D+1)^2 zero), indirect_dc [P,1,3], indirect_rest [P,15,3]: 96 of the 111 gradient floats per gaussian never cross the links. */
+int mrgs_sh_grad_expand_surfel(int32_t P, int32_t D, int32_t V, const float* xyz, const float* rotation_raw, const float* gathered,
+                               int64_t row_stride, float* g_features_dc, float* g_features_rest, float* g_indirect_dc, float* g_indirect_rest,
+                               void* stream);
+
 /* Introspection used by the parity tests: copies of internal state in the reference's layouts.
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
  * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],

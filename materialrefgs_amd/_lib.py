@@ -130,6 +130,8 @@ SYMBOLS = {
                                                     ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p]),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mrgs_sh_grad_expand_surfel": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -328,9 +328,77 @@ __global__ void __launch_bounds__(256) sh_grad_expand_kernel(int P, int M, int D
     }
 }
 
+
+// The same factoring for the parameter set of render_surfel (BASELINE config 5: 111 floats per gaussian): both SH families are
+// rank one per view -- the colour SH along the view direction (as above) and the indirect-radiance SH along the mirror direction
+// make_frame(...).r of this file (d indirect_sh[p][k][c] = B_k(r_v(p)) g_v[p][c], clamp already folded into g) -- and both
+// directions can be rebuilt from replicated parameters (xyz, rotation) and the rank's camera centre.  gathered row v =
+// [dRGB_v (P x 3) | dIND_v (P x 3) | campos_v (3)]; outputs are the four split tensors of the model (dc [P,1,3], rest [P,15,3]).
+__global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D, int V, const float* __restrict__ xyz,
+                                                                    const float* __restrict__ rotation_raw, const float* __restrict__ gathered,
+                                                                    long long row_stride, float* __restrict__ g_dc, float* __restrict__ g_rest,
+                                                                    float* __restrict__ g_ind_dc, float* __restrict__ g_ind_rest)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float p[3] = {xyz[3 * (size_t)idx], xyz[3 * (size_t)idx + 1], xyz[3 * (size_t)idx + 2]};
+    const float4 q = reinterpret_cast<const float4*>(rotation_raw)[idx];
+    float a[16][3], b[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { a[k][0] = a[k][1] = a[k][2] = 0.0f; b[k][0] = b[k][1] = b[k][2] = 0.0f; }
+    const int ncoef = (D + 1) * (D + 1);
+    for (int v = 0; v < V; v++) {
+        const float* row = gathered + (size_t)v * row_stride;
+        const float* cam = row + 6 * (size_t)P;
+        const float g[3] = {row[3 * (size_t)idx], row[3 * (size_t)idx + 1], row[3 * (size_t)idx + 2]};
+        const float* ri = row + 3 * (size_t)P;
+        const float h[3] = {ri[3 * (size_t)idx], ri[3 * (size_t)idx + 1], ri[3 * (size_t)idx + 2]};
+        const bool has_g = (g[0] != 0.0f) | (g[1] != 0.0f) | (g[2] != 0.0f), has_h = (h[0] != 0.0f) | (h[1] != 0.0f) | (h[2] != 0.0f);
+        if (!has_g && !has_h) continue;
+        const Frame f = make_frame(p, q, cam);
+        float B[16];
+        if (has_g) {
+            sh_basis16(f.v[0], f.v[1], f.v[2], B);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float w = k < ncoef ? B[k] : 0.0f;
+                a[k][0] += w * g[0]; a[k][1] += w * g[1]; a[k][2] += w * g[2];
+            }
+        }
+        if (has_h) {
+            sh_basis16(f.r[0], f.r[1], f.r[2], B);          // eval_sh(3, ...) along the mirror direction (__init__.py:350-352)
+#pragma unroll
+            for (int k = 0; k < 16; k++) { b[k][0] += B[k] * h[0]; b[k][1] += B[k] * h[1]; b[k][2] += B[k] * h[2]; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        g_dc[3 * (size_t)idx + c] = a[0][c];
+        g_ind_dc[3 * (size_t)idx + c] = b[0][c];
+    }
+    float* o1 = g_rest + (size_t)idx * 45;
+    float* o2 = g_ind_rest + (size_t)idx * 45;
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { o1[3 * (k - 1) + c] = a[k][c]; o2[3 * (k - 1) + c] = b[k][c]; }
+}
+
 }   // namespace
 
 extern "C" {
+
+int mrgs_sh_grad_expand_surfel(int32_t P, int32_t D, int32_t V, const float* xyz, const float* rotation_raw, const float* gathered,
+                               int64_t row_stride, float* g_features_dc, float* g_features_rest, float* g_indirect_dc, float* g_indirect_rest,
+                               void* stream)
+{
+    if (P < 0 || D < 0 || D > 3 || V < 1 || row_stride < 6 * (int64_t)P + 3) return MRGS_E_BAD_ARG;
+    if (P == 0) return MRGS_OK;
+    if (!xyz || !rotation_raw || !gathered || !g_features_dc || !g_features_rest || !g_indirect_dc || !g_indirect_rest) return MRGS_E_BAD_ARG;
+    hipLaunchKernelGGL(sh_grad_expand_surfel_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, V, xyz, rotation_raw, gathered,
+                       (long long)row_stride, g_features_dc, g_features_rest, g_indirect_dc, g_indirect_rest);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
 
 int mrgs_sh_grad_expand(int32_t P, int32_t M, int32_t D, int32_t V, const float* means3D, const float* gathered, int64_t row_stride,
                         float* dL_dsh, void* stream)

@@ -12,6 +12,8 @@ dL/dsh_v[p][k][c] = B_k(dir_v(p)) * dRGB_v[p][c] (backward.cu:22-141).  `Factore
 floats dRGB_v[p] (= dL/dsh_v[p][0] / SH_C0) plus the camera centre of every rank and lets each rank rebuild
 sum_v dL/dsh_v locally (csrc/mrgs_surfel.hip: sh_grad_expand_kernel), and all-reduces only the other 13 floats: 2.4x fewer
 bytes over the point-to-point xGMI links than the dense all-reduce, which at 300k surfels costs about as much as the render.
+`SurfelGradReducer` does the same for render_surfel's parameter set (111 floats per gaussian, BASELINE config 5), whose second SH
+family (indirect radiance along the mirror direction) factors the same way: 21 floats per gaussian on the wire instead of 111.
 """
 import ctypes
 from typing import Dict, List, Optional, Sequence
@@ -118,6 +120,96 @@ class FactoredGradReducer:
         w2.wait()
         views = self.small.views()
         return views[:self.sh_index] + [sh_sum] + views[self.sh_index:]
+
+
+def _view_and_mirror_dirs(xyz, rotation_raw, cam):
+    """Unit view direction and mirror direction of the facing normal (csrc/mrgs_surfel.hip: make_frame) with torch ops."""
+    q = rotation_raw / rotation_raw.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    nr = torch.stack([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    d = xyz - cam
+    v = d / d.norm(dim=1, keepdim=True)
+    flip = torch.where(-(nr * v).sum(1, keepdim=True) >= 0, 1.0, -1.0)
+    nn = nr * flip
+    nn = nn / nn.norm(dim=1, keepdim=True).clamp_min(1e-20)
+    c = -(nn * v).sum(1, keepdim=True)
+    return v, 2 * c * nn + v
+
+
+def expand_surfel_sh_gradients(gathered: torch.Tensor, xyz: torch.Tensor, rotation_raw: torch.Tensor, sh_degree: int):
+    """gathered [V, 6P + 3] rows [dRGB_v | dIND_v | campos_v] -> summed gradients of (features_dc [P,1,3], features_rest [P,15,3],
+    indirect_dc [P,1,3], indirect_rest [P,15,3]).  GPU tensors: libmrgs.so (mrgs_sh_grad_expand_surfel); CPU tensors (the gloo tests
+    of the collective plumbing): torch restatement."""
+    V, P = gathered.shape[0], xyz.shape[0]
+    assert gathered.shape[1] == 6 * P + 3 and gathered.is_contiguous()
+    if xyz.is_cuda:
+        from . import _lib
+        o = dict(dtype=torch.float32, device=xyz.device)
+        out = [torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o), torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o)]
+        x3, q4 = xyz.detach().float().contiguous(), rotation_raw.detach().float().contiguous()
+        with torch.cuda.device(xyz.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(xyz.device).cuda_stream)
+            _lib.check(_lib.lib().mrgs_sh_grad_expand_surfel(P, int(sh_degree), V, ctypes.c_void_p(x3.data_ptr()), ctypes.c_void_p(q4.data_ptr()),
+                                                             ctypes.c_void_p(gathered.data_ptr()), gathered.stride(0),
+                                                             *[ctypes.c_void_p(t.data_ptr()) for t in out], st))
+        return out
+    from .gs_utils import sh_basis
+    sh, ind = torch.zeros((P, 16, 3)), torch.zeros((P, 16, 3))
+    n = (sh_degree + 1) ** 2
+    for v in range(V):
+        g, h, cam = gathered[v, :3 * P].view(P, 3), gathered[v, 3 * P:6 * P].view(P, 3), gathered[v, 6 * P:]
+        vd, rd = _view_and_mirror_dirs(xyz.detach(), rotation_raw.detach(), cam)
+        sh[:, :n] += sh_basis(sh_degree, vd).unsqueeze(-1) * g.unsqueeze(1)
+        ind += sh_basis(3, rd).unsqueeze(-1) * h.unsqueeze(1)
+    return [sh[:, :1].contiguous(), sh[:, 1:].contiguous(), ind[:, :1].contiguous(), ind[:, 1:].contiguous()]
+
+
+class SurfelGradReducer:
+    """View-parallel gradient sum for render_surfel's parameter set (BASELINE config 5).  `names` labels the gradient tensors in the
+    order they are passed and must contain "xyz", "rotation", "features_dc", "features_rest", "indirect_dc", "indirect_rest"; the four
+    SH tensors (96 of 111 floats per gaussian) are exchanged as 6 floats per gaussian (all-gather) and rebuilt locally, everything else
+    (incl. tensors that are not per-gaussian, e.g. the environment cubemap) goes through one flat all-reduce."""
+    SH_NAMES = ("features_dc", "features_rest", "indirect_dc", "indirect_rest")
+
+    def __init__(self, shapes: Sequence[torch.Size], names: Sequence[str], device):
+        self.names = list(names)
+        assert all(n in self.names for n in self.SH_NAMES + ("xyz", "rotation"))
+        self.sh_pos = [self.names.index(n) for n in self.SH_NAMES]
+        self.dense_pos = [i for i in range(len(self.names)) if i not in self.sh_pos]
+        self.dense = GradBucket([shapes[i] for i in self.dense_pos], device)
+        self.P = int(shapes[self.names.index("xyz")][0])
+        self.row = torch.empty(6 * self.P + 3, dtype=torch.float32, device=device)
+        self.gathered = None
+
+    def reduce(self, tensors: Sequence[Optional[torch.Tensor]], xyz: torch.Tensor, rotation_raw: torch.Tensor, campos: torch.Tensor,
+               sh_degree: int, group=None):
+        """Returns the summed gradients in the order of `tensors`."""
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1:
+            return list(tensors)
+        P = self.P
+        flat = self.dense.pack([tensors[i] for i in self.dense_pos])
+        for k, name in enumerate(("features_dc", "indirect_dc")):
+            t = tensors[self.names.index(name)]
+            seg = self.row[3 * P * k:3 * P * (k + 1)]
+            if t is None:
+                seg.zero_()
+            else:
+                seg.copy_((t[:, 0, :] / SH_C0).reshape(-1))
+        self.row[6 * P:].copy_(campos.reshape(-1))
+        if self.gathered is None or self.gathered.shape[0] != world:
+            self.gathered = torch.empty((world, 6 * P + 3), dtype=torch.float32, device=self.row.device)
+        w1 = dist.all_gather_into_tensor(self.gathered.view(-1), self.row, group=group, async_op=True)
+        w2 = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        w1.wait()
+        sh = expand_surfel_sh_gradients(self.gathered, xyz, rotation_raw, sh_degree)
+        w2.wait()
+        out = [None] * len(self.names)
+        for i, v in zip(self.dense_pos, self.dense.views()):
+            out[i] = v
+        for i, v in zip(self.sh_pos, sh):
+            out[i] = v
+        return out
 
 
 def reduce_densification_stats(viewspace_grad_norm: torch.Tensor, visible: torch.Tensor, radii: torch.Tensor, group=None):

@@ -110,3 +110,53 @@ def test_factored_sh_gradient_exchange_world2():
         expect = sum((np.zeros_like(res[0][1][i]) if r[2][i] is None else r[2][i]) for r in res)
         for r in res:
             np.testing.assert_allclose(r[1][i], expect, rtol=2e-5, atol=2e-6)
+
+
+def _worker_surfel(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from materialrefgs_amd import dist as mdist
+    from materialrefgs_amd.gs_utils import sh_basis
+    mdist.init_from_env(backend="gloo")
+    P, deg = 257, 2
+    shared = torch.Generator().manual_seed(9)
+    xyz = torch.randn(P, 3, generator=shared) * 2               # replicated parameters
+    rot = torch.randn(P, 4, generator=shared)
+    gen = torch.Generator().manual_seed(300 + rank)
+    campos = torch.randn(3, generator=gen) * 5
+    drgb, dind = torch.randn(P, 3, generator=gen), torch.randn(P, 3, generator=gen)
+    drgb[torch.rand(P, generator=gen) < 0.3] = 0.0
+    dind[torch.rand(P, generator=gen) < 0.5] = 0.0             # clamp_min(0) cut the indirect radiance of these
+    vd, rd = mdist._view_and_mirror_dirs(xyz, rot, campos)
+    sh = torch.zeros(P, 16, 3)
+    sh[:, :(deg + 1) ** 2] = sh_basis(deg, vd).unsqueeze(-1) * drgb.unsqueeze(1)       # what the rasterizer backward yields
+    ind = sh_basis(3, rd).unsqueeze(-1) * dind.unsqueeze(1)                             # what surfel_features' backward yields
+    names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl", "rough", "ori_color", "indirect_dc",
+             "indirect_rest", "env"]
+    grads = [torch.randn(P, 3, generator=gen), torch.randn(P, 2, generator=gen), torch.randn(P, 4, generator=gen), None,
+             sh[:, :1].contiguous(), sh[:, 1:].contiguous(), torch.randn(P, 1, generator=gen), torch.randn(P, 1, generator=gen),
+             torch.randn(P, 3, generator=gen), ind[:, :1].contiguous(), ind[:, 1:].contiguous(), torch.randn(6, 4, 4, 3, generator=gen)]
+    shapes = [torch.Size((P, 3)), torch.Size((P, 2)), torch.Size((P, 4)), torch.Size((P, 1)), torch.Size((P, 1, 3)), torch.Size((P, 15, 3)),
+              torch.Size((P, 1)), torch.Size((P, 1)), torch.Size((P, 3)), torch.Size((P, 1, 3)), torch.Size((P, 15, 3)), torch.Size((6, 4, 4, 3))]
+    red = mdist.SurfelGradReducer(shapes, names, "cpu")
+    out = red.reduce(grads, xyz, rot, campos, deg)
+    q.put((rank, [o.clone().numpy() for o in out], [None if g is None else g.numpy() for g in grads]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_surfel_gradient_exchange_world2():
+    """SurfelGradReducer (6 floats per gaussian all-gathered for the two SH families, the rest all-reduced) = dense sums."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_surfel, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(12):
+        expect = sum((np.zeros_like(res[0][1][i]) if r[2][i] is None else r[2][i]) for r in res)
+        for r in res:
+            np.testing.assert_allclose(r[1][i], expect, rtol=2e-5, atol=2e-6)

@@ -440,3 +440,58 @@ def test_shade_and_composite_node_matches_the_separate_ops(gpu_device, srgb):
         assert torch.equal(a, b)
     for a, b in zip(res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(b.abs().max()))
+
+
+@pytest.mark.gpu
+def test_surfel_factored_sh_exchange_equals_the_dense_sum(gpu_device):
+    """mrgs_sh_grad_expand_surfel on the real gradients of render_surfel from three views: the four SH gradient tensors rebuilt
+    from 6 floats per gaussian and the camera centres equal the sum of the per-view dense gradients."""
+    from types import SimpleNamespace
+    from materialrefgs_amd import dist as mdist
+    from materialrefgs_amd.renderer import SurfelModel, render_surfel
+    from materialrefgs_amd.shading import EnvLight
+    from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera
+    P, H, W = 4000, 96, 128
+    sc = make_shell_scene(P, S=0, seed=2, radius_px=6.0, image_size=128).to(gpu_device)
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(gpu_device)   # noqa: E731
+    env = EnvLight(device=gpu_device, trainable=True)
+    with torch.no_grad():
+        env.base.copy_(rnd(6, 128, 128, 3))
+    env.build_mips()
+    inv_sig = lambda x: torch.log(x / (1 - x))   # noqa: E731
+    pc = SurfelModel(sc.means3D.clone(), torch.log(sc.scales), sc.rotations.clone() * 1.7, inv_sig(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                     sc.shs[:, :1].clone(), sc.shs[:, 1:].clone(), refl_strength=rnd(P, 1), roughness=rnd(P, 1), ori_color=rnd(P, 3),
+                     indirect_dc=rnd(P, 1, 3) * 0.3, indirect_rest=rnd(P, 15, 3) * 0.1, envmap=env, active_sh_degree=2)
+    for t in pc.parameters():
+        t.requires_grad_(True)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+    bg = torch.zeros(3, device=gpu_device)
+    # the indirect radiance only reaches the image through the visibility blend: give the model an occluder
+    from materialrefgs_amd.raytracing import RayTracer
+    from materialrefgs_amd.synthetic import sphere_mesh
+    v1, t1 = sphere_mesh(16, 24, 0.9)
+    v2, t2 = sphere_mesh(12, 16, 1.2, centre=(0.0, 2.6, 0.5))
+    pc.ray_tracer = RayTracer(np.concatenate([v1, v2]), np.concatenate([t1, t2 + len(v1)]), device=gpu_device)
+    names = ("features_dc", "features_rest", "indirect_dc", "indirect_rest")
+    dense = {n: 0 for n in names}
+    rows = []
+    for view in range(3):
+        cam = orbit_camera(view, H, W).to(gpu_device)
+        for t in pc.parameters():
+            t.grad = None
+        out = render_surfel(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=True))
+        (out["render"] * torch.linspace(0.5, 1.5, W, device=gpu_device)).sum().backward()
+        gr = {"features_dc": pc._features_dc.grad, "features_rest": pc._features_rest.grad, "indirect_dc": pc._indirect_dc.grad,
+              "indirect_rest": pc._indirect_rest.grad}
+        for n in names:
+            dense[n] = dense[n] + gr[n]
+        rows.append(torch.cat([(gr["features_dc"][:, 0, :] / mdist.SH_C0).reshape(-1), (gr["indirect_dc"][:, 0, :] / mdist.SH_C0).reshape(-1),
+                               cam.camera_center.reshape(-1)]))
+    gathered = torch.stack(rows).contiguous()
+    got = mdist.expand_surfel_sh_gradients(gathered, pc._xyz, pc._rotation, 2)
+    assert float(dense["indirect_rest"].abs().max()) > 0 and float(dense["features_rest"].abs().max()) > 0
+    assert float(dense["features_rest"][:, 8:].abs().max()) == 0          # active degree 2: coefficients 9..15 untouched
+    for n, t in zip(names, got):
+        scale = float(dense[n].abs().max())
+        assert float((t - dense[n]).abs().max()) < 3e-5 * scale, n
