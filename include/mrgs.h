@@ -337,6 +337,23 @@ typedef struct MrgsAdamTensor {
 } MrgsAdamTensor;
 int mrgs_adam_step(const MrgsAdamTensor* tensors, int32_t n_tensors, double beta1, double beta2, double eps, void* stream);
 
+/* ---- densify / prune compaction ----------------------------------------------------------------
+ * Replaces the ~50 boolean-index calls of _prune_optimizer / prune_points (scene/gaussian_model.py:856-905) -- parameter tensors, their
+ * two Adam moments, xyz_gradient_accum / denom / max_radii2D -- by one scan of the keep mask and one gather launch for all tensors.
+ * keep: device uint8 [n_rows] (non-zero = keep).  mrgs_compact_count scans it into ws (mrgs_compact_ws_bytes) and writes the number
+ * of surviving rows to count_dev (device int64): the caller reads it once, allocates the exact-size destinations and calls
+ * mrgs_compact_rows with the same keep / ws.  Rows are fp32 rows of `row_floats` values (any 4-byte type can be passed as such);
+ * surviving rows keep their order, like tensor[mask]. */
+#define MRGS_COMPACT_MAX_TENSORS 64
+typedef struct MrgsCompactTensor {
+    const float* src;      /* [n_rows, row_floats] */
+    float* dst;            /* [count, row_floats] */
+    int32_t row_floats;
+} MrgsCompactTensor;
+size_t mrgs_compact_ws_bytes(int64_t n_rows);
+int mrgs_compact_count(int64_t n_rows, const uint8_t* keep, void* ws, size_t ws_bytes, int64_t* count_dev, void* stream);
+int mrgs_compact_rows(int64_t n_rows, const uint8_t* keep, const void* ws, const MrgsCompactTensor* tensors, int32_t n_tensors, void* stream);
+
 /* View-parallel training (materialrefgs_amd/dist.py): sum over V views of the SH colour gradients from each view's masked colour
  * gradient dRGB_v = dL/dsh_v[:,0,:] / SH_C0 and camera centre: dL_dsh[p][k][c] = sum_v B_k(normalize(means3D[p] - campos_v)) dRGB_v[p][c]
  * for k < (D+1)^2, 0 beyond (backward.cu:22-141).  gathered = V rows of row_stride floats, row v = [dRGB_v (P x 3) | campos_v (3)]

@@ -76,6 +76,10 @@ class MrgsAdamTensor(ctypes.Structure):
                 ("lr", c_float), ("step", c_int32)]
 
 
+class MrgsCompactTensor(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_floats", c_int32)]
+
+
 class MrgsKernelTimes(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("preprocess_ms", "sort_ms", "duplicate_ms", "render_fwd_ms", "render_bwd_ms",
                                        "preprocess_bwd_ms")]
@@ -132,6 +136,9 @@ SYMBOLS = {
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_sh_grad_expand_surfel": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p]),
+    "mrgs_compact_ws_bytes": (c_size_t, [c_int64]),
+    "mrgs_compact_count": (ctypes.c_int, [c_int64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mrgs_compact_rows": (ctypes.c_int, [c_int64, c_void_p, c_void_p, ctypes.POINTER(MrgsCompactTensor), c_int32, c_void_p]),
     "mrgs_mark_visible": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_envmap_lookup_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

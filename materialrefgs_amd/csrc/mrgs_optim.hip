@@ -114,3 +114,142 @@ extern "C" int mrgs_adam_step(const MrgsAdamTensor* tensors, int32_t n_tensors, 
     }
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
+
+// ---- densify / prune compaction (scene/gaussian_model.py:856-905: _prune_optimizer + prune_points) -------------------------------
+// The reference drops pruned gaussians with `tensor[mask]` on each of ~16 parameter tensors, their two Adam moments and three
+// statistics vectors: ~50 boolean-index calls, each with its own nonzero() pass and host sync.  Here the keep mask is scanned once
+// (count per 1024-row block, one-workgroup scan of the block counts) and ONE launch gathers the surviving rows of every tensor:
+// grid = (row blocks, tensors), rows keep their order (stable, like boolean indexing).
+namespace {
+
+constexpr int COMPACT_ROWS = 1024;      // rows per workgroup
+
+struct CompactTable {
+    const float* src[MRGS_COMPACT_MAX_TENSORS];
+    float* dst[MRGS_COMPACT_MAX_TENSORS];
+    int row_floats[MRGS_COMPACT_MAX_TENSORS];
+};
+
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned* s_wave, unsigned& total)
+{
+    // v = this thread's count; returns the exclusive prefix over the 256 threads of the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void compact_count_kernel(long long n, const uint8_t* __restrict__ keep, unsigned* __restrict__ block_count)
+{
+    __shared__ unsigned s_wave[4];
+    const long long r0 = (long long)blockIdx.x * COMPACT_ROWS + threadIdx.x * 4;
+    unsigned c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += (r0 + j < n && keep[r0 + j]) ? 1u : 0u;
+    unsigned total;
+    block_exclusive_scan_256(c, s_wave, total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int nblocks, const unsigned* __restrict__ block_count, unsigned* __restrict__ block_off,
+                                                            long long* __restrict__ total_out)
+{
+    __shared__ unsigned s_part[1024];
+    const int per = (nblocks + 1023) / 1024, b0 = threadIdx.x * per;
+    unsigned s = 0;
+    for (int i = 0; i < per && b0 + i < nblocks; ++i) s += block_count[b0 + i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < 1024; ++i) { const unsigned v = s_part[i]; s_part[i] = run; run += v; }
+        total_out[0] = (long long)run;
+    }
+    __syncthreads();
+    unsigned run = s_part[threadIdx.x];
+    for (int i = 0; i < per && b0 + i < nblocks; ++i) { block_off[b0 + i] = run; run += block_count[b0 + i]; }
+}
+
+__global__ __launch_bounds__(256) void compact_gather_kernel(long long n, const uint8_t* __restrict__ keep, const unsigned* __restrict__ block_off,
+                                                             CompactTable t)
+{
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned s_dst[COMPACT_ROWS];        // destination row of each kept row of this block, 0xFFFFFFFF for dropped rows
+    const long long rb = (long long)blockIdx.x * COMPACT_ROWS, r0 = rb + threadIdx.x * 4;
+    unsigned k[4], c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k[j] = (r0 + j < n && keep[r0 + j]) ? 1u : 0u; c += k[j]; }
+    unsigned total;
+    unsigned pre = block_exclusive_scan_256(c, s_wave, total) + block_off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_dst[threadIdx.x * 4 + j] = k[j] ? pre : 0xFFFFFFFFu; pre += k[j]; }
+    __syncthreads();
+    if (total == 0) return;
+    const int ti = blockIdx.y, L = t.row_floats[ti];
+    const float* __restrict__ src = t.src[ti] + rb * L;
+    float* __restrict__ dst = t.dst[ti];
+    const long long rows = n - rb < COMPACT_ROWS ? n - rb : COMPACT_ROWS;
+    const int ne = (int)rows * L;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+        const int row = e / L, col = e - row * L;
+        const unsigned d = s_dst[row];
+        if (d != 0xFFFFFFFFu) dst[(size_t)d * L + col] = src[e];
+    }
+}
+
+}   // namespace
+
+extern "C" size_t mrgs_compact_ws_bytes(int64_t n_rows)
+{
+    if (n_rows <= 0) return 256;
+    const size_t nb = (size_t)((n_rows + COMPACT_ROWS - 1) / COMPACT_ROWS);
+    return mrgs_align_up(2 * nb * sizeof(unsigned), 256) + 256;
+}
+
+extern "C" int mrgs_compact_count(int64_t n_rows, const uint8_t* keep, void* ws, size_t ws_bytes, int64_t* count_dev, void* stream)
+{
+    if (n_rows < 0 || !ws || !count_dev || ws_bytes < mrgs_compact_ws_bytes(n_rows)) return MRGS_E_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows == 0) return hipMemsetAsync(count_dev, 0, sizeof(int64_t), st) == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+    if (!keep) return MRGS_E_BAD_ARG;
+    const long long nb = (n_rows + COMPACT_ROWS - 1) / COMPACT_ROWS;
+    if (nb > (1 << 22)) return MRGS_E_UNSUPPORTED;
+    unsigned* counts = (unsigned*)ws;
+    unsigned* offs = counts + nb;
+    compact_count_kernel<<<dim3((unsigned)nb), 256, 0, st>>>(n_rows, keep, counts);
+    compact_scan_kernel<<<1, 1024, 0, st>>>((int)nb, counts, offs, (long long*)count_dev);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+extern "C" int mrgs_compact_rows(int64_t n_rows, const uint8_t* keep, const void* ws, const MrgsCompactTensor* tensors, int32_t n_tensors,
+                                 void* stream)
+{
+    if (n_rows < 0 || n_tensors < 0 || (n_tensors > 0 && !tensors)) return MRGS_E_BAD_ARG;
+    if (n_rows == 0 || n_tensors == 0) return MRGS_OK;
+    if (!keep || !ws) return MRGS_E_BAD_ARG;
+    const long long nb = (n_rows + COMPACT_ROWS - 1) / COMPACT_ROWS;
+    const unsigned* offs = (const unsigned*)ws + nb;
+    for (int32_t first = 0; first < n_tensors; first += MRGS_COMPACT_MAX_TENSORS) {
+        CompactTable t;
+        int m = 0;
+        for (int32_t i = first; i < n_tensors && i < first + MRGS_COMPACT_MAX_TENSORS; ++i) {
+            if (tensors[i].row_floats < 0 || tensors[i].row_floats > (1 << 20)) return MRGS_E_BAD_ARG;
+            if (tensors[i].row_floats == 0) continue;
+            if (!tensors[i].src || !tensors[i].dst) return MRGS_E_BAD_ARG;
+            t.src[m] = tensors[i].src; t.dst[m] = tensors[i].dst; t.row_floats[m] = tensors[i].row_floats;
+            ++m;
+        }
+        if (m == 0) continue;
+        compact_gather_kernel<<<dim3((unsigned)nb, (unsigned)m), 256, 0, (hipStream_t)stream>>>(n_rows, keep, offs, t);
+    }
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}

@@ -136,3 +136,73 @@ def test_adam_full_size_properties():
     for i, p in enumerate(ps):                                  # first Adam step = -lr * sign(g) (bias-corrected m / sqrt(v) = g / |g|)
         lr = 1e-3 * (i + 1)
         torch.testing.assert_close(p.data, -lr * torch.sign(p.grad), rtol=1e-5, atol=1e-9)
+
+
+def _reference_prune(optimizer, mask):
+    """_prune_optimizer as the reference writes it (scene/gaussian_model.py:856-874), torch boolean indexing."""
+    out = {}
+    for group in optimizer.param_groups:
+        if group["name"] in ("mlp", "env", "env2"):
+            continue
+        stored = optimizer.state.get(group["params"][0], None)
+        if stored is not None:
+            stored["exp_avg"] = stored["exp_avg"][mask]
+            stored["exp_avg_sq"] = stored["exp_avg_sq"][mask]
+            del optimizer.state[group["params"][0]]
+            group["params"][0] = torch.nn.Parameter(group["params"][0][mask].requires_grad_(True))
+            optimizer.state[group["params"][0]] = stored
+        else:
+            group["params"][0] = torch.nn.Parameter(group["params"][0][mask].requires_grad_(True))
+        out[group["name"]] = group["params"][0]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,frac", [(5000, 0.7), (1, 1.0), (1025, 0.0), (300001, 0.93)])
+def test_prune_matches_boolean_indexing(P, frac):
+    from materialrefgs_amd import densify
+    from materialrefgs_amd.optim import Adam
+    dev = "cuda"
+    g = torch.Generator().manual_seed(P)
+    shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, 15, 3), "opacity": (P, 1), "scaling": (P, 2), "rotation": (P, 4),
+              "ind_asg": (P, 32, 5), "nostate": (P, 7), "env": (6, 8, 8, 3)}
+    vals = {k: torch.randn(*s, generator=g).to(dev) for k, s in shapes.items()}
+
+    def make():
+        ps = {k: torch.nn.Parameter(v.clone()) for k, v in vals.items()}
+        opt = Adam([{"params": [ps[k]], "lr": 1e-3, "name": k} for k in ps], lr=0.0, eps=1e-15)
+        for k, p in ps.items():
+            if k != "nostate":                                    # a group that never received a gradient has no state yet
+                p.grad = torch.randn(*p.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        opt.step()
+        return ps, opt
+    pa, oa = make()
+    pb, ob = make()
+    keep = (torch.rand(P, generator=g) < frac).to(dev)
+    accum, radii = torch.randn(P, 1, generator=g).to(dev), torch.randint(0, 50, (P,), generator=g, dtype=torch.int32).to(dev)
+    got, (accum2, radii2) = densify.prune_optimizer(oa, keep, extra=[accum, radii])
+    want = _reference_prune(ob, keep)
+    assert set(got) == set(want) and "env" not in got
+    for k in want:
+        assert got[k].shape == want[k].shape and got[k].requires_grad
+        assert torch.equal(got[k].data, want[k].data), k
+        sa, sb = oa.state.get(got[k], None), ob.state.get(want[k], None)
+        assert (sa is None) == (sb is None), k
+        if sb is not None:
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
+            assert int(sa["step"]) == int(sb["step"])
+    assert torch.equal(accum2, accum[keep]) and torch.equal(radii2, radii[keep]) and radii2.dtype == torch.int32
+    # the optimizer keeps working on the compacted tensors; appended rows get zero moments (cat_tensors_to_optimizer)
+    n_new = 17
+    add = {k: torch.randn(n_new, *shapes[k][1:], generator=g).to(dev) for k in shapes if k != "env"}
+    grown = densify.cat_tensors_to_optimizer(oa, add)
+    m = int(keep.sum())
+    for k, p in grown.items():
+        assert p.shape[0] == m + n_new
+        st = oa.state.get(p, None)
+        if st is not None:
+            assert float(st["exp_avg"][m:].abs().sum()) == 0.0
+        p.grad = torch.ones_like(p)
+    oa.step()
+    rep = densify.replace_tensor_to_optimizer(oa, torch.full((m + n_new, 1), -3.0, device=dev), "opacity")
+    assert float(oa.state[rep["opacity"]]["exp_avg"].abs().sum()) == 0.0
