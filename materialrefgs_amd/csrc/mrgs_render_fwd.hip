@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
-    uint32_t* __restrict__ item_work)
+    uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
@@ -197,8 +197,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         unsigned long long* w = g_wave_stats_fwd + 8 * (size_t)b;
         w[0] = ws_t0; w[1] = wall_clock64(); w[2] = __builtin_amdgcn_s_memtime() - ws_c0;
         w[3] = ((unsigned long long)(work - 3u * ws_blend) << 32) | ws_blend; w[4] = ((unsigned long long)0 << 32) | (unsigned)total;
+        w[6] = item_est[tile * 4 + quad];          // the estimate the queues were built from, next to the measured work
         w[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
-        w[6] = 0; w[7] = 0;
+        w[7] = 0;
     }
 #endif
     if (inside) {
@@ -234,7 +235,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
     hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work)
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est)
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
     if (cfg.S == 0) LAUNCH(0, false);
