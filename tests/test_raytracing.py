@@ -338,3 +338,20 @@ def test_indirect_blend_kernel_matches_torch_ops():
     want = torch.autograd.grad([spec_ref, ic_ref], [direct, weight, feat, alpha_chw], [gs, gi])
     for a, b in zip(got, want):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_trace_tiny_and_degenerate_meshes():
+    """Nine triangles (the reference's minimum is > 8) incl. zero-area and duplicated ones, rays parallel to faces, zero rays."""
+    from materialrefgs_amd.raytracing import RayTracer
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1], [0.5, 0.5, 0.5], [2, 2, 2]], dtype=np.float32)
+    t = np.array([[0, 2, 1], [1, 2, 3], [4, 5, 6], [5, 7, 6], [0, 1, 4], [1, 5, 4], [8, 8, 8], [9, 9, 1], [0, 2, 1]], dtype=np.int32)
+    o, d = rays(500, 3)
+    o[:4] = np.array([[0.25, 0.25, 3], [0.25, 0.25, -3], [-1, 0.5, 0.0], [0.5, 0.5, 0.5]], dtype=np.float32)
+    d[:4] = np.array([[0, 0, -1], [0, 0, 1], [1, 0, 0], [0, 0, 1]], dtype=np.float32)        # ray 2 runs inside the plane z = 0
+    _check_against_oracle(v, t, o * 0.7, d)
+    rt = RayTracer(v, t)
+    pos, nrm, depth = rt.trace(torch.zeros(0, 3, device="cuda"), torch.zeros(0, 3, device="cuda"))
+    assert pos.shape == (0, 3) and depth.shape == (0,)
+    with pytest.raises(AssertionError):
+        RayTracer(v, t[:8])
