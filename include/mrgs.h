@@ -69,6 +69,11 @@ typedef struct MrgsRasterInputs {
     const float* viewmatrix;
     const float* projmatrix;
     const float* campos;
+    uint32_t* work_hint;   /* optional, in/out, device, mrgs_work_hint_bytes(H, W), zero-initialised by the caller once per camera: the
+                              forward orders its blend waves by the work each (tile, quadrant) took the last time this buffer was
+                              passed (falling back to the cull count where it holds 0) and stores the work of this call.  A training
+                              loop revisits the same cameras, so the previous visit predicts where rays terminate early far better than
+                              any count available before the blend.  NULL: cull counts only.  Results do not depend on it. */
 } MrgsRasterInputs;
 
 /* Workspace sizes.  geom <-> geomBuffer (GeometryState, rasterizer_impl.cu:157-172), img <-> imgBuffer
@@ -76,6 +81,7 @@ typedef struct MrgsRasterInputs {
 size_t mrgs_geom_bytes(int32_t P, int32_t H, int32_t W);
 size_t mrgs_img_bytes(int32_t H, int32_t W);
 size_t mrgs_binning_bytes(int64_t num_rendered);
+size_t mrgs_work_hint_bytes(int32_t H, int32_t W);
 
 /* Forward, phase 1 of 2.  Replaces the first half of CudaRasterizer::Rasterizer::forward
  * (rasterizer_impl.cu:200-291: preprocess, prefix sum, blocking read-back of num_rendered).

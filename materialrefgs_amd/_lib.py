@@ -25,7 +25,7 @@ class MrgsRasterConfig(ctypes.Structure):
 
 class MrgsRasterInputs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
-                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos")]
+                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint")]
 
 
 class MrgsRasterGrads(ctypes.Structure):
@@ -90,6 +90,7 @@ SYMBOLS = {
     "mrgs_geom_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mrgs_img_bytes": (c_size_t, [c_int32, c_int32]),
     "mrgs_binning_bytes": (c_size_t, [c_int64]),
+    "mrgs_work_hint_bytes": (c_size_t, [c_int32, c_int32]),
     "mrgs_grad_bytes": (c_size_t, [c_int32, c_int32]),
     "mrgs_rasterize_forward_geom": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p,
                                                    c_size_t, c_void_p, ctypes.POINTER(c_int64), c_void_p]),

@@ -172,6 +172,11 @@ extern "C" {
 size_t mrgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return mrgs_carve_geom(nullptr, P, H, W).total; }
 size_t mrgs_img_bytes(int32_t H, int32_t W) { return mrgs_carve_img(nullptr, H, W).total; }
 size_t mrgs_binning_bytes(int64_t R) { return mrgs_carve_bin(nullptr, R).total; }
+size_t mrgs_work_hint_bytes(int32_t H, int32_t W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return 4 * (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y) * sizeof(uint32_t);
+}
 size_t mrgs_grad_bytes(int32_t P, int32_t S) { return mrgs_align_up((size_t)(P > 0 ? P : 1) * MRGS_GRAD_STRIDE(S) * sizeof(float), 256); }
 
 // phase 1: preprocess, depth sort, scan; leaves num_rendered and the look-back error flag in g.counters[0..1]
@@ -213,7 +218,7 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
     STAGE_CHECK(cfg, stream);
     mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
-    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, nullptr, 0, stream);
+    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, nullptr, 0, in->work_hint, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
@@ -348,7 +353,7 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     StageTimer t0(stream, ST_BWD);
     if (R > 0) {
         // (the gradient rows are cleared by spare workgroups of the ordering launch; mrgs_grad_bytes is a multiple of 256)
-        mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, grad_rec, mrgs_grad_bytes(cfg->P, cfg->S), stream);
+        mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, grad_rec, mrgs_grad_bytes(cfg->P, cfg->S), nullptr, stream);
         mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.qmask, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
     } else {
         HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));

@@ -132,6 +132,7 @@ void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, in
                              uint8_t* qmask, const MrgsImgWs& img, int tiles_x, int ntiles, hipStream_t stream);
 // bulk_zero (nullable, 16-byte aligned, size a multiple of 16): cleared by extra workgroups of the same launch
 void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, void* bulk_zero, size_t bulk_zero_bytes,
+                             const uint32_t* fwd_hint,
                              hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,

@@ -172,8 +172,14 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #define WS_END()
 #endif
 
+#ifndef MRGS_BWD_WPE0
+#define MRGS_BWD_WPE0 4
+#endif
+#ifndef MRGS_BWD_WPE8
+#define MRGS_BWD_WPE8 3
+#endif
 template <int S_MAX, bool FV>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 4 : S_MAX <= 8 ? 3 : 2, 8))) render_bwd_kernel(
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? MRGS_BWD_WPE0 : S_MAX <= 8 ? MRGS_BWD_WPE8 : 2, 8))) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,

@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
-    uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */)
+    uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */,
+    uint32_t* __restrict__ work_hint)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
@@ -191,7 +192,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 
     // entries this wave tested + 3 x entries it blended: the cost of the backward wave of the same pixel block, which walks
     // the same entries (bwd_order_kernel)
-    if (lane == 0) item_work[tile * 4 + quad] = work;
+    if (lane == 0) {
+        item_work[tile * 4 + quad] = work;
+        if (work_hint != nullptr) work_hint[tile * 4 + quad] = work;     // next visit of this camera orders its waves by it
+    }
 #ifdef MRGS_WAVE_STATS
     if (lane == 0 && b < 65536) {
         unsigned long long* w = g_wave_stats_fwd + 8 * (size_t)b;
@@ -235,7 +239,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
     hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est)
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint)
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
     if (cfg.S == 0) LAUNCH(0, false);

@@ -483,13 +483,23 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
 // when its own is empty (mrgs_pull_item): nothing depends on how the hardware places waves.
 // Work per item: the forward uses the cull counts of tile_ranges_kernel, the backward what the forward waves actually walked.
 // The first call of a forward also turns the CU census (bits set by the preprocess waves) into a dense CU numbering.
+// Work of an item.  Forward with a hint buffer (MrgsRasterInputs::work_hint): what the item's wave measured the last time this
+// camera was rendered (entries tested + 3 x entries blended, the unit of the backward's queues) -- it knows where rays terminate
+// early, which no count taken before the blend does; items the hint has never seen fall back to 3 x the cull count (same unit).
+__device__ __forceinline__ uint32_t item_cost(const uint32_t* __restrict__ item_src, const uint32_t* __restrict__ hint, int idx)
+{
+    const uint32_t e = item_src[idx];
+    if (hint == nullptr) return e;
+    const uint32_t h = hint[idx];
+    return (h != 0u && e != 0u) ? h : 3u * e;
+}
 #define ORDER_ADAPTIVE_PASSES 16
 #define ORDER_LDS_ITEMS 4096
 __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __restrict__ item_src, int ntiles, uint32_t* __restrict__ items_ws,
                                                            uint32_t* __restrict__ work_ws, uint32_t* __restrict__ assign_ws,
                                                            uint32_t* __restrict__ qstate, const uint32_t* __restrict__ census,
                                                            uint32_t* __restrict__ cu_state, int forward, uint32_t* __restrict__ zero_this,
-                                                           float4* __restrict__ bulk_zero, size_t bulk_zero_f4)
+                                                           float4* __restrict__ bulk_zero, size_t bulk_zero_f4, const uint32_t* __restrict__ hint)
 {
     // workgroups beyond the eight that order the lists only clear a buffer for the kernel that follows (the gradient rows of
     // the blend backward, 24 MB at P = 300k): the ordering occupies 8 CUs for ~10 us, the clear runs beside it on the others
@@ -531,7 +541,7 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     for (int i0 = 0; i0 < per_list; i0 += 1024) {
         const int i = i0 + tid;
         const int tile = (i >> 2) * 8 + x;
-        const uint32_t w = (i < per_list && tile < ntiles) ? item_src[tile * 4 + (i & 3)] + idle : 0u;
+        const uint32_t w = (i < per_list && tile < ntiles) ? item_cost(item_src, hint, tile * 4 + (i & 3)) + idle : 0u;
         const bool lightest = w > 0u && (w >> 2) == 0u;
         const uint64_t lm = __builtin_amdgcn_ballot_w64(lightest);
         if (lightest) { if ((tid & 63) == __builtin_ctzll(lm)) atomicAdd(&hist[1023], (uint32_t)__builtin_popcountll(lm)); }
@@ -553,7 +563,7 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     for (int i0 = 0; i0 < per_list; i0 += 1024) {
         const int i = i0 + tid;
         const int tile = (i >> 2) * 8 + x;
-        const uint32_t w = (i < per_list && tile < ntiles) ? item_src[tile * 4 + (i & 3)] + idle : 0u;
+        const uint32_t w = (i < per_list && tile < ntiles) ? item_cost(item_src, hint, tile * 4 + (i & 3)) + idle : 0u;
         const bool lightest = w > 0u && (w >> 2) == 0u;
         const uint64_t lm = __builtin_amdgcn_ballot_w64(lightest);
         uint32_t pos = 0;
@@ -636,18 +646,18 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
 }
 
 void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int ntiles, int backward, void* bulk_zero, size_t bulk_zero_bytes,
-                             hipStream_t stream)
+                             const uint32_t* fwd_hint, hipStream_t stream)
 {
     const size_t f4 = bulk_zero ? bulk_zero_bytes / sizeof(float4) : 0;   // callers pass multiples of 16 bytes
     const unsigned extra = f4 ? (unsigned)((f4 + 8191) / 8192 < 504 ? (f4 + 8191) / 8192 : 504) : 0u;
     if (backward)
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
                            img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr,
-                           (float4*)bulk_zero, f4);
+                           (float4*)bulk_zero, f4, (const uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
                            img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work,
-                           (float4*)bulk_zero, f4);
+                           (float4*)bulk_zero, f4, fwd_hint);
 }
 
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,

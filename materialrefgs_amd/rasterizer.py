@@ -18,6 +18,27 @@ from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
 
 
 _PAIR_GUESS = {}   # device index -> pair capacity to try first (previous count + 25 %)
+# Per-camera work hints (MrgsRasterInputs::work_hint): the forward orders its blend waves by what each 8x8 block cost the last time the
+# same camera was rendered.  Keyed by the camera's matrices (the tensors a training loop keeps per camera), bounded, and purely a
+# scheduling aid: results do not depend on it.
+_WORK_HINTS = {}
+_NO_HINT = bool(int(__import__("os").environ.get("MRGS_NO_WORK_HINT", "0")))   # developer switch for A/B timing
+_WORK_HINTS_MAX = 2048
+
+
+def _work_hint(raster_settings, device):
+    if _NO_HINT:
+        return None
+    vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
+    key = (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr())
+    h = _WORK_HINTS.get(key)
+    if h is None:
+        if len(_WORK_HINTS) >= _WORK_HINTS_MAX:
+            _WORK_HINTS.pop(next(iter(_WORK_HINTS)))
+        n = _lib.lib().mrgs_work_hint_bytes(int(raster_settings.image_height), int(raster_settings.image_width)) // 4
+        h = torch.zeros(max(int(n), 1), dtype=torch.int32, device=device)
+        _WORK_HINTS[key] = h
+    return h
 LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (bench.py reads it for the roofline figure)
 
 
@@ -50,7 +71,8 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
                            int(bool(raster_settings.debug)))
     inp = MrgsRasterInputs(_ptr(raster_settings.bg), _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(features),
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
-                           _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos))
+                           _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
+                           _ptr(_work_hint(raster_settings, means3D.device)) if means3D.is_cuda else None)
     return cfg, inp
 
 

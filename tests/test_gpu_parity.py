@@ -178,6 +178,26 @@ def test_forward_on_a_capacity_guess_matches_the_two_phase_forward(gpu_device):
             assert rel_err(r[5][k], ref[5][k]) <= 1e-5, k
 
 
+def test_work_hints_only_change_the_schedule(gpu_device):
+    """MrgsRasterInputs::work_hint (per-camera work of the previous visit) reorders the blend waves and nothing else: first visit
+    (hint all zero), second visit (hint from the first) and a visit with a deliberately wrong hint give identical images."""
+    from materialrefgs_amd import rasterizer as rz
+    S, H, W = 4, 160, 120
+    scene = make_shell_scene(3000, S=S, seed=11, radius_px=6.0, image_size=160)
+    cam = orbit_camera(5, H, W)
+    rz._WORK_HINTS.clear()
+    a = HipRender(scene, cam, gpu_device)                   # hint zero -> cull counts
+    hints = [h for k, h in rz._WORK_HINTS.items() if k[1] == H and k[2] == W]
+    assert len(hints) >= 1 and int(sum(int(h.sum()) for h in hints)) > 0      # the forward stored its measured work
+    b = HipRender(scene, cam, gpu_device)                   # ordered by the measured work (if the same camera tensors are reused)
+    for h in hints:
+        h.copy_(torch.randint(1, 4000, h.shape, device=h.device, dtype=torch.int32))
+    c = HipRender(scene, cam, gpu_device)                   # garbage hint: still only a schedule
+    for r in (b, c):
+        assert r.num_rendered == a.num_rendered
+        assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others) and torch.equal(r.feature, a.feature)
+
+
 def test_mark_visible(gpu_device):
     from materialrefgs_amd.rasterizer import GaussianRasterizer
     from helpers import raster_settings
