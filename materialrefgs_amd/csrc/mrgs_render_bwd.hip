@@ -173,10 +173,10 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #endif
 
 #ifndef MRGS_BWD_WPE0
-#define MRGS_BWD_WPE0 4
+#define MRGS_BWD_WPE0 5
 #endif
 #ifndef MRGS_BWD_WPE8
-#define MRGS_BWD_WPE8 3
+#define MRGS_BWD_WPE8 4
 #endif
 template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? MRGS_BWD_WPE0 : S_MAX <= 8 ? MRGS_BWD_WPE8 : 2, 8))) render_bwd_kernel(
@@ -220,10 +220,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 
     const float T_final = inside ? final_Ts[pix] : 0.f;
     float T = T_final;
-    float accum_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f}, dL_dpixel[3] = {0.f, 0.f, 0.f};
-    float accum_rec_f[SF], last_feature[SF], dL_dpixel_f[SF];
+    // accum_* hold the reference's accum_rec recurrences (backward.cu:340-372) WITH the term of the entry processed last already
+    // folded in: the reference keeps last_alpha / last_color / last_depth / last_normal / last_feature and folds them at the start of
+    // the next entry; folding right after an entry's last use of accum_* is the same expression on the same operands, evaluated
+    // earlier -- bit-identical -- and frees 8 + S registers across the gradient reduction, which is where the kernel's register
+    // peak sits: 104 -> 96 VGPRs (5 waves per SIMD instead of 4) without feature channels, 140 -> 128 (4 instead of 3) with 8.
+    float accum_rec[3] = {0.f, 0.f, 0.f}, dL_dpixel[3] = {0.f, 0.f, 0.f};
+    float accum_rec_f[SF], dL_dpixel_f[SF];
 #pragma unroll
-    for (int i = 0; i < SF; i++) { accum_rec_f[i] = 0.f; last_feature[i] = 0.f; dL_dpixel_f[i] = 0.f; }
+    for (int i = 0; i < SF; i++) { accum_rec_f[i] = 0.f; dL_dpixel_f[i] = 0.f; }
     float dL_dreg = 0.f, dL_ddepth = 0.f, dL_daccum = 0.f, dL_dnormal2D[3] = {0.f, 0.f, 0.f}, dL_dmedian_depth = 0.f;
     // A pixel nothing was blended into takes no part in any sum; its upstream gradients are not even read (they may
     // hold non-finite values, e.g. from a division by the zero accumulated alpha, and the entry body below multiplies
@@ -244,12 +249,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 if (i < S) dL_dpixel_f[i] = dL_dpixels_f[(size_t)i * HW + pix];
         }
     }
-    float last_depth = 0.f, last_normal[3] = {0.f, 0.f, 0.f}, accum_depth_rec = 0.f, accum_alpha_rec = 0.f,
-          accum_normal_rec[3] = {0.f, 0.f, 0.f};
+    float accum_depth_rec = 0.f, accum_alpha_rec = 0.f, accum_normal_rec[3] = {0.f, 0.f, 0.f};
     const float final_D = inside ? final_Ts[pix + HW] : 0.f;
     const float final_D2 = inside ? final_Ts[pix + 2 * HW] : 0.f;
-    const float final_A = 1.0f - T_final;
-    float last_dL_dT = 0.f, last_alpha = 0.f;
+    float last_dL_dT = 0.f;
     const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
     const float dmd_scale = (MRGS_FAR_N * MRGS_NEAR_N) / (MRGS_FAR_N - MRGS_NEAR_N);
     const float bg_dot_dpixel = fmaf(bg[2], dL_dpixel[2], fmaf(bg[1], dL_dpixel[1], bg[0] * dL_dpixel[0]));
@@ -262,13 +265,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const ReduceLane rl = mrgs_reduce_lane(lane);
     const uint32_t row_bytes = (uint32_t)gstride * 4u;
     const int c_top = (max_contrib - 1) / MRGS_CHUNK;
-    uint32_t id1 = 0, id2 = 0, q1 = 0, q2 = 0;
+    // prefetched (surfel id, cull bits) of the two chunks ahead, one register each: the four cull bits ride in bits 28-31
+    // (P < 2^26: the gradient rows are addressed with 32-bit byte offsets)
+    uint32_t idq1 = 0, idq2 = 0;
     uint64_t mask_cur;
     {
         uint32_t id0 = 0, q0 = 0;
         if (c_top * MRGS_CHUNK + lane < max_contrib) { id0 = plist[c_top * MRGS_CHUNK + lane]; q0 = qm[c_top * MRGS_CHUNK + lane]; }
-        if (c_top >= 1) { id1 = plist[(c_top - 1) * MRGS_CHUNK + lane]; q1 = qm[(c_top - 1) * MRGS_CHUNK + lane]; }
-        if (c_top >= 2) { id2 = plist[(c_top - 2) * MRGS_CHUNK + lane]; q2 = qm[(c_top - 2) * MRGS_CHUNK + lane]; }
+        if (c_top >= 1) idq1 = plist[(c_top - 1) * MRGS_CHUNK + lane] | ((uint32_t)qm[(c_top - 1) * MRGS_CHUNK + lane] << 28);
+        if (c_top >= 2) idq2 = plist[(c_top - 2) * MRGS_CHUNK + lane] | ((uint32_t)qm[(c_top - 2) * MRGS_CHUNK + lane] << 28);
         const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         mrgs_stage_async<S_MAX, SF, FV>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
@@ -281,13 +286,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         WS_CHUNK();
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
-            const bool cand1 = (q1 >> quad) & 1u;
+            const bool cand1 = (idq1 >> (28 + quad)) & 1u;
+            const uint32_t id1 = idq1 & 0x0FFFFFFFu;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
-            id1 = id2; q1 = q2;
-            id2 = 0; q2 = 0;
-            if (c >= 3) { id2 = plist[(c - 3) * MRGS_CHUNK + lane]; q2 = qm[(c - 3) * MRGS_CHUNK + lane]; }
+            idq1 = idq2;
+            idq2 = 0;
+            if (c >= 3) idq2 = plist[(c - 3) * MRGS_CHUNK + lane] | ((uint32_t)qm[(c - 3) * MRGS_CHUNK + lane] << 28);
         };
         if (MRGS_BWD_STAGES == 2) stage_next();
 
@@ -322,49 +328,45 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             const float inv_1ma = mrgs_rcp(1.0f - alpha);
             T = T * inv_1ma;                                   // backward.cu:330
             const float w = alpha * T;
-            const float one_m_la = 1.0f - last_alpha;
+            const float one_m_a = 1.0f - alpha;                // the next entry's (1 - last_alpha)
             float dL_dalpha = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                accum_rec[ch] = fmaf(last_alpha, last_color[ch], one_m_la * accum_rec[ch]);
-                last_color[ch] = col[ch];
                 dL_dalpha = fmaf(col[ch] - accum_rec[ch], dL_dpixel[ch], dL_dalpha);
                 g[MRGS_G_COL + ch] = w * dL_dpixel[ch];
+                accum_rec[ch] = fmaf(alpha, col[ch], one_m_a * accum_rec[ch]);      // backward.cu:340-342, for the next entry
             }
             if (S_MAX > 0) {
 #pragma unroll
                 for (int ch = 0; ch < S_MAX; ch++) {
                     // no branch on the runtime S (see the forward): slots beyond S read as 0 and have dL_dpixel_f = 0
                     const float f = (FV || ch < S) ? mrgs_staged_feature<FV>(sb, ch, j) : 0.0f;
-                    accum_rec_f[ch] = fmaf(last_alpha, last_feature[ch], one_m_la * accum_rec_f[ch]);
-                    last_feature[ch] = f;
                     dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
                     g[MRGS_G_FEAT + ch] = w * dL_dpixel_f[ch];
+                    accum_rec_f[ch] = fmaf(alpha, f, one_m_a * accum_rec_f[ch]);
                 }
             }
             const float inv_cd = mrgs_rcp(c_d);
             const float m_d = mscale * (1.0f - MRGS_NEAR_N * inv_cd);
             const float dmd_dd = dmd_scale * inv_cd * inv_cd;
             float dL_dz = (active & (contributor == median_contributor - 1)) ? dL_dmedian_depth : 0.0f;
+            const float final_A = 1.0f - T_final;              // recomputed per entry: one instruction for one register
             const float dL_dweight = fmaf(-2.0f * m_d, final_D, fmaf(m_d * m_d, final_A, final_D2)) * dL_dreg;
             dL_dalpha += dL_dweight - last_dL_dT;
             last_dL_dT = fmaf(dL_dweight, alpha, (1.0f - alpha) * last_dL_dT);
             const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
             dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
-            accum_depth_rec = fmaf(last_alpha, last_depth, one_m_la * accum_depth_rec);
-            last_depth = c_d;
             dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
-            accum_alpha_rec = fmaf(one_m_la, accum_alpha_rec, last_alpha);
+            accum_depth_rec = fmaf(alpha, c_d, one_m_a * accum_depth_rec);
             dL_dalpha = fmaf(1.0f - accum_alpha_rec, dL_daccum, dL_dalpha);
+            accum_alpha_rec = fmaf(one_m_a, accum_alpha_rec, alpha);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                accum_normal_rec[ch] = fmaf(last_alpha, last_normal[ch], one_m_la * accum_normal_rec[ch]);
-                last_normal[ch] = normal[ch];
                 dL_dalpha = fmaf(normal[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
                 g[MRGS_G_NRM + ch] = w * dL_dnormal2D[ch];
+                accum_normal_rec[ch] = fmaf(alpha, normal[ch], one_m_a * accum_normal_rec[ch]);
             }
             dL_dalpha *= T;
-            last_alpha = alpha;
             dL_dalpha = fmaf(-T_final * inv_1ma, bg_dot_dpixel, dL_dalpha);
             dL_dalpha = active ? dL_dalpha : 0.0f;
             const float dL_dG = sg.g2.w * dL_dalpha;
