@@ -583,6 +583,9 @@ __global__ void __launch_bounds__(256) cubemap_filter_build_kernel(int N, int ki
 // The kernel streams its matrix from HBM once per call, so the matrix is kept small: 16-bit column indices when they fit and
 // 16-bit fixed-point weights with one fp32 scale per row (weight = q * scale[r], q in [0, 65535]: absolute error <= row
 // maximum / 131070 per weight, ~1e-6 of the result for the rows of hundreds of similar weights these filters have).
+#ifndef MRGS_SPMV_ROUNDS
+#define MRGS_SPMV_ROUNDS 4
+#endif
 template <int G, typename IDX, typename WT>
 __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
                                                         const WT* __restrict__ val, const float* __restrict__ row_scale,
@@ -592,7 +595,26 @@ __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_
     const int r = min(gid, nrows - 1);
     const uint32_t a = row_ptr[r], b = gid < nrows ? row_ptr[r + 1] : a;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    for (uint32_t k = a + sub; k < b; k += G) {
+    uint32_t k = a + sub;
+#ifndef MRGS_SPMV_NO_UNROLL
+    // The matrix streams from HBM (it does not survive in the last-level cache between two iterations of a training step) and a wave
+    // has only 2 x 128 bytes of it in flight per round: with every wave slot of the chip taken that is 2 MB against the ~8 MB that
+    // 8 TB/s x 1 us of latency want.  MRGS_SPMV_ROUNDS rounds of (index, weight) loads are issued before the first gather.
+    for (; k + (MRGS_SPMV_ROUNDS - 1) * G < b; k += MRGS_SPMV_ROUNDS * G) {
+        uint32_t c[MRGS_SPMV_ROUNDS];
+        float w[MRGS_SPMV_ROUNDS], v[MRGS_SPMV_ROUNDS][3];
+#pragma unroll
+        for (int u = 0; u < MRGS_SPMV_ROUNDS; ++u) { c[u] = col[k + u * G]; w[u] = (float)val[k + u * G]; }
+#pragma unroll
+        for (int u = 0; u < MRGS_SPMV_ROUNDS; ++u) {
+            const float* xv = x + 3 * (size_t)c[u];
+            v[u][0] = xv[0]; v[u][1] = xv[1]; v[u][2] = xv[2];
+        }
+#pragma unroll
+        for (int u = 0; u < MRGS_SPMV_ROUNDS; ++u) { s0 += w[u] * v[u][0]; s1 += w[u] * v[u][1]; s2 += w[u] * v[u][2]; }
+    }
+#endif
+    for (; k < b; k += G) {
         const float w = (float)val[k];
         const float* xv = x + 3 * (size_t)col[k];
         s0 += w * xv[0]; s1 += w * xv[1]; s2 += w * xv[2];
