@@ -28,6 +28,7 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, image, gt, rend_normal, surf_normal, rend_dist, image_weight, lambda_dssim, lambda_normal, lambda_dist):
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not image.is_cuda:
             raise RuntimeError("materialrefgs_amd.losses needs device tensors (libmrgs.so has no CPU path)")
         C, H, W = image.shape[-3:]
@@ -66,6 +67,8 @@ class _FusedLoss(torch.autograd.Function):
         use_n, use_d = ctx.use
         shp_i, shp_rn, shp_sn, shp_d = ctx.shapes
         cfg = ctx.cfg
+        if g_loss is None:
+            return (None,) * 9
         gl = g_loss.detach().float().contiguous()
         g_img = torch.empty_like(img)
         g_rn = torch.empty_like(rn) if use_n else None

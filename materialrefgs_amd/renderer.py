@@ -83,6 +83,7 @@ class _SurfelFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos):
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not xyz.is_cuda:
             raise RuntimeError("surfel_features needs CUDA(HIP) tensors: the per-gaussian glue runs in libmrgs.so, there is no CPU path")
         ts = [_c(t) for t in (xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos)]
@@ -217,6 +218,7 @@ class _SurfelMaps(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, allmap, fr, want_surf_normal, want_normal_map):
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not allmap.is_cuda:
             raise RuntimeError("the fused map kernels need CUDA(HIP) tensors; use compute_2dgs_normal_and_regularizations_reference on the CPU")
         allmap = _c(allmap)
@@ -252,6 +254,7 @@ class _SurfelComposite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, base, refl, spec, alpha, bg, srgb):
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         base, refl, spec, alpha, bg = _c(base), _c(refl), _c(spec), _c(alpha), _c(bg)
         H, W, dev = base.shape[1], base.shape[2], base.device
         render, diffuse = torch.empty_like(base), torch.empty_like(base)
