@@ -74,6 +74,10 @@ typedef struct MrgsRasterInputs {
                               passed (falling back to the cull count where it holds 0) and stores the work of this call.  A training
                               loop revisits the same cameras, so the previous visit predicts where rays terminate early far better than
                               any count available before the blend.  NULL: cull counts only.  Results do not depend on it. */
+    const float* shs_rest; /* optional: split SH layout.  When set, `shs` holds the DC coefficients [P,1,3] and shs_rest the higher orders
+                              [P,M-1,3] (M = 2..16) -- the two tensors GaussianModel stores (_features_dc / _features_rest,
+                              scene/gaussian_model.py:401-402), which the reference concatenates for every render (get_features,
+                              :256-259); MrgsRasterGrads::dL_dsh_rest must then be set too (dL_dsh receives [P,1,3]). */
 } MrgsRasterInputs;
 
 /* Workspace sizes.  geom <-> geomBuffer (GeometryState, rasterizer_impl.cu:157-172), img <-> imgBuffer
@@ -121,6 +125,7 @@ typedef struct MrgsRasterGrads {
     float* dL_dsh;         /* [P,M,3] */
     float* dL_dscales;     /* [P,2] */
     float* dL_drotations;  /* [P,4] */
+    float* dL_dsh_rest;    /* [P,M-1,3] with the split SH layout (MrgsRasterInputs::shs_rest; dL_dsh is then [P,1,3]), else NULL */
 } MrgsRasterGrads;
 
 /* Backward.  Replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:353-462).  The three

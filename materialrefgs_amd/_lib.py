@@ -25,12 +25,12 @@ class MrgsRasterConfig(ctypes.Structure):
 
 class MrgsRasterInputs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
-                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint")]
+                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint", "shs_rest")]
 
 
 class MrgsRasterGrads(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dfeatures", "dL_dopacity", "dL_dmeans3D",
-                                        "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations")]
+                                        "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dsh_rest")]
 
 
 MRGS_MAX_MIPS = 8

@@ -157,6 +157,7 @@ static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
         if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->campos || !in->bg) return MRGS_E_BAD_ARG;
         if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) return MRGS_E_NEED_COLORS;
         if (in->shs && cfg->M <= 0) return MRGS_E_BAD_ARG;
+        if (in->shs_rest && (!in->shs || cfg->M < 2 || cfg->M > 16)) return MRGS_E_BAD_ARG;   // split SH: DC + 1..15 higher coefficients
         const bool have_sr = in->scales && in->rotations;
         if (have_sr == (in->transMat_precomp != nullptr)) return MRGS_E_BAD_ARG;
         if (cfg->S > 0 && !in->features) return MRGS_E_BAD_ARG;
@@ -341,7 +342,8 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     if (!radii || !geom_ws || !binning_ws || !img_ws || !grad_ws || !dL_dout_color || !dL_dout_others) return MRGS_E_BAD_ARG;
     if (cfg->S > 0 && !dL_dout_feature) return MRGS_E_BAD_ARG;
     if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
-        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh))
+        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh) ||
+        ((in->shs_rest != nullptr) != (grads->dL_dsh_rest != nullptr)))
         return MRGS_E_BAD_ARG;
     const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);

@@ -134,15 +134,93 @@ __device__ __forceinline__ void wave_rows_store(const float* __restrict__ tile, 
     }
 }
 
+// Split SH layout (MrgsRasterInputs::shs_rest): the DC coefficients [P,1,3] and the higher orders [P,M-1,3] live in two tensors, as
+// GaussianModel stores them (_features_dc / _features_rest, scene/gaussian_model.py:401-402) -- the reference concatenates them for
+// every render (get_features, :256-259), a 58 MB copy each way at P = 300k.  A wave's 64 rows of either tensor are one contiguous,
+// 16-byte aligned range: copied with 16-byte accesses between global memory and the per-wave LDS tile, whose row layout
+// (DC first) is the one the unsplit path uses.
+__device__ __forceinline__ void wave_rows_load_split(float* __restrict__ tile, const float* __restrict__ dc, const float* __restrict__ rest,
+                                                     int nrows, int Lr, int lane)
+{
+    for (int t = lane; t < nrows * 3; t += 64) {
+        const int r = t / 3;
+        tile[r * SH_LDS_STRIDE + (t - 3 * r)] = dc[t];
+    }
+    if (Lr == 45 && nrows == 64 && (((uintptr_t)rest) & 15) == 0) {
+        const float4* src4 = reinterpret_cast<const float4*>(rest);      // 2880 floats = 720 float4
+        float4 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) v[k] = (k * 64 + lane < 720) ? src4[k * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            if (k * 64 + lane >= 720) continue;
+            const float q[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * (k * 64 + lane) + j, r = e / 45, c = e - 45 * r;
+                tile[r * SH_LDS_STRIDE + 3 + c] = q[j];
+            }
+        }
+        return;
+    }
+    const int total = nrows * Lr;
+    for (int t = lane; t < total; t += 64) {
+        const int r = t / Lr;
+        tile[r * SH_LDS_STRIDE + 3 + (t - Lr * r)] = rest[t];
+    }
+}
+__device__ __forceinline__ void wave_rows_store_split(const float* __restrict__ tile, float* __restrict__ dc, float* __restrict__ rest, int nrows,
+                                                      int Lr, int lane)
+{
+    for (int t = lane; t < nrows * 3; t += 64) {
+        const int r = t / 3;
+        dc[t] = tile[r * SH_LDS_STRIDE + (t - 3 * r)];
+    }
+    if (Lr == 45 && nrows == 64 && (((uintptr_t)rest) & 15) == 0) {
+        float4* dst4 = reinterpret_cast<float4*>(rest);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            if (k * 64 + lane >= 720) continue;
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * (k * 64 + lane) + j, r = e / 45, c = e - 45 * r;
+                q[j] = tile[r * SH_LDS_STRIDE + 3 + c];
+            }
+            dst4[k * 64 + lane] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        return;
+    }
+    const int total = nrows * Lr;
+    for (int t = lane; t < total; t += 64) {
+        const int r = t / Lr;
+        rest[t] = tile[r * SH_LDS_STRIDE + 3 + (t - Lr * r)];
+    }
+}
+
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, int W, int H, int tiles_x, int tiles_y, float scale_modifier, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ opacities,
-    const float* __restrict__ shs, const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
-    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    int32_t* __restrict__ radii, float4* __restrict__ rec, float4* __restrict__ cull, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order,
-    uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped, uint32_t* __restrict__ clear_ptr,
-    unsigned clear_words)
+    const float* __restrict__ shs, const float* __restrict__ shs_rest, const float* __restrict__ transMat_precomp,
+    const float* __restrict__ colors_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    const float* __restrict__ campos, int32_t* __restrict__ radii, float4* __restrict__ rec, float4* __restrict__ cull,
+    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order, uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ clear_ptr, unsigned clear_words)
 {
+    // SPLIT (shs = DC [P,1,3], shs_rest = [P,M-1,3]): the rows of the two tensors are staged through a per-wave LDS tile in the unsplit
+    // row layout; 180-byte rows cannot be fetched per lane with 16-byte loads the way the 192-byte rows of the unsplit tensor are
+    __shared__ float s_sh[SPLIT ? 4 * 64 * SH_LDS_STRIDE : 1];
+    if (SPLIT) {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        const int row0 = blockIdx.x * blockDim.x + wave_ * 64;
+        const int nrows = min(64, P - row0);
+        if (nrows > 0 && colors_precomp == nullptr)
+            wave_rows_load_split(s_sh + wave_ * 64 * SH_LDS_STRIDE, shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * (M - 1) * 3, nrows, (M - 1) * 3,
+                                 lane_);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     // first kernel of a forward: clears the per-call state of the later binning kernels (num_rendered, error flag, CU census,
     // tickets / totals / look-back words of the depth sort and the scan) instead of a separate memset launch
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < clear_words; i += gridDim.x * blockDim.x) clear_ptr[i] = 0u;
@@ -263,7 +341,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
                     rgb[c] = r > 0.0f ? r : 0.0f;
                 }
             };
-            if (M == 16) {
+            if (SPLIT) {
+                const float* row = s_sh + (size_t)threadIdx.x * SH_LDS_STRIDE;
+                shade([&](int i, int c) { return row[i * 3 + c]; });
+            } else if (M == 16) {
                 float row[48];
                 const float4* sh4 = reinterpret_cast<const float4*>(sh);   // 192-byte rows of a 16-byte aligned tensor
 #pragma unroll
@@ -348,10 +429,15 @@ void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
                                 hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H,
-                       tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs,
-                       in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec, g.cull,
-                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters, (unsigned)(g.clear_bytes / sizeof(uint32_t)));
+#define LAUNCH_PRE(SPLIT_)                                                                                                              \
+    hipLaunchKernelGGL(preprocess_fwd_kernel<SPLIT_>, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H, \
+                       tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs, in.shs_rest,     \
+                       in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec, g.cull,              \
+                       g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters,                                       \
+                       (unsigned)(g.clear_bytes / sizeof(uint32_t)))
+    if (in.shs_rest != nullptr && in.colors_precomp == nullptr) LAUNCH_PRE(true);
+    else LAUNCH_PRE(false);
+#undef LAUNCH_PRE
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -379,7 +465,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     const float4* __restrict__ rec, const float* __restrict__ grad_rec, int gstride, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeatures, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drotations)
+    float* __restrict__ dL_drotations, const float* __restrict__ shs_rest, float* __restrict__ dL_dsh_rest)
 {
     __shared__ float s_sh[4][64 * SH_LDS_STRIDE];
     const int idx_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,7 +476,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     const int row0 = blockIdx.x * blockDim.x + wave * 64;
     const int nrows = min(64, P - row0);
     if (sh_staged && shs != nullptr && nrows > 0) {
-        wave_rows_load(s_sh[wave], shs + (size_t)row0 * L, nrows, L, lane);
+        // (shs_rest: split layout, shs = DC rows; the tile holds the rows in the unsplit layout either way)
+        if (shs_rest != nullptr) wave_rows_load_split(s_sh[wave], shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * (L - 3), nrows, L - 3, lane);
+        else wave_rows_load(s_sh[wave], shs + (size_t)row0 * L, nrows, L, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -614,7 +702,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
         if (sh_staged) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (nrows > 0) wave_rows_store(s_sh[wave], dL_dsh + (size_t)row0 * L, nrows, L, lane);
+            if (nrows > 0) {
+                if (dL_dsh_rest != nullptr) wave_rows_store_split(s_sh[wave], dL_dsh + (size_t)row0 * 3, dL_dsh_rest + (size_t)row0 * (L - 3), nrows, L - 3, lane);
+                else wave_rows_store(s_sh[wave], dL_dsh + (size_t)row0 * L, nrows, L, lane);
+            }
         }
     }
     // the per-gaussian outputs leave through the wave's LDS tile as well (every lane of the wave is still here)
@@ -643,7 +734,7 @@ void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
                        cfg.H, cfg.tanfovx, cfg.tanfovy, in.means3D, in.scales, in.rotations, in.shs, in.transMat_precomp,
                        in.viewmatrix, in.projmatrix, in.campos, radii, g.clamped, g.rec, grad_rec, MRGS_GRAD_STRIDE(cfg.S),
                        out.dL_dmeans2D, out.dL_dcolors, out.dL_dfeatures, out.dL_dopacity, out.dL_dmeans3D, out.dL_dtransMat,
-                       out.dL_dsh, out.dL_dscales, out.dL_drotations);
+                       out.dL_dsh, out.dL_dscales, out.dL_drotations, in.shs_rest, out.dL_dsh_rest);
 }
 
 // checkFrustum, rasterizer_impl.cu:56-68

@@ -61,10 +61,12 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp):
+def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None):
     P = means3D.shape[0]
     S = features.shape[1] if features.dim() == 2 else 0
     M = sh.shape[1] if sh.numel() != 0 else 0
+    if sh_rest is not None:       # split layout: sh = DC [P,1,3], sh_rest = [P,M-1,3]
+        M = 1 + sh_rest.shape[1]
     cfg = MrgsRasterConfig(P, S, int(raster_settings.sh_degree), M, int(raster_settings.image_height),
                            int(raster_settings.image_width), float(raster_settings.tanfovx), float(raster_settings.tanfovy),
                            float(raster_settings.scale_modifier), int(bool(raster_settings.prefiltered)),
@@ -72,11 +74,12 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
     inp = MrgsRasterInputs(_ptr(raster_settings.bg), _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(features),
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
                            _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
-                           _ptr(_work_hint(raster_settings, means3D.device)) if means3D.is_cuda else None)
+                           _ptr(_work_hint(raster_settings, means3D.device)) if means3D.is_cuda else None, _ptr(sh_rest))
     return cfg, inp
 
 
-def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp):
+def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                              sh_rest=None):
     """Counterpart of `_C.rasterize_gaussians` (rasterize_points.cu:41-144)."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -85,7 +88,8 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
     L = _lib.lib()
     dev = means3D.device
     H, W = int(raster_settings.image_height), int(raster_settings.image_width)
-    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp)
+    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                                sh_rest)
     P, S = cfg.P, cfg.S
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -127,11 +131,13 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
 
 
 def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp,
-                               grad_out_color, grad_out_feature, grad_out_others, sh, opacities, geom, num_rendered, binning, img):
+                               grad_out_color, grad_out_feature, grad_out_others, sh, opacities, geom, num_rendered, binning, img,
+                               sh_rest=None):
     """Counterpart of `_C.rasterize_gaussians_backward` (rasterize_points.cu:146-252)."""
     L = _lib.lib()
     dev = means3D.device
-    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp)
+    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                                sh_rest)
     P, S, M = cfg.P, cfg.S, cfg.M
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -139,32 +145,36 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
         g = {"dL_dmeans2D": torch.empty((P, 3), **opts), "dL_dcolors": torch.empty((P, 3), **opts),
              "dL_dfeatures": torch.empty((P, S), **opts), "dL_dopacity": torch.empty((P, 1), **opts),
              "dL_dmeans3D": torch.empty((P, 3), **opts), "dL_dtransMat": torch.empty((P, 9), **opts),
-             "dL_dsh": torch.empty((P, M, 3), **opts), "dL_dscales": torch.empty((P, 2), **opts),
-             "dL_drotations": torch.empty((P, 4), **opts)}
+             "dL_dsh": torch.empty((P, 1 if sh_rest is not None else M, 3), **opts), "dL_dscales": torch.empty((P, 2), **opts),
+             "dL_drotations": torch.empty((P, 4), **opts),
+             "dL_dsh_rest": torch.empty((P, M - 1, 3), **opts) if sh_rest is not None else None}
         grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_])
         grad_ws = torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
         _lib.check(L.mrgs_rasterize_backward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
                                              num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),
                                              _ptr(grad_ws), ctypes.byref(grads), st))
     return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dfeatures"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dtransMat"],
-            g["dL_dsh"], g["dL_dscales"], g["dL_drotations"])
+            g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dsh_rest"])
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, sh_rest)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, sh_rest=None):
+        # sh_rest: split SH layout (extension over the reference's signature): sh = _features_dc [P,1,3], sh_rest = _features_rest
+        # [P,M-1,3] -- the model's own tensors, no torch.cat per render and no slicing of the gradient in its backward
         means3D, sh, colors_precomp, features = _f32c(means3D), _f32c(sh), _f32c(colors_precomp), _f32c(features)
+        sh_rest = None if sh_rest is None else _f32c(sh_rest)
         opacities, scales, rotations, cov3Ds_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_f32c(raster_settings.viewmatrix),
                                       projmatrix=_f32c(raster_settings.projmatrix), campos=_f32c(raster_settings.campos))
-        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp)
+        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted
             try:
@@ -180,7 +190,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.binning_pairs = binning_pairs   # pair count binningBuffer is carved for (>= num_rendered)
         ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
-                              geomBuffer, binningBuffer, imgBuffer, contrib)
+                              geomBuffer, binningBuffer, imgBuffer, contrib, sh_rest)
         ctx.mark_non_differentiable(contrib, radii)
         return contrib, color, feature, radii, depth
 
@@ -189,7 +199,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered = ctx.binning_pairs
         rs = ctx.raster_settings
         (colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
-         imgBuffer, contrib) = ctx.saved_tensors
+         imgBuffer, contrib, sh_rest) = ctx.saved_tensors
         H, W = int(rs.image_height), int(rs.image_width)
         S = features.shape[1] if features.dim() == 2 else 0
         dev = means3D.device
@@ -200,7 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_depth is None:
             grad_depth = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
         args = (rs, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp, _f32c(grad_out_color),
-                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer)
+                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])
             try:
@@ -212,7 +222,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             out = _rasterize_backward_native(*args)
         (grad_means2D, grad_colors_precomp, grad_features, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = out
+         grad_rotations, grad_sh_rest) = out
         # empty inputs (the `torch.Tensor([])` placeholders) get empty gradients of matching shape
         if sh.numel() == 0:
             grad_sh = None
@@ -224,7 +234,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if cov3Ds_precomp.numel() == 0:
             grad_cov3Ds_precomp = None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_features, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, None)
+                grad_rotations, grad_cov3Ds_precomp, None, grad_sh_rest)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -272,6 +282,13 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
         empty = torch.empty((0,), dtype=torch.float32, device=means3D.device)
+        # extension: shs may be the pair (features_dc [P,1,3], features_rest [P,M-1,3]) -- GaussianModel's own two tensors instead of
+        # their concatenation (get_features, scene/gaussian_model.py:256-259)
+        shs_rest = None
+        if isinstance(shs, (tuple, list)):
+            shs, shs_rest = shs
+            if shs.dim() != 3 or shs.shape[1] != 1 or shs_rest.dim() != 3 or shs_rest.shape[1] < 1 or shs_rest.shape[1] > 15:
+                raise Exception('split SHs must be (dc [P,1,3], rest [P,1..15,3])')
         if shs is None:
             shs = empty
         if colors_precomp is None:
@@ -286,4 +303,4 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = empty
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings)
+                                   raster_settings, shs_rest)

@@ -313,7 +313,7 @@ def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, o
     """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour)."""
     means2D = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
-    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=pc.get_xyz, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=None, opacities=pc.get_opacity,
         scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
@@ -336,7 +336,7 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     means2D = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
     means3D = pc.get_xyz
-    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)
 
     # activations, facing normal, mirror direction, indirect radiance along it and the feature concat (__init__.py:338-355):
     # one HIP kernel each way

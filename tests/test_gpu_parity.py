@@ -198,6 +198,41 @@ def test_work_hints_only_change_the_schedule(gpu_device):
         assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others) and torch.equal(r.feature, a.feature)
 
 
+@pytest.mark.parametrize("P,M,deg", [(3000, 16, 3), (4096, 16, 2), (777, 4, 1), (64, 9, 2)])
+def test_split_sh_layout_is_bit_identical(gpu_device, P, M, deg):
+    """shs = (features_dc [P,1,3], features_rest [P,M-1,3]) -- GaussianModel's own tensors -- gives the images and gradients of the
+    concatenated [P,M,3] tensor: images bit for bit, gradients to the reordering of the blend's atomics (full waves, a ragged last
+    wave, M < 16)."""
+    from helpers import raster_settings
+    from materialrefgs_amd.rasterizer import GaussianRasterizer
+    H, W = 96, 128
+    sc = make_shell_scene(P, S=0, seed=P, radius_px=6.0, image_size=128).to(gpu_device)
+    cam = orbit_camera(2, H, W)
+    rs = raster_settings(cam, gpu_device, deg, 1.0, None)
+    g_color, _, g_others = upstream_grads(0, H, W, device=gpu_device)
+    res = []
+    for split in (False, True):
+        leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, torch.zeros_like(sc.means3D), sc.opacities, sc.scales, sc.rotations)]
+        sh = sc.shs[:, :M].contiguous()
+        if split:
+            dc, rest = sh[:, :1].clone().requires_grad_(True), sh[:, 1:].clone().requires_grad_(True)
+            shs = (dc, rest)
+        else:
+            full = sh.clone().requires_grad_(True)
+            shs = full
+        _, color, _, radii, others = GaussianRasterizer(rs)(means3D=leaves[0], means2D=leaves[1], opacities=leaves[2], shs=shs,
+                                                            scales=leaves[3], rotations=leaves[4])
+        torch.autograd.backward([color, others], [g_color, g_others])
+        g_sh = torch.cat((dc.grad, rest.grad), dim=1) if split else full.grad
+        res.append((color.detach(), others.detach(), radii, g_sh, [t.grad for t in leaves]))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # gradients: same kernels, but the blend's fp32 atomics reorder sums from run to run
+    assert float(a[3].abs().max()) > 0 and rel_err(b[3].cpu().numpy(), a[3].cpu().numpy()) <= 1e-5
+    for x, y in zip(a[4], b[4]):
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) <= 1e-5
+
+
 def test_mark_visible(gpu_device):
     from materialrefgs_amd.rasterizer import GaussianRasterizer
     from helpers import raster_settings
