@@ -153,6 +153,16 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint
     if ((int64_t)blk * (SORT_THREADS * ITEMS) >= n) return;   // launched for the capacity, not needed for the actual count
     const int64_t wbase = (int64_t)blk * (SORT_THREADS * ITEMS) + (int64_t)wave * (64 * ITEMS) + lane;
     const uint64_t lt = lanemask_lt();
+    // All keys share this digit (the sign / high exponent byte of the depths of an ordinary scene): a stable pass is the identity,
+    // every workgroup sees it in the digit totals and just copies its tile -- no ranking, no look-back.
+    if (__syncthreads_or(totals[tid] == (uint32_t)n)) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+            const int64_t idx = wbase + it * 64;
+            if (idx < n) { kout[idx] = kin[idx]; vout[idx] = vin[idx]; }
+        }
+        return;
+    }
 
     uint32_t key[ITEMS], val[ITEMS], off[ITEMS];
 #pragma unroll
