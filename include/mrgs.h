@@ -393,7 +393,8 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
 typedef struct MrgsKernelTimes {
     float preprocess_ms, sort_ms, duplicate_ms, render_fwd_ms, render_bwd_ms, preprocess_bwd_ms;
 } MrgsKernelTimes;
-int mrgs_set_profiling(int32_t level);   /* 0 off, 1 every stage, 2 only the two blend kernels */
+int mrgs_set_profiling(int32_t level);   /* 0 off, 1 every stage, 2 only the two blend kernels, 3 the backward blend kernel on every
+                                            fourth call (an event pair costs two ~6 us bubbles on the stream) */
 int mrgs_get_kernel_times(MrgsKernelTimes* out);
 
 const char* mrgs_strerror(int code);
