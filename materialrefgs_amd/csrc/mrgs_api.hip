@@ -209,7 +209,7 @@ static int enqueue_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in,
 // R_dev != nullptr it is a capacity and the kernels take the actual count from device memory.
 static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, MrgsGeomWs g, MrgsBinWs b,
                           const MrgsImgWs& img, int64_t R, const uint32_t* R_dev, float* out_color, float* out_feature,
-                          float* out_others, hipStream_t stream)
+                          float* out_others, hipStream_t stream, uint32_t* host_slot = nullptr, hipEvent_t slot_event = nullptr)
 {
     const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
@@ -217,7 +217,8 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
 
     StageTimer t0(stream, ST_DUP);
     if (R > 0) {
-        mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, b, img, stream);
+        mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, b, img, host_slot, stream);
+        if (slot_event != nullptr) HIP_TRY(hipEventRecord(slot_event, stream));   // the host slot is written when this completes
     } else {   // nothing visible: no kernel touches the pair buffers, only the ranges have to read as empty
         HIP_TRY(hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream));
     }
@@ -294,10 +295,11 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
 }
 
 namespace {
-// pinned landing slot + event for the asynchronous num_rendered read-back of mrgs_rasterize_forward (one per host thread:
+// pinned, device-mapped landing slot + event for the asynchronous num_rendered read-back of mrgs_rasterize_forward (one per host thread:
 // the call waits for its own copy before it returns)
 struct ReadbackSlot {
     uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;    // device address of the same pinned words
     hipEvent_t ev = nullptr;
 };
 static thread_local ReadbackSlot g_slot;
@@ -320,15 +322,15 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
     MrgsBinWs b = mrgs_carve_bin(binning_ws, capacity_pairs);
     if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
     if (!g_slot.host) {
-        HIP_TRY(hipHostMalloc((void**)&g_slot.host, 64, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&g_slot.host, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&g_slot.dev, g_slot.host, 0));
         HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming));
     }
     rc = enqueue_geom(cfg, in, g, radii, stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(g_slot.host, g.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(g_slot.ev, stream));
-    // phase 2 is queued behind the copy without waiting for it: the kernels read the count from g.counters
-    rc = enqueue_render(cfg, in, g, b, img, capacity_pairs, g.counters, out_color, out_feature, out_others, stream);
+    // phase 2 is queued without waiting for the count: its kernels read it from g.counters, and the first of them stores it (and the
+    // error flag of phase 1) into the pinned host slot -- no copy-engine transfer in the middle of the stream
+    rc = enqueue_render(cfg, in, g, b, img, capacity_pairs, g.counters, out_color, out_feature, out_others, stream, g_slot.dev, g_slot.ev);
     if (rc) return rc;
     HIP_TRY(hipEventSynchronize(g_slot.ev));
     rc = check_counters(g_slot.host, num_rendered_host);

@@ -127,7 +127,8 @@ void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
 void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
-                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, const MrgsBinWs& b, const MrgsImgWs& img, hipStream_t stream);
+                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, const MrgsBinWs& b, const MrgsImgWs& img, uint32_t* host_slot,
+                           hipStream_t stream);
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,
                              uint8_t* qmask, const MrgsImgWs& img, int tiles_x, int ntiles, hipStream_t stream);
 // bulk_zero (nullable, 16-byte aligned, size a multiple of 16): cleared by extra workgroups of the same launch

@@ -378,8 +378,14 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* _
                                                         int tiles_x, uint32_t* __restrict__ tile_key, uint32_t* __restrict__ plist,
                                                         uint32_t capacity, const uint32_t* __restrict__ R_dev, uint32_t* __restrict__ census,
                                                         uint32_t* __restrict__ clear_a, unsigned words_a, uint32_t* __restrict__ clear_b,
-                                                        unsigned words_b)
+                                                        unsigned words_b, uint32_t* __restrict__ host_slot)
 {
+    // mrgs_rasterize_forward: the pair count and the error flag of the first phase go straight into the caller's pinned host slot
+    // (a copy engine transfer in the middle of the stream costs the copy and a ~6 us bubble)
+    if (host_slot != nullptr && R_dev != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(host_slot, R_dev[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 1, R_dev[1], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // first kernel of the second phase: clears the look-back state of the tile sort (clear_a) and the tile ranges + cull counts
     // (clear_b; rasterizer_impl.cu:316 clears the ranges) instead of two memset launches, and takes the CU census for the
     // work queues of the blend kernels (one flag per CU some wave of this launch runs on)
@@ -403,12 +409,13 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint32_t* _
 }
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,
-                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, const MrgsBinWs& b, const MrgsImgWs& img, hipStream_t stream)
+                           uint32_t* plist, int64_t capacity, const uint32_t* R_dev, const MrgsBinWs& b, const MrgsImgWs& img, uint32_t* host_slot,
+                           hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X;
     hipLaunchKernelGGL(duplicate_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, order, g.tiles_touched, g.offsets,
                        g.rect, tiles_x, tile_key, plist, (uint32_t)capacity, R_dev, g.counters + 16, b.sort_ws,
-                       (unsigned)(b.sort_ws_bytes / sizeof(uint32_t)), (uint32_t*)img.ranges, (unsigned)(img.ranges_est_bytes / sizeof(uint32_t)));
+                       (unsigned)(b.sort_ws_bytes / sizeof(uint32_t)), (uint32_t*)img.ranges, (unsigned)(img.ranges_est_bytes / sizeof(uint32_t)), host_slot);
 }
 
 // ---- identifyTileRanges (rasterizer_impl.cu:118-140) on the sorted tile ids + quadrant cull ------------------
