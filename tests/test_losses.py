@@ -162,3 +162,12 @@ def test_loss_needs_the_device():
     from materialrefgs_amd import losses
     with pytest.raises(RuntimeError):
         losses.l1_loss(torch.rand(3, 8, 8), torch.rand(3, 8, 8))
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_image_weight_matches_reference_get_img_grad_weight(tag):
+    """losses.image_weight (plain torch ops, evaluated once per camera) = (1 - get_img_grad_weight(gt)).clamp(0, 1) ** 2 of
+    utils/loss_utils.py:127-140 / train_refnerf.py:1178-1179."""
+    from materialrefgs_amd import losses
+    w = losses.image_weight(torch.from_numpy(GOLD[f"{tag}_gt"]))
+    np.testing.assert_allclose(w.numpy(), GOLD[f"{tag}_weight"], rtol=0, atol=1e-6)
