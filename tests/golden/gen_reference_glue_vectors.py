@@ -1,6 +1,6 @@
 """Generates tests/golden/reference_glue.npz by IMPORTING the reference's utils/point_utils.py and utils/refl_utils.py in the build
 container and running their own functions (depths_to_points, depth_to_normal, sample_camera_rays, sample_camera_rays_unnormalize,
-reflection) on seeded inputs, plus probe texels / statistics of the split-sum table the reference ships as a data file
+reflection; cube_to_dir and cubemap_mip.forward of scene/light_utils.py, loaded by file path) on seeded inputs, plus probe texels / statistics of the split-sum table the reference ships as a data file
 (assets/bsdf_256_256.bin, loaded by refl_utils at import).  Modules the image lacks and these functions never call (cv2, kornia,
 nvdiffrast, ...) are registered as empty placeholders so the import statements succeed; `.cuda()` is the identity.  Only inputs and
 outputs are committed; the reference source never travels.
@@ -49,6 +49,18 @@ for tag, (view, H, W) in {"a": (1, 40, 56), "b": (5, 33, 47)}.items():
     out[f"{tag}_n"] = n.numpy()
     wk, ndv = refl_utils.reflection(-rays_d, n)                                              # :95-98
     out[f"{tag}_refl"], out[f"{tag}_ndotv"] = wk.numpy(), ndv.numpy()
+
+# cube face convention and the box mip of the environment map (scene/light_utils.py:24-31, 66-69)
+import importlib.util  # noqa: E402
+spec = importlib.util.spec_from_file_location("ref_light_utils", os.path.join(REF, "scene", "light_utils.py"))   # the `scene` package pulls
+light_utils = importlib.util.module_from_spec(spec)                                                             # dataset readers in
+spec.loader.exec_module(light_utils)
+gy, gx = torch.meshgrid(torch.linspace(-0.9, 0.9, 5), torch.linspace(-0.8, 0.8, 4), indexing="ij")
+out["cube_xy"] = torch.stack((gx, gy)).numpy()
+out["cube_dirs"] = torch.stack([light_utils.cube_to_dir(s_, gx, gy) for s_ in range(6)]).numpy()               # [6,5,4,3]
+cube = torch.randn(6, 8, 8, 3, generator=g)
+out["mip_in"] = cube.numpy()
+out["mip_out"] = light_utils.cubemap_mip.forward(None, cube).numpy()
 
 lut = refl_utils.FG_LUT[0].numpy()                                                           # [256,256,2], :9
 probes = [(0, 0), (0, 255), (255, 0), (255, 255), (128, 128), (10, 200), (200, 10), (64, 32), (32, 64), (3, 3), (250, 5), (5, 250),
