@@ -269,7 +269,9 @@ def main():
                            "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(dom_ms, 4)}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
 
-        if not args.no_cpu_baseline and surfel_mode:
+        if world > 1:
+            pass                         # the CPU baseline and the oracle comparison belong to the N = 1 run only
+        elif not args.no_cpu_baseline and surfel_mode:
             out["cpu_baseline"] = None   # the C oracle covers the rasterizer only; use --workload C3 for its CPU baseline
         elif not args.no_cpu_baseline:
             from oracle import raster_oracle as ro
