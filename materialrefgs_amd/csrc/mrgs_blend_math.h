@@ -47,7 +47,27 @@ __device__ __forceinline__ uint32_t mrgs_pull_item(uint32_t* __restrict__ qstate
     return __builtin_amdgcn_readfirstlane(item);
 }
 
+#ifdef MRGS_EXACT_RCP   // developer build: correctly rounded division, to tell 1-ulp effects of v_rcp_f32 from real differences
+__device__ __forceinline__ float mrgs_rcp(float x) { return 1.0f / x; }
+#else
 __device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
+// 1 / p.z of the ray/splat intersection.  p.z cancels catastrophically for grazing surfels, s = p.xy / p.z feeds exp(-|s|^2 / 2), and
+// at a pixel where the resulting alpha sits on the 1/255 threshold one ulp of v_rcp_f32 can flip the surfel in or out of the blend: a
+// 1e-3 jump of ONE pixel, seen in 2 of 400 random scenes of tools/stress_parity.py (40 000 surfels on ~200 x 300 images) against the
+// oracle's IEEE division.  Building with EXTRA=-DMRGS_PZ_REFINED adds one Newton step, after which those scenes agree to 5e-7 as
+// well; it costs 2.3 % of the C2 step (the two instructions sit at the head of every entry's dependency chain), so it is not the
+// default -- the reference's own fmad contraction moves such pixels by more than that.
+#ifdef MRGS_PZ_REFINED
+__device__ __forceinline__ float mrgs_rcp_pz(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+#else
+__device__ __forceinline__ float mrgs_rcp_pz(float x) { return mrgs_rcp(x); }
+#endif
 
 // exp(x) for x <= 0 through v_exp_f32: 2^(x*log2e) with the rounding error of the product folded back in
 __device__ __forceinline__ float mrgs_exp(float x)
@@ -82,7 +102,7 @@ __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, fl
     const float ppx = fmaf(h.ky, h.lz, -(h.kz * h.ly));
     const float ppy = fmaf(h.kz, h.lx, -(h.kx * h.lz));
     const float ppz = fmaf(h.kx, h.ly, -(h.ky * h.lx));
-    h.inv_pz = mrgs_rcp(ppz);
+    h.inv_pz = mrgs_rcp_pz(ppz);
     h.sx = ppx * h.inv_pz;
     h.sy = ppy * h.inv_pz;
     h.rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);

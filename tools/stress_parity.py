@@ -34,7 +34,9 @@ for i in range(n):
         status = "ok"
     except AssertionError as e:
         bad += 1
-        status = "FAIL " + str(e)[:120].replace("\n", " ")
+        import traceback
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        status = f"FAIL line {tb.lineno}: {tb.line} | " + str(e)[:160].replace("\n", " ")
     print(f"[{i:3d}] P={P:6d} S={S:2d} {H}x{W} deg={deg} r={rpx:4.1f} view={view}: {status}", flush=True)
 print(f"{n - bad} of {n} cases passed in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
