@@ -12,42 +12,33 @@ import numpy as np
 import torch
 
 
-def get_world2view2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    """R is the camera-to-world rotation, t the world-to-camera translation (graphics_utils.py:37-49)."""
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = R.transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + translate) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float32(Rt)
+def get_world2view2(R, t, translate=(0.0, 0.0, 0.0), scale=1.0):
+    """World-to-view matrix of a camera given as (camera-to-world rotation R, world-to-camera translation t), with the optional
+    recentring / rescaling of the camera position the dataset readers use (same arithmetic as graphics_utils.py:37-49, so that the
+    float32 result is the reference's: two 4x4 inversions in float64, then the cast)."""
+    w2c = np.eye(4)
+    w2c[:3, :3] = np.asarray(R).T
+    w2c[:3, 3] = t
+    c2w = np.linalg.inv(w2c)
+    c2w[:3, 3] = (c2w[:3, 3] + np.asarray(translate, dtype=np.float64)) * scale
+    return np.linalg.inv(c2w).astype(np.float32)
 
 
 def get_projection_matrix(znear, zfar, fovX, fovY):
-    """graphics_utils.py:51-71."""
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
-    P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    return P
+    """OpenGL-style perspective matrix of a symmetric frustum with z pointing forward (graphics_utils.py:51-71): depth is mapped to
+    [0, 1] by rows 2 and 3, x / y by the frustum half-extents at the near plane."""
+    half_w, half_h = math.tan(0.5 * fovX) * znear, math.tan(0.5 * fovY) * znear
+    x0, x1, y0, y1 = -half_w, half_w, -half_h, half_h                    # left, right, bottom, top
+    rows = [[2.0 * znear / (x1 - x0), 0.0, (x1 + x0) / (x1 - x0), 0.0],
+            [0.0, 2.0 * znear / (y1 - y0), (y1 + y0) / (y1 - y0), 0.0],
+            [0.0, 0.0, zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)],
+            [0.0, 0.0, 1.0, 0.0]]
+    return torch.tensor(rows, dtype=torch.float32)
 
 
 def fov2focal(fov, pixels):
-    return pixels / (2 * math.tan(fov / 2))
+    """Focal length in pixels of a pinhole with field of view `fov` across `pixels` (graphics_utils.py:73-74)."""
+    return 0.5 * pixels / math.tan(0.5 * fov)
 
 
 class MiniCam(NamedTuple):
