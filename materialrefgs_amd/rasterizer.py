@@ -43,8 +43,8 @@ LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (
 
 
 def cpu_deep_copy_tuple(input_tuple):
-    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
-    return tuple(copied_tensors)
+    """Host copies of the tensors of an argument tuple (for the snapshot_*.dump files of debug mode); other items pass through."""
+    return tuple(x.detach().cpu().clone() if torch.is_tensor(x) else x for x in input_tuple)
 
 
 def _ptr(t):
