@@ -37,6 +37,10 @@ class GradBucket:
 
     def pack(self, tensors: Sequence[Optional[torch.Tensor]]):
         assert len(tensors) == len(self.shapes)
+        if all(t is not None and t.dtype == self.flat.dtype and t.device == self.flat.device for t in tensors):
+            # one concatenation kernel instead of a copy launch per tensor (a dozen small launches per step at N > 1)
+            torch.cat([t.reshape(-1) for t in tensors], out=self.flat)
+            return self.flat
         for t, o, n in zip(tensors, self.offsets, self.numels):
             if t is None:
                 self.flat[o:o + n].zero_()
@@ -109,7 +113,7 @@ class FactoredGradReducer:
         if sh is None:
             self.row[:3 * P].zero_()
         else:
-            self.row[:3 * P].copy_((sh[:, 0, :] / SH_C0).reshape(-1))
+            torch.div(sh[:, 0, :], SH_C0, out=self.row[:3 * P].view(P, 3))
         self.row[3 * P:].copy_(campos.reshape(-1))
         if self.gathered is None or self.gathered.shape[0] != world:
             self.gathered = torch.empty((world, 3 * P + 3), dtype=torch.float32, device=self.row.device)
@@ -195,7 +199,7 @@ class SurfelGradReducer:
             if t is None:
                 seg.zero_()
             else:
-                seg.copy_((t[:, 0, :] / SH_C0).reshape(-1))
+                torch.div(t[:, 0, :], SH_C0, out=seg.view(P, 3))
         self.row[6 * P:].copy_(campos.reshape(-1))
         if self.gathered is None or self.gathered.shape[0] != world:
             self.gathered = torch.empty((world, 6 * P + 3), dtype=torch.float32, device=self.row.device)
