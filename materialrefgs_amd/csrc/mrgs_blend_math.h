@@ -15,20 +15,42 @@
 #define MRGS_T_MIN 0.0001f
 #define MRGS_CHUNK 64   // list entries staged per step = one per lane
 
+// waves of a one-wave-workgroup kernel that one SIMD keeps resident (registers and LDS of that instance), asked once
+template <auto KERNEL> static int mrgs_waves_per_simd()
+{
+    static const int n = [] {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 64, 0) != hipSuccess || per_cu < 4) return 1;
+        return per_cu / 4;
+    }();
+    return n;
+}
+
 
 // Work-item pull shared by the two blend kernels (queues built by blend_order_kernel, mrgs_sort.hip).  Wave `wv` of XCD
 // list `xcd` (blockIdx = wv * 8 + xcd: blockIdx % 8 selects the XCD) takes the next item from the queue of the SIMD it runs
-// on and falls back to the other queues of the list when its own is empty.  Exactly n_items waves of a list take part and
-// exactly n_items tickets are valid, so every participant ends up with one item.  Returns 0xFFFFFFFF for "no work",
-// otherwise tile << 2 | quadrant, with the wave's issue priority in bits 29-30.
+// on.  passes * NQ waves of a list take part -- one per queue SLOT, not one per item.  When the whole launch is resident at
+// once (C2 backward: 4.47 items per SIMD, 5 wave slots) the hardware fills every SIMD with `passes` waves, each queue is
+// drained by waves of its own SIMD, and the load of a SIMD is the load blend_order_kernel dealt to it.  With one wave per item
+// the hardware chose which half of the SIMDs got a fifth wave, those waves took whatever fifth item was left anywhere (after
+// a lane-0 walk over the queues that cost them 20-65 us), and the most loaded SIMD carried 1.20x the mean load instead of
+// 1.08x; the backward blend is issue-bound per SIMD (finish time of a SIMD against its load: r = 0.93), so that was its
+// duration.
+// A wave that finds nothing in its own queue (the spare wave of a queue whose slot of the last, partly filled pass is empty;
+// or uneven placement) looks through the other queues, 64 per round trip, takes what is left and otherwise retires.  Tickets
+// only grow, so a wave that saw every queue exhausted leaves nothing behind, and every item is handed out exactly once.
+// The planned spare wave waits ~4 us first when the launch fits the machine (`slots` waves per SIMD hold a whole queue), so
+// that the owners of the other queues have taken their tickets; when the launch is larger than the machine waves arrive as
+// slots free up, that is the dynamic part of the schedule, and nobody waits.
+// Returns 0xFFFFFFFF for "no work", otherwise tile << 2 | quadrant, with the wave's issue priority in bits 29-30.
 __device__ __forceinline__ uint32_t mrgs_pull_item(uint32_t* __restrict__ qstate, const uint32_t* __restrict__ cu_state,
-                                                   const uint32_t* __restrict__ assign_ws, int ntiles, int xcd, int wv, int lane)
+                                                   const uint32_t* __restrict__ assign_ws, int ntiles, int xcd, int wv, int lane,
+                                                   int slots, unsigned long long* dbg = nullptr)
 {
-    const int n_items = (int)qstate[MRGS_QS_COUNT + xcd];
-    if (wv >= n_items) return 0xFFFFFFFFu;
-    const int per_list = ((ntiles + 7) >> 3) * 4;
     const uint32_t pw = qstate[MRGS_QS_PASSES + xcd];
     const int passes = (int)(pw & 0xFFFFu), NQ = (int)(pw >> 16);
+    if (wv >= passes * NQ) return 0xFFFFFFFFu;
+    const int per_list = ((ntiles + 7) >> 3) * 4;
     const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));              // HW_REG_HW_ID
     const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;           // HW_REG_XCC_ID
     const uint32_t dense = cu_state[MRGS_CS_DENSE + xcc * 256 + mrgs_cu_key(hw_id)];
@@ -36,15 +58,35 @@ __device__ __forceinline__ uint32_t mrgs_pull_item(uint32_t* __restrict__ qstate
     const uint32_t* assign = assign_ws + (size_t)xcd * (per_list + MRGS_MAX_SIMD_QUEUES);
     uint32_t* tickets = qstate + MRGS_QS_TICKET + xcd * MRGS_MAX_SIMD_QUEUES;
     uint32_t item = 0xFFFFFFFFu;
+    int t = 0;
     if (lane == 0) {
-        for (int d = 0; d < NQ && item == 0xFFFFFFFFu; d++) {
-            const int q = q0 + d < NQ ? q0 + d : q0 + d - NQ;
-            if (d > 0 && __hip_atomic_load(&tickets[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)passes) continue;
-            const int t = (int)atomicAdd(&tickets[q], 1u);
-            if (t < passes) item = assign[t * NQ + q];
-        }
+        t = (int)atomicAdd(&tickets[q0], 1u);
+        if (t < passes) item = assign[t * NQ + q0];
     }
-    return __builtin_amdgcn_readfirstlane(item);
+    item = __builtin_amdgcn_readfirstlane(item);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (dbg) { dbg[0] = dbg[2] = wall_clock64(); dbg[1] = 0; }
+    if (item != 0xFFFFFFFFu) return item;
+    if (t < passes && passes <= slots) __builtin_amdgcn_s_sleep(127);
+    for (int base = 1; item == 0xFFFFFFFFu && base < NQ;) {
+        const int d = base + lane;
+        const int q = d < NQ ? (q0 + d < NQ ? q0 + d : q0 + d - NQ) : q0;
+        // (a queue whose slot of the last pass is empty is exhausted one ticket earlier)
+        const uint32_t tk = __hip_atomic_load(&tickets[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t last = assign[(passes - 1) * NQ + q];
+        const bool has = d < NQ && (int)tk < passes - (last == 0xFFFFFFFFu ? 1 : 0);
+        const unsigned long long m = __ballot(has);
+        if (dbg) dbg[1] += 1 + (m == 0ull ? 256 : 0);
+        if (m == 0ull) { base += 64; continue; }
+        const int qs = __builtin_amdgcn_readlane(q, (int)__builtin_ctzll(m));
+        if (lane == 0) {
+            const int ts = (int)atomicAdd(&tickets[qs], 1u);
+            if (ts < passes) item = assign[ts * NQ + qs];
+        }
+        item = __builtin_amdgcn_readfirstlane(item);   // lost the race for that ticket: look again from the same base
+    }
+    if (dbg) dbg[2] = wall_clock64();
+    return item;
 }
 
 #ifdef MRGS_EXACT_RCP   // developer build: correctly rounded division, to tell 1-ulp effects of v_rcp_f32 from real differences

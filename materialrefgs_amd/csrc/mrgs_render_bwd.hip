@@ -159,13 +159,17 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stats), sizeof(unsigned long long) * n);
 }
+#define WS_ENTRY() const unsigned long long ws_te = wall_clock64(); unsigned long long ws_dbg[3];
+#define WS_DBG , ws_dbg
 #define WS_BEGIN() const unsigned long long ws_t0 = wall_clock64(), ws_c0 = __builtin_amdgcn_s_memtime(); unsigned ws_iters = 0, ws_act = 0, ws_chunks = 0;
 #define WS_ITER(a) { ws_iters++; ws_act += (a) ? 1 : 0; }
 #define WS_CHUNK() ws_chunks++;
-#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 8 * (size_t)b; w[6] = 0; w[7] = 0; w[0] = ws_t0; w[1] = wall_clock64(); \
+#define WS_END() if (lane == 0 && b < 65536) { unsigned long long* w = g_wave_stats + 8 * (size_t)b; w[6] = ((ws_dbg[0] - ws_te) << 40) | ((ws_dbg[2] - ws_te) << 16) | ws_dbg[1]; w[7] = ws_te; w[0] = ws_t0; w[1] = wall_clock64(); \
         w[2] = __builtin_amdgcn_s_memtime() - ws_c0; w[3] = ((unsigned long long)ws_iters << 32) | ws_act; w[4] = ((unsigned long long)ws_chunks << 32) | (unsigned)max_contrib; \
         w[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); }
 #else
+#define WS_ENTRY()
+#define WS_DBG
 #define WS_BEGIN()
 #define WS_ITER(a)
 #define WS_CHUNK()
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride)
+    const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride, int slots)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     constexpr int K = 16 + S_MAX;   // values through the transposing reduction (the dL/dmean2D pair goes apart)
@@ -192,7 +196,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_BWD, blend_state + MRGS_CS_BASE, bwd_assign, ntiles, b & 7, b >> 3, lane);
+    WS_ENTRY();
+    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_BWD, blend_state + MRGS_CS_BASE, bwd_assign, ntiles, b & 7, b >> 3, lane, slots WS_DBG);
     if (item == 0xFFFFFFFFu) return;
     const int tile = (int)((item & 0x1FFFFFFFu) >> 2), quad = (int)(item & 3u);
     const uint32_t prio = (item >> 29) & 3u;
@@ -439,11 +444,12 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // one wave per (tile, quadrant); blockIdx % 8 = XCD list
+    // one wave per slot of the work queues (mrgs_pull_item): items rounded up to whole dealing passes; blockIdx % 8 = XCD list
+    const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV, GS)                                                                                                       \
     hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.bwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS)
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<render_bwd_kernel<SM, FVV>>())
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
     uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */,
-    uint32_t* __restrict__ work_hint)
+    uint32_t* __restrict__ work_hint, int slots)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const int lane = threadIdx.x;
     // XCD-aware mapping: b % 8 selects the XCD; within an XCD consecutive blocks are the 4 quadrants of one tile
     const int b = blockIdx.x;
-    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_FWD, blend_state + MRGS_CS_BASE, fwd_assign, ntiles, b & 7, b >> 3, lane);
+    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_FWD, blend_state + MRGS_CS_BASE, fwd_assign, ntiles, b & 7, b >> 3, lane, slots);
     if (item == 0xFFFFFFFFu) return;
     const int tile = (int)((item & 0x1FFFFFFFu) >> 2), quad = (int)(item & 3u);
     const uint32_t prio = (item >> 29) & 3u;
@@ -235,11 +235,12 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
-    const int nblocks = ((ntiles + 7) / 8) * 8 * 4;   // one wave per (tile, quadrant); blockIdx % 8 = XCD list
+    // one wave per slot of the work queues (mrgs_pull_item): items rounded up to whole dealing passes; blockIdx % 8 = XCD list
+    const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
     hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint)
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<render_fwd_kernel<SM, FVV>>())
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
     if (cfg.S == 0) LAUNCH(0, false);

@@ -496,8 +496,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t* __rest
 // This kernel (one workgroup per XCD list; list x = the tiles t with t % 8 == x, so that the four quadrant waves of a tile
 // share one L2) counting-sorts the work items (tile, quadrant) with work > 0 by decreasing work and deals them to one
 // queue per SIMD of an XCD in passes of NQ items; in every pass the heaviest item goes to the queue with the smallest load
-// so far (LPT per pass).  A blend wave pulls from the queue of the SIMD it finds itself on and steals from the other queues
-// when its own is empty (mrgs_pull_item): nothing depends on how the hardware places waves.
+// so far (LPT per pass).  The blend kernels launch one wave per queue slot (passes * NQ per list); a wave pulls from the queue
+// of the SIMD it finds itself on and looks through the other queues when its own is empty (mrgs_pull_item): correctness does
+// not depend on how the hardware places waves, the balance of a launch that fits the machine relies on it filling all SIMDs
+// evenly (it does: 1.09x the mean load on the most loaded SIMD, measured, against 1.08x dealt).
 // Work per item: the forward uses the cull counts of tile_ranges_kernel, the backward what the forward waves actually walked.
 // The first call of a forward also turns the CU census (bits set by the preprocess waves) into a dense CU numbering.
 // Work of an item.  Forward with a hint buffer (MrgsRasterInputs::work_hint): what the item's wave measured the last time this

@@ -63,20 +63,18 @@ print(f"CUs used {len(ucu)}; active iters/CU mean {loadc.mean():.0f} p10 {np.per
 xl = np.bincount(xcc, weights=act)
 print("active iters per XCC:", [int(v) for v in xl])
 
-w6 = a[:, 6]; rank = (w6 & np.uint64(0xffffffff)).astype(np.int64); kk = ((w6 >> np.uint64(32)) & np.uint64(0xff)).astype(np.int64); dist = ((w6 >> np.uint64(48)) & np.uint64(1)).astype(np.int64)
-print(f"waves in workgroups with 4 distinct SIMDs: {dist.mean()*100:.1f}%")
-for c in range(4):
-    m = kk == c
-    print(f"  class {c}: waves {m.sum()} mean active {act[m].mean():.0f} mean iters {iters[m].mean():.0f}")
-print("corr(rank, active) = %.3f  corr(rank, iters) = %.3f" % (np.corrcoef(rank, act)[0,1], np.corrcoef(rank, iters)[0,1]))
-# SIMD composition by class
-comp = np.zeros((len(uk), 4)); np.add.at(comp, (inv, kk), 1)
-print("SIMDs whose first-round waves hold one of each class:", int(((comp >= 1).all(axis=1)).sum()), "of", len(uk))
+print("corr(SIMD load in active iters, SIMD finish time) = %.3f   most loaded SIMD / mean = %.3f" % (np.corrcoef(load, last)[0, 1], load.max() / load.mean()))
 wcu = np.bincount(invc)
-print("waves per CU histogram:", dict(zip(*np.unique(wcu, return_counts=True))))
-grp = rank // 4
-for c in range(3):
-    m = invc == c
-    print(f"  CU {c}: xcc {xcc[m][0]} groups {sorted(set(grp[m].tolist()))} start {sorted(set(np.round(t0[m]).astype(int).tolist()))} active {act[m].sum():.0f}")
-gw = np.bincount(grp, weights=act)
-print("group weights (first 12, then every 16th):", [int(v) for v in gw[:12]], [int(v) for v in gw[::16]])
+print("waves per CU histogram:", {int(k): int(v) for k, v in zip(*np.unique(wcu, return_counts=True))})
+if not FWD:
+    # backward build: w[7] = time at kernel entry, w[6] = (own-queue ticket done, pull done) relative to it | scan rounds
+    te = (a[:, 7].astype(np.int64) - a[:, 0].min().astype(np.int64)) * 0.01
+    d0 = (a[:, 6] >> np.uint64(40)).astype(np.float64) * 0.01
+    d2 = ((a[:, 6] >> np.uint64(16)) & np.uint64(0xffffff)).astype(np.float64) * 0.01
+    rounds = (a[:, 6] & np.uint64(0xffff)).astype(np.int64)
+    print("kernel entry (us) p0/50/100:", np.round(np.percentile(te, [0, 50, 100]), 1), " own ticket done after:", np.round(np.percentile(d0, [0, 50, 100]), 1),
+          " pull done after:", np.round(np.percentile(d2, [0, 50, 99, 100]), 1), " waves that looked in other queues:", int((rounds > 0).sum()))
+for lo, hi in ((0, 50), (50, 100), (100, 150), (150, 200), (200, 300), (300, 400), (400, 100000)):
+    m = (act >= lo) & (act < hi)
+    if m.sum():
+        print(f"  active [{lo},{hi}): waves {m.sum()} duration mean {dur[m].mean():.1f} max {dur[m].max():.1f} us, end max {t1[m].max():.1f}, us per active iter {dur[m].sum() / max(act[m].sum(), 1):.3f}")
