@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         // pixel already terminated, or terminating right now) runs the accumulation with alpha = 0 -- every sum gets
         // + x * 0 with a finite x, T gets * 1 -- and the depth, the only operand that can be non-finite for such a lane, is
         // replaced.  The results are bit-identical to skipping the entry.
-        auto blend_entry = [&](const SurfelGeom& sg, int j) {
+        // (a0, a1: normal and color of the entry, fetched together with its geometry one entry ahead -- inside the branch
+        // below their LDS latency sat on the critical path of the longest waves, which set the duration of this kernel)
+        auto blend_entry = [&](const SurfelGeom& sg, const float4& a0, const float2& a1, int j) {
             Hit h;
             const bool hit = mrgs_intersect(sg, px, py, h);
             const bool ok = hit & !done;
@@ -129,7 +131,6 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             ws_blend++;
 #endif
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
-            const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
             const float test_T = T * (1.0f - h.alpha);
             const bool term = ok & (test_T < MRGS_T_MIN);     // forward.cu:400-404: the pixel stops BEFORE blending this entry
             done |= term;
@@ -168,19 +169,23 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             int j = __builtin_ctzll(m);
             SurfelGeom sA, sB;
             sA.g0 = sb.rec[0][j]; sA.g1 = sb.rec[1][j]; sA.g2 = sb.rec[2][j];
+            float4 tA0 = sb.rec[3][j], tB0;
+            float2 tA1 = *reinterpret_cast<const float2*>(&sb.rec[4][j]), tB1;
             while (true) {
                 m &= m - 1;
                 bool more = m != 0ull;
                 int jn = more ? __builtin_ctzll(m) : j;
                 sB.g0 = sb.rec[0][jn]; sB.g1 = sb.rec[1][jn]; sB.g2 = sb.rec[2][jn];
-                blend_entry(sA, j);
+                tB0 = sb.rec[3][jn]; tB1 = *reinterpret_cast<const float2*>(&sb.rec[4][jn]);
+                blend_entry(sA, tA0, tA1, j);
                 if (!more) break;
                 j = jn;
                 m &= m - 1;
                 more = m != 0ull;
                 jn = more ? __builtin_ctzll(m) : j;
                 sA.g0 = sb.rec[0][jn]; sA.g1 = sb.rec[1][jn]; sA.g2 = sb.rec[2][jn];
-                blend_entry(sB, j);
+                tA0 = sb.rec[3][jn]; tA1 = *reinterpret_cast<const float2*>(&sb.rec[4][jn]);
+                blend_entry(sB, tB0, tB1, j);
                 if (!more) break;
                 j = jn;
             }
