@@ -267,6 +267,18 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(dom_ms, 4)}
+        # The dominant kernel is fp32 VALU work (no matrix shape in it) and sits at the VALU issue rate, not at the HBM rate the
+        # required fields above price it against: the committed SQ counter pass says how close.
+        sq_path = os.path.join(ROOT, "profiles", "pmc_sq.json")
+        if os.path.exists(sq_path):
+            try:
+                sq = json.load(open(sq_path)).get(args.workload, {}).get(dom)
+                if sq:
+                    out["roofline"]["valu_issue"] = {"cycles_per_inst_per_simd": sq["cycles_per_valu_inst_per_simd"], "peak": 4.0,
+                                                     "frac": round(4.0 / sq["cycles_per_valu_inst_per_simd"], 3),
+                                                     "insts_per_launch": sq["valu_insts_per_launch"], "source": "profiles/pmc_sq.json"}
+            except Exception:
+                pass
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
 
         if world > 1:
