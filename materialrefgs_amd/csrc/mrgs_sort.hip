@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint
     }
     uint32_t all;
     const uint32_t digit_base = block_exclusive_scan<SORT_THREADS>(totals[tid], scan_tmp, all);
+#ifdef MRGS_SORT_DIRECT_SCATTER
     start[tid] = digit_base + excl;
     if (__syncthreads_or(!ok)) {
         if (tid == 0) atomicExch(error_flag, 1u);
@@ -226,6 +227,41 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_onesweep_kernel(const uint
             vout[pos] = val[it];
         }
     }
+#else
+    // The tile is put in digit order in LDS first and leaves in runs: consecutive threads then store to consecutive addresses
+    // of a run (a wave's 64 stores touch a handful of cache lines), where storing straight from the ranking registers sends the
+    // 64 keys of a wave instruction to up to 64 different runs.
+    __shared__ uint32_t s_key[SORT_THREADS * ITEMS], s_val[SORT_THREADS * ITEMS];
+    __shared__ uint32_t lstart[256];
+    uint32_t tile_n;
+    const uint32_t lbase = block_exclusive_scan<SORT_THREADS>(cnt, scan_tmp, tile_n);   // digit runs inside the tile
+    lstart[tid] = lbase;
+    start[tid] = digit_base + excl - lbase;                                              // global position of local position 0 of the run
+    if (__syncthreads_or(!ok)) {
+        if (tid == 0) atomicExch(error_flag, 1u);
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        if (wbase + it * 64 < n) {
+            const uint32_t d = (key[it] >> shift) & 255u;
+            const uint32_t lp = lstart[d] + whist[wave][d] + off[it];
+            s_key[lp] = key[it];
+            s_val[lp] = val[it];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t e = (uint32_t)(it * SORT_THREADS + tid);
+        if (e < tile_n) {
+            const uint32_t k = s_key[e];
+            const uint32_t pos = start[(k >> shift) & 255u] + e;
+            kout[pos] = k;
+            vout[pos] = s_val[e];
+        }
+    }
+#endif
 }
 
 // tile size of the passes for n keys: enough workgroups to fill 256 CUs for small inputs, longer tiles (shorter look-back
