@@ -118,10 +118,19 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_totals_kernel(const uint32
 #pragma unroll
     for (int p = 0; p < NPASS; p++) h[p][tid] = 0;
     __syncthreads();
-    for (int64_t idx = (int64_t)blockIdx.x * SORT_THREADS + tid; idx < n; idx += (int64_t)gridDim.x * SORT_THREADS) {
-        const uint32_t k = keys[idx];
+    // eight keys in flight per thread: a rolled load -> LDS-atomic loop waits for every load's round trip in turn
+    const int64_t stride = (int64_t)gridDim.x * SORT_THREADS;
+    for (int64_t base = (int64_t)blockIdx.x * SORT_THREADS + tid; base < n; base += 8 * stride) {
+        uint32_t k[8];
 #pragma unroll
-        for (int p = 0; p < NPASS; p++) atomicAdd(&h[p][(k >> (bit_lo + 8 * p)) & 255u], 1u);
+        for (int j = 0; j < 8; j++) k[j] = base + j * stride < n ? keys[base + j * stride] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (base + j * stride < n) {
+#pragma unroll
+                for (int p = 0; p < NPASS; p++) atomicAdd(&h[p][(k[j] >> (bit_lo + 8 * p)) & 255u], 1u);
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
