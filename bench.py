@@ -56,6 +56,44 @@ def algorithmic_bytes(kernel, P, R, HW, S):
     raise KeyError(kernel)
 
 
+def spawn_ranks(n):
+    """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plumbing_only(args, world, rank):
+    """Launch-path check (tests/test_dist_cpu.py): every rank joins the group, one flat gradient bucket goes through the
+    all-reduce, rank 0 prints a line that says what it is.  Nothing is rendered and nothing here is a measurement."""
+    from materialrefgs_amd import dist as mdist
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if torch.cuda.is_available() and \
+        os.environ.get("MRGS_DIST_BACKEND") != "gloo" else torch.device("cpu")
+    shapes = [torch.Size((1000, 3)), torch.Size((1000, 1)), torch.Size((1000, 4))]
+    bucket = mdist.GradBucket(shapes, dev)
+    grads = [torch.full(tuple(s), float(rank + 1), device=dev) for s in shapes]
+    summed = mdist.allreduce_gradients(bucket, grads)
+    expect = world * (world + 1) / 2
+    ok = all(bool((t == expect).all()) for t in summed)
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing check only (no render, not a benchmark result)", "value": None, "unit": None,
+                          "n_gpus": world, "plumbing_only": True, "allreduce_ok": ok,
+                          "backend": torch.distributed.get_backend() if world > 1 else None}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,11 +101,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also skips grad_max_rel_err)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no render: launch the ranks, check the world size and push one gradient bucket through the collective "
+                         "(works without a GPU over gloo; the line it prints is NOT a benchmark result)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  A fresh child process, started before
+        # anything here has touched the GPU (never an exec of this one); rank 0 of the child prints the JSON line on our stdout.
+        return spawn_ranks(args.gpus)
 
     from materialrefgs_amd import dist as mdist
     env = mdist.init_from_env(backend=os.environ.get("MRGS_DIST_BACKEND"))   # default: RCCL ("nccl"); "gloo" for plumbing checks on one GPU
     world, rank, local = env["world"], env["rank"], env["local"]
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1:
+        world = torch.distributed.get_world_size()   # what the process group (RCCL) reports, not what the environment claimed
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
@@ -329,4 +381,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -160,3 +160,26 @@ def test_surfel_gradient_exchange_world2():
         expect = sum((np.zeros_like(res[0][1][i]) if r[2][i] is None else r[2][i]) for r in res)
         for r in res:
             np.testing.assert_allclose(r[1][i], expect, rtol=2e-5, atol=2e-6)
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (child torch.distributed.run) and report the
+    world size of the process group; `--plumbing-only` keeps the check GPU-free (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MRGS_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["allreduce_ok"] and out["backend"] == "gloo"
+    # a launcher that started the wrong number of ranks is an error, not a silent 1-GPU run
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env1,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
