@@ -64,27 +64,20 @@ def allreduce_gradients(bucket: GradBucket, tensors: Sequence[Optional[torch.Ten
 
 def expand_sh_gradients(gathered: torch.Tensor, means3D: torch.Tensor, M: int, sh_degree: int) -> torch.Tensor:
     """sum_v B_k(normalize(means3D - campos_v)) * dRGB_v  ->  [P, M, 3].  gathered: [V, 3P + 3] rows [dRGB_v | campos_v].
-    GPU tensors go through libmrgs.so; CPU tensors (the gloo tests of the collective plumbing) through the torch restatement."""
+    Runs in libmrgs.so (mrgs_sh_grad_expand); there is no CPU path -- the gloo tests of the collective plumbing inject their own
+    checker through the reducers' `expand_fn` argument."""
     V, P = gathered.shape[0], means3D.shape[0]
     assert gathered.shape[1] == 3 * P + 3 and gathered.is_contiguous()
-    if means3D.is_cuda:
-        from . import _lib
-        out = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
-        m3 = means3D.detach().float().contiguous()
-        with torch.cuda.device(means3D.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(means3D.device).cuda_stream)
-            _lib.check(_lib.lib().mrgs_sh_grad_expand(P, M, int(sh_degree), V, ctypes.c_void_p(m3.data_ptr()),
-                                                      ctypes.c_void_p(gathered.data_ptr()), gathered.stride(0),
-                                                      ctypes.c_void_p(out.data_ptr()), st))
-        return out
-    from .gs_utils import sh_basis
-    out = torch.zeros((P, M, 3), dtype=torch.float32)
-    n = (sh_degree + 1) ** 2
-    for v in range(V):
-        drgb, cam = gathered[v, :3 * P].view(P, 3), gathered[v, 3 * P:]
-        d = means3D.detach() - cam
-        basis = sh_basis(sh_degree, d / d.norm(dim=1, keepdim=True))          # [P, n]
-        out[:, :n] += basis.unsqueeze(-1) * drgb.unsqueeze(1)
+    if not means3D.is_cuda:
+        raise RuntimeError("expand_sh_gradients needs CUDA(HIP) tensors: the expansion runs in libmrgs.so, there is no CPU path")
+    from . import _lib
+    out = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
+    m3 = means3D.detach().float().contiguous()
+    with torch.cuda.device(means3D.device):
+        st = ctypes.c_void_p(torch.cuda.current_stream(means3D.device).cuda_stream)
+        _lib.check(_lib.lib().mrgs_sh_grad_expand(P, M, int(sh_degree), V, ctypes.c_void_p(m3.data_ptr()),
+                                                  ctypes.c_void_p(gathered.data_ptr()), gathered.stride(0),
+                                                  ctypes.c_void_p(out.data_ptr()), st))
     return out
 
 
@@ -92,7 +85,8 @@ class FactoredGradReducer:
     """Sum of the per-view gradients over all ranks with the SH gradient sent in factored form (module docstring).
     `shapes`: shapes of the gradient tensors in the order they will be passed; `sh_index`: position of dL/dsh [P, M, 3]."""
 
-    def __init__(self, shapes: Sequence[torch.Size], sh_index: int, device):
+    def __init__(self, shapes: Sequence[torch.Size], sh_index: int, device, expand_fn=None):
+        self.expand_fn = expand_fn or expand_sh_gradients   # tests on CPU tensors pass oracle.dist_oracle.expand_sh_gradients
         self.sh_index = sh_index
         self.sh_shape = torch.Size(shapes[sh_index])
         self.small = GradBucket([s for i, s in enumerate(shapes) if i != sh_index], device)
@@ -120,52 +114,29 @@ class FactoredGradReducer:
         w1 = dist.all_gather_into_tensor(self.gathered.view(-1), self.row, group=group, async_op=True)   # flat output: gloo insists
         w2 = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         w1.wait()
-        sh_sum = expand_sh_gradients(self.gathered, means3D, M, sh_degree)
+        sh_sum = self.expand_fn(self.gathered, means3D, M, sh_degree)
         w2.wait()
         views = self.small.views()
         return views[:self.sh_index] + [sh_sum] + views[self.sh_index:]
 
 
-def _view_and_mirror_dirs(xyz, rotation_raw, cam):
-    """Unit view direction and mirror direction of the facing normal (csrc/mrgs_surfel.hip: make_frame) with torch ops."""
-    q = rotation_raw / rotation_raw.norm(dim=1, keepdim=True)
-    w, x, y, z = q.unbind(1)
-    nr = torch.stack([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], dim=1)
-    d = xyz - cam
-    v = d / d.norm(dim=1, keepdim=True)
-    flip = torch.where(-(nr * v).sum(1, keepdim=True) >= 0, 1.0, -1.0)
-    nn = nr * flip
-    nn = nn / nn.norm(dim=1, keepdim=True).clamp_min(1e-20)
-    c = -(nn * v).sum(1, keepdim=True)
-    return v, 2 * c * nn + v
-
-
 def expand_surfel_sh_gradients(gathered: torch.Tensor, xyz: torch.Tensor, rotation_raw: torch.Tensor, sh_degree: int):
     """gathered [V, 6P + 3] rows [dRGB_v | dIND_v | campos_v] -> summed gradients of (features_dc [P,1,3], features_rest [P,15,3],
-    indirect_dc [P,1,3], indirect_rest [P,15,3]).  GPU tensors: libmrgs.so (mrgs_sh_grad_expand_surfel); CPU tensors (the gloo tests
-    of the collective plumbing): torch restatement."""
+    indirect_dc [P,1,3], indirect_rest [P,15,3]) in libmrgs.so (mrgs_sh_grad_expand_surfel); no CPU path (see expand_sh_gradients)."""
     V, P = gathered.shape[0], xyz.shape[0]
     assert gathered.shape[1] == 6 * P + 3 and gathered.is_contiguous()
-    if xyz.is_cuda:
-        from . import _lib
-        o = dict(dtype=torch.float32, device=xyz.device)
-        out = [torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o), torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o)]
-        x3, q4 = xyz.detach().float().contiguous(), rotation_raw.detach().float().contiguous()
-        with torch.cuda.device(xyz.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(xyz.device).cuda_stream)
-            _lib.check(_lib.lib().mrgs_sh_grad_expand_surfel(P, int(sh_degree), V, ctypes.c_void_p(x3.data_ptr()), ctypes.c_void_p(q4.data_ptr()),
-                                                             ctypes.c_void_p(gathered.data_ptr()), gathered.stride(0),
-                                                             *[ctypes.c_void_p(t.data_ptr()) for t in out], st))
-        return out
-    from .gs_utils import sh_basis
-    sh, ind = torch.zeros((P, 16, 3)), torch.zeros((P, 16, 3))
-    n = (sh_degree + 1) ** 2
-    for v in range(V):
-        g, h, cam = gathered[v, :3 * P].view(P, 3), gathered[v, 3 * P:6 * P].view(P, 3), gathered[v, 6 * P:]
-        vd, rd = _view_and_mirror_dirs(xyz.detach(), rotation_raw.detach(), cam)
-        sh[:, :n] += sh_basis(sh_degree, vd).unsqueeze(-1) * g.unsqueeze(1)
-        ind += sh_basis(3, rd).unsqueeze(-1) * h.unsqueeze(1)
-    return [sh[:, :1].contiguous(), sh[:, 1:].contiguous(), ind[:, :1].contiguous(), ind[:, 1:].contiguous()]
+    if not xyz.is_cuda:
+        raise RuntimeError("expand_surfel_sh_gradients needs CUDA(HIP) tensors: the expansion runs in libmrgs.so, there is no CPU path")
+    from . import _lib
+    o = dict(dtype=torch.float32, device=xyz.device)
+    out = [torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o), torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o)]
+    x3, q4 = xyz.detach().float().contiguous(), rotation_raw.detach().float().contiguous()
+    with torch.cuda.device(xyz.device):
+        st = ctypes.c_void_p(torch.cuda.current_stream(xyz.device).cuda_stream)
+        _lib.check(_lib.lib().mrgs_sh_grad_expand_surfel(P, int(sh_degree), V, ctypes.c_void_p(x3.data_ptr()), ctypes.c_void_p(q4.data_ptr()),
+                                                         ctypes.c_void_p(gathered.data_ptr()), gathered.stride(0),
+                                                         *[ctypes.c_void_p(t.data_ptr()) for t in out], st))
+    return out
 
 
 class SurfelGradReducer:
@@ -175,7 +146,8 @@ class SurfelGradReducer:
     (incl. tensors that are not per-gaussian, e.g. the environment cubemap) goes through one flat all-reduce."""
     SH_NAMES = ("features_dc", "features_rest", "indirect_dc", "indirect_rest")
 
-    def __init__(self, shapes: Sequence[torch.Size], names: Sequence[str], device):
+    def __init__(self, shapes: Sequence[torch.Size], names: Sequence[str], device, expand_fn=None):
+        self.expand_fn = expand_fn or expand_surfel_sh_gradients   # tests on CPU tensors pass the oracle.dist_oracle restatement
         self.names = list(names)
         assert all(n in self.names for n in self.SH_NAMES + ("xyz", "rotation"))
         self.sh_pos = [self.names.index(n) for n in self.SH_NAMES]
@@ -206,7 +178,7 @@ class SurfelGradReducer:
         w1 = dist.all_gather_into_tensor(self.gathered.view(-1), self.row, group=group, async_op=True)
         w2 = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         w1.wait()
-        sh = expand_surfel_sh_gradients(self.gathered, xyz, rotation_raw, sh_degree)
+        sh = self.expand_fn(self.gathered, xyz, rotation_raw, sh_degree)
         w2.wait()
         out = [None] * len(self.names)
         for i, v in zip(self.dense_pos, self.dense.views()):

@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's render functions for the hot path (appendix C).
 
-  compute_2dgs_normal_and_regularizations <-> gaussian_renderer/__init__.py:42-90 ("2dgs" flavour: 7-channel allmap)
-  depths_to_points / depth_to_normal      <-> utils/point_utils.py:9-37
+  compute_2dgs_normal_and_regularizations <-> gaussian_renderer/__init__.py:42-90 ("2dgs" flavour: 7-channel allmap), with
+                                              depths_to_points / depth_to_normal of utils/point_utils.py:9-37 inside the kernel
   render_initial                          <-> gaussian_renderer/__init__.py:94-220
   render_surfel                           <-> gaussian_renderer/__init__.py:225-483 (SH-indirect branch, opt.indirect = False)
 
@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from ._lib import MrgsMapsFrame, MrgsSurfelGrads, MrgsSurfelParams
 
-from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
+from .gs_utils import build_scaling_rotation, flip_align_view, linear_to_srgb, safe_normalize
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from .shading import EnvLight, get_specular_color_surfel, shade_and_composite_surfel
 
@@ -79,7 +79,7 @@ def _c(t):
 
 class _SurfelFeatures(torch.autograd.Function):
     """mrgs_surfel_features_forward/backward (include/mrgs.h): raw GaussianModel parameters -> (opacity, scales, rotations,
-    features[P,8]) in one kernel each way.  Torch restatement = `surfel_features_reference` below (the reference's own ops)."""
+    features[P,8]) in one kernel each way (checker: oracle/glue_oracle.py, the reference's own chain of torch ops)."""
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos):
@@ -119,65 +119,6 @@ def surfel_features(pc, camera_center):
                                  pc._indirect_dc, pc._indirect_rest, camera_center)
 
 
-def surfel_features_reference(pc, camera_center, scaling_modifier=1.0):
-    """The same quantities with the reference's torch ops (gaussian_renderer/__init__.py:338-355 + the GaussianModel getters);
-    runs on any device -- the parity tests use it as the checker of `surfel_features`."""
-    means3D = pc.get_xyz
-    dir_pp = means3D - camera_center
-    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-    normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
-    w_o = -dir_pp_normalized
-    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
-    shs_indirect = pc.get_indirect.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-    indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
-    features = torch.cat((pc.get_refl, pc.get_rough, pc.get_ori_color, indirect), dim=-1)          # "2dgs" flavour: S = 8
-    return pc.get_opacity, pc.get_scaling, pc.get_rotation, features
-
-
-def depths_to_points(view, depthmap):
-    """utils/point_utils.py:9-24 (note: this back-projection uses W/2, H/2 pixel offsets, not (W-1)/2)."""
-    dev = depthmap.device
-    c2w = (view.world_view_transform.T).inverse()
-    W, H = view.image_width, view.image_height
-    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=depthmap.dtype, device=dev).T
-    projection_matrix = c2w.T @ view.full_proj_transform
-    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
-    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).to(depthmap.dtype), torch.arange(H, device=dev).to(depthmap.dtype), indexing="xy")
-    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
-    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
-    rays_o = c2w[:3, 3]
-    return depthmap.reshape(-1, 1) * rays_d + rays_o
-
-
-def depth_to_normal(view, depth):
-    """utils/point_utils.py:26-37: finite differences of the back-projected points; border pixels stay zero."""
-    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
-    output = torch.zeros_like(points)
-    dx = points[2:, 1:-1] - points[:-2, 1:-1]
-    dy = points[1:-1, 2:] - points[1:-1, :-2]
-    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
-    return output
-
-
-def compute_2dgs_normal_and_regularizations_reference(allmap, viewpoint_camera, pipe, return_depth_normal=True):
-    """gaussian_renderer/__init__.py:42-90 with the reference's torch ops (any device); the checker of the fused version below."""
-    render_alpha = allmap[1:2]
-    render_normal = allmap[2:5]
-    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
-    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
-    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
-    render_dist = allmap[6:7]
-    surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + pipe.depth_ratio * render_depth_median
-    if return_depth_normal:
-        surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
-        surf_normal = surf_normal * render_alpha.detach()
-    else:
-        surf_normal = None
-    return {"render_alpha": render_alpha, "render_normal": render_normal, "render_depth_median": render_depth_median,
-            "render_depth_expected": render_depth_expected, "render_dist": render_dist, "surf_depth": surf_depth,
-            "surf_normal": surf_normal}
-
-
 _MAPS_FRAME_CACHE = {}
 
 
@@ -187,6 +128,10 @@ def _maps_frame(view, depth_ratio):
     wvt, fpt = view.world_view_transform, view.full_proj_transform
     key = (wvt.data_ptr(), fpt.data_ptr(), wvt._version, fpt._version, int(view.image_width), int(view.image_height))
     ent = _MAPS_FRAME_CACHE.get(key)
+    # An entry keeps its two matrices alive, so their addresses cannot be handed to other tensors while it exists; a hit must be
+    # the very same tensor objects' storage at the same version (in-place writes bump _version).
+    if ent is not None and not (ent[3].data_ptr() == wvt.data_ptr() and ent[4].data_ptr() == fpt.data_ptr()):
+        ent = None
     if ent is None:
         import numpy as np
         wv = wvt.detach().cpu().double().numpy()
@@ -196,7 +141,7 @@ def _maps_frame(view, depth_ratio):
         ndc2pix = np.array([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=np.float64).T
         intrins = ((c2w.T @ fp) @ ndc2pix)[:3, :3].T
         M = c2w[:3, :3] @ np.linalg.inv(intrins)
-        ent = (wv[:3, :3].reshape(-1).tolist(), M.reshape(-1).tolist(), c2w[:3, 3].tolist())
+        ent = (wv[:3, :3].reshape(-1).tolist(), M.reshape(-1).tolist(), c2w[:3, 3].tolist(), wvt, fpt)
         if len(_MAPS_FRAME_CACHE) > 4096:
             _MAPS_FRAME_CACHE.clear()
         _MAPS_FRAME_CACHE[key] = ent
@@ -220,7 +165,7 @@ class _SurfelMaps(torch.autograd.Function):
     def forward(ctx, allmap, fr, want_surf_normal, want_normal_map):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not allmap.is_cuda:
-            raise RuntimeError("the fused map kernels need CUDA(HIP) tensors; use compute_2dgs_normal_and_regularizations_reference on the CPU")
+            raise RuntimeError("the fused map kernels need CUDA(HIP) tensors: there is no CPU path")
         allmap = _c(allmap)
         H, W, dev = fr.H, fr.W, allmap.device
         o = dict(dtype=torch.float32, device=dev)

@@ -239,7 +239,8 @@ def test_render_surfel_end_to_end(gpu_device):
 def test_surfel_features_match_the_reference_ops(gpu_device):
     """mrgs_surfel_features_forward/backward (one HIP kernel each way) against the reference's own chain of torch ops
     (GaussianModel getters, get_normal, mirror direction, eval_sh, clamp, cat) evaluated in float64 on the CPU."""
-    from materialrefgs_amd.renderer import SurfelModel, surfel_features, surfel_features_reference
+    from materialrefgs_amd.renderer import SurfelModel, surfel_features
+    from oracle.glue_oracle import surfel_features_reference
     torch.manual_seed(7)
     for P in (1, 63, 64, 1000, 4097):
         raw = dict(xyz=torch.randn(P, 3) * 2, scaling=torch.randn(P, 2) * 0.5 - 2, rotation=torch.randn(P, 4), opacity=torch.randn(P, 1),
@@ -274,7 +275,8 @@ def test_fused_maps_match_the_reference_ops(gpu_device, depth_ratio):
     """mrgs_surfel_maps_forward/backward against compute_2dgs_normal_and_regularizations + depth_to_normal + the normal_map
     division evaluated with the reference's torch ops in float64 on the CPU (including pixels with alpha = 0 -> nan_to_num)."""
     from types import SimpleNamespace
-    from materialrefgs_amd.renderer import (compute_2dgs_normal_and_regularizations, compute_2dgs_normal_and_regularizations_reference)
+    from materialrefgs_amd.renderer import compute_2dgs_normal_and_regularizations
+    from oracle.glue_oracle import compute_2dgs_normal_and_regularizations_reference
     from materialrefgs_amd.synthetic import orbit_camera
     H, W = 37, 53
     cam = orbit_camera(2, H, W)
@@ -385,7 +387,8 @@ def test_envfilter_oracle_known_answers():
 def test_maps_frame_matches_depths_to_points():
     """CPU: the camera constants handed to the fused map kernels (built on the host in float64) reproduce the reference's
     depths_to_points (utils/point_utils.py:9-24): point(x, y) = depth * (M (x, y, 1)) + o."""
-    from materialrefgs_amd.renderer import _maps_frame, depths_to_points
+    from materialrefgs_amd.renderer import _maps_frame
+    from oracle.glue_oracle import depths_to_points
     from materialrefgs_amd.synthetic import orbit_camera
     H, W = 21, 34
     cam = orbit_camera(5, H, W)
