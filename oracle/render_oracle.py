@@ -1,0 +1,144 @@
+"""End-to-end checker of `render_surfel` -- TEST INFRASTRUCTURE ONLY (tests/ may import it; the product never does).
+
+Composes, on the CPU, the checkers of the individual stages in the order of the reference's
+gaussian_renderer/__init__.py:225-483 (`render_surfel`, "2dgs" flavour, SH-indirect branch):
+
+    glue_oracle.surfel_features_reference   :338-355   (torch, float64, autograd)
+    raster oracle (mrgs_oracle.c)           :359-370   (C, any arithmetic mode; wrapped as an autograd node below)
+    glue_oracle.compute_2dgs_normal_...     :42-90, 392  (torch, float64, autograd)
+    normal_map, get_specular_color_surfel   :419-433, utils/refl_utils.py:364-419  (shading_oracle; visibility by trace_oracle)
+    compositing, sRGB, background           :436-449
+    EnvLight.build_mips                     scene/light.py:72-86 (envfilter_oracle, dense float64 operators)
+
+so that the wiring of the product's render_surfel -- feature-channel order (refl, roughness, albedo 3, indirect 3), strided views,
+which maps feed which stage, gradient routing back to every parameter incl. the environment cubemap -- is compared as a whole.
+Parity status of the parts: see the headers of the individual oracle modules.
+"""
+import math
+
+import numpy as np
+import torch
+
+from materialrefgs_amd.gs_utils import linear_to_srgb
+from . import envfilter_oracle as ef
+from . import glue_oracle as go
+from . import raster_oracle as ro
+from . import shading_oracle as so
+from . import trace_oracle as to
+
+
+class _OracleRaster(torch.autograd.Function):
+    """diff_surfel_rasterization forward/backward through oracle/mrgs_oracle.c (inputs rounded to fp32 at the boundary, as the
+    reference's fp32 tensors are)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, shs, features, scales, rotations, cam, sh_degree, variant):
+        r = ro.OracleRender(means3D=means3D, opacities=opacities, H=cam.image_height, W=cam.image_width,
+                            tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), viewmatrix=cam.world_view_transform,
+                            projmatrix=cam.full_proj_transform, campos=cam.camera_center, shs=shs, features=features, scales=scales,
+                            rotations=rotations, sh_degree=sh_degree, variant=variant)
+        ctx.r = r
+        ctx.dtype = means3D.dtype
+        ctx.shapes = (means3D.shape, opacities.shape, shs.shape, features.shape, scales.shape, rotations.shape)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(means3D.dtype)
+        radii = torch.from_numpy(r.radii.copy())
+        ctx.mark_non_differentiable(radii)
+        return t(r.color), t(r.feature), t(r.others), radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_feature, g_others, _g_radii):
+        r = ctx.r
+        z = lambda g, shp: np.zeros(shp, np.float32) if g is None else g.detach().numpy()
+        H, W, S = r.H, r.W, r.S
+        g = r.backward(z(g_color, (3, H, W)), z(g_feature, (S, H, W)), z(g_others, (7, H, W)))
+        t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.dtype).reshape(shp)
+        s = ctx.shapes
+        return (t(g["means3D"], s[0]), t(g["means2D"], (s[0][0], 3)), t(g["opacity"], s[1]), t(g["sh"], s[2]), t(g["features"], s[3]),
+                t(g["scales"], s[4]), t(g["rotations"], s[5]), None, None, None)
+
+
+class _OracleBuildMips(torch.autograd.Function):
+    """EnvLight.build_mips (scene/light.py:72-86) with the dense float64 operators of envfilter_oracle."""
+
+    @staticmethod
+    def forward(ctx, base, min_res, min_roughness, max_roughness):
+        spec, _diffuse, ops = ef.build_mips(base.detach().numpy(), min_res, min_roughness, max_roughness)
+        ctx.ops = ops
+        ctx.dtype = base.dtype
+        return tuple(torch.from_numpy(np.ascontiguousarray(s)).to(base.dtype) for s in spec)
+
+    @staticmethod
+    def backward(ctx, *g_spec):
+        shapes = [(6, int(round(math.sqrt(op.shape[0] / 6))), int(round(math.sqrt(op.shape[0] / 6))), 3) for op in ctx.ops]
+        g = [np.zeros(s) if gi is None else gi.detach().numpy() for gi, s in zip(g_spec, shapes)]
+        return torch.from_numpy(ef.build_mips_backward(ctx.ops, g)).to(ctx.dtype), None, None, None
+
+
+def sample_camera_rays_unnormalize(H, W, K, R, T):
+    """utils/refl_utils.py:75-93."""
+    R = R.T
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
+    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
+    pixel_camera = torch.tensor(np.dot(xy1, np.linalg.inv(K.astype(np.float32)).T))
+    rays_o = (-R.T @ T.unsqueeze(-1)).flatten()
+    pixel_world = (pixel_camera - T[None, None]).reshape(-1, 3) @ R
+    return (pixel_world - rays_o[None]).reshape(H, W, 3), rays_o
+
+
+def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=False, indirect=False, mesh=None, variant="fused",
+                         min_roughness=0.08, max_roughness=0.5, lut=None):
+    """`pc`: a SurfelModel on the CPU (float64 leaves recommended); `env_base`: [6,N,N,3] pre-sigmoid texels (leaf);
+    `mesh`: (vertices, triangles) for opt.indirect.  Returns the reference's dictionary (CPU tensors, autograd attached)."""
+    from materialrefgs_amd.shading import load_fg_lut
+    dt = pc._xyz.dtype
+    H, W = cam.image_height, cam.image_width
+    lut = load_fg_lut("cpu") if lut is None else lut
+    means2D = torch.zeros_like(pc._xyz, requires_grad=True)                                           # :229-233
+    opacities, scales, rotations, features = go.surfel_features_reference(pc, cam.camera_center.to(dt))   # :338-355
+    shs = pc.get_features
+    color, feat, allmap, radii = _OracleRaster.apply(pc.get_xyz, means2D, opacities, shs, features, scales, rotations, cam,
+                                                     pc.active_sh_degree, variant)                   # :359-370
+    base_color = color
+    refl_strength, roughness = feat[:1], feat[1:2]                                                    # :372-378 ("2dgs")
+    albedo, indirect_light = feat[2:5], feat[5:8]
+    cam_dt = cam._replace(world_view_transform=cam.world_view_transform.to(dt), full_proj_transform=cam.full_proj_transform.to(dt))
+    reg = go.compute_2dgs_normal_and_regularizations_reference(allmap, cam_dt, pipe)                  # :392
+    render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
+    normal_map = render_normal.permute(1, 2, 0) / render_alpha.permute(1, 2, 0).clamp_min(1e-6)       # :419-421
+    mips = _OracleBuildMips.apply(env_base, env_min_res, min_roughness, max_roughness)
+    _H, _W, K = cam.HWK
+    R32, T32 = cam.R.float(), cam.T.float()
+    a_hw, r_hw, ro_hw = render_alpha.permute(1, 2, 0), refl_strength.permute(1, 2, 0), roughness.permute(1, 2, 0)
+    specular, direct_light, specular_weight = so.specular_color_surfel(list(mips), lut, albedo.permute(1, 2, 0), H, W, K, R32, T32, normal_map,
+                                                                       a_hw, r_hw, ro_hw, min_roughness, max_roughness)
+    extra = {"direct_light": direct_light, "specular_weight": specular_weight}
+    if indirect:                                                                                       # utils/refl_utils.py:379-401
+        visibility = torch.ones_like(a_hw)
+        mask = (a_hw > 0)[..., 0]
+        rays_cam, rays_o = sample_camera_rays_unnormalize(H, W, K, R32, T32)
+        w_o = -rays_cam / torch.clamp(torch.linalg.norm(rays_cam, dim=-1, keepdim=True), min=1e-20)
+        rays_refl = 2 * normal_map * torch.sum(w_o * normal_map, dim=-1, keepdim=True) - w_o
+        rays_refl = rays_refl / torch.clamp(torch.linalg.norm(rays_refl, dim=-1, keepdim=True), min=1e-20)
+        inter = rays_o + reg["surf_depth"].permute(1, 2, 0) * rays_cam
+        if mesh is not None:
+            _, _, depth, _ = to.trace(mesh[0], mesh[1], inter[mask].detach().numpy(), rays_refl[mask].detach().numpy())
+            visibility[mask] = torch.from_numpy((depth >= 10).astype(np.float64)).to(dt).unsqueeze(-1)
+        ind_hw = indirect_light.permute(1, 2, 0)
+        light = direct_light.permute(1, 2, 0) * visibility + (1 - visibility) * ind_hw
+        specular = (light * a_hw * specular_weight).permute(2, 0, 1)
+        indirect_color = ((1 - visibility) * ind_hw * a_hw * specular_weight).permute(2, 0, 1)
+        extra.update({"visibility": visibility.permute(2, 0, 1), "indirect_light": indirect_light, "indirect_color": indirect_color})
+    diffuse = (1 - refl_strength) * base_color
+    final_image = diffuse + specular                                                                   # :436
+    if srgb:                                                                                           # :442-445
+        final_image, albedo, specular = linear_to_srgb(final_image), linear_to_srgb(albedo), linear_to_srgb(specular)
+    background = bg_color.to(dt)[:, None, None] * (1 - render_alpha)
+    final_image = final_image + background                                                             # :448
+    out = {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": diffuse, "diffuse_map_ori": base_color,
+           "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness, "viewspace_points": means2D,
+           "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha, "rend_normal": render_normal,
+           "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if indirect:
+        out.update(extra)
+        out["indirect_color"] = diffuse + extra["indirect_color"] + background                        # :449-452
+    return out

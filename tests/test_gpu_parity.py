@@ -35,7 +35,18 @@ CASES = [
 ]
 
 
-def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, check_grads=True):
+def _map_ok(a, b, tol, absolute=False):
+    """[..., H, W] boolean map of the pixels within `tol` (relative to max|b| unless absolute)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    den = 1.0 if absolute else max(float(np.abs(b).max()), 1e-30)
+    d = np.abs(a - b) / den
+    return (d <= tol).reshape(-1, *d.shape[-2:]).all(0), float(d.max())
+
+
+def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, check_grads=True, pixel_allowance=0):
+    """`pixel_allowance`: number of pixels that may sit outside the map tolerances (the randomised soak allows ONE: a surfel whose
+    alpha lands on the 1/255 threshold at that pixel is blended on one side and skipped on the other -- one ulp of v_rcp_f32 /
+    v_exp_f32); such a pixel must still be within 2e-3 of the map's maximum."""
     from oracle import raster_oracle as ro
     H, W = cam.image_height, cam.image_width
     S = scene.features.shape[1]
@@ -56,17 +67,20 @@ def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp
     np.testing.assert_array_equal(hr.export("ranges").astype(np.uint32), orc.ranges)
     # ---- maps
     nc_bad = int((hr.export("n_contrib").astype(np.uint32) != orc.n_contrib).sum())
-    assert nc_bad <= max(1, int(1e-5 * orc.n_contrib.size)), nc_bad
-    assert rel_err(hr.color.detach().cpu().numpy(), orc.color) <= MAP_TOL
-    if S:
-        assert rel_err(hr.feature.detach().cpu().numpy(), orc.feature) <= MAP_TOL
+    assert nc_bad <= max(1, int(1e-5 * orc.n_contrib.size)) + 2 * pixel_allowance, nc_bad
     others = hr.others.detach().cpu().numpy()
+    checks = [("color", hr.color.detach().cpu().numpy(), orc.color, MAP_TOL, False)]
+    if S:
+        checks.append(("feature", hr.feature.detach().cpu().numpy(), orc.feature, MAP_TOL, False))
     for ch in range(7):
-        if ch == 6:
-            assert float(np.abs(others[ch].astype(np.float64) - orc.others[ch]).max()) <= DIST_ABS_TOL
-        else:
-            assert rel_err(others[ch], orc.others[ch]) <= MAP_TOL, ch
-    assert rel_err(hr.export("final_T"), orc.final_T) <= MAP_TOL
+        checks.append((f"others[{ch}]", others[ch], orc.others[ch], DIST_ABS_TOL if ch == 6 else MAP_TOL, ch == 6))
+    checks.append(("final_T", hr.export("final_T"), orc.final_T, MAP_TOL, False))
+    good = np.ones((H, W), bool)
+    for name, a, b, tol, absolute in checks:
+        ok, worst = _map_ok(a, b, tol, absolute)
+        good &= ok
+        assert worst <= (tol if pixel_allowance == 0 else 2e-3), (name, worst)
+    assert int((~good).sum()) <= pixel_allowance, int((~good).sum())
     assert int(hr.contrib.abs().sum()) == 0   # out_contrib is allocated and returned but never written
     # ---- gradients
     if check_grads:
@@ -316,3 +330,28 @@ def test_factored_sh_gradient_equals_the_sum_over_views(gpu_device):
     assert float((out_gpu - dense).abs().max()) <= 2e-5 * scale
     out_deg1 = mdist.expand_sh_gradients(gathered.to(gpu_device), m3.to(gpu_device), 16, 1).cpu()
     assert float(out_deg1[:, 4:].abs().max()) == 0.0 and float((out_deg1[:, :4] - out_cpu[:, :4]).abs().max()) <= 2e-6 * scale
+
+
+def _soak_cases(n, seed):
+    """The generator of tools/stress_parity.py with a fixed seed: scene sizes 1 ... 40 000, 17 ... 420 px, 0 ... 24 channels,
+    SH degree 0 ... 3, splat radii 1.5 ... 40 px."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        P = int(rng.choice([1, 7, 63, 64, 65, 500, 3000, 12000, 40000]))
+        S = int(rng.choice([0, 1, 3, 4, 8, 11, 12, 24]))
+        H, W = int(rng.integers(17, 420)), int(rng.integers(17, 420))
+        deg = int(rng.integers(0, 4))
+        rpx = float(rng.choice([1.5, 4.0, 7.0, 15.0, 40.0]))
+        view = int(rng.integers(0, 8))
+        out.append((P, S, H, W, deg, rpx, view, int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("case", _soak_cases(20, 0), ids=lambda c: f"P{c[0]}-S{c[1]}-{c[2]}x{c[3]}-d{c[4]}-r{c[5]}")
+def test_randomised_soak_fixed_seed(gpu_device, case):
+    """Twenty fixed scenes of the randomised soak run (tools/stress_parity.py runs hundreds), full bit-exact binning state, maps
+    and gradients, with the documented allowance of one threshold pixel per scene."""
+    P, S, H, W, deg, rpx, view, seed = case
+    scene = make_shell_scene(P, S=S, seed=seed, radius_px=rpx, image_size=max(H, W))
+    compare_all(scene, orbit_camera(view, H, W), gpu_device, sh_degree=deg, pixel_allowance=1)
