@@ -9,8 +9,12 @@ Restates, literally and densely (one weight for every (output texel, source texe
   * EnvLight.build_mips                                      scene/light.py:72-86
 PARITY UNPINNED: renderutils is a CUDA extension (cannot be built here) and the reference has no test or fixture for it; the
 cube fetch of the mip backward is nvdiffrast's `dr.texture` (not vendored), restated in shading_oracle.cube_fetch.  The
-specular filter's window is the set {dot(L, V) >= cos_cutoff}: the reference walks a per-face bounding box of exactly that
-set (SpecularBoundsKernel, cubemap.cu:178-236) and re-tests the dot product per texel.
+specular filter's window is {dot(L, V) >= cos_cutoff} INSIDE the per-face bounding boxes of SpecularBoundsKernel
+(cubemap.cu:183-236), whose 16x16-tile interval test is restated in `bounds_mask`: it is conservative while no tile straddles a
+face axis (resolutions that are multiples of 32) and drops qualifying texels below that -- at 16x16 and roughness 0.08 a whole
+face is one tile whose corner directions all have the same major component, the test fails for the face's own centre, the window
+is empty and the reference divides 0 by 0.  (Rows with an empty window are NaN here, as in the reference; the HIP operator leaves
+them zero.  The reference's defaults, 128 -> 16 with roughness 1 on the 16x16 level, never get there.)
 Usable for cubemaps up to ~32x32 (6144^2 weights).
 """
 import numpy as np
@@ -50,8 +54,55 @@ def cos_cutoff(roughness, cutoff=0.99):
     return float(costheta[np.argmax(D >= D[..., -1] * cutoff)])
 
 
+def _corner_dir(x, y, s, N):
+    """cube_to_dir at integer texel coordinates that may equal N (tile corners, cubemap.cu:208-209)."""
+    fx, fy = 2.0 * ((x + 0.5) / N) - 1.0, 2.0 * ((y + 0.5) / N) - 1.0
+    d = np.array([(1.0, -fy, -fx), (-1.0, -fy, fx), (fx, 1.0, fy), (fx, -1.0, -fy), (fx, -fy, 1.0), (-fx, -fy, -1.0)][s])
+    return d / np.sqrt(max(float(d @ d), 1e-20))
+
+
+def bounds_mask(N, cosc, TS=16):
+    """[6N^2 (output texel), 6N^2 (source texel)] bool: the source texel lies inside the bounding box SpecularBoundsKernel
+    (cubemap.cu:183-236) stores for (output texel, source face): tiles are kept when the interval bound of dot(L, VNR) over the
+    tile's four corner directions reaches the cut-off, the box is spanned by the qualifying texels of the kept tiles."""
+    D = cube_to_dir(N)
+    dots = D @ D.T
+    NT = 6 * N * N
+    mask = np.zeros((NT, NT), bool)
+    ys, xs = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    for s in range(6):
+        kept = np.zeros((NT, N, N), bool)                    # qualifying texels of the kept tiles, per output texel
+        for ty in range((N + TS - 1) // TS):
+            for tx in range((N + TS - 1) // TS):
+                tsx, tsy, tex, tey = tx * TS, ty * TS, min((tx + 1) * TS, N), min((ty + 1) * TS, N)
+                L = np.stack([_corner_dir(tsx, tsy, s, N), _corner_dir(tex, tsy, s, N), _corner_dir(tsx, tey, s, N), _corner_dir(tex, tey, s, N)])
+                lo, hi = L.min(0), L.max(0)
+                maxdp = np.maximum(lo[None] * D, hi[None] * D).sum(1)              # [NT]
+                keep = maxdp >= cosc
+                sub = dots[:, s * N * N:(s + 1) * N * N].reshape(NT, N, N)[:, tsy:tey, tsx:tex] >= cosc
+                kept[:, tsy:tey, tsx:tex] = sub & keep[:, None, None]
+        any_ = kept.any((1, 2))
+        big = N + 1
+        xmin = np.where(kept, xs[None], big).min((1, 2)); xmax = np.where(kept, xs[None], -1).max((1, 2))
+        ymin = np.where(kept, ys[None], big).min((1, 2)); ymax = np.where(kept, ys[None], -1).max((1, 2))
+        box = (xs[None] >= xmin[:, None, None]) & (xs[None] <= xmax[:, None, None]) & (ys[None] >= ymin[:, None, None]) & \
+              (ys[None] <= ymax[:, None, None]) & any_[:, None, None]
+        mask[:, s * N * N:(s + 1) * N * N] = box.reshape(NT, N * N)
+    return mask
+
+
+_SPEC_CACHE = {}
+
+
 def specular_matrix(N, roughness, cutoff=0.99):
-    """Row-normalised dense operator [6N^2, 6N^2] of specular_cubemap."""
+    """Row-normalised dense operator [6N^2, 6N^2] of specular_cubemap (cached per (N, roughness, cutoff): it is a constant)."""
+    key = (int(N), float(roughness), float(cutoff))
+    if key not in _SPEC_CACHE:
+        _SPEC_CACHE[key] = _specular_matrix(N, roughness, cutoff)
+    return _SPEC_CACHE[key]
+
+
+def _specular_matrix(N, roughness, cutoff):
     D = cube_to_dir(N)
     dots = D @ D.T                                        # [out t, src s] = dot(L_s, VNR_t)
     a2 = (roughness * roughness) ** 2
@@ -62,8 +113,10 @@ def specular_matrix(N, roughness, cutoff=0.99):
     dd = (c * a2 - c) * c + 1.0
     ndf = a2 / (dd * dd * np.pi)
     W = np.maximum(dots, 0.0) * ndf * pixel_area(N)[None, :] / 4.0
-    W = np.where(dots >= np.float32(cos_cutoff(roughness, cutoff)), W, 0.0)
-    return W / W.sum(1, keepdims=True)
+    cosc = np.float32(cos_cutoff(roughness, cutoff))
+    W = np.where((dots >= cosc) & bounds_mask(N, cosc), W, 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return W / W.sum(1, keepdims=True)
 
 
 def diffuse_matrix(N):

@@ -372,11 +372,20 @@ def test_envfilter_oracle_known_answers():
     N = 8
     P = eo.specular_matrix(N, 0.5)
     assert np.allclose(P.sum(1), 1.0) and (P >= 0).all()
-    const = np.full((6, 16, 16, 3), 0.7)
-    spec, diffuse, ops = eo.build_mips(const, 4)           # 16 -> 8 -> 4 (the reference's roughness schedule needs >= 3 levels)
+    const = np.full((6, 32, 32, 3), 0.7)
+    spec, diffuse, ops = eo.build_mips(const, 8)           # 32 -> 16 -> 8 (the reference's roughness schedule needs >= 3 levels)
     for s in spec:
         assert np.allclose(s, 0.7)
-    assert 0.7 < float(diffuse.mean()) / 0.7 < 1.1      # atan-product texel areas are coarse at 4x4 (the reference's formula)
+    assert 0.7 < float(diffuse.mean()) / 0.7 < 1.1      # atan-product texel areas are coarse at 8x8 (the reference's formula)
+    # the reference's 16x16-tile interval test (cubemap.cu:203-214) is not conservative when one tile spans a face: at 16x16 and
+    # roughness 0.08 most windows come out empty (0 / 0 in the reference); from 32x32 on nothing that qualifies is dropped
+    D16, c08 = eo.cube_to_dir(16), np.float32(eo.cos_cutoff(0.08))
+    assert int((~(eo.bounds_mask(16, c08) & (D16 @ D16.T >= c08)).any(1)).sum()) > 1000
+    D32 = eo.cube_to_dir(32)
+    for r in (0.08, 0.29):
+        cc = np.float32(eo.cos_cutoff(r))
+        full = D32 @ D32.T >= cc
+        assert not (full & ~eo.bounds_mask(32, cc)).any()
     assert eo.cos_cutoff(0.08) > eo.cos_cutoff(0.29) > eo.cos_cutoff(0.5) > eo.cos_cutoff(1.0) > 0.0
     g = np.random.default_rng(0).normal(size=(6, 4, 4, 3))
     assert np.allclose(eo.mip_backward(g).sum(axis=(0, 1, 2)), g.sum(axis=(0, 1, 2)), rtol=1e-6, atol=1e-9)
