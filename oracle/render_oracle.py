@@ -86,9 +86,13 @@ def sample_camera_rays_unnormalize(H, W, K, R, T):
 
 
 def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=False, indirect=False, mesh=None, variant="fused",
-                         min_roughness=0.08, max_roughness=0.5, lut=None):
+                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None):
     """`pc`: a SurfelModel on the CPU (float64 leaves recommended); `env_base`: [6,N,N,3] pre-sigmoid texels (leaf);
-    `mesh`: (vertices, triangles) for opt.indirect.  Returns the reference's dictionary (CPU tensors, autograd attached)."""
+    `mesh`: (vertices, triangles) for opt.indirect.  Returns the reference's dictionary (CPU tensors, autograd attached).
+    `visibility_bits` [H,W]: use these bits instead of the own trace in the blend (the trace result is still returned under
+    "visibility_traced"): visibility is a step function of the mirror ray, a pixel on a silhouette flips with the last bit of the
+    ray set-up, and a test that wants to compare GRADIENTS first checks the two bit maps against each other and then removes
+    that source of difference."""
     from materialrefgs_amd.shading import load_fg_lut
     dt = pc._xyz.dtype
     H, W = cam.image_height, cam.image_width
@@ -123,11 +127,15 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
         if mesh is not None:
             _, _, depth, _ = to.trace(mesh[0], mesh[1], inter[mask].detach().numpy(), rays_refl[mask].detach().numpy())
             visibility[mask] = torch.from_numpy((depth >= 10).astype(np.float64)).to(dt).unsqueeze(-1)
+        traced = visibility
+        if visibility_bits is not None:
+            visibility = visibility_bits.to(dt).reshape(H, W, 1)
         ind_hw = indirect_light.permute(1, 2, 0)
         light = direct_light.permute(1, 2, 0) * visibility + (1 - visibility) * ind_hw
         specular = (light * a_hw * specular_weight).permute(2, 0, 1)
         indirect_color = ((1 - visibility) * ind_hw * a_hw * specular_weight).permute(2, 0, 1)
-        extra.update({"visibility": visibility.permute(2, 0, 1), "indirect_light": indirect_light, "indirect_color": indirect_color})
+        extra.update({"visibility": visibility.permute(2, 0, 1), "visibility_traced": traced.permute(2, 0, 1), "indirect_light": indirect_light,
+                      "indirect_color": indirect_color})
     diffuse = (1 - refl_strength) * base_color
     final_image = diffuse + specular                                                                   # :436
     if srgb:                                                                                           # :442-445

@@ -104,12 +104,14 @@ def test_render_surfel_matches_the_composed_oracle(gpu_device, indirect, srgb):
         pc_h.ray_tracer = RayTracer(*mesh)
     env.build_mips()
     out_h = render_surfel(cam.to(gpu_device), pc_h, pipe, bg.to(gpu_device), srgb=srgb, opt=SimpleNamespace(indirect=indirect))
-    out_o = render_oracle.render_surfel_oracle(cam, pc_o, base_o, 8, pipe, bg, srgb=srgb, indirect=indirect, mesh=mesh)
-    assert set(out_o) <= set(out_h), set(out_o) - set(out_h)
+    vis_bits = out_h["visibility"].detach().cpu()[0] if indirect else None     # compared with the oracle's own trace below
+    out_o = render_oracle.render_surfel_oracle(cam, pc_o, base_o, 8, pipe, bg, srgb=srgb, indirect=indirect, mesh=mesh, visibility_bits=vis_bits)
+    assert set(out_o) - {"visibility_traced"} <= set(out_h), set(out_o) - set(out_h)
+    assert ("specular_weight" in out_h) == indirect            # extra_dict is merged only under opt.indirect (__init__.py:472-473)
     assert torch.equal(out_h["radii"].cpu(), out_o["radii"]) and torch.equal(out_h["visibility_filter"].cpu(), out_o["visibility_filter"])
     ok = torch.ones(H, W, dtype=torch.bool)
     if indirect:
-        vh, vo = out_h["visibility"].cpu()[0], out_o["visibility"][0].float()
+        vh, vo = out_h["visibility"].cpu()[0], out_o["visibility_traced"][0].float()
         ok = vh == vo
         assert float((~ok).float().mean()) < 2e-3           # ray set-up rounding at silhouettes only
         assert 0.02 < float((vo == 0).float().mean()) < 0.98
@@ -118,19 +120,26 @@ def test_render_surfel_matches_the_composed_oracle(gpu_device, indirect, srgb):
         a, b = out_h[k].detach().cpu().double(), out_o[k].detach()
         scale = max(float(b.abs().max()), 1e-6)
         tol = 2e-4 if k in ("surf_normal",) else 5e-5       # surf_normal: normalised cross product of depth differences
-        d = (a - b).abs()[..., ok] if k in ("render", "specular_map", "indirect_color") else (a - b).abs()
+        d = (a - b).abs()
+        if k == "rend_dist":                                # O(1e-5) values from O(1) terms: absolute bar (test_gpu_parity.DIST_ABS_TOL)
+            scale, tol = 1.0, 5e-6
         bad = float((d > tol * scale).float().mean())
         assert bad < (2e-3 if k == "surf_normal" else 1e-4), (k, float(d.max()), scale, bad)
-    w_h = out_h["specular_weight"].detach().cpu().double()
-    assert float((w_h - out_o["specular_weight"].detach()).abs().max()) < 5e-5
+    if indirect:
+        w_h = out_h["specular_weight"].detach().cpu().double()
+        assert float((w_h - out_o["specular_weight"].detach()).abs().max()) < 5e-5
     # ---- gradients of one scalar that reads every map
     _loss(out_h, H, W, indirect, gpu_device).backward()
     _loss(out_o, H, W, indirect, "cpu").backward()
-    bar = 3e-3 if indirect else 3e-4                        # indirect: pixels whose visibility bit differs feed different branches
-    for n in PARAMS:
-        a, b = getattr(pc_h, n).grad.detach().cpu().double(), getattr(pc_o, n).grad
-        assert float((a - b).abs().max()) <= bar * float(b.abs().max()), (n, float((a - b).abs().max()), float(b.abs().max()))
-    a, b = env.base.grad.detach().cpu().double(), base_o.grad
-    assert float((a - b).abs().max()) <= bar * float(b.abs().max()), ("env.base", float((a - b).abs().max()), float(b.abs().max()))
-    a, b = out_h["viewspace_points"].grad.detach().cpu().double(), out_o["viewspace_points"].grad
-    assert float((a - b).abs().max()) <= bar * float(b.abs().max())
+    # bar: max-norm per tensor, relative to the tensor's largest gradient (measured: <= 1.1e-4, rotation; every other tensor <= 9e-5)
+    bar = 3e-4
+    rows = []
+    pairs = [(n, getattr(pc_h, n).grad, getattr(pc_o, n).grad) for n in PARAMS]
+    pairs += [("env.base", env.base.grad, base_o.grad), ("viewspace_points", out_h["viewspace_points"].grad, out_o["viewspace_points"].grad)]
+    for n, gh, go_ in pairs:
+        a, b = gh.detach().cpu().double(), go_
+        d = (a - b).abs() / max(float(b.abs().max()), 1e-30)     # (both sides exactly zero: the indirect SH without opt.indirect)
+        rows.append((n, float(d.max()), float((d > bar).double().mean()), int((d > bar).sum()), float(b.abs().max())))
+    print("\n".join(f"{n:18s} max-norm err {m:.2e}  elements beyond {bar:g}: {c} ({f:.1e})  max|g| {g:.3e}" for n, m, f, c, g in rows))
+    for n, m, f, c, g in rows:
+        assert m <= bar, (n, m, c)
