@@ -38,8 +38,12 @@ WORKLOADS = {
     "C4full": (1000000, 1600, 1600, 8, "C4 shell scene: render_surfel + visibility rays vs a 1 M triangle mesh + calculate_loss + Adam step, P=1000000, 1600x1600, S=8, one full training view"),
     # raster part of BASELINE.json configs[3]
     "C4raster": (1000000, 1600, 1600, 8, "C4-size shell scene: P=1000000 surfels, 1600x1600, SH deg 3, S=8 material channels, raster fwd+bwd"),
+    # same P / image as C2 with the pair count the survey assumed (R ~ 6 P instead of 3.8 P) and heavy-tailed splat sizes (log-normal
+    # sigma 0.8 instead of 0.35: splats from sub-pixel to ~450 px); reported as the secondary line of the default run
+    "C2heavy": (300000, 800, 800, 0, "C2heavy shell scene: P=300000 surfels, 800x800, SH deg 3, S=0, log-normal splat sizes sigma 0.8, R ~ 6 P, fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
 }
+SCENE_KW = {"C2heavy": dict(radius_px=6.5, scale_sigma=0.8)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -54,6 +58,26 @@ def algorithmic_bytes(kernel, P, R, HW, S):
         # final_T 3, n_contrib 2)
         return (5 + 80 + 4 * S) * R + (60 + 4 * S) * HW
     raise KeyError(kernel)
+
+
+def kernel_source_digest():
+    """sha256[:16] over the HIP sources and headers of libmrgs.so, in name order: the identity of the kernels a counter was measured on
+    (the repository's .git does not travel to the GPU box, so a commit id is not available there)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "materialrefgs_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _load_json(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
 
 
 def spawn_ranks(n):
@@ -97,10 +121,11 @@ def plumbing_only(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1500)     # ~1 s timed region at C2
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also skips grad_max_rel_err)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2heavy secondary line of the default C2 run")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no render: launch the ranks, check the world size and push one gradient bucket through the collective "
                          "(works without a GPU over gloo; the line it prints is NOT a benchmark result)")
@@ -133,7 +158,9 @@ def main():
     L = _lib.lib()
 
     P, H, W, S, desc = WORKLOADS[args.workload]
-    scene_cpu = make_shell_scene(P, S=S, seed=0, radius_px=7.0 * max(H, W) / 800.0 if args.workload == "tiny" else 7.0, image_size=max(H, W))
+    scene_kw = dict(radius_px=7.0 * max(H, W) / 800.0 if args.workload == "tiny" else 7.0)
+    scene_kw.update(SCENE_KW.get(args.workload, {}))
+    scene_cpu = make_shell_scene(P, S=S, seed=0, image_size=max(H, W), **scene_kw)
     scene = scene_cpu.to(dev)
     cams = [orbit_camera(v, H, W) for v in range(8)]
     settings = []
@@ -293,7 +320,7 @@ def main():
     out = {
         "metric": "full-render fwd+bwd views/sec at 800x800/300k surfels; grad max-rel-err vs ref",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "P": P, "H": H, "W": W, "S": S, "sh_degree": 3, "num_rendered": int(state["R"]),
                    "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
@@ -309,28 +336,26 @@ def main():
         dom_ms = stage_ms[dom]
         nbytes = algorithmic_bytes(dom, P, R, HW, S)
         achieved = nbytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(args.workload, {}).get(dom)
-            except Exception:
-                traffic = None
+        # HBM traffic (FETCH_SIZE / WRITE_SIZE passes) and the VALU issue rate (SQ pass) of the dominant kernel come from separate
+        # rocprofv3 --pmc runs of this same command (tools/pmc_traffic.py, tools/pmc_sq.py), which stamp their JSON with the digest of
+        # the kernel sources they measured.  A figure whose digest differs from the sources of THIS run is stale and reported as null.
+        digest = kernel_source_digest()
+        traffic, traffic_src = None, None
+        pmc = _load_json(os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+        if pmc.get("kernel_source_digest") == digest:
+            traffic = pmc.get(args.workload, {}).get(dom)
+            traffic_src = pmc.get("measured_by")
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(dom_ms, 4)}
+                           "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(dom_ms, 4),
+                           "kernel_source_digest": digest, "traffic_source": traffic_src}
         # The dominant kernel is fp32 VALU work (no matrix shape in it) and sits at the VALU issue rate, not at the HBM rate the
-        # required fields above price it against: the committed SQ counter pass says how close.
-        sq_path = os.path.join(ROOT, "profiles", "pmc_sq.json")
-        if os.path.exists(sq_path):
-            try:
-                sq = json.load(open(sq_path)).get(args.workload, {}).get(dom)
-                if sq:
-                    out["roofline"]["valu_issue"] = {"cycles_per_inst_per_simd": sq["cycles_per_valu_inst_per_simd"], "peak": 4.0,
-                                                     "frac": round(4.0 / sq["cycles_per_valu_inst_per_simd"], 3),
-                                                     "insts_per_launch": sq["valu_insts_per_launch"], "source": "profiles/pmc_sq.json"}
-            except Exception:
-                pass
+        # required fields above price it against: the SQ counter pass says how close.
+        sqj = _load_json(os.path.join(ROOT, "profiles", "pmc_sq.json"))
+        sq = sqj.get(args.workload, {}).get(dom) if sqj.get("kernel_source_digest") == digest else None
+        out["roofline"]["valu_issue"] = None if not sq else {
+            "cycles_per_inst_per_simd": sq["cycles_per_valu_inst_per_simd"], "peak": 4.0, "frac": round(4.0 / sq["cycles_per_valu_inst_per_simd"], 3),
+            "insts_per_launch": sq["valu_insts_per_launch"], "source": sqj.get("measured_by", "profiles/pmc_sq.json")}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
 
         if world > 1:
@@ -374,6 +399,45 @@ def main():
             out["grad_rel_err"] = {k: float(f"{v:.3e}") for k, v in errs.items()}
             out["num_rendered_matches_oracle"] = bool(orc.R == color.grad_fn.num_rendered)
             orc.close()
+            # truth leg (tests/test_truth_leg.py at this size): distance of the HIP gradients, of the oracle with the kernels' FMA pattern
+            # and of the literal un-fused fp32 reading from the SAME formulas evaluated in float64 -- max-norm and, over the elements
+            # above 1e-3 max|g|, the median / 99th percentile of the per-element relative error
+            from oracle import compare
+            hip = {k: params[k].grad.detach().cpu().numpy() for k in params}
+            hip["means2D"] = means2D.grad.detach().cpu().numpy()
+            legs = {}
+            for v in ("lit32", "f64"):
+                o = ro.render_scene(scene_cpu, cam, variant=v)
+                legs[v] = o.backward(g_color.cpu(), g_feat.cpu(), g_others.cpu())
+                o.close()
+            out["grad_err_vs_f64"] = compare.three_way(hip, go, legs["lit32"], legs["f64"])
+            out["hip_no_further_from_f64_than_literal_fp32"] = bool(all(
+                r["hip"]["max_norm"] <= max(1.5 * r["literal32"]["max_norm"], 2e-5) for r in out["grad_err_vs_f64"].values()))
+            # the north star's pure-PyTorch CPU alpha-blend baseline (forward only; BASELINE.json configs[0] and a down-scaled C2)
+            from oracle import torch_blend
+            torch.set_num_threads(os.cpu_count() or 1)
+            tb = {}
+            for name, (P_, HW_) in {"C1 (P=1000, 128x128)": (1000, 128), "C2/10 (P=30000, 256x256)": (30000, 256)}.items():
+                sc_ = make_shell_scene(P_, S=0, seed=0, radius_px=7.0 * HW_ / 800.0 if P_ > 1000 else 7.0, image_size=HW_)
+                t = time.perf_counter()
+                r_ = torch_blend.render(sc_, orbit_camera(0, HW_, HW_))
+                tb[name] = {"seconds": round(time.perf_counter() - t, 3), "num_rendered": r_[-1]}
+            out["cpu_baseline_torch"] = {"kind": "port", "what": "forward-only alpha blend, pure torch tensor ops (oracle/torch_blend.py)",
+                                         "threads": torch.get_num_threads(), "runs": tb,
+                                         "value": round(1.0 / tb["C2/10 (P=30000, 256x256)"]["seconds"], 4), "unit": "forward views/s at C2/10"}
+        if world == 1 and args.workload == "C2" and not args.no_secondary:
+            # secondary line: the heavier scene (R ~ 6 P, heavy-tailed splat sizes), a fresh child process after everything here is done
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "C2heavy", "--steps", str(min(args.steps, 500)),
+                                "--warmup", str(min(args.warmup, 30)), "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True)
+            sec = None
+            for line in r.stdout.splitlines():
+                if line.startswith("{"):
+                    j = json.loads(line)
+                    sec = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                           "steps": j["steps"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
+                           "roofline_frac": j["roofline"]["frac"]}
+            out["secondary"] = sec if sec is not None else {"error": (r.stderr or r.stdout)[-300:]}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -50,7 +50,7 @@ def _quat_from_z_to(n, spin, rng):
 
 
 def make_shell_scene(P: int, S: int = 0, seed: int = 0, radius_px: float = 7.0, image_size: int = 800,
-                     sh_degree_filled: int = 3, device: Optional[str] = None) -> Scene:
+                     sh_degree_filled: int = 3, device: Optional[str] = None, scale_sigma: float = 0.35) -> Scene:
     rng = np.random.default_rng(seed)
     d = rng.normal(size=(P, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
@@ -59,7 +59,7 @@ def make_shell_scene(P: int, S: int = 0, seed: int = 0, radius_px: float = 7.0, 
     q = _quat_from_z_to(d, rng.uniform(0, 2 * math.pi, size=P), rng)
     focal = fov2focal(FOV, image_size)
     s_bar = radius_px * CAM_DISTANCE / (3.0 * focal)
-    scales = np.exp(rng.normal(math.log(s_bar), 0.35, size=(P, 2)))
+    scales = np.exp(rng.normal(math.log(s_bar), scale_sigma, size=(P, 2)))   # scale_sigma: spread of the log-normal splat sizes
     opac = 1.0 / (1.0 + np.exp(-rng.normal(1.5, 1.0, size=(P, 1))))
     shs = np.zeros((P, 16, 3))
     shs[:, 0, :] = (rng.uniform(0, 1, size=(P, 3)) - 0.5) / C0

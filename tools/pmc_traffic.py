@@ -37,6 +37,10 @@ def main():
             entry[k] = int(rd + wr)
             detail[k] = {"fetch_bytes_corrected_x2": int(rd), "write_bytes": int(wr)}
     data[workload] = entry
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_digest
+    data["kernel_source_digest"] = kernel_source_digest()     # bench.py reports the traffic only for these very sources
+    data["measured_by"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 5 --warmup 2 (tools/profile_round.sh)"
     data.setdefault("_detail", {})[workload] = detail
     data["_note"] = "bytes per launch; FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B) + WRITE_SIZE KiB"
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
