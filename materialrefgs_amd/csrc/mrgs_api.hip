@@ -81,7 +81,6 @@ struct Carver {
 
 MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
 {
-    (void)H; (void)W;
     Carver c(base);
     MrgsGeomWs g;
     const size_t n = (size_t)(P > 0 ? P : 1);
@@ -100,6 +99,17 @@ MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
     g.sort_ws = c.take<uint32_t>(mrgs_sort_ws_words((int64_t)n));
     g.scan_ws = c.take<uint32_t>(mrgs_scan_ws_words((int)n));
     g.clear_bytes = c.used - clear_from;
+    const int T = ((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y);
+    g.tile_mat = g.tile_cnt = g.tile_loc = g.chunk_tot = g.chunk_base = g.big_list = nullptr;
+    if (mrgs_bin_supported(T)) {
+        const size_t Tpad = (size_t)mrgs_bin_tpad(T);
+        g.tile_mat = c.take<uint32_t>((size_t)mrgs_bin_groups(P) * Tpad);
+        g.tile_cnt = c.take<uint32_t>(Tpad);
+        g.tile_loc = c.take<uint32_t>(Tpad);
+        g.chunk_tot = c.take<uint32_t>(Tpad / 256);
+        g.chunk_base = c.take<uint32_t>(Tpad / 256);
+        g.big_list = c.take<uint32_t>(Tpad);
+    }
     g.total = mrgs_align_up(c.used, 256);
     return g;
 }
@@ -134,8 +144,9 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R)
     Carver c(base);
     MrgsBinWs b;
     const size_t n = (size_t)(R > 0 ? R : 1);
-    b.tile_key[0] = c.take<uint32_t>(n);
-    b.tile_key[1] = c.take<uint32_t>(n);
+    const size_t n64 = mrgs_align_up(n, 64);
+    b.tile_key[0] = c.take<uint32_t>(2 * n64);       // one block: [R] 64-bit keys of mrgs_binning.hip, or the two ping-pong halves
+    b.tile_key[1] = b.tile_key[0] ? b.tile_key[0] + n64 : nullptr;
     b.plist[0] = c.take<uint32_t>(n);
     b.plist[1] = c.take<uint32_t>(n);
     b.sort_ws = c.take<uint32_t>(16 + mrgs_sort_ws_words((int64_t)n));
@@ -154,6 +165,8 @@ static int tile_bits(int ntiles)
 
 // which of the two ping-pong buffers holds the final data after sorting `bits` bits in 8-bit passes
 static int sorted_buf(int bits) { return ((bits + 7) / 8) & 1; }
+// ... and which plist buffer holds the point list of a forward: buffer 0 on the tile-binning path (mrgs_binning.hip)
+static int plist_buf(const MrgsGeomWs& g, int ntiles) { return g.tile_mat != nullptr ? 0 : sorted_buf(tile_bits(ntiles)); }
 
 static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
 {
@@ -169,6 +182,7 @@ static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
         if (have_sr == (in->transMat_precomp != nullptr)) return MRGS_E_BAD_ARG;
         if (cfg->S > 0 && !in->features) return MRGS_E_BAD_ARG;
         if ((cfg->W + 15) / 16 > 65535 || (cfg->H + 15) / 16 > 65535) return MRGS_E_UNSUPPORTED;
+        if (cfg->P >= (1 << 28)) return MRGS_E_UNSUPPORTED;   // binning keys carry the gaussian index in 28 bits
         // the blend backward addresses a surfel's gradient row with a 32-bit byte offset
         if ((uint64_t)cfg->P * MRGS_GRAD_STRIDE(cfg->S) * sizeof(float) >= (1ull << 32)) return MRGS_E_UNSUPPORTED;
     }
@@ -188,7 +202,8 @@ size_t mrgs_work_hint_bytes(int32_t H, int32_t W)
 size_t mrgs_grad_bytes(int32_t P, int32_t S) { return mrgs_align_up((size_t)(P > 0 ? P : 1) * MRGS_GRAD_STRIDE(S) * sizeof(float), 256); }
 
 // phase 1: preprocess, depth sort, scan; leaves num_rendered and the look-back error flag in g.counters[0..1]
-static int enqueue_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, MrgsGeomWs g, int32_t* radii, hipStream_t stream)
+static int enqueue_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, MrgsGeomWs g, int32_t* radii, hipStream_t stream,
+                        uint32_t* host_slot = nullptr, hipEvent_t slot_event = nullptr)
 {
     StageTimer t0(stream, ST_PRE);
     mrgs_launch_preprocess_fwd(*cfg, *in, g, radii, stream);
@@ -196,10 +211,17 @@ static int enqueue_geom(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in,
     STAGE_CHECK(cfg, stream);
 
     StageTimer t1(stream, ST_SORT);
-    // depth sort of the gaussians (32 key bits, 4 passes -> result back in buffer 0)
-    const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_ws, g.counters + 1, cfg->P, nullptr, 0, 32, stream);
-    STAGE_CHECK(cfg, stream);
-    mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_ws, g.counters, g.counters + 1, cfg->P, stream);
+    if (g.tile_mat != nullptr) {
+        // per-tile pair counts of fixed surfel slices, column prefixes, tile offsets, num_rendered (mrgs_binning.hip)
+        mrgs_launch_tile_count_scan(*cfg, g, host_slot, stream);
+        if (slot_event != nullptr) HIP_TRY(hipEventRecord(slot_event, stream));   // the host slot is written when this completes
+    } else {
+        // images with more tiles than the slice histograms hold: global radix path of round 1 (mrgs_sort.hip).
+        // depth sort of the gaussians (32 key bits, 4 passes -> result back in buffer 0)
+        const int cur = mrgs_radix_sort_pairs(g.depth_key, g.order, g.sort_ws, g.counters + 1, cfg->P, nullptr, 0, 32, stream);
+        STAGE_CHECK(cfg, stream);
+        mrgs_scan_tiles(g.tiles_touched, g.order[cur], g.offsets, g.scan_ws, g.counters, g.counters + 1, cfg->P, stream);
+    }
     t1.stop();
     STAGE_CHECK(cfg, stream);
     return MRGS_OK;
@@ -216,17 +238,25 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     const int dcur = sorted_buf(32);
 
     StageTimer t0(stream, ST_DUP);
-    if (R > 0) {
-        mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, b, img, host_slot, stream);
-        if (slot_event != nullptr) HIP_TRY(hipEventRecord(slot_event, stream));   // the host slot is written when this completes
-    } else {   // nothing visible: no kernel touches the pair buffers, only the ranges have to read as empty
-        HIP_TRY(hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream));
+    int cur = 0;
+    if (g.tile_mat != nullptr) {
+        // pairs into their tile's segment (one LDS atomic each), per-tile LDS sort -> point_list, cull bits, ranges, work estimates
+        if (R > 0) mrgs_launch_tile_emit_sort(*cfg, g, b, img, R, stream);
+        else HIP_TRY(hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream));   // nothing visible: the ranges read as empty
+        STAGE_CHECK(cfg, stream);
+    } else {
+        if (R > 0) {
+            mrgs_launch_duplicate(*cfg, g, g.order[dcur], b.tile_key[0], b.plist[0], R, R_dev, b, img, host_slot, stream);
+            if (slot_event != nullptr) HIP_TRY(hipEventRecord(slot_event, stream));   // the host slot is written when this completes
+        } else {   // nothing visible: no kernel touches the pair buffers, only the ranges have to read as empty
+            HIP_TRY(hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream));
+        }
+        STAGE_CHECK(cfg, stream);
+        const int bits = tile_bits(ntiles);
+        cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
+        STAGE_CHECK(cfg, stream);
+        mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
     }
-    STAGE_CHECK(cfg, stream);
-    const int bits = tile_bits(ntiles);
-    const int cur = mrgs_radix_sort_pairs(b.tile_key, b.plist, b.sort_ws + 16, b.sort_ws, R, R_dev, 0, bits, stream);
-    STAGE_CHECK(cfg, stream);
-    mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
     mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, nullptr, 0, in->work_hint, stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
@@ -326,10 +356,11 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
         HIP_TRY(hipHostGetDevicePointer((void**)&g_slot.dev, g_slot.host, 0));
         HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming));
     }
-    rc = enqueue_geom(cfg, in, g, radii, stream);
+    rc = enqueue_geom(cfg, in, g, radii, stream, g_slot.dev, g_slot.ev);
     if (rc) return rc;
-    // phase 2 is queued without waiting for the count: its kernels read it from g.counters, and the first of them stores it (and the
-    // error flag of phase 1) into the pinned host slot -- no copy-engine transfer in the middle of the stream
+    // phase 2 is queued without waiting for the count: its kernels read it from g.counters; the count (and the error flag of phase 1)
+    // reaches the pinned host slot through a kernel -- the tile scan, or on the radix path the first kernel of phase 2 -- with no
+    // copy-engine transfer in the middle of the stream
     rc = enqueue_render(cfg, in, g, b, img, capacity_pairs, g.counters, out_color, out_feature, out_others, stream, g_slot.dev, g_slot.ev);
     if (rc) return rc;
     HIP_TRY(hipEventSynchronize(g_slot.ev));
@@ -358,7 +389,7 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
     MrgsImgWs img = mrgs_carve_img(const_cast<void*>(img_ws), cfg->H, cfg->W);
-    const int cur = sorted_buf(tile_bits(tiles_x * tiles_y));
+    const int cur = plist_buf(g, tiles_x * tiles_y);
     float* grad_rec = (float*)grad_ws;
 
     StageTimer t0(stream, ST_BWD);
@@ -434,7 +465,7 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
     case 5: HIP_TRY(hipMemcpyAsync(dst, g.tiles_touched, sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, stream)); break;
     case 7: {
         MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
-        const int cur = sorted_buf(tile_bits(tiles_x * tiles_y));
+        const int cur = plist_buf(g, tiles_x * tiles_y);
         if (R > 0) HIP_TRY(hipMemcpyAsync(dst, b.plist[cur], sizeof(uint32_t) * R, hipMemcpyDeviceToDevice, stream));
     } break;
     case 8: HIP_TRY(hipMemcpyAsync(dst, img.ranges, sizeof(uint2) * tiles_x * tiles_y, hipMemcpyDeviceToDevice, stream)); break;

@@ -1,0 +1,417 @@
+// mrgs_binning.hip -- tile binning of the surfel rasterizer on gfx950 without a global sort.
+//
+// Reference behaviour being reproduced (rasterizer_impl.cu:283-324): point_list = gaussian ids ordered by
+// (tile id, raw depth bits), ties in emission order (gaussian index); ranges[tile] = its slice of the list.  The reference
+// (and round 1 of this library, mrgs_sort.hip) gets there with global radix passes over all R (tile, gaussian) pairs plus an
+// inclusive scan and a blocking read-back.  The order inside a tile is a TOTAL order on (depth bits, gaussian index), so it
+// does not matter in which order the pairs arrive in their tile's segment -- only that the segment is sorted afterwards:
+//
+//   tile_count_kernel   G workgroups, each over a fixed slice of the surfels: per-tile pair counts of the slice in an LDS
+//                       histogram (LDS atomics only), written out as row g of a [G][tiles] matrix
+//   tile_scan_kernel    one thread per tile: exclusive prefix of its column (= where each slice's pairs start inside the tile's
+//                       segment), tile totals, exclusive scan over the tiles (per 256-tile chunk; the last workgroup to finish
+//                       scans the chunk totals), num_rendered for the host
+//   tile_emit_kernel    same slices: LDS cursors = segment start + column prefix; every pair takes its slot with ONE LDS atomic and is
+//                       stored as a 64-bit key  depth bits << 32 | gaussian index << 4 | quadrant cull bits  -- no global atomic, no
+//                       look-back, no dependence between workgroups.  The cull of the surfel against the four 8x8 quadrants of the
+//                       tile is evaluated here, where the surfel's conic is in registers (round 1 gathered it per list entry)
+//   tile_sort_kernel    one workgroup per tile: bitonic sort of the segment's keys in LDS; writes point_list, the cull bits,
+//                       ranges[tile] and the per-quadrant survivor counts (the forward's work estimate)
+//   tile_sort_big_kernel  the rare tiles beyond the small kernel's LDS capacity (a device-side list): up to 16 384 keys in LDS,
+//                       beyond that the outer network stages run on global memory
+//
+// Four dependent launches and ~45 MB of traffic at C2 (P = 300k, R = 1.15 M) where the radix pipeline had eleven launches and
+// 116 MB; point_list, ranges and n_contrib stay bit-identical to the reference's 64-bit-key sort (tests/test_gpu_parity.py).
+#include "mrgs_blend_math.h"
+
+#define BIN_THREADS 1024
+#define SORT_SMALL_THREADS 256
+#define SORT_SMALL_CAP 2048
+#define SORT_BIG_THREADS 1024
+#define SORT_BIG_CAP 16384
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Visits every tile of the rectangles of one wave's surfels: lanes with few tiles walk them serially, a surfel with many tiles
+// (a heavy-tailed scene has splats of hundreds of tiles) is spread over the 64 lanes.  own() / take(src) switch the caller's
+// "current surfel" to the lane's own one / to the one of lane src; take runs in wave-uniform control flow (all lanes active, src
+// uniform), so it may use readlane broadcasts.  f(tile) is then called once per tile of the current surfel.
+#define BIN_COOP_MIN 24
+template <typename Own, typename Take, typename F>
+__device__ __forceinline__ void for_each_tile(bool have, uint2 r, int tiles_x, Own own, Take take, F f)
+{
+    const int lane = threadIdx.x & 63;
+    const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+    const int w = x1 - x0, n = have ? w * (y1 - y0) : 0;
+    const bool big = n >= BIN_COOP_MIN;
+    own();
+    if (have && !big)
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) f(y * tiles_x + x);
+    uint64_t todo = __builtin_amdgcn_ballot_w64(big);
+    while (todo != 0ull) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
+        const int sw = __builtin_amdgcn_readlane(w, src), sn = __builtin_amdgcn_readlane(n, src);
+        take(src);
+        for (int k = lane; k < sn; k += 64) {
+            const int yy = k / sw;
+            f((sy0 + yy) * tiles_x + sx0 + (k - yy * sw));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, int per_group, const uint32_t* __restrict__ tiles_touched,
+                                                                 const uint2* __restrict__ rect, int tiles_x, int T, int Tpad,
+                                                                 uint32_t* __restrict__ mat)
+{
+    extern __shared__ uint32_t s_cnt[];
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_cnt[t] = 0u;
+    __syncthreads();
+    const int beg = blockIdx.x * per_group, end = min(P, beg + per_group);
+    for (int i0 = beg; i0 < end; i0 += BIN_THREADS) {          // wave-uniform trip count: the cooperative part needs all lanes
+        const int i = i0 + threadIdx.x;
+        const bool have = i < end && tiles_touched[i] != 0u;
+        const uint2 r = have ? rect[i] : make_uint2(0u, 0u);
+        for_each_tile(have, r, tiles_x, [] {}, [](int) {}, [&](int tile) { atomicAdd(&s_cnt[tile], 1u); });
+    }
+    __syncthreads();
+    uint32_t* row = mat + (size_t)blockIdx.x * Tpad;
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_cnt[t];
+}
+
+// One thread per tile.  mat[g][t]: in: pairs of slice g in tile t; out: pairs of slices < g in tile t.
+// tile_cnt[t] = pairs of tile t; tile_loc[t] = exclusive scan of tile_cnt inside the tile's 256-tile chunk; chunk_base[c] = pairs of the
+// chunks before c (written by the last workgroup to finish); state[0] = num_rendered, state[2] = ticket (zero on entry).
+__global__ void __launch_bounds__(256) tile_scan_kernel(int G, int T, int Tpad, uint32_t* __restrict__ mat, uint32_t* __restrict__ tile_cnt,
+                                                        uint32_t* __restrict__ tile_loc, uint32_t* __restrict__ chunk_tot,
+                                                        uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
+                                                        uint32_t* __restrict__ host_slot)
+{
+    __shared__ uint32_t wave_sums[4];
+    __shared__ int s_last;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t run = 0;
+    if (t < T) {
+        uint32_t* col = mat + t;
+        int g = 0;
+        for (; g + 8 <= G; g += 8) {                 // eight rows in flight
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = col[(size_t)(g + k) * Tpad];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { col[(size_t)(g + k) * Tpad] = run; run += v[k]; }
+        }
+        for (; g < G; g++) { const uint32_t v = col[(size_t)g * Tpad]; col[(size_t)g * Tpad] = run; run += v; }
+        tile_cnt[t] = run;
+    }
+    // exclusive scan of the chunk's tile totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t s = wave_sums[w]; if (w < wave) off += s; tot += s; }
+    if (t < T) tile_loc[t] = off + inc - run;
+    if (threadIdx.x == 0) {
+        st_agent(chunk_tot + blockIdx.x, tot);
+        __threadfence();
+        s_last = atomicAdd(state + 2, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // last workgroup: exclusive scan over the chunk totals (<= 144 chunks for the tile counts this path serves)
+    uint32_t carry = 0;
+    for (int c0 = 0; c0 < (int)gridDim.x; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const uint32_t v = c < (int)gridDim.x ? ld_agent(chunk_tot + c) : 0u;
+        uint32_t in2 = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(in2, d, 64);
+            if (lane >= d) in2 += u;
+        }
+        __syncthreads();
+        if (lane == 63) wave_sums[wave] = in2;
+        __syncthreads();
+        uint32_t o2 = 0, t2 = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t s = wave_sums[w]; if (w < wave) o2 += s; t2 += s; }
+        if (c < (int)gridDim.x) chunk_base[c] = carry + o2 + in2 - v;
+        carry += t2;
+    }
+    if (threadIdx.x == 0) {
+        state[0] = carry;                             // num_rendered (pair counts are checked against 2^30 by the host)
+        if (host_slot != nullptr) {                   // pinned, device-mapped: the host waits for the event recorded behind this kernel
+            __hip_atomic_store(host_slot, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_slot + 1, state[1], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_group, const uint32_t* __restrict__ tiles_touched,
+                                                                const uint2* __restrict__ rect, const uint32_t* __restrict__ depth_key,
+                                                                const float4* __restrict__ cull, int tiles_x, int T, int Tpad,
+                                                                const uint32_t* __restrict__ mat, const uint32_t* __restrict__ tile_loc,
+                                                                const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ state,
+                                                                int64_t capacity, unsigned long long* __restrict__ pairs, uint32_t* __restrict__ census,
+                                                                uint32_t* __restrict__ big_count)
+{
+    extern __shared__ uint32_t s_cur[];
+    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
+    if (blockIdx.x == 0 && threadIdx.x == 0) big_count[0] = 0u;   // list of oversized tiles of tile_sort_kernel: empty
+    if ((int64_t)state[0] > capacity) return;          // binning workspace sized from a guess that was too small: the host redoes this phase
+    const uint32_t* row = mat + (size_t)blockIdx.x * Tpad;
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_cur[t] = chunk_base[t >> 8] + tile_loc[t] + row[t];
+    __syncthreads();
+    const int beg = blockIdx.x * per_group, end = min(P, beg + per_group);
+    for (int i0 = beg; i0 < end; i0 += BIN_THREADS) {
+        const int i = i0 + threadIdx.x;
+        const bool have = i < end && tiles_touched[i] != 0u;
+        uint2 r = make_uint2(0u, 0u);
+        CullConic c = mrgs_cull_never();
+        uint32_t dk = 0;
+        if (have) { r = rect[i]; c = mrgs_cull_load(cull, (uint32_t)i); dk = depth_key[i]; }
+        CullConic cc;
+        uint32_t d, id;
+        auto rl = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+        for_each_tile(have, r, tiles_x,
+            [&] { cc = c; d = dk; id = (uint32_t)i; },
+            [&](int src) {
+                cc.a = make_float4(rl(c.a.x, src), rl(c.a.y, src), rl(c.a.z, src), rl(c.a.w, src));
+                cc.b = make_float4(rl(c.b.x, src), rl(c.b.y, src), rl(c.b.z, src), rl(c.b.w, src));
+                d = (uint32_t)__builtin_amdgcn_readlane((int)dk, src);
+                id = (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + src);
+            },
+            [&](int tile) {
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const float x0 = (float)(tx * MRGS_BLOCK_X), y0 = (float)(ty * MRGS_BLOCK_Y);
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                m |= mrgs_block_may_touch(cc, x0 + (float)(8 * (q & 1)), y0 + (float)(8 * (q >> 1)), 7.0f, 7.0f) ? (1u << q) : 0u;
+            const uint32_t pos = atomicAdd(&s_cur[tile], 1u);
+            pairs[pos] = ((unsigned long long)d << 32) | (unsigned long long)((id << 4) | m);
+        });
+    }
+}
+
+// ---- bitonic network with ascending comparators only (first step of a merge level mirrors, the rest are half-cleaners): a
+// virtual +inf padding beyond n then never moves, so comparators whose upper element is >= n are skipped and nothing is padded.
+template <int THREADS>
+__device__ __forceinline__ void lds_levels(unsigned long long* s, int n, int k_from, int k_to)
+{
+    // merge levels k = k_from .. k_to (powers of two, <= capacity) on s[0, n)
+    for (int k = k_from; k <= k_to; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool flip = j == (k >> 1);
+            for (int i = threadIdx.x; 2 * i < n + j; i += THREADS) {     // comparators whose lower element can exist
+                int lo, hi;
+                if (flip) { const int blk = i / j, o = i - blk * j; lo = blk * k + o; hi = blk * k + k - 1 - o; }
+                else { lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)); hi = lo | j; }
+                if (hi < n) {
+                    const unsigned long long a = s[lo], b = s[hi];
+                    if (a > b) { s[lo] = b; s[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// half-cleaner steps j = j_from .. 1 of level k on s[0, m) where s holds the elements [base, base + m) of the tile (m = chunk)
+template <int THREADS>
+__device__ __forceinline__ void lds_tail(unsigned long long* s, int m, int j_from)
+{
+    for (int j = j_from; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; 2 * i < m + j; i += THREADS) {
+            const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+            if (hi < m) {
+                const unsigned long long a = s[lo], b = s[hi];
+                if (a > b) { s[lo] = b; s[hi] = a; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// sorted keys of one tile (in LDS: s, or in global memory: gkeys) -> point_list, cull bits, per-quadrant counts
+template <int THREADS>
+__device__ __forceinline__ void write_tile(const unsigned long long* src, int n, uint32_t beg, int tile, uint32_t* __restrict__ plist,
+                                           uint8_t* __restrict__ qmask, uint32_t* __restrict__ item_est, uint32_t* s_q /*[4]*/)
+{
+    if (threadIdx.x < 4) s_q[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t cq[4] = {0u, 0u, 0u, 0u};
+    for (int e0 = 0; e0 < n; e0 += THREADS) {
+        const int e = e0 + threadIdx.x;
+        uint32_t m = 0;
+        if (e < n) {
+            const uint32_t low = (uint32_t)src[e];
+            m = low & 15u;
+            plist[beg + e] = low >> 4;
+            qmask[beg + e] = (uint8_t)m;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) cq[q] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((m >> q) & 1u));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (cq[q]) atomicAdd(&s_q[q], cq[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = s_q[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_SMALL_THREADS) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
+                                                                       const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
+                                                                       int64_t capacity, const unsigned long long* __restrict__ pairs,
+                                                                       uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask, uint2* __restrict__ ranges,
+                                                                       uint32_t* __restrict__ item_est, uint32_t* __restrict__ big_list,
+                                                                       uint32_t* __restrict__ census)
+{
+    __shared__ unsigned long long s[SORT_SMALL_CAP];
+    __shared__ uint32_t s_q[4];
+    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
+    const int tile = blockIdx.x;
+    // binning workspace sized from a guess that was too small: nothing was emitted; the blend kernels queued behind this one must
+    // find empty lists (the host redoes the phase on an exactly sized workspace)
+    const int n = (int64_t)state[0] > capacity ? 0 : (int)tile_cnt[tile];
+    const uint32_t beg = chunk_base[tile >> 8] + tile_loc[tile];
+    if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, beg + (uint32_t)n) : make_uint2(0u, 0u);   // empty tiles read (0, 0), rasterizer_impl.cu:316
+    if (n == 0) {
+        if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = 0u;
+        return;
+    }
+    if (n > SORT_SMALL_CAP) {                            // rare: handed to tile_sort_big_kernel
+        if (threadIdx.x == 0) big_list[atomicAdd(state + 3, 1u)] = (uint32_t)tile;
+        return;
+    }
+    for (int e = threadIdx.x; e < n; e += SORT_SMALL_THREADS) s[e] = pairs[beg + e];
+    __syncthreads();
+    lds_levels<SORT_SMALL_THREADS>(s, n, 2, next_pow2(n));
+    write_tile<SORT_SMALL_THREADS>(s, n, beg, tile, plist, qmask, item_est, s_q);
+}
+
+__global__ void __launch_bounds__(SORT_BIG_THREADS) tile_sort_big_kernel(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
+                                                                         const uint32_t* __restrict__ chunk_base, const uint32_t* __restrict__ state,
+                                                                         int64_t capacity, unsigned long long* __restrict__ pairs,
+                                                                         uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask,
+                                                                         uint32_t* __restrict__ item_est, const uint32_t* __restrict__ big_list)
+{
+    extern __shared__ unsigned long long s_big[];        // SORT_BIG_CAP keys
+    __shared__ uint32_t s_q[4];
+    if ((int64_t)state[0] > capacity) return;
+    const int n_big = (int)state[3];
+    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const int tile = (int)big_list[b];
+        const int n = (int)tile_cnt[tile];
+        const uint32_t beg = chunk_base[tile >> 8] + tile_loc[tile];
+        unsigned long long* g = pairs + beg;
+        if (n <= SORT_BIG_CAP) {
+            for (int e = threadIdx.x; e < n; e += SORT_BIG_THREADS) s_big[e] = g[e];
+            __syncthreads();
+            lds_levels<SORT_BIG_THREADS>(s_big, n, 2, next_pow2(n));
+            write_tile<SORT_BIG_THREADS>(s_big, n, beg, tile, plist, qmask, item_est, s_q);
+            __syncthreads();
+            continue;
+        }
+        // more keys than LDS holds: levels up to SORT_BIG_CAP chunk by chunk in LDS, then per level the wide steps on global
+        // memory (one workgroup: __syncthreads orders them) and the narrow steps in LDS again
+        for (int c0 = 0; c0 < n; c0 += SORT_BIG_CAP) {
+            const int m = min(SORT_BIG_CAP, n - c0);
+            for (int e = threadIdx.x; e < m; e += SORT_BIG_THREADS) s_big[e] = g[c0 + e];
+            __syncthreads();
+            lds_levels<SORT_BIG_THREADS>(s_big, m, 2, SORT_BIG_CAP);
+            for (int e = threadIdx.x; e < m; e += SORT_BIG_THREADS) g[c0 + e] = s_big[e];
+            __syncthreads();
+        }
+        const int npad = next_pow2(n);
+        for (int k = 2 * SORT_BIG_CAP; k <= npad; k <<= 1) {
+            for (int j = k >> 1; j >= SORT_BIG_CAP; j >>= 1) {
+                const bool flip = j == (k >> 1);
+                __threadfence_block();
+                for (int i = threadIdx.x; 2 * i < n + j; i += SORT_BIG_THREADS) {
+                    int lo, hi;
+                    if (flip) { const int blk = i / j, o = i - blk * j; lo = blk * k + o; hi = blk * k + k - 1 - o; }
+                    else { lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)); hi = lo | j; }
+                    if (hi < n) {
+                        const unsigned long long a = g[lo], bb = g[hi];
+                        if (a > bb) { g[lo] = bb; g[hi] = a; }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            for (int c0 = 0; c0 < n; c0 += SORT_BIG_CAP) {
+                const int m = min(SORT_BIG_CAP, n - c0);
+                for (int e = threadIdx.x; e < m; e += SORT_BIG_THREADS) s_big[e] = g[c0 + e];
+                __syncthreads();
+                lds_tail<SORT_BIG_THREADS>(s_big, m, SORT_BIG_CAP >> 1);
+                for (int e = threadIdx.x; e < m; e += SORT_BIG_THREADS) g[c0 + e] = s_big[e];
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        write_tile<SORT_BIG_THREADS>(g, n, beg, tile, plist, qmask, item_est, s_q);
+        __syncthreads();
+    }
+}
+
+}   // namespace
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+int mrgs_bin_groups(int P) { const int g = (P + BIN_THREADS - 1) / BIN_THREADS; return g < 1 ? 1 : g > 256 ? 256 : g; }
+int mrgs_bin_tpad(int T) { return (T + 255) & ~255; }
+// the LDS histogram / cursor array of a slice workgroup holds one word per tile (160 KiB per workgroup on gfx950)
+bool mrgs_bin_supported(int T) { return T <= 36864; }
+
+static int per_group(int P) { const int G = mrgs_bin_groups(P); return ((P + G - 1) / G + 63) & ~63; }
+
+void mrgs_launch_tile_count_scan(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, uint32_t* host_slot, hipStream_t stream)
+{
+    const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    const int T = tiles_x * tiles_y, Tpad = mrgs_bin_tpad(T), G = mrgs_bin_groups(cfg.P);
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& attr_set = attr_done[dev & 63];
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void*)tile_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_BIG_CAP * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_count_kernel, dim3(G), dim3(BIN_THREADS), (size_t)T * sizeof(uint32_t), stream, cfg.P, per_group(cfg.P), g.tiles_touched,
+                       g.rect, tiles_x, T, Tpad, g.tile_mat);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(Tpad / 256), dim3(256), 0, stream, G, T, Tpad, g.tile_mat, g.tile_cnt, g.tile_loc, g.chunk_tot,
+                       g.chunk_base, g.counters, host_slot);
+}
+
+void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const MrgsBinWs& b, const MrgsImgWs& img, int64_t capacity,
+                                hipStream_t stream)
+{
+    const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    const int T = tiles_x * tiles_y, Tpad = mrgs_bin_tpad(T), G = mrgs_bin_groups(cfg.P);
+    unsigned long long* pairs = (unsigned long long*)b.tile_key[0];
+    hipLaunchKernelGGL(tile_emit_kernel, dim3(G), dim3(BIN_THREADS), (size_t)T * sizeof(uint32_t), stream, cfg.P, per_group(cfg.P), g.tiles_touched,
+                       g.rect, g.depth_key[0], g.cull, tiles_x, T, Tpad, g.tile_mat, g.tile_loc, g.chunk_base, g.counters, capacity, pairs,
+                       g.counters + 16, g.counters + 3);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(SORT_SMALL_THREADS), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,
+                       pairs, b.plist[0], b.qmask, img.ranges, img.item_est, g.big_list, g.counters + 16);
+    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(64), dim3(SORT_BIG_THREADS), (size_t)SORT_BIG_CAP * 8, stream, g.tile_cnt, g.tile_loc, g.chunk_base,
+                       g.counters, capacity, pairs, b.plist[0], b.qmask, img.item_est, g.big_list);
+}

@@ -52,8 +52,16 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
     uint32_t* sort_ws;      // tickets / digit totals / status words of the depth sort (mrgs_sort_ws_words)
     uint32_t* scan_ws;      // ticket / status words of the tiles_touched scan (mrgs_scan_ws_words)
     size_t clear_bytes;     // size of the region that starts at counters
+    // tile binning without a global sort (mrgs_binning.hip); null when the image has more tiles than that path serves
+    uint32_t* tile_mat;     // [groups][Tpad] pairs of surfel slice g in tile t -> exclusive prefix over the slices
+    uint32_t* tile_cnt;     // [Tpad] pairs per tile
+    uint32_t* tile_loc;     // [Tpad] exclusive scan of tile_cnt inside the tile's 256-tile chunk
+    uint32_t* chunk_tot;    // [Tpad / 256]
+    uint32_t* chunk_base;   // [Tpad / 256] pairs of the chunks before
+    uint32_t* big_list;     // [Tpad] tiles whose segment exceeds the small sort kernel's LDS capacity (count: counters[3])
     size_t total;
 };
+// counters[]: 0 num_rendered, 1 error flag of the look-back kernels, 2 ticket of tile_scan_kernel, 3 length of big_list
 
 struct MrgsImgWs {
     uint2* ranges;       // [tiles]
@@ -69,7 +77,7 @@ struct MrgsImgWs {
 };
 
 struct MrgsBinWs {
-    uint32_t* tile_key[2];  // [R] ping-pong: tile id of each pair
+    uint32_t* tile_key[2];  // [R] ping-pong: tile id of each pair (one contiguous block: the 64-bit keys of mrgs_binning.hip alias it)
     uint32_t* plist[2];     // [R] ping-pong: gaussian index of each pair
     uint32_t* sort_ws;      // [16] 0: error flag; then tickets / digit totals / status words of the tile-id sort; cleared per forward
     size_t sort_ws_bytes;
@@ -119,6 +127,14 @@ int mrgs_radix_sort_pairs(uint32_t* key[2], uint32_t* val[2], uint32_t* ws, uint
 size_t mrgs_scan_ws_words(int n);
 void mrgs_scan_tiles(const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets, uint32_t* ws, uint32_t* total_out,
                      uint32_t* error_flag, int n, hipStream_t stream);
+
+// tile binning without a global sort (mrgs_binning.hip)
+int mrgs_bin_groups(int P);
+int mrgs_bin_tpad(int T);
+bool mrgs_bin_supported(int T);
+void mrgs_launch_tile_count_scan(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, uint32_t* host_slot, hipStream_t stream);
+void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const MrgsBinWs& b, const MrgsImgWs& img, int64_t capacity,
+                                hipStream_t stream);
 
 void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, int32_t* radii,
                                 hipStream_t stream);
