@@ -211,6 +211,19 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
 int mrgs_cubemap_mip_forward(int32_t res_out, const float* in, float* out, void* stream);
 int mrgs_cubemap_mip_backward(int32_t res_fine, const float* dout, float* g_fine, void* stream);
 
+/* ---- cubemapencoder fetch primitive (BASELINE.json north star: "the cubemapencoder mip lookup") ---------------------------
+ * Replaces `_cubemapencoder.cubemap_encode_forward / cubemap_encode_backward` of the reference's CUDA extension
+ * (submodules/cubemapencoder/src/cubemapencoder.cu:430-485, 713-775; bindings.cpp), same argument meaning and layouts:
+ * inputs [B,3] directions (a zero vector yields fail_value), cubemap [6,C,L,L], fail_value [C], outputs [C,B];
+ * interp 0 = nearest (:380-428), 1 = bilinear; seamless != 0 takes edge texels from the neighbouring face and averages the three
+ * texels of a cube vertex (:298-334, face / edge tables :66-187).  Backward: grad_cubemap [6,C,L,L] and grad_fail [C] are ACCUMULATED
+ * into (the caller passes zeros, as cubemap_encoder.py:55-57 does), grad_inputs [B,3] is written in full (zeros for nearest, which
+ * the reference leaves uninitialised). */
+int mrgs_cubemap_encode_forward(const float* inputs, const float* cubemap, const float* fail_value, float* outputs, int32_t interp,
+                                int32_t seamless, int64_t B, int32_t C, int32_t L, void* stream);
+int mrgs_cubemap_encode_backward(const float* grad_outputs, const float* inputs, const float* cubemap, float* grad_cubemap, float* grad_inputs,
+                                 float* grad_fail, int32_t interp, int32_t seamless, int64_t B, int32_t C, int32_t L, void* stream);
+
 /* Visibility blend of get_specular_color_surfel (utils/refl_utils.py:393-401), one pass each way:
  * specular = (direct * vis + (1 - vis) * indirect) * alpha * weight, indirect_color = (1 - vis) * indirect * alpha * weight.
  * direct / specular / indirect_color [3,H,W], weight [H,W,3] (layouts of mrgs_shade_specular_forward), indirect [H,W,3] and alpha

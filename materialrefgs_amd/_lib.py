@@ -134,6 +134,9 @@ SYMBOLS = {
     "mrgs_indirect_blend_backward": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap),
                                                     ctypes.POINTER(MrgsStridedMap), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p]),
+    "mrgs_cubemap_encode_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p]),
+    "mrgs_cubemap_encode_backward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32,
+                                                    c_int32, c_void_p]),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_sh_grad_expand_surfel": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p]),
