@@ -21,9 +21,10 @@ import torch
 from . import _lib
 from ._lib import MrgsMapsFrame, MrgsSurfelGrads, MrgsSurfelParams
 
-from .gs_utils import build_scaling_rotation, flip_align_view, linear_to_srgb, safe_normalize
+from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
-from .shading import EnvLight, get_specular_color_surfel, shade_and_composite_surfel
+from .shading import (EnvLight, get_full_color_volume, get_full_color_volume_indirect, get_specular_color_surfel,
+                      shade_and_composite_surfel)
 
 
 class SurfelModel:
@@ -41,6 +42,7 @@ class SurfelModel:
         self._indirect_dc = indirect_dc if indirect_dc is not None else z(P, 1, 3)
         self._indirect_rest = indirect_rest if indirect_rest is not None else z(P, 15, 3)
         self.env_map = envmap
+        self.env_map_2 = None           # the second environment map render_volume shades with (GaussianModel.get_envmap_2)
         self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
         self.ray_tracer = None
 
@@ -59,6 +61,7 @@ class SurfelModel:
     get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
     get_indirect = property(lambda s: torch.cat((s._indirect_dc, s._indirect_rest), dim=1))
     get_envmap = property(lambda s: s.env_map)
+    get_envmap_2 = property(lambda s: s.env_map_2 if s.env_map_2 is not None else s.env_map)
 
     def get_normal(self, scaling_modifier, dir_pp_normalized):
         """gaussian_model.py:269-285 (return_delta=False): third column of R(q), flipped to face the viewer."""
@@ -324,4 +327,60 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
         background = bg_color[:, None, None] * (1 - render_alpha)
         out.update(extra_dict)
         out["indirect_color"] = diffuse_map + extra_dict["indirect_color"] + background          # :446-449
+    return out
+
+
+def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None):
+    """gaussian_renderer/__init__.py:521-749: every gaussian is shaded on its own (per-gaussian normal, mirror direction, split-sum
+    weight, environment lookups: utils/refl_utils.py:426-484) and the rasterizer blends the shaded colour (`colors_precomp =
+    specular + diffuse`) plus S = 11 material channels (roughness, refl, diffuse 3, specular 3, ori_color 3; 18 with opt.indirect:
+    + visibility, indirect 3, direct_light 3).  SH-indirect branch (`pipe.use_asg` False) and the rasterizer's own covariance path
+    (`pipe.compute_cov3D_python` False), which are the reference's defaults.  Environment lookups and the rasterizer run in
+    libmrgs.so; the per-gaussian elementwise glue is torch, as in the reference."""
+    if opt is None:
+        opt = SimpleNamespace(indirect=False)
+    if getattr(pipe, "use_asg", False) or getattr(pipe, "compute_cov3D_python", False):
+        raise NotImplementedError("render_volume: pipe.use_asg / pipe.compute_cov3D_python are not supported (reference defaults are False)")
+    means2D = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
+    means3D, opacity = pc.get_xyz, pc.get_opacity
+    refl, ori_color, roughness = pc.get_refl, pc.get_ori_color, pc.get_rough
+    scales, rotations = pc.get_scaling, pc.get_rotation
+    dir_pp = means3D - viewpoint_camera.camera_center
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
+    w_o = -dir_pp_normalized
+    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
+    shs_indirect = pc.get_indirect.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
+    indirect_on = bool(getattr(opt, "indirect", False))
+    if indirect_on:
+        diffuse, specular, extra = get_full_color_volume_indirect(pc.get_envmap_2, means3D, ori_color, viewpoint_camera.HWK, viewpoint_camera.R,
+                                                                  viewpoint_camera.T, normals.contiguous(), opacity, refl_strength=refl,
+                                                                  roughness=roughness, pc=pc, indirect_light=indirect)
+        features = torch.cat((roughness, refl, diffuse, specular, ori_color, extra["visibility"], indirect, extra["direct_light"]), dim=-1)
+    else:
+        diffuse, specular = get_full_color_volume(pc.get_envmap_2, means3D, ori_color, viewpoint_camera.HWK, viewpoint_camera.R,
+                                                  viewpoint_camera.T, normals.contiguous(), opacity, refl_strength=refl, roughness=roughness)
+        features = torch.cat((roughness, refl, diffuse, specular, ori_color), dim=-1)
+    colors_precomp = specular + diffuse
+    contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
+        means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, features=features, opacities=opacity, scales=scales,
+        rotations=rotations, cov3D_precomp=None)
+    full_color = rendered_image
+    render_roughness, render_refl_strength = rendered_features[:1], rendered_features[1:2]
+    render_diffuse_color, render_specular_color = rendered_features[2:5], rendered_features[5:8]
+    render_ori_color = rendered_features[8:11]
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe)
+    render_alpha = reg["render_alpha"]
+    if srgb:
+        render_diffuse_color, render_specular_color = linear_to_srgb(render_diffuse_color), linear_to_srgb(render_specular_color)
+        full_color = linear_to_srgb(full_color)
+    final_image = full_color + bg_color[:, None, None] * (1 - render_alpha)
+    out = {"render": final_image, "refl_strength_map": render_refl_strength, "diffuse_map": render_diffuse_color,
+           "specular_map": render_specular_color, "base_color_map": render_ori_color, "roughness_map": render_roughness,
+           "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
+           "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if indirect_on:
+        out.update({"visibility": rendered_features[11:12], "indirect_light": rendered_features[12:15], "direct_light": rendered_features[15:18]})
     return out

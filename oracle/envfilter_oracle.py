@@ -161,11 +161,14 @@ def build_mips(base, min_res, min_roughness=0.08, max_roughness=0.5, cutoff=0.99
     return spec, diffuse, ops
 
 
-def build_mips_backward(ops, g_spec):
-    """Gradient w.r.t. base of sum_l <g_spec[l], specular[l]> under the reference's autograd rules."""
+def build_mips_backward(ops, g_spec, g_diffuse=None):
+    """Gradient w.r.t. base of sum_l <g_spec[l], specular[l]> (+ <g_diffuse, diffuse>) under the reference's autograd rules."""
     g = None
     for l in range(len(ops) - 1, -1, -1):
         gl = (ops[l].T @ np.asarray(g_spec[l], dtype=np.float64).reshape(-1, 3)).reshape(g_spec[l].shape)
+        if l == len(ops) - 1 and g_diffuse is not None:      # diffuse_cubemap reads the raw last level (scene/light.py:84-86)
+            N = g_spec[l].shape[1]
+            gl = gl + (diffuse_matrix(N).T @ np.asarray(g_diffuse, dtype=np.float64).reshape(-1, 3)).reshape(g_spec[l].shape)
         if g is not None:
             gl = gl + mip_backward(g)
         g = gl

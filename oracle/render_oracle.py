@@ -32,11 +32,14 @@ class _OracleRaster(torch.autograd.Function):
     reference's fp32 tensors are)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, opacities, shs, features, scales, rotations, cam, sh_degree, variant):
+    def forward(ctx, means3D, means2D, opacities, shs, features, scales, rotations, cam, sh_degree, variant, precomp=False):
+        # precomp: `shs` holds precomputed colours [P,3] (render_volume: colors_precomp = specular + diffuse)
         r = ro.OracleRender(means3D=means3D, opacities=opacities, H=cam.image_height, W=cam.image_width,
                             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), viewmatrix=cam.world_view_transform,
-                            projmatrix=cam.full_proj_transform, campos=cam.camera_center, shs=shs, features=features, scales=scales,
+                            projmatrix=cam.full_proj_transform, campos=cam.camera_center, shs=None if precomp else shs,
+                            colors_precomp=shs if precomp else None, features=features, scales=scales,
                             rotations=rotations, sh_degree=sh_degree, variant=variant)
+        ctx.precomp = precomp
         ctx.r = r
         ctx.dtype = means3D.dtype
         ctx.shapes = (means3D.shape, opacities.shape, shs.shape, features.shape, scales.shape, rotations.shape)
@@ -53,25 +56,27 @@ class _OracleRaster(torch.autograd.Function):
         g = r.backward(z(g_color, (3, H, W)), z(g_feature, (S, H, W)), z(g_others, (7, H, W)))
         t = lambda a, shp: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.dtype).reshape(shp)
         s = ctx.shapes
-        return (t(g["means3D"], s[0]), t(g["means2D"], (s[0][0], 3)), t(g["opacity"], s[1]), t(g["sh"], s[2]), t(g["features"], s[3]),
-                t(g["scales"], s[4]), t(g["rotations"], s[5]), None, None, None)
+        return (t(g["means3D"], s[0]), t(g["means2D"], (s[0][0], 3)), t(g["opacity"], s[1]), t(g["colors" if ctx.precomp else "sh"], s[2]),
+                t(g["features"], s[3]), t(g["scales"], s[4]), t(g["rotations"], s[5]), None, None, None, None)
 
 
 class _OracleBuildMips(torch.autograd.Function):
-    """EnvLight.build_mips (scene/light.py:72-86) with the dense float64 operators of envfilter_oracle."""
+    """EnvLight.build_mips (scene/light.py:72-86) with the dense float64 operators of envfilter_oracle: (specular levels..., diffuse)."""
 
     @staticmethod
     def forward(ctx, base, min_res, min_roughness, max_roughness):
-        spec, _diffuse, ops = ef.build_mips(base.detach().numpy(), min_res, min_roughness, max_roughness)
+        spec, diffuse, ops = ef.build_mips(base.detach().numpy(), min_res, min_roughness, max_roughness)
         ctx.ops = ops
         ctx.dtype = base.dtype
-        return tuple(torch.from_numpy(np.ascontiguousarray(s)).to(base.dtype) for s in spec)
+        return tuple(torch.from_numpy(np.ascontiguousarray(s)).to(base.dtype) for s in list(spec) + [diffuse])
 
     @staticmethod
-    def backward(ctx, *g_spec):
+    def backward(ctx, *g_all):
+        g_spec, g_diff = g_all[:-1], g_all[-1]
         shapes = [(6, int(round(math.sqrt(op.shape[0] / 6))), int(round(math.sqrt(op.shape[0] / 6))), 3) for op in ctx.ops]
         g = [np.zeros(s) if gi is None else gi.detach().numpy() for gi, s in zip(g_spec, shapes)]
-        return torch.from_numpy(ef.build_mips_backward(ctx.ops, g)).to(ctx.dtype), None, None, None
+        gd = None if g_diff is None else g_diff.detach().numpy()
+        return torch.from_numpy(ef.build_mips_backward(ctx.ops, g, gd)).to(ctx.dtype), None, None, None
 
 
 def sample_camera_rays_unnormalize(H, W, K, R, T):
@@ -109,7 +114,7 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
     reg = go.compute_2dgs_normal_and_regularizations_reference(allmap, cam_dt, pipe)                  # :392
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
     normal_map = render_normal.permute(1, 2, 0) / render_alpha.permute(1, 2, 0).clamp_min(1e-6)       # :419-421
-    mips = _OracleBuildMips.apply(env_base, env_min_res, min_roughness, max_roughness)
+    *mips, _diffuse_tex = _OracleBuildMips.apply(env_base, env_min_res, min_roughness, max_roughness)
     _H, _W, K = cam.HWK
     R32, T32 = cam.R.float(), cam.T.float()
     a_hw, r_hw, ro_hw = render_alpha.permute(1, 2, 0), refl_strength.permute(1, 2, 0), roughness.permute(1, 2, 0)
@@ -149,4 +154,68 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
     if indirect:
         out.update(extra)
         out["indirect_color"] = diffuse + extra["indirect_color"] + background                        # :449-452
+    return out
+
+
+def render_volume_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=False, indirect=False, mesh=None, variant="fused",
+                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None):
+    """gaussian_renderer/__init__.py:521-749 (`render_volume`, SH-indirect branch) with utils/refl_utils.py:426-484 for the
+    per-gaussian shading, INCLUDING the reference's `fg[0]` indexing (appendix B-27: every gaussian gets the split-sum table value of
+    gaussian 0).  `pc`: SurfelModel on the CPU; `env_base`: the texels of pc.get_envmap_2."""
+    from materialrefgs_amd.gs_utils import eval_sh
+    from materialrefgs_amd.shading import load_fg_lut
+    dt = pc._xyz.dtype
+    lut = (load_fg_lut("cpu") if lut is None else lut).to(dt)
+    means2D = torch.zeros_like(pc._xyz, requires_grad=True)
+    means3D, opacity = pc.get_xyz, pc.get_opacity
+    refl, ori_color, roughness = pc.get_refl, pc.get_ori_color, pc.get_rough
+    dir_pp = means3D - cam.camera_center.to(dt)
+    dir_n = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    normals = pc.get_normal(1.0, dir_n)
+    w_o = -dir_n
+    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o                  # :631-634
+    shs_indirect = pc.get_indirect.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    indirect_light = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
+    # get_full_color_volume[_indirect], utils/refl_utils.py:426-484
+    *mips, diffuse_tex = _OracleBuildMips.apply(env_base, env_min_res, min_roughness, max_roughness)
+    Rt = cam.R.to(dt).T
+    rays_o = (-Rt.T @ cam.T.to(dt).unsqueeze(-1)).flatten()
+    wo2 = rays_o - means3D
+    wo2 = wo2 / torch.clamp(torch.linalg.norm(wo2, dim=-1, keepdim=True), min=1e-20)
+    NdotV = torch.sum(wo2 * normals, dim=-1, keepdim=True)
+    rays_refl = 2 * normals * NdotV - wo2
+    rays_refl = rays_refl / torch.clamp(torch.linalg.norm(rays_refl, dim=-1, keepdim=True), min=1e-20)
+    fg = so.lut_fetch(lut, torch.cat([NdotV, roughness], -1).clamp(0, 1))                               # [N,2]
+    fg0 = fg[0]                                                                                          # the reference's fg[0] (B-27)
+    diffuse = so.env_lookup([diffuse_tex], normals) * (1 - refl) * ori_color
+    direct_light = so.env_lookup(list(mips), rays_refl, roughness.reshape(-1), min_roughness, max_roughness)
+    specular_weight = (0.04 * (1 - refl) + ori_color * refl) * fg0[0:1] + fg0[1:2]
+    if indirect:
+        visibility = torch.ones_like(opacity)
+        mask = (opacity > 0).squeeze(-1)
+        traced = visibility.clone()
+        if mesh is not None:
+            _, _, depth, _ = to.trace(mesh[0], mesh[1], means3D[mask].detach().numpy(), rays_refl[mask].detach().numpy())
+            traced[mask] = torch.from_numpy((depth >= 10).astype(np.float64)).to(dt).unsqueeze(-1)
+        visibility = traced if visibility_bits is None else visibility_bits.to(dt).reshape(-1, 1)
+        specular = (direct_light * visibility + (1 - visibility) * indirect_light) * specular_weight
+        features = torch.cat((roughness, refl, diffuse, specular, ori_color, visibility, indirect_light, direct_light), dim=-1)
+    else:
+        specular = direct_light * specular_weight
+        features = torch.cat((roughness, refl, diffuse, specular, ori_color), dim=-1)
+    colors_precomp = specular + diffuse
+    color, feat, allmap, radii = _OracleRaster.apply(means3D, means2D, opacity, colors_precomp, features, pc.get_scaling, pc.get_rotation, cam,
+                                                     pc.active_sh_degree, variant, True)
+    cam_dt = cam._replace(world_view_transform=cam.world_view_transform.to(dt), full_proj_transform=cam.full_proj_transform.to(dt))
+    reg = go.compute_2dgs_normal_and_regularizations_reference(allmap, cam_dt, pipe)
+    full_color, d_map, s_map = color, feat[2:5], feat[5:8]
+    if srgb:
+        d_map, s_map, full_color = linear_to_srgb(d_map), linear_to_srgb(s_map), linear_to_srgb(full_color)
+    final_image = full_color + bg_color.to(dt)[:, None, None] * (1 - reg["render_alpha"])
+    out = {"render": final_image, "refl_strength_map": feat[1:2], "diffuse_map": d_map, "specular_map": s_map, "base_color_map": feat[8:11],
+           "roughness_map": feat[:1], "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+           "rend_alpha": reg["render_alpha"], "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"],
+           "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if indirect:
+        out.update({"visibility": feat[11:12], "indirect_light": feat[12:15], "direct_light": feat[15:18], "visibility_traced": traced})
     return out

@@ -143,3 +143,93 @@ def test_render_surfel_matches_the_composed_oracle(gpu_device, indirect, srgb):
     print("\n".join(f"{n:18s} max-norm err {m:.2e}  elements beyond {bar:g}: {c} ({f:.1e})  max|g| {g:.3e}" for n, m, f, c, g in rows))
     for n, m, f, c, g in rows:
         assert m <= bar, (n, m, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------- render_volume
+VOL_KEYS = ("render", "refl_strength_map", "diffuse_map", "specular_map", "base_color_map", "roughness_map", "rend_alpha", "rend_normal",
+            "rend_dist", "surf_depth", "surf_normal")
+
+
+def test_render_volume_oracle_keeps_the_fg0_indexing_of_the_reference():
+    """CPU: the checker reproduces appendix B-27 -- every gaussian is weighted with the split-sum table value of gaussian 0 -- so
+    moving gaussian 0's roughness changes the specular colour of ALL gaussians, moving another one's changes only its own lookups."""
+    from oracle import render_oracle
+    P, H, W = 200, 32, 48
+    pc, base, _, _ = _models(P, H, W, seed=3)
+    cam = orbit_camera(2, H, W)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+    bg = torch.zeros(3)
+    out = render_oracle.render_volume_oracle(cam, pc, base, 8, pipe, bg)
+    for k in VOL_KEYS:
+        assert torch.isfinite(out[k]).all(), k
+    (out["specular_map"].sum() + out["render"].sum()).backward()
+    g_rough = pc._roughness.grad.abs().reshape(-1)
+    assert float(g_rough[0]) > 5 * float(g_rough[1:].median())      # gaussian 0 carries everyone's table lookup
+    assert base.grad is not None and float(base.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("indirect,srgb", [(False, False), (False, True), (True, False)])
+def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb):
+    from materialrefgs_amd.raytracing import RayTracer
+    from materialrefgs_amd.renderer import render_volume
+    from oracle import render_oracle
+    P, H, W = 3000, 96, 128
+    pc_o, base_o, pc_h, env = _models(P, H, W, seed=2, dev=gpu_device)
+    cam = orbit_camera(1, H, W)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False, use_asg=False, compute_cov3D_python=False)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    mesh = None
+    if indirect:
+        v1, t1 = sphere_mesh(24, 36, 0.9)
+        v2, t2 = sphere_mesh(12, 16, 0.8)
+        v2 = v2 + np.array([0.0, 2.2, 0.0], dtype=np.float32)
+        mesh = (np.concatenate([v1, v2]), np.concatenate([t1, t2 + len(v1)]))
+        pc_h.ray_tracer = RayTracer(*mesh)
+    env.build_mips()
+    out_h = render_volume(cam.to(gpu_device), pc_h, pipe, bg.to(gpu_device), srgb=srgb, opt=SimpleNamespace(indirect=indirect))
+    # visibility per gaussian: take the product's bits into the checker after comparing them with the checker's own trace
+    vis_bits = None
+    if indirect:
+        probe = render_oracle.render_volume_oracle(cam, pc_o, base_o.detach(), 8, pipe, bg, indirect=True, mesh=mesh)
+        traced = probe["visibility_traced"].reshape(-1)
+        # the product's per-gaussian visibility is not returned as such; recover it from a second call of its shading function
+        from materialrefgs_amd.shading import get_full_color_volume_indirect
+        with torch.no_grad():
+            camd = cam.to(gpu_device)
+            dirn = torch.nn.functional.normalize(pc_h.get_xyz - camd.camera_center, dim=1)
+            _, _, ex = get_full_color_volume_indirect(env, pc_h.get_xyz, pc_h.get_ori_color, cam.HWK, camd.R, camd.T, pc_h.get_normal(1.0, dirn).contiguous(),
+                                                      pc_h.get_opacity, refl_strength=pc_h.get_refl, roughness=pc_h.get_rough, pc=pc_h,
+                                                      indirect_light=torch.zeros(P, 3, device=gpu_device))
+        vis_bits = ex["visibility"].reshape(-1).cpu()
+        assert float((vis_bits.double() != traced).double().mean()) < 5e-3
+        assert 0.02 < float((traced == 0).double().mean()) < 0.98
+    out_o = render_oracle.render_volume_oracle(cam, pc_o, base_o, 8, pipe, bg, srgb=srgb, indirect=indirect, mesh=mesh, visibility_bits=vis_bits)
+    assert torch.equal(out_h["radii"].cpu(), out_o["radii"])
+    keys = VOL_KEYS + (("visibility", "indirect_light", "direct_light") if indirect else ())
+    for k in keys:
+        a, b = out_h[k].detach().cpu().double(), out_o[k].detach()
+        scale, tol = max(float(b.abs().max()), 1e-6), (2e-4 if k == "surf_normal" else 5e-5)
+        if k == "rend_dist":
+            scale, tol = 1.0, 5e-6
+        bad = float(((a - b).abs() > tol * scale).float().mean())
+        assert bad < (2e-3 if k == "surf_normal" else 1e-4), (k, float((a - b).abs().max()), scale, bad)
+    g = torch.Generator().manual_seed(5)
+    def loss(out, dev):
+        tot = 0
+        for k in keys:
+            w = torch.rand(out[k].shape, generator=g).to(out[k].dtype).to(dev)
+            tot = tot + (out[k] * w).sum() * (0.01 if k == "surf_depth" else 1.0)
+        return tot
+    loss(out_h, gpu_device).backward()
+    g = torch.Generator().manual_seed(5)
+    loss(out_o, "cpu").backward()
+    rows = []
+    for n, gh, go_ in [(n, getattr(pc_h, n).grad, getattr(pc_o, n).grad) for n in PARAMS if getattr(pc_o, n).grad is not None] + \
+                      [("env.base", env.base.grad, base_o.grad), ("viewspace_points", out_h["viewspace_points"].grad, out_o["viewspace_points"].grad)]:
+        assert gh is not None, n
+        a, b = gh.detach().cpu().double(), go_
+        rows.append((n, float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30), float(b.abs().max())))
+    print("\n".join(f"{n:18s} max-norm err {m:.2e}  max|g| {gm:.3e}" for n, m, gm in rows))
+    for n, m, gm in rows:
+        assert m <= 3e-4, (n, m)
