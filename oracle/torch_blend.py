@@ -188,3 +188,22 @@ def render(scene, cam, sh_degree=3, dtype=torch.float32):
     point_list, ranges = binning(st, H, W)
     color, feature, others, n_contrib = blend(st, c(scene.opacities)[:, 0], c(scene.features), point_list, ranges, H, W)
     return color, feature, others, n_contrib, int(point_list.shape[0])
+
+
+if __name__ == "__main__":
+    # bench.py's cpu_baseline_torch leg runs this file as a child process under a timeout: `python -m oracle.torch_blend <threads>`
+    import json
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera
+    threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    torch.set_num_threads(threads)
+    runs = {}
+    for name, (P_, HW_) in {"C1 (P=1000, 128x128)": (1000, 128), "C2/10 (P=30000, 256x256)": (30000, 256)}.items():
+        sc_ = make_shell_scene(P_, S=0, seed=0, radius_px=7.0 * HW_ / 800.0 if P_ > 1000 else 7.0, image_size=HW_)
+        t = time.perf_counter()
+        r_ = render(sc_, orbit_camera(0, HW_, HW_))
+        runs[name] = {"seconds": round(time.perf_counter() - t, 3), "num_rendered": r_[-1]}
+    print(json.dumps({"threads": torch.get_num_threads(), "runs": runs}))
