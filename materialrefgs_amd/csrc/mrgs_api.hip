@@ -106,8 +106,8 @@ MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W)
         g.tile_mat = c.take<uint32_t>((size_t)mrgs_bin_groups(P) * Tpad);
         g.tile_cnt = c.take<uint32_t>(Tpad);
         g.tile_loc = c.take<uint32_t>(Tpad);
-        g.chunk_tot = c.take<uint32_t>(Tpad / 256);
-        g.chunk_base = c.take<uint32_t>(Tpad / 256);
+        g.chunk_tot = c.take<uint32_t>(Tpad / 64);      // BIN_CHUNK tiles per chunk (mrgs_binning.hip)
+        g.chunk_base = c.take<uint32_t>(Tpad / 64);
         g.big_list = c.take<uint32_t>(Tpad);
     }
     g.total = mrgs_align_up(c.used, 256);

@@ -15,18 +15,21 @@
 //                       stored as a 64-bit key  depth bits << 32 | gaussian index << 4 | quadrant cull bits  -- no global atomic, no
 //                       look-back, no dependence between workgroups.  The cull of the surfel against the four 8x8 quadrants of the
 //                       tile is evaluated here, where the surfel's conic is in registers (round 1 gathered it per list entry)
-//   tile_sort_kernel    one workgroup per tile: bitonic sort of the segment's keys in LDS; writes point_list, the cull bits,
+//   tile_sort_kernel    one workgroup of eight waves per tile: a wave sorts up to 512 keys in its REGISTERS (8 per lane; a bitonic network
+//                       whose short-distance steps are compare-exchanges inside a lane and whose long-distance steps are lane-XOR
+//                       shuffles -- no LDS, no barrier); longer segments (up to 4 096 keys) are up to eight such runs merged by rank: every key
+//                       binary-searches the other runs in LDS and is stored at its final position.  Writes point_list, the cull bits,
 //                       ranges[tile] and the per-quadrant survivor counts (the forward's work estimate)
-//   tile_sort_big_kernel  the rare tiles beyond the small kernel's LDS capacity (a device-side list): up to 16 384 keys in LDS,
-//                       beyond that the outer network stages run on global memory
+//   tile_sort_big_kernel  the rare tiles beyond 4 096 keys (a device-side list): up to 16 384 keys in LDS, beyond that the outer
+//                       network stages run on global memory
 //
 // Four dependent launches and ~45 MB of traffic at C2 (P = 300k, R = 1.15 M) where the radix pipeline had eleven launches and
 // 116 MB; point_list, ranges and n_contrib stay bit-identical to the reference's 64-bit-key sort (tests/test_gpu_parity.py).
 #include "mrgs_blend_math.h"
 
 #define BIN_THREADS 1024
-#define SORT_SMALL_THREADS 256
-#define SORT_SMALL_CAP 2048
+#define SORT_SMALL_CAP 4096       // eight runs of 512 keys, one per wave of tile_sort_kernel
+#define BIN_CHUNK 64              // tiles per workgroup of tile_scan_kernel = granularity of tile_loc / chunk_base
 #define SORT_BIG_THREADS 1024
 #define SORT_BIG_CAP 16384
 
@@ -84,59 +87,64 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, int per_
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) row[t] = s_cnt[t];
 }
 
-// One thread per tile.  mat[g][t]: in: pairs of slice g in tile t; out: pairs of slices < g in tile t.
-// tile_cnt[t] = pairs of tile t; tile_loc[t] = exclusive scan of tile_cnt inside the tile's 256-tile chunk; chunk_base[c] = pairs of the
+// Workgroup = 64 consecutive tiles x 16 waves; wave w owns the slice rows [w * rpw, (w + 1) * rpw), lane = tile.
+// mat[g][t]: in: pairs of slice g in tile t; out: pairs of slices < g in tile t (all loads of a lane in flight at once).
+// tile_cnt[t] = pairs of tile t; tile_loc[t] = exclusive scan of tile_cnt inside the tile's 64-tile chunk; chunk_base[c] = pairs of the
 // chunks before c (written by the last workgroup to finish); state[0] = num_rendered, state[2] = ticket (zero on entry).
-__global__ void __launch_bounds__(256) tile_scan_kernel(int G, int T, int Tpad, uint32_t* __restrict__ mat, uint32_t* __restrict__ tile_cnt,
-                                                        uint32_t* __restrict__ tile_loc, uint32_t* __restrict__ chunk_tot,
-                                                        uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
-                                                        uint32_t* __restrict__ host_slot)
+#define SCAN_ROWS_MAX 16          // rows per wave: mrgs_bin_groups() <= 256 slices / 16 waves
+__global__ void __launch_bounds__(1024) tile_scan_kernel(int G, int T, int Tpad, uint32_t* __restrict__ mat, uint32_t* __restrict__ tile_cnt,
+                                                         uint32_t* __restrict__ tile_loc, uint32_t* __restrict__ chunk_tot,
+                                                         uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
+                                                         uint32_t* __restrict__ host_slot)
 {
-    __shared__ uint32_t wave_sums[4];
+    __shared__ uint32_t part[16][64];
+    __shared__ uint32_t wave_sums[16];
     __shared__ int s_last;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    uint32_t run = 0;
-    if (t < T) {
-        uint32_t* col = mat + t;
-        int g = 0;
-        for (; g + 8 <= G; g += 8) {                 // eight rows in flight
-            uint32_t v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = col[(size_t)(g + k) * Tpad];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { col[(size_t)(g + k) * Tpad] = run; run += v[k]; }
-        }
-        for (; g < G; g++) { const uint32_t v = col[(size_t)g * Tpad]; col[(size_t)g * Tpad] = run; run += v; }
-        tile_cnt[t] = run;
-    }
-    // exclusive scan of the chunk's tile totals
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = run;
+    const int t = blockIdx.x * BIN_CHUNK + lane;
+    const int rpw = (G + 15) >> 4, g0 = wave * rpw;
+    uint32_t v[SCAN_ROWS_MAX];
+    uint32_t sum = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t u = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += u;
+    for (int k = 0; k < SCAN_ROWS_MAX; k++) {
+        v[k] = (k < rpw && g0 + k < G && t < T) ? mat[(size_t)(g0 + k) * Tpad + t] : 0u;
     }
-    if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const uint32_t s = wave_sums[w]; if (w < wave) off += s; tot += s; }
-    if (t < T) tile_loc[t] = off + inc - run;
-    if (threadIdx.x == 0) {
-        st_agent(chunk_tot + blockIdx.x, tot);
-        __threadfence();
-        s_last = atomicAdd(state + 2, 1u) == gridDim.x - 1 ? 1 : 0;
+    for (int k = 0; k < SCAN_ROWS_MAX; k++) sum += v[k];
+    part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const uint32_t pw = part[w][lane]; if (w < wave) run += pw; total += pw; }
+#pragma unroll
+    for (int k = 0; k < SCAN_ROWS_MAX; k++) {
+        if (k < rpw && g0 + k < G && t < T) mat[(size_t)(g0 + k) * Tpad + t] = run;
+        run += v[k];
+    }
+    if (wave == 0) {
+        // exclusive scan of the 64 tile totals of the chunk
+        uint32_t inc = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += u;
+        }
+        if (t < T) { tile_cnt[t] = total; tile_loc[t] = inc - total; }
+        if (lane == 63) {
+            st_agent(chunk_tot + blockIdx.x, inc);
+            __threadfence();
+            s_last = atomicAdd(state + 2, 1u) == gridDim.x - 1 ? 1 : 0;
+        }
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    // last workgroup: exclusive scan over the chunk totals (<= 144 chunks for the tile counts this path serves)
+    // last workgroup: exclusive scan over the chunk totals (<= 576 chunks for the tile counts this path serves)
     uint32_t carry = 0;
-    for (int c0 = 0; c0 < (int)gridDim.x; c0 += 256) {
+    for (int c0 = 0; c0 < (int)gridDim.x; c0 += 1024) {
         const int c = c0 + threadIdx.x;
-        const uint32_t v = c < (int)gridDim.x ? ld_agent(chunk_tot + c) : 0u;
-        uint32_t in2 = v;
+        const uint32_t val = c < (int)gridDim.x ? ld_agent(chunk_tot + c) : 0u;
+        uint32_t in2 = val;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t u = __shfl_up(in2, d, 64);
@@ -147,8 +155,8 @@ __global__ void __launch_bounds__(256) tile_scan_kernel(int G, int T, int Tpad, 
         __syncthreads();
         uint32_t o2 = 0, t2 = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const uint32_t s = wave_sums[w]; if (w < wave) o2 += s; t2 += s; }
-        if (c < (int)gridDim.x) chunk_base[c] = carry + o2 + in2 - v;
+        for (int w = 0; w < 16; w++) { const uint32_t sw = wave_sums[w]; if (w < wave) o2 += sw; t2 += sw; }
+        if (c < (int)gridDim.x) chunk_base[c] = carry + o2 + in2 - val;
         carry += t2;
     }
     if (threadIdx.x == 0) {
@@ -173,7 +181,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
     if (blockIdx.x == 0 && threadIdx.x == 0) big_count[0] = 0u;   // list of oversized tiles of tile_sort_kernel: empty
     if ((int64_t)state[0] > capacity) return;          // binning workspace sized from a guess that was too small: the host redoes this phase
     const uint32_t* row = mat + (size_t)blockIdx.x * Tpad;
-    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_cur[t] = chunk_base[t >> 8] + tile_loc[t] + row[t];
+    for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_cur[t] = chunk_base[t / BIN_CHUNK] + tile_loc[t] + row[t];
     __syncthreads();
     const int beg = blockIdx.x * per_group, end = min(P, beg + per_group);
     for (int i0 = beg; i0 < end; i0 += BIN_THREADS) {
@@ -276,21 +284,108 @@ __device__ __forceinline__ void write_tile(const unsigned long long* src, int n,
     if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = s_q[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(SORT_SMALL_THREADS) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
-                                                                       const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
-                                                                       int64_t capacity, const unsigned long long* __restrict__ pairs,
-                                                                       uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask, uint2* __restrict__ ranges,
-                                                                       uint32_t* __restrict__ item_est, uint32_t* __restrict__ big_list,
-                                                                       uint32_t* __restrict__ census)
+// ---- one wave sorts 64 * K keys held in registers: element p = lane * K + r.  Same network as lds_levels (ascending comparators,
+// mirrored first step per merge level); distances below K stay inside a lane, distances >= K pair lane l with lane l ^ (distance / K).
+__device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b)
 {
-    __shared__ unsigned long long s[SORT_SMALL_CAP];
+    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+template <int K>
+__device__ __forceinline__ void wave_sort(unsigned long long (&key)[K])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64 * K; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool flip = j == (k >> 1);
+            if (j < K) {
+                // both elements in this lane: flip pairs r with r ^ (k - 1) (k <= K here), a half-cleaner r with r ^ j
+#pragma unroll
+                for (int r = 0; r < K; r++) {
+                    const int q = flip ? (r ^ (k - 1)) : (r ^ j);
+                    if (q > r) cmpx(key[r], key[q]);
+                }
+            } else {
+                // partner lane: flip -> lane ^ (k / K - 1) and the registers in mirrored order; half-cleaner -> lane ^ (j / K), same register
+                const int lmask = flip ? (k / K - 1) : (j / K);
+                const bool lower = (lane & (j / K)) == 0;          // this lane holds the smaller index of each pair
+                unsigned long long other[K];
+#pragma unroll
+                for (int r = 0; r < K; r++) other[r] = __shfl_xor(key[flip ? K - 1 - r : r], lmask, 64);
+#pragma unroll
+                for (int r = 0; r < K; r++) {
+                    const unsigned long long a = key[r], o = other[r];
+                    const bool take_o = lower ? (o < a) : (o > a);
+                    key[r] = take_o ? o : a;
+                }
+            }
+        }
+    }
+}
+
+// per-quadrant survivor counts of the keys a lane holds, packed 4 x 16 bits (a tile of this kernel holds <= 4 096 keys)
+__device__ __forceinline__ unsigned long long quad_counts(uint32_t m)
+{
+    return (unsigned long long)(m & 1u) | ((unsigned long long)((m >> 1) & 1u) << 16) | ((unsigned long long)((m >> 2) & 1u) << 32) |
+           ((unsigned long long)((m >> 3) & 1u) << 48);
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// a tile of at most 64 * K keys, one wave: sort in registers, write in rank order (lane l holds ranks [l K, l K + K))
+template <int K>
+__device__ __forceinline__ void sort_tile_one_wave(const unsigned long long* __restrict__ src, int n, uint32_t beg, int tile,
+                                                   uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask, uint32_t* __restrict__ item_est)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long key[K];
+    // (which key starts where does not matter to a sort: consecutive lanes read consecutive keys)
+#pragma unroll
+    for (int r = 0; r < K; r++) { const int e = r * 64 + lane; key[r] = e < n ? src[e] : ~0ull; }
+    wave_sort<K>(key);
+    unsigned long long cnt = 0ull;
+    uint32_t* pl = plist + beg + lane * K;
+    uint8_t* qp = qmask + beg + lane * K;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const uint32_t low = (uint32_t)key[r];
+        if (lane * K + r < n) {
+            pl[r] = low >> 4;
+            qp[r] = (uint8_t)(low & 15u);
+            cnt += quad_counts(low & 15u);
+        }
+    }
+    cnt = wave_sum64(cnt);
+    if (lane < 4) item_est[tile * 4 + lane] = (uint32_t)(cnt >> (16 * lane)) & 0xFFFFu;
+}
+
+// One workgroup of eight waves per tile.  Up to 512 keys: wave 0 alone, in registers.  Up to 4 096: wave w sorts the run
+// [512 w, 512 w + 512) in its registers and publishes it in LDS; every key then finds its final position as its index in its own run
+// plus the number of smaller keys in each other run (a 10-step binary search per run; the keys are distinct: they carry the gaussian
+// index) and goes straight to that slot of the point list.  Several waves share a long list instead of one wave carrying it alone
+// (the kernel lasts as long as its most loaded SIMD).
+#define SORT_RUN 512
+__global__ void __launch_bounds__(512) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
+                                                        const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state, int64_t capacity,
+                                                        const unsigned long long* __restrict__ pairs, uint32_t* __restrict__ plist,
+                                                        uint8_t* __restrict__ qmask, uint2* __restrict__ ranges, uint32_t* __restrict__ item_est,
+                                                        uint32_t* __restrict__ big_list, uint32_t* __restrict__ census)
+{
+    __shared__ unsigned long long s_run[SORT_SMALL_CAP];
     __shared__ uint32_t s_q[4];
-    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) mrgs_census_mark(census);
     const int tile = blockIdx.x;
     // binning workspace sized from a guess that was too small: nothing was emitted; the blend kernels queued behind this one must
     // find empty lists (the host redoes the phase on an exactly sized workspace)
     const int n = (int64_t)state[0] > capacity ? 0 : (int)tile_cnt[tile];
-    const uint32_t beg = chunk_base[tile >> 8] + tile_loc[tile];
+    const uint32_t beg = chunk_base[tile / BIN_CHUNK] + tile_loc[tile];
     if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, beg + (uint32_t)n) : make_uint2(0u, 0u);   // empty tiles read (0, 0), rasterizer_impl.cu:316
     if (n == 0) {
         if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = 0u;
@@ -300,10 +395,62 @@ __global__ void __launch_bounds__(SORT_SMALL_THREADS) tile_sort_kernel(int T, co
         if (threadIdx.x == 0) big_list[atomicAdd(state + 3, 1u)] = (uint32_t)tile;
         return;
     }
-    for (int e = threadIdx.x; e < n; e += SORT_SMALL_THREADS) s[e] = pairs[beg + e];
+    const unsigned long long* src = pairs + beg;
+    if (n <= SORT_RUN) {
+        if (wave != 0) return;
+        if (n <= 128) sort_tile_one_wave<2>(src, n, beg, tile, plist, qmask, item_est);
+        else sort_tile_one_wave<8>(src, n, beg, tile, plist, qmask, item_est);
+        return;
+    }
+    const int nruns = (n + SORT_RUN - 1) / SORT_RUN;
+    const int r0 = wave * SORT_RUN, len = min(max(n - r0, 0), SORT_RUN);
+    unsigned long long key[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const int e = r * 64 + lane; key[r] = e < len ? src[r0 + e] : ~0ull; }
+    if (threadIdx.x < 4) s_q[threadIdx.x] = 0u;
+    if (len > 0) {
+        wave_sort<8>(key);
+#pragma unroll
+        for (int r = 0; r < 8; r++) s_run[r0 + lane * 8 + r] = key[r];       // (the +inf padding of a short last run is never searched)
+    }
     __syncthreads();
-    lds_levels<SORT_SMALL_THREADS>(s, n, 2, next_pow2(n));
-    write_tile<SORT_SMALL_THREADS>(s, n, beg, tile, plist, qmask, item_est, s_q);
+    unsigned long long cnt = 0ull;
+    if (len > 0) {
+        uint32_t rank[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) rank[r] = (uint32_t)(lane * 8 + r);
+        for (int q = 0; q < nruns; q++) {
+            if (q == wave) continue;
+            const unsigned long long* run = s_run + q * SORT_RUN;
+            const int qlen = min(n - q * SORT_RUN, SORT_RUN);
+            uint32_t pos[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) pos[r] = 0u;
+#pragma unroll
+            for (int step = SORT_RUN; step > 0; step >>= 1) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const uint32_t probe = pos[r] + (uint32_t)step;
+                    if (probe <= (uint32_t)qlen && run[probe - 1] < key[r]) pos[r] = probe;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) rank[r] += pos[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (lane * 8 + r < len) {
+                const uint32_t low = (uint32_t)key[r];
+                plist[beg + rank[r]] = low >> 4;
+                qmask[beg + rank[r]] = (uint8_t)(low & 15u);
+                cnt += quad_counts(low & 15u);
+            }
+        }
+        cnt = wave_sum64(cnt);
+        if (lane < 4) atomicAdd(&s_q[lane], (uint32_t)(cnt >> (16 * lane)) & 0xFFFFu);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = s_q[threadIdx.x];
 }
 
 __global__ void __launch_bounds__(SORT_BIG_THREADS) tile_sort_big_kernel(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
@@ -319,7 +466,7 @@ __global__ void __launch_bounds__(SORT_BIG_THREADS) tile_sort_big_kernel(const u
     for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
         const int tile = (int)big_list[b];
         const int n = (int)tile_cnt[tile];
-        const uint32_t beg = chunk_base[tile >> 8] + tile_loc[tile];
+        const uint32_t beg = chunk_base[tile / BIN_CHUNK] + tile_loc[tile];
         unsigned long long* g = pairs + beg;
         if (n <= SORT_BIG_CAP) {
             for (int e = threadIdx.x; e < n; e += SORT_BIG_THREADS) s_big[e] = g[e];
@@ -397,7 +544,7 @@ void mrgs_launch_tile_count_scan(const MrgsRasterConfig& cfg, const MrgsGeomWs& 
     }
     hipLaunchKernelGGL(tile_count_kernel, dim3(G), dim3(BIN_THREADS), (size_t)T * sizeof(uint32_t), stream, cfg.P, per_group(cfg.P), g.tiles_touched,
                        g.rect, tiles_x, T, Tpad, g.tile_mat);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(Tpad / 256), dim3(256), 0, stream, G, T, Tpad, g.tile_mat, g.tile_cnt, g.tile_loc, g.chunk_tot,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(Tpad / BIN_CHUNK), dim3(1024), 0, stream, G, T, Tpad, g.tile_mat, g.tile_cnt, g.tile_loc, g.chunk_tot,
                        g.chunk_base, g.counters, host_slot);
 }
 
@@ -410,8 +557,8 @@ void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g
     hipLaunchKernelGGL(tile_emit_kernel, dim3(G), dim3(BIN_THREADS), (size_t)T * sizeof(uint32_t), stream, cfg.P, per_group(cfg.P), g.tiles_touched,
                        g.rect, g.depth_key[0], g.cull, tiles_x, T, Tpad, g.tile_mat, g.tile_loc, g.chunk_base, g.counters, capacity, pairs,
                        g.counters + 16, g.counters + 3);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(SORT_SMALL_THREADS), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(512), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,
                        pairs, b.plist[0], b.qmask, img.ranges, img.item_est, g.big_list, g.counters + 16);
-    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(64), dim3(SORT_BIG_THREADS), (size_t)SORT_BIG_CAP * 8, stream, g.tile_cnt, g.tile_loc, g.chunk_base,
+    hipLaunchKernelGGL(tile_sort_big_kernel, dim3(32), dim3(SORT_BIG_THREADS), (size_t)SORT_BIG_CAP * 8, stream, g.tile_cnt, g.tile_loc, g.chunk_base,
                        g.counters, capacity, pairs, b.plist[0], b.qmask, img.item_est, g.big_list);
 }

@@ -55,9 +55,9 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
     // tile binning without a global sort (mrgs_binning.hip); null when the image has more tiles than that path serves
     uint32_t* tile_mat;     // [groups][Tpad] pairs of surfel slice g in tile t -> exclusive prefix over the slices
     uint32_t* tile_cnt;     // [Tpad] pairs per tile
-    uint32_t* tile_loc;     // [Tpad] exclusive scan of tile_cnt inside the tile's 256-tile chunk
-    uint32_t* chunk_tot;    // [Tpad / 256]
-    uint32_t* chunk_base;   // [Tpad / 256] pairs of the chunks before
+    uint32_t* tile_loc;     // [Tpad] exclusive scan of tile_cnt inside the tile's 64-tile chunk
+    uint32_t* chunk_tot;    // [Tpad / 64]
+    uint32_t* chunk_base;   // [Tpad / 64] pairs of the chunks before
     uint32_t* big_list;     // [Tpad] tiles whose segment exceeds the small sort kernel's LDS capacity (count: counters[3])
     size_t total;
 };

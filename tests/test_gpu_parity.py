@@ -357,15 +357,15 @@ def test_randomised_soak_fixed_seed(gpu_device, case):
     compare_all(scene, orbit_camera(view, H, W), gpu_device, sh_degree=deg, pixel_allowance=1)
 
 
-@pytest.mark.parametrize("P,H,W,rpx", [(5000, 64, 64, 40.0),      # every tile holds ~5 000 pairs: tile_sort_big_kernel, keys in LDS
+@pytest.mark.parametrize("P,H,W,rpx", [(6000, 64, 64, 40.0),      # every tile holds ~6 000 pairs: tile_sort_big_kernel, keys in LDS
                                        (24000, 48, 64, 60.0)])    # ~24 000 pairs per tile: beyond its LDS, outer network stages on global memory
 def test_dense_tiles_take_the_big_sort_path(gpu_device, P, H, W, rpx):
-    """Tiles whose segment exceeds the per-tile LDS sort (2 048 keys) go through the device-side list of oversized tiles
+    """Tiles whose segment exceeds the per-tile sort kernel (4 096 keys) go through the device-side list of oversized tiles
     (mrgs_binning.hip); point_list / ranges / n_contrib must stay bit-exact and the images within the usual bars."""
     scene = make_shell_scene(P, S=2, seed=77, radius_px=rpx, image_size=max(H, W))
-    hr = compare_all(scene, orbit_camera(3, H, W), gpu_device, check_grads=(P <= 5000), pixel_allowance=1)
+    hr = compare_all(scene, orbit_camera(3, H, W), gpu_device, check_grads=(P <= 6000), pixel_allowance=1)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    assert hr.num_rendered / tiles > (2048 if P <= 5000 else 16384)
+    assert hr.num_rendered / tiles > (4096 if P <= 6000 else 16384)
 
 
 def test_image_with_more_tiles_than_the_slice_histograms_hold(gpu_device):
