@@ -118,20 +118,48 @@ def image_weight(gt_image):
     return (1.0 - get_img_grad_weight(gt_image)).clamp(0, 1).detach() ** 2
 
 
+def spatial_gradient(x):
+    """kornia.filters.spatial_gradient(x, mode="sobel", order=1, normalized=True) for x [B,C,H,W] -> [B,C,2,H,W] (d/dx, d/dy): the 3x3
+    Sobel pair divided by the sum of its absolute weights (8), replicate padding.  kornia is a pip dependency of the reference
+    (utils/loss_utils.py:12) that is not installed here: restated from its documented behaviour, parity unpinned; only the absolute
+    value of the result enters the losses below, so the sign convention of the kernel does not matter."""
+    B, C, H, W = x.shape
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], dtype=x.dtype, device=x.device) / 8.0
+    k = torch.stack([kx, kx.t()])[:, None]                                     # [2,1,3,3]
+    xp = torch.nn.functional.pad(x.reshape(B * C, 1, H, W), (1, 1, 1, 1), mode="replicate")
+    return torch.nn.functional.conv2d(xp, k).reshape(B, C, 2, H, W)
+
+
+def first_order_edge_aware_loss(data, img):
+    """utils/loss_utils.py:121-122: |grad data| damped by exp(-|grad img|), summed over the two directions, mean."""
+    return (spatial_gradient(data[None])[0].abs() * torch.exp(-spatial_gradient(img[None])[0].abs())).sum(1).mean()
+
+
+def smooth_loss(data):
+    """utils/loss_utils.py:124-125."""
+    return spatial_gradient(data[None])[0].abs().sum(1).mean()
+
+
+def check_loss_config(opt):
+    """Call once at set-up: the reference enables the LPIPS term by default (arguments/__init__.py: use_perceptual_loss = True from
+    iteration 18 000); it needs the `lpips` package and its VGG weights, which this build does not ship, and failing 18 000
+    iterations into a run is the wrong moment to find out."""
+    if getattr(opt, "use_perceptual_loss", False):
+        raise NotImplementedError("lpips_loss (utils/loss_utils.py:35-43) needs the LPIPS network weights, which are not part of this build: "
+                                  "run with --no-use_perceptual_loss (INTEGRATION.md)")
+
+
 def calculate_loss(viewpoint_camera, pc, render_pkg, opt, iteration, image_weight=None, bg_mask=None):
     """utils/loss_utils.py:142-228: same arguments, same keys in tb_dict (values are 0-d tensors, see module docstring)."""
+    check_loss_config(opt)      # at the FIRST call, whatever the iteration
     image = render_pkg["render"]
     gt_image = viewpoint_camera.original_image
     if not gt_image.is_cuda:
         gt_image = gt_image.to(image.device)
     use_normal = opt.lambda_normal_render_depth > 0 and iteration > opt.normal_loss_start
     use_dist = opt.lambda_dist > 0 and iteration > opt.dist_loss_start
-    if getattr(opt, "lambda_normal_smooth", 0) > 0 and opt.normal_smooth_from_iter < iteration < opt.normal_smooth_until_iter:
-        raise NotImplementedError("first_order_edge_aware_loss (kornia spatial_gradient) is not part of this build")
-    if getattr(opt, "lambda_depth_smooth", 0) > 0 and iteration > 3000:
-        raise NotImplementedError("first_order_edge_aware_loss (kornia spatial_gradient) is not part of this build")
-    if getattr(opt, "use_perceptual_loss", False) and iteration > opt.perceptual_loss_start_iter:
-        raise NotImplementedError("lpips_loss needs the LPIPS network weights; not part of this build")
+    use_nsmooth = getattr(opt, "lambda_normal_smooth", 0) > 0 and opt.normal_smooth_from_iter < iteration < opt.normal_smooth_until_iter
+    use_dsmooth = getattr(opt, "lambda_depth_smooth", 0) > 0 and iteration > 3000
     loss, terms = fused_loss(image, gt_image,
                              render_pkg["rend_normal"] if use_normal else None, render_pkg["surf_normal"] if use_normal else None,
                              render_pkg["rend_dist"] if use_dist else None, image_weight if use_normal else None,
@@ -146,4 +174,13 @@ def calculate_loss(viewpoint_camera, pc, render_pkg, opt, iteration, image_weigh
         "loss_normal_smooth": zero, "loss_depth_smooth": zero,
         "loss": terms[0],
     }
+    # the two edge-aware smoothness terms (:185-197; lambda = 0 in the reference's defaults): torch ops on top of the fused loss
+    if use_nsmooth:
+        tb_dict["loss_normal_smooth"] = first_order_edge_aware_loss(render_pkg["rend_normal"], gt_image)
+        loss = loss + opt.lambda_normal_smooth * tb_dict["loss_normal_smooth"]
+    if use_dsmooth:
+        tb_dict["loss_depth_smooth"] = first_order_edge_aware_loss(render_pkg["surf_depth"], gt_image)
+        loss = loss + opt.lambda_depth_smooth * tb_dict["loss_depth_smooth"]
+    if use_nsmooth or use_dsmooth:
+        tb_dict["loss"] = loss.detach()
     return loss, tb_dict

@@ -63,3 +63,32 @@ def test_env_map_files_round_trip(tmp_path):
     mio.load_env_maps(path, f1, f2)
     torch.testing.assert_close(f1.base, e1.base, rtol=0, atol=0)
     torch.testing.assert_close(f2.base, e2.base, rtol=0, atol=0)
+
+
+def test_envlight_signature_and_hdr_loading(tmp_path):
+    """EnvLight takes the reference's constructor arguments in the reference's order (scene/light.py:22: path first, then device,
+    scale); the Radiance .hdr reader and latlong_to_cubemap (scene/light_utils.py:34-48) round-trip a known image."""
+    import inspect
+    import numpy as np
+    import torch
+    from materialrefgs_amd import shading as sh
+    params = list(inspect.signature(sh.EnvLight.__init__).parameters)
+    assert params[:9] == ["self", "path", "device", "scale", "min_res", "max_res", "min_roughness", "max_roughness", "trainable"]
+    rng = np.random.default_rng(0)
+    H, W = 16, 32
+    img = (rng.random((H, W, 3)) * 3).astype(np.float32)
+    e = np.ceil(np.log2(img.max(-1))).astype(int)
+    mant = np.clip(np.floor(img / np.ldexp(1.0, e)[..., None] * 256), 0, 255).astype(np.uint8)
+    rgbe = np.concatenate([mant, (e + 128).astype(np.uint8)[..., None]], -1)
+    p = tmp_path / "env.hdr"
+    with open(p, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (H, W))
+        f.write(rgbe.tobytes())
+    back = sh.read_radiance_hdr(str(p))
+    assert back.dtype == np.float32 and float(np.abs(back - img).max()) <= img.max() / 128          # 8-bit mantissas
+    # a constant lat-long image maps to a constant cube; the +y face looks at the top rows of the image (v = acos(y) / pi -> 0)
+    const = torch.full((H, W, 3), 0.25)
+    assert torch.allclose(sh.latlong_to_cubemap(const, [8, 8], "cpu"), torch.full((6, 8, 8, 3), 0.25))
+    grad = torch.linspace(0, 1, H)[:, None, None].expand(H, W, 3).contiguous()      # brightness grows towards the bottom (-y)
+    cm = sh.latlong_to_cubemap(grad, [8, 8], "cpu")
+    assert float(cm[2].mean()) < float(cm[0].mean()) < float(cm[3].mean())

@@ -171,3 +171,22 @@ def test_image_weight_matches_reference_get_img_grad_weight(tag):
     from materialrefgs_amd import losses
     w = losses.image_weight(torch.from_numpy(GOLD[f"{tag}_gt"]))
     np.testing.assert_allclose(w.numpy(), GOLD[f"{tag}_weight"], rtol=0, atol=1e-6)
+
+
+def test_edge_aware_terms_and_early_failure_of_the_perceptual_loss():
+    """first_order_edge_aware_loss / smooth_loss (utils/loss_utils.py:121-125) on kornia's documented Sobel: zero for constants, the
+    known value of a ramp, damped by image edges; use_perceptual_loss fails at the first call, not at iteration 18 001."""
+    from types import SimpleNamespace
+    from materialrefgs_amd import losses
+    H, W = 12, 16
+    ramp = torch.arange(W, dtype=torch.float64).repeat(H, 1)[None]             # d/dx = 1 everywhere inside (Sobel / 8 normalised), 0 in y
+    g = losses.spatial_gradient(ramp[None])[0, 0]
+    assert torch.allclose(g[0][:, 1:-1], torch.ones(H, W - 2, dtype=torch.float64)) and torch.allclose(g[1], torch.zeros(H, W, dtype=torch.float64))
+    assert torch.allclose(g[0][:, 0], torch.full((H,), 0.5, dtype=torch.float64))   # replicate padding halves the border difference
+    const_img = torch.zeros(3, H, W, dtype=torch.float64)
+    assert abs(float(losses.smooth_loss(ramp)) - float(g[0].mean())) < 1e-12
+    assert abs(float(losses.first_order_edge_aware_loss(ramp, const_img)) - float(g[0].mean())) < 1e-12
+    edgy = torch.zeros(3, H, W, dtype=torch.float64); edgy[:, :, W // 2:] = 8.0
+    assert float(losses.first_order_edge_aware_loss(ramp, edgy)) < float(losses.first_order_edge_aware_loss(ramp, const_img))
+    with pytest.raises(NotImplementedError, match="no-use_perceptual_loss"):
+        losses.calculate_loss(None, None, {}, SimpleNamespace(use_perceptual_loss=True, perceptual_loss_start_iter=18000), 1)
