@@ -2,6 +2,7 @@
 // interfaces each entry replaces).
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "mrgs_internal.h"
 
@@ -32,6 +33,7 @@ enum { ST_PRE = 0, ST_SORT, ST_DUP, ST_FWD, ST_BWD, ST_PREB, ST_COUNT };
 struct EvPair { hipEvent_t a, b; int stage; };
 static std::vector<EvPair> g_pairs;
 static std::vector<EvPair> g_free;
+static std::mutex g_prof_mutex;   // autograd runs the backward (and its StageTimer) on a worker thread
 
 struct StageTimer {
     EvPair p;
@@ -48,8 +50,12 @@ struct StageTimer {
         : s(stream), on(g_profiling == 1 || (g_profiling == 2 && (stage == ST_FWD || stage == ST_BWD)) || (g_profiling == 3 && sampled(stage)))
     {
         if (on) {
-            if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
-            else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+            bool reuse = false;
+            {
+                std::lock_guard<std::mutex> lk(g_prof_mutex);
+                if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); reuse = true; }
+            }
+            if (!reuse) { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
             p.stage = stage;
             (void)hipEventRecord(p.a, s);
         }
@@ -58,6 +64,7 @@ struct StageTimer {
     {
         if (on) {
             (void)hipEventRecord(p.b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mutex);
             g_pairs.push_back(p);
             on = false;
         }
@@ -332,7 +339,9 @@ struct ReadbackSlot {
     uint32_t* dev = nullptr;    // device address of the same pinned words
     hipEvent_t ev = nullptr;
 };
-static thread_local ReadbackSlot g_slot;
+// one slot per (host thread, device): the pinned words are mapped into the device that allocated them and the event belongs to it
+#define MRGS_MAX_DEVICES 64
+static thread_local ReadbackSlot g_slots[MRGS_MAX_DEVICES];
 }   // namespace
 
 int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
@@ -351,8 +360,12 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
     MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(binning_ws, capacity_pairs);
     if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= MRGS_MAX_DEVICES) return MRGS_E_UNSUPPORTED;
+    ReadbackSlot& g_slot = g_slots[device];
     if (!g_slot.host) {
-        HIP_TRY(hipHostMalloc((void**)&g_slot.host, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void**)&g_slot.host, 64, hipHostMallocMapped | hipHostMallocPortable));
         HIP_TRY(hipHostGetDevicePointer((void**)&g_slot.dev, g_slot.host, 0));
         HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming));
     }
@@ -480,6 +493,7 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
 
 int mrgs_set_profiling(int32_t enabled)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
     g_profiling = enabled;
     for (auto& p : g_pairs) g_free.push_back(p);   // reset the statistics
     g_pairs.clear();
@@ -490,6 +504,7 @@ int mrgs_get_kernel_times(MrgsKernelTimes* out)
     if (!out) return MRGS_E_BAD_ARG;
     double sum[ST_COUNT] = {0};
     int cnt[ST_COUNT] = {0};
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
     for (auto& p : g_pairs) {
         float ms = 0;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { sum[p.stage] += ms; cnt[p.stage]++; }
