@@ -15,20 +15,19 @@
 //                       stored as a 64-bit key  depth bits << 32 | gaussian index << 4 | quadrant cull bits  -- no global atomic, no
 //                       look-back, no dependence between workgroups.  The cull of the surfel against the four 8x8 quadrants of the
 //                       tile is evaluated here, where the surfel's conic is in registers (round 1 gathered it per list entry)
-//   tile_sort_kernel    one workgroup of eight waves per tile: a wave sorts up to 512 keys in its REGISTERS (8 per lane; a bitonic network
-//                       whose short-distance steps are compare-exchanges inside a lane and whose long-distance steps are lane-XOR
-//                       shuffles -- no LDS, no barrier); longer segments (up to 4 096 keys) are up to eight such runs merged by rank: every key
-//                       binary-searches the other runs in LDS and is stored at its final position.  Writes point_list, the cull bits,
-//                       ranges[tile] and the per-quadrant survivor counts (the forward's work estimate)
+//   tile_sort_kernel    one workgroup per tile (up to 4 096 keys): bucket sort in LDS with an order-preserving linear hash of the depth
+//                       (count, scan, drop into the bucket's range) and an exact ordering of the handful of keys inside each
+//                       bucket; writes point_list, the cull bits, ranges[tile] and the per-quadrant survivor counts (the forward's
+//                       work estimate)
 //   tile_sort_big_kernel  the rare tiles beyond 4 096 keys (a device-side list): up to 16 384 keys in LDS, beyond that the outer
 //                       network stages run on global memory
 //
-// Four dependent launches and ~45 MB of traffic at C2 (P = 300k, R = 1.15 M) where the radix pipeline had eleven launches and
+// Five short launches and ~45 MB of traffic at C2 (P = 300k, R = 1.15 M) where the radix pipeline had eleven launches and
 // 116 MB; point_list, ranges and n_contrib stay bit-identical to the reference's 64-bit-key sort (tests/test_gpu_parity.py).
 #include "mrgs_blend_math.h"
 
 #define BIN_THREADS 1024
-#define SORT_SMALL_CAP 4096       // eight runs of 512 keys, one per wave of tile_sort_kernel
+#define SORT_SMALL_CAP 4096       // keys per tile the bucket sort of tile_sort_kernel holds in LDS
 #define BIN_CHUNK 64              // tiles per workgroup of tile_scan_kernel = granularity of tile_loc / chunk_base
 #define SORT_BIG_THREADS 1024
 #define SORT_BIG_CAP 16384
@@ -284,45 +283,11 @@ __device__ __forceinline__ void write_tile(const unsigned long long* src, int n,
     if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = s_q[threadIdx.x];
 }
 
-// ---- one wave sorts 64 * K keys held in registers: element p = lane * K + r.  Same network as lds_levels (ascending comparators,
-// mirrored first step per merge level); distances below K stay inside a lane, distances >= K pair lane l with lane l ^ (distance / K).
-__device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b)
+// a < b on 64-bit keys through 32-bit compares
+__device__ __forceinline__ bool lt64(unsigned long long a, unsigned long long b)
 {
-    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
-    a = lo; b = hi;
-}
-template <int K>
-__device__ __forceinline__ void wave_sort(unsigned long long (&key)[K])
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 2; k <= 64 * K; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool flip = j == (k >> 1);
-            if (j < K) {
-                // both elements in this lane: flip pairs r with r ^ (k - 1) (k <= K here), a half-cleaner r with r ^ j
-#pragma unroll
-                for (int r = 0; r < K; r++) {
-                    const int q = flip ? (r ^ (k - 1)) : (r ^ j);
-                    if (q > r) cmpx(key[r], key[q]);
-                }
-            } else {
-                // partner lane: flip -> lane ^ (k / K - 1) and the registers in mirrored order; half-cleaner -> lane ^ (j / K), same register
-                const int lmask = flip ? (k / K - 1) : (j / K);
-                const bool lower = (lane & (j / K)) == 0;          // this lane holds the smaller index of each pair
-                unsigned long long other[K];
-#pragma unroll
-                for (int r = 0; r < K; r++) other[r] = __shfl_xor(key[flip ? K - 1 - r : r], lmask, 64);
-#pragma unroll
-                for (int r = 0; r < K; r++) {
-                    const unsigned long long a = key[r], o = other[r];
-                    const bool take_o = lower ? (o < a) : (o > a);
-                    key[r] = take_o ? o : a;
-                }
-            }
-        }
-    }
+    const uint32_t ah = (uint32_t)(a >> 32), bh = (uint32_t)(b >> 32), al = (uint32_t)a, bl = (uint32_t)b;
+    return (ah < bh) | ((ah == bh) & (al < bl));
 }
 
 // per-quadrant survivor counts of the keys a lane holds, packed 4 x 16 bits (a tile of this kernel holds <= 4 096 keys)
@@ -338,119 +303,135 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
     return v;
 }
 
-// a tile of at most 64 * K keys, one wave: sort in registers, write in rank order (lane l holds ranks [l K, l K + K))
-template <int K>
-__device__ __forceinline__ void sort_tile_one_wave(const unsigned long long* __restrict__ src, int n, uint32_t beg, int tile,
-                                                   uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask, uint32_t* __restrict__ item_est)
+// One workgroup per tile: bucket sort with an order-preserving linear hash.  The keys of a tile are (depth bits, gaussian index,
+// cull bits); its depths fill some interval [dmin, dmax].  bucket(key) = floor((depth - dmin) * NB / (dmax - dmin + 1)) is monotone
+// in the depth, so sorting = counting the keys of every bucket (LDS atomics), an exclusive scan over the NB counters, dropping every
+// key into its bucket's range, and ordering the few keys INSIDE a bucket exactly: a key's final position is its bucket's start plus
+// the number of smaller keys in the bucket (they are distinct: they carry the gaussian index), found by walking the bucket.  With
+// NB = 4 096 buckets for at most 4 096 keys a bucket holds a handful of keys, and the whole sort is ~100 lane instructions per key --
+// a comparator network on 64-bit keys (a bitonic sort in registers with lane-XOR exchanges, or in LDS) measured 52 - 92 us at C2 for
+// the same job, of which every variant was instruction issue.  Equal depths share a bucket whatever NB is; the walk makes that exact,
+// at quadratic cost in the number of EQUAL depths of one tile.
+#define BS_THREADS 512
+#define BS_NB 4096
+#define BS_PER_THREAD (SORT_SMALL_CAP / BS_THREADS)
+#define BS_OWN (BS_NB / BS_THREADS)                                       // consecutive counters a thread owns in the scan
+__device__ __forceinline__ int bs_pad(int b) { return b + b / BS_OWN; }    // ... read without bank conflicts (lane stride BS_OWN + 1 words)
+// (amdgpu_waves_per_eu: without the cap the compiler has been seen to spend 237 VGPRs on this kernel -- one workgroup per CU -- and the
+// sort took three times as long)
+__global__ void __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
+                                                               const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
+                                                               int64_t capacity, const unsigned long long* __restrict__ pairs,
+                                                               uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask,
+                                                               uint2* __restrict__ ranges, uint32_t* __restrict__ item_est,
+                                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ census)
 {
-    const int lane = threadIdx.x & 63;
-    unsigned long long key[K];
-    // (which key starts where does not matter to a sort: consecutive lanes read consecutive keys)
-#pragma unroll
-    for (int r = 0; r < K; r++) { const int e = r * 64 + lane; key[r] = e < n ? src[e] : ~0ull; }
-    wave_sort<K>(key);
-    unsigned long long cnt = 0ull;
-    uint32_t* pl = plist + beg + lane * K;
-    uint8_t* qp = qmask + beg + lane * K;
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        const uint32_t low = (uint32_t)key[r];
-        if (lane * K + r < n) {
-            pl[r] = low >> 4;
-            qp[r] = (uint8_t)(low & 15u);
-            cnt += quad_counts(low & 15u);
-        }
-    }
-    cnt = wave_sum64(cnt);
-    if (lane < 4) item_est[tile * 4 + lane] = (uint32_t)(cnt >> (16 * lane)) & 0xFFFFu;
-}
-
-// One workgroup of eight waves per tile.  Up to 512 keys: wave 0 alone, in registers.  Up to 4 096: wave w sorts the run
-// [512 w, 512 w + 512) in its registers and publishes it in LDS; every key then finds its final position as its index in its own run
-// plus the number of smaller keys in each other run (a 10-step binary search per run; the keys are distinct: they carry the gaussian
-// index) and goes straight to that slot of the point list.  Several waves share a long list instead of one wave carrying it alone
-// (the kernel lasts as long as its most loaded SIMD).
-#define SORT_RUN 512
-__global__ void __launch_bounds__(512) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
-                                                        const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state, int64_t capacity,
-                                                        const unsigned long long* __restrict__ pairs, uint32_t* __restrict__ plist,
-                                                        uint8_t* __restrict__ qmask, uint2* __restrict__ ranges, uint32_t* __restrict__ item_est,
-                                                        uint32_t* __restrict__ big_list, uint32_t* __restrict__ census)
-{
-    __shared__ unsigned long long s_run[SORT_SMALL_CAP];
-    __shared__ uint32_t s_q[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned long long s_tmp[SORT_SMALL_CAP];          // the keys in bucket order
+    __shared__ uint32_t s_cnt[BS_NB + BS_NB / BS_OWN];             // counts -> bucket starts -> bucket ends (padded index: bs_pad)
+    __shared__ uint32_t s_lo[BS_THREADS / 64], s_hi[BS_THREADS / 64], s_wsum[BS_THREADS / 64], s_q[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (lane == 0) mrgs_census_mark(census);
     const int tile = blockIdx.x;
     // binning workspace sized from a guess that was too small: nothing was emitted; the blend kernels queued behind this one must
     // find empty lists (the host redoes the phase on an exactly sized workspace)
     const int n = (int64_t)state[0] > capacity ? 0 : (int)tile_cnt[tile];
     const uint32_t beg = chunk_base[tile / BIN_CHUNK] + tile_loc[tile];
-    if (threadIdx.x == 0) ranges[tile] = n ? make_uint2(beg, beg + (uint32_t)n) : make_uint2(0u, 0u);   // empty tiles read (0, 0), rasterizer_impl.cu:316
-    if (n == 0) {
-        if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = 0u;
-        return;
+    if (tid == 0) {
+        ranges[tile] = n ? make_uint2(beg, beg + (uint32_t)n) : make_uint2(0u, 0u);   // empty tiles read (0, 0), rasterizer_impl.cu:316
+        if (n > SORT_SMALL_CAP) big_list[atomicAdd(state + 6, 1u)] = (uint32_t)tile;   // rare: handed to tile_sort_big_kernel
     }
-    if (n > SORT_SMALL_CAP) {                            // rare: handed to tile_sort_big_kernel
-        if (threadIdx.x == 0) big_list[atomicAdd(state + 3, 1u)] = (uint32_t)tile;
-        return;
-    }
+    if (n == 0 && tid < 4) item_est[tile * 4 + tid] = 0u;
+    if (n == 0 || n > SORT_SMALL_CAP) return;
     const unsigned long long* src = pairs + beg;
-    if (n <= SORT_RUN) {
-        if (wave != 0) return;
-        if (n <= 128) sort_tile_one_wave<2>(src, n, beg, tile, plist, qmask, item_est);
-        else sort_tile_one_wave<8>(src, n, beg, tile, plist, qmask, item_est);
-        return;
+    // 1. keys into registers (consecutive threads read consecutive keys), depth range of the tile
+    unsigned long long key[BS_PER_THREAD];
+    uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+#pragma unroll
+    for (int i = 0; i < BS_PER_THREAD; i++) {
+        const int e = i * BS_THREADS + tid;
+        key[i] = 0ull;
+        if (i * BS_THREADS < n && e < n) {
+            key[i] = src[e];
+            const uint32_t d = (uint32_t)(key[i] >> 32);
+            dmin = min(dmin, d); dmax = max(dmax, d);
+        }
     }
-    const int nruns = (n + SORT_RUN - 1) / SORT_RUN;
-    const int r0 = wave * SORT_RUN, len = min(max(n - r0, 0), SORT_RUN);
-    unsigned long long key[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { const int e = r * 64 + lane; key[r] = e < len ? src[r0 + e] : ~0ull; }
-    if (threadIdx.x < 4) s_q[threadIdx.x] = 0u;
-    if (len > 0) {
-        wave_sort<8>(key);
+    for (int d = 32; d >= 1; d >>= 1) { dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64)); dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64)); }
+    if (lane == 0) { s_lo[wave] = dmin; s_hi[wave] = dmax; }
 #pragma unroll
-        for (int r = 0; r < 8; r++) s_run[r0 + lane * 8 + r] = key[r];       // (the +inf padding of a short last run is never searched)
+    for (int i = 0; i < (BS_NB + BS_NB / BS_OWN + BS_THREADS - 1) / BS_THREADS; i++) {
+        const int k = i * BS_THREADS + tid;
+        if (k < BS_NB + BS_NB / BS_OWN) s_cnt[k] = 0u;
+    }
+    if (tid < 4) s_q[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BS_THREADS / 64; w++) { dmin = min(dmin, s_lo[w]); dmax = max(dmax, s_hi[w]); }
+    const float scale = (float)BS_NB / ((float)(dmax - dmin) + 1.0f);
+    // 2. count the keys of every bucket
+    int bucket[BS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < BS_PER_THREAD; i++) {
+        bucket[i] = 0;
+        if (i * BS_THREADS < n && i * BS_THREADS + tid < n) {
+            // monotone in the depth: u32 -> float conversion, the product with a positive constant and the truncation are all monotone
+            bucket[i] = min((int)((float)((uint32_t)(key[i] >> 32) - dmin) * scale), BS_NB - 1);
+            atomicAdd(&s_cnt[bs_pad(bucket[i])], 1u);
+        }
     }
     __syncthreads();
+    // 3. exclusive scan over the buckets: thread t owns the BS_OWN consecutive buckets [BS_OWN t, BS_OWN t + BS_OWN)
+    {
+        uint32_t c[BS_OWN], sum = 0;
+#pragma unroll
+        for (int k = 0; k < BS_OWN; k++) { c[k] = s_cnt[bs_pad(BS_OWN * tid + k)]; sum += c[k]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += u;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (int w = 0; w < BS_THREADS / 64; w++) if (w < wave) run += s_wsum[w];
+#pragma unroll
+        for (int k = 0; k < BS_OWN; k++) { s_cnt[bs_pad(BS_OWN * tid + k)] = run; run += c[k]; }
+    }
+    __syncthreads();
+    // 4. every key into its bucket's range (any order inside the bucket); the counter of a bucket ends up at the bucket's END
+#pragma unroll
+    for (int i = 0; i < BS_PER_THREAD; i++) {
+        if (i * BS_THREADS < n && i * BS_THREADS + tid < n) {
+            const uint32_t pos = atomicAdd(&s_cnt[bs_pad(bucket[i])], 1u);
+            s_tmp[pos] = key[i];
+        }
+    }
+    __syncthreads();
+    // 5. exact position = bucket start + number of smaller keys in the bucket; straight to the point list
     unsigned long long cnt = 0ull;
-    if (len > 0) {
-        uint32_t rank[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) rank[r] = (uint32_t)(lane * 8 + r);
-        for (int q = 0; q < nruns; q++) {
-            if (q == wave) continue;
-            const unsigned long long* run = s_run + q * SORT_RUN;
-            const int qlen = min(n - q * SORT_RUN, SORT_RUN);
-            uint32_t pos[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) pos[r] = 0u;
-#pragma unroll
-            for (int step = SORT_RUN; step > 0; step >>= 1) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const uint32_t probe = pos[r] + (uint32_t)step;
-                    if (probe <= (uint32_t)qlen && run[probe - 1] < key[r]) pos[r] = probe;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) rank[r] += pos[r];
+    for (int i = 0; i < BS_PER_THREAD; i++) {
+        if (i * BS_THREADS < n && i * BS_THREADS + tid < n) {
+            const int b = bucket[i];
+            const uint32_t lo = b ? s_cnt[bs_pad(b - 1)] : 0u, hi = s_cnt[bs_pad(b)];
+            uint32_t rank = lo;
+            for (uint32_t m = lo; m < hi; m++) rank += lt64(s_tmp[m], key[i]) ? 1u : 0u;
+            const uint32_t low = (uint32_t)key[i];
+            plist[beg + rank] = low >> 4;
+            qmask[beg + rank] = (uint8_t)(low & 15u);
+            cnt += quad_counts(low & 15u);
         }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (lane * 8 + r < len) {
-                const uint32_t low = (uint32_t)key[r];
-                plist[beg + rank[r]] = low >> 4;
-                qmask[beg + rank[r]] = (uint8_t)(low & 15u);
-                cnt += quad_counts(low & 15u);
-            }
-        }
-        cnt = wave_sum64(cnt);
-        if (lane < 4) atomicAdd(&s_q[lane], (uint32_t)(cnt >> (16 * lane)) & 0xFFFFu);
+    }
+    cnt = wave_sum64(cnt);
+    if (lane < 4) {
+        const uint32_t c = (uint32_t)(cnt >> (16 * lane)) & 0xFFFFu;
+        if (c) atomicAdd(&s_q[lane], c);
     }
     __syncthreads();
-    if (threadIdx.x < 4) item_est[tile * 4 + threadIdx.x] = s_q[threadIdx.x];
+    if (tid < 4) item_est[tile * 4 + tid] = s_q[tid];
 }
 
 __global__ void __launch_bounds__(SORT_BIG_THREADS) tile_sort_big_kernel(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
@@ -462,7 +443,7 @@ __global__ void __launch_bounds__(SORT_BIG_THREADS) tile_sort_big_kernel(const u
     extern __shared__ unsigned long long s_big[];        // SORT_BIG_CAP keys
     __shared__ uint32_t s_q[4];
     if ((int64_t)state[0] > capacity) return;
-    const int n_big = (int)state[3];
+    const int n_big = (int)state[6];
     for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
         const int tile = (int)big_list[b];
         const int n = (int)tile_cnt[tile];
@@ -556,8 +537,8 @@ void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g
     unsigned long long* pairs = (unsigned long long*)b.tile_key[0];
     hipLaunchKernelGGL(tile_emit_kernel, dim3(G), dim3(BIN_THREADS), (size_t)T * sizeof(uint32_t), stream, cfg.P, per_group(cfg.P), g.tiles_touched,
                        g.rect, g.depth_key[0], g.cull, tiles_x, T, Tpad, g.tile_mat, g.tile_loc, g.chunk_base, g.counters, capacity, pairs,
-                       g.counters + 16, g.counters + 3);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(512), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,
+                       g.counters + 16, g.counters + 6);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(BS_THREADS), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,
                        pairs, b.plist[0], b.qmask, img.ranges, img.item_est, g.big_list, g.counters + 16);
     hipLaunchKernelGGL(tile_sort_big_kernel, dim3(32), dim3(SORT_BIG_THREADS), (size_t)SORT_BIG_CAP * 8, stream, g.tile_cnt, g.tile_loc, g.chunk_base,
                        g.counters, capacity, pairs, b.plist[0], b.qmask, img.item_est, g.big_list);

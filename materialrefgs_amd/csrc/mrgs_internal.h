@@ -61,7 +61,7 @@ struct MrgsGeomWs {   // carved from geom_ws (all offsets 256-B aligned)
     uint32_t* big_list;     // [Tpad] tiles whose segment exceeds the small sort kernel's LDS capacity (count: counters[3])
     size_t total;
 };
-// counters[]: 0 num_rendered, 1 error flag of the look-back kernels, 2 ticket of tile_scan_kernel, 3 length of big_list
+// counters[]: 0 num_rendered, 1 error flag of the look-back kernels, 2 ticket of tile_scan_kernel, 6 length of big_list
 
 struct MrgsImgWs {
     uint2* ranges;       // [tiles]

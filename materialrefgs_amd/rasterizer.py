@@ -39,6 +39,21 @@ def _work_hint(raster_settings, device):
         h = torch.zeros(max(int(n), 1), dtype=torch.int32, device=device)
         _WORK_HINTS[key] = h
     return h
+_ZERO_CONTRIB = {}
+
+
+def _zero_contrib(dev, H, W):
+    """`out_contrib` of the reference is allocated zero-filled and never written by any kernel (rasterize_points.cu:89); one read-only
+    zero tensor per (device, size) stands in for it instead of a 4 H W byte fill per render."""
+    key = (dev.index, H, W)
+    t = _ZERO_CONTRIB.get(key)
+    if t is None:
+        if len(_ZERO_CONTRIB) > 16:
+            _ZERO_CONTRIB.clear()
+        t = _ZERO_CONTRIB[key] = torch.zeros((1, H, W), dtype=torch.int32, device=dev)
+    return t
+
+
 LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (bench.py reads it for the roofline figure)
 
 
@@ -93,7 +108,7 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
     P, S = cfg.P, cfg.S
     with torch.cuda.device(dev):
         st = _stream(dev)
-        contrib = torch.zeros((1, H, W), dtype=torch.int32, device=dev)   # allocated, never written
+        contrib = _zero_contrib(dev, H, W)   # allocated, never written
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         feature = torch.empty((S, H, W), dtype=torch.float32, device=dev)
         others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
@@ -167,6 +182,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings, sh_rest=None):
+        ctx.set_materialize_grads(False)   # output gradients nobody supplied arrive as None (handled in backward), not as zero-filled maps
         # sh_rest: split SH layout (extension over the reference's signature): sh = _features_dc [P,1,3], sh_rest = _features_rest
         # [P,M-1,3] -- the model's own tensors, no torch.cat per render and no slicing of the gradient in its backward
         means3D, sh, colors_precomp, features = _f32c(means3D), _f32c(sh), _f32c(colors_precomp), _f32c(features)

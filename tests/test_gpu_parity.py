@@ -46,7 +46,7 @@ def _map_ok(a, b, tol, absolute=False):
 def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, check_grads=True, pixel_allowance=0):
     """`pixel_allowance`: number of pixels that may sit outside the map tolerances (the randomised soak allows ONE: a surfel whose
     alpha lands on the 1/255 threshold at that pixel is blended on one side and skipped on the other -- one ulp of v_rcp_f32 /
-    v_exp_f32); such a pixel must still be within 2e-3 of the map's maximum."""
+    v_exp_f32); such a pixel must still be within 5e-3 of the map's maximum (the pair's weight is <= 1/255)."""
     from oracle import raster_oracle as ro
     H, W = cam.image_height, cam.image_width
     S = scene.features.shape[1]
@@ -79,7 +79,7 @@ def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp
     for name, a, b, tol, absolute in checks:
         ok, worst = _map_ok(a, b, tol, absolute)
         good &= ok
-        assert worst <= (tol if pixel_allowance == 0 else 2e-3), (name, worst)
+        assert worst <= (tol if pixel_allowance == 0 else 5e-3), (name, worst)   # one pair at the alpha = 1/255 threshold: <= 3.9e-3 of a map's range
     assert int((~good).sum()) <= pixel_allowance, int((~good).sum())
     assert int(hr.contrib.abs().sum()) == 0   # out_contrib is allocated and returned but never written
     # ---- gradients
