@@ -167,6 +167,14 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int G, int T, int Tpad,
     }
 }
 
+// Per wave of tile_emit_kernel: the 64 surfels of a step publish their record in LDS, and the (surfel, tile) pairs of the surfels
+// with fewer than BIN_COOP_MIN tiles are numbered consecutively (wave prefix sum); lane l then takes pair 64 j + l -- every lane has
+// work in every iteration but the last.  (One lane walking the tiles of its own surfel ran the wave for as many iterations as its
+// largest surfel has tiles, with a quarter of the lanes busy on average: 190 instructions per iteration, 10.6 M VALU instructions per
+// launch at C2.)
+#define EMIT_REC_WORDS 12                       // conic 8 | depth bits | rect.x | rect.y | first pair number
+#define EMIT_PAIRS_MAX (64 * (BIN_COOP_MIN - 1))
+#define EMIT_WAVE_BYTES (64 * EMIT_REC_WORDS * 4 + ((EMIT_PAIRS_MAX + 15) & ~15))
 __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_group, const uint32_t* __restrict__ tiles_touched,
                                                                 const uint2* __restrict__ rect, const uint32_t* __restrict__ depth_key,
                                                                 const float4* __restrict__ cull, int tiles_x, int T, int Tpad,
@@ -175,13 +183,27 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
                                                                 int64_t capacity, unsigned long long* __restrict__ pairs, uint32_t* __restrict__ census,
                                                                 uint32_t* __restrict__ big_count)
 {
-    extern __shared__ uint32_t s_cur[];
-    if ((threadIdx.x & 63) == 0) mrgs_census_mark(census);
+    extern __shared__ uint32_t s_cur[];                 // [T] cursors, then per wave: records [64][12] and owner lane of each pair
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) mrgs_census_mark(census);
     if (blockIdx.x == 0 && threadIdx.x == 0) big_count[0] = 0u;   // list of oversized tiles of tile_sort_kernel: empty
     if ((int64_t)state[0] > capacity) return;          // binning workspace sized from a guess that was too small: the host redoes this phase
     const uint32_t* row = mat + (size_t)blockIdx.x * Tpad;
     for (int t = threadIdx.x; t < T; t += BIN_THREADS) s_cur[t] = chunk_base[t / BIN_CHUNK] + tile_loc[t] + row[t];
     __syncthreads();
+    char* wbase = (char*)(s_cur + ((T + 3) & ~3)) + (size_t)wave * EMIT_WAVE_BYTES;
+    uint32_t* wrec = (uint32_t*)wbase;
+    uint8_t* wown = (uint8_t*)(wbase + 64 * EMIT_REC_WORDS * 4);
+    auto emit = [&](const CullConic& cc, uint32_t d, uint32_t id, int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const float x0 = (float)(tx * MRGS_BLOCK_X), y0 = (float)(ty * MRGS_BLOCK_Y);
+        uint32_t m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            m |= mrgs_block_may_touch(cc, x0 + (float)(8 * (q & 1)), y0 + (float)(8 * (q >> 1)), 7.0f, 7.0f) ? (1u << q) : 0u;
+        const uint32_t pos = atomicAdd(&s_cur[tile], 1u);
+        pairs[pos] = ((unsigned long long)d << 32) | (unsigned long long)((id << 4) | m);
+    };
     const int beg = blockIdx.x * per_group, end = min(P, beg + per_group);
     for (int i0 = beg; i0 < end; i0 += BIN_THREADS) {
         const int i = i0 + threadIdx.x;
@@ -190,27 +212,60 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
         CullConic c = mrgs_cull_never();
         uint32_t dk = 0;
         if (have) { r = rect[i]; c = mrgs_cull_load(cull, (uint32_t)i); dk = depth_key[i]; }
-        CullConic cc;
-        uint32_t d, id;
-        auto rl = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-        for_each_tile(have, r, tiles_x,
-            [&] { cc = c; d = dk; id = (uint32_t)i; },
-            [&](int src) {
-                cc.a = make_float4(rl(c.a.x, src), rl(c.a.y, src), rl(c.a.z, src), rl(c.a.w, src));
-                cc.b = make_float4(rl(c.b.x, src), rl(c.b.y, src), rl(c.b.z, src), rl(c.b.w, src));
-                d = (uint32_t)__builtin_amdgcn_readlane((int)dk, src);
-                id = (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + src);
-            },
-            [&](int tile) {
-            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-            const float x0 = (float)(tx * MRGS_BLOCK_X), y0 = (float)(ty * MRGS_BLOCK_Y);
-            uint32_t m = 0;
+        const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+        const int w = x1 - x0, n = have ? w * (y1 - y0) : 0;
+        const bool big = n >= BIN_COOP_MIN;
+        const uint32_t small_n = big ? 0u : (uint32_t)n;
+        uint32_t incl = small_n;
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                m |= mrgs_block_may_touch(cc, x0 + (float)(8 * (q & 1)), y0 + (float)(8 * (q >> 1)), 7.0f, 7.0f) ? (1u << q) : 0u;
-            const uint32_t pos = atomicAdd(&s_cur[tile], 1u);
-            pairs[pos] = ((unsigned long long)d << 32) | (unsigned long long)((id << 4) | m);
-        });
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += u;
+        }
+        const uint32_t excl = incl - small_n;
+        const int total = __builtin_amdgcn_readlane((int)incl, 63);
+        // records of this step's 64 surfels, and the owner lane of every numbered pair
+        uint4* rec4 = (uint4*)(wrec + lane * EMIT_REC_WORDS);
+        rec4[0] = make_uint4(__float_as_uint(c.a.x), __float_as_uint(c.a.y), __float_as_uint(c.a.z), __float_as_uint(c.a.w));
+        rec4[1] = make_uint4(__float_as_uint(c.b.x), __float_as_uint(c.b.y), __float_as_uint(c.b.z), __float_as_uint(c.b.w));
+        rec4[2] = make_uint4(dk, r.x, r.y, excl);
+        for (uint32_t k = 0; k < small_n; k++) wown[excl + k] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int base = 0; base < total; base += 64) {
+            const int p = base + lane;
+            if (p < total) {
+                const int o = (int)wown[p];
+                const uint4* q4 = (const uint4*)(wrec + o * EMIT_REC_WORDS);
+                const uint4 qa = q4[0], qb = q4[1], qc = q4[2];
+                CullConic cc;
+                cc.a = make_float4(__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z), __uint_as_float(qa.w));
+                cc.b = make_float4(__uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z), __uint_as_float(qb.w));
+                const int ox0 = qc.y & 0xFFFF, oy0 = qc.y >> 16, ow = (int)(qc.z & 0xFFFF) - ox0;
+                const int k = p - (int)qc.w, yy = k / ow;
+                emit(cc, qc.x, (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + o), (oy0 + yy) * tiles_x + ox0 + (k - yy * ow));
+            }
+        }
+        // surfels with many tiles (a heavy-tailed scene has splats of hundreds of tiles): one at a time, spread over the 64 lanes
+        uint64_t todo = __builtin_amdgcn_ballot_w64(big);
+        auto rl = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+        while (todo != 0ull) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int sx0 = __builtin_amdgcn_readlane(x0, src), sy0 = __builtin_amdgcn_readlane(y0, src);
+            const int sw = __builtin_amdgcn_readlane(w, src), sn = __builtin_amdgcn_readlane(n, src);
+            CullConic cc;
+            cc.a = make_float4(rl(c.a.x, src), rl(c.a.y, src), rl(c.a.z, src), rl(c.a.w, src));
+            cc.b = make_float4(rl(c.b.x, src), rl(c.b.y, src), rl(c.b.z, src), rl(c.b.w, src));
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dk, src);
+            const uint32_t id = (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + src);
+            for (int k = lane; k < sn; k += 64) {
+                const int yy = k / sw;
+                emit(cc, d, id, (sy0 + yy) * tiles_x + sx0 + (k - yy * sw));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // the next step overwrites the wave's records
     }
 }
 
@@ -504,8 +559,9 @@ __global__ void __launch_bounds__(SORT_BIG_THREADS) tile_sort_big_kernel(const u
 // ---- host side --------------------------------------------------------------------------------------------------------
 int mrgs_bin_groups(int P) { const int g = (P + BIN_THREADS - 1) / BIN_THREADS; return g < 1 ? 1 : g > 256 ? 256 : g; }
 int mrgs_bin_tpad(int T) { return (T + 255) & ~255; }
-// the LDS histogram / cursor array of a slice workgroup holds one word per tile (160 KiB per workgroup on gfx950)
-bool mrgs_bin_supported(int T) { return T <= 36864; }
+// the LDS histogram / cursor array of a slice workgroup holds one word per tile (160 KiB per workgroup on gfx950, shared with the
+// emit kernel's per-wave staging)
+bool mrgs_bin_supported(int T) { return T <= 20480; }   // 80 KB of cursors + 72 KB of per-wave staging in tile_emit_kernel
 
 static int per_group(int P) { const int G = mrgs_bin_groups(P); return ((P + G - 1) / G + 63) & ~63; }
 
@@ -535,7 +591,7 @@ void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int T = tiles_x * tiles_y, Tpad = mrgs_bin_tpad(T), G = mrgs_bin_groups(cfg.P);
     unsigned long long* pairs = (unsigned long long*)b.tile_key[0];
-    hipLaunchKernelGGL(tile_emit_kernel, dim3(G), dim3(BIN_THREADS), (size_t)T * sizeof(uint32_t), stream, cfg.P, per_group(cfg.P), g.tiles_touched,
+    hipLaunchKernelGGL(tile_emit_kernel, dim3(G), dim3(BIN_THREADS), (size_t)((T + 3) & ~3) * sizeof(uint32_t) + (BIN_THREADS / 64) * EMIT_WAVE_BYTES, stream, cfg.P, per_group(cfg.P), g.tiles_touched,
                        g.rect, g.depth_key[0], g.cull, tiles_x, T, Tpad, g.tile_mat, g.tile_loc, g.chunk_base, g.counters, capacity, pairs,
                        g.counters + 16, g.counters + 6);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(BS_THREADS), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,

@@ -369,7 +369,7 @@ def test_dense_tiles_take_the_big_sort_path(gpu_device, P, H, W, rpx):
 
 
 def test_image_with_more_tiles_than_the_slice_histograms_hold(gpu_device):
-    """Above 36 864 tiles (here 3 200 x 3 200 px = 40 000) the binning falls back to the global radix path of mrgs_sort.hip:
+    """Above 20 480 tiles (here 3 200 x 3 200 px = 40 000) the binning falls back to the global radix path of mrgs_sort.hip:
     same bit-exact binning state."""
     H = W = 3200
     scene = make_shell_scene(3000, S=0, seed=5, radius_px=30.0, image_size=W)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces the profile artefacts of one code state on the MI355X box (run through gpurun from the repository root):
 #   tools/profile_round.sh <tag> [full]
-# -> gpurun_out/round/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py C2), the two HBM-traffic passes and the
+# -> gpurun_out/round/: <tag>_kernel_stats.csv (timeout 300 rocprofv3 --kernel-trace --stats of bench.py C2), the two HBM-traffic passes and the
 #    SQ pass (each counter set in its own run, kernel-trace only), their reductions (profiles/pmc_traffic.json, profiles/pmc_sq.json
 #    stamped with the digest of the kernel sources), and the un-profiled bench lines.  With "full" also the C3* / C4* workloads.
 # Copy what should be judged from gpurun_out/round/ into profiles/.
@@ -11,11 +11,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o $TAG -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o $TAG -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o pmc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o pmc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   -d $O/pmc_sq -o pmc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1
 cd $R
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
@@ -26,13 +26,13 @@ python tools/pmc_sq.py $S $O/${TAG}_pmc_sq_C2.json C2 profiles/pmc_sq.json > $O/
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $F | head -400 > $O/${TAG}_pmc_FETCH_SIZE_C2.csv
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $W | head -400 > $O/${TAG}_pmc_WRITE_SIZE_C2.csv
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
-python bench.py > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
+timeout 600 python bench.py > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
 if [ "$FULL" = "full" ]; then
-  python bench.py --workload C3 --steps 300 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_C3.json 2>> $O/bench_C2.err
-  python bench.py --workload C3full --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3full.json 2>> $O/bench_C2.err
-  python bench.py --workload C3train --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3train.json 2>> $O/bench_C2.err
-  python bench.py --workload C4raster --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4raster.json 2>> $O/bench_C2.err
-  python bench.py --workload C4full --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4full.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C3 --steps 300 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_C3.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C3full --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3full.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C3train --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3train.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C4raster --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4raster.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C4full --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4full.json 2>> $O/bench_C2.err
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 tail -1 $O/${TAG}_bench_C2.json | cut -c1-600
