@@ -78,6 +78,12 @@ typedef struct MrgsRasterInputs {
                               [P,M-1,3] (M = 2..16) -- the two tensors GaussianModel stores (_features_dc / _features_rest,
                               scene/gaussian_model.py:401-402), which the reference concatenates for every render (get_features,
                               :256-259); MrgsRasterGrads::dL_dsh_rest must then be set too (dL_dsh receives [P,1,3]). */
+    void* bwd_grad_ws;     /* optional.  FORWARD calls: the grad_ws (mrgs_grad_bytes) the caller will hand to mrgs_rasterize_backward for
+                              this render.  The forward then prepares the backward while it runs anyway -- the gradient rows are cleared by
+                              spare workgroups of its ordering launch and the backward's work queues are set up as a copy of its own -- and the
+                              backward needs no launch before its blend kernel.  BACKWARD call: pass the same pointer (and the same
+                              grad_ws) to say that this was done; NULL, or a pointer other than grad_ws, makes the backward order and clear
+                              by itself.  Valid for ONE backward per forward.  Results do not depend on it. */
 } MrgsRasterInputs;
 
 /* Workspace sizes.  geom <-> geomBuffer (GeometryState, rasterizer_impl.cu:157-172), img <-> imgBuffer

@@ -25,7 +25,8 @@ class MrgsRasterConfig(ctypes.Structure):
 
 class MrgsRasterInputs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
-                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint", "shs_rest")]
+                                        "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint", "shs_rest",
+                                        "bwd_grad_ws")]
 
 
 class MrgsRasterGrads(ctypes.Structure):

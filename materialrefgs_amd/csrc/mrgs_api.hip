@@ -264,7 +264,9 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
         STAGE_CHECK(cfg, stream);
         mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
     }
-    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, nullptr, 0, in->work_hint, stream);
+    // (with MrgsRasterInputs::bwd_grad_ws the ordering launch also prepares the backward: rows cleared, queues copied)
+    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, in->bwd_grad_ws, in->bwd_grad_ws ? mrgs_grad_bytes(cfg->P, cfg->S) : 0, in->work_hint,
+                            stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
@@ -406,11 +408,12 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     float* grad_rec = (float*)grad_ws;
 
     StageTimer t0(stream, ST_BWD);
+    const bool prepared = in->bwd_grad_ws != nullptr && in->bwd_grad_ws == grad_ws;   // the forward cleared the rows and set up the queues
     if (R > 0) {
         // (the gradient rows are cleared by spare workgroups of the ordering launch; mrgs_grad_bytes is a multiple of 256)
-        mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, grad_rec, mrgs_grad_bytes(cfg->P, cfg->S), nullptr, stream);
-        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.qmask, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, stream);
-    } else {
+        if (!prepared) mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, grad_rec, mrgs_grad_bytes(cfg->P, cfg->S), nullptr, stream);
+        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.qmask, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, prepared, stream);
+    } else if (!prepared) {
         HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
     }
     t0.stop();

@@ -156,7 +156,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
                             const uint8_t* qmask, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const uint8_t* qmask, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
-                            float* grad_rec, hipStream_t stream);
+                            float* grad_rec, bool forward_queues, hipStream_t stream);
 
 #ifndef MRGS_EXP
 #define MRGS_EXP(x) expf(x)

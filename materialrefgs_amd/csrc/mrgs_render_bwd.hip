@@ -440,15 +440,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const uint8_t* qmask, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
-                            float* grad_rec, hipStream_t stream)
+                            float* grad_rec, bool forward_queues, hipStream_t stream)
 {
+    // forward_queues: the forward set the backward's queue state up as a copy of its own (MrgsRasterInputs::bwd_grad_ws): same dealing,
+    // read from the forward's assignment array
+    const uint32_t* assign = forward_queues ? img.fwd_assign : img.bwd_assign;
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
     // one wave per slot of the work queues (mrgs_pull_item): items rounded up to whole dealing passes; blockIdx % 8 = XCD list
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV, GS)                                                                                                       \
-    hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.bwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<render_bwd_kernel<SM, FVV>>())
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);

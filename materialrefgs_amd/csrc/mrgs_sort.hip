@@ -563,7 +563,8 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ work_ws, uint32_t* __restrict__ assign_ws,
                                                            uint32_t* __restrict__ qstate, const uint32_t* __restrict__ census,
                                                            uint32_t* __restrict__ cu_state, int forward, uint32_t* __restrict__ zero_this,
-                                                           float4* __restrict__ bulk_zero, size_t bulk_zero_f4, const uint32_t* __restrict__ hint)
+                                                           float4* __restrict__ bulk_zero, size_t bulk_zero_f4, const uint32_t* __restrict__ hint,
+                                                           uint32_t* __restrict__ qstate_twin)
 {
     // workgroups beyond the eight that order the lists only clear a buffer for the kernel that follows (the gradient rows of
     // the blend backward, 24 MB at P = 300k): the ordering occupies 8 CUs for ~10 us, the clear runs beside it on the others
@@ -581,7 +582,12 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     const int per_list = ((ntiles + 7) >> 3) * 4;           // items of one XCD list (upper bound)
     hist[tid] = 0;
     if (tid == 0) { s_total = 0ull; s_busy = 0u; }
-    if (tid < MRGS_MAX_SIMD_QUEUES) { qstate[MRGS_QS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u; load[tid] = 0u; }
+    if (tid < MRGS_MAX_SIMD_QUEUES) {
+        qstate[MRGS_QS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u;
+        // the forward may set up the backward's queues as a copy of its own (MrgsRasterInputs::bwd_grad_ws)
+        if (qstate_twin != nullptr) qstate_twin[MRGS_QS_TICKET + x * MRGS_MAX_SIMD_QUEUES + tid] = 0u;
+        load[tid] = 0u;
+    }
     if (zero_this != nullptr)
         for (int i = tid + 1024 * x; i < 4 * ntiles; i += 8 * 1024) zero_this[i] = 0u;
     // forward: every (tile, quadrant) is an item (idle ones still write their pixels: key = work + 1); backward: only those
@@ -706,6 +712,10 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     if (tid == 0) {
         qstate[MRGS_QS_COUNT + x] = tot;
         qstate[MRGS_QS_PASSES + x] = (uint32_t)passes | ((uint32_t)NQ << 16);
+        if (qstate_twin != nullptr) {
+            qstate_twin[MRGS_QS_COUNT + x] = tot;
+            qstate_twin[MRGS_QS_PASSES + x] = (uint32_t)passes | ((uint32_t)NQ << 16);
+        }
     }
 }
 
@@ -717,11 +727,11 @@ void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int n
     if (backward)
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
                            img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr,
-                           (float4*)bulk_zero, f4, (const uint32_t*)nullptr);
+                           (float4*)bulk_zero, f4, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
                            img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work,
-                           (float4*)bulk_zero, f4, fwd_hint);
+                           (float4*)bulk_zero, f4, fwd_hint, bulk_zero ? img.blend_state + MRGS_QS_BWD : (uint32_t*)nullptr);
 }
 
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,

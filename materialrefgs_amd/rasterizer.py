@@ -23,6 +23,7 @@ _PAIR_GUESS = {}   # device index -> pair capacity to try first (previous count 
 # scheduling aid: results do not depend on it.
 _WORK_HINTS = {}
 _NO_HINT = bool(int(__import__("os").environ.get("MRGS_NO_WORK_HINT", "0")))   # developer switch for A/B timing
+_NO_PREPARE = bool(int(__import__("os").environ.get("MRGS_NO_PREPARE_BWD", "0")))   # developer switch: the backward orders / clears by itself
 _WORK_HINTS_MAX = 2048
 
 
@@ -76,7 +77,8 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None):
+def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None,
+                     bwd_grad_ws=None):
     P = means3D.shape[0]
     S = features.shape[1] if features.dim() == 2 else 0
     M = sh.shape[1] if sh.numel() != 0 else 0
@@ -89,13 +91,16 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
     inp = MrgsRasterInputs(_ptr(raster_settings.bg), _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(features),
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
                            _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
-                           _ptr(_work_hint(raster_settings, means3D.device)) if means3D.is_cuda else None, _ptr(sh_rest))
+                           _ptr(_work_hint(raster_settings, means3D.device)) if means3D.is_cuda else None, _ptr(sh_rest),
+                           _ptr(bwd_grad_ws))
     return cfg, inp
 
 
 def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                              sh_rest=None):
-    """Counterpart of `_C.rasterize_gaussians` (rasterize_points.cu:41-144)."""
+                              sh_rest=None, prepare_backward=False):
+    """Counterpart of `_C.rasterize_gaussians` (rasterize_points.cu:41-144).  prepare_backward: also allocate the backward's gradient-row
+    workspace and let the forward clear it and set up the backward's work queues (MrgsRasterInputs::bwd_grad_ws); it is appended to
+    the returned tuple."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -103,8 +108,13 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
     L = _lib.lib()
     dev = means3D.device
     H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    S_ = features.shape[1] if features.dim() == 2 else 0
+    grad_ws = None
+    if prepare_backward and means3D.shape[0] > 0:
+        with torch.cuda.device(dev):
+            grad_ws = torch.empty((L.mrgs_grad_bytes(means3D.shape[0], S_),), dtype=torch.uint8, device=dev)
     cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                                sh_rest)
+                                sh_rest, grad_ws)
     P, S = cfg.P, cfg.S
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -142,17 +152,18 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
                                                        _ptr(img), pairs, _ptr(color), _ptr(feature), _ptr(others), st))
         if P > 0:
             _PAIR_GUESS[dev.index] = max(int(num_rendered * 1.25) + 65536, 1)
-    return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img
+    return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
 
 
 def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp,
                                grad_out_color, grad_out_feature, grad_out_others, sh, opacities, geom, num_rendered, binning, img,
-                               sh_rest=None):
-    """Counterpart of `_C.rasterize_gaussians_backward` (rasterize_points.cu:146-252)."""
+                               sh_rest=None, prepared_grad_ws=None):
+    """Counterpart of `_C.rasterize_gaussians_backward` (rasterize_points.cu:146-252).  prepared_grad_ws: the workspace the forward of
+    this render was given (cleared, queues set up) -- valid for one backward."""
     L = _lib.lib()
     dev = means3D.device
     cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                                sh_rest)
+                                sh_rest, prepared_grad_ws)
     P, S, M = cfg.P, cfg.S, cfg.M
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -164,7 +175,7 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
              "dL_drotations": torch.empty((P, 4), **opts),
              "dL_dsh_rest": torch.empty((P, M - 1, 3), **opts) if sh_rest is not None else None}
         grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_])
-        grad_ws = torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
+        grad_ws = prepared_grad_ws if prepared_grad_ws is not None else torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
         _lib.check(L.mrgs_rasterize_backward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
                                              num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),
                                              _ptr(grad_ws), ctypes.byref(grads), st))
@@ -190,7 +201,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         opacities, scales, rotations, cov3Ds_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_f32c(raster_settings.viewmatrix),
                                       projmatrix=_f32c(raster_settings.projmatrix), campos=_f32c(raster_settings.campos))
-        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest)
+        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest, any(ctx.needs_input_grad) and not _NO_PREPARE)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted
             try:
@@ -201,7 +212,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ex
         else:
             out = _rasterize_forward_native(*args)
-        (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer = out
+        (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer, grad_ws = out
+        ctx.prepared_grad_ws = grad_ws       # cleared by the forward, queues of the backward set up: good for ONE backward
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.binning_pairs = binning_pairs   # pair count binningBuffer is carved for (>= num_rendered)
@@ -225,8 +237,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_out_feature = torch.zeros((S, H, W), dtype=torch.float32, device=dev)
         if grad_depth is None:
             grad_depth = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
+        prepared, ctx.prepared_grad_ws = ctx.prepared_grad_ws, None
         args = (rs, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp, _f32c(grad_out_color),
-                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest)
+                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest, prepared)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])
             try:

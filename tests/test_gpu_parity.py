@@ -374,3 +374,25 @@ def test_image_with_more_tiles_than_the_slice_histograms_hold(gpu_device):
     H = W = 3200
     scene = make_shell_scene(3000, S=0, seed=5, radius_px=30.0, image_size=W)
     compare_all(scene, orbit_camera(2, H, W), gpu_device, check_grads=False, pixel_allowance=1)
+
+
+def test_backward_prepared_by_the_forward_equals_the_self_contained_backward(gpu_device):
+    """The forward clears the gradient rows and sets the backward's queues up (MrgsRasterInputs::bwd_grad_ws) for ONE backward; a
+    second backward of the same graph orders and clears by itself.  Both must give the same gradients (up to the order of the
+    float atomics)."""
+    from helpers import HipRender
+    S, H, W = 8, 160, 208
+    scene = make_shell_scene(6000, S=S, seed=9, radius_px=6.0, image_size=W)
+    hr = HipRender(scene, orbit_camera(4, H, W), gpu_device)
+    g = [t.to(gpu_device) for t in upstream_grads(S, H, W)]
+    outs, grads = [hr.color, hr.others, hr.feature], [g[0], g[2], g[1]]
+    assert hr.fn.prepared_grad_ws is not None
+    torch.autograd.backward(outs, grads, retain_graph=True)
+    first = {k: v.grad.clone() for k, v in hr.leaves.items() if v.grad is not None}
+    assert hr.fn.prepared_grad_ws is None
+    for v in hr.leaves.values():
+        v.grad = None
+    torch.autograd.backward(outs, grads)
+    for k, a in first.items():
+        b = hr.leaves[k].grad
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-20), k
