@@ -27,6 +27,14 @@ _NO_PREPARE = bool(int(__import__("os").environ.get("MRGS_NO_PREPARE_BWD", "0"))
 _WORK_HINTS_MAX = 2048
 
 
+def _hint_is_warm(raster_settings, device):
+    """True when this camera was rendered before, i.e. its hint holds measured work.  Only then may the forward set up the backward's
+    queues (they are a copy of its own): built from the cull counts alone they balance the backward a third worse than the
+    backward's own ordering by what the forward waves walked."""
+    vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
+    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr()) in _WORK_HINTS
+
+
 def _work_hint(raster_settings, device):
     if _NO_HINT:
         return None
@@ -201,7 +209,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         opacities, scales, rotations, cov3Ds_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_f32c(raster_settings.viewmatrix),
                                       projmatrix=_f32c(raster_settings.projmatrix), campos=_f32c(raster_settings.campos))
-        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest, any(ctx.needs_input_grad) and not _NO_PREPARE)
+        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest, any(ctx.needs_input_grad) and not _NO_PREPARE and means3D.is_cuda and _hint_is_warm(rs, means3D.device))
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted
             try:

@@ -32,7 +32,7 @@ def raster_settings(cam, device, sh_degree=3, scale_modifier=1.0, bg=None, debug
 class HipRender:
     """Forward (+ optional backward) through materialrefgs_amd.rasterizer, keeping handles for introspection."""
 
-    def __init__(self, scene, cam, device, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, use_features=True):
+    def __init__(self, scene, cam, device, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, use_features=True, rs=None):
         from materialrefgs_amd.rasterizer import GaussianRasterizer
         self.dev = device
         sc = scene.to(device)
@@ -41,7 +41,7 @@ class HipRender:
             t = t.clone().requires_grad_(True)
             self.leaves[name] = t
             return t
-        self.rs = raster_settings(cam, device, sh_degree, scale_modifier, bg)
+        self.rs = rs if rs is not None else raster_settings(cam, device, sh_degree, scale_modifier, bg)   # rs: the settings (camera tensors) of an earlier render
         means3D = leaf("means3D", sc.means3D)
         means2D = leaf("means2D", torch.zeros_like(sc.means3D))
         opac = leaf("opacity", sc.opacities)

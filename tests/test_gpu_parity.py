@@ -383,7 +383,9 @@ def test_backward_prepared_by_the_forward_equals_the_self_contained_backward(gpu
     from helpers import HipRender
     S, H, W = 8, 160, 208
     scene = make_shell_scene(6000, S=S, seed=9, radius_px=6.0, image_size=W)
-    hr = HipRender(scene, orbit_camera(4, H, W), gpu_device)
+    cold = HipRender(scene, orbit_camera(4, H, W), gpu_device)
+    assert cold.fn.prepared_grad_ws is None          # first render of a camera: no measured work to build the backward's queues from
+    hr = HipRender(scene, orbit_camera(4, H, W), gpu_device, rs=cold.rs)
     g = [t.to(gpu_device) for t in upstream_grads(S, H, W)]
     outs, grads = [hr.color, hr.others, hr.feature], [g[0], g[2], g[1]]
     assert hr.fn.prepared_grad_ws is not None
