@@ -348,6 +348,36 @@ int mrgs_bvh_trace(const void* blob_dev, int64_t n_triangles, int64_t n_rays, co
 int mrgs_bvh_visibility(const void* blob_dev, int64_t n_triangles, int32_t H, int32_t W, const float* Kinv, const float* R, const float* T,
                         const MrgsStridedMap* normal, const MrgsStridedMap* alpha, const float* surf_depth, float* visibility, void* stream);
 
+/* ---- surfel ray tracer (second half) -----------------------------------------------------------------
+ * Replaces the un-vendored OptiX extension `diff_surfel_tracing` behind HardwareRendering (gaussian_renderer/optix_utils.py:14-271):
+ * SurfelTracer.build_acceleration_structure(v, f, rebuild) (:76) -> mrgs_surfel_bvh_build, SurfelTracer.forward (:185-197) ->
+ * mrgs_surfel_trace_forward, its autograd backward -> mrgs_surfel_trace_backward.  The extension's arithmetic is not in the reference
+ * tree: the definition is stated in csrc/mrgs_surfel_trace.hip (2DGS compositing of forward.cu:366-420 along a ray) and restated
+ * densely in oracle/surfel_trace_oracle.py; parity with the OptiX binary is unpinned.  All pointers are device pointers except
+ * bg_host (3 floats on the host).
+ * Build (on the device, every call): quad_vertices [n_surfels,4,3] = the four corners get_disks (:36-66) produces per surfel; blob
+ * (mrgs_surfel_bvh_bytes) receives the hierarchy, ws (mrgs_surfel_bvh_ws_bytes) is scratch that may be reused after the call's
+ * kernels have run.
+ * Trace: ray_o / ray_d [n_rays,3] (direction not normalised: depths are ray parameters); ray_width > 0 says the rays are an image
+ * with rows of that length (n_rays a multiple of it): a wavefront then takes an 8x8 block of neighbouring rays instead of 64 of a
+ * row (same results, shorter walks); the trace calls write the surfel records in leaf order into the blob (not const); geom [n_surfels,16] per surfel
+ * (mean.xyz, a.xyz, b.xyz, n.xyz, opacity, 3 unused) with a = r_u / s_u, b = r_v / s_v, n = r_u x r_v; attr [n_surfels,8] =
+ * (rgb, others[2], 3 unused).  Outputs rgb / norm [n_rays,3], dpt / acc / dist [n_rays], aux [n_rays,2], wet [n_surfels] (summed
+ * blend weight per surfel, cleared by the call), state [n_rays,4] (sum w t^2, final transmittance, hits blended, passes: what the
+ * backward needs beyond the outputs).  Backward: g_* of the six outputs in, g_geom [n_surfels,16] / g_attr [n_surfels,8] (cleared by
+ * the call, same layout as geom / attr) and g_ray_o / g_ray_d [n_rays,3] out. */
+size_t mrgs_surfel_bvh_bytes(int64_t n_surfels);
+size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels);
+int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* blob, size_t blob_bytes, void* ws, size_t ws_bytes, void* stream);
+int mrgs_surfel_trace_forward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
+                              const float* attr, const float* bg_host, float* rgb, float* dpt, float* acc, float* norm, float* dist,
+                              float* aux, float* wet, float* state, void* stream);
+int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
+                               const float* attr, const float* bg_host, const float* rgb, const float* dpt, const float* acc,
+                               const float* norm, const float* aux, const float* state, const float* g_rgb, const float* g_dpt,
+                               const float* g_acc, const float* g_norm, const float* g_dist, const float* g_aux, float* g_geom,
+                               float* g_attr, float* g_ray_o, float* g_ray_d, void* stream);
+
 /* ---- optimizer step -------------------------------------------------------------------------
  * torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of GaussianModel.training_setup (scene/gaussian_model.py:417-453) for every
  * parameter tensor in one launch (per MRGS_ADAM_MAX_TENSORS tensors): amsgrad off, no weight decay.  `tensors` is a HOST array;

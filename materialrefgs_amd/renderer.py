@@ -63,6 +63,15 @@ class SurfelModel:
     get_envmap = property(lambda s: s.env_map)
     get_envmap_2 = property(lambda s: s.env_map_2 if s.env_map_2 is not None else s.env_map)
 
+    def get_covariance(self, scaling_modifier=1):
+        """gaussian_model.py:48-54, 346-347: the splat-to-world transform, transposed -- rows s_u r_u, s_v r_v, r_w, mean."""
+        s3 = torch.cat([self.get_scaling * scaling_modifier, torch.ones_like(self.get_scaling[:, :1])], dim=-1)
+        trans = torch.zeros((self._xyz.shape[0], 4, 4), dtype=torch.float32, device=self._xyz.device)
+        trans[:, :3, :3] = build_scaling_rotation(s3, self._rotation).permute(0, 2, 1)
+        trans[:, 3, :3] = self.get_xyz
+        trans[:, 3, 3] = 1
+        return trans
+
     def get_normal(self, scaling_modifier, dir_pp_normalized):
         """gaussian_model.py:269-285 (return_delta=False): third column of R(q), flipped to face the viewer."""
         s3 = torch.cat([self.get_scaling * scaling_modifier, torch.ones_like(self.get_scaling[:, :1])], dim=-1)
@@ -384,3 +393,54 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     if indirect_on:
         out.update({"visibility": rendered_features[11:12], "indirect_light": rendered_features[12:15], "direct_light": rendered_features[15:18]})
     return out
+
+
+# ---- traced indirect light (second half) ---------------------------------------------------------------
+def _pixel_rays_unnormalized(HWK, R, T, device):
+    """sample_camera_rays_unnormalize (utils/refl_utils.py:75-93): per pixel the world-space vector from the camera centre to the point
+    at view depth 1 behind the pixel (x, y integer pixel coordinates), and the camera centre.  R is Camera.R (stored transposed)."""
+    H, W, K = HWK
+    Kinv = torch.linalg.inv(torch.as_tensor(K, dtype=torch.float32, device=device))
+    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32), torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    pix_cam = torch.stack([xs, ys, torch.ones_like(xs)], dim=-1) @ Kinv.T
+    R = torch.as_tensor(R, dtype=torch.float32, device=device)
+    T = torch.as_tensor(T, dtype=torch.float32, device=device)
+    Rw = R.T                                               # the world-to-camera rotation
+    rays_o = (-Rw.T @ T.unsqueeze(-1)).flatten()
+    rays_d = (pix_cam - T[None, None]).reshape(-1, 3) @ Rw - rays_o[None]
+    return rays_d.reshape(H, W, 3), rays_o
+
+
+def _mirror_rays(viewpoint_camera, normal_map, surf_depth):
+    """The ray set of render_indirect / render_surfel_with_envgs (gaussian_renderer/__init__.py:496-505, envgs_renderer.py:717-724):
+    from the surface point of every pixel along the mirror direction of the view ray, origin moved 1e-3 along it."""
+    H, W, _ = viewpoint_camera.HWK
+    rays_cam, rays_o = _pixel_rays_unnormalized(viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, surf_depth.device)
+    hit = rays_o + surf_depth.reshape(H, W, 1) * rays_cam
+    w_o = safe_normalize(-rays_cam)
+    n = normal_map.reshape(H, W, 3)
+    refl = safe_normalize(2 * n * torch.sum(w_o * n, dim=-1, keepdim=True) - w_o)          # reflection(), utils/refl_utils.py:95-98
+    return hit + 1e-3 * refl, refl
+
+
+def render_indirect(indirect_renderer, viewpoint_camera, pc, pipe, bg_color, normal_map=None, surf_depth=None):
+    """gaussian_renderer/envgs_renderer.py:716-731: the surfel set `pc` seen along the mirror rays of a rendered view."""
+    ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, surf_depth)
+    return indirect_renderer.render_gaussians(viewpoint_camera, ray_o=ray_o, ray_d=ray_d, pcd=pc, pipe=pipe, bg_color=bg_color,
+                                              start_from_first=True)
+
+
+def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
+                             opt=None, wo_render_img=False, normal_img_map=None):
+    """gaussian_renderer/__init__.py:486-520: render_surfel, then the same surfels traced along every pixel's mirror ray
+    (`indirect_renderer`: HardwareRendering, here materialrefgs_amd.surfel_tracing) and blended in with the traced `specular`
+    channel as weight; the tracer's dictionary is returned under "indirect_out"."""
+    results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt)
+    alpha = results["rend_alpha"].permute(1, 2, 0)
+    normal_map = safe_normalize(results["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))
+    ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, results["surf_depth"])
+    traced = indirect_renderer(viewpoint_camera, ray_o=ray_o, ray_d=ray_d, pcd=pc, pipe=pipe, bg_color=bg_color, start_from_first=False)
+    specular = traced["specular"]
+    results["render"] = results["render"] * (1 - specular) + specular * traced["render"]
+    results["indirect_out"] = traced
+    return results

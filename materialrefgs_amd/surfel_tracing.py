@@ -1,0 +1,282 @@
+"""Surfel ray tracing: the Python surface of the reference's `diff_surfel_tracing` extension and of `HardwareRendering`.
+
+Mirrors (names, arguments, outputs)
+  * `from diff_surfel_tracing import SurfelTracer, SurfelTracingSettings`          gaussian_renderer/optix_utils.py:7
+      SurfelTracer().build_acceleration_structure(v, f, rebuild=True)              :76
+      SurfelTracer()(ray_o, ray_d, v, means3D=..., grads3D=..., shs=..., colors_precomp=..., others_precomp=..., opacities=...,
+                     scales=..., rotations=..., cov3D_precomp=..., tracer_settings=..., start_from_first=...)       :185-197
+        -> rgb, dpt, acc, norm, dist, aux, mid, wet
+  * `HardwareRendering` (optix_utils.py:14-271): get_disks, build_bvh, render_gaussians -> the same output dictionary.
+The extension itself is not in the reference tree (OptiX, un-vendored): what it computes is defined in csrc/mrgs_surfel_trace.hip and
+checked against oracle/surfel_trace_oracle.py; parity with the OptiX binary is unpinned.  The hierarchy is built on the
+GPU by libmrgs (no host round trip), the tracing and its backward are HIP kernels; there is no CPU path.
+"""
+import ctypes
+import math
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from .gs_utils import build_rotation, eval_sh
+
+MID_CHANNELS = 16    # optix_utils.py:28-35: ray_o 3, ray_d 3, dpt 1, acc 1, norm 3, aux 2, rgb 3 per tracing depth
+
+
+class SurfelTracingSettings(NamedTuple):
+    """Fields as constructed at optix_utils.py:101-116."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    max_trace_depth: int = 0
+    specular_threshold: float = 0.0
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be a CUDA(HIP) tensor: the surfel tracer has no CPU path")
+
+
+class _Trace(torch.autograd.Function):
+    """mrgs_surfel_trace_forward / _backward.  geom [P,16] = (mean, r_u / s_u, r_v / s_v, normal, opacity, -), attr [P,8] = (rgb, others, -)."""
+
+    @staticmethod
+    def forward(ctx, ray_o, ray_d, geom, attr, blob, bg3, ray_width):
+        L = _lib.lib()
+        dev = ray_o.device
+        n_rays, P = ray_o.shape[0], geom.shape[0]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        rgb, norm, aux, dpt, acc, dist = new(n_rays, 3), new(n_rays, 3), new(n_rays, 2), new(n_rays), new(n_rays), new(n_rays)
+        wet, state = new(P), new(n_rays, 4)
+        bg = (ctypes.c_float * 3)(*bg3)
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_surfel_trace_forward(_ptr(blob), P, n_rays, ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
+                                                   _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(dist), _ptr(aux), _ptr(wet), _ptr(state), _stream(dev)))
+        ctx.save_for_backward(ray_o, ray_d, geom, attr, blob, rgb, dpt, acc, norm, aux, state)
+        ctx.bg3, ctx.ray_width = bg3, ray_width
+        ctx.mark_non_differentiable(wet, state)
+        return rgb, dpt, acc, norm, dist, aux, wet, state
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_dpt, g_acc, g_norm, g_dist, g_aux, _g_wet, _g_state):
+        ray_o, ray_d, geom, attr, blob, rgb, dpt, acc, norm, aux, state = ctx.saved_tensors
+        L = _lib.lib()
+        dev = ray_o.device
+        n_rays, P = ray_o.shape[0], geom.shape[0]
+        z = lambda ref: torch.zeros_like(ref)
+        c = lambda g, ref: z(ref) if g is None else g.contiguous().float()
+        g_rgb, g_dpt, g_acc, g_norm, g_aux = c(g_rgb, rgb), c(g_dpt, dpt), c(g_acc, acc), c(g_norm, norm), c(g_aux, aux)
+        g_dist = c(g_dist, dpt)
+        g_geom, g_attr = torch.empty_like(geom), torch.empty_like(attr)
+        g_o, g_d = torch.empty_like(ray_o), torch.empty_like(ray_d)
+        bg = (ctypes.c_float * 3)(*ctx.bg3)
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_surfel_trace_backward(_ptr(blob), P, n_rays, ctx.ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
+                                                    _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(aux), _ptr(state), _ptr(g_rgb), _ptr(g_dpt),
+                                                    _ptr(g_acc), _ptr(g_norm), _ptr(g_dist), _ptr(g_aux), _ptr(g_geom), _ptr(g_attr),
+                                                    _ptr(g_o), _ptr(g_d), _stream(dev)))
+        return g_o, g_d, g_geom, g_attr, None, None, None
+
+
+def surfel_records(means3D, scales, rotations, opacities, colors, others, scale_modifier=1.0):
+    """The per-surfel records of the C ABI from the model's tensors (torch ops: autograd carries the tracer's gradients back)."""
+    R = build_rotation(rotations)
+    s = scales * scale_modifier
+    a = R[:, :, 0] / s[:, 0:1]
+    b = R[:, :, 1] / s[:, 1:2]
+    pad3 = torch.zeros_like(means3D)
+    geom = torch.cat([means3D, a, b, R[:, :, 2], opacities.reshape(-1, 1), pad3], dim=1).contiguous()
+    attr = torch.cat([colors, others, pad3], dim=1).contiguous()
+    return geom, attr
+
+
+class SurfelTracer(nn.Module):
+    """Counterpart of diff_surfel_tracing.SurfelTracer (optix_utils.py:21, 76, 185)."""
+
+    def __init__(self):
+        super().__init__()
+        self._blob = None
+        self._ws = None
+        self._n = 0
+
+    def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
+        """vertices [4 P, 3]: four corners per surfel in get_disks' order; faces are implied by that order (two triangles per quad,
+        optix_utils.py:58-60) and only checked for their count."""
+        _need_gpu(vertices, "vertices")
+        if vertices.dim() != 2 or vertices.shape[1] != 3 or vertices.shape[0] % 4 != 0:
+            raise RuntimeError("vertices must have dimensions (4 * num_surfels, 3)")
+        P = vertices.shape[0] // 4
+        if faces is not None and faces.shape[0] != 2 * P:
+            raise RuntimeError("faces must hold two triangles per surfel")
+        L = _lib.lib()
+        dev = vertices.device
+        v = vertices.detach().contiguous().float()
+        with torch.cuda.device(dev):
+            if self._blob is None or self._n != P or self._blob.device != dev:
+                self._blob = torch.empty(L.mrgs_surfel_bvh_bytes(P), dtype=torch.uint8, device=dev)
+                self._ws = torch.empty(L.mrgs_surfel_bvh_ws_bytes(P), dtype=torch.uint8, device=dev)
+                self._n = P
+            _lib.check(L.mrgs_surfel_bvh_build(_ptr(v), P, _ptr(self._blob), self._blob.numel(), _ptr(self._ws), self._ws.numel(), _stream(dev)))
+        return self
+
+    def forward(self, ray_o, ray_d, v=None, means3D=None, grads3D=None, shs=None, colors_precomp=None, others_precomp=None, opacities=None,
+                scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
+        ts = tracer_settings
+        if self._blob is None:
+            raise RuntimeError("build_acceleration_structure has not been called")
+        if cov3D_precomp is not None or scales is None or rotations is None:
+            raise NotImplementedError("the tracer intersects surfels from scales / rotations; cov3D_precomp is not supported")
+        if ts.max_trace_depth != 0:
+            raise NotImplementedError("max_trace_depth > 0 (bounces inside the tracer) is not built; every caller of the reference uses 0")
+        if (shs is None) == (colors_precomp is None):
+            raise RuntimeError("Please provide exactly one of either SHs or precomputed colors!")
+        _need_gpu(means3D, "means3D")
+        P = means3D.shape[0]
+        if P != self._n:
+            raise RuntimeError("the acceleration structure was built for a different number of surfels")
+        shape = ray_o.shape[:-1]
+        means = means3D if grads3D is None else means3D + grads3D          # the densification proxy receives d/d means3D
+        if colors_precomp is None:
+            # computeColorFromSH of the rasterizer family (forward.cu:20-81): direction from the settings' camera position
+            dirs = means - ts.campos.reshape(1, 3)
+            dirs = dirs / dirs.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(ts.sh_degree, shs.transpose(1, 2), dirs) + 0.5, 0.0)
+        if others_precomp is None:
+            others_precomp = torch.zeros(P, 2, device=means3D.device)
+        geom, attr = surfel_records(means.float(), scales.float(), rotations.float(), opacities.float(), colors_precomp.float(),
+                                    others_precomp.float(), float(ts.scale_modifier))
+        o = ray_o.reshape(-1, 3).contiguous().float()
+        d = ray_d.reshape(-1, 3).contiguous().float()
+        bg3 = tuple(float(x) for x in ts.bg.detach().reshape(-1)[:3].tolist())
+        rgb, dpt, acc, norm, dist, aux, wet, _state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
+        r = lambda x, c: x.reshape(*shape, c)
+        rgb, dpt, acc, norm, dist, aux = r(rgb, 3), r(dpt, 1), r(acc, 1), r(norm, 3), r(dist, 1), r(aux, 2)
+        # stage 0 of the per-depth record (optix_utils.py:28-35); deeper stages do not exist at max_trace_depth = 0
+        mid = torch.cat([ray_o.reshape(*shape, 3).float(), ray_d.reshape(*shape, 3).float(), dpt, acc, norm, aux, rgb], dim=-1).detach()
+        return rgb, dpt, acc, norm, dist, aux, mid, wet.reshape(P, 1)
+
+
+def _depth_to_normal(view, depth):
+    """utils/point_utils.py:9-37 for a depth map [H,W]: back-project every pixel with the camera's intrinsics (pixel = integer
+    coordinates, principal point W/2, H/2), central differences over two pixels, unit cross product; the border stays zero."""
+    H, W = depth.shape
+    dev = depth.device
+    c2w = view.world_view_transform.T.inverse()
+    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32, device=dev).T
+    intr = ((c2w.T @ view.full_proj_transform) @ ndc2pix)[:3, :3].T
+    gx, gy = torch.meshgrid(torch.arange(W, device=dev, dtype=torch.float32), torch.arange(H, device=dev, dtype=torch.float32), indexing="xy")
+    pix = torch.stack([gx, gy, torch.ones_like(gx)], dim=-1).reshape(-1, 3)
+    dirs = pix @ intr.inverse().T @ c2w[:3, :3].T
+    pts = (depth.reshape(-1, 1) * dirs + c2w[:3, 3]).reshape(H, W, 3)
+    out = torch.zeros_like(pts)
+    du = pts[2:, 1:-1] - pts[:-2, 1:-1]
+    dv = pts[1:-1, 2:] - pts[1:-1, :-2]
+    out[1:-1, 1:-1] = torch.nn.functional.normalize(torch.cross(du, dv, dim=-1), dim=-1)
+    return out
+
+
+class HardwareRendering(nn.Module):
+    """Counterpart of gaussian_renderer/optix_utils.py:14-271 on the HIP tracer."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tracer = SurfelTracer()
+        self.has_bvh = False
+        self.mid_channel = MID_CHANNELS
+        self.rayo_off, self.rayd_off, self.dpt_off, self.acc_off, self.norm_off, self.aux_off, self.rgb_off = 0, 3, 6, 7, 8, 11, 13
+
+    def get_disks(self, pcd):
+        """Corners (-3,3), (-3,-3), (3,3), (3,-3) of every surfel in its tangent frame and the two triangles (0,1,2), (1,2,3) (:36-66)."""
+        T = pcd.get_covariance()                       # [P,4,4], rows: s_u r_u, s_v r_v, r_w, mean (gaussian_model.py:48-54)
+        su, sv, m = T[:, 0, :3], T[:, 1, :3], T[:, 3, :3]
+        corners = torch.tensor([[-3.0, 3.0], [-3.0, -3.0], [3.0, 3.0], [3.0, -3.0]], device=T.device)
+        v = (m[:, None, :] + corners[None, :, 0:1] * su[:, None, :] + corners[None, :, 1:2] * sv[:, None, :]).reshape(-1, 3)
+        idx = torch.arange(v.shape[0], device=T.device, dtype=torch.int32).reshape(-1, 4)
+        f = torch.stack([idx[:, :3], idx[:, 1:]], dim=1).reshape(-1, 3)
+        return v.contiguous(), f.contiguous()
+
+    def build_bvh(self, pcd, rebuild=1):
+        if rebuild or self.training or not self.has_bvh:
+            v, f = self.get_disks(pcd)
+            self.tracer.build_acceleration_structure(v.detach(), f, rebuild=True)
+            self.has_bvh = not self.training
+            return v, f
+        return None, None
+
+    def render_gaussians(self, camera, ray_o, ray_d, pcd, pipe, bg_color, max_trace_depth=0, specular_threshold=0.0, start_from_first=True,
+                         scaling_modifier=1, override_color=None):
+        settings = SurfelTracingSettings(
+            image_height=int(camera.image_height), image_width=int(camera.image_width), tanfovx=math.tan(camera.FoVx * 0.5),
+            tanfovy=math.tan(camera.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
+            viewmatrix=camera.world_view_transform.contiguous(), projmatrix=camera.full_proj_transform.contiguous(),
+            sh_degree=pcd.active_sh_degree, campos=camera.camera_center.contiguous(), prefiltered=False, debug=False,
+            max_trace_depth=max_trace_depth, specular_threshold=specular_threshold)
+        v, _f = self.build_bvh(pcd, rebuild=self.training)
+        means3D, opacities = pcd.get_xyz.contiguous(), pcd.get_opacity.contiguous()
+        grads3D = torch.zeros_like(means3D, requires_grad=True) + 0
+        try:
+            grads3D.retain_grad()
+        except RuntimeError:
+            pass
+        if getattr(pipe, "compute_cov3D_python", False):
+            raise NotImplementedError("compute_cov3D_python: the tracer takes scales / rotations")
+        scales, rotations = pcd.get_scaling.contiguous(), pcd.get_rotation.contiguous()
+        shs = colors_precomp = None
+        if override_color is None or (getattr(pcd, "render_reflection", False) and getattr(pcd, "feature_splatting", False)):
+            if getattr(pipe, "convert_SHs_python", False):
+                shs_view = pcd.get_features.transpose(1, 2).view(-1, 3, (pcd.max_sh_degree + 1) ** 2)
+                dirs = pcd.get_xyz - camera.camera_center.reshape(1, 3)
+                colors_precomp = torch.clamp_min(eval_sh(pcd.active_sh_degree, shs_view, dirs / dirs.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+            else:
+                shs = pcd.get_features.contiguous()
+        else:
+            colors_precomp = override_color.contiguous()
+        others = torch.full((means3D.shape[0], 2), 0.01, device=means3D.device)          # the reference's placeholder (:173-177)
+        rgb, dpt, acc, norm, dist, aux, mid, wet = self.tracer(
+            ray_o.contiguous(), ray_d.contiguous(), v, means3D=means3D, grads3D=grads3D, shs=shs, colors_precomp=colors_precomp,
+            others_precomp=others, opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None, tracer_settings=settings,
+            start_from_first=start_from_first)
+        with torch.no_grad():
+            visibility_filter = wet[..., 0] > 0.0
+            if start_from_first:                                                             # + what projects into the image (:203-211)
+                # the reference writes K (R m + T) with Camera.R / Camera.T; the same projection through the camera's own
+                # world-to-view matrix (row-vector convention of scene/cameras.py), which does not depend on how R is stored
+                _, _, K = camera.HWK
+                K = torch.as_tensor(K, dtype=torch.float32, device=means3D.device)
+                Wv = camera.world_view_transform.to(means3D.device).float()
+                cam = means3D.detach() @ Wv[:3, :3] + Wv[3, :3]
+                uvd = cam @ K.T
+                uv = uvd[..., :2] / uvd[..., 2:]
+                vis = (uvd[..., 2] >= 0.2) & (uv[..., 0] >= 0.0) & (uv[..., 0] <= camera.image_width) & (uv[..., 1] >= 0.0) & (uv[..., 1] <= camera.image_height)
+                visibility_filter = visibility_filter | vis
+        chw = lambda x: x.permute(2, 0, 1)
+        out = {"viewspace_points": grads3D, "visibility_filter": visibility_filter.detach().clone(), "weight_accumulate": wet,
+               "render": chw(rgb), "rend_alpha": chw(acc), "rend_normal": chw(norm), "rend_dist": chw(dist), "surf_depth": chw(dpt)}
+        if start_from_first:
+            out["surf_normal"] = chw(_depth_to_normal(camera, dpt[..., 0]) * acc.detach())
+        else:
+            out["surf_normal"] = torch.zeros_like(chw(norm))
+        out["specular"] = chw(aux[..., :1])
+        out["roughness"] = chw(aux[..., 1:2])
+        return out
+
+    def forward(self, *args, **kwargs):
+        return self.render_gaussians(*args, **kwargs)

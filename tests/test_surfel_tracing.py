@@ -1,0 +1,312 @@
+"""Surfel ray tracer (second half; reference call site gaussian_renderer/optix_utils.py:36-271).
+
+CPU: the dense oracle against closed forms (one surfel, two layers, quad extent = get_disks' corners, termination, ordering), the
+host mirror's shapes.  GPU (-m gpu): the HIP tracer -- hierarchy built on the device -- against the dense oracle: outputs, per-surfel
+weights, and every gradient against the oracle's autograd in float64.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import surfel_trace_oracle as sto  # noqa: E402
+from materialrefgs_amd.synthetic import make_shell_scene  # noqa: E402
+
+
+def one_surfel(dtype=torch.float64, scale=(0.2, 0.1), opacity=0.8, mean=(0.0, 0.0, 2.0)):
+    return dict(means=torch.tensor([mean], dtype=dtype), scales=torch.tensor([scale], dtype=dtype),
+                rotations=torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=dtype), opacities=torch.tensor([[opacity]], dtype=dtype),
+                colors=torch.tensor([[0.9, 0.5, 0.1]], dtype=dtype), others=torch.tensor([[0.3, 0.7]], dtype=dtype))
+
+
+BG = torch.tensor([0.2, 0.3, 0.4], dtype=torch.float64)
+
+
+def test_one_surfel_closed_form():
+    """A surfel in the plane z = 2 with axes x, y; rays from the origin.  Direction (x, y, 1) hits at t = 2 (the ray parameter, not
+    the distance), local coordinates (2x / s_u, 2y / s_v)."""
+    s = one_surfel()
+    d = torch.tensor([[0.0, 0.0, 1.0], [0.05, 0.02, 1.0], [0.0, 0.0, 2.0], [0.0, 0.0, -1.0]], dtype=torch.float64)
+    o = torch.zeros_like(d)
+    out = sto.trace_dense(o, d, bg=BG, **s)
+    a0 = 0.8
+    u, v = 2 * 0.05 / 0.2, 2 * 0.02 / 0.1
+    a1 = 0.8 * math.exp(-0.5 * (u * u + v * v))
+    assert torch.allclose(out["acc"], torch.tensor([a0, a1, a0, 0.0], dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(out["dpt"], torch.tensor([2 * a0, 2 * a1, 1 * a0, 0.0], dtype=torch.float64), atol=1e-12)     # d = (0,0,2): t = 1
+    assert torch.allclose(out["rgb"][0], a0 * s["colors"][0] + (1 - a0) * BG, atol=1e-12)
+    assert torch.allclose(out["rgb"][3], BG, atol=0)                                                                     # behind the origin
+    assert torch.allclose(out["aux"][1], a1 * s["others"][0], atol=1e-12)
+    # the normal is turned against the ray: the surfel's +z normal seen from below gives -z
+    assert torch.allclose(out["norm"][0], torch.tensor([0.0, 0.0, -a0], dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(out["dist"], torch.zeros(4, dtype=torch.float64), atol=1e-15)
+    assert torch.allclose(out["wet"], torch.tensor([a0 + a1 + a0], dtype=torch.float64), atol=1e-12)
+
+
+def test_quad_extent_is_the_three_sigma_square_of_get_disks():
+    """optix_utils.py:44: corners at +-3 in the splat's (u, v).  Inside the square the hit counts (alpha permitting), outside not."""
+    s = one_surfel(opacity=1.0)
+    v = sto.quad_vertices(s["means"], s["scales"], s["rotations"])
+    assert torch.allclose(v[0], torch.tensor([[-0.6, 0.3, 2.0], [-0.6, -0.3, 2.0], [0.6, 0.3, 2.0], [0.6, -0.3, 2.0]], dtype=torch.float64))
+    # u = 2.9 -> alpha = exp(-4.205) = 0.0149 > 1/255; u = 3.1 outside the quad although exp(-4.805) = 0.0082 > 1/255
+    d = torch.tensor([[0.5 * 2.9 * 0.2, 0.0, 1.0], [0.5 * 3.1 * 0.2, 0.0, 1.0], [0.0, 0.5 * 3.1 * 0.1, 1.0]], dtype=torch.float64)
+    out = sto.trace_dense(torch.zeros_like(d), d, bg=BG, **s)
+    assert out["hits"].tolist() == [1, 0, 0]
+    assert abs(float(out["acc"][0]) - math.exp(-0.5 * 2.9 ** 2)) < 1e-12
+
+
+def test_two_layers_order_distortion_and_termination():
+    dt = torch.float64
+    mk = lambda z, o: (torch.tensor([0.0, 0.0, z], dtype=dt), o)
+    layers = [mk(3.0, 0.6), mk(2.0, 0.5)]                      # given far first: the order must come from t
+    s = dict(means=torch.stack([l[0] for l in layers]), scales=torch.full((2, 2), 0.5, dtype=dt),
+             rotations=torch.tensor([[1.0, 0, 0, 0]] * 2, dtype=dt), opacities=torch.tensor([[l[1]] for l in layers], dtype=dt),
+             colors=torch.tensor([[1.0, 0, 0], [0, 1.0, 0]], dtype=dt), others=torch.zeros(2, 2, dtype=dt))
+    d = torch.tensor([[0.0, 0.0, 1.0]], dtype=dt)
+    out = sto.trace_dense(torch.zeros_like(d), d, bg=BG, **s)
+    w_near, w_far = 0.5, 0.5 * 0.6
+    assert torch.allclose(out["rgb"][0], torch.tensor([w_far, w_near, 0.0], dtype=dt) + 0.5 * 0.4 * BG, atol=1e-12)
+    assert abs(float(out["dpt"][0]) - (2 * w_near + 3 * w_far)) < 1e-12
+    assert abs(float(out["dist"][0]) - w_near * w_far * 1.0) < 1e-12            # w1 w2 (t1 - t2)^2
+    assert torch.allclose(out["wet"], torch.tensor([w_far, w_near], dtype=dt), atol=1e-12)
+    # termination (the rasterizer's rule, forward.cu:395-399): alphas 0.99, 0.9, 0.99, 0.99 -> T = 0.01, 0.001, and the third hit would
+    # give 1e-5 < 1e-4: it is not blended and nothing behind it either
+    s3 = dict(means=torch.tensor([[0, 0, 1.0 + k] for k in range(4)], dtype=dt), scales=torch.full((4, 2), 0.5, dtype=dt),
+              rotations=torch.tensor([[1.0, 0, 0, 0]] * 4, dtype=dt), opacities=torch.tensor([[1.0], [0.9], [1.0], [1.0]], dtype=dt),
+              colors=torch.ones(4, 3, dtype=dt), others=torch.zeros(4, 2, dtype=dt))
+    out = sto.trace_dense(torch.zeros_like(d), d, bg=BG, **s3)
+    assert int(out["hits"][0]) == 2 and abs(float(out["T"][0]) - 0.001) < 1e-15
+    assert torch.allclose(out["wet"], torch.tensor([0.99, 0.009, 0.0, 0.0], dtype=dt), atol=1e-15)
+    # equal depths: index order
+    s2 = dict(s)
+    s2["means"] = torch.tensor([[0, 0, 2.0], [0, 0, 2.0]], dtype=dt)
+    out = sto.trace_dense(torch.zeros_like(d), d, bg=BG, **s2)
+    assert torch.allclose(out["wet"], torch.tensor([0.6, 0.4 * 0.5], dtype=dt), atol=1e-12)
+
+
+def test_distortion_equals_the_pairwise_form_and_autograd_runs():
+    torch.manual_seed(0)
+    sc = make_shell_scene(60, seed=3, radius_px=60.0, image_size=200)
+    f = lambda t: t.double().requires_grad_(True)
+    means, scales, rots, opac = f(sc.means3D), f(sc.scales), f(sc.rotations), f(sc.opacities)
+    colors, others = f(torch.rand(60, 3)), f(torch.rand(60, 2))
+    o = torch.tensor([[0.0, 0.0, 0.0]], dtype=torch.float64).repeat(64, 1)
+    d = torch.nn.functional.normalize(torch.randn(64, 3, dtype=torch.float64), dim=1) * 1.7
+    out = sto.trace_dense(o, d, means, scales, rots, opac, colors, others, BG)
+    assert int(out["hits"].max()) >= 2
+    # A M2 - M1^2 with the sums taken over the blended hits
+    t = sto.brute_force_hits(o, d, means, scales, rots, opac)
+    assert torch.isfinite(t).sum() >= int(out["hits"].sum())
+    loss = out["rgb"].sum() + out["dist"].sum() + (out["norm"] ** 2).sum() + out["dpt"].sum()
+    loss.backward()
+    assert all(torch.isfinite(x.grad).all() for x in (means, scales, rots, opac, colors))
+
+
+def test_host_mirror_shapes_without_a_gpu():
+    from materialrefgs_amd.surfel_tracing import SurfelTracer, SurfelTracingSettings, surfel_records, MID_CHANNELS
+    import diff_surfel_tracing
+    assert diff_surfel_tracing.SurfelTracer is SurfelTracer and diff_surfel_tracing.SurfelTracingSettings is SurfelTracingSettings
+    sc = make_shell_scene(10, seed=1)
+    geom, attr = surfel_records(sc.means3D, sc.scales, sc.rotations, sc.opacities, torch.rand(10, 3), torch.rand(10, 2))
+    assert geom.shape == (10, 16) and attr.shape == (10, 8) and MID_CHANNELS == 16
+    R = sto.rotation_matrix(sc.rotations)
+    assert torch.allclose(geom[:, 9:12], R[:, :, 2], atol=1e-6) and torch.allclose(geom[:, 3:6] * sc.scales[:, 0:1], R[:, :, 0], atol=1e-5)
+    with pytest.raises(RuntimeError):
+        SurfelTracer().build_acceleration_structure(torch.zeros(8, 3), None)          # no CPU path
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------------
+
+def _scene(P, seed, radius_px=40.0):
+    sc = make_shell_scene(P, seed=seed, radius_px=radius_px, image_size=400)
+    g = torch.Generator().manual_seed(seed)
+    return sc, torch.rand(P, 3, generator=g), torch.rand(P, 2, generator=g)
+
+
+def _rays(n, seed, inside=True):
+    g = torch.Generator().manual_seed(100 + seed)
+    if inside:      # from points inside the shell outwards: every ray crosses the shell once
+        o = torch.randn(n, 3, generator=g) * 0.2
+    else:           # from outside through the whole shell: two crossings, many layers
+        o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1) * 3.0
+    tgt = torch.randn(n, 3, generator=g) * 0.3
+    d = (tgt - o) if not inside else torch.randn(n, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True) * (0.5 + torch.rand(n, 1, generator=g))       # not normalised on purpose
+    return o, d
+
+
+def _hip_trace(dev, sc, colors, others, o, d, bg, need_grad=False, scale_modifier=1.0):
+    from materialrefgs_amd.surfel_tracing import SurfelTracer, SurfelTracingSettings
+    leaf = lambda t: t.to(dev).clone().requires_grad_(need_grad)
+    L = dict(means=leaf(sc.means3D), scales=leaf(sc.scales), rotations=leaf(sc.rotations), opacities=leaf(sc.opacities), colors=leaf(colors),
+             others=leaf(others), o=leaf(o), d=leaf(d))
+    tr = SurfelTracer()
+    v = sto.quad_vertices(L["means"].detach(), L["scales"].detach(), L["rotations"].detach(), scale_modifier).reshape(-1, 3)
+    tr.build_acceleration_structure(v, None)
+    eye = torch.eye(4, device=dev)
+    ts = SurfelTracingSettings(1, o.shape[0], 1.0, 1.0, bg.to(dev).float(), scale_modifier, eye, eye, 0, torch.zeros(3, device=dev), False, False)
+    rgb, dpt, acc, norm, dist, aux, mid, wet = tr(L["o"], L["d"], v, means3D=L["means"], grads3D=None, shs=None, colors_precomp=L["colors"],
+                                                   others_precomp=L["others"], opacities=L["opacities"], scales=L["scales"],
+                                                   rotations=L["rotations"], cov3D_precomp=None, tracer_settings=ts)
+    return dict(rgb=rgb, dpt=dpt[..., 0], acc=acc[..., 0], norm=norm, dist=dist[..., 0], aux=aux, wet=wet[:, 0], mid=mid), L
+
+
+def _oracle(sc, colors, others, o, d, bg, dtype, need_grad=False, scale_modifier=1.0):
+    leaf = lambda t: t.to(dtype).clone().requires_grad_(need_grad)
+    L = dict(means=leaf(sc.means3D), scales=leaf(sc.scales), rotations=leaf(sc.rotations), opacities=leaf(sc.opacities), colors=leaf(colors),
+             others=leaf(others), o=leaf(o), d=leaf(d))
+    out = sto.trace_dense(L["o"], L["d"], L["means"], L["scales"], L["rotations"], L["opacities"], L["colors"], L["others"], bg.to(dtype),
+                          scale_modifier)
+    return out, L
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,n,inside,radius", [(1, 64, True, 400.0), (3, 256, True, 300.0), (5, 256, False, 200.0), (900, 2048, True, 40.0),
+                                               (4000, 4096, False, 30.0), (20000, 4096, False, 12.0)])
+def test_hip_tracer_matches_the_dense_oracle(gpu_device, P, n, inside, radius):
+    sc, colors, others = _scene(P, P, radius)
+    o, d = _rays(n, P, inside)
+    bg = torch.tensor([0.1, 0.5, 0.9])
+    hip, _ = _hip_trace(gpu_device, sc, colors, others, o, d, bg)
+    ref, _ = _oracle(sc, colors, others, o, d, bg, torch.float64)
+    # a ray whose fp32 decision at a threshold (quad edge, 1/255, T < 1e-4) differs from float64 may gain / lose one hit: allowed
+    # for a handful of rays, everything else agrees to fp32 rounding
+    bad = torch.zeros(n, dtype=torch.bool)
+    for k in ("rgb", "dpt", "acc", "norm", "dist", "aux"):
+        a, b = hip[k].cpu().double(), ref[k]
+        err = (a - b).abs().reshape(n, -1).max(dim=1).values
+        bad |= err > 2e-4 * max(1.0, float(b.abs().max()))
+    assert int(bad.sum()) <= max(1, n // 500), (int(bad.sum()), n)
+    assert float(ref["acc"].max()) > 0.5 or P < 10                      # the scene is actually hit
+    ok = ~bad
+    assert float((hip["acc"].cpu().double() - ref["acc"])[ok].abs().max()) < 2e-5
+    wet_err = (hip["wet"].cpu().double() - ref["wet"]).abs()
+    assert float(wet_err.max()) <= 1e-4 * max(1.0, float(ref["wet"].max())) + 1.0 * int(bad.sum())
+    assert hip["mid"].shape == (n, 16)
+
+
+@pytest.mark.gpu
+def test_hip_tracer_many_layers_need_several_passes(gpu_device):
+    """60 faint coplanar-stacked layers in front of every ray: more hits than one 16-entry pass holds, in scrambled index order."""
+    P, n = 60, 512
+    g = torch.Generator().manual_seed(5)
+    z = 1.0 + torch.randperm(P, generator=g).float() * 0.05
+    sc_means = torch.stack([torch.zeros(P), torch.zeros(P), z], dim=1)
+    from types import SimpleNamespace
+    sc = SimpleNamespace(means3D=sc_means, scales=torch.full((P, 2), 2.0), rotations=torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1),
+                         opacities=torch.full((P, 1), 0.05))
+    colors, others = torch.rand(P, 3, generator=g), torch.rand(P, 2, generator=g)
+    o = torch.zeros(n, 3)
+    d = torch.cat([torch.randn(n, 2, generator=g) * 0.3, torch.ones(n, 1)], dim=1)
+    bg = torch.zeros(3)
+    hip, _ = _hip_trace(gpu_device, sc, colors, others, o, d, bg)
+    ref, _ = _oracle(sc, colors, others, o, d, bg, torch.float64)
+    assert int(ref["hits"].max()) > 48
+    for k in ("rgb", "dpt", "acc", "norm", "dist", "aux"):
+        assert float((hip[k].cpu().double() - ref[k]).abs().max()) < 2e-5 * max(1.0, float(ref[k].abs().max())), k
+    assert float((hip["wet"].cpu().double() - ref["wet"]).abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,n,inside,radius", [(3, 128, True, 300.0), (600, 1024, True, 40.0), (3000, 1024, False, 30.0)])
+def test_hip_tracer_gradients_match_autograd_of_the_oracle(gpu_device, P, n, inside, radius):
+    sc, colors, others = _scene(P, 7 + P, radius)
+    o, d = _rays(n, 7 + P, inside)
+    bg = torch.tensor([0.3, 0.2, 0.6])
+    g = torch.Generator().manual_seed(11)
+    up = dict(rgb=torch.randn(n, 3, generator=g), dpt=torch.randn(n, generator=g), acc=torch.randn(n, generator=g),
+              norm=torch.randn(n, 3, generator=g), dist=torch.randn(n, generator=g), aux=torch.randn(n, 2, generator=g))
+    hip, Lh = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
+    ref, Lr = _oracle(sc, colors, others, o, d, bg, torch.float64, need_grad=True)
+    # rays on which the two disagree about a threshold are taken out of BOTH losses
+    same = torch.ones(n, dtype=torch.bool)
+    for k in up:
+        err = (hip[k].detach().cpu().double() - ref[k].detach()).abs().reshape(n, -1).max(dim=1).values
+        same &= err <= 2e-4 * max(1.0, float(ref[k].abs().max()))
+    assert int((~same).sum()) <= max(1, n // 200)
+    m = same.double()
+    loss_h = sum((hip[k] * (up[k] * m.float().reshape(n, *([1] * (up[k].dim() - 1)))).to(gpu_device)).sum() for k in up)
+    loss_r = sum((ref[k] * (up[k].double() * m.reshape(n, *([1] * (up[k].dim() - 1))))).sum() for k in up)
+    loss_h.backward()
+    loss_r.backward()
+    for k in ("means", "scales", "rotations", "opacities", "colors", "others", "o", "d"):
+        a, b = Lh[k].grad.cpu().double(), Lr[k].grad
+        scale = max(float(b.abs().max()), 1e-12)
+        assert float((a - b).abs().max()) <= 3e-4 * scale, (k, float((a - b).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+def test_hardware_rendering_mirror(gpu_device):
+    """render_gaussians of the HardwareRendering mirror: dictionary keys and shapes of optix_utils.py:218-233 on a small scene."""
+    from types import SimpleNamespace
+    from materialrefgs_amd.surfel_tracing import HardwareRendering
+    from materialrefgs_amd.renderer import SurfelModel
+    from materialrefgs_amd.synthetic import orbit_camera
+    dev = gpu_device
+    sc = make_shell_scene(2000, seed=2, radius_px=25.0, image_size=64).to(dev)
+    pc = SurfelModel(sc.means3D.clone().requires_grad_(True), torch.log(sc.scales), sc.rotations, torch.logit(sc.opacities),
+                     sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous())
+    H = W = 64
+    cam = orbit_camera(0, H, W).to(dev)
+    hr = HardwareRendering().train()
+    g = torch.Generator().manual_seed(3)
+    ray_o = (torch.randn(H, W, 3, generator=g) * 0.1).to(dev)
+    ray_d = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1).to(dev)
+    out = hr.render_gaussians(cam, ray_o, ray_d, pc, SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False),
+                              torch.zeros(3, device=dev))
+    for k, c in (("render", 3), ("rend_alpha", 1), ("rend_normal", 3), ("rend_dist", 1), ("surf_depth", 1), ("surf_normal", 3), ("specular", 1),
+                 ("roughness", 1)):
+        assert out[k].shape == (c, H, W), k
+    assert out["weight_accumulate"].shape == (2000, 1) and out["visibility_filter"].shape == (2000,)
+    assert float(out["rend_alpha"].mean()) > 0.3
+    # every surfel carries others = 0.01 (optix_utils.py:173-177): specular = 0.01 * alpha
+    assert torch.allclose(out["specular"], 0.01 * out["rend_alpha"], atol=1e-6)
+    out["render"].sum().backward()
+    assert out["viewspace_points"].grad is not None and torch.allclose(out["viewspace_points"].grad, pc._xyz.grad)
+
+
+@pytest.mark.gpu
+def test_render_surfel_with_envgs_composes_raster_and_traced_light(gpu_device):
+    """gaussian_renderer/__init__.py:486-520: the traced dictionary is what the dense oracle gives for the mirror rays of the rendered
+    view, the final image is the documented blend, and the gradient reaches the model through both paths."""
+    from types import SimpleNamespace
+    from test_render_e2e import _models
+    from materialrefgs_amd import renderer
+    from materialrefgs_amd.surfel_tracing import HardwareRendering
+    from materialrefgs_amd.synthetic import orbit_camera
+    dev = gpu_device
+    P, H, W = 1500, 40, 56
+    _, _, pc, env = _models(P, H, W, seed=4, dev=dev)
+    cam = orbit_camera(2, H, W).to(dev)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    opt = SimpleNamespace(indirect=False)
+    hr = HardwareRendering().train()
+    out = renderer.render_surfel_with_envgs(hr, cam, pc, pipe, bg, srgb=False, opt=opt)
+    base = renderer.render_surfel(cam, pc, pipe, bg, srgb=False, opt=opt)
+    tr = out["indirect_out"]
+    spec = tr["specular"]
+    assert torch.allclose(out["render"], base["render"] * (1 - spec) + spec * tr["render"], atol=1e-6)
+    # the traced part against the dense oracle on the same rays
+    alpha = base["rend_alpha"].permute(1, 2, 0)
+    nmap = renderer.safe_normalize(base["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))
+    ro, rd = renderer._mirror_rays(cam, nmap, base["surf_depth"])
+    dirs = pc.get_xyz - cam.camera_center.reshape(1, 3)
+    from materialrefgs_amd.gs_utils import eval_sh
+    colors = torch.clamp_min(eval_sh(pc.active_sh_degree, pc.get_features.transpose(1, 2), dirs / dirs.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+    f = lambda t: t.detach().cpu().double()
+    ref = sto.trace_dense(f(ro).reshape(-1, 3), f(rd).reshape(-1, 3), f(pc.get_xyz), f(pc.get_scaling), f(pc.get_rotation), f(pc.get_opacity),
+                          f(colors), torch.full((P, 2), 0.01, dtype=torch.float64), f(bg))
+    err = (f(tr["render"]).permute(1, 2, 0).reshape(-1, 3) - ref["rgb"]).abs().max(dim=1).values
+    assert int((err > 2e-4).sum()) <= 3 and float(ref["acc"].mean()) > 0.05
+    same = renderer.render_indirect(hr, cam, pc, pipe, bg, normal_map=nmap, surf_depth=base["surf_depth"])
+    assert torch.allclose(same["render"], tr["render"], atol=1e-6)
+    out["render"].sum().backward()
+    assert pc._xyz.grad is not None and float(pc._xyz.grad.abs().sum()) > 0
+    assert tr["viewspace_points"].grad is not None and float(tr["viewspace_points"].grad.abs().sum()) > 0
