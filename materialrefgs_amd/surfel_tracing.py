@@ -166,7 +166,7 @@ class SurfelTracer(nn.Module):
         o = ray_o.reshape(-1, 3).contiguous().float()
         d = ray_d.reshape(-1, 3).contiguous().float()
         bg3 = tuple(float(x) for x in ts.bg.detach().reshape(-1)[:3].tolist())
-        rgb, dpt, acc, norm, dist, aux, wet, _state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
+        rgb, dpt, acc, norm, dist, aux, wet, self.last_state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
         r = lambda x, c: x.reshape(*shape, c)
         rgb, dpt, acc, norm, dist, aux = r(rgb, 3), r(dpt, 1), r(acc, 1), r(norm, 3), r(dist, 1), r(aux, 2)
         # stage 0 of the per-depth record (optix_utils.py:28-35); deeper stages do not exist at max_trace_depth = 0

@@ -84,6 +84,10 @@ def main():
     from materialrefgs_amd.surfel_tracing import _Trace  # noqa: F401
     res.update(P=P, rays=int(ro.shape[0] * ro.shape[1]), rays_with_direction=int((rd.abs().sum(-1) > 0).sum()), mode=mode,
                mean_alpha=float(out[2].mean()), surfels_touched=int((wet > 0).sum()))
+    st = tr.last_state
+    live = st[:, 3] != 0
+    res.update(rays_in_packets=int((st[:, 3] < 0).sum()), mean_passes=float(st[:, 3].abs()[live].mean()), mean_hits=float(st[:, 2][live].mean()),
+               max_hits=int(st[:, 2].max()))
     res["Mrays_per_s_forward"] = res["rays"] / res["forward_ms"] / 1e3
     print(json.dumps(res))
 
