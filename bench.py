@@ -41,6 +41,9 @@ WORKLOADS = {
     # same P / image as C2 with the pair count the survey assumed (R ~ 6 P instead of 3.8 P) and heavy-tailed splat sizes (log-normal
     # sigma 0.8 instead of 0.35: splats from sub-pixel to ~450 px); reported as the secondary line of the default run
     "C2heavy": (300000, 800, 800, 0, "C2heavy shell scene: P=300000 surfels, 800x800, SH deg 3, S=0, log-normal splat sizes sigma 0.8, R ~ 6 P, fwd+bwd"),
+    # the last training stage of the reference (train_refnerf.py:1501-1504): render_surfel, then the same surfels traced along every pixel's
+    # mirror ray (HardwareRendering, gaussian_renderer/__init__.py:486-520) and blended in; hierarchy rebuilt every view as in training
+    "C3trace": (300000, 800, 800, 8, "C3 shell scene through render_surfel_with_envgs: render_surfel + surfel-traced mirror rays of all 800x800 pixels (hierarchy rebuilt per view), fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
 }
 SCENE_KW = {"C2heavy": dict(radius_px=6.5, scale_sigma=0.8)}
@@ -172,7 +175,8 @@ def main():
             debug=False))
     g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
 
-    surfel_mode = args.workload in ("C3full", "C3train", "C4full")
+    surfel_mode = args.workload in ("C3full", "C3train", "C4full", "C3trace")
+    traced = args.workload == "C3trace"
     use_loss = args.workload in ("C3train", "C4full")
     indirect = args.workload == "C4full"
     if surfel_mode:
@@ -192,8 +196,12 @@ def main():
         surfel_params = pc.parameters() + [env.base]
         for t_ in surfel_params:
             t_.requires_grad_(True)
-        pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+        pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False)
         bg_color = torch.zeros(3, device=dev)
+        if traced:
+            from materialrefgs_amd.renderer import render_surfel_with_envgs
+            from materialrefgs_amd.surfel_tracing import HardwareRendering
+            hw_tracer = HardwareRendering().train()
         cams_dev = [c.to(dev) for c in cams]
         if indirect:
             from materialrefgs_amd.raytracing import RayTracer
@@ -241,7 +249,10 @@ def main():
         for t_ in surfel_params:
             t_.grad = None
         env.build_mips()                                       # every iteration in the reference (train_refnerf.py:1157-1163)
-        out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect))
+        if traced:
+            out = render_surfel_with_envgs(hw_tracer, cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
+        else:
+            out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect))
         state["R"] = rasterizer_mod.LAST_NUM_RENDERED
         if use_loss:
             loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)

@@ -316,6 +316,8 @@ struct StArgs {
     int32_t ray_width;                    // > 0: rays form rows of this length and a wave takes an 8x8 block of them
     int32_t packets;                      // waves whose rays run together walk the wide hierarchy as one (st_gather_wide)
     StWide wide;
+    uint32_t* lone_list;                  // [0] count, [16..] indices of the rays that walk alone (behind the per-ray state)
+    float cone;                           // 1 - cos of the half-angle within which a packet's directions must stay
     const float4* attr;                   // [P][2]: (rgb, others.x) (others.y, -, -, -)
     float bg[3];
     float *rgb, *dpt, *acc, *norm, *dist, *aux, *wet, *state;     // state [n_rays][4]: M2, T_final, hits blended, passes
@@ -715,9 +717,9 @@ __device__ __forceinline__ int st_gather_wide(const StWide& W, const float* __re
     return n;
 }
 
-// Rays "run together" when their directions stay within a cone of ~25 degrees about their mean and their origins within 2 % of the
+// Rays "run together" when their directions stay within a cone of ~11 degrees about their mean (1 - cos <= 0.02: wider beams of grazing rays sweep thousands of surfels -- measured 16 -> 9.5 ms on mirror rays off a rendered view) and their origins within 2 % of the
 // scene's extent of their centre.  `on` selects the rays asked about; the answer is wave-uniform.
-__device__ __forceinline__ bool st_run_together(float extent, bool on, float ox, float oy, float oz, float dx, float dy, float dz)
+__device__ __forceinline__ bool st_run_together(float extent, float cone, bool on, float ox, float oy, float oz, float dx, float dy, float dz)
 {
     const float cnt = wave_sum_f(on ? 1.0f : 0.0f);
     if (cnt < 1.0f) return false;
@@ -730,7 +732,7 @@ __device__ __forceinline__ bool st_run_together(float extent, bool on, float ox,
     const float worst = wave_max_f(on ? 1.0f - (ux * mx + uy * my + uz * mz) : 0.0f);
     const float cx = wave_sum_f(on ? ox : 0.0f) / cnt, cy = wave_sum_f(on ? oy : 0.0f) / cnt, cz = wave_sum_f(on ? oz : 0.0f) / cnt;
     const float spread = wave_max_f(on ? fmaxf(fabsf(ox - cx), fmaxf(fabsf(oy - cy), fabsf(oz - cz))) : 0.0f);
-    return worst <= 0.1f && spread <= 0.02f * extent;
+    return worst <= cone && spread <= 0.02f * extent;
 }
 
 // Packet of every lane: 0 = the whole wave, 1..4 = its quadrant (4x4 rays of the 8x8 block, or 16 consecutive rays), 5..20 = its
@@ -749,7 +751,7 @@ __device__ __forceinline__ int st_assign_packets(const StArgs& A, const int32_t*
             if (root->child[c] != ST_EMPTY) { lo = fminf(lo, root->lo[k][c]); hi = fmaxf(hi, root->hi[k][c]); }
         extent = fmaxf(extent, hi - lo);
     }
-    if (st_run_together(extent, on, ox, oy, oz, dx, dy, dz)) { present = 1u; return 0; }
+    if (st_run_together(extent, A.cone, on, ox, oy, oz, dx, dy, dz)) { present = 1u; return 0; }
     const bool tiled = A.ray_width > 0;
     const int quad = tiled ? ((lane >> 2) & 1) + 2 * (lane >> 5) : lane >> 4;
     const int sub = tiled ? ((lane >> 1) & 1) + 2 * ((lane >> 4) & 1) : (lane >> 2) & 3;
@@ -757,7 +759,7 @@ __device__ __forceinline__ int st_assign_packets(const StArgs& A, const int32_t*
     for (int q = 0; q < 4; ++q) {
         const bool in_q = on && quad == q;
         if (__ballot(in_q) == 0) continue;
-        if (st_run_together(extent, in_q, ox, oy, oz, dx, dy, dz)) {
+        if (st_run_together(extent, A.cone, in_q, ox, oy, oz, dx, dy, dz)) {
             if (in_q) mine = 1 + q;
             present |= 1u << (1 + q);
             continue;
@@ -765,7 +767,7 @@ __device__ __forceinline__ int st_assign_packets(const StArgs& A, const int32_t*
         for (int g = 0; g < 4; ++g) {
             const bool in_g = in_q && sub == g;
             if (__ballot(in_g) == 0) continue;
-            if (st_run_together(extent, in_g, ox, oy, oz, dx, dy, dz)) {
+            if (st_run_together(extent, A.cone, in_g, ox, oy, oz, dx, dy, dz)) {
                 if (in_g) mine = 5 + 4 * q + g;
                 present |= 1u << (5 + 4 * q + g);
             }
@@ -841,7 +843,19 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
                   fabsf(dz) < 1e30f && (dx != 0.0f || dy != 0.0f || dz != 0.0f));
     uint32_t packets_present;
     const int packet = st_assign_packets(A, lv_off, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
-    bool want = !done;
+    // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
+    const bool lone = A.packets == 1 && !done && packet < 0;
+    if (!BWD) {
+        const unsigned long long lm = __ballot(lone);
+        if (lm) {
+            const int first = __builtin_ctzll(lm), lane = tid & 63;
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(A.lone_list, (uint32_t)__popcll(lm));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+            if (lone) A.lone_list[16 + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        }
+    }
+    bool want = !done && !lone;
     StProf prof = {0, 0, 0};
     for (int pass = 0; pass < ST_MAX_PASSES; ++pass) {
         if (__ballot(want) == 0) break;
@@ -912,7 +926,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
         prev_t = kb_t[ST_K - 1][tid];
         prev_id = kb_id[ST_K - 1][tid];
     }
-    if (!exists) return;
+    if (!exists || lone) return;
     if (!BWD) {
         A.rgb[3 * r] = C[0] + T * A.bg[0]; A.rgb[3 * r + 1] = C[1] + T * A.bg[1]; A.rgb[3 * r + 2] = C[2] + T * A.bg[2];
         A.dpt[r] = D; A.acc[r] = Aw; A.dist[r] = dist;
@@ -925,6 +939,236 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     } else {
         A.g_ray_o[3 * r] = go[0]; A.g_ray_o[3 * r + 1] = go[1]; A.g_ray_o[3 * r + 2] = go[2];
         A.g_ray_d[3 * r] = gdir[0]; A.g_ray_d[3 * r + 1] = gdir[1]; A.g_ray_d[3 * r + 2] = gdir[2];
+    }
+}
+
+
+// ---- rays that run with nobody: one WAVE per ray --------------------------------------------------------------------------------
+// A ray whose 2x2 neighbours point elsewhere (silhouettes, normals of barely covered pixels) cannot share a walk.  Walking alone in
+// a lane is the slow way on this machine: every step is a dependent ~1 us gather and the wave lasts as long as its slowest lane
+// (measured: 4-10 ms for a wave of such lanes, the whole kernel's duration).  So the main kernel only LISTS these rays and this
+// kernel gives each of them a wave, with the parallelism turned sideways: the 64 lanes are the 64 children of a wide node, then the
+// 64 surfels of a leaf group -- each lane tests ITS surfel against the one ray.  The ray's 16 nearest hits live in lanes 0..15
+// (sorted); new hits are merged by rank (rank = entries in front of me, counted with one v_readlane sweep over the other side);
+// blending is lane-parallel too: transmittance and the running sums are 16-lane scans, the pixel sums wave reductions, every hit's
+// gradient is written by its own lane.
+__device__ __forceinline__ float scan16_mul_excl(float v, int lane)          // exclusive prefix product over lanes 0..15 (others: don't care)
+{
+    float inc = v;
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) { const float o = __shfl_up(inc, s); if (lane >= s) inc *= o; }
+    const float prev = __shfl_up(inc, 1);
+    return lane == 0 ? 1.0f : prev;
+}
+__device__ __forceinline__ float scan16_add_excl(float v, int lane)
+{
+    float inc = v;
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) { const float o = __shfl_up(inc, s); if (lane >= s) inc += o; }
+    const float prev = __shfl_up(inc, 1);
+    return lane == 0 ? 0.0f : prev;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(64) void st_trace_lone_kernel(StArgs A, const float4* __restrict__ leaf, const float* __restrict__ boxes,
+                                                           const unsigned long long* __restrict__ vmask, const uint32_t* __restrict__ lone_list)
+{
+    __shared__ unsigned long long slot[ST_K];
+    const int lane = threadIdx.x;
+    const uint32_t count = lone_list[0];
+    const StWide& W = A.wide;
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const int64_t r = lone_list[16 + item];
+        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        const float ivx = 1.0f / dx, ivy = 1.0f / dy, ivz = 1.0f / dz;
+        // running totals (uniform) and, for the backward, the forward's totals
+        float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, D = 0, Aw = 0, N0 = 0, N1 = 0, N2 = 0, X0 = 0, X1 = 0, dist = 0, M1 = 0, M2 = 0;
+        int blended = 0, passes = 0;
+        float gc0 = 0, gc1 = 0, gc2 = 0, gd = 0, ga = 0, gn0 = 0, gn1 = 0, gn2 = 0, gx0 = 0, gx1 = 0, gdist = 0;
+        float fA = 0, fM1 = 0, fM2 = 0, fT = 0, Qtot = 0, Qpre = 0, bgdot = 0;
+        float go0 = 0, go1 = 0, go2 = 0, gv0 = 0, gv1 = 0, gv2 = 0;         // per lane partial sums of the ray's own gradient
+        if (BWD) {
+            gc0 = A.g_rgb[3 * r]; gc1 = A.g_rgb[3 * r + 1]; gc2 = A.g_rgb[3 * r + 2];
+            gd = A.g_dpt[r]; ga = A.g_acc[r]; gdist = A.g_dist[r];
+            gn0 = A.g_norm[3 * r]; gn1 = A.g_norm[3 * r + 1]; gn2 = A.g_norm[3 * r + 2];
+            gx0 = A.g_aux[2 * r]; gx1 = A.g_aux[2 * r + 1];
+            fA = A.acc[r]; fM1 = A.dpt[r]; fM2 = A.state[4 * r]; fT = A.state[4 * r + 1];
+            bgdot = gc0 * A.bg[0] + gc1 * A.bg[1] + gc2 * A.bg[2];
+            Qtot = gc0 * (A.rgb[3 * r] - fT * A.bg[0]) + gc1 * (A.rgb[3 * r + 1] - fT * A.bg[1]) + gc2 * (A.rgb[3 * r + 2] - fT * A.bg[2])
+                 + gd * fM1 + ga * fA + gn0 * A.norm[3 * r] + gn1 * A.norm[3 * r + 1] + gn2 * A.norm[3 * r + 2]
+                 + gx0 * A.aux[2 * r] + gx1 * A.aux[2 * r + 1] + gdist * 2.0f * (fA * fM2 - fM1 * fM1);
+        }
+        unsigned long long prev_key = 0;
+        bool done = false;
+        for (int pass = 0; pass < ST_MAX_PASSES && !done; ++pass) {
+            // ---- gather: the ST_K smallest keys above prev_key, sorted, one per lane 0..ST_K-1 ----
+            unsigned long long mine = ~0ull;                                   // lanes >= nb hold "none"
+            int nb = 0;
+            float t_far = INFINITY;
+            unsigned long long mask[SW_MAX_LEVELS] = {0, 0, 0, 0};
+            int node[SW_MAX_LEVELS] = {0, 0, 0, 0};
+            float near1 = 0.f, near2 = 0.f, near3 = 0.f;
+            const float prev_t = __uint_as_float((uint32_t)(prev_key >> 32));
+            int l = W.n - 1;
+            bool fresh = true;
+            for (;;) {
+                if (fresh) {
+                    const int nd = W.off[l] + node[l];
+                    fresh = false;
+                    if (l > 0) {
+                        const float* bx = boxes + (size_t)nd * 384 + lane;
+                        const float ax = (bx[0] - ox) * ivx, bxx = (bx[192] - ox) * ivx, ay = (bx[64] - oy) * ivy, by = (bx[256] - oy) * ivy;
+                        const float az = (bx[128] - oz) * ivz, bz = (bx[320] - oz) * ivz;
+                        const float t_in = fmaxf(fmaxf(fminf(ax, bxx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                        const float t_out = fminf(fminf(fmaxf(ax, bxx), fmaxf(ay, by)), fmaxf(az, bz));
+                        const bool h = t_in <= t_out * 1.00001f + 1e-30f && t_in * 0.99999f <= t_far && t_out * 1.00001f + 1e-30f >= prev_t;
+                        mask[l] = __ballot(h) & vmask[nd];
+                        if (l == 1) near1 = t_in; else if (l == 2) near2 = t_in; else near3 = t_in;
+                    } else {
+                        // 64 surfels against the ray at once
+                        const float4* g = leaf + ((size_t)node[0] * 64 + lane) * 4;
+                        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                        const StHit h = st_hit(g0, g1, g2, g3.x, ox, oy, oz, dx, dy, dz);
+                        const unsigned long long cand = ((unsigned long long)__float_as_uint(h.t) << 32) | __float_as_uint(g3.y);
+                        const unsigned long long kth = readlane_u64(mine, ST_K - 1);
+                        const bool c_ok = ((vmask[nd] >> lane) & 1ull) && h.ok && (pass == 0 || cand > prev_key) && cand < kth;
+                        const unsigned long long cmask = __ballot(c_ok);
+                        if (cmask) {
+                            // new rank of every item: buffer entries keep their order, candidates slot in by key
+                            int rank_b = lane;                                 // for lanes < nb
+                            int rank_c = 0;
+                            for (unsigned long long m = cmask; m; m &= m - 1) {
+                                const unsigned long long k = readlane_u64(cand, __builtin_ctzll(m));
+                                rank_b += k < mine ? 1 : 0;
+                                rank_c += k < cand ? 1 : 0;
+                            }
+                            for (int j = 0; j < nb; ++j) rank_c += readlane_u64(mine, j) < cand ? 1 : 0;
+                            if (lane < ST_K) slot[lane] = ~0ull;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (lane < nb && rank_b < ST_K) slot[rank_b] = mine;
+                            if (c_ok && rank_c < ST_K) slot[rank_c] = cand;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            mine = lane < ST_K ? slot[lane] : ~0ull;
+                            nb = min(ST_K, nb + (int)__popcll(cmask));
+                            if (nb == ST_K) t_far = __uint_as_float((uint32_t)(readlane_u64(mine, ST_K - 1) >> 32)) * 1.00001f + 1e-30f;
+                        }
+                        mask[0] = 0;
+                    }
+                }
+                if (mask[l] == 0) {
+                    if (l == W.n - 1) break;
+                    ++l;
+                    continue;
+                }
+                const float my_near = l == 1 ? near1 : l == 2 ? near2 : near3;
+                const float key = ((mask[l] >> lane) & 1ull) ? my_near : INFINITY;
+                const float nearest = wave_min_f(key);
+                if (nearest * 0.99999f > t_far) { mask[l] = 0; continue; }
+                const int c = __builtin_ctzll(__ballot(key == nearest));
+                mask[l] &= ~(1ull << c);
+                node[l - 1] = node[l] * 64 + c;
+                --l;
+                fresh = true;
+            }
+            ++passes;
+            // ---- blend: hit j in lane j ----
+            const bool has = lane < nb;
+            const uint32_t id = (uint32_t)mine;
+            const float t = has ? __uint_as_float((uint32_t)(mine >> 32)) : 0.0f;      // "none" is all ones: a NaN as a float
+            float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, a0 = g0, a1 = g0;
+            float opacity = 0.f;
+            StHit h;
+            h.alpha = 0.f; h.den = 1.f; h.u = h.v = h.G = 0.f;
+            if (has) {
+                const float4* g = A.geom + (size_t)id * 4;
+                g0 = g[0]; g1 = g[1]; g2 = g[2]; opacity = g[3].x;
+                a0 = A.attr[(size_t)id * 2]; a1 = A.attr[(size_t)id * 2 + 1];
+                h = st_hit(g0, g1, g2, opacity, ox, oy, oz, dx, dy, dz);
+            }
+            const float alpha = has ? h.alpha : 0.0f;
+            const float Tj = T * scan16_mul_excl(1.0f - alpha, lane);          // transmittance in front of hit j
+            const unsigned long long stop = __ballot(has && Tj * (1.0f - alpha) < 0.0001f);
+            const int n_bl = stop ? min(nb, (int)__builtin_ctzll(stop)) : nb;
+            const bool bl = lane < n_bl;
+            const float w = bl ? alpha * Tj : 0.0f;
+            const float sgn = h.den > 0.0f ? -1.0f : 1.0f;
+            const float nfx = sgn * g2.y, nfy = sgn * g2.z, nfz = sgn * g2.w;
+            const float Ab = Aw + scan16_add_excl(w, lane), M1b = M1 + scan16_add_excl(w * t, lane), M2b = M2 + scan16_add_excl(w * t * t, lane);
+            if (!BWD) {
+                C0 += wave_sum_f(w * a0.x); C1 += wave_sum_f(w * a0.y); C2 += wave_sum_f(w * a0.z);
+                N0 += wave_sum_f(w * nfx); N1 += wave_sum_f(w * nfy); N2 += wave_sum_f(w * nfz);
+                X0 += wave_sum_f(w * a0.w); X1 += wave_sum_f(w * a1.x);
+                dist += wave_sum_f(w * (t * t * Ab + M2b - 2.0f * t * M1b));
+                if (bl) atomicAdd(A.wet + id, w);
+            } else {
+                const float q = gc0 * a0.x + gc1 * a0.y + gc2 * a0.z + gd * t + ga + gn0 * nfx + gn1 * nfy + gn2 * nfz + gx0 * a0.w + gx1 * a1.x
+                              + gdist * (t * t * fA - 2.0f * t * fM1 + fM2);
+                const float wq = w * q;
+                const float Qin = Qpre + scan16_add_excl(wq, lane) + wq;            // inclusive
+                if (bl) {
+                    const float inv1ma = 1.0f / (1.0f - alpha);
+                    const float dalpha = Tj * q - (Qtot - Qin) * inv1ma - fT * bgdot * inv1ma;
+                    const float dG = opacity * dalpha;
+                    const float du = -h.u * h.G * dG, dv = -h.v * h.G * dG;
+                    const float ax = g0.w, ay = g1.x, az = g1.y, bx = g1.z, by = g1.w, bz = g2.x, nx = g2.y, ny = g2.z, nz = g2.w;
+                    const float px = (ox + t * dx) - g0.x, py = (oy + t * dy) - g0.y, pz = (oz + t * dz) - g0.z;
+                    const float dpx = du * ax + dv * bx, dpy = du * ay + dv * by, dpz = du * az + dv * bz;
+                    const float dt = w * (gd + gdist * 2.0f * (t * fA - fM1)) + (dpx * dx + dpy * dy + dpz * dz);
+                    const float dnum = dt / h.den, dden = -dt * t / h.den;
+                    float* gg = A.g_geom + (size_t)id * 16;
+                    atomicAdd(gg + 0, -dpx + dnum * nx); atomicAdd(gg + 1, -dpy + dnum * ny); atomicAdd(gg + 2, -dpz + dnum * nz);
+                    atomicAdd(gg + 3, du * px); atomicAdd(gg + 4, du * py); atomicAdd(gg + 5, du * pz);
+                    atomicAdd(gg + 6, dv * px); atomicAdd(gg + 7, dv * py); atomicAdd(gg + 8, dv * pz);
+                    atomicAdd(gg + 9, dnum * (g0.x - ox) + dden * dx + sgn * w * gn0);
+                    atomicAdd(gg + 10, dnum * (g0.y - oy) + dden * dy + sgn * w * gn1);
+                    atomicAdd(gg + 11, dnum * (g0.z - oz) + dden * dz + sgn * w * gn2);
+                    atomicAdd(gg + 12, h.G * dalpha);
+                    float* ga_ = A.g_attr + (size_t)id * 8;
+                    atomicAdd(ga_ + 0, w * gc0); atomicAdd(ga_ + 1, w * gc1); atomicAdd(ga_ + 2, w * gc2);
+                    atomicAdd(ga_ + 3, w * gx0); atomicAdd(ga_ + 4, w * gx1);
+                    go0 += dpx - dnum * nx; go1 += dpy - dnum * ny; go2 += dpz - dnum * nz;
+                    gv0 += t * dpx + dden * nx; gv1 += t * dpy + dden * ny; gv2 += t * dpz + dden * nz;
+                }
+                Qpre += wave_sum_f(wq);
+            }
+            D += wave_sum_f(w * t);
+            const float sw = wave_sum_f(w);
+            Aw += sw; M1 += wave_sum_f(w * t); M2 += wave_sum_f(w * t * t);
+            // transmittance behind the blended hits
+            const float keep = bl ? 1.0f - alpha : 1.0f;
+            float prod = keep;
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) prod *= __shfl_xor(prod, sft);
+            T *= st_uniform(prod);
+            blended += n_bl;
+            if (stop || nb < ST_K) done = true;
+            else prev_key = readlane_u64(mine, ST_K - 1);
+        }
+        if (!BWD) {
+            if (lane == 0) {
+                A.rgb[3 * r] = C0 + T * A.bg[0]; A.rgb[3 * r + 1] = C1 + T * A.bg[1]; A.rgb[3 * r + 2] = C2 + T * A.bg[2];
+                A.dpt[r] = D; A.acc[r] = Aw; A.dist[r] = dist;
+                A.norm[3 * r] = N0; A.norm[3 * r + 1] = N1; A.norm[3 * r + 2] = N2;
+                A.aux[2 * r] = X0; A.aux[2 * r + 1] = X1;
+                reinterpret_cast<float4*>(A.state)[r] = make_float4(M2, T, (float)blended, (float)passes);
+            }
+        } else {
+            const float s0 = wave_sum_f(go0), s1 = wave_sum_f(go1), s2 = wave_sum_f(go2), v0 = wave_sum_f(gv0), v1 = wave_sum_f(gv1), v2 = wave_sum_f(gv2);
+            if (lane == 0) {
+                A.g_ray_o[3 * r] = s0; A.g_ray_o[3 * r + 1] = s1; A.g_ray_o[3 * r + 2] = s2;
+                A.g_ray_d[3 * r] = v0; A.g_ray_d[3 * r + 1] = v1; A.g_ray_d[3 * r + 2] = v2;
+            }
+        }
     }
 }
 
@@ -953,6 +1197,8 @@ size_t mrgs_surfel_bvh_bytes(int64_t n_surfels)
     if (n_surfels < 0) return 0;
     return st_blob(n_surfels).total;
 }
+
+size_t mrgs_surfel_trace_state_floats(int64_t n_rays) { return n_rays < 0 ? 0 : (size_t)(5 * n_rays + 16); }
 
 size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels)
 {
@@ -1007,11 +1253,20 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     static const bool no_packets = getenv("MRGS_TRACE_NO_PACKETS") != nullptr;      // developer switch for A/B timing
     a.packets = no_packets ? 0 : 1;
     if (getenv("MRGS_TRACE_DIAG_NO_LONE")) a.packets = 2;
+    static const char* cone_env = getenv("MRGS_TRACE_CONE");
+    a.cone = cone_env ? (float)atof(cone_env) : 0.02f;
     int64_t threads = n_rays;
     if (a.ray_width > 0) threads = (int64_t)((a.ray_width + 7) / 8) * ((n_rays / a.ray_width + 7) / 8) * 64;
     const dim3 grid((unsigned)((threads + ST_THREADS - 1) / ST_THREADS));
+    a.lone_list = reinterpret_cast<uint32_t*>(a.state + 4 * n_rays);
+    if (!bwd && hipMemsetAsync(a.lone_list, 0, 64, st) != hipSuccess) return MRGS_E_HIP;
     if (bwd) hipLaunchKernelGGL(st_trace_kernel<true>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
     else hipLaunchKernelGGL(st_trace_kernel<false>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+    if (a.packets == 1) {
+        const dim3 lgrid((unsigned)(n_rays < 16384 ? n_rays : 16384));
+        if (bwd) hipLaunchKernelGGL(st_trace_lone_kernel<true>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
+        else hipLaunchKernelGGL(st_trace_lone_kernel<false>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
+    }
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

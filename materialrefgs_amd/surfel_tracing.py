@@ -65,7 +65,7 @@ class _Trace(torch.autograd.Function):
         n_rays, P = ray_o.shape[0], geom.shape[0]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         rgb, norm, aux, dpt, acc, dist = new(n_rays, 3), new(n_rays, 3), new(n_rays, 2), new(n_rays), new(n_rays), new(n_rays)
-        wet, state = new(P), new(n_rays, 4)
+        wet, state = new(P), new(L.mrgs_surfel_trace_state_floats(n_rays))
         bg = (ctypes.c_float * 3)(*bg3)
         with torch.cuda.device(dev):
             _lib.check(L.mrgs_surfel_trace_forward(_ptr(blob), P, n_rays, ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
@@ -166,7 +166,9 @@ class SurfelTracer(nn.Module):
         o = ray_o.reshape(-1, 3).contiguous().float()
         d = ray_d.reshape(-1, 3).contiguous().float()
         bg3 = tuple(float(x) for x in ts.bg.detach().reshape(-1)[:3].tolist())
-        rgb, dpt, acc, norm, dist, aux, wet, self.last_state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
+        rgb, dpt, acc, norm, dist, aux, wet, state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
+        self.last_state = state[:4 * o.shape[0]].reshape(-1, 4)      # diagnostics: sum w t^2, final T, hits blended, passes (negative: in a packet)
+        self.last_lone = state[4 * o.shape[0]:4 * o.shape[0] + 1].view(torch.int32)
         r = lambda x, c: x.reshape(*shape, c)
         rgb, dpt, acc, norm, dist, aux = r(rgb, 3), r(dpt, 1), r(acc, 1), r(norm, 3), r(dist, 1), r(aux, 2)
         # stage 0 of the per-depth record (optix_utils.py:28-35); deeper stages do not exist at max_trace_depth = 0

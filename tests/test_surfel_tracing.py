@@ -181,7 +181,7 @@ def test_hip_tracer_matches_the_dense_oracle(gpu_device, P, n, inside, radius):
     for k in ("rgb", "dpt", "acc", "norm", "dist", "aux"):
         a, b = hip[k].cpu().double(), ref[k]
         err = (a - b).abs().reshape(n, -1).max(dim=1).values
-        bad |= err > 2e-4 * max(1.0, float(b.abs().max()))
+        bad |= ~(err <= 2e-4 * max(1.0, float(b.abs().max())))           # NaN counts as a mismatch
     assert int(bad.sum()) <= max(1, n // 500), (int(bad.sum()), n)
     assert float(ref["acc"].max()) > 0.5 or P < 10                      # the scene is actually hit
     ok = ~bad
@@ -228,7 +228,7 @@ def test_hip_tracer_gradients_match_autograd_of_the_oracle(gpu_device, P, n, ins
     same = torch.ones(n, dtype=torch.bool)
     for k in up:
         err = (hip[k].detach().cpu().double() - ref[k].detach()).abs().reshape(n, -1).max(dim=1).values
-        same &= err <= 2e-4 * max(1.0, float(ref[k].abs().max()))
+        same &= err <= 2e-4 * max(1.0, float(ref[k].detach().abs().max()))
     assert int((~same).sum()) <= max(1, n // 200)
     m = same.double()
     loss_h = sum((hip[k] * (up[k] * m.float().reshape(n, *([1] * (up[k].dim() - 1)))).to(gpu_device)).sum() for k in up)

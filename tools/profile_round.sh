@@ -33,6 +33,13 @@ if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C3train --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3train.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C4raster --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4raster.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C4full --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4full.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C3trace --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C3trace.json 2>> $O/bench_C2.err
+  timeout 300 python tools/trace_time.py 300000 800 mirror > $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
+  timeout 300 python tools/trace_time.py 300000 800 primary >> $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_trace -o ${TAG}_C3trace -- python3 $R/bench.py --workload C3trace --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_profiled_C3trace.log 2>&1
+  cd $R
+  cp $(find $O/stats_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_C3trace_kernel_stats.csv
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 tail -1 $O/${TAG}_bench_C2.json | cut -c1-600
