@@ -16,20 +16,29 @@
 // oracle/surfel_trace_oracle.py states the same definition densely (every ray against every surfel) in torch; its autograd is the
 // check of the hand-written backward below.
 //
-// MI355X design.  No RT cores, so the hierarchy is built for a SIMD traversal:
-//  * BUILD ON THE DEVICE, every iteration (the reference rebuilds per iteration too): quad boxes + scene bounds -> 30-bit Morton keys
-//    -> the radix sort of mrgs_sort.hip -> an IMPLICIT COMPLETE 4-ary tree over the sorted order: node i of level l owns nodes
-//    4i..4i+3 of level l-1, level 0 owns surfels.  Boxes are filled bottom-up in one launch (the last child to arrive builds the
-//    parent).  ~0.1 ms for 300 k surfels; nothing crosses PCIe.
-//  * TRAVERSAL STATE IN REGISTERS: with an implicit tree the position is (level, index) and going up is a shift, so the stack
-//    shrinks to one byte per level -- the not-yet-visited siblings in near-to-far order (count + three 2-bit slots) -- twelve
-//    levels in two 64-bit registers.  No LDS stack, no stack traffic.
-//  * K-NEAREST PASSES: a ray gathers its 16 nearest not-yet-blended hits (sorted insertion into a per-lane LDS buffer, [slot][lane]
-//    layout: conflict-free), blends them front to back, and continues behind the last one while the buffer came back full and the
-//    ray is not saturated.  The far bound of the traversal shrinks to the 16th hit as soon as the buffer is full.
+// MI355X design.  No RT cores; what the machine has is 64 lanes per wave, scalar registers for what a wave shares, and LDS.
+//  * BUILD ON THE DEVICE, every iteration (the reference rebuilds per iteration too): quad boxes + scene bounds (per-block partials,
+//    folded by the last block: no same-address atomics) -> 30-bit Morton keys -> the radix sort of mrgs_sort.hip -> a complete 64-ARY
+//    tree over the sorted order, one kernel per level (3-4 levels): node n of level l owns nodes 64 n .. 64 n + 63 of level l-1,
+//    level 0 owns surfels.  A node is six rows of 64 floats: child c's box is read by LANE c.  ~0.2 ms for 300 k surfels.
+//  * 64 RAYS, ONE WALK (st_gather_wide): a wave takes an 8x8 block of rays.  While they run together (directions within ~11 degrees,
+//    origins close) the wave walks the tree once for all of them: lane c tests child c against the BEAM of the rays (bounds on offset
+//    and slope in the rays' own frame), a ballot names the children to enter, the nearest first (wave-min of the near depths).  At the
+//    bottom lane c tests surfel c's own square against the beam; the surviving surfels are visited one by one, their record broadcast
+//    from lane c (v_readlane), every lane evaluating the exact hit for ITS ray and inserting into its own sorted 16-entry buffer
+//    (LDS, [slot][lane]).  Blocks that do not run together split into 4x4 quadrants, then 2x2 groups.
+//  * ONE RAY, ONE WAVE (st_trace_lone_kernel): what is left over walks with the lanes turned sideways -- 64 children, then the 64
+//    surfels of a leaf group, against the one ray -- instead of alone in a lane (a dependent ~1 us gather per step).
+//  * 16-NEAREST PASSES: a ray gathers its 16 nearest not-yet-blended hits, blends them front to back, and continues behind the last
+//    one while the buffer came back full and the ray is not saturated; the walk's far bound closes when every ray of the packet has
+//    a full buffer.
 //  * BACKWARD FRONT TO BACK as well: with the forward's totals at hand, d/d alpha_i = T_i q_i - (Q - Q_i) / (1 - alpha_i)
 //    (q: the pixel gradient contracted with hit i's contribution, Q its weighted sum over all hits, Q_i over hits <= i), so the
 //    backward re-walks exactly the forward's passes and needs no per-ray hit storage.
+// What was measured on the way (800x800 primary rays through the 300 k shell scene, forward): a 4-ary tree walked per lane with the
+// stack in registers 42 ms; + leaf-ordered records, 8x8 ray blocks 29; the same tree walked per wave (scalar node loads, every lane
+// tests its ray) 10; 64-wide nodes with the beam test 4.8.  Mirror rays off a rendered view: 16 ms with a 25-degree cone, 9.5 with
+// 11 degrees, 3.9 with the left-over rays traced one per wave.
 // Compiled with -ffp-contract=off: forward and backward evaluate the hit expression identically.
 #include <cmath>
 #include <cstdlib>
@@ -41,44 +50,9 @@ namespace {
 
 constexpr int ST_K = 16;                  // hits gathered per pass
 constexpr int ST_THREADS = 256;
-constexpr int ST_MAX_LEVELS = 12;         // 4^12 surfels
 constexpr int ST_MAX_PASSES = 256;        // 4096 hits per ray at most
 constexpr float ST_EXTENT = 3.0f;         // optix_utils.py:44 (3-sigma quad)
-constexpr int32_t ST_EMPTY = 0x7FFFFFFF;
 constexpr int ST_AABB_BLOCKS = 256;
-
-struct StNode {                           // 128 bytes: four child boxes (SoA) + four child codes
-    float lo[3][4], hi[3][4];
-    int32_t child[4];                     // level 0: surfel index, ST_EMPTY none; above: 0 present, ST_EMPTY none
-    int32_t pad[4];
-};
-static_assert(sizeof(StNode) == 128, "node layout");
-
-struct StLevels {
-    int32_t n;                            // number of levels; the root is the single node of level n-1
-    int32_t off[ST_MAX_LEVELS];           // first node of level l
-    int32_t cnt[ST_MAX_LEVELS];           // nodes in level l
-    int32_t total;
-};
-
-StLevels st_levels(int64_t P)
-{
-    StLevels lv;
-    std::memset(&lv, 0, sizeof(lv));
-    int64_t c = (P + 3) / 4;
-    if (c < 1) c = 1;
-    int32_t off = 0;
-    for (int l = 0; l < ST_MAX_LEVELS; ++l) {
-        lv.off[l] = off;
-        lv.cnt[l] = (int32_t)c;
-        off += (int32_t)c;
-        lv.n = l + 1;
-        if (c == 1) break;
-        c = (c + 3) / 4;
-    }
-    lv.total = off;
-    return lv;
-}
 
 constexpr int SW_MAX_LEVELS = 4;          // 64^4 surfels
 struct StWide {
@@ -105,22 +79,19 @@ StWide st_wide(int64_t P)
 }
 
 struct BuildWs {
-    size_t aabb, key0, key1, val0, val1, sortws, ubox, counters, bounds, total, zero_from, zero_bytes;
+    size_t aabb, key0, key1, val0, val1, sortws, bounds, total, zero_from, zero_bytes;
 };
 
 BuildWs st_build_ws(int64_t P)
 {
-    const StLevels lv = st_levels(P);
     BuildWs w;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = mrgs_align_up(o + bytes, 256); return at; };
     w.aabb = take((size_t)P * 24);
     w.key0 = take((size_t)P * 4); w.key1 = take((size_t)P * 4);
     w.val0 = take((size_t)P * 4); w.val1 = take((size_t)P * 4);
-    w.ubox = take((size_t)lv.total * 24);
     w.zero_from = o;
     w.sortws = take(mrgs_sort_ws_words(P) * 4);
-    w.counters = take((size_t)lv.total * 4);
     w.bounds = take(64 + ST_AABB_BLOCKS * 6 * 4);   // 6 ordered-uint extrema, [8] sort error flag, [9] ticket, [16..] per-block partial extrema
     w.zero_bytes = o - w.zero_from;
     w.total = o;
@@ -139,14 +110,6 @@ __device__ __forceinline__ float unord_f(uint32_t u)
 
 __device__ __forceinline__ uint32_t ld_agent_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent_f(const float* p)
-{
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_agent_f(float* p, float v)
-{
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ uint32_t wave_max_u(uint32_t v)
 {
@@ -239,76 +202,9 @@ __global__ __launch_bounds__(256) void st_morton_kernel(int P, const float* __re
     val[p] = (uint32_t)p;
 }
 
-// One thread per level-0 node; the last child to arrive at a parent builds it (counters zeroed by the caller).
-__global__ __launch_bounds__(256) void st_build_kernel(int P, StLevels lv, const uint32_t* __restrict__ sorted, const float* __restrict__ aabb,
-                                                       StNode* __restrict__ nodes, float* __restrict__ ubox, uint32_t* __restrict__ counters)
-{
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= lv.cnt[0]) return;
-    StNode nd;
-    float ulo[3] = {INFINITY, INFINITY, INFINITY}, uhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int s = 4 * i + c;
-        bool ok = s < P;
-        uint32_t id = 0;
-        float b[6] = {0, 0, 0, 0, 0, 0};
-        if (ok) {
-            id = sorted[s];
-            const float* src = aabb + (size_t)id * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) b[k] = src[k];
-            ok = b[0] == b[0];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float pad = 1e-5f * fmaxf(fabsf(b[k]), fabsf(b[3 + k])) + 1e-30f;
-            nd.lo[k][c] = ok ? b[k] - pad : 0.f;
-            nd.hi[k][c] = ok ? b[3 + k] + pad : 0.f;
-            if (ok) { ulo[k] = fminf(ulo[k], nd.lo[k][c]); uhi[k] = fmaxf(uhi[k], nd.hi[k][c]); }
-        }
-        nd.child[c] = ok ? (int32_t)id : ST_EMPTY;
-        nd.pad[c] = 0;
-    }
-    nodes[lv.off[0] + i] = nd;
-    float* ub = ubox + (size_t)(lv.off[0] + i) * 6;
-    for (int k = 0; k < 3; ++k) { st_agent_f(ub + k, ulo[k]); st_agent_f(ub + 3 + k, uhi[k]); }
-    for (int l = 1; l < lv.n; ++l) {
-        const int pi = i >> 2;
-        const int expect = min(4, lv.cnt[l - 1] - 4 * pi);
-        __threadfence();
-        const uint32_t seen = atomicAdd(counters + lv.off[l] + pi, 1u);
-        if ((int)seen + 1 < expect) return;
-        __threadfence();
-        float plo[3] = {INFINITY, INFINITY, INFINITY}, phi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int c = 0; c < 4; ++c) {
-            const int ci = 4 * pi + c;
-            const bool there = ci < lv.cnt[l - 1];
-            float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (there) {
-                const float* src = ubox + (size_t)(lv.off[l - 1] + ci) * 6;
-                for (int k = 0; k < 6; ++k) b[k] = ld_agent_f(src + k);
-            }
-            const bool ok = there && b[0] <= b[3];                      // a subtree without a valid surfel has an inverted box
-            for (int k = 0; k < 3; ++k) {
-                nd.lo[k][c] = ok ? b[k] : 0.f;
-                nd.hi[k][c] = ok ? b[3 + k] : 0.f;
-                if (ok) { plo[k] = fminf(plo[k], b[k]); phi[k] = fmaxf(phi[k], b[3 + k]); }
-            }
-            nd.child[c] = ok ? 0 : ST_EMPTY;
-        }
-        nodes[lv.off[l] + pi] = nd;
-        float* pb = ubox + (size_t)(lv.off[l] + pi) * 6;
-        for (int k = 0; k < 3; ++k) { st_agent_f(pb + k, plo[k]); st_agent_f(pb + 3 + k, phi[k]); }
-        i = pi;
-    }
-}
-
 // ---- tracing ------------------------------------------------------------------------------------------------------------
 
 struct StArgs {
-    const StNode* nodes;
-    StLevels lv;
     int64_t n_rays;
     const float* ray_o; const float* ray_d;
     const float4* geom;                   // [P][4]: (m.xyz, a.x) (a.yz, b.xy) (b.z, n.xyz) (opacity, -, -, -);  a = r_u / s_u, b = r_v / s_v
@@ -344,114 +240,6 @@ __device__ __forceinline__ StHit st_hit(const float4 g0, const float4 g1, const 
     return h;
 }
 
-__device__ __forceinline__ void st_cswap(float& da, int& ca, float& db, int& cb)
-{
-    const bool sw = db < da;
-    const float d0 = sw ? db : da, d1 = sw ? da : db;
-    const int c0 = sw ? cb : ca, c1 = sw ? ca : cb;
-    da = d0; db = d1; ca = c0; cb = c1;
-}
-
-// Gathers into the lane's buffer the (up to) ST_K hits with the smallest key = (t, index) above `prev`; returns their number.
-__device__ __forceinline__ int st_gather(const StArgs& A, const int32_t* __restrict__ lv_off, uint32_t (*kb_id)[ST_THREADS],
-                                         float (*kb_t)[ST_THREADS], int tid, float ox, float oy, float oz,
-                                         float dx, float dy, float dz, float ivx, float ivy, float ivz, float prev_t, uint32_t prev_id,
-                                         bool first_pass)
-{
-    int n = 0;
-    float t_far = INFINITY;
-    int lvl = A.lv.n - 1;
-    uint32_t idx = 0;
-    unsigned long long pend_lo = 0, pend_hi = 0;          // one byte per level: count << 6 | third << 4 | second << 2 | first
-    for (;;) {
-        const float4* nd = reinterpret_cast<const float4*>(A.nodes + (lv_off[lvl] + idx));
-        const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-        const int4 ch = reinterpret_cast<const int4*>(nd)[6];
-        float dist[4];
-        int slot[4] = {0, 1, 2, 3};
-        const int32_t code[4] = {ch.x, ch.y, ch.z, ch.w};
-        const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w}, lzs[4] = {lz.x, lz.y, lz.z, lz.w};
-        const float hxs[4] = {hx.x, hx.y, hx.z, hx.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ax = (lxs[c] - ox) * ivx, bx = (hxs[c] - ox) * ivx;
-            const float ay = (lys[c] - oy) * ivy, by = (hys[c] - oy) * ivy;
-            const float az = (lzs[c] - oz) * ivz, bz = (hzs[c] - oz) * ivz;
-            // fminf / fmaxf drop a NaN operand (0 * inf: origin on a slab plane of an axis-parallel ray)
-            const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-            // conservative: intervals widened by 1e-5 relative, boxes padded at build time as well
-            const bool h = t_in <= t_out * 1.00001f + 1e-30f && t_in * 0.99999f <= t_far && t_out * 1.00001f + 1e-30f >= prev_t && code[c] != ST_EMPTY;
-            dist[c] = h ? t_in : INFINITY;
-        }
-        int first_child = -1;
-        if (lvl == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (dist[c] < INFINITY) {
-                    const uint32_t id = (uint32_t)code[c];
-                    const float4* g = A.geom_leaf + ((size_t)idx * 4 + c) * 4;
-                    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
-                    const float opacity = g[3].x;
-                    const StHit h = st_hit(g0, g1, g2, opacity, ox, oy, oz, dx, dy, dz);
-                    bool take = h.ok && (first_pass || h.t > prev_t || (h.t == prev_t && id > prev_id));
-                    if (take && n == ST_K) {
-                        const float lt = kb_t[ST_K - 1][tid];
-                        take = h.t < lt || (h.t == lt && id < kb_id[ST_K - 1][tid]);
-                    }
-                    if (take) {
-                        int pos = n < ST_K ? n++ : ST_K - 1;
-                        while (pos > 0) {
-                            const float pt = kb_t[pos - 1][tid];
-                            const uint32_t pid = kb_id[pos - 1][tid];
-                            if (pt < h.t || (pt == h.t && pid < id)) break;
-                            kb_t[pos][tid] = pt; kb_id[pos][tid] = pid;
-                            --pos;
-                        }
-                        kb_t[pos][tid] = h.t; kb_id[pos][tid] = id;
-                        if (n == ST_K) t_far = kb_t[ST_K - 1][tid];
-                    }
-                }
-            }
-        } else {
-            st_cswap(dist[0], slot[0], dist[1], slot[1]);
-            st_cswap(dist[2], slot[2], dist[3], slot[3]);
-            st_cswap(dist[0], slot[0], dist[2], slot[2]);
-            st_cswap(dist[1], slot[1], dist[3], slot[3]);
-            st_cswap(dist[1], slot[1], dist[2], slot[2]);
-            const int k = (dist[0] < INFINITY) + (dist[1] < INFINITY) + (dist[2] < INFINITY) + (dist[3] < INFINITY);
-            if (k > 0) {
-                first_child = slot[0];
-                const unsigned long long e = k > 1 ? (unsigned long long)(((k - 1) << 6) | (slot[3] << 4) | (slot[2] << 2) | slot[1]) : 0ull;
-                const int sh = 8 * (lvl & 7);
-                if (lvl < 8) pend_lo = (pend_lo & ~(0xFFull << sh)) | (e << sh);
-                else pend_hi = (pend_hi & ~(0xFFull << sh)) | (e << sh);
-            }
-        }
-        if (first_child >= 0) {
-            idx = 4 * idx + (uint32_t)first_child;
-            --lvl;
-            continue;
-        }
-        // up to the nearest level that still has a sibling to visit
-        const unsigned long long cm = 0xC0C0C0C0C0C0C0C0ull;
-        int up;
-        if (pend_lo & cm) up = __builtin_ctzll(pend_lo & cm) >> 3;
-        else if (pend_hi & cm) up = 8 + (__builtin_ctzll(pend_hi & cm) >> 3);
-        else break;
-        unsigned long long& word = up < 8 ? pend_lo : pend_hi;
-        const int sh = 8 * (up & 7);
-        const uint32_t e = (uint32_t)(word >> sh) & 0xFFu;
-        const uint32_t next = e & 3u;
-        const uint32_t left = (e >> 6) - 1u;
-        const uint32_t ne = left ? ((left << 6) | ((e >> 2) & 0x0Fu)) : 0u;
-        word = (word & ~(0xFFull << sh)) | ((unsigned long long)ne << sh);
-        idx = ((idx >> (2 * (up - lvl))) << 2) + next;
-        lvl = up - 1;
-    }
-    return n;
-}
-
 struct StProf { int nodes, tests, lanes; };     // developer counters (-DST_PROFILE writes them into `state`)
 
 // wave-wide reductions; the result is handed back through v_readfirstlane so that the compiler keeps it in a scalar register
@@ -481,8 +269,8 @@ __device__ __forceinline__ float wave_min_f(float v)
 // surface): 64 children per node, stored one child per LANE (six rows of 64 floats), three to four levels for 10^5..10^7 surfels.
 // The wave walks it ONCE for all its rays: a node's 64 child boxes arrive with six coalesced loads, lane c tests child c against the
 // BEAM of the wave's rays (interval arithmetic over the rays' origins and inverse directions: conservative for every ray), one
-// ballot names the children to enter.  Ten dependent round trips per candidate become three, and the 4 x 64 ray-box tests of a
-// packet walk through the 4-ary tree become one test per lane.  At the bottom the surviving surfels are visited one by one: their
+// ballot names the children to enter.  Ten dependent round trips per candidate (in a 4-ary tree) become three, and the 4 x 64
+// ray-box tests of a packet walking such a tree become one test per lane.  At the bottom the surviving surfels are visited one by one: their
 // record comes from a wave-uniform address (scalar loads, the next one in flight while this one is tested), every lane evaluates
 // the exact hit for its own ray and inserts into its own buffer.  No ordering of the walk: the far bound of a packet only closes
 // when all its lanes have full buffers, which a measurement with 32-entry buffers showed to be rare.
@@ -533,7 +321,7 @@ __global__ __launch_bounds__(64) void st_wide_level_kernel(int level, int n_chil
 // (u, v)(s) = (u0_i + k1_i s, v0_i + k2_i s) over the depth s along m, so the beam's cross-section at depth s lies inside
 // [min u0 + min(k1 s), max u0 + max(k1 s)] x (same in v): interval arithmetic again, but on slopes and offsets that are SMALL for rays
 // that run together (in world axes the same bound multiplies O(1) numbers and lets almost every box through -- measured: 2.5x more
-// candidates than the 4-ary packet walk, 20x on diverging mirror rays).
+// candidates than a walk in which every lane tests its own ray, 20x on diverging mirror rays).
 struct StBeam {
     float oc[3], m[3], e1[3], e2[3], am[3], a1[3], a2[3];       // frame and |components| (for the extent of a box along each frame axis)
     float u0min, u0max, v0min, v0max, k1min, k1max, k2min, k2max;
@@ -738,18 +526,20 @@ __device__ __forceinline__ bool st_run_together(float extent, float cone, bool o
 // Packet of every lane: 0 = the whole wave, 1..4 = its quadrant (4x4 rays of the 8x8 block, or 16 consecutive rays), 5..20 = its
 // 2x2 group inside the quadrant, -1 = the ray walks alone.  The coarsest grouping whose rays run together wins; `present` gets one bit
 // per packet in use.
-__device__ __forceinline__ int st_assign_packets(const StArgs& A, const int32_t* lv_off, bool on, int lane, float ox, float oy, float oz,
-                                                 float dx, float dy, float dz, uint32_t& present)
+__device__ __forceinline__ int st_assign_packets(const StArgs& A, const float* __restrict__ boxes, const unsigned long long* __restrict__ vmask, bool on,
+                                                 int lane, float ox, float oy, float oz, float dx, float dy, float dz, uint32_t& present)
 {
     present = 0;
     if (!A.packets || __ballot(on) == 0) return -1;
-    const StNode* root = A.nodes + lv_off[A.lv.n - 1];
+    const int root = A.wide.off[A.wide.n - 1];                                // lane c: child c of the root of the wide hierarchy
     float extent = 0.0f;
-    for (int k = 0; k < 3; ++k) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int c = 0; c < 4; ++c)
-            if (root->child[c] != ST_EMPTY) { lo = fminf(lo, root->lo[k][c]); hi = fmaxf(hi, root->hi[k][c]); }
-        extent = fmaxf(extent, hi - lo);
+    if (A.wide.n > 1) {
+        const bool there = (vmask[root] >> lane) & 1ull;
+        const float* bx = boxes + (size_t)root * 384 + lane;
+        for (int k = 0; k < 3; ++k)
+            extent = fmaxf(extent, wave_max_f(there ? bx[(3 + k) * 64] : -INFINITY) - wave_min_f(there ? bx[k * 64] : INFINITY));
+    } else {
+        extent = INFINITY;                                                    // <= 64 surfels: no scale to compare origins with
     }
     if (st_run_together(extent, A.cone, on, ox, oy, oz, dx, dy, dz)) { present = 1u; return 0; }
     const bool tiled = A.ray_width > 0;
@@ -776,19 +566,19 @@ __device__ __forceinline__ int st_assign_packets(const StArgs& A, const int32_t*
     return mine;
 }
 
-// The surfel records in leaf (= sorted) order: a 4-ary level-0 node's four candidates are one contiguous 256-byte read, a wide group's
-// 64 candidates one 4 KB run; the surfel's index rides in the record's spare word.
-__global__ __launch_bounds__(256) void st_leaf_order_kernel(int n_slots, int n_slots4, const StNode* __restrict__ nodes,
-                                                            const float4* __restrict__ geom, float4* __restrict__ geom_leaf)
+// The surfel records in leaf (= sorted) order: a wide group's 64 candidates are one 4 KB run, the surfel's index rides in the record's
+// spare word.
+__global__ __launch_bounds__(256) void st_leaf_order_kernel(int n_slots, int P, const uint32_t* __restrict__ perm, const float4* __restrict__ geom,
+                                                            float4* __restrict__ geom_leaf)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;            // one thread per 16 bytes
     if (i >= n_slots * 4) return;
     const int slot = i >> 2, part = i & 3;
-    const int32_t id = slot < n_slots4 ? nodes[slot >> 2].child[slot & 3] : ST_EMPTY;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (id != ST_EMPTY) {
+    if (slot < P) {
+        const uint32_t id = perm[slot];
         v = geom[(size_t)id * 4 + part];
-        if (part == 3) v.y = __uint_as_float((uint32_t)id);
+        if (part == 3) v.y = __uint_as_float(id);
     }
     geom_leaf[i] = v;
 }
@@ -799,10 +589,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
     __shared__ float kb_t[ST_K][ST_THREADS];
-    __shared__ int32_t lv_off[ST_MAX_LEVELS];
     const int tid = threadIdx.x;
-    if (tid < ST_MAX_LEVELS) lv_off[tid] = A.lv.off[tid];
-    __syncthreads();
     int64_t r = (int64_t)blockIdx.x * ST_THREADS + tid;
     if (A.ray_width > 0) {                 // 8x8 blocks of neighbouring rays per wave: neighbours walk the same nodes
         const int64_t tiles_x = (A.ray_width + 7) >> 3, rows = A.n_rays / A.ray_width, tile = r >> 6;
@@ -842,9 +629,9 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     bool done = !(exists && fabsf(ox) < 1e30f && fabsf(oy) < 1e30f && fabsf(oz) < 1e30f && fabsf(dx) < 1e30f && fabsf(dy) < 1e30f &&
                   fabsf(dz) < 1e30f && (dx != 0.0f || dy != 0.0f || dz != 0.0f));
     uint32_t packets_present;
-    const int packet = st_assign_packets(A, lv_off, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
+    const int packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
     // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
-    const bool lone = A.packets == 1 && !done && packet < 0;
+    const bool lone = !done && packet < 0;
     if (!BWD) {
         const unsigned long long lm = __ballot(lone);
         if (lm) {
@@ -867,8 +654,6 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
                                            prev_id, pass == 0, mine, prof);
             if (mine) n = got;
         }
-        if (A.packets == 2 && packet < 0) want = false;
-        if (want && packet < 0) n = st_gather(A, lv_off, kb_id, kb_t, tid, ox, oy, oz, dx, dy, dz, ivx, ivy, ivz, prev_t, prev_id, pass == 0);
         if (!want) continue;
         ++passes;
         for (int j = 0; j < n && !done; ++j) {
@@ -1176,16 +961,15 @@ __global__ __launch_bounds__(64) void st_trace_lone_kernel(StArgs A, const float
 
 extern "C" {
 
-struct BlobLayout { size_t leaf, wide_boxes, wide_vmask, total; int n_slots, n_slots4; };
+struct BlobLayout { size_t perm, leaf, wide_boxes, wide_vmask, total; int n_slots; };
 
-static BlobLayout st_blob(int64_t n_surfels)          // 4-ary nodes | surfel records in leaf order (filled by the trace calls) | wide boxes | wide masks
+static BlobLayout st_blob(int64_t n_surfels)          // sorted order | surfel records in that order (filled by the trace calls) | wide boxes | wide masks
 {
-    const StLevels lv = st_levels(n_surfels);
     const StWide w = st_wide(n_surfels);
     BlobLayout b;
-    b.n_slots4 = 4 * lv.cnt[0];
-    b.n_slots = b.n_slots4 > 64 * w.cnt[0] ? b.n_slots4 : 64 * w.cnt[0];
-    b.leaf = mrgs_align_up((size_t)lv.total * sizeof(StNode), 256);
+    b.n_slots = 64 * w.cnt[0];
+    b.perm = 0;
+    b.leaf = mrgs_align_up((size_t)b.n_slots * 4, 256);
     b.wide_boxes = mrgs_align_up(b.leaf + (size_t)b.n_slots * 64, 256);
     b.wide_vmask = mrgs_align_up(b.wide_boxes + (size_t)w.total * 1536, 256);
     b.total = mrgs_align_up(b.wide_vmask + (size_t)w.total * 8, 256);
@@ -1208,10 +992,9 @@ size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels)
 
 int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* blob, size_t blob_bytes, void* ws, size_t ws_bytes, void* stream)
 {
-    if (n_surfels < 0 || n_surfels > (int64_t)1 << 24) return MRGS_E_UNSUPPORTED;      // 4^12 = 64^4 surfels
+    if (n_surfels < 0 || n_surfels > (int64_t)1 << 24) return MRGS_E_UNSUPPORTED;      // 64^4 surfels
     if (n_surfels == 0) return MRGS_OK;
     if (!quad_vertices || !blob || !ws) return MRGS_E_BAD_ARG;
-    const StLevels lv = st_levels(n_surfels);
     const BuildWs w = st_build_ws(n_surfels);
     if (blob_bytes < mrgs_surfel_bvh_bytes(n_surfels) || ws_bytes < w.total) return MRGS_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1227,8 +1010,7 @@ int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* b
                        bounds + 9, bounds);
     hipLaunchKernelGGL(st_morton_kernel, dim3(nb), dim3(256), 0, st, P, aabb, bounds, key[0], val[0]);
     const int cur = mrgs_radix_sort_pairs(key, val, (uint32_t*)(base + w.sortws), bounds + 8, n_surfels, nullptr, 0, 32, st);
-    hipLaunchKernelGGL(st_build_kernel, dim3((lv.cnt[0] + 255) / 256), dim3(256), 0, st, P, lv, val[cur], aabb, (StNode*)blob,
-                       (float*)(base + w.ubox), (uint32_t*)(base + w.counters));
+    if (hipMemcpyAsync(blob, val[cur], (size_t)P * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return MRGS_E_HIP;      // the sorted order
     const StWide wd = st_wide(n_surfels);
     const BlobLayout bl = st_blob(n_surfels);
     for (int l = 0; l < wd.n; ++l)
@@ -1239,8 +1021,6 @@ int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* b
 
 static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, StArgs& a, hipStream_t st)
 {
-    a.nodes = (const StNode*)blob;
-    a.lv = st_levels(n_surfels);
     a.n_rays = n_rays;
     const BlobLayout bl = st_blob(n_surfels);
     float4* leaf = (float4*)((char*)blob + bl.leaf);
@@ -1248,11 +1028,11 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     a.wide = st_wide(n_surfels);
     const float* wide_boxes = (const float*)((char*)blob + bl.wide_boxes);
     const unsigned long long* wide_vmask = (const unsigned long long*)((char*)blob + bl.wide_vmask);
-    hipLaunchKernelGGL(st_leaf_order_kernel, dim3((bl.n_slots * 4 + 255) / 256), dim3(256), 0, st, bl.n_slots, bl.n_slots4, a.nodes, a.geom, leaf);
+    hipLaunchKernelGGL(st_leaf_order_kernel, dim3((bl.n_slots * 4 + 255) / 256), dim3(256), 0, st, bl.n_slots, (int)n_surfels,
+                       (const uint32_t*)((char*)blob + bl.perm), a.geom, leaf);
     a.ray_width = (ray_width > 0 && n_rays % ray_width == 0) ? ray_width : 0;
-    static const bool no_packets = getenv("MRGS_TRACE_NO_PACKETS") != nullptr;      // developer switch for A/B timing
+    static const bool no_packets = getenv("MRGS_TRACE_NO_PACKETS") != nullptr;      // developer switch: every ray gets a wave of its own
     a.packets = no_packets ? 0 : 1;
-    if (getenv("MRGS_TRACE_DIAG_NO_LONE")) a.packets = 2;
     static const char* cone_env = getenv("MRGS_TRACE_CONE");
     a.cone = cone_env ? (float)atof(cone_env) : 0.02f;
     int64_t threads = n_rays;
@@ -1262,11 +1042,9 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     if (!bwd && hipMemsetAsync(a.lone_list, 0, 64, st) != hipSuccess) return MRGS_E_HIP;
     if (bwd) hipLaunchKernelGGL(st_trace_kernel<true>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
     else hipLaunchKernelGGL(st_trace_kernel<false>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
-    if (a.packets == 1) {
-        const dim3 lgrid((unsigned)(n_rays < 16384 ? n_rays : 16384));
-        if (bwd) hipLaunchKernelGGL(st_trace_lone_kernel<true>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
-        else hipLaunchKernelGGL(st_trace_lone_kernel<false>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
-    }
+    const dim3 lgrid((unsigned)(n_rays < 16384 ? n_rays : 16384));
+    if (bwd) hipLaunchKernelGGL(st_trace_lone_kernel<true>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
+    else hipLaunchKernelGGL(st_trace_lone_kernel<false>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
