@@ -177,22 +177,14 @@ class SurfelTracer(nn.Module):
 
 
 def _depth_to_normal(view, depth):
-    """utils/point_utils.py:9-37 for a depth map [H,W]: back-project every pixel with the camera's intrinsics (pixel = integer
-    coordinates, principal point W/2, H/2), central differences over two pixels, unit cross product; the border stays zero."""
+    """depth_to_normal(view, depth) of utils/point_utils.py:26-37 for a depth map [H,W] through the maps kernel of render_surfel
+    (`mrgs_surfel_maps_*`): an all-map whose expected depth is `depth` and whose alpha is 1 makes its surf_normal exactly that."""
+    from types import SimpleNamespace
+    from .renderer import compute_2dgs_normal_and_regularizations
     H, W = depth.shape
-    dev = depth.device
-    c2w = view.world_view_transform.T.inverse()
-    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32, device=dev).T
-    intr = ((c2w.T @ view.full_proj_transform) @ ndc2pix)[:3, :3].T
-    gx, gy = torch.meshgrid(torch.arange(W, device=dev, dtype=torch.float32), torch.arange(H, device=dev, dtype=torch.float32), indexing="xy")
-    pix = torch.stack([gx, gy, torch.ones_like(gx)], dim=-1).reshape(-1, 3)
-    dirs = pix @ intr.inverse().T @ c2w[:3, :3].T
-    pts = (depth.reshape(-1, 1) * dirs + c2w[:3, 3]).reshape(H, W, 3)
-    out = torch.zeros_like(pts)
-    du = pts[2:, 1:-1] - pts[:-2, 1:-1]
-    dv = pts[1:-1, 2:] - pts[1:-1, :-2]
-    out[1:-1, 1:-1] = torch.nn.functional.normalize(torch.cross(du, dv, dim=-1), dim=-1)
-    return out
+    allmap = torch.zeros(7, H, W, dtype=torch.float32, device=depth.device)
+    allmap[0], allmap[1] = depth, 1.0
+    return compute_2dgs_normal_and_regularizations(allmap, view, SimpleNamespace(depth_ratio=0.0))["surf_normal"].permute(1, 2, 0)
 
 
 class HardwareRendering(nn.Module):

@@ -265,6 +265,9 @@ def test_hardware_rendering_mirror(gpu_device):
         assert out[k].shape == (c, H, W), k
     assert out["weight_accumulate"].shape == (2000, 1) and out["visibility_filter"].shape == (2000,)
     assert float(out["rend_alpha"].mean()) > 0.3
+    import glue_oracle
+    sn_ref = glue_oracle.depth_to_normal(cam, out["surf_depth"].detach()).permute(2, 0, 1) * out["rend_alpha"].detach()
+    assert float((out["surf_normal"].detach() - sn_ref).abs().max()) < 2e-4              # optix_utils.py:236-242 through the maps kernel
     # every surfel carries others = 0.01 (optix_utils.py:173-177): specular = 0.01 * alpha
     assert torch.allclose(out["specular"], 0.01 * out["rend_alpha"], atol=1e-6)
     out["render"].sum().backward()
