@@ -41,6 +41,7 @@ class SurfelModel:
         self._ori_color = ori_color if ori_color is not None else z(P, 3)
         self._indirect_dc = indirect_dc if indirect_dc is not None else z(P, 1, 3)
         self._indirect_rest = indirect_rest if indirect_rest is not None else z(P, 15, 3)
+        self._metalness = z(P, 1)       # GaussianModel._metalness: the per-gaussian blend weight render_surfel2 rasterizes (get_specular)
         self.env_map = envmap
         self.env_map_2 = None           # the second environment map render_volume shades with (GaussianModel.get_envmap_2)
         self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
@@ -58,6 +59,7 @@ class SurfelModel:
     get_refl = property(lambda s: torch.sigmoid(s._refl_strength))
     get_rough = property(lambda s: torch.sigmoid(s._roughness))
     get_ori_color = property(lambda s: torch.sigmoid(s._ori_color))
+    get_specular = property(lambda s: torch.sigmoid(s._metalness))          # gaussian_model.py:309-311
     get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
     get_indirect = property(lambda s: torch.cat((s._indirect_dc, s._indirect_rest), dim=1))
     get_envmap = property(lambda s: s.env_map)
@@ -444,3 +446,71 @@ def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_c
     results["render"] = results["render"] * (1 - specular) + specular * traced["render"]
     results["indirect_out"] = traced
     return results
+
+
+def get_distance(scaling_modifier, means3D, viewpoint_camera, pc):
+    """gaussian_renderer/envgs_renderer.py:30-38: |facing normal . centre| in the camera frame, [P,1] (the plane distance the "pgsr"
+    flavour rasterizes as its last feature channel)."""
+    Wv = viewpoint_camera.world_view_transform
+    d = pc.get_xyz - viewpoint_camera.camera_center
+    normal_cam = pc.get_normal(scaling_modifier, d / d.norm(dim=1, keepdim=True)) @ Wv[:3, :3]
+    centre_cam = means3D @ Wv[:3, :3] + Wv[3, :3]
+    return (normal_cam * centre_cam).sum(-1).abs().unsqueeze(-1)
+
+
+def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
+                   opt=None, wo_render_img=False, normal_img_map=None, flag="pgsr"):
+    """gaussian_renderer/envgs_renderer.py:461-715, the last training stage (train_refnerf.py:1501-1504): render_surfel's material
+    channels plus (flag "pgsr", arguments/config.py:1) the per-gaussian blend weight and plane distance (S = 10), the mirror rays of the
+    view traced through the ENVIRONMENT surfel set `env` (render_indirect, :659), and that traced light standing in for the blended
+    indirect radiance where the mesh occludes the environment (get_specular_color_surfel4, utils/refl_utils.py:302-362, with its
+    `use_indirect_light_residual = False`).  `pipe.use_asg` (off by default, arguments/__init__.py:101) is not built.
+    The reference binds `diff_surfel_rasterization2` here; its blending of feature channels is the vendored rasterizer's, which is what
+    runs."""
+    if opt is None:
+        opt = SimpleNamespace(indirect=False)
+    if getattr(pipe, "use_asg", False):
+        raise NotImplementedError("pipe.use_asg: the anisotropic-spherical-gaussian indirect term is not built")
+    means2D = _screenspace_points(pc)
+    settings = _raster_settings(viewpoint_camera, pc, pipe, torch.zeros_like(bg_color), scaling_modifier)     # bg = 0 as at :483
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+    means3D = pc.get_xyz
+    shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)
+    opacities, scales, rotations, features = surfel_features(pc, viewpoint_camera.camera_center)        # refl, rough, albedo 3, indirect 3
+    if flag != "2dgs":
+        features = torch.cat((features, pc.get_specular, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
+    contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
+        scales=scales, rotations=rotations, cov3D_precomp=None)
+    base_color = rendered_image
+    refl_strength, roughness_map, albedo = rendered_features[:1], rendered_features[1:2], rendered_features[2:5]
+    blend_weight = rendered_features[8:9]
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img),
+                                                  return_normal_map=True)
+    render_alpha = reg["render_alpha"]
+    geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
+           "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"],
+           "blend_weight": blend_weight}
+    if flag != "2dgs":
+        geo["rend_distance"] = rendered_features[-1:]
+    if wo_render_img:
+        return {"refl_strength_map": refl_strength, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
+
+    normal_map = reg["normal_map"]                                              # render_normal / max(alpha, 1e-6), not normalised (:655-657)
+    indirect_results = render_indirect(indirect_renderer, viewpoint_camera, env, pipe, bg_color, normal_map, reg["surf_depth"])
+    hwc = lambda m: m.permute(1, 2, 0)
+    kw = dict(refl_strength=hwc(refl_strength), roughness=hwc(roughness_map), pc=pc, surf_depth=reg["surf_depth"])
+    if getattr(opt, "indirect", False):
+        kw["indirect_light"] = hwc(indirect_results["render"])
+    specular, extra_dict = get_specular_color_surfel(pc.get_envmap, hwc(albedo), viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T,
+                                                     normal_map, hwc(render_alpha), **kw)
+    final_image = (1 - refl_strength) * base_color + specular
+    if srgb:
+        final_image, albedo, specular = linear_to_srgb(final_image), linear_to_srgb(albedo), linear_to_srgb(specular)
+    final_image = final_image + bg_color[:, None, None] * (1 - render_alpha)
+    out = {"render": final_image, "refl_strength_map": refl_strength, "diffuse_map": (1 - refl_strength) * base_color,
+           "diffuse_map_ori": base_color, "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness_map, **geo,
+           "indirect_out": indirect_results}
+    if getattr(opt, "indirect", False):
+        out.update(extra_dict)
+    return out

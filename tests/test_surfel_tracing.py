@@ -313,3 +313,55 @@ def test_render_surfel_with_envgs_composes_raster_and_traced_light(gpu_device):
     out["render"].sum().backward()
     assert pc._xyz.grad is not None and float(pc._xyz.grad.abs().sum()) > 0
     assert tr["viewspace_points"].grad is not None and float(tr["viewspace_points"].grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_render_surfel2_wiring(gpu_device):
+    """gaussian_renderer/envgs_renderer.py:461-715 on the HIP pieces: (1) with the "2dgs" channel set and no indirect term it is
+    render_surfel; (2) the two extra "pgsr" channels are the rasterized blend weight and plane distance (checked against a separate
+    rasterization of each); (3) with opt.indirect the traced light of the ENVIRONMENT surfels stands where the mesh occludes the
+    environment map, and its gradient reaches the environment surfels."""
+    from types import SimpleNamespace
+    from test_render_e2e import _models
+    from materialrefgs_amd import renderer
+    from materialrefgs_amd.rasterizer import GaussianRasterizer
+    from materialrefgs_amd.raytracing import RayTracer
+    from materialrefgs_amd.surfel_tracing import HardwareRendering
+    from materialrefgs_amd.synthetic import orbit_camera, make_occluder_mesh
+    dev = gpu_device
+    P, H, W = 1500, 40, 56
+    _, _, pc, _env = _models(P, H, W, seed=6, dev=dev)
+    _, _, envgs, _ = _models(700, H, W, seed=8, dev=dev)                       # the second surfel set (EnvGaussianModel's role)
+    with torch.no_grad():
+        envgs._xyz.mul_(2.5)                                                   # a shell around the object
+        pc._metalness.copy_(torch.randn(P, 1, device=dev))
+    pc._metalness.requires_grad_(True)
+    cam = orbit_camera(3, H, W).to(dev)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False, use_asg=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    hr = HardwareRendering().train()
+    plain = renderer.render_surfel(cam, pc, pipe, bg, srgb=True, opt=SimpleNamespace(indirect=False))
+    two = renderer.render_surfel2(hr, envgs, cam, pc, pipe, bg, srgb=True, opt=SimpleNamespace(indirect=False), flag="2dgs")
+    for k in ("render", "specular_map", "diffuse_map", "base_color_map", "rend_alpha", "rend_normal", "surf_depth", "surf_normal", "rend_dist"):
+        assert float((two[k] - plain[k]).abs().max()) < 2e-6, k
+    assert two["blend_weight"].shape[0] == 0
+    pg = renderer.render_surfel2(hr, envgs, cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+    rast = GaussianRasterizer(raster_settings=renderer._raster_settings(cam, pc, pipe, torch.zeros_like(bg), 1.0))
+    args = dict(means3D=pc.get_xyz, means2D=torch.zeros_like(pc.get_xyz), shs=pc.get_features, opacities=pc.get_opacity, scales=pc.get_scaling,
+                rotations=pc.get_rotation)
+    only_w = rast(features=pc.get_specular, **args)[2]
+    only_d = rast(features=renderer.get_distance(1.0, pc.get_xyz, cam, pc), **args)[2]
+    assert float((pg["blend_weight"] - only_w).abs().max()) < 2e-6 and float((pg["rend_distance"] - only_d).abs().max()) < 2e-5
+    assert float(only_w.max()) > 0.05
+    # the mesh occluder makes part of the mirror rays "not visible": there the traced environment surfels are the specular light
+    pc.ray_tracer = RayTracer(*make_occluder_mesh(4000), device=dev)
+    ind = renderer.render_surfel2(hr, envgs, cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=True))
+    vis = ind["visibility"]
+    assert 0.02 < float(1 - vis[ind["rend_alpha"] > 0.5].mean()) < 0.98
+    assert torch.allclose(ind["indirect_light"], ind["indirect_out"]["render"], atol=1e-6)
+    expect = (ind["direct_light"] * vis + (1 - vis) * ind["indirect_out"]["render"]) * ind["rend_alpha"] * ind["specular_weight"].permute(2, 0, 1)     # the reference leaves this one [H,W,3] (refl_utils.py:357)
+    assert float((ind["specular_map"] - expect).abs().max()) < 1e-5
+    ind["render"].sum().backward()
+    assert envgs._xyz.grad is not None and float(envgs._xyz.grad.abs().sum()) > 0            # through the tracer into the environment set
+    assert pc._metalness.grad is None or float(pc._metalness.grad.abs().sum()) == 0          # the blend weight is rasterized but not consumed
+    assert float(pc._xyz.grad.abs().sum()) > 0
