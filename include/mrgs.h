@@ -379,6 +379,20 @@ int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, in
                                const float* g_acc, const float* g_norm, const float* g_dist, const float* g_aux, float* g_geom,
                                float* g_attr, float* g_ray_o, float* g_ray_d, void* stream);
 
+/* The per-surfel records of the tracer from the model's tensors, and the way back: what HardwareRendering.render_gaussians prepares
+ * around the tracer call (gaussian_renderer/optix_utils.py:36-66 get_disks, :124-183) in one launch each.  scales [P,2] (multiplied by
+ * scale_modifier), rotations [P,4] (w,x,y,z; normalised inside as build_rotation does), opacities [P]; exactly one of shs [P,M,3]
+ * (colour = max(SH(degree, direction from campos) + 0.5, 0), forward.cu:20-81) and colors_precomp [P,3]; others [P,2] nullable;
+ * campos: 3 floats on the device.  quad_vertices [P,4,3] (nullable) receives get_disks' corners for mrgs_surfel_bvh_build.
+ * Backward: g_geom [P,16] / g_attr [P,8] in, gradients of every input out (g_shs or g_colors_precomp, g_others nullable). */
+int mrgs_surfel_trace_prep_forward(int64_t P, const float* means3D, const float* scales, const float* rotations, const float* opacities,
+                                   const float* shs, int32_t M, int32_t sh_degree, const float* colors_precomp, const float* others,
+                                   const float* campos, float scale_modifier, float* geom, float* attr, float* quad_vertices, void* stream);
+int mrgs_surfel_trace_prep_backward(int64_t P, const float* means3D, const float* scales, const float* rotations, const float* shs, int32_t M,
+                                    int32_t sh_degree, const float* campos, float scale_modifier, const float* g_geom, const float* g_attr,
+                                    float* g_means3D, float* g_scales, float* g_rotations, float* g_opacities, float* g_shs,
+                                    float* g_colors_precomp, float* g_others, void* stream);
+
 /* ---- optimizer step -------------------------------------------------------------------------
  * torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of GaussianModel.training_setup (scene/gaussian_model.py:417-453) for every
  * parameter tensor in one launch (per MRGS_ADAM_MAX_TENSORS tensors): amsgrad off, no weight decay.  `tensors` is a HOST array;

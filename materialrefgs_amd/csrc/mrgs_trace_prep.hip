@@ -1,0 +1,212 @@
+// Per-surfel records of the surfel ray tracer from the model's tensors, and the way back (one launch each).
+//
+// What HardwareRendering.render_gaussians prepares around the tracer call (gaussian_renderer/optix_utils.py:124-183): the quad corners
+// of get_disks (:36-66) for the hierarchy, the splat frame from scales / rotations, and -- when SHs are passed -- the colour of every
+// surfel seen from the settings' camera position, computeColorFromSH of the rasterizer family (forward.cu:20-81: basis of degree
+// <= 3 in the 3DGS sign convention, + 0.5, clamped at 0).  In torch that is ~130 small launches forward and as many backward per view
+// (measured: 3.3 ms of a 14 ms traced view, host-bound); here it is one kernel each way:
+//   geom  [P,16] = mean (3), r_u / s_u (3), r_v / s_v (3), normal r_w (3), opacity, 3 unused     (s = scale * scale_modifier)
+//   attr  [P,8]  = rgb (3), others (2), 3 unused
+//   quads [P,4,3] = mean -+ 3 s_u r_u +- 3 s_v r_v in get_disks' corner order (-3,3), (-3,-3), (3,3), (3,-3)
+// R = rotation matrix of q / |q| (utils/general_utils.py:80-99: the reference normalises inside build_rotation).
+// Backward: g_geom / g_attr (the tracer's outputs) -> gradients of means, scales, rotations (through the normalisation), opacities,
+// SH coefficients or colours, others.  The quads carry no gradient (the reference detaches them, optix_utils.py:76).
+#include "mrgs_internal.h"
+
+namespace {
+
+__device__ __constant__ float pSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float pSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float pSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                           0.5462742152960396f};
+__device__ __constant__ float pSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                           -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+struct PrepArgs {
+    int P, M, degree;                     // M coefficients per channel in `shs` (layout [P,M,3]), active degree
+    float scale_modifier;
+    const float *means, *scales, *rotations, *opacities, *shs, *colors, *others, *campos;
+    float *geom, *attr, *quads;
+    const float *g_geom, *g_attr;
+    float *g_means, *g_scales, *g_rotations, *g_opacities, *g_shs, *g_colors, *g_others;
+};
+
+// basis values B[0..n) and their derivatives with respect to the unit direction (x, y, z)
+__device__ __forceinline__ void sh_basis_and_grad(int degree, float x, float y, float z, float (&B)[16], float (&Bx)[16], float (&By)[16], float (&Bz)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { B[i] = 0.f; Bx[i] = 0.f; By[i] = 0.f; Bz[i] = 0.f; }
+    B[0] = pSH_C0;
+    if (degree < 1) return;
+    B[1] = -pSH_C1 * y; By[1] = -pSH_C1;
+    B[2] = pSH_C1 * z; Bz[2] = pSH_C1;
+    B[3] = -pSH_C1 * x; Bx[3] = -pSH_C1;
+    if (degree < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    B[4] = pSH_C2[0] * xy; Bx[4] = pSH_C2[0] * y; By[4] = pSH_C2[0] * x;
+    B[5] = pSH_C2[1] * yz; By[5] = pSH_C2[1] * z; Bz[5] = pSH_C2[1] * y;
+    B[6] = pSH_C2[2] * (2.0f * zz - xx - yy); Bx[6] = -2.0f * pSH_C2[2] * x; By[6] = -2.0f * pSH_C2[2] * y; Bz[6] = 4.0f * pSH_C2[2] * z;
+    B[7] = pSH_C2[3] * xz; Bx[7] = pSH_C2[3] * z; Bz[7] = pSH_C2[3] * x;
+    B[8] = pSH_C2[4] * (xx - yy); Bx[8] = 2.0f * pSH_C2[4] * x; By[8] = -2.0f * pSH_C2[4] * y;
+    if (degree < 3) return;
+    B[9] = pSH_C3[0] * y * (3.0f * xx - yy); Bx[9] = pSH_C3[0] * 6.0f * xy; By[9] = pSH_C3[0] * 3.0f * (xx - yy);
+    B[10] = pSH_C3[1] * xy * z; Bx[10] = pSH_C3[1] * yz; By[10] = pSH_C3[1] * xz; Bz[10] = pSH_C3[1] * xy;
+    B[11] = pSH_C3[2] * y * (4.0f * zz - xx - yy); Bx[11] = -2.0f * pSH_C3[2] * xy; By[11] = pSH_C3[2] * (4.0f * zz - xx - 3.0f * yy); Bz[11] = 8.0f * pSH_C3[2] * yz;
+    B[12] = pSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); Bx[12] = -6.0f * pSH_C3[3] * xz; By[12] = -6.0f * pSH_C3[3] * yz;
+    Bz[12] = pSH_C3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+    B[13] = pSH_C3[4] * x * (4.0f * zz - xx - yy); Bx[13] = pSH_C3[4] * (4.0f * zz - 3.0f * xx - yy); By[13] = -2.0f * pSH_C3[4] * xy; Bz[13] = 8.0f * pSH_C3[4] * xz;
+    B[14] = pSH_C3[5] * z * (xx - yy); Bx[14] = 2.0f * pSH_C3[5] * xz; By[14] = -2.0f * pSH_C3[5] * yz; Bz[14] = pSH_C3[5] * (xx - yy);
+    B[15] = pSH_C3[6] * x * (xx - 3.0f * yy); Bx[15] = pSH_C3[6] * 3.0f * (xx - yy); By[15] = -6.0f * pSH_C3[6] * xy;
+}
+
+struct Rot { float qn[4], len, R[3][3]; };
+
+__device__ __forceinline__ Rot make_rot(const float4 q)
+{
+    Rot r;
+    r.len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float w = q.x / r.len, x = q.y / r.len, y = q.z / r.len, z = q.w / r.len;
+    r.qn[0] = w; r.qn[1] = x; r.qn[2] = y; r.qn[3] = z;
+    r.R[0][0] = 1.f - 2.f * (y * y + z * z); r.R[0][1] = 2.f * (x * y - w * z); r.R[0][2] = 2.f * (x * z + w * y);
+    r.R[1][0] = 2.f * (x * y + w * z); r.R[1][1] = 1.f - 2.f * (x * x + z * z); r.R[1][2] = 2.f * (y * z - w * x);
+    r.R[2][0] = 2.f * (x * z - w * y); r.R[2][1] = 2.f * (y * z + w * x); r.R[2][2] = 1.f - 2.f * (x * x + y * y);
+    return r;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void trace_prep_kernel(PrepArgs A)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= A.P) return;
+    const float mx = A.means[3 * p], my = A.means[3 * p + 1], mz = A.means[3 * p + 2];
+    const float su = A.scales[2 * p] * A.scale_modifier, sv = A.scales[2 * p + 1] * A.scale_modifier;
+    const Rot r = make_rot(reinterpret_cast<const float4*>(A.rotations)[p]);
+    const float ru[3] = {r.R[0][0], r.R[1][0], r.R[2][0]}, rv[3] = {r.R[0][1], r.R[1][1], r.R[2][1]}, rw[3] = {r.R[0][2], r.R[1][2], r.R[2][2]};
+    // view direction and colour
+    float dirx = 0.f, diry = 0.f, dirz = 0.f, dlen = 1.f;
+    float B[16], Bx[16], By[16], Bz[16];
+    float rgb[3] = {0.f, 0.f, 0.f};
+    const bool from_sh = A.shs != nullptr;
+    if (from_sh) {
+        const float ex = mx - A.campos[0], ey = my - A.campos[1], ez = mz - A.campos[2];
+        dlen = sqrtf(ex * ex + ey * ey + ez * ez);
+        dirx = ex / dlen; diry = ey / dlen; dirz = ez / dlen;
+        sh_basis_and_grad(A.degree, dirx, diry, dirz, B, Bx, By, Bz);
+    }
+    const int ncoef = min((A.degree + 1) * (A.degree + 1), A.M);
+    if (!BWD) {
+        if (from_sh) {
+            const float* sh = A.shs + (size_t)p * A.M * 3;
+            for (int k = 0; k < ncoef; ++k) { rgb[0] += B[k] * sh[3 * k]; rgb[1] += B[k] * sh[3 * k + 1]; rgb[2] += B[k] * sh[3 * k + 2]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(rgb[c] + 0.5f, 0.0f);
+        } else {
+            rgb[0] = A.colors[3 * p]; rgb[1] = A.colors[3 * p + 1]; rgb[2] = A.colors[3 * p + 2];
+        }
+        float4* g = reinterpret_cast<float4*>(A.geom) + (size_t)p * 4;
+        g[0] = make_float4(mx, my, mz, ru[0] / su);
+        g[1] = make_float4(ru[1] / su, ru[2] / su, rv[0] / sv, rv[1] / sv);
+        g[2] = make_float4(rv[2] / sv, rw[0], rw[1], rw[2]);
+        g[3] = make_float4(A.opacities[p], 0.f, 0.f, 0.f);
+        float4* a = reinterpret_cast<float4*>(A.attr) + (size_t)p * 2;
+        a[0] = make_float4(rgb[0], rgb[1], rgb[2], A.others ? A.others[2 * p] : 0.f);
+        a[1] = make_float4(A.others ? A.others[2 * p + 1] : 0.f, 0.f, 0.f, 0.f);
+        if (A.quads) {
+            float* q = A.quads + (size_t)p * 12;
+            const float cu[4] = {-3.f, -3.f, 3.f, 3.f}, cv[4] = {3.f, -3.f, 3.f, -3.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[3 * k] = mx + cu[k] * su * ru[0] + cv[k] * sv * rv[0];
+                q[3 * k + 1] = my + cu[k] * su * ru[1] + cv[k] * sv * rv[1];
+                q[3 * k + 2] = mz + cu[k] * su * ru[2] + cv[k] * sv * rv[2];
+            }
+        }
+        return;
+    }
+    // ---- backward ----
+    const float4* gg = reinterpret_cast<const float4*>(A.g_geom) + (size_t)p * 4;
+    const float4 g0 = gg[0], g1 = gg[1], g2 = gg[2], g3 = gg[3];
+    const float4* ga = reinterpret_cast<const float4*>(A.g_attr) + (size_t)p * 2;
+    const float4 a0 = ga[0], a1 = ga[1];
+    float dm[3] = {g0.x, g0.y, g0.z};
+    const float da[3] = {g0.w, g1.x, g1.y}, db[3] = {g1.z, g1.w, g2.x}, dn[3] = {g2.y, g2.z, g2.w};
+    // a = r_u / s_u: d r_u = da / s_u, d s_u = -(da . r_u) / s_u^2
+    float dR[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dR[k][0] = da[k] / su; dR[k][1] = db[k] / sv; dR[k][2] = dn[k]; }
+    const float dsu = -(da[0] * ru[0] + da[1] * ru[1] + da[2] * ru[2]) / (su * su), dsv = -(db[0] * rv[0] + db[1] * rv[1] + db[2] * rv[2]) / (sv * sv);
+    A.g_scales[2 * p] = dsu * A.scale_modifier;
+    A.g_scales[2 * p + 1] = dsv * A.scale_modifier;
+    // rotation matrix -> unit quaternion -> raw quaternion
+    const float w = r.qn[0], x = r.qn[1], y = r.qn[2], z = r.qn[3];
+    const float dw = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+    const float dx = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - w * dR[1][2] + z * dR[2][0] + w * dR[2][1] - 2.f * x * dR[2][2]);
+    const float dy = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + w * dR[0][2] + x * dR[1][0] + z * dR[1][2] - w * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+    const float dz = 2.f * (-2.f * z * dR[0][0] - w * dR[0][1] + x * dR[0][2] + w * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+    const float dot = w * dw + x * dx + y * dy + z * dz;
+    reinterpret_cast<float4*>(A.g_rotations)[p] = make_float4((dw - w * dot) / r.len, (dx - x * dot) / r.len, (dy - y * dot) / r.len, (dz - z * dot) / r.len);
+    A.g_opacities[p] = g3.x;
+    if (A.g_others) { A.g_others[2 * p] = a0.w; A.g_others[2 * p + 1] = a1.x; }
+    if (from_sh) {
+        const float* sh = A.shs + (size_t)p * A.M * 3;
+        float* gsh = A.g_shs + (size_t)p * A.M * 3;
+        float val[3] = {0.5f, 0.5f, 0.5f};
+        for (int k = 0; k < ncoef; ++k) { val[0] += B[k] * sh[3 * k]; val[1] += B[k] * sh[3 * k + 1]; val[2] += B[k] * sh[3 * k + 2]; }
+        const float dc[3] = {val[0] >= 0.f ? a0.x : 0.f, val[1] >= 0.f ? a0.y : 0.f, val[2] >= 0.f ? a0.z : 0.f};
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        for (int k = 0; k < A.M; ++k) {
+            const bool live = k < ncoef;
+            gsh[3 * k] = live ? B[k] * dc[0] : 0.f; gsh[3 * k + 1] = live ? B[k] * dc[1] : 0.f; gsh[3 * k + 2] = live ? B[k] * dc[2] : 0.f;
+            if (live) {
+                const float s = sh[3 * k] * dc[0] + sh[3 * k + 1] * dc[1] + sh[3 * k + 2] * dc[2];
+                ddx += Bx[k] * s; ddy += By[k] * s; ddz += Bz[k] * s;
+            }
+        }
+        // dir = e / |e|
+        const float dd = dirx * ddx + diry * ddy + dirz * ddz;
+        dm[0] += (ddx - dirx * dd) / dlen; dm[1] += (ddy - diry * dd) / dlen; dm[2] += (ddz - dirz * dd) / dlen;
+    } else if (A.g_colors) {
+        A.g_colors[3 * p] = a0.x; A.g_colors[3 * p + 1] = a0.y; A.g_colors[3 * p + 2] = a0.z;
+    }
+    A.g_means[3 * p] = dm[0]; A.g_means[3 * p + 1] = dm[1]; A.g_means[3 * p + 2] = dm[2];
+}
+
+}   // namespace
+
+extern "C" {
+
+int mrgs_surfel_trace_prep_forward(int64_t P, const float* means3D, const float* scales, const float* rotations, const float* opacities,
+                                   const float* shs, int32_t M, int32_t sh_degree, const float* colors_precomp, const float* others,
+                                   const float* campos, float scale_modifier, float* geom, float* attr, float* quad_vertices, void* stream)
+{
+    if (P < 0 || P > (int64_t)1 << 24) return MRGS_E_UNSUPPORTED;
+    if (P == 0) return MRGS_OK;
+    if (!means3D || !scales || !rotations || !opacities || !geom || !attr || (shs == nullptr) == (colors_precomp == nullptr)) return MRGS_E_BAD_ARG;
+    if (shs && (!campos || M < 1 || M > 16 || sh_degree < 0 || sh_degree > 3)) return MRGS_E_BAD_ARG;
+    PrepArgs a = {};
+    a.P = (int)P; a.M = M; a.degree = sh_degree; a.scale_modifier = scale_modifier;
+    a.means = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.shs = shs; a.colors = colors_precomp; a.others = others;
+    a.campos = campos; a.geom = geom; a.attr = attr; a.quads = quad_vertices;
+    hipLaunchKernelGGL(trace_prep_kernel<false>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_surfel_trace_prep_backward(int64_t P, const float* means3D, const float* scales, const float* rotations, const float* shs, int32_t M,
+                                    int32_t sh_degree, const float* campos, float scale_modifier, const float* g_geom, const float* g_attr,
+                                    float* g_means3D, float* g_scales, float* g_rotations, float* g_opacities, float* g_shs,
+                                    float* g_colors_precomp, float* g_others, void* stream)
+{
+    if (P < 0 || P > (int64_t)1 << 24) return MRGS_E_UNSUPPORTED;
+    if (P == 0) return MRGS_OK;
+    if (!means3D || !scales || !rotations || !g_geom || !g_attr || !g_means3D || !g_scales || !g_rotations || !g_opacities) return MRGS_E_BAD_ARG;
+    if (shs && (!campos || !g_shs || M < 1 || M > 16 || sh_degree < 0 || sh_degree > 3)) return MRGS_E_BAD_ARG;
+    PrepArgs a = {};
+    a.P = (int)P; a.M = M; a.degree = sh_degree; a.scale_modifier = scale_modifier;
+    a.means = means3D; a.scales = scales; a.rotations = rotations; a.shs = shs; a.campos = campos;
+    a.g_geom = g_geom; a.g_attr = g_attr; a.g_means = g_means3D; a.g_scales = g_scales; a.g_rotations = g_rotations; a.g_opacities = g_opacities;
+    a.g_shs = g_shs; a.g_colors = g_colors_precomp; a.g_others = g_others;
+    hipLaunchKernelGGL(trace_prep_kernel<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+}   // extern "C"

@@ -96,8 +96,53 @@ class _Trace(torch.autograd.Function):
         return g_o, g_d, g_geom, g_attr, None, None, None
 
 
+class _Prep(torch.autograd.Function):
+    """mrgs_surfel_trace_prep_forward / _backward: (means, scales, rotations, opacities, shs | colours, others) -> geom [P,16], attr [P,8]
+    and get_disks' quad corners [4 P, 3] in one launch; exactly one of shs / colors is a tensor."""
+
+    @staticmethod
+    def forward(ctx, means, scales, rotations, opacities, shs, colors, others, campos, sh_degree, scale_modifier):
+        L = _lib.lib()
+        dev = means.device
+        P = means.shape[0]
+        f = lambda t: None if t is None else t.detach().contiguous().float()
+        means, scales, rotations, opacities, shs, colors, others, campos = map(f, (means, scales, rotations, opacities, shs, colors, others, campos))
+        geom = torch.empty(P, 16, dtype=torch.float32, device=dev)
+        attr = torch.empty(P, 8, dtype=torch.float32, device=dev)
+        quads = torch.empty(4 * P, 3, dtype=torch.float32, device=dev)
+        M = 0 if shs is None else shs.shape[1]
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_surfel_trace_prep_forward(P, _ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs), M, int(sh_degree),
+                                                        _ptr(colors), _ptr(others), _ptr(campos), float(scale_modifier), _ptr(geom), _ptr(attr),
+                                                        _ptr(quads), _stream(dev)))
+        ctx.save_for_backward(means, scales, rotations, shs, campos)
+        ctx.cfg = (M, int(sh_degree), float(scale_modifier), colors is not None, others is not None)
+        ctx.mark_non_differentiable(quads)
+        return geom, attr, quads
+
+    @staticmethod
+    def backward(ctx, g_geom, g_attr, _g_quads):
+        means, scales, rotations, shs, campos = ctx.saved_tensors
+        M, degree, modifier, has_colors, has_others = ctx.cfg
+        L = _lib.lib()
+        dev = means.device
+        P = means.shape[0]
+        z = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
+        g_geom, g_attr = z(g_geom, (P, 16)), z(g_attr, (P, 8))
+        new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        g_means, g_scales, g_rot, g_op = new(P, 3), new(P, 2), new(P, 4), new(P, 1)
+        g_shs = new(P, M, 3) if shs is not None else None
+        g_colors = new(P, 3) if has_colors else None
+        g_others = new(P, 2) if has_others else None
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_surfel_trace_prep_backward(P, _ptr(means), _ptr(scales), _ptr(rotations), _ptr(shs), M, degree, _ptr(campos), modifier,
+                                                         _ptr(g_geom), _ptr(g_attr), _ptr(g_means), _ptr(g_scales), _ptr(g_rot), _ptr(g_op),
+                                                         _ptr(g_shs), _ptr(g_colors), _ptr(g_others), _stream(dev)))
+        return g_means, g_scales, g_rot, g_op, g_shs, g_colors, g_others, None, None, None
+
+
 def surfel_records(means3D, scales, rotations, opacities, colors, others, scale_modifier=1.0):
-    """The per-surfel records of the C ABI from the model's tensors (torch ops: autograd carries the tracer's gradients back)."""
+    """The per-surfel records of the C ABI stated with torch ops (the checker of mrgs_surfel_trace_prep_*; any device)."""
     R = build_rotation(rotations)
     s = scales * scale_modifier
     a = R[:, :, 0] / s[:, 0:1]
@@ -116,6 +161,7 @@ class SurfelTracer(nn.Module):
         self._blob = None
         self._ws = None
         self._n = 0
+        self.build_on_trace = False      # HardwareRendering sets it: build from the corners the record kernel writes (= get_disks')
 
     def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
         """vertices [4 P, 3]: four corners per surfel in get_disks' order; faces are implied by that order (two triangles per quad,
@@ -140,7 +186,7 @@ class SurfelTracer(nn.Module):
     def forward(self, ray_o, ray_d, v=None, means3D=None, grads3D=None, shs=None, colors_precomp=None, others_precomp=None, opacities=None,
                 scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
         ts = tracer_settings
-        if self._blob is None:
+        if self._blob is None and not self.build_on_trace:
             raise RuntimeError("build_acceleration_structure has not been called")
         if cov3D_precomp is not None or scales is None or rotations is None:
             raise NotImplementedError("the tracer intersects surfels from scales / rotations; cov3D_precomp is not supported")
@@ -150,19 +196,18 @@ class SurfelTracer(nn.Module):
             raise RuntimeError("Please provide exactly one of either SHs or precomputed colors!")
         _need_gpu(means3D, "means3D")
         P = means3D.shape[0]
-        if P != self._n:
-            raise RuntimeError("the acceleration structure was built for a different number of surfels")
         shape = ray_o.shape[:-1]
         means = means3D if grads3D is None else means3D + grads3D          # the densification proxy receives d/d means3D
-        if colors_precomp is None:
-            # computeColorFromSH of the rasterizer family (forward.cu:20-81): direction from the settings' camera position
-            dirs = means - ts.campos.reshape(1, 3)
-            dirs = dirs / dirs.norm(dim=1, keepdim=True)
-            colors_precomp = torch.clamp_min(eval_sh(ts.sh_degree, shs.transpose(1, 2), dirs) + 0.5, 0.0)
-        if others_precomp is None:
-            others_precomp = torch.zeros(P, 2, device=means3D.device)
-        geom, attr = surfel_records(means.float(), scales.float(), rotations.float(), opacities.float(), colors_precomp.float(),
-                                    others_precomp.float(), float(ts.scale_modifier))
+        # computeColorFromSH of the rasterizer family (forward.cu:20-81, direction from the settings' camera position), the splat frame
+        # and get_disks' corners: one launch (mrgs_surfel_trace_prep_forward)
+        shs_pm3 = None if shs is None else (shs if shs.shape[-1] == 3 else shs.transpose(1, 2))
+        geom, attr, _quads = _Prep.apply(means, scales, rotations, opacities.reshape(P, 1), shs_pm3, colors_precomp, others_precomp,
+                                         ts.campos.reshape(3), ts.sh_degree, float(ts.scale_modifier))
+        if self.build_on_trace:
+            self.build_acceleration_structure(_quads, None)
+            self.build_on_trace = False
+        if P != self._n:
+            raise RuntimeError("the acceleration structure was built for a different number of surfels")
         o = ray_o.reshape(-1, 3).contiguous().float()
         d = ray_d.reshape(-1, 3).contiguous().float()
         bg3 = tuple(float(x) for x in ts.bg.detach().reshape(-1)[:3].tolist())
@@ -223,7 +268,11 @@ class HardwareRendering(nn.Module):
             viewmatrix=camera.world_view_transform.contiguous(), projmatrix=camera.full_proj_transform.contiguous(),
             sh_degree=pcd.active_sh_degree, campos=camera.camera_center.contiguous(), prefiltered=False, debug=False,
             max_trace_depth=max_trace_depth, specular_threshold=specular_threshold)
-        v, _f = self.build_bvh(pcd, rebuild=self.training)
+        # build_bvh (:68-82) without the torch detour through get_disks: the tracer builds from the corners its record kernel writes
+        if self.training or not self.has_bvh:
+            self.tracer.build_on_trace = True
+            self.has_bvh = not self.training
+        v = None
         means3D, opacities = pcd.get_xyz.contiguous(), pcd.get_opacity.contiguous()
         grads3D = torch.zeros_like(means3D, requires_grad=True) + 0
         try:
