@@ -268,26 +268,43 @@ def _screenspace_points(pc):
     return torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True)
 
 
-def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None):
-    """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour)."""
+def get_distance(scaling_modifier, means3D, viewpoint_camera, pc):
+    """gaussian_renderer/envgs_renderer.py:30-38: |facing normal . centre| in the camera frame, [P,1] (the plane distance the "pgsr"
+    flavour rasterizes as its last feature channel)."""
+    Wv = viewpoint_camera.world_view_transform
+    d = pc.get_xyz - viewpoint_camera.camera_center
+    normal_cam = pc.get_normal(scaling_modifier, d / d.norm(dim=1, keepdim=True)) @ Wv[:3, :3]
+    centre_cam = means3D @ Wv[:3, :3] + Wv[3, :3]
+    return (normal_cam * centre_cam).sum(-1).abs().unsqueeze(-1)
+
+
+def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None, flag="2dgs"):
+    """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour).  flag "pgsr"
+    (arguments/config.py:1): the plane distance of get_distance rides as the one feature channel and comes back as "rend_distance"
+    (:170-176, 215-218) -- blended by the vendored rasterizer's rule; the pgsr flavour's unbiased-depth all-map channel is not
+    reproduced."""
     means2D = _screenspace_points(pc)
+    dist_feature = get_distance(scaling_modifier, pc.get_xyz, viewpoint_camera, pc) if flag != "2dgs" else None
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
     shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
-        means3D=pc.get_xyz, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=None, opacities=pc.get_opacity,
+        means3D=pc.get_xyz, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=dist_feature, opacities=pc.get_opacity,
         scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
     reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe)
     final_image = rendered_image
     if srgb:
         final_image = linear_to_srgb(final_image)
     final_image = final_image + bg_color[:, None, None] * (1 - reg["render_alpha"])
-    return {"render": final_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
-            "rend_alpha": reg["render_alpha"], "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"],
-            "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    out = {"render": final_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+           "rend_alpha": reg["render_alpha"], "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"],
+           "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if flag != "2dgs":
+        out["rend_distance"] = rendered_features[0:1]
+    return out
 
 
 def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None,
-                  wo_render_img=False, normal_img_map=None):
+                  wo_render_img=False, normal_img_map=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:225-483: per-gaussian material channels (S = 8: refl 1, roughness 1, albedo 3, indirect 3)
     blended by the rasterizer, then deferred split-sum shading."""
     if opt is None:
@@ -300,10 +317,14 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     # activations, facing normal, mirror direction, indirect radiance along it and the feature concat (__init__.py:338-355):
     # one HIP kernel each way
     opacities, scales, rotations, features = surfel_features(pc, viewpoint_camera.camera_center)
+    if flag != "2dgs":          # "pgsr": + the plane distance as a ninth channel, back as "rend_distance" (:348-355, 411-413, 478-480)
+        features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
 
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
         scales=scales, rotations=rotations, cov3D_precomp=None)
+    rend_distance = rendered_features[8:9] if flag != "2dgs" else None
+    rendered_features = rendered_features[:8]
 
     base_color = rendered_image
     refl_strength, roughness_map = rendered_features[:1], rendered_features[1:2]
@@ -314,6 +335,8 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
     geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": render_normal, "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if rend_distance is not None:
+        geo["rend_distance"] = rend_distance
     if wo_render_img:
         return {"refl_strength_map": refl_strength, "base_color_map": albedo, "roughness_map": roughness_map, **geo}
 
@@ -341,7 +364,7 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     return out
 
 
-def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None):
+def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:521-749: every gaussian is shaded on its own (per-gaussian normal, mirror direction, split-sum
     weight, environment lookups: utils/refl_utils.py:426-484) and the rasterizer blends the shaded colour (`colors_precomp =
     specular + diffuse`) plus S = 11 material channels (roughness, refl, diffuse 3, specular 3, ori_color 3; 18 with opt.indirect:
@@ -375,6 +398,8 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
                                                   viewpoint_camera.T, normals.contiguous(), opacity, refl_strength=refl, roughness=roughness)
         features = torch.cat((roughness, refl, diffuse, specular, ori_color), dim=-1)
     colors_precomp = specular + diffuse
+    if flag != "2dgs":          # "pgsr": + the plane distance as the last channel, back as "rend_distance" (:657-661, 744-746)
+        features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, features=features, opacities=opacity, scales=scales,
         rotations=rotations, cov3D_precomp=None)
@@ -394,6 +419,8 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
            "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
     if indirect_on:
         out.update({"visibility": rendered_features[11:12], "indirect_light": rendered_features[12:15], "direct_light": rendered_features[15:18]})
+    if flag != "2dgs":
+        out["rend_distance"] = rendered_features[-1:]
     return out
 
 
@@ -446,16 +473,6 @@ def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_c
     results["render"] = results["render"] * (1 - specular) + specular * traced["render"]
     results["indirect_out"] = traced
     return results
-
-
-def get_distance(scaling_modifier, means3D, viewpoint_camera, pc):
-    """gaussian_renderer/envgs_renderer.py:30-38: |facing normal . centre| in the camera frame, [P,1] (the plane distance the "pgsr"
-    flavour rasterizes as its last feature channel)."""
-    Wv = viewpoint_camera.world_view_transform
-    d = pc.get_xyz - viewpoint_camera.camera_center
-    normal_cam = pc.get_normal(scaling_modifier, d / d.norm(dim=1, keepdim=True)) @ Wv[:3, :3]
-    centre_cam = means3D @ Wv[:3, :3] + Wv[3, :3]
-    return (normal_cam * centre_cam).sum(-1).abs().unsqueeze(-1)
 
 
 def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,

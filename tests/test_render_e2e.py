@@ -233,3 +233,32 @@ def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb):
     print("\n".join(f"{n:18s} max-norm err {m:.2e}  max|g| {gm:.3e}" for n, m, gm in rows))
     for n, m, gm in rows:
         assert m <= 3e-4, (n, m)
+
+
+@pytest.mark.gpu
+def test_pgsr_flag_adds_the_plane_distance_channel(gpu_device):
+    """arguments/config.py:1 ships FLAG = "pgsr": every render function rasterizes get_distance (gaussian_renderer/__init__.py:30-40) as
+    its last feature channel and returns it as "rend_distance" (:215-218, 411-413, 478-480, 744-746).  The other maps do not change,
+    and the channel equals a separate rasterization of that one quantity."""
+    from materialrefgs_amd import renderer
+    from materialrefgs_amd.rasterizer import GaussianRasterizer
+    dev = gpu_device
+    P, H, W = 1200, 40, 56
+    _, _, pc, _env = _models(P, H, W, seed=5, dev=dev)
+    pc.env_map_2 = pc.env_map
+    cam = orbit_camera(2, H, W).to(dev)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    d = renderer.get_distance(1.0, pc.get_xyz, cam, pc)
+    assert d.shape == (P, 1) and float(d.min()) >= 0
+    rast = GaussianRasterizer(raster_settings=renderer._raster_settings(cam, pc, pipe, bg, 1.0))
+    alone = rast(means3D=pc.get_xyz, means2D=torch.zeros_like(pc.get_xyz), shs=pc.get_features, opacities=pc.get_opacity, scales=pc.get_scaling,
+                 rotations=pc.get_rotation, features=d)[2]
+    for fn, kw in ((renderer.render_initial, {}), (renderer.render_surfel, {"opt": SimpleNamespace(indirect=False)}),
+                   (renderer.render_volume, {"opt": SimpleNamespace(indirect=False)})):
+        a = fn(cam, pc, pipe, bg, srgb=False, **kw)
+        b = fn(cam, pc, pipe, bg, srgb=False, flag="pgsr", **kw)
+        assert "rend_distance" not in a and b["rend_distance"].shape == (1, H, W), fn.__name__
+        assert float((b["rend_distance"] - alone).abs().max()) < 2e-5 * max(1.0, float(alone.abs().max())), fn.__name__
+        for k in ("render", "rend_alpha", "rend_normal", "surf_depth"):
+            assert float((a[k] - b[k]).abs().max()) < 2e-6, (fn.__name__, k)
