@@ -159,6 +159,7 @@ MrgsBinWs mrgs_carve_bin(void* base, int64_t R)
     b.sort_ws = c.take<uint32_t>(16 + mrgs_sort_ws_words((int64_t)n));
     b.sort_ws_bytes = sizeof(uint32_t) * (16 + mrgs_sort_ws_words((int64_t)n));
     b.qmask = c.take<uint8_t>(n);
+    b.cflag = c.take<uint8_t>(4 * n);
     b.total = mrgs_align_up(c.used, 256);
     return b;
 }
@@ -271,7 +272,7 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     STAGE_CHECK(cfg, stream);
 
     StageTimer t1(stream, ST_FWD);
-    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], b.qmask, img, out_color, out_feature, out_others, stream);
+    mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], b.qmask, b.cflag, img, out_color, out_feature, out_others, stream);
     t1.stop();
     STAGE_CHECK(cfg, stream);
     return MRGS_OK;
@@ -412,7 +413,7 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     if (R > 0) {
         // (the gradient rows are cleared by spare workgroups of the ordering launch; mrgs_grad_bytes is a multiple of 256)
         if (!prepared) mrgs_launch_blend_order(img, g.counters + 16, tiles_x * tiles_y, 1, grad_rec, mrgs_grad_bytes(cfg->P, cfg->S), nullptr, stream);
-        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.qmask, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, prepared, stream);
+        mrgs_launch_render_bwd(*cfg, *in, g, b.plist[cur], b.cflag, img, dL_dout_color, dL_dout_feature, dL_dout_others, grad_rec, prepared, stream);
     } else if (!prepared) {
         HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
     }

@@ -82,6 +82,7 @@ struct MrgsBinWs {
     uint32_t* sort_ws;      // [16] 0: error flag; then tickets / digit totals / status words of the tile-id sort; cleared per forward
     size_t sort_ws_bytes;
     uint8_t* qmask;         // [R] bit q: the entry's surfel can touch quadrant q of its tile (tile_ranges_kernel)
+    uint8_t* cflag;         // [R][4] written by the forward blend: 1 = some pixel of quadrant q blended the entry (the backward walks only these)
     size_t total;
 };
 
@@ -153,9 +154,9 @@ void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int n
                              hipStream_t stream);
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const uint8_t* qmask, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);
+                            const uint8_t* qmask, uint8_t* cflag, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream);
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const uint8_t* qmask, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
+                            const uint8_t* cflag, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
                             float* grad_rec, bool forward_queues, hipStream_t stream);
 
 #ifndef MRGS_EXP

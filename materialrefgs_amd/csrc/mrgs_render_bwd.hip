@@ -185,7 +185,7 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? MRGS_BWD_WPE0 : S_MAX <= 8 ? MRGS_BWD_WPE8 : 2, 8))) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
-    const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
+    const uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride, int slots)
@@ -266,7 +266,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     // Same staging pipeline as the forward (LDS-DMA, cull conics two chunks and ids three chunks ahead), walked
     // towards the front of the list.  The id slot of a staged entry holds the BYTE offset of the surfel's gradient row.
     const uint32_t* plist = point_list + range.x;
-    const uint8_t* qm = qmask + range.x;
+    // the forward's flag of this quadrant for every list entry: 1 = some pixel of the block blended it.  Only those are walked -- an
+    // entry no pixel blended has `active` false in every lane and would leave after its intersection test
+    const uint8_t* qm = cflag + (size_t)range.x * 4 + quad;
     const ReduceLane rl = mrgs_reduce_lane(lane);
     const uint32_t row_bytes = (uint32_t)gstride * 4u;
     const int c_top = (max_contrib - 1) / MRGS_CHUNK;
@@ -276,10 +278,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     uint64_t mask_cur;
     {
         uint32_t id0 = 0, q0 = 0;
-        if (c_top * MRGS_CHUNK + lane < max_contrib) { id0 = plist[c_top * MRGS_CHUNK + lane]; q0 = qm[c_top * MRGS_CHUNK + lane]; }
-        if (c_top >= 1) idq1 = plist[(c_top - 1) * MRGS_CHUNK + lane] | ((uint32_t)qm[(c_top - 1) * MRGS_CHUNK + lane] << 28);
-        if (c_top >= 2) idq2 = plist[(c_top - 2) * MRGS_CHUNK + lane] | ((uint32_t)qm[(c_top - 2) * MRGS_CHUNK + lane] << 28);
-        const bool cand0 = (q0 >> quad) & 1u;
+        if (c_top * MRGS_CHUNK + lane < max_contrib) { id0 = plist[c_top * MRGS_CHUNK + lane]; q0 = qm[(size_t)(c_top * MRGS_CHUNK + lane) * 4]; }
+        if (c_top >= 1) idq1 = plist[(c_top - 1) * MRGS_CHUNK + lane] | ((uint32_t)qm[(size_t)((c_top - 1) * MRGS_CHUNK + lane) * 4] << 28);
+        if (c_top >= 2) idq2 = plist[(c_top - 2) * MRGS_CHUNK + lane] | ((uint32_t)qm[(size_t)((c_top - 2) * MRGS_CHUNK + lane) * 4] << 28);
+        const bool cand0 = q0 & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         mrgs_stage_async<S_MAX, SF, FV>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
@@ -291,14 +293,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         WS_CHUNK();
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
-            const bool cand1 = (idq1 >> (28 + quad)) & 1u;
+            const bool cand1 = (idq1 >> 28) & 1u;
             const uint32_t id1 = idq1 & 0x0FFFFFFFu;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
             idq1 = idq2;
             idq2 = 0;
-            if (c >= 3) idq2 = plist[(c - 3) * MRGS_CHUNK + lane] | ((uint32_t)qm[(c - 3) * MRGS_CHUNK + lane] << 28);
+            if (c >= 3) idq2 = plist[(c - 3) * MRGS_CHUNK + lane] | ((uint32_t)qm[(size_t)((c - 3) * MRGS_CHUNK + lane) * 4] << 28);
         };
         if (MRGS_BWD_STAGES == 2) stage_next();
 
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 }
 
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const uint8_t* qmask, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
+                            const uint8_t* cflag, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
                             float* grad_rec, bool forward_queues, hipStream_t stream)
 {
     // forward_queues: the forward set the backward's queue state up as a copy of its own (MrgsRasterInputs::bwd_grad_ws): same dealing,
@@ -451,7 +453,7 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV, GS)                                                                                                       \
-    hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.blend_state, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<render_bwd_kernel<SM, FVV>>())
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);

@@ -35,7 +35,7 @@ extern "C" int mrgs_wave_stats_fwd(unsigned long long* host, int n)
 template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
-    const uint8_t* __restrict__ qmask, int S, int W, int H, int tiles_x, int ntiles,
+    const uint8_t* __restrict__ qmask, uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
     uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */,
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     // (the block-level cull was evaluated once per entry and quadrant by tile_ranges_kernel: bit `quad` of qmask)
     const uint32_t* plist = point_list + range.x;
     const uint8_t* qm = qmask + range.x;
+    uint8_t* cf = cflag + (size_t)range.x * 4 + quad;       // this quadrant's "blended by some pixel" flag of every list entry
     uint32_t id1 = 0, id2 = 0, q1 = 0, q2 = 0;
     uint64_t mask_cur;
     {
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         uint64_t m = mask_cur;
         work += (uint32_t)__builtin_popcountll(m);
         const StageBuf<SF>& sb = stage[c % MRGS_FWD_STAGES];
+        uint64_t contributed = 0ull;          // bit j: some live pixel of the block is hit by entry base + j
 
         // One list entry (forward.cu:358-442).  Branch-free across lanes: a lane that does not blend this entry (no hit,
         // pixel already terminated, or terminating right now) runs the accumulation with alpha = 0 -- every sum gets
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             ws_blend++;
 #endif
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
+            contributed |= 1ull << j;          // (a superset of "blended": a pixel may terminate on it instead; the backward sorts that out)
             const float test_T = T * (1.0f - h.alpha);
             const bool term = ok & (test_T < MRGS_T_MIN);     // forward.cu:400-404: the pixel stops BEFORE blending this entry
             done |= term;
@@ -190,6 +193,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
                 j = jn;
             }
         }
+        // the backward walks exactly the entries flagged here: for every other entry all of its gradient terms are zeros
+        // (no pixel of the block blended it), so skipping it there is bit-identical and saves the staging and the intersection
+        if (base + lane < total) cf[(size_t)(base + lane) * 4] = (uint8_t)((contributed >> lane) & 1ull);
         if (MRGS_FWD_STAGES == 1) stage_next();
         mask_cur = mask_nxt;
     }
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 }
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
-                            const uint8_t* qmask, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream)
+                            const uint8_t* qmask, uint8_t* cflag, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int ntiles = tiles_x * tiles_y;
@@ -244,7 +250,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
-    hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<render_fwd_kernel<SM, FVV>>())
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
