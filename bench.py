@@ -44,6 +44,8 @@ WORKLOADS = {
     # the last training stage of the reference (train_refnerf.py:1501-1504): render_surfel, then the same surfels traced along every pixel's
     # mirror ray (HardwareRendering, gaussian_renderer/__init__.py:486-520) and blended in; hierarchy rebuilt every view as in training
     "C3trace": (300000, 800, 800, 8, "C3 shell scene through render_surfel_with_envgs: render_surfel + surfel-traced mirror rays of all 800x800 pixels (hierarchy rebuilt per view), fwd+bwd"),
+    # BASELINE.json configs[3] with the traced reflection term: C4 size through render_surfel_with_envgs
+    "C4trace": (1000000, 1600, 1600, 8, "C4-size shell scene through render_surfel_with_envgs: P=1000000, 1600x1600, render_surfel + surfel-traced mirror rays of all 2.56 M pixels (hierarchy rebuilt per view), fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
 }
 SCENE_KW = {"C2heavy": dict(radius_px=6.5, scale_sigma=0.8)}
@@ -175,8 +177,8 @@ def main():
             debug=False))
     g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
 
-    surfel_mode = args.workload in ("C3full", "C3train", "C4full", "C3trace")
-    traced = args.workload == "C3trace"
+    surfel_mode = args.workload in ("C3full", "C3train", "C4full", "C3trace", "C4trace")
+    traced = args.workload in ("C3trace", "C4trace")
     use_loss = args.workload in ("C3train", "C4full")
     indirect = args.workload == "C4full"
     if surfel_mode:

@@ -34,6 +34,7 @@ if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C4raster --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4raster.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C4full --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4full.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C3trace --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C3trace.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C4trace --steps 30 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_C4trace.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 mirror > $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 primary >> $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
   cd /tmp
