@@ -363,12 +363,13 @@ int mrgs_bvh_visibility(const void* blob_dev, int64_t n_triangles, int32_t H, in
  * row (same results, shorter walks); the trace calls write the surfel records in leaf order into the blob (not const); geom [n_surfels,16] per surfel
  * (mean.xyz, a.xyz, b.xyz, n.xyz, opacity, 3 unused) with a = r_u / s_u, b = r_v / s_v, n = r_u x r_v; attr [n_surfels,8] =
  * (rgb, others[2], 3 unused).  Outputs rgb / norm [n_rays,3], dpt / acc / dist [n_rays], aux [n_rays,2], wet [n_surfels] (summed
- * blend weight per surfel, cleared by the call), state [mrgs_surfel_trace_state_floats(n_rays)] (per ray: sum w t^2, final transmittance, hits blended, passes -- negative when the ray walked in a packet --; behind them the list of the rays traced one per wavefront: what the
+ * blend weight per surfel, cleared by the call), state [mrgs_surfel_trace_state_floats(n_rays, ray_width)] (per ray: sum w t^2, final transmittance, hits blended, passes -- negative when the ray walked in a packet --; behind them the list of the rays traced one per wavefront and the record of the ids every wavefront gathered, pass by pass, which the
+ * backward replays instead of walking the hierarchy again (4 KB per wavefront and pass; when it overflows the backward walks): what the
  * backward needs beyond the outputs).  Backward: g_* of the six outputs in, g_geom [n_surfels,16] / g_attr [n_surfels,8] (cleared by
  * the call, same layout as geom / attr) and g_ray_o / g_ray_d [n_rays,3] out. */
 size_t mrgs_surfel_bvh_bytes(int64_t n_surfels);
 size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels);
-size_t mrgs_surfel_trace_state_floats(int64_t n_rays);
+size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width);
 int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* blob, size_t blob_bytes, void* ws, size_t ws_bytes, void* stream);
 int mrgs_surfel_trace_forward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
                               const float* attr, const float* bg_host, float* rgb, float* dpt, float* acc, float* norm, float* dist,

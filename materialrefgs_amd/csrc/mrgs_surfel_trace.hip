@@ -54,6 +54,9 @@ constexpr int ST_MAX_PASSES = 256;        // 4096 hits per ray at most
 constexpr float ST_EXTENT = 3.0f;         // optix_utils.py:44 (3-sigma quad)
 constexpr int ST_AABB_BLOCKS = 256;
 
+constexpr int ST_REC_STATIC = 3;          // chunks of the hit record every wave owns; further passes draw from a shared pool
+constexpr int ST_REC_PASSES = 16;         // passes of a wave the record can hold (beyond: the backward traces again)
+constexpr uint32_t ST_REC_NONE = 0xFFFFFFFFu;
 constexpr int SW_MAX_LEVELS = 4;          // 64^4 surfels
 struct StWide {
     int32_t n;                            // levels; level 0 holds surfels (sorted position 64 g + c), the root is node 0 of level n-1
@@ -212,6 +215,10 @@ struct StArgs {
     int32_t ray_width;                    // > 0: rays form rows of this length and a wave takes an 8x8 block of them
     int32_t packets;                      // waves whose rays run together walk the wide hierarchy as one (st_gather_wide)
     StWide wide;
+    // the forward's record of what every wave gathered, pass by pass (ids, [slot][lane] like the LDS buffer): the backward replays it
+    // instead of walking the hierarchy again.  hdr[0] chunks drawn from the pool, hdr[1] overflow flag (then the backward traces).
+    uint32_t *rec_hdr, *rec_chunks, *rec_arena;
+    uint32_t rec_pool;                    // chunks in the shared pool (behind the n_waves * ST_REC_STATIC owned ones)
     uint32_t* lone_list;                  // [0] count, [16..] indices of the rays that walk alone (behind the per-ray state)
     float cone;                           // 1 - cos of the half-angle within which a packet's directions must stay
     const float4* attr;                   // [P][2]: (rgb, others.x) (others.y, -, -, -)
@@ -583,13 +590,18 @@ __global__ __launch_bounds__(256) void st_leaf_order_kernel(int n_slots, int P, 
     geom_leaf[i] = v;
 }
 
-template <bool BWD>
+// MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again (no record, or it overflowed);
+// 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same order, no hierarchy.
+template <int MODE>
 __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
                                                               const unsigned long long* __restrict__ wide_vmask)
 {
+    constexpr bool BWD = MODE != 0;
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
     __shared__ float kb_t[ST_K][ST_THREADS];
+    if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
+    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6);
     int64_t r = (int64_t)blockIdx.x * ST_THREADS + tid;
     if (A.ray_width > 0) {                 // 8x8 blocks of neighbouring rays per wave: neighbours walk the same nodes
         const int64_t tiles_x = (A.ray_width + 7) >> 3, rows = A.n_rays / A.ray_width, tile = r >> 6;
@@ -628,11 +640,17 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     // a ray without a direction (or with a non-finite one) would visit every node: it sees the background
     bool done = !(exists && fabsf(ox) < 1e30f && fabsf(oy) < 1e30f && fabsf(oz) < 1e30f && fabsf(dx) < 1e30f && fabsf(dy) < 1e30f &&
                   fabsf(dz) < 1e30f && (dx != 0.0f || dy != 0.0f || dz != 0.0f));
-    uint32_t packets_present;
-    const int packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
-    // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
-    const bool lone = !done && packet < 0;
-    if (!BWD) {
+    uint32_t packets_present = 0;
+    int packet = -1;
+    bool lone;
+    if (MODE == 2) {
+        lone = exists && A.state[4 * r + 3] > 0.0f;        // the forward's pass count is positive for the rays its second kernel traced
+    } else {
+        packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
+        // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
+        lone = !done && packet < 0;
+    }
+    if (MODE == 0) {
         const unsigned long long lm = __ballot(lone);
         if (lm) {
             const int first = __builtin_ctzll(lm), lane = tid & 63;
@@ -647,22 +665,55 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     for (int pass = 0; pass < ST_MAX_PASSES; ++pass) {
         if (__ballot(want) == 0) break;
         int n = 0;
-        for (uint32_t left = packets_present; left; left &= left - 1) {          // wave-uniform: one walk per packet
-            const int pk = __builtin_ctz(left);
-            const bool mine = want && packet == pk;
-            const int got = st_gather_wide(A.wide, wide_boxes, wide_vmask, leaf_ro, kb_id, kb_t, tid, ox, oy, oz, dx, dy, dz, ivx, ivy, ivz, prev_t,
-                                           prev_id, pass == 0, mine, prof);
-            if (mine) n = got;
+        if (MODE == 2) {
+            if (pass >= ST_REC_PASSES) break;
+            const uint32_t chunk = A.rec_chunks[wave * ST_REC_PASSES + pass];
+            if (chunk == ST_REC_NONE) break;
+            const uint32_t* src = A.rec_arena + (size_t)chunk * (ST_K * 64) + (tid & 63);
+#pragma unroll
+            for (int j = 0; j < ST_K; ++j) {
+                const uint32_t id = src[j * 64];
+                kb_id[j][tid] = id;
+                if (id != ST_REC_NONE) n = j + 1;
+            }
+        } else {
+            for (uint32_t left = packets_present; left; left &= left - 1) {          // wave-uniform: one walk per packet
+                const int pk = __builtin_ctz(left);
+                const bool mine = want && packet == pk;
+                const int got = st_gather_wide(A.wide, wide_boxes, wide_vmask, leaf_ro, kb_id, kb_t, tid, ox, oy, oz, dx, dy, dz, ivx, ivy, ivz, prev_t,
+                                               prev_id, pass == 0, mine, prof);
+                if (mine) n = got;
+            }
+        }
+        if (MODE == 0 && A.rec_arena != nullptr) {
+            // the record of this pass: the wave's own chunks first, then one drawn from the pool (one atomic per wave and late pass)
+            uint32_t chunk = ST_REC_NONE;
+            if (pass < ST_REC_STATIC) {
+                chunk = wave * ST_REC_STATIC + pass;
+            } else if (pass < ST_REC_PASSES) {
+                uint32_t got = 0;
+                if ((tid & 63) == 0) got = atomicAdd(A.rec_hdr, 1u);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                if (got < A.rec_pool) chunk = gridDim.x * (ST_THREADS / 64) * ST_REC_STATIC + got;
+            }
+            if (chunk != ST_REC_NONE) {
+                if ((tid & 63) == 0) A.rec_chunks[wave * ST_REC_PASSES + pass] = chunk;
+                uint32_t* dst = A.rec_arena + (size_t)chunk * (ST_K * 64) + (tid & 63);
+#pragma unroll
+                for (int j = 0; j < ST_K; ++j) dst[j * 64] = (want && j < n) ? kb_id[j][tid] : ST_REC_NONE;
+            } else if ((tid & 63) == 0) {
+                A.rec_hdr[1] = 1u;                 // the backward walks again
+            }
         }
         if (!want) continue;
         ++passes;
         for (int j = 0; j < n && !done; ++j) {
             const uint32_t id = kb_id[j][tid];
-            const float t = kb_t[j][tid];
             const float4* g = A.geom + (size_t)id * 4;
             const float4 g0 = g[0], g1 = g[1], g2 = g[2];
             const float opacity = g[3].x;
             const StHit h = st_hit(g0, g1, g2, opacity, ox, oy, oz, dx, dy, dz);      // same expression, same operands as in the gather
+            const float t = MODE == 2 ? h.t : kb_t[j][tid];                           // (the same number)
             const float alpha = h.alpha;
             const float test_T = T * (1.0f - alpha);
             if (test_T < 0.0001f) { done = true; break; }
@@ -708,8 +759,10 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
             ++blended;
         }
         if (n < ST_K || done) { want = false; continue; }
-        prev_t = kb_t[ST_K - 1][tid];
-        prev_id = kb_id[ST_K - 1][tid];
+        if (MODE != 2) {
+            prev_t = kb_t[ST_K - 1][tid];
+            prev_id = kb_id[ST_K - 1][tid];
+        }
     }
     if (!exists || lone) return;
     if (!BWD) {
@@ -982,7 +1035,25 @@ size_t mrgs_surfel_bvh_bytes(int64_t n_surfels)
     return st_blob(n_surfels).total;
 }
 
-size_t mrgs_surfel_trace_state_floats(int64_t n_rays) { return n_rays < 0 ? 0 : (size_t)(5 * n_rays + 16); }
+struct StateLayout { int64_t grid, n_waves; size_t lone, rec_hdr, rec_chunks, rec_arena, total; uint32_t pool; };
+
+static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte words
+{
+    StateLayout L;
+    int64_t threads = n_rays;
+    if (ray_width > 0 && n_rays % ray_width == 0) threads = (int64_t)((ray_width + 7) / 8) * ((n_rays / ray_width + 7) / 8) * 64;
+    L.grid = (threads + ST_THREADS - 1) / ST_THREADS;
+    L.n_waves = L.grid * (ST_THREADS / 64);
+    L.pool = (uint32_t)(L.n_waves + 64);
+    L.lone = (size_t)4 * n_rays;                                     // [0] count, [16..] ray indices
+    L.rec_hdr = L.lone + 16 + (size_t)n_rays;
+    L.rec_chunks = L.rec_hdr + 16;
+    L.rec_arena = L.rec_chunks + (size_t)L.n_waves * ST_REC_PASSES;
+    L.total = L.rec_arena + ((size_t)L.n_waves * ST_REC_STATIC + L.pool) * (ST_K * 64);
+    return L;
+}
+
+size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).total; }
 
 size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels)
 {
@@ -1035,13 +1106,26 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     a.packets = no_packets ? 0 : 1;
     static const char* cone_env = getenv("MRGS_TRACE_CONE");
     a.cone = cone_env ? (float)atof(cone_env) : 0.02f;
-    int64_t threads = n_rays;
-    if (a.ray_width > 0) threads = (int64_t)((a.ray_width + 7) / 8) * ((n_rays / a.ray_width + 7) / 8) * 64;
-    const dim3 grid((unsigned)((threads + ST_THREADS - 1) / ST_THREADS));
-    a.lone_list = reinterpret_cast<uint32_t*>(a.state + 4 * n_rays);
-    if (!bwd && hipMemsetAsync(a.lone_list, 0, 64, st) != hipSuccess) return MRGS_E_HIP;
-    if (bwd) hipLaunchKernelGGL(st_trace_kernel<true>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
-    else hipLaunchKernelGGL(st_trace_kernel<false>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+    const StateLayout SL = st_state(n_rays, a.ray_width);
+    const dim3 grid((unsigned)SL.grid);
+    uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
+    a.lone_list = words + SL.lone;
+    a.rec_hdr = words + SL.rec_hdr;
+    a.rec_chunks = words + SL.rec_chunks;
+    a.rec_arena = words + SL.rec_arena;
+    a.rec_pool = SL.pool;
+    static const bool no_record = getenv("MRGS_TRACE_NO_RECORD") != nullptr;          // developer switch: the backward always walks again
+    if (!bwd) {
+        if (hipMemsetAsync(a.lone_list, 0, 64, st) != hipSuccess || hipMemsetAsync(a.rec_hdr, 0, 64, st) != hipSuccess ||
+            hipMemsetAsync(a.rec_chunks, 0xFF, (size_t)SL.n_waves * ST_REC_PASSES * 4, st) != hipSuccess)
+            return MRGS_E_HIP;
+        if (no_record) { a.rec_arena = nullptr; (void)hipMemsetAsync(a.rec_hdr + 1, 0x01, 4, st); }
+        hipLaunchKernelGGL(st_trace_kernel<0>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+    } else {
+        // exactly one of the two does the work: the replay of the forward's record, or -- when the record overflowed -- the walk
+        hipLaunchKernelGGL(st_trace_kernel<2>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        hipLaunchKernelGGL(st_trace_kernel<1>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+    }
     const dim3 lgrid((unsigned)(n_rays < 16384 ? n_rays : 16384));
     if (bwd) hipLaunchKernelGGL(st_trace_lone_kernel<true>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
     else hipLaunchKernelGGL(st_trace_lone_kernel<false>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);

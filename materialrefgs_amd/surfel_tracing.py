@@ -65,7 +65,7 @@ class _Trace(torch.autograd.Function):
         n_rays, P = ray_o.shape[0], geom.shape[0]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         rgb, norm, aux, dpt, acc, dist = new(n_rays, 3), new(n_rays, 3), new(n_rays, 2), new(n_rays), new(n_rays), new(n_rays)
-        wet, state = new(P), new(L.mrgs_surfel_trace_state_floats(n_rays))
+        wet, state = new(P), new(L.mrgs_surfel_trace_state_floats(n_rays, ray_width))
         bg = (ctypes.c_float * 3)(*bg3)
         with torch.cuda.device(dev):
             _lib.check(L.mrgs_surfel_trace_forward(_ptr(blob), P, n_rays, ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
