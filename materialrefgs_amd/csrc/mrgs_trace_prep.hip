@@ -97,6 +97,14 @@ __global__ __launch_bounds__(256) void trace_prep_kernel(PrepArgs A)
     if (!BWD) {
         if (from_sh) {
             const float* sh = A.shs + (size_t)p * A.M * 3;
+            if (A.M == 16) {          // the 192-byte row with twelve 16-byte loads (a 4-byte load per coefficient walks 48 cache lines per wave)
+                float row[48];
+                const float4* sh4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { const float4 v = sh4[i]; row[4 * i] = v.x; row[4 * i + 1] = v.y; row[4 * i + 2] = v.z; row[4 * i + 3] = v.w; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { rgb[0] += B[k] * row[3 * k]; rgb[1] += B[k] * row[3 * k + 1]; rgb[2] += B[k] * row[3 * k + 2]; }   // B[k] = 0 beyond the degree
+            } else
             for (int k = 0; k < ncoef; ++k) { rgb[0] += B[k] * sh[3 * k]; rgb[1] += B[k] * sh[3 * k + 1]; rgb[2] += B[k] * sh[3 * k + 2]; }
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(rgb[c] + 0.5f, 0.0f);
@@ -151,9 +159,28 @@ __global__ __launch_bounds__(256) void trace_prep_kernel(PrepArgs A)
         const float* sh = A.shs + (size_t)p * A.M * 3;
         float* gsh = A.g_shs + (size_t)p * A.M * 3;
         float val[3] = {0.5f, 0.5f, 0.5f};
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        if (A.M == 16) {              // vector loads and stores of the two 192-byte rows
+            float row[48];
+            const float4* sh4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { const float4 v = sh4[i]; row[4 * i] = v.x; row[4 * i + 1] = v.y; row[4 * i + 2] = v.z; row[4 * i + 3] = v.w; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { val[0] += B[k] * row[3 * k]; val[1] += B[k] * row[3 * k + 1]; val[2] += B[k] * row[3 * k + 2]; }
+            const float dcv[3] = {val[0] >= 0.f ? a0.x : 0.f, val[1] >= 0.f ? a0.y : 0.f, val[2] >= 0.f ? a0.z : 0.f};
+            float out[48];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                out[3 * k] = B[k] * dcv[0]; out[3 * k + 1] = B[k] * dcv[1]; out[3 * k + 2] = B[k] * dcv[2];
+                const float sdot = row[3 * k] * dcv[0] + row[3 * k + 1] * dcv[1] + row[3 * k + 2] * dcv[2];
+                ddx += Bx[k] * sdot; ddy += By[k] * sdot; ddz += Bz[k] * sdot;
+            }
+            float4* g4 = reinterpret_cast<float4*>(gsh);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) g4[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+        } else {
         for (int k = 0; k < ncoef; ++k) { val[0] += B[k] * sh[3 * k]; val[1] += B[k] * sh[3 * k + 1]; val[2] += B[k] * sh[3 * k + 2]; }
         const float dc[3] = {val[0] >= 0.f ? a0.x : 0.f, val[1] >= 0.f ? a0.y : 0.f, val[2] >= 0.f ? a0.z : 0.f};
-        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
         for (int k = 0; k < A.M; ++k) {
             const bool live = k < ncoef;
             gsh[3 * k] = live ? B[k] * dc[0] : 0.f; gsh[3 * k + 1] = live ? B[k] * dc[1] : 0.f; gsh[3 * k + 2] = live ? B[k] * dc[2] : 0.f;
@@ -161,6 +188,7 @@ __global__ __launch_bounds__(256) void trace_prep_kernel(PrepArgs A)
                 const float s = sh[3 * k] * dc[0] + sh[3 * k + 1] * dc[1] + sh[3 * k + 2] * dc[2];
                 ddx += Bx[k] * s; ddy += By[k] * s; ddz += Bz[k] * s;
             }
+        }
         }
         // dir = e / |e|
         const float dd = dirx * ddx + diry * ddy + dirz * ddz;
