@@ -218,7 +218,11 @@ struct StArgs {
     // the forward's record of what every wave gathered, pass by pass (ids, [slot][lane] like the LDS buffer): the backward replays it
     // instead of walking the hierarchy again.  hdr[0] chunks drawn from the pool, hdr[1] overflow flag (then the backward traces).
     uint32_t *rec_hdr, *rec_chunks, *rec_arena;
-    uint32_t rec_pool;                    // chunks in the shared pool (behind the n_waves * ST_REC_STATIC owned ones)
+    uint32_t rec_pool;                    // chunks in the shared pool (behind the n_tiles * ST_REC_STATIC owned ones)
+    uint32_t rec_static;                  // n_tiles * ST_REC_STATIC: where the pool starts
+    uint32_t n_tiles;                     // waves of the first launch (one 8x8 block of rays each)
+    uint32_t* defer_list;                 // [0] count, [16..] (tile << 5 | packet): the packets traced by the second launch, one per wave
+    uint32_t defer_cap;
     uint32_t* lone_list;                  // [0] count, [16..] indices of the rays that walk alone (behind the per-ray state)
     float cone;                           // 1 - cos of the half-angle within which a packet's directions must stay
     const float4* attr;                   // [P][2]: (rgb, others.x) (others.y, -, -, -)
@@ -592,19 +596,21 @@ __global__ __launch_bounds__(256) void st_leaf_order_kernel(int n_slots, int P, 
 
 // MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again (no record, or it overflowed);
 // 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same order, no hierarchy.
+constexpr uint32_t ST_REC_DEFERRED = 0xFFFFFFFEu;   // in the last slot of a block's row of the chunk table: its packets went to the second launch
+
+// One 8x8 block of rays (64 consecutive rays when the rays are no image).  only_packet < 0: the first launch -- the block walks as one
+// packet if its rays run together; otherwise its packets (quadrants, 2x2 groups) are LISTED for the second launch, one wave each,
+// because a wave that walks 16 packets one after the other lasts 16 times as long as its neighbours and the launch as long as that
+// wave (measured: total work of 0.2 ms of perfectly spread waves, 3.5 ms launch).  only_packet >= 1: that packet of the block.
 template <int MODE>
-__global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
-                                                              const unsigned long long* __restrict__ wide_vmask)
+__device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
+                                              const unsigned long long* __restrict__ wide_vmask, uint32_t (*kb_id)[ST_THREADS],
+                                              float (*kb_t)[ST_THREADS], int tid, int64_t tile, int only_packet, uint32_t rec_row)
 {
     constexpr bool BWD = MODE != 0;
-    __shared__ uint32_t kb_id[ST_K][ST_THREADS];
-    __shared__ float kb_t[ST_K][ST_THREADS];
-    if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
-    const int tid = threadIdx.x;
-    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6);
-    int64_t r = (int64_t)blockIdx.x * ST_THREADS + tid;
+    int64_t r = tile * 64 + (tid & 63);
     if (A.ray_width > 0) {                 // 8x8 blocks of neighbouring rays per wave: neighbours walk the same nodes
-        const int64_t tiles_x = (A.ray_width + 7) >> 3, rows = A.n_rays / A.ray_width, tile = r >> 6;
+        const int64_t tiles_x = (A.ray_width + 7) >> 3, rows = A.n_rays / A.ray_width;
         const int64_t px = (tile % tiles_x) * 8 + (tid & 7), py = (tile / tiles_x) * 8 + ((tid >> 3) & 7);
         r = (px < A.ray_width && py < rows) ? py * A.ray_width + px : A.n_rays;
     }
@@ -640,35 +646,51 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     // a ray without a direction (or with a non-finite one) would visit every node: it sees the background
     bool done = !(exists && fabsf(ox) < 1e30f && fabsf(oy) < 1e30f && fabsf(oz) < 1e30f && fabsf(dx) < 1e30f && fabsf(dy) < 1e30f &&
                   fabsf(dz) < 1e30f && (dx != 0.0f || dy != 0.0f || dz != 0.0f));
+    const bool no_ray = done;                       // sees the background; written by the first launch
     uint32_t packets_present = 0;
-    int packet = -1;
-    bool lone;
-    if (MODE == 2) {
-        lone = exists && A.state[4 * r + 3] > 0.0f;        // the forward's pass count is positive for the rays its second kernel traced
-    } else {
-        packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
-        // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
-        lone = !done && packet < 0;
-    }
-    if (MODE == 0) {
-        const unsigned long long lm = __ballot(lone);
-        if (lm) {
-            const int first = __builtin_ctzll(lm), lane = tid & 63;
-            uint32_t base = 0;
-            if (lane == first) base = atomicAdd(A.lone_list, (uint32_t)__popcll(lm));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-            if (lone) A.lone_list[16 + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+    const int packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
+    // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
+    const bool lone = !done && packet < 0;
+    bool deferred = false;                          // this block's packets are the second launch's
+    if (only_packet < 0) {
+        const uint32_t dm = packets_present & ~1u;
+        if (MODE == 0) {
+            const unsigned long long lm = __ballot(lone);
+            if (lm) {
+                const int first = __builtin_ctzll(lm), lane = tid & 63;
+                uint32_t base = 0;
+                if (lane == first) base = atomicAdd(A.lone_list, (uint32_t)__popcll(lm));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+                if (lone) A.lone_list[16 + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            }
+            if (dm != 0 && A.defer_list != nullptr) {
+                const uint32_t cnt = (uint32_t)__popc(dm);
+                uint32_t base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(A.defer_list, cnt);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                deferred = base + cnt <= A.defer_cap;                      // else: the list is full and the block walks its packets itself
+                if (deferred && (tid & 63) == 0) {
+                    uint32_t i = 0;
+                    for (uint32_t left = dm; left; left &= left - 1) A.defer_list[16 + base + i++] = ((uint32_t)tile << 5) | (uint32_t)__builtin_ctz(left);
+                    A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 1] = ST_REC_DEFERRED;
+                }
+            }
+        } else {
+            deferred = dm != 0 && A.defer_list != nullptr && A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 1] == ST_REC_DEFERRED;
         }
+    } else {
+        packets_present = 1u << only_packet;
     }
-    bool want = !done && !lone;
+    const bool mine = only_packet < 0 ? (no_ray || (packet >= 0 && !deferred)) : (packet == only_packet);
+    bool want = !done && !lone && mine;
     StProf prof = {0, 0, 0};
     for (int pass = 0; pass < ST_MAX_PASSES; ++pass) {
         if (__ballot(want) == 0) break;
         int n = 0;
         if (MODE == 2) {
-            if (pass >= ST_REC_PASSES) break;
-            const uint32_t chunk = A.rec_chunks[wave * ST_REC_PASSES + pass];
-            if (chunk == ST_REC_NONE) break;
+            if (pass >= ST_REC_PASSES - 1) break;
+            const uint32_t chunk = A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + pass];
+            if (chunk >= ST_REC_DEFERRED) break;
             const uint32_t* src = A.rec_arena + (size_t)chunk * (ST_K * 64) + (tid & 63);
 #pragma unroll
             for (int j = 0; j < ST_K; ++j) {
@@ -688,16 +710,16 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
         if (MODE == 0 && A.rec_arena != nullptr) {
             // the record of this pass: the wave's own chunks first, then one drawn from the pool (one atomic per wave and late pass)
             uint32_t chunk = ST_REC_NONE;
-            if (pass < ST_REC_STATIC) {
-                chunk = wave * ST_REC_STATIC + pass;
-            } else if (pass < ST_REC_PASSES) {
+            if (only_packet < 0 && pass < ST_REC_STATIC) {
+                chunk = rec_row * ST_REC_STATIC + pass;
+            } else if (pass < ST_REC_PASSES - 1) {
                 uint32_t got = 0;
                 if ((tid & 63) == 0) got = atomicAdd(A.rec_hdr, 1u);
                 got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                if (got < A.rec_pool) chunk = gridDim.x * (ST_THREADS / 64) * ST_REC_STATIC + got;
+                if (got < A.rec_pool) chunk = A.rec_static + got;
             }
             if (chunk != ST_REC_NONE) {
-                if ((tid & 63) == 0) A.rec_chunks[wave * ST_REC_PASSES + pass] = chunk;
+                if ((tid & 63) == 0) A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + pass] = chunk;
                 uint32_t* dst = A.rec_arena + (size_t)chunk * (ST_K * 64) + (tid & 63);
 #pragma unroll
                 for (int j = 0; j < ST_K; ++j) dst[j * 64] = (want && j < n) ? kb_id[j][tid] : ST_REC_NONE;
@@ -764,7 +786,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
             prev_id = kb_id[ST_K - 1][tid];
         }
     }
-    if (!exists || lone) return;
+    if (!exists || !mine || lone) return;
     if (!BWD) {
         A.rgb[3 * r] = C[0] + T * A.bg[0]; A.rgb[3 * r + 1] = C[1] + T * A.bg[1]; A.rgb[3 * r + 2] = C[2] + T * A.bg[2];
         A.dpt[r] = D; A.acc[r] = Aw; A.dist[r] = dist;
@@ -777,6 +799,41 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     } else {
         A.g_ray_o[3 * r] = go[0]; A.g_ray_o[3 * r + 1] = go[1]; A.g_ray_o[3 * r + 2] = go[2];
         A.g_ray_d[3 * r] = gdir[0]; A.g_ray_d[3 * r + 1] = gdir[1]; A.g_ray_d[3 * r + 2] = gdir[2];
+    }
+}
+
+// first launch: one wave per block of rays.  MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again
+// (no record, or it overflowed); 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same
+// order, no hierarchy.
+template <int MODE>
+__global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
+                                                              const unsigned long long* __restrict__ wide_vmask)
+{
+    __shared__ uint32_t kb_id[ST_K][ST_THREADS];
+    __shared__ float kb_t[ST_K][ST_THREADS];
+    if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
+    const int tid = threadIdx.x;
+    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6);
+    if (wave >= A.n_tiles) return;
+    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)wave, -1, wave);
+}
+
+// second launch: one wave per listed packet
+template <int MODE>
+__global__ __launch_bounds__(ST_THREADS) void st_trace_packets_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
+                                                                      const unsigned long long* __restrict__ wide_vmask)
+{
+    __shared__ uint32_t kb_id[ST_K][ST_THREADS];
+    __shared__ float kb_t[ST_K][ST_THREADS];
+    if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;
+    const int tid = threadIdx.x;
+    const uint32_t listed = A.defer_list[0];
+    const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
+    const uint32_t stride = gridDim.x * (ST_THREADS / 64);
+    for (uint32_t item = blockIdx.x * (ST_THREADS / 64) + (tid >> 6); item < count; item += stride) {
+        const uint32_t code = A.defer_list[16 + item];
+        if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
+        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
     }
 }
 
@@ -1035,21 +1092,22 @@ size_t mrgs_surfel_bvh_bytes(int64_t n_surfels)
     return st_blob(n_surfels).total;
 }
 
-struct StateLayout { int64_t grid, n_waves; size_t lone, rec_hdr, rec_chunks, rec_arena, total; uint32_t pool; };
+struct StateLayout { int64_t grid, n_tiles; size_t lone, defer, rec_hdr, rec_chunks, rec_arena, total; uint32_t pool, defer_cap; };
 
 static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte words
 {
     StateLayout L;
-    int64_t threads = n_rays;
-    if (ray_width > 0 && n_rays % ray_width == 0) threads = (int64_t)((ray_width + 7) / 8) * ((n_rays / ray_width + 7) / 8) * 64;
-    L.grid = (threads + ST_THREADS - 1) / ST_THREADS;
-    L.n_waves = L.grid * (ST_THREADS / 64);
-    L.pool = (uint32_t)(L.n_waves + 64);
+    L.n_tiles = (n_rays + 63) / 64;
+    if (ray_width > 0 && n_rays % ray_width == 0) L.n_tiles = (int64_t)((ray_width + 7) / 8) * ((n_rays / ray_width + 7) / 8);
+    L.grid = (L.n_tiles * 64 + ST_THREADS - 1) / ST_THREADS;
+    L.defer_cap = (uint32_t)(4 * L.n_tiles + 1024);
+    L.pool = (uint32_t)(3 * L.n_tiles + 64);
     L.lone = (size_t)4 * n_rays;                                     // [0] count, [16..] ray indices
-    L.rec_hdr = L.lone + 16 + (size_t)n_rays;
-    L.rec_chunks = L.rec_hdr + 16;
-    L.rec_arena = L.rec_chunks + (size_t)L.n_waves * ST_REC_PASSES;
-    L.total = L.rec_arena + ((size_t)L.n_waves * ST_REC_STATIC + L.pool) * (ST_K * 64);
+    L.defer = L.lone + 16 + (size_t)n_rays;                          // [0] count, [16..] packets of the second launch
+    L.rec_hdr = L.defer + 16 + L.defer_cap;
+    L.rec_chunks = L.rec_hdr + 16;                                   // one row per block of rays, then one per listed packet
+    L.rec_arena = L.rec_chunks + ((size_t)L.n_tiles + L.defer_cap) * ST_REC_PASSES;
+    L.total = L.rec_arena + ((size_t)L.n_tiles * ST_REC_STATIC + L.pool) * (ST_K * 64);
     return L;
 }
 
@@ -1107,24 +1165,34 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     static const char* cone_env = getenv("MRGS_TRACE_CONE");
     a.cone = cone_env ? (float)atof(cone_env) : 0.02f;
     const StateLayout SL = st_state(n_rays, a.ray_width);
-    const dim3 grid((unsigned)SL.grid);
+    const dim3 grid((unsigned)SL.grid), pgrid(2048);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
     a.lone_list = words + SL.lone;
+    a.defer_list = words + SL.defer;
+    a.defer_cap = SL.defer_cap;
     a.rec_hdr = words + SL.rec_hdr;
     a.rec_chunks = words + SL.rec_chunks;
     a.rec_arena = words + SL.rec_arena;
     a.rec_pool = SL.pool;
+    a.rec_static = (uint32_t)(SL.n_tiles * ST_REC_STATIC);
+    a.n_tiles = (uint32_t)SL.n_tiles;
     static const bool no_record = getenv("MRGS_TRACE_NO_RECORD") != nullptr;          // developer switch: the backward always walks again
+    static const bool no_defer = getenv("MRGS_TRACE_NO_DEFER") != nullptr;            // developer switch: every block walks its own packets
+    if (no_defer) a.defer_list = nullptr;
     if (!bwd) {
         if (hipMemsetAsync(a.lone_list, 0, 64, st) != hipSuccess || hipMemsetAsync(a.rec_hdr, 0, 64, st) != hipSuccess ||
-            hipMemsetAsync(a.rec_chunks, 0xFF, (size_t)SL.n_waves * ST_REC_PASSES * 4, st) != hipSuccess)
+            hipMemsetAsync(words + SL.defer, 0, 64, st) != hipSuccess || hipMemsetAsync(words + SL.defer + 16, 0xFF, (size_t)SL.defer_cap * 4, st) != hipSuccess ||
+            hipMemsetAsync(a.rec_chunks, 0xFF, ((size_t)SL.n_tiles + SL.defer_cap) * ST_REC_PASSES * 4, st) != hipSuccess)
             return MRGS_E_HIP;
         if (no_record) { a.rec_arena = nullptr; (void)hipMemsetAsync(a.rec_hdr + 1, 0x01, 4, st); }
         hipLaunchKernelGGL(st_trace_kernel<0>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        if (a.defer_list) hipLaunchKernelGGL(st_trace_packets_kernel<0>, pgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
     } else {
-        // exactly one of the two does the work: the replay of the forward's record, or -- when the record overflowed -- the walk
+        // exactly one of the two pairs does the work: the replay of the forward's record, or -- when the record overflowed -- the walk
         hipLaunchKernelGGL(st_trace_kernel<2>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        if (a.defer_list) hipLaunchKernelGGL(st_trace_packets_kernel<2>, pgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
         hipLaunchKernelGGL(st_trace_kernel<1>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        if (a.defer_list) hipLaunchKernelGGL(st_trace_packets_kernel<1>, pgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
     }
     const dim3 lgrid((unsigned)(n_rays < 16384 ? n_rays : 16384));
     if (bwd) hipLaunchKernelGGL(st_trace_lone_kernel<true>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
