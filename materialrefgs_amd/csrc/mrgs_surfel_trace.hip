@@ -516,7 +516,7 @@ __device__ __forceinline__ int st_gather_wide(const StWide& W, const float* __re
     return n;
 }
 
-// Rays "run together" when their directions stay within a cone of ~11 degrees about their mean (1 - cos <= 0.02: wider beams of grazing rays sweep thousands of surfels -- measured 16 -> 9.5 ms on mirror rays off a rendered view) and their origins within 2 % of the
+// Rays "run together" when their directions stay within a cone of ~4.4 degrees about their mean (1 - cos <= 0.003: wider beams of grazing rays sweep thousands of surfels; measured on mirror rays off a rendered view: 16 ms at 25 degrees, 9.5 at 11 before and 3.65 -> 1.9 at 11 -> 4.4 after the rays left over got waves of their own) and their origins within 2 % of the
 // scene's extent of their centre.  `on` selects the rays asked about; the answer is wave-uniform.
 __device__ __forceinline__ bool st_run_together(float extent, float cone, bool on, float ox, float oy, float oz, float dx, float dy, float dz)
 {
@@ -727,10 +727,14 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                 A.rec_hdr[1] = 1u;                 // the backward walks again
             }
         }
-        if (!want) continue;
-        ++passes;
-        for (int j = 0; j < n && !done; ++j) {
-            const uint32_t id = kb_id[j][tid];
+        if (!want) n = 0;                  // (every lane stays with the wave: the merge below moves data across lanes)
+        passes += want ? 1 : 0;
+        // The wave steps through its lanes' buffers together (a lane without an entry j idles): in the backward, neighbouring rays
+        // mostly hold the SAME surfel at the same rank, and lanes that do merge their 18 gradient terms before the atomics.
+        for (int j = 0; j < ST_K; ++j) {
+            bool act = j < n && !done;
+            if (__ballot(act) == 0) break;
+            const uint32_t id = act ? kb_id[j][tid] : 0u;
             const float4* g = A.geom + (size_t)id * 4;
             const float4 g0 = g[0], g1 = g[1], g2 = g[2];
             const float opacity = g[3].x;
@@ -738,50 +742,100 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
             const float t = MODE == 2 ? h.t : kb_t[j][tid];                           // (the same number)
             const float alpha = h.alpha;
             const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) { done = true; break; }
-            const float w = alpha * T;
+            if (act && test_T < 0.0001f) { done = true; act = false; }
+            const float w = act ? alpha * T : 0.0f;
             const float4 a0 = A.attr[(size_t)id * 2], a1 = A.attr[(size_t)id * 2 + 1];
             const float sgn = h.den > 0.0f ? -1.0f : 1.0f;                   // the normal faces the ray's origin
             const float nfx = sgn * g2.y, nfy = sgn * g2.z, nfz = sgn * g2.w;
             if (!BWD) {
-                C[0] += w * a0.x; C[1] += w * a0.y; C[2] += w * a0.z;
-                N[0] += w * nfx; N[1] += w * nfy; N[2] += w * nfz;
-                X[0] += w * a0.w; X[1] += w * a1.x;
-                dist += w * (t * t * Aw + M2 - 2.0f * t * M1);
-                D += w * t; Aw += w; M1 += w * t; M2 += w * t * t;
-                atomicAdd(A.wet + id, w);
+                if (act) {
+                    C[0] += w * a0.x; C[1] += w * a0.y; C[2] += w * a0.z;
+                    N[0] += w * nfx; N[1] += w * nfy; N[2] += w * nfz;
+                    X[0] += w * a0.w; X[1] += w * a1.x;
+                    dist += w * (t * t * Aw + M2 - 2.0f * t * M1);
+                    D += w * t; Aw += w; M1 += w * t; M2 += w * t * t;
+                    atomicAdd(A.wet + id, w);
+                }
             } else {
-                const float q = gc[0] * a0.x + gc[1] * a0.y + gc[2] * a0.z + gd * t + ga + gn[0] * nfx + gn[1] * nfy + gn[2] * nfz
-                              + gx[0] * a0.w + gx[1] * a1.x + gdist * (t * t * fA - 2.0f * t * fM1 + fM2);
-                Qpre += w * q;
-                const float inv1ma = 1.0f / (1.0f - alpha);
-                const float dalpha = T * q - (Qtot - Qpre) * inv1ma - fT * bgdot * inv1ma;
-                const float dG = opacity * dalpha;                                    // no clamp mask, as backward.cu:411-413
-                const float du = -h.u * h.G * dG, dv = -h.v * h.G * dG;
-                const float ax = g0.w, ay = g1.x, az = g1.y, bx = g1.z, by = g1.w, bz = g2.x, nx = g2.y, ny = g2.z, nz = g2.w;
-                const float px = (ox + t * dx) - g0.x, py = (oy + t * dy) - g0.y, pz = (oz + t * dz) - g0.z;
-                const float dpx = du * ax + dv * bx, dpy = du * ay + dv * by, dpz = du * az + dv * bz;
-                const float dt = w * (gd + gdist * 2.0f * (t * fA - fM1)) + (dpx * dx + dpy * dy + dpz * dz);
-                const float dnum = dt / h.den, dden = -dt * t / h.den;
-                float* gg = A.g_geom + (size_t)id * 16;
-                atomicAdd(gg + 0, -dpx + dnum * nx); atomicAdd(gg + 1, -dpy + dnum * ny); atomicAdd(gg + 2, -dpz + dnum * nz);
-                atomicAdd(gg + 3, du * px); atomicAdd(gg + 4, du * py); atomicAdd(gg + 5, du * pz);
-                atomicAdd(gg + 6, dv * px); atomicAdd(gg + 7, dv * py); atomicAdd(gg + 8, dv * pz);
-                atomicAdd(gg + 9, dnum * (g0.x - ox) + dden * dx + sgn * w * gn[0]);
-                atomicAdd(gg + 10, dnum * (g0.y - oy) + dden * dy + sgn * w * gn[1]);
-                atomicAdd(gg + 11, dnum * (g0.z - oz) + dden * dz + sgn * w * gn[2]);
-                atomicAdd(gg + 12, h.G * dalpha);
-                float* ga_ = A.g_attr + (size_t)id * 8;
-                atomicAdd(ga_ + 0, w * gc[0]); atomicAdd(ga_ + 1, w * gc[1]); atomicAdd(ga_ + 2, w * gc[2]);
-                atomicAdd(ga_ + 3, w * gx[0]); atomicAdd(ga_ + 4, w * gx[1]);
-                go[0] += dpx - dnum * nx; go[1] += dpy - dnum * ny; go[2] += dpz - dnum * nz;
-                gdir[0] += t * dpx + dden * nx; gdir[1] += t * dpy + dden * ny; gdir[2] += t * dpz + dden * nz;
+                float gv[18];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) gv[k] = 0.0f;
+                if (act) {
+                    const float q = gc[0] * a0.x + gc[1] * a0.y + gc[2] * a0.z + gd * t + ga + gn[0] * nfx + gn[1] * nfy + gn[2] * nfz
+                                  + gx[0] * a0.w + gx[1] * a1.x + gdist * (t * t * fA - 2.0f * t * fM1 + fM2);
+                    Qpre += w * q;
+                    const float inv1ma = 1.0f / (1.0f - alpha);
+                    const float dalpha = T * q - (Qtot - Qpre) * inv1ma - fT * bgdot * inv1ma;
+                    const float dG = opacity * dalpha;                                    // no clamp mask, as backward.cu:411-413
+                    const float du = -h.u * h.G * dG, dv = -h.v * h.G * dG;
+                    const float ax = g0.w, ay = g1.x, az = g1.y, bx = g1.z, by = g1.w, bz = g2.x, nx = g2.y, ny = g2.z, nz = g2.w;
+                    const float px = (ox + t * dx) - g0.x, py = (oy + t * dy) - g0.y, pz = (oz + t * dz) - g0.z;
+                    const float dpx = du * ax + dv * bx, dpy = du * ay + dv * by, dpz = du * az + dv * bz;
+                    const float dt = w * (gd + gdist * 2.0f * (t * fA - fM1)) + (dpx * dx + dpy * dy + dpz * dz);
+                    const float dnum = dt / h.den, dden = -dt * t / h.den;
+                    gv[0] = -dpx + dnum * nx; gv[1] = -dpy + dnum * ny; gv[2] = -dpz + dnum * nz;
+                    gv[3] = du * px; gv[4] = du * py; gv[5] = du * pz;
+                    gv[6] = dv * px; gv[7] = dv * py; gv[8] = dv * pz;
+                    gv[9] = dnum * (g0.x - ox) + dden * dx + sgn * w * gn[0];
+                    gv[10] = dnum * (g0.y - oy) + dden * dy + sgn * w * gn[1];
+                    gv[11] = dnum * (g0.z - oz) + dden * dz + sgn * w * gn[2];
+                    gv[12] = h.G * dalpha;
+                    gv[13] = w * gc[0]; gv[14] = w * gc[1]; gv[15] = w * gc[2]; gv[16] = w * gx[0]; gv[17] = w * gx[1];
+                    go[0] += dpx - dnum * nx; go[1] += dpy - dnum * ny; go[2] += dpz - dnum * nz;
+                    gdir[0] += t * dpx + dden * nx; gdir[1] += t * dpy + dden * ny; gdir[2] += t * dpz + dden * nz;
+                }
+                // merge with the horizontal, then the vertical neighbour of the 8x8 block when both hold the same surfel: the lower
+                // lane of a pair carries the sum, the upper one is done (DPP moves: quad_perm [1,0,3,2] = lane ^ 1, [2,3,0,1] = lane ^ 2, row_ror:8 = lane ^ 8)
+                bool live = act;
+                {
+                    const uint32_t pid = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, 0xB1, 0xf, 0xf, true);
+                    const bool plive = __builtin_amdgcn_update_dpp(0, (int)live, 0xB1, 0xf, 0xf, true) != 0;
+                    const bool merge = live && plive && pid == id;
+                    const bool lower = (tid & 1) == 0;
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) {
+                        const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv[k]), 0xB1, 0xf, 0xf, true));
+                        gv[k] += (merge && lower) ? pv : 0.0f;
+                    }
+                    live = live && !(merge && !lower);
+                }
+                {
+                    const uint32_t pid = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, 0x4E, 0xf, 0xf, true);        // quad_perm [2,3,0,1] = lane ^ 2
+                    const bool plive = __builtin_amdgcn_update_dpp(0, (int)live, 0x4E, 0xf, 0xf, true) != 0;
+                    const bool merge = live && plive && pid == id;
+                    const bool lower = (tid & 2) == 0;
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) {
+                        const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv[k]), 0x4E, 0xf, 0xf, true));
+                        gv[k] += (merge && lower) ? pv : 0.0f;
+                    }
+                    live = live && !(merge && !lower);
+                }
+                {
+                    const uint32_t pid = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, 0x128, 0xf, 0xf, true);
+                    const bool plive = __builtin_amdgcn_update_dpp(0, (int)live, 0x128, 0xf, 0xf, true) != 0;
+                    const bool merge = live && plive && pid == id;
+                    const bool lower = (tid & 8) == 0;
+#pragma unroll
+                    for (int k = 0; k < 18; ++k) {
+                        const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv[k]), 0x128, 0xf, 0xf, true));
+                        gv[k] += (merge && lower) ? pv : 0.0f;
+                    }
+                    live = live && !(merge && !lower);
+                }
+                if (live) {
+                    float* gg = A.g_geom + (size_t)id * 16;
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) atomicAdd(gg + k, gv[k]);
+                    float* ga_ = A.g_attr + (size_t)id * 8;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) atomicAdd(ga_ + k, gv[13 + k]);
+                }
             }
-            T = test_T;
-            ++blended;
+            if (act) { T = test_T; ++blended; }
         }
-        if (n < ST_K || done) { want = false; continue; }
-        if (MODE != 2) {
+        if (n < ST_K || done) want = false;
+        if (want && MODE != 2) {
             prev_t = kb_t[ST_K - 1][tid];
             prev_id = kb_id[ST_K - 1][tid];
         }
@@ -1163,7 +1217,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     static const bool no_packets = getenv("MRGS_TRACE_NO_PACKETS") != nullptr;      // developer switch: every ray gets a wave of its own
     a.packets = no_packets ? 0 : 1;
     static const char* cone_env = getenv("MRGS_TRACE_CONE");
-    a.cone = cone_env ? (float)atof(cone_env) : 0.02f;
+    a.cone = cone_env ? (float)atof(cone_env) : 0.003f;
     const StateLayout SL = st_state(n_rays, a.ray_width);
     const dim3 grid((unsigned)SL.grid), pgrid(2048);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
