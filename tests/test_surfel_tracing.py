@@ -408,3 +408,30 @@ def test_record_kernel_matches_the_torch_statement(gpu_device, use_sh, degree):
     for k in ("means", "scales", "rotations", "opacities", "others") + (("shs",) if use_sh else ("colors",)):
         a, b = Lh[k].grad.cpu().double(), Lr[k].grad
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-12), k
+
+
+@pytest.mark.gpu
+def test_backward_walks_again_when_the_record_overflows(gpu_device):
+    """300 faint layers in front of every ray: 19 passes of 16 hits, more than a wave's record holds (15).  The forward raises the
+    overflow flag and the backward walks the hierarchy again instead of replaying -- same gradients as the dense statement either way."""
+    P, n = 300, 256
+    g = torch.Generator().manual_seed(9)
+    z = 1.0 + torch.randperm(P, generator=g).float() * 0.01
+    from types import SimpleNamespace
+    sc = SimpleNamespace(means3D=torch.stack([torch.zeros(P), torch.zeros(P), z], dim=1), scales=torch.full((P, 2), 2.0),
+                         rotations=torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1), opacities=torch.full((P, 1), 0.02))
+    colors, others = torch.rand(P, 3, generator=g), torch.rand(P, 2, generator=g)
+    o = torch.zeros(n, 3)
+    d = torch.cat([torch.randn(n, 2, generator=g) * 0.05, torch.ones(n, 1)], dim=1)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    hip, Lh = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
+    ref, Lr = _oracle(sc, colors, others, o, d, bg, torch.float64, need_grad=True)
+    assert int(ref["hits"].min()) > 15 * 16
+    for k in ("rgb", "dpt", "acc", "norm", "dist", "aux"):
+        assert float((hip[k].detach().cpu().double() - ref[k].detach()).abs().max()) < 5e-5 * max(1.0, float(ref[k].detach().abs().max())), k
+    w = torch.randn(n, 3, generator=g)
+    (hip["rgb"] * w.to(gpu_device)).sum().backward()
+    (ref["rgb"] * w.double()).sum().backward()
+    for k in ("means", "scales", "rotations", "opacities", "colors", "o", "d"):
+        a, b = Lh[k].grad.cpu().double(), Lr[k].grad
+        assert float((a - b).abs().max()) <= 1e-3 * max(float(b.abs().max()), 1e-12), k
