@@ -435,3 +435,23 @@ def test_backward_walks_again_when_the_record_overflows(gpu_device):
     for k in ("means", "scales", "rotations", "opacities", "colors", "o", "d"):
         a, b = Lh[k].grad.cpu().double(), Lr[k].grad
         assert float((a - b).abs().max()) <= 1e-3 * max(float(b.abs().max()), 1e-12), k
+
+
+@pytest.mark.gpu
+def test_degenerate_ray_sets(gpu_device):
+    """No rays, rays without a direction, non-finite rays, a ray set that is not a multiple of anything: background and zeros, no hang."""
+    sc, colors, others = _scene(200, 3, 60.0)
+    bg = torch.tensor([0.3, 0.6, 0.9])
+    hip, _ = _hip_trace(gpu_device, sc, colors, others, torch.zeros(0, 3), torch.zeros(0, 3), bg)
+    assert hip["rgb"].shape == (0, 3) and hip["wet"].shape == (200,) and float(hip["wet"].abs().sum()) == 0.0
+    o = torch.zeros(7, 3)
+    d = torch.zeros(7, 3)
+    d[1] = torch.tensor([float("nan"), 0.0, 1.0]); d[2] = torch.tensor([float("inf"), 0.0, 1.0]); d[3] = torch.tensor([0.0, 0.0, 1.0])
+    o[4] = torch.tensor([float("nan"), 0.0, 0.0]); d[4] = torch.tensor([0.0, 0.0, 1.0])
+    hip, L = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
+    ref, _ = _oracle(sc, colors, others, o[3:4], d[3:4], bg, torch.float64)
+    for r in (0, 1, 2, 4, 5, 6):
+        assert torch.allclose(hip["rgb"][r].cpu(), bg) and float(hip["acc"][r]) == 0.0, r
+    assert float((hip["rgb"][3].detach().cpu().double() - ref["rgb"][0]).abs().max()) < 1e-5 and float(ref["acc"][0]) > 0
+    hip["rgb"].sum().backward()
+    assert torch.isfinite(L["means"].grad).all() and torch.isfinite(L["d"].grad[3]).all()
