@@ -475,6 +475,22 @@ def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_c
     return results
 
 
+def render_surfel_with_envgs_sep(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
+                                 opt=None, wo_render_img=False, normal_img_map=None):
+    """gaussian_renderer/envgs_renderer.py:771-807: as render_surfel_with_envgs, but the mirror rays see the separate ENVIRONMENT surfel
+    set `env`, and the blend weight is render_surfel's per-pixel "specular_weight" ([H,W,3], returned with opt.indirect)."""
+    results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt)
+    weight = results["specular_weight"].permute(2, 0, 1)
+    alpha = results["rend_alpha"].permute(1, 2, 0)
+    normal_map = safe_normalize(results["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))
+    ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, results["surf_depth"])
+    traced = indirect_renderer.render_gaussians(viewpoint_camera, ray_o=ray_o, ray_d=ray_d, pcd=env, pipe=pipe, bg_color=bg_color, start_from_first=True)
+    traced["specular"] = weight
+    results["render"] = results["render"] * (1 - weight) + weight * traced["render"]
+    results["indirect_out"] = traced
+    return results
+
+
 def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
                    opt=None, wo_render_img=False, normal_img_map=None, flag="pgsr"):
     """gaussian_renderer/envgs_renderer.py:461-715, the last training stage (train_refnerf.py:1501-1504): render_surfel's material
