@@ -365,6 +365,11 @@ def test_render_surfel2_wiring(gpu_device):
     assert envgs._xyz.grad is not None and float(envgs._xyz.grad.abs().sum()) > 0            # through the tracer into the environment set
     assert pc._metalness.grad is None or float(pc._metalness.grad.abs().sum()) == 0          # the blend weight is rasterized but not consumed
     assert float(pc._xyz.grad.abs().sum()) > 0
+    # render_surfel_with_envgs_sep (envgs_renderer.py:771-807): render_surfel blended with the traced environment set by specular_weight
+    sep = renderer.render_surfel_with_envgs_sep(hr, envgs, cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=True))
+    base = renderer.render_surfel(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=True))
+    wgt = base["specular_weight"].permute(2, 0, 1)
+    assert torch.allclose(sep["render"], base["render"] * (1 - wgt) + wgt * sep["indirect_out"]["render"], atol=1e-6)
 
 
 @pytest.mark.gpu
