@@ -460,3 +460,22 @@ def test_degenerate_ray_sets(gpu_device):
     assert float((hip["rgb"][3].detach().cpu().double() - ref["rgb"][0]).abs().max()) < 1e-5 and float(ref["acc"][0]) > 0
     hip["rgb"].sum().backward()
     assert torch.isfinite(L["means"].grad).all() and torch.isfinite(L["d"].grad[3]).all()
+
+
+def test_size_functions_of_the_c_abi_without_a_gpu():
+    """mrgs_surfel_bvh_bytes / _ws_bytes / _trace_state_floats are pure host arithmetic: monotone, and large enough for what the header
+    says they hold (64-wide nodes over ceil(P / 64) groups; per ray 4 state floats + a list slot; per block of 64 rays two 4 KB chunks)."""
+    from materialrefgs_amd import _lib
+    L = _lib.lib()
+    prev = (0, 0)
+    for P in (0, 1, 63, 64, 65, 4096, 4097, 300000, 1 << 20):
+        b, w = L.mrgs_surfel_bvh_bytes(P), L.mrgs_surfel_bvh_ws_bytes(P)
+        groups = max(1, (P + 63) // 64)
+        assert b >= groups * (1536 + 8) + groups * 64 * 64 + P * 4 and w >= P * (24 + 16)
+        assert b >= prev[0] and w >= prev[1]
+        prev = (b, w)
+    for n, width in ((0, 0), (1, 0), (640000, 800), (640000, 0), (2560000, 1600), (1000, 37)):
+        f = L.mrgs_surfel_trace_state_floats(n, width)
+        blocks = ((width + 7) // 8) * ((n // width + 7) // 8) if width and n % width == 0 else (n + 63) // 64
+        assert f >= 5 * n + 32 + blocks * 2 * 1024, (n, width, f)
+    assert L.mrgs_surfel_trace_state_floats(640000, 800) >= L.mrgs_surfel_trace_state_floats(640000, 0)       # 8x8 blocks pad the image's edges
