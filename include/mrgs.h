@@ -394,6 +394,15 @@ int mrgs_surfel_trace_prep_backward(int64_t P, const float* means3D, const float
                                     float* g_means3D, float* g_scales, float* g_rotations, float* g_opacities, float* g_shs,
                                     float* g_colors_precomp, float* g_others, void* stream);
 
+/* The mirror rays of a rendered view, as render_indirect / render_surfel_with_envgs set them up (gaussian_renderer/envgs_renderer.py:717-724,
+ * __init__.py:496-505): origin = camera centre + surf_depth * un-normalised pixel ray + 1e-3 * direction, direction = unit mirror
+ * direction of the view ray about `normal` ([H,W,3], any strides).  Kinv: inverse intrinsics on the host; R / T: device Camera.R /
+ * Camera.T as in MrgsShadeFrame.  Backward: gradients of ray_o / ray_d to normal ([H,W,3] contiguous) and surf_depth. */
+int mrgs_mirror_rays_forward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* normal,
+                             const float* surf_depth, float* ray_o, float* ray_d, void* stream);
+int mrgs_mirror_rays_backward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* normal,
+                              const float* g_ray_o, const float* g_ray_d, float* g_normal, float* g_surf_depth, void* stream);
+
 /* ---- optimizer step -------------------------------------------------------------------------
  * torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of GaussianModel.training_setup (scene/gaussian_model.py:417-453) for every
  * parameter tensor in one launch (per MRGS_ADAM_MAX_TENSORS tensors): amsgrad off, no weight decay.  `tensors` is a HOST array;

@@ -199,6 +199,67 @@ __global__ __launch_bounds__(256) void trace_prep_kernel(PrepArgs A)
     A.g_means[3 * p] = dm[0]; A.g_means[3 * p + 1] = dm[1]; A.g_means[3 * p + 2] = dm[2];
 }
 
+
+// ---- the mirror rays of a rendered view ------------------------------------------------------------------------------------------
+// render_indirect / render_surfel_with_envgs (gaussian_renderer/envgs_renderer.py:717-724, __init__.py:496-505): per pixel the surface
+// point rays_o + surf_depth * rays_cam (rays_cam: un-normalised pixel ray, sample_camera_rays_unnormalize utils/refl_utils.py:75-93),
+// the mirror direction of the view ray about `normal` (reflection :95-98, safe_normalize before and after), origin moved 1e-3 along it.
+// ~20 torch launches each way otherwise.  Same camera conventions as bvh_visibility_kernel (Kinv host, R = Camera.R, T = Camera.T).
+struct MirrorArgs {
+    int H, W;
+    float Kinv[9];
+    const float *R, *T;
+    const float* normal; long long nh, nw, nc;      // [H,W,3], element strides
+    const float* depth;                              // [H,W]
+    float *ray_o, *ray_d;                            // [H,W,3]
+    const float *g_ray_o, *g_ray_d;
+    float *g_normal, *g_depth;                       // [H,W,3] contiguous, [H,W]
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void mirror_rays_kernel(MirrorArgs A)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= A.W || y >= A.H) return;
+    const size_t pix = (size_t)y * A.W + x;
+    const float fx = (float)x, fy = (float)y;
+    const float pcx = A.Kinv[0] * fx + A.Kinv[1] * fy + A.Kinv[2], pcy = A.Kinv[3] * fx + A.Kinv[4] * fy + A.Kinv[5],
+                pcz = A.Kinv[6] * fx + A.Kinv[7] * fy + A.Kinv[8];
+    const float* R = A.R;
+    const float tx = A.T[0], ty = A.T[1], tz = A.T[2];
+    const float qx = pcx - tx, qy = pcy - ty, qz = pcz - tz;
+    const float rox = -(R[0] * tx + R[1] * ty + R[2] * tz), roy = -(R[3] * tx + R[4] * ty + R[5] * tz), roz = -(R[6] * tx + R[7] * ty + R[8] * tz);
+    const float cx = (R[0] * qx + R[1] * qy + R[2] * qz) - rox, cy = (R[3] * qx + R[4] * qy + R[5] * qz) - roy,
+                cz = (R[6] * qx + R[7] * qy + R[8] * qz) - roz;                          // rays_cam (un-normalised)
+    const float cl = fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-20f);
+    const float wx = -cx / cl, wy = -cy / cl, wz = -cz / cl;                            // w_o
+    const long long on = (long long)y * A.nh + (long long)x * A.nw;
+    const float nx = A.normal[on], ny = A.normal[on + A.nc], nz = A.normal[on + 2 * A.nc];
+    const float ndv = wx * nx + wy * ny + wz * nz;
+    const float ax = 2.f * nx * ndv - wx, ay = 2.f * ny * ndv - wy, az = 2.f * nz * ndv - wz;
+    const float len = sqrtf(ax * ax + ay * ay + az * az), rl = fmaxf(len, 1e-20f);
+    const float rx = ax / rl, ry = ay / rl, rz = az / rl;
+    if (!BWD) {
+        const float sd = A.depth[pix];
+        A.ray_o[3 * pix] = (rox + sd * cx) + 1e-3f * rx; A.ray_o[3 * pix + 1] = (roy + sd * cy) + 1e-3f * ry; A.ray_o[3 * pix + 2] = (roz + sd * cz) + 1e-3f * rz;
+        A.ray_d[3 * pix] = rx; A.ray_d[3 * pix + 1] = ry; A.ray_d[3 * pix + 2] = rz;
+        return;
+    }
+    const float gox = A.g_ray_o[3 * pix], goy = A.g_ray_o[3 * pix + 1], goz = A.g_ray_o[3 * pix + 2];
+    A.g_depth[pix] = gox * cx + goy * cy + goz * cz;
+    const float grx = A.g_ray_d[3 * pix] + 1e-3f * gox, gry = A.g_ray_d[3 * pix + 1] + 1e-3f * goy, grz = A.g_ray_d[3 * pix + 2] + 1e-3f * goz;
+    float gax = 0.f, gay = 0.f, gaz = 0.f;                   // through x / max(|x|, eps): the clamp is flat below eps
+    if (len > 1e-20f) {
+        const float dot = rx * grx + ry * gry + rz * grz;
+        gax = (grx - rx * dot) / rl; gay = (gry - ry * dot) / rl; gaz = (grz - rz * dot) / rl;
+    } else {
+        gax = grx / rl; gay = gry / rl; gaz = grz / rl;
+    }
+    // a = 2 n (w_o . n) - w_o
+    const float ng = nx * gax + ny * gay + nz * gaz;
+    A.g_normal[3 * pix] = 2.f * (ndv * gax + ng * wx); A.g_normal[3 * pix + 1] = 2.f * (ndv * gay + ng * wy); A.g_normal[3 * pix + 2] = 2.f * (ndv * gaz + ng * wz);
+}
+
 }   // namespace
 
 extern "C" {
@@ -234,6 +295,38 @@ int mrgs_surfel_trace_prep_backward(int64_t P, const float* means3D, const float
     a.g_geom = g_geom; a.g_attr = g_attr; a.g_means = g_means3D; a.g_scales = g_scales; a.g_rotations = g_rotations; a.g_opacities = g_opacities;
     a.g_shs = g_shs; a.g_colors = g_colors_precomp; a.g_others = g_others;
     hipLaunchKernelGGL(trace_prep_kernel<true>, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+static void mirror_fill(MirrorArgs& a, int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* normal)
+{
+    a.H = H; a.W = W;
+    for (int i = 0; i < 9; ++i) a.Kinv[i] = Kinv_host[i];
+    a.R = R; a.T = T;
+    a.normal = normal->ptr; a.nh = normal->stride_h; a.nw = normal->stride_w; a.nc = normal->stride_c;
+}
+
+int mrgs_mirror_rays_forward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* normal,
+                             const float* surf_depth, float* ray_o, float* ray_d, void* stream)
+{
+    if (H <= 0 || W <= 0) return MRGS_OK;
+    if (!Kinv_host || !R || !T || !normal || !normal->ptr || !surf_depth || !ray_o || !ray_d) return MRGS_E_BAD_ARG;
+    MirrorArgs a = {};
+    mirror_fill(a, H, W, Kinv_host, R, T, normal);
+    a.depth = surf_depth; a.ray_o = ray_o; a.ray_d = ray_d;
+    hipLaunchKernelGGL(mirror_rays_kernel<false>, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_mirror_rays_backward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* normal,
+                              const float* g_ray_o, const float* g_ray_d, float* g_normal, float* g_surf_depth, void* stream)
+{
+    if (H <= 0 || W <= 0) return MRGS_OK;
+    if (!Kinv_host || !R || !T || !normal || !normal->ptr || !g_ray_o || !g_ray_d || !g_normal || !g_surf_depth) return MRGS_E_BAD_ARG;
+    MirrorArgs a = {};
+    mirror_fill(a, H, W, Kinv_host, R, T, normal);
+    a.g_ray_o = g_ray_o; a.g_ray_d = g_ray_d; a.g_normal = g_normal; a.g_depth = g_surf_depth;
+    hipLaunchKernelGGL(mirror_rays_kernel<true>, dim3((W + 31) / 32, (H + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -425,31 +425,82 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
 
 
 # ---- traced indirect light (second half) ---------------------------------------------------------------
-def _pixel_rays_unnormalized(HWK, R, T, device):
+def _pixel_rays_unnormalized(HWK, R, T, device, dtype=torch.float32):
     """sample_camera_rays_unnormalize (utils/refl_utils.py:75-93): per pixel the world-space vector from the camera centre to the point
     at view depth 1 behind the pixel (x, y integer pixel coordinates), and the camera centre.  R is Camera.R (stored transposed)."""
     H, W, K = HWK
-    Kinv = torch.linalg.inv(torch.as_tensor(K, dtype=torch.float32, device=device))
-    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32), torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    Kinv = torch.linalg.inv(torch.as_tensor(K, dtype=dtype, device=device))
+    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=dtype), torch.arange(W, device=device, dtype=dtype), indexing="ij")
     pix_cam = torch.stack([xs, ys, torch.ones_like(xs)], dim=-1) @ Kinv.T
-    R = torch.as_tensor(R, dtype=torch.float32, device=device)
-    T = torch.as_tensor(T, dtype=torch.float32, device=device)
+    R = torch.as_tensor(R, dtype=dtype, device=device)
+    T = torch.as_tensor(T, dtype=dtype, device=device)
     Rw = R.T                                               # the world-to-camera rotation
     rays_o = (-Rw.T @ T.unsqueeze(-1)).flatten()
     rays_d = (pix_cam - T[None, None]).reshape(-1, 3) @ Rw - rays_o[None]
     return rays_d.reshape(H, W, 3), rays_o
 
 
-def _mirror_rays(viewpoint_camera, normal_map, surf_depth):
-    """The ray set of render_indirect / render_surfel_with_envgs (gaussian_renderer/__init__.py:496-505, envgs_renderer.py:717-724):
-    from the surface point of every pixel along the mirror direction of the view ray, origin moved 1e-3 along it."""
+def mirror_rays_torch(viewpoint_camera, normal_map, surf_depth):
+    """The ray set of render_indirect / render_surfel_with_envgs (gaussian_renderer/__init__.py:496-505, envgs_renderer.py:717-724)
+    with torch ops (any device): the checker of mrgs_mirror_rays_*."""
     H, W, _ = viewpoint_camera.HWK
-    rays_cam, rays_o = _pixel_rays_unnormalized(viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, surf_depth.device)
+    rays_cam, rays_o = _pixel_rays_unnormalized(viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, surf_depth.device, normal_map.dtype)
     hit = rays_o + surf_depth.reshape(H, W, 1) * rays_cam
     w_o = safe_normalize(-rays_cam)
     n = normal_map.reshape(H, W, 3)
     refl = safe_normalize(2 * n * torch.sum(w_o * n, dim=-1, keepdim=True) - w_o)          # reflection(), utils/refl_utils.py:95-98
     return hit + 1e-3 * refl, refl
+
+
+class _MirrorRays(torch.autograd.Function):
+    """mrgs_mirror_rays_forward / _backward: one launch each way."""
+
+    @staticmethod
+    def forward(ctx, normal_map, surf_depth, Kinv, R, T):
+        L = _lib.lib()
+        H, W = normal_map.shape[0], normal_map.shape[1]
+        dev = normal_map.device
+        nm = normal_map.detach()
+        sd = surf_depth.detach().reshape(H, W).contiguous().float()
+        ray_o = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        ray_d = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        kinv = (ctypes.c_float * 9)(*Kinv)
+        m = _lib.MrgsStridedMap(nm.data_ptr(), nm.stride(0), nm.stride(1), nm.stride(2))
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_mirror_rays_forward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(sd), _p(ray_o), _p(ray_d),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.save_for_backward(nm, R, T)
+        ctx.Kinv, ctx.depth_shape = Kinv, surf_depth.shape
+        return ray_o, ray_d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        nm, R, T = ctx.saved_tensors
+        L = _lib.lib()
+        H, W = nm.shape[0], nm.shape[1]
+        dev = nm.device
+        z = lambda g: torch.zeros(H, W, 3, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
+        g_o, g_d = z(g_o), z(g_d)
+        g_n = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        g_sd = torch.empty(H, W, dtype=torch.float32, device=dev)
+        kinv = (ctypes.c_float * 9)(*ctx.Kinv)
+        m = _lib.MrgsStridedMap(nm.data_ptr(), nm.stride(0), nm.stride(1), nm.stride(2))
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_mirror_rays_backward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(g_o), _p(g_d), _p(g_n), _p(g_sd),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return g_n, g_sd.reshape(ctx.depth_shape), None, None, None
+
+
+def _mirror_rays(viewpoint_camera, normal_map, surf_depth):
+    """Mirror rays of every pixel of a rendered view: from the surface point along the mirror direction of the view ray about
+    `normal_map`, origin moved 1e-3 along it (one HIP launch; `mirror_rays_torch` states the same with torch ops)."""
+    import numpy as np
+    H, W, K = viewpoint_camera.HWK
+    dev = surf_depth.device
+    Kinv = tuple(np.linalg.inv(np.asarray(K, dtype=np.float32)).astype(np.float32).reshape(-1).tolist())
+    R = torch.as_tensor(viewpoint_camera.R, dtype=torch.float32, device=dev).contiguous()
+    T = torch.as_tensor(viewpoint_camera.T, dtype=torch.float32, device=dev).contiguous()
+    return _MirrorRays.apply(normal_map.reshape(H, W, 3).float(), surf_depth, Kinv, R, T)
 
 
 def render_indirect(indirect_renderer, viewpoint_camera, pc, pipe, bg_color, normal_map=None, surf_depth=None):

@@ -479,3 +479,31 @@ def test_size_functions_of_the_c_abi_without_a_gpu():
         blocks = ((width + 7) // 8) * ((n // width + 7) // 8) if width and n % width == 0 else (n + 63) // 64
         assert f >= 5 * n + 32 + blocks * 2 * 1024, (n, width, f)
     assert L.mrgs_surfel_trace_state_floats(640000, 800) >= L.mrgs_surfel_trace_state_floats(640000, 0)       # 8x8 blocks pad the image's edges
+
+
+@pytest.mark.gpu
+def test_mirror_ray_kernel_matches_the_torch_statement(gpu_device):
+    """mrgs_mirror_rays_*: ray origins / directions and the gradients to the normal map and the depth against renderer.mirror_rays_torch in
+    float64 (utils/refl_utils.py:75-98, envgs_renderer.py:717-724), incl. a strided normal map and pixels with a zero normal."""
+    from materialrefgs_amd import renderer
+    from materialrefgs_amd.synthetic import orbit_camera
+    H, W = 37, 53
+    g = torch.Generator().manual_seed(2)
+    cam = orbit_camera(5, H, W)
+    n_chw = torch.randn(3, H, W, generator=g)
+    n_chw[:, :3, :5] = 0.0                                              # uncovered pixels: normal 0 -> the ray looks back along the view ray
+    depth = torch.rand(1, H, W, generator=g) * 3 + 0.5
+    def run(dev, dt, fn):
+        n = n_chw.to(dev).to(dt).clone().requires_grad_(True)
+        d = depth.to(dev).to(dt).clone().requires_grad_(True)
+        c = cam.to(dev) if dev != "cpu" else cam
+        o, r = fn(c, n.permute(1, 2, 0), d)                             # a permuted (strided) view, as render_surfel hands it over
+        return n, d, o, r
+    nh, dh, oh, rh = run(gpu_device, torch.float32, renderer._mirror_rays)
+    nr, dr, orf, rr = run("cpu", torch.float64, renderer.mirror_rays_torch)
+    assert float((oh.cpu().double() - orf).detach().abs().max()) < 2e-5 and float((rh.cpu().double() - rr).detach().abs().max()) < 1e-5
+    wo, wr = torch.randn(H, W, 3, generator=g), torch.randn(H, W, 3, generator=g)
+    ((oh * wo.to(gpu_device)).sum() + (rh * wr.to(gpu_device)).sum()).backward()
+    ((orf * wo.double()).sum() + (rr * wr.double()).sum()).backward()
+    assert float((nh.grad.cpu().double() - nr.grad).abs().max()) <= 3e-5 * float(nr.grad.abs().max())
+    assert float((dh.grad.cpu().double() - dr.grad).abs().max()) <= 3e-5 * float(dr.grad.abs().max())
