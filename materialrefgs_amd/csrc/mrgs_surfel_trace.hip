@@ -27,7 +27,7 @@
 //    bottom lane c tests surfel c's own square against the beam; the surviving surfels are visited one by one, their record broadcast
 //    from lane c (v_readlane), every lane evaluating the exact hit for ITS ray and inserting into its own sorted 16-entry buffer
 //    (LDS, [slot][lane]).  Blocks that do not run together split into 4x4 quadrants, then 2x2 groups.
-//  * ONE RAY, ONE WAVE (st_trace_lone_kernel): what is left over walks with the lanes turned sideways -- 64 children, then the 64
+//  * ONE RAY, ONE WAVE (st_trace_lone_rays): what is left over walks with the lanes turned sideways -- 64 children, then the 64
 //    surfels of a leaf group, against the one ray -- instead of alone in a lane (a dependent ~1 us gather per step).
 //  * 16-NEAREST PASSES: a ray gathers its 16 nearest not-yet-blended hits, blends them front to back, and continues behind the last
 //    one while the buffer came back full and the ray is not saturated; the walk's far bound closes when every ray of the packet has
@@ -649,7 +649,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     const bool no_ray = done;                       // sees the background; written by the first launch
     uint32_t packets_present = 0;
     const int packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
-    // rays that run with nobody are only listed here; st_trace_lone_kernel gives each a wave of its own
+    // rays that run with nobody are only listed here; the second launch gives each a wave of its own
     const bool lone = !done && packet < 0;
     bool deferred = false;                          // this block's packets are the second launch's
     if (only_packet < 0) {
@@ -872,26 +872,6 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
     st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)wave, -1, wave);
 }
 
-// second launch: one wave per listed packet
-template <int MODE>
-__global__ __launch_bounds__(ST_THREADS) void st_trace_packets_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
-                                                                      const unsigned long long* __restrict__ wide_vmask)
-{
-    __shared__ uint32_t kb_id[ST_K][ST_THREADS];
-    __shared__ float kb_t[ST_K][ST_THREADS];
-    if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;
-    const int tid = threadIdx.x;
-    const uint32_t listed = A.defer_list[0];
-    const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
-    const uint32_t stride = gridDim.x * (ST_THREADS / 64);
-    for (uint32_t item = blockIdx.x * (ST_THREADS / 64) + (tid >> 6); item < count; item += stride) {
-        const uint32_t code = A.defer_list[16 + item];
-        if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
-        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
-    }
-}
-
-
 // ---- rays that run with nobody: one WAVE per ray --------------------------------------------------------------------------------
 // A ray whose 2x2 neighbours point elsewhere (silhouettes, normals of barely covered pixels) cannot share a walk.  Walking alone in
 // a lane is the slow way on this machine: every step is a dependent ~1 us gather and the wave lasts as long as its slowest lane
@@ -924,14 +904,13 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(64) void st_trace_lone_kernel(StArgs A, const float4* __restrict__ leaf, const float* __restrict__ boxes,
-                                                           const unsigned long long* __restrict__ vmask, const uint32_t* __restrict__ lone_list)
+__device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4* __restrict__ leaf, const float* __restrict__ boxes,
+                                                   const unsigned long long* __restrict__ vmask, const uint32_t* __restrict__ lone_list,
+                                                   unsigned long long* slot, int lane, uint32_t first_item, uint32_t item_stride)
 {
-    __shared__ unsigned long long slot[ST_K];
-    const int lane = threadIdx.x;
     const uint32_t count = lone_list[0];
     const StWide& W = A.wide;
-    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    for (uint32_t item = first_item; item < count; item += item_stride) {
         const int64_t r = lone_list[16 + item];
         const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
         const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
@@ -1121,6 +1100,36 @@ __global__ __launch_bounds__(64) void st_trace_lone_kernel(StArgs A, const float
     }
 }
 
+// second launch: the first ST_PACKET_BLOCKS blocks give every listed packet a wave, the blocks behind them every listed single ray.
+// One launch for both: each kind ends in a tail of a few long waves, and the two tails overlap instead of following each other.
+constexpr int ST_PACKET_BLOCKS = 2048;
+constexpr int ST_LONE_BLOCKS = 4096;
+
+template <int MODE>
+__global__ __launch_bounds__(ST_THREADS) void st_trace_rest_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
+                                                                   const unsigned long long* __restrict__ wide_vmask, const uint32_t* __restrict__ lone_list)
+{
+    __shared__ uint32_t kb_id[ST_K][ST_THREADS];
+    __shared__ float kb_t[ST_K][ST_THREADS];
+    __shared__ unsigned long long slot[ST_THREADS / 64][ST_K];
+    if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= ST_PACKET_BLOCKS) {
+        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], tid & 63,
+                                      (blockIdx.x - ST_PACKET_BLOCKS) * (ST_THREADS / 64) + (tid >> 6), ST_LONE_BLOCKS * (ST_THREADS / 64));
+        return;
+    }
+    if (A.defer_list == nullptr) return;
+    const uint32_t listed = A.defer_list[0];
+    const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
+    const uint32_t stride = ST_PACKET_BLOCKS * (ST_THREADS / 64);
+    for (uint32_t item = blockIdx.x * (ST_THREADS / 64) + (tid >> 6); item < count; item += stride) {
+        const uint32_t code = A.defer_list[16 + item];
+        if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
+        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
+    }
+}
+
 }   // namespace
 
 extern "C" {
@@ -1219,7 +1228,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     static const char* cone_env = getenv("MRGS_TRACE_CONE");
     a.cone = cone_env ? (float)atof(cone_env) : 0.003f;
     const StateLayout SL = st_state(n_rays, a.ray_width);
-    const dim3 grid((unsigned)SL.grid), pgrid(2048);
+    const dim3 grid((unsigned)SL.grid), rgrid(ST_PACKET_BLOCKS + ST_LONE_BLOCKS);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
     a.lone_list = words + SL.lone;
     a.defer_list = words + SL.defer;
@@ -1240,17 +1249,14 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
             return MRGS_E_HIP;
         if (no_record) { a.rec_arena = nullptr; (void)hipMemsetAsync(a.rec_hdr + 1, 0x01, 4, st); }
         hipLaunchKernelGGL(st_trace_kernel<0>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
-        if (a.defer_list) hipLaunchKernelGGL(st_trace_packets_kernel<0>, pgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        hipLaunchKernelGGL(st_trace_rest_kernel<0>, rgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
     } else {
         // exactly one of the two pairs does the work: the replay of the forward's record, or -- when the record overflowed -- the walk
         hipLaunchKernelGGL(st_trace_kernel<2>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
-        if (a.defer_list) hipLaunchKernelGGL(st_trace_packets_kernel<2>, pgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        hipLaunchKernelGGL(st_trace_rest_kernel<2>, rgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
         hipLaunchKernelGGL(st_trace_kernel<1>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
-        if (a.defer_list) hipLaunchKernelGGL(st_trace_packets_kernel<1>, pgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
+        hipLaunchKernelGGL(st_trace_rest_kernel<1>, rgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
     }
-    const dim3 lgrid((unsigned)(n_rays < 16384 ? n_rays : 16384));
-    if (bwd) hipLaunchKernelGGL(st_trace_lone_kernel<true>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
-    else hipLaunchKernelGGL(st_trace_lone_kernel<false>, lgrid, dim3(64), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
