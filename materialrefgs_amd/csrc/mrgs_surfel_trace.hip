@@ -166,11 +166,18 @@ __global__ __launch_bounds__(256) void st_aabb_kernel(int P, const float* __rest
     __syncthreads();
     if (!last) return;
     __threadfence();
-    if (threadIdx.x < 6) {
-        uint32_t m = 0;
-        for (unsigned b = 0; b < gridDim.x; ++b) m = max(m, ld_agent_u(partial + b * 6 + threadIdx.x));
-        bounds[threadIdx.x] = m;
+    // thread b folds block b's row (gridDim.x <= 256 = blockDim.x); six dependent loops over 256 agent-scope loads cost 50 us
+    uint32_t mine[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mine[k] = threadIdx.x < gridDim.x ? ld_agent_u(partial + threadIdx.x * 6 + k) : 0u;
+    __syncthreads();                       // `red` is reused
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t m = wave_max_u(mine[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = m;
     }
+    __syncthreads();
+    if (threadIdx.x < 6) bounds[threadIdx.x] = max(max(red[0][threadIdx.x], red[1][threadIdx.x]), max(red[2][threadIdx.x], red[3][threadIdx.x]));
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)      // 10 bits -> every third bit

@@ -161,6 +161,7 @@ class SurfelTracer(nn.Module):
         self._blob = None
         self._ws = None
         self._n = 0
+        self.want_mid = True             # the per-depth record `mid` (41 MB for an 800x800 view): HardwareRendering reads it only for max_trace_depth > 0
         self.build_on_trace = False      # HardwareRendering sets it: build from the corners the record kernel writes (= get_disks')
 
     def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
@@ -217,7 +218,8 @@ class SurfelTracer(nn.Module):
         r = lambda x, c: x.reshape(*shape, c)
         rgb, dpt, acc, norm, dist, aux = r(rgb, 3), r(dpt, 1), r(acc, 1), r(norm, 3), r(dist, 1), r(aux, 2)
         # stage 0 of the per-depth record (optix_utils.py:28-35); deeper stages do not exist at max_trace_depth = 0
-        mid = torch.cat([ray_o.reshape(*shape, 3).float(), ray_d.reshape(*shape, 3).float(), dpt, acc, norm, aux, rgb], dim=-1).detach()
+        mid = torch.cat([ray_o.reshape(*shape, 3).float(), ray_d.reshape(*shape, 3).float(), dpt, acc, norm, aux, rgb], dim=-1).detach() \
+            if self.want_mid else rgb.new_empty((*shape, 0))
         return rgb, dpt, acc, norm, dist, aux, mid, wet.reshape(P, 1)
 
 
@@ -238,6 +240,7 @@ class HardwareRendering(nn.Module):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.tracer = SurfelTracer()
+        self.tracer.want_mid = False       # only read for max_trace_depth > 0 (:244-268), which is not built
         self.has_bvh = False
         self.mid_channel = MID_CHANNELS
         self.rayo_off, self.rayd_off, self.dpt_off, self.acc_off, self.norm_off, self.aux_off, self.rgb_off = 0, 3, 6, 7, 8, 11, 13
