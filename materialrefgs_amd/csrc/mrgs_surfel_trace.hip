@@ -802,7 +802,8 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
 #pragma unroll
                     for (int k = 0; k < 18; ++k) {
                         const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv[k]), 0xB1, 0xf, 0xf, true));
-                        gv[k] += (merge && lower) ? pv : 0.0f;
+                        const float sum = gv[k] + pv;                    // (v_add_f32_dpp: the move folds into the add)
+                        gv[k] = (merge && lower) ? sum : gv[k];
                     }
                     live = live && !(merge && !lower);
                 }
@@ -814,7 +815,8 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
 #pragma unroll
                     for (int k = 0; k < 18; ++k) {
                         const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv[k]), 0x4E, 0xf, 0xf, true));
-                        gv[k] += (merge && lower) ? pv : 0.0f;
+                        const float sum = gv[k] + pv;                    // (v_add_f32_dpp: the move folds into the add)
+                        gv[k] = (merge && lower) ? sum : gv[k];
                     }
                     live = live && !(merge && !lower);
                 }
@@ -826,7 +828,8 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
 #pragma unroll
                     for (int k = 0; k < 18; ++k) {
                         const float pv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv[k]), 0x128, 0xf, 0xf, true));
-                        gv[k] += (merge && lower) ? pv : 0.0f;
+                        const float sum = gv[k] + pv;                    // (v_add_f32_dpp: the move folds into the add)
+                        gv[k] = (merge && lower) ? sum : gv[k];
                     }
                     live = live && !(merge && !lower);
                 }
