@@ -603,6 +603,8 @@ __global__ __launch_bounds__(256) void st_leaf_order_kernel(int n_slots, int P, 
 
 // MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again (no record, or it overflowed);
 // 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same order, no hierarchy.
+constexpr int ST_TAB = 96;                // surfels a wave of the replaying backward accumulates in LDS before its gradients go out
+constexpr int ST_TAB_WORDS = ST_TAB * 19; // 18 gradient terms + the surfel's index per entry
 constexpr uint32_t ST_REC_DEFERRED = 0xFFFFFFFEu;   // in the last slot of a block's row of the chunk table: its packets went to the second launch
 
 // One 8x8 block of rays (64 consecutive rays when the rays are no image).  only_packet < 0: the first launch -- the block walks as one
@@ -612,7 +614,7 @@ constexpr uint32_t ST_REC_DEFERRED = 0xFFFFFFFEu;   // in the last slot of a blo
 template <int MODE>
 __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
                                               const unsigned long long* __restrict__ wide_vmask, uint32_t (*kb_id)[ST_THREADS],
-                                              float (*kb_t)[ST_THREADS], int tid, int64_t tile, int only_packet, uint32_t rec_row)
+                                              float (*kb_t)[ST_THREADS], uint32_t* tab, int tid, int64_t tile, int only_packet, uint32_t rec_row)
 {
     constexpr bool BWD = MODE != 0;
     int64_t r = tile * 64 + (tid & 63);
@@ -690,6 +692,19 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     }
     const bool mine = only_packet < 0 ? (no_ray || (packet >= 0 && !deferred)) : (packet == only_packet);
     bool want = !done && !lone && mine;
+    // The replaying backward first collects a surfel's gradient terms in LDS (per wave: ST_TAB entries, open addressing on the surfel's
+    // index): the rays of a block meet the same ~100 surfels at different ranks and in different passes, and the global float atomics
+    // (18 per hit) are what bounds this kernel.  An entry that finds no place within four probes goes out directly.
+    if (MODE == 2) {
+        for (int e = tid & 63; e < ST_TAB; e += 64) {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) tab[e * 19 + k] = 0u;
+            tab[e * 19 + 18] = ST_REC_NONE;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     StProf prof = {0, 0, 0};
     for (int pass = 0; pass < ST_MAX_PASSES; ++pass) {
         if (__ballot(want) == 0) break;
@@ -791,9 +806,25 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                     go[0] += dpx - dnum * nx; go[1] += dpy - dnum * ny; go[2] += dpz - dnum * nz;
                     gdir[0] += t * dpx + dden * nx; gdir[1] += t * dpy + dden * ny; gdir[2] += t * dpz + dden * nz;
                 }
+                bool placed = false;
+                if (MODE == 2 && act) {
+                    int slot = (int)(((id * 2654435761u) >> 16) % (uint32_t)ST_TAB);
+                    for (int probe = 0; probe < 4 && !placed; ++probe) {
+                        const uint32_t old = atomicCAS(&tab[slot * 19 + 18], ST_REC_NONE, id);
+                        if (old == ST_REC_NONE || old == id) placed = true;
+                        else slot = slot + 1 == ST_TAB ? 0 : slot + 1;
+                    }
+                    if (placed) {
+                        float* row = reinterpret_cast<float*>(tab) + slot * 19;
+#pragma unroll
+                        for (int k = 0; k < 18; ++k) atomicAdd(row + k, gv[k]);
+                    }
+                }
+                if (MODE != 2 || __ballot(act && !placed) != 0) {
+                const bool act_g = act && !placed;                          // (what is collected in LDS takes no part in the merge below)
                 // merge with the horizontal, then the vertical neighbour of the 8x8 block when both hold the same surfel: the lower
                 // lane of a pair carries the sum, the upper one is done (DPP moves: quad_perm [1,0,3,2] = lane ^ 1, [2,3,0,1] = lane ^ 2, row_ror:8 = lane ^ 8)
-                bool live = act;
+                bool live = act_g;
                 {
                     const uint32_t pid = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, 0xB1, 0xf, 0xf, true);
                     const bool plive = __builtin_amdgcn_update_dpp(0, (int)live, 0xB1, 0xf, 0xf, true) != 0;
@@ -841,6 +872,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
 #pragma unroll
                     for (int k = 0; k < 5; ++k) atomicAdd(ga_ + k, gv[13 + k]);
                 }
+                }
             }
             if (act) { T = test_T; ++blended; }
         }
@@ -848,6 +880,23 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         if (want && MODE != 2) {
             prev_t = kb_t[ST_K - 1][tid];
             prev_id = kb_id[ST_K - 1][tid];
+        }
+    }
+    if (MODE == 2) {                           // the collected gradients go out: one entry per lane and round
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = tid & 63; e < ST_TAB; e += 64) {
+            const uint32_t key = tab[e * 19 + 18];
+            if (key != ST_REC_NONE) {
+                const float* row = reinterpret_cast<const float*>(tab) + e * 19;
+                float* gg = A.g_geom + (size_t)key * 16;
+#pragma unroll
+                for (int k = 0; k < 13; ++k) atomicAdd(gg + k, row[k]);
+                float* ga_ = A.g_attr + (size_t)key * 8;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) atomicAdd(ga_ + k, row[13 + k]);
+            }
         }
     }
     if (!exists || !mine || lone) return;
@@ -874,12 +923,13 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_kernel(StArgs A, const fl
                                                               const unsigned long long* __restrict__ wide_vmask)
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
-    __shared__ float kb_t[ST_K][ST_THREADS];
+    __shared__ float kb_t[MODE == 2 ? 1 : ST_K][ST_THREADS];                 // (the replay needs no depths: it recomputes them)
+    __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
     const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6);
     if (wave >= A.n_tiles) return;
-    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)wave, -1, wave);
+    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)wave, -1, wave);
 }
 
 // ---- rays that run with nobody: one WAVE per ray --------------------------------------------------------------------------------
@@ -1120,7 +1170,8 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_rest_kernel(StArgs A, con
                                                                    const unsigned long long* __restrict__ wide_vmask, const uint32_t* __restrict__ lone_list)
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
-    __shared__ float kb_t[ST_K][ST_THREADS];
+    __shared__ float kb_t[MODE == 2 ? 1 : ST_K][ST_THREADS];
+    __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     __shared__ unsigned long long slot[ST_THREADS / 64][ST_K];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
@@ -1136,7 +1187,7 @@ __global__ __launch_bounds__(ST_THREADS) void st_trace_rest_kernel(StArgs A, con
     for (uint32_t item = blockIdx.x * (ST_THREADS / 64) + (tid >> 6); item < count; item += stride) {
         const uint32_t code = A.defer_list[16 + item];
         if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
-        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
+        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
     }
 }
 
