@@ -231,7 +231,7 @@ struct StArgs {
     uint32_t* defer_list;                 // [0] count, [16..] (tile << 5 | packet): the packets traced by the second launch, one per wave
     uint32_t defer_cap;
     uint32_t* lone_list;                  // [0] count, [16..] indices of the rays that walk alone (behind the per-ray state)
-    float cone;                           // 1 - cos of the half-angle within which a packet's directions must stay
+    float cone, cone_quad, cone_group;    // 1 - cos of the half-angle within which the directions of a block / quadrant / 2x2 group must stay
     const float4* attr;                   // [P][2]: (rgb, others.x) (others.y, -, -, -)
     float bg[3];
     float *rgb, *dpt, *acc, *norm, *dist, *aux, *wet, *state;     // state [n_rays][4]: M2, T_final, hits blended, passes
@@ -523,7 +523,7 @@ __device__ __forceinline__ int st_gather_wide(const StWide& W, const float* __re
     return n;
 }
 
-// Rays "run together" when their directions stay within a cone of ~4.4 degrees about their mean (1 - cos <= 0.003: wider beams of grazing rays sweep thousands of surfels; measured on mirror rays off a rendered view: 16 ms at 25 degrees, 9.5 at 11 before and 3.65 -> 1.9 at 11 -> 4.4 after the rays left over got waves of their own) and their origins within 2 % of the
+// Rays "run together" when their directions stay within a cone of ~5.7 degrees about their mean (1 - cos <= 0.005 for a block or a quadrant, 0.001 = 2.6 degrees for a 2x2 group: wider beams of grazing rays sweep thousands of surfels; measured on mirror rays off a rendered view: 16 ms at 25 degrees, 9.5 at 11 before and 3.65 -> 1.9 at 11 -> 4.4 after the rays left over got waves of their own) and their origins within 2 % of the
 // scene's extent of their centre.  `on` selects the rays asked about; the answer is wave-uniform.
 __device__ __forceinline__ bool st_run_together(float extent, float cone, bool on, float ox, float oy, float oz, float dx, float dy, float dz)
 {
@@ -567,7 +567,7 @@ __device__ __forceinline__ int st_assign_packets(const StArgs& A, const float* _
     for (int q = 0; q < 4; ++q) {
         const bool in_q = on && quad == q;
         if (__ballot(in_q) == 0) continue;
-        if (st_run_together(extent, A.cone, in_q, ox, oy, oz, dx, dy, dz)) {
+        if (st_run_together(extent, A.cone_quad, in_q, ox, oy, oz, dx, dy, dz)) {
             if (in_q) mine = 1 + q;
             present |= 1u << (1 + q);
             continue;
@@ -575,7 +575,7 @@ __device__ __forceinline__ int st_assign_packets(const StArgs& A, const float* _
         for (int g = 0; g < 4; ++g) {
             const bool in_g = in_q && sub == g;
             if (__ballot(in_g) == 0) continue;
-            if (st_run_together(extent, A.cone, in_g, ox, oy, oz, dx, dy, dz)) {
+            if (st_run_together(extent, A.cone_group, in_g, ox, oy, oz, dx, dy, dz)) {
                 if (in_g) mine = 5 + 4 * q + g;
                 present |= 1u << (5 + 4 * q + g);
             }
@@ -1287,7 +1287,11 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     static const bool no_packets = getenv("MRGS_TRACE_NO_PACKETS") != nullptr;      // developer switch: every ray gets a wave of its own
     a.packets = no_packets ? 0 : 1;
     static const char* cone_env = getenv("MRGS_TRACE_CONE");
-    a.cone = cone_env ? (float)atof(cone_env) : 0.003f;
+    a.cone = cone_env ? (float)atof(cone_env) : 0.005f;
+    static const char* cone1_env = getenv("MRGS_TRACE_CONE_QUAD");
+    static const char* cone2_env = getenv("MRGS_TRACE_CONE_GROUP");
+    a.cone_quad = cone1_env ? (float)atof(cone1_env) : a.cone;
+    a.cone_group = cone2_env ? (float)atof(cone2_env) : 0.2f * a.cone;       // 2x2 groups must be tighter still: four rays rarely pay for a wide beam
     const StateLayout SL = st_state(n_rays, a.ray_width);
     const dim3 grid((unsigned)SL.grid), rgrid(ST_PACKET_BLOCKS + ST_LONE_BLOCKS);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
