@@ -264,6 +264,10 @@ def test_hardware_rendering_mirror(gpu_device):
                  ("roughness", 1)):
         assert out[k].shape == (c, H, W), k
     assert out["weight_accumulate"].shape == (2000, 1) and out["visibility_filter"].shape == (2000,)
+    v, f = hr.get_disks(pc)                                   # optix_utils.py:36-66: corners and the two triangles per surfel
+    ref_v = sto.quad_vertices(pc.get_xyz.detach().cpu().double(), pc.get_scaling.detach().cpu().double(), pc._rotation.detach().cpu().double())
+    assert v.shape == (8000, 3) and f.shape == (4000, 3) and float((v.detach().cpu().double() - ref_v.reshape(-1, 3)).abs().max()) < 1e-5
+    assert f[:2].tolist() == [[0, 1, 2], [1, 2, 3]] and f.dtype == torch.int32
     assert float(out["rend_alpha"].mean()) > 0.3
     import glue_oracle
     sn_ref = glue_oracle.depth_to_normal(cam, out["surf_depth"].detach()).permute(2, 0, 1) * out["rend_alpha"].detach()
