@@ -56,7 +56,6 @@ def main():
     eye = torch.eye(4, device=dev)
     ts = SurfelTracingSettings(H, H, 1.0, 1.0, torch.zeros(3, device=dev), 1.0, eye, eye, 0, torch.zeros(3, device=dev), False, False)
     tr = SurfelTracer()
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
     def quads():
         from materialrefgs_amd.gs_utils import build_rotation
