@@ -511,3 +511,18 @@ def test_mirror_ray_kernel_matches_the_torch_statement(gpu_device):
     ((orf * wo.double()).sum() + (rr * wr.double()).sum()).backward()
     assert float((nh.grad.cpu().double() - nr.grad).abs().max()) <= 3e-5 * float(nr.grad.abs().max())
     assert float((dh.grad.cpu().double() - dr.grad).abs().max()) <= 3e-5 * float(dr.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["MRGS_TRACE_NO_DEFER", "MRGS_TRACE_NO_PACKETS", "MRGS_TRACE_NO_RECORD"])
+def test_fallback_paths_of_the_tracer(gpu_device, switch):
+    """The paths taken when a list is full (a block walks its own packets), when no rays run together (every ray a wave of its own) and
+    when the record is not kept (the backward walks again) are selected by developer switches read once per process: the gradient and
+    forward parity tests are run again in a child process with each switch set."""
+    import subprocess
+    env = dict(os.environ, **{switch: "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "gradients_match or many_layers or matches_the_dense_oracle and not 20000"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
