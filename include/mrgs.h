@@ -41,6 +41,8 @@ enum {
  * (diff_surfel_rasterization/__init__.py:167-179) plus the tensor extents the pybind layer derives
  * (rasterize_points.cu:69-72,116-121). */
 typedef struct MrgsRasterConfig {
+    uint32_t struct_size; /* = sizeof(MrgsRasterConfig) of the header the caller was built against; any other value -> MRGS_E_BAD_ARG
+                             (a caller built against another revision of this header is refused instead of being misread) */
     int32_t P;            /* number of gaussians (means3D.size(0)) */
     int32_t S;            /* extra feature channels (features.size(1)), 0..MRGS_MAX_FEATURES */
     int32_t D;            /* active SH degree (raster_settings.sh_degree) */
@@ -57,6 +59,9 @@ typedef struct MrgsRasterConfig {
  * opacities[P], scales[P,2]+rotations[P,4] (w,x,y,z) or both NULL with transMat_precomp[P,9] given.
  * Camera: viewmatrix[16], projmatrix[16] (row-vector convention tensors, read as stored), campos[3], bg[3]. */
 typedef struct MrgsRasterInputs {
+    uint64_t struct_size;  /* = sizeof(MrgsRasterInputs); checked like MrgsRasterConfig::struct_size.  The struct has grown optional
+                              trailing pointers (work_hint, shs_rest, bwd_grad_ws) which the calls ACT on: a shorter struct from an older
+                              header would make the library read them past its end */
     const float* bg;
     const float* means3D;
     const float* shs;
@@ -122,6 +127,7 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
 /* Gradient outputs of mrgs_rasterize_backward, the tuple returned by RasterizeGaussiansBackwardCUDA
  * (rasterize_points.cu:146-252): all fully written by the call (no pre-zeroing needed). */
 typedef struct MrgsRasterGrads {
+    uint64_t struct_size;  /* = sizeof(MrgsRasterGrads); checked like MrgsRasterConfig::struct_size */
     float* dL_dmeans2D;    /* [P,3]  (.xy = densification proxy, backward.cu:665-668; .z = 0) */
     float* dL_dcolors;     /* [P,3] */
     float* dL_dfeatures;   /* [P,S] */
@@ -474,6 +480,10 @@ int mrgs_get_kernel_times(MrgsKernelTimes* out);
 const char* mrgs_strerror(int code);
 const char* mrgs_last_hip_error(void);
 const char* mrgs_version(void);
+/* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
+ * against before the first call (materialrefgs_amd/_lib.py does). */
+#define MRGS_ABI_VERSION 3
+int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus
 }

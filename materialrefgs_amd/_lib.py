@@ -17,20 +17,27 @@ LIB_PATH = os.environ.get("MRGS_LIB") or os.path.join(_CSRC, "libmrgs.so")
 c_int32, c_int64, c_float, c_void_p, c_size_t = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 
-class MrgsRasterConfig(ctypes.Structure):
-    _fields_ = [("P", c_int32), ("S", c_int32), ("D", c_int32), ("M", c_int32), ("H", c_int32), ("W", c_int32),
+class _Sized(ctypes.Structure):
+    """Structs whose first field is `struct_size` (include/mrgs.h): filled in here, so positional arguments start at the second field."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(type(self)), *args, **kw)
+
+
+class MrgsRasterConfig(_Sized):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("P", c_int32), ("S", c_int32), ("D", c_int32), ("M", c_int32), ("H", c_int32), ("W", c_int32),
                 ("tanfovx", c_float), ("tanfovy", c_float), ("scale_modifier", c_float), ("prefiltered", c_int32),
                 ("debug", c_int32)]
 
 
-class MrgsRasterInputs(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
+class MrgsRasterInputs(_Sized):
+    _fields_ = [("struct_size", ctypes.c_uint64)] + [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
                                         "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint", "shs_rest",
                                         "bwd_grad_ws")]
 
 
-class MrgsRasterGrads(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dfeatures", "dL_dopacity", "dL_dmeans3D",
+class MrgsRasterGrads(_Sized):
+    _fields_ = [("struct_size", ctypes.c_uint64)] + [(n, c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dfeatures", "dL_dopacity", "dL_dmeans3D",
                                         "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dsh_rest")]
 
 
@@ -171,7 +178,9 @@ SYMBOLS = {
     "mrgs_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "mrgs_last_hip_error": (ctypes.c_char_p, []),
     "mrgs_version": (ctypes.c_char_p, []),
+    "mrgs_abi_version": (c_int32, []),
 }
+MRGS_ABI_VERSION = 3   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 
@@ -196,6 +205,9 @@ def lib():
             fn = getattr(L, name)   # AttributeError here = the library does not export what mrgs.h declares
             fn.restype = res
             fn.argtypes = args
+        if L.mrgs_abi_version() != MRGS_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} implements ABI revision {L.mrgs_abi_version()} of include/mrgs.h, this binding was written "
+                              f"against revision {MRGS_ABI_VERSION}: rebuild the library (make -C materialrefgs_amd/csrc)")
         _lib = L
     return _lib
 

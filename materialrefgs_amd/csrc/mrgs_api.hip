@@ -2,6 +2,7 @@
 // interfaces each entry replaces).
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "mrgs_internal.h"
@@ -43,8 +44,8 @@ struct StageTimer {
     // an event pair costs two ~6 us bubbles on the stream, which a throughput measurement should not pay on every launch
     static bool sampled(int stage)
     {
-        static unsigned calls = 0;
-        return stage == ST_BWD && (calls++ & 3u) == 0u;
+        static std::atomic<unsigned> calls{0};   // autograd runs the backward on worker threads
+        return stage == ST_BWD && (calls.fetch_add(1u, std::memory_order_relaxed) & 3u) == 0u;
     }
     StageTimer(hipStream_t stream, int stage)
         : s(stream), on(g_profiling == 1 || (g_profiling == 2 && (stage == ST_FWD || stage == ST_BWD)) || (g_profiling == 3 && sampled(stage)))
@@ -179,6 +180,9 @@ static int plist_buf(const MrgsGeomWs& g, int ntiles) { return g.tile_mat != nul
 static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
 {
     if (!cfg || !in) return MRGS_E_BAD_ARG;
+    // a caller built against another revision of mrgs.h (e.g. MrgsRasterInputs without its trailing optional pointers, which the calls act
+    // on) is refused before anything is read
+    if (cfg->struct_size != sizeof(MrgsRasterConfig) || in->struct_size != sizeof(MrgsRasterInputs)) return MRGS_E_BAD_ARG;
     if (cfg->P < 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->S < 0 || cfg->M < 0) return MRGS_E_BAD_ARG;
     if (cfg->S > MRGS_MAX_FEATURES) return MRGS_E_TOO_MANY_FEATURES;
     if (cfg->P > 0) {
@@ -393,7 +397,7 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     hipStream_t stream = (hipStream_t)stream_;
     int rc = check_cfg(cfg, in);
     if (rc) return rc;
-    if (!grads) return MRGS_E_BAD_ARG;
+    if (!grads || grads->struct_size != sizeof(MrgsRasterGrads)) return MRGS_E_BAD_ARG;
     if (cfg->P == 0) return MRGS_OK;   // every gradient tensor has zero elements
     if (!radii || !geom_ws || !binning_ws || !img_ws || !grad_ws || !dL_dout_color || !dL_dout_others) return MRGS_E_BAD_ARG;
     if (cfg->S > 0 && !dL_dout_feature) return MRGS_E_BAD_ARG;
@@ -469,7 +473,7 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
                       int32_t which, void* dst, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!cfg || !dst) return MRGS_E_BAD_ARG;
+    if (!cfg || !dst || cfg->struct_size != sizeof(MrgsRasterConfig)) return MRGS_E_BAD_ARG;
     const int P = cfg->P;
     const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const size_t hw = (size_t)cfg->H * cfg->W;
@@ -534,6 +538,7 @@ const char* mrgs_strerror(int code)
     }
 }
 const char* mrgs_last_hip_error(void) { return g_hip_err; }
-const char* mrgs_version(void) { return "mrgs 0.1.0 (gfx950)"; }
+const char* mrgs_version(void) { return "mrgs 0.3.0 (gfx950)"; }
+int32_t mrgs_abi_version(void) { return MRGS_ABI_VERSION; }
 
 }   // extern "C"

@@ -17,37 +17,65 @@ from . import _lib
 from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
 
 
-_PAIR_GUESS = {}   # device index -> pair capacity to try first (previous count + 25 %)
+_PAIR_GUESS = {}   # (device index, P, H, W) -> pair capacity to try first (previous count of that configuration + 25 %)
+_PAIR_GUESS_MAX = 64
 # Per-camera work hints (MrgsRasterInputs::work_hint): the forward orders its blend waves by what each 8x8 block cost the last time the
 # same camera was rendered.  Keyed by the camera's matrices (the tensors a training loop keeps per camera), bounded, and purely a
-# scheduling aid: results do not depend on it.
+# scheduling aid: results do not depend on it.  An entry holds its two matrices, so their storage cannot be handed to another camera's
+# tensors while the entry exists (the address is the key), and a hit must be the same storage at the same version.
 _WORK_HINTS = {}
 _NO_HINT = bool(int(__import__("os").environ.get("MRGS_NO_WORK_HINT", "0")))   # developer switch for A/B timing
 _NO_PREPARE = bool(int(__import__("os").environ.get("MRGS_NO_PREPARE_BWD", "0")))   # developer switch: the backward orders / clears by itself
 _WORK_HINTS_MAX = 2048
 
 
+def _hint_key(raster_settings, device):
+    vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
+    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr())
+
+
+def _hint_entry(raster_settings, device):
+    """The (hint buffer, viewmatrix, projmatrix, versions, visits) entry of this camera, or None when it was never rendered or when its
+    matrices were written in place since."""
+    ent = _WORK_HINTS.get(_hint_key(raster_settings, device))
+    if ent is None:
+        return None
+    vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
+    if ent[3] != (vm._version, pm._version):
+        return None
+    return ent
+
+
 def _hint_is_warm(raster_settings, device):
     """True when this camera was rendered before, i.e. its hint holds measured work.  Only then may the forward set up the backward's
     queues (they are a copy of its own): built from the cull counts alone they balance the backward a third worse than the
     backward's own ordering by what the forward waves walked."""
-    vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
-    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr()) in _WORK_HINTS
+    ent = _hint_entry(raster_settings, device)
+    return ent is not None and ent[4][0] > 0
 
 
-def _work_hint(raster_settings, device):
+def _work_hint(raster_settings, device, count_visit=False):
     if _NO_HINT:
         return None
-    vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
-    key = (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr())
-    h = _WORK_HINTS.get(key)
-    if h is None:
+    ent = _hint_entry(raster_settings, device)
+    if ent is None:
         if len(_WORK_HINTS) >= _WORK_HINTS_MAX:
             _WORK_HINTS.pop(next(iter(_WORK_HINTS)))
         n = _lib.lib().mrgs_work_hint_bytes(int(raster_settings.image_height), int(raster_settings.image_width)) // 4
-        h = torch.zeros(max(int(n), 1), dtype=torch.int32, device=device)
-        _WORK_HINTS[key] = h
-    return h
+        vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
+        ent = (torch.zeros(max(int(n), 1), dtype=torch.int32, device=device), vm, pm, (vm._version, pm._version), [0])
+        _WORK_HINTS[_hint_key(raster_settings, device)] = ent
+    if count_visit:
+        ent[4][0] += 1
+    return ent[0]
+
+
+def reset_work_hints():
+    """Forget every camera's measured work (the next render of each camera is a first visit again).  A training loop calls this after
+    densification / pruning changed the surfel set; bench.py uses it to time first visits."""
+    _WORK_HINTS.clear()
+
+
 _ZERO_CONTRIB = {}
 
 
@@ -135,7 +163,8 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         img = torch.empty((L.mrgs_img_bytes(H, W),), dtype=torch.uint8, device=dev)
         R = ctypes.c_int64(0)
         global LAST_NUM_RENDERED
-        guess = _PAIR_GUESS.get(dev.index)
+        guess_key = (dev.index, P, H, W)
+        guess = _PAIR_GUESS.get(guess_key)
         pairs = None            # pair count the binning workspace is carved for (what the backward must be given)
         if guess is not None and P > 0:
             # one call, no host round trip in the middle of the GPU work: the workspace is sized from the previous call's
@@ -159,7 +188,11 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
             _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
                                                        _ptr(img), pairs, _ptr(color), _ptr(feature), _ptr(others), st))
         if P > 0:
-            _PAIR_GUESS[dev.index] = max(int(num_rendered * 1.25) + 65536, 1)
+            if guess_key not in _PAIR_GUESS and len(_PAIR_GUESS) >= _PAIR_GUESS_MAX:
+                _PAIR_GUESS.pop(next(iter(_PAIR_GUESS)))
+            _PAIR_GUESS[guess_key] = max(int(num_rendered * 1.25) + 65536, 1)
+            if inp.work_hint:
+                _work_hint(raster_settings, dev, count_visit=True)   # this camera's hint now holds measured work
     return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
 
 
@@ -182,7 +215,7 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
              "dL_dsh": torch.empty((P, 1 if sh_rest is not None else M, 3), **opts), "dL_dscales": torch.empty((P, 2), **opts),
              "dL_drotations": torch.empty((P, 4), **opts),
              "dL_dsh_rest": torch.empty((P, M - 1, 3), **opts) if sh_rest is not None else None}
-        grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_])
+        grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_[1:]])
         grad_ws = prepared_grad_ws if prepared_grad_ws is not None else torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
         _lib.check(L.mrgs_rasterize_backward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
                                              num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),

@@ -515,13 +515,16 @@ def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_c
     """gaussian_renderer/__init__.py:486-520: render_surfel, then the same surfels traced along every pixel's mirror ray
     (`indirect_renderer`: HardwareRendering, here materialrefgs_amd.surfel_tracing) and blended in with the traced `specular`
     channel as weight; the tracer's dictionary is returned under "indirect_out"."""
-    results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt)
+    # wo_render_img / normal_img_map are handed on as the reference does (:487-489); with wo_render_img the dictionary has no "render"
+    # and the lines below fail with the reference's own KeyError
+    results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt, wo_render_img, normal_img_map)
+    final_image = results["render"]
     alpha = results["rend_alpha"].permute(1, 2, 0)
     normal_map = safe_normalize(results["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))
     ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, results["surf_depth"])
     traced = indirect_renderer(viewpoint_camera, ray_o=ray_o, ray_d=ray_d, pcd=pc, pipe=pipe, bg_color=bg_color, start_from_first=False)
     specular = traced["specular"]
-    results["render"] = results["render"] * (1 - specular) + specular * traced["render"]
+    results["render"] = final_image * (1 - specular) + specular * traced["render"]
     results["indirect_out"] = traced
     return results
 
@@ -530,7 +533,7 @@ def render_surfel_with_envgs_sep(indirect_renderer, env, viewpoint_camera, pc, p
                                  opt=None, wo_render_img=False, normal_img_map=None):
     """gaussian_renderer/envgs_renderer.py:771-807: as render_surfel_with_envgs, but the mirror rays see the separate ENVIRONMENT surfel
     set `env`, and the blend weight is render_surfel's per-pixel "specular_weight" ([H,W,3], returned with opt.indirect)."""
-    results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt)
+    results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt, wo_render_img, normal_img_map)
     weight = results["specular_weight"].permute(2, 0, 1)
     alpha = results["rend_alpha"].permute(1, 2, 0)
     normal_map = safe_normalize(results["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))

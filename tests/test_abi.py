@@ -55,6 +55,52 @@ def test_argument_validation_without_gpu():
     assert R.value == 0
 
 
+def test_struct_size_guard():
+    """A caller built against another revision of include/mrgs.h -- e.g. the 14-pointer MrgsRasterInputs of the header before
+    `bwd_grad_ws` was appended, which the forward ACTS on -- is refused with MRGS_E_BAD_ARG before anything is read (no GPU needed:
+    the check precedes every HIP call).  sizeof of the ctypes declarations is pinned to the header's layout."""
+    from materialrefgs_amd import _lib
+    from materialrefgs_amd._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
+    L = _lib.lib()
+    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 3
+    assert ctypes.sizeof(MrgsRasterConfig) == 4 + 11 * 4          # struct_size + 6 ints + 3 floats + 2 ints
+    assert ctypes.sizeof(MrgsRasterInputs) == 8 + 15 * 8          # struct_size + 12 pointers + work_hint, shs_rest, bwd_grad_ws
+    assert ctypes.sizeof(MrgsRasterGrads) == 8 + 10 * 8
+    hdr = open(os.path.join(ROOT, "include", "mrgs.h")).read()
+    assert "#define MRGS_ABI_VERSION 3" in hdr
+
+    class OldInputs(ctypes.Structure):                           # the struct as INTEGRATION.md printed it in round 2: 14 pointers, no size
+        _fields_ = [(n, ctypes.c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales", "rotations",
+                                                   "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint", "shs_rest")]
+
+    class ShortInputs(ctypes.Structure):                         # right first field, one trailing pointer short
+        _fields_ = [("struct_size", ctypes.c_uint64)] + OldInputs._fields_
+
+    cfg = MrgsRasterConfig(10, 0, 3, 16, 64, 64, 0.3, 0.3, 1.0, 0, 0)
+    R = ctypes.c_int64(-1)
+    fwd = L.mrgs_rasterize_forward_geom
+    keep = fwd.argtypes
+    fwd.argtypes = None                                          # let the foreign structs through the ctypes type check
+    try:
+        junk = ctypes.c_void_p(0xdead0000)
+        old = OldInputs(*([junk] * 14))
+        assert fwd(ctypes.byref(cfg), ctypes.byref(old), None, ctypes.c_size_t(0), None, ctypes.byref(R), None) == 1
+        short = ShortInputs(ctypes.sizeof(ShortInputs), *([junk] * 14))
+        assert fwd(ctypes.byref(cfg), ctypes.byref(short), None, ctypes.c_size_t(0), None, ctypes.byref(R), None) == 1
+        good = MrgsRasterInputs()
+        bad_cfg = MrgsRasterConfig(0, 0, 3, 16, 64, 64, 0.3, 0.3, 1.0, 0, 0)
+        bad_cfg.struct_size = 44                                 # the round-2 MrgsRasterConfig had no size field
+        assert fwd(ctypes.byref(bad_cfg), ctypes.byref(good), None, ctypes.c_size_t(0), None, ctypes.byref(R), None) == 1
+        bad_cfg.struct_size = ctypes.sizeof(MrgsRasterConfig)    # P = 0 with the right sizes: accepted, nothing to launch
+        assert fwd(ctypes.byref(bad_cfg), ctypes.byref(good), None, ctypes.c_size_t(0), None, ctypes.byref(R), None) == 0
+    finally:
+        fwd.argtypes = keep
+    g = MrgsRasterGrads()
+    g.struct_size = 80
+    assert L.mrgs_rasterize_backward(ctypes.byref(bad_cfg), ctypes.byref(good), None, None, None, None, 0, None, None, None, None,
+                                     ctypes.byref(g), None) == 1
+
+
 def test_python_wrapper_validation():
     """Same exceptions as the reference wrapper (diff_surfel_rasterization/__init__.py:201-205)."""
     import torch
