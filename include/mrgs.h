@@ -376,13 +376,19 @@ int mrgs_bvh_visibility(const void* blob_dev, int64_t n_triangles, int32_t H, in
 size_t mrgs_surfel_bvh_bytes(int64_t n_surfels);
 size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels);
 size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width);
+/* A state WITHOUT the replay record (the per-ray part and the lists only; ~1/100 of the full size): enough for a forward whose
+ * backward will never run (evaluation, torch.no_grad()).  Both trace calls take the size of the state they are handed (state_floats):
+ * at least the full size -> the forward records; at least this size -> it does not, and a backward on such a state walks the hierarchy
+ * again; smaller -> MRGS_E_WORKSPACE.  n_rays >= 2^31 (or >= 2^27 blocks of rays) -> MRGS_E_UNSUPPORTED.  n_surfels == 0: outputs are
+ * the background / zeros, `state` is not touched. */
+size_t mrgs_surfel_trace_state_floats_norecord(int64_t n_rays, int32_t ray_width);
 int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* blob, size_t blob_bytes, void* ws, size_t ws_bytes, void* stream);
 int mrgs_surfel_trace_forward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
                               const float* attr, const float* bg_host, float* rgb, float* dpt, float* acc, float* norm, float* dist,
-                              float* aux, float* wet, float* state, void* stream);
+                              float* aux, float* wet, float* state, size_t state_floats, void* stream);
 int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
                                const float* attr, const float* bg_host, const float* rgb, const float* dpt, const float* acc,
-                               const float* norm, const float* aux, const float* state, const float* g_rgb, const float* g_dpt,
+                               const float* norm, const float* aux, const float* state, size_t state_floats, const float* g_rgb, const float* g_dpt,
                                const float* g_acc, const float* g_norm, const float* g_dist, const float* g_aux, float* g_geom,
                                float* g_attr, float* g_ray_o, float* g_ray_d, void* stream);
 

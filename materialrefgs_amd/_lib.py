@@ -148,6 +148,7 @@ SYMBOLS = {
     "mrgs_surfel_bvh_bytes": (c_size_t, [c_int64]),
     "mrgs_surfel_bvh_ws_bytes": (c_size_t, [c_int64]),
     "mrgs_surfel_trace_state_floats": (c_size_t, [c_int64, c_int32]),
+    "mrgs_surfel_trace_state_floats_norecord": (c_size_t, [c_int64, c_int32]),
     "mrgs_mirror_rays_forward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap), c_void_p,
                                                 c_void_p, c_void_p, c_void_p]),
     "mrgs_mirror_rays_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap), c_void_p,
@@ -155,8 +156,8 @@ SYMBOLS = {
     "mrgs_surfel_trace_prep_forward": (ctypes.c_int, [c_int64] + [c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 3 + [c_float] + [c_void_p] * 4),
     "mrgs_surfel_trace_prep_backward": (ctypes.c_int, [c_int64] + [c_void_p] * 4 + [c_int32, c_int32, c_void_p, c_float] + [c_void_p] * 10),
     "mrgs_surfel_bvh_build": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
-    "mrgs_surfel_trace_forward": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32] + [c_void_p] * 4 + [ctypes.POINTER(c_float)] + [c_void_p] * 9),
-    "mrgs_surfel_trace_backward": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32] + [c_void_p] * 4 + [ctypes.POINTER(c_float)] + [c_void_p] * 17),
+    "mrgs_surfel_trace_forward": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32] + [c_void_p] * 4 + [ctypes.POINTER(c_float)] + [c_void_p] * 8 + [c_size_t, c_void_p]),
+    "mrgs_surfel_trace_backward": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32] + [c_void_p] * 4 + [ctypes.POINTER(c_float)] + [c_void_p] * 6 + [c_size_t] + [c_void_p] * 11),
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_sh_grad_expand_surfel": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p]),

@@ -1236,6 +1236,20 @@ static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte
 }
 
 size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).total; }
+size_t mrgs_surfel_trace_state_floats_norecord(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).rec_arena; }
+
+// rays and blocks of rays are carried in 32-bit words (ray indices in the lists, `tile << 5 | packet` codes, the launch grid)
+static bool st_ray_count_supported(int64_t n_rays, int32_t ray_width)
+{
+    if (n_rays >= ((int64_t)1 << 31)) return false;
+    return st_state(n_rays, ray_width).n_tiles < ((int64_t)1 << 27);
+}
+
+__global__ void st_fill_bg_kernel(int64_t n_rays, float b0, float b1, float b2, float* __restrict__ rgb)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rays) { rgb[3 * i] = b0; rgb[3 * i + 1] = b1; rgb[3 * i + 2] = b2; }
+}
 
 size_t mrgs_surfel_bvh_ws_bytes(int64_t n_surfels)
 {
@@ -1272,7 +1286,7 @@ int mrgs_surfel_bvh_build(const float* quad_vertices, int64_t n_surfels, void* b
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
-static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, StArgs& a, hipStream_t st)
+static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, size_t state_floats, StArgs& a, hipStream_t st)
 {
     a.n_rays = n_rays;
     const BlobLayout bl = st_blob(n_surfels);
@@ -1293,6 +1307,8 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     a.cone_quad = cone1_env ? (float)atof(cone1_env) : a.cone;
     a.cone_group = cone2_env ? (float)atof(cone2_env) : 0.2f * a.cone;       // 2x2 groups must be tighter still: four rays rarely pay for a wide beam
     const StateLayout SL = st_state(n_rays, a.ray_width);
+    if (state_floats < SL.rec_arena) return MRGS_E_WORKSPACE;
+    const bool have_arena = state_floats >= SL.total;       // a state without the replay record (forward-only callers): the backward walks again
     const dim3 grid((unsigned)SL.grid), rgrid(ST_PACKET_BLOCKS + ST_LONE_BLOCKS);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
     a.lone_list = words + SL.lone;
@@ -1312,7 +1328,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
             hipMemsetAsync(words + SL.defer, 0, 64, st) != hipSuccess || hipMemsetAsync(words + SL.defer + 16, 0xFF, (size_t)SL.defer_cap * 4, st) != hipSuccess ||
             hipMemsetAsync(a.rec_chunks, 0xFF, ((size_t)SL.n_tiles + SL.defer_cap) * ST_REC_PASSES * 4, st) != hipSuccess)
             return MRGS_E_HIP;
-        if (no_record) { a.rec_arena = nullptr; (void)hipMemsetAsync(a.rec_hdr + 1, 0x01, 4, st); }
+        if (no_record || !have_arena) { a.rec_arena = nullptr; (void)hipMemsetAsync(a.rec_hdr + 1, 0x01, 4, st); }
         hipLaunchKernelGGL(st_trace_kernel<0>, grid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask);
         hipLaunchKernelGGL(st_trace_rest_kernel<0>, rgrid, dim3(ST_THREADS), 0, st, a, a.geom_leaf, wide_boxes, wide_vmask, a.lone_list);
     } else {
@@ -1327,36 +1343,37 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
 
 int mrgs_surfel_trace_forward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
                               const float* attr, const float* bg_host, float* rgb, float* dpt, float* acc, float* norm, float* dist,
-                              float* aux, float* wet, float* state, void* stream)
+                              float* aux, float* wet, float* state, size_t state_floats, void* stream)
 {
-    if (n_rays < 0 || n_surfels < 0 || n_surfels > (int64_t)1 << 24) return MRGS_E_UNSUPPORTED;
+    if (n_rays < 0 || n_surfels < 0 || n_surfels > (int64_t)1 << 24 || !st_ray_count_supported(n_rays, ray_width)) return MRGS_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (n_surfels > 0 && wet && hipMemsetAsync(wet, 0, (size_t)n_surfels * 4, st) != hipSuccess) return MRGS_E_HIP;
     if (n_rays == 0) return MRGS_OK;
-    if (!ray_o || !ray_d || !bg_host || !rgb || !dpt || !acc || !norm || !dist || !aux || !state) return MRGS_E_BAD_ARG;
-    if (n_surfels > 0 && (!blob || !geom || !attr || !wet)) return MRGS_E_BAD_ARG;
+    if (!bg_host || !rgb || !dpt || !acc || !norm || !dist || !aux) return MRGS_E_BAD_ARG;
+    if (n_surfels > 0 && (!ray_o || !ray_d || !state || !blob || !geom || !attr || !wet)) return MRGS_E_BAD_ARG;
     if (n_surfels == 0) {                                                  // nothing to hit: background everywhere
         if (hipMemsetAsync(dpt, 0, n_rays * 4, st) != hipSuccess || hipMemsetAsync(acc, 0, n_rays * 4, st) != hipSuccess ||
             hipMemsetAsync(norm, 0, n_rays * 12, st) != hipSuccess || hipMemsetAsync(dist, 0, n_rays * 4, st) != hipSuccess ||
             hipMemsetAsync(aux, 0, n_rays * 8, st) != hipSuccess)
             return MRGS_E_HIP;
-        return MRGS_E_UNSUPPORTED;                                         // rgb = bg needs a kernel; callers do not trace empty sets
+        hipLaunchKernelGGL(st_fill_bg_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, n_rays, bg_host[0], bg_host[1], bg_host[2], rgb);
+        return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;    // (an empty model, e.g. after pruning everything; `state` is not touched)
     }
     StArgs a;
     std::memset(&a, 0, sizeof(a));
     a.ray_o = ray_o; a.ray_d = ray_d; a.geom = (const float4*)geom; a.attr = (const float4*)attr;
     a.bg[0] = bg_host[0]; a.bg[1] = bg_host[1]; a.bg[2] = bg_host[2];
     a.rgb = rgb; a.dpt = dpt; a.acc = acc; a.norm = norm; a.dist = dist; a.aux = aux; a.wet = wet; a.state = state;
-    return st_launch(false, blob, n_surfels, n_rays, ray_width, a, st);
+    return st_launch(false, blob, n_surfels, n_rays, ray_width, state_floats, a, st);
 }
 
 int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
                                const float* attr, const float* bg_host, const float* rgb, const float* dpt, const float* acc,
-                               const float* norm, const float* aux, const float* state, const float* g_rgb, const float* g_dpt,
+                               const float* norm, const float* aux, const float* state, size_t state_floats, const float* g_rgb, const float* g_dpt,
                                const float* g_acc, const float* g_norm, const float* g_dist, const float* g_aux, float* g_geom,
                                float* g_attr, float* g_ray_o, float* g_ray_d, void* stream)
 {
-    if (n_rays < 0 || n_surfels <= 0 || n_surfels > (int64_t)1 << 24) return MRGS_E_UNSUPPORTED;
+    if (n_rays < 0 || n_surfels <= 0 || n_surfels > (int64_t)1 << 24 || !st_ray_count_supported(n_rays, ray_width)) return MRGS_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (!g_geom || !g_attr) return MRGS_E_BAD_ARG;
     if (hipMemsetAsync(g_geom, 0, (size_t)n_surfels * 64, st) != hipSuccess || hipMemsetAsync(g_attr, 0, (size_t)n_surfels * 32, st) != hipSuccess)
@@ -1373,7 +1390,7 @@ int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, in
     a.aux = const_cast<float*>(aux); a.state = const_cast<float*>(state);
     a.g_rgb = g_rgb; a.g_dpt = g_dpt; a.g_acc = g_acc; a.g_norm = g_norm; a.g_dist = g_dist; a.g_aux = g_aux;
     a.g_geom = g_geom; a.g_attr = g_attr; a.g_ray_o = g_ray_o; a.g_ray_d = g_ray_d;
-    return st_launch(true, blob, n_surfels, n_rays, ray_width, a, st);
+    return st_launch(true, blob, n_surfels, n_rays, ray_width, state_floats, a, st);
 }
 
 }   // extern "C"

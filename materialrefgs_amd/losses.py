@@ -140,18 +140,56 @@ def smooth_loss(data):
     return spatial_gradient(data[None])[0].abs().sum(1).mean()
 
 
+_LPIPS_FN = None          # the network behind lpips_loss: callable(x, y) on [1,3,H,W] images scaled to [-1, 1] -> per-image distances
+_LPIPS_WARNED = False
+
+
+def set_lpips_fn(fn):
+    """Register the perceptual network of utils/loss_utils.py:35-43 (`lpips.LPIPS(net='vgg')` in the reference).  Its VGG weights are a
+    network download and not part of this build, so the term is pluggable: `set_lpips_fn(lpips.LPIPS(net='vgg').cuda())` where the
+    package is installed, or any callable with that signature.  None unregisters."""
+    global _LPIPS_FN
+    _LPIPS_FN = fn
+
+
+def lpips_loss(x, y, net="vgg"):
+    """utils/loss_utils.py:35-43: the registered network on the images mapped from [0, 1] to [-1, 1], mean over the batch."""
+    global _LPIPS_FN
+    if _LPIPS_FN is None:
+        try:
+            import lpips as lpips_module           # the reference's own lazy construction (:38-41), where the package exists
+        except ImportError as ex:
+            raise NotImplementedError(
+                "lpips_loss (utils/loss_utils.py:35-43) needs the LPIPS network: `pip install lpips` is not possible here and its weights are "
+                "not part of this build.  Register a network with materialrefgs_amd.losses.set_lpips_fn(...) or run with "
+                "--no-use_perceptual_loss (INTEGRATION.md)") from ex
+        _LPIPS_FN = lpips_module.LPIPS(net=net, verbose=False).to(x.device)
+    return _LPIPS_FN(x * 2.0 - 1.0, y * 2.0 - 1.0).mean()
+
+
 def check_loss_config(opt):
-    """Call once at set-up: the reference enables the LPIPS term by default (arguments/__init__.py: use_perceptual_loss = True from
-    iteration 18 000); it needs the `lpips` package and its VGG weights, which this build does not ship, and failing 18 000
-    iterations into a run is the wrong moment to find out."""
-    if getattr(opt, "use_perceptual_loss", False):
-        raise NotImplementedError("lpips_loss (utils/loss_utils.py:35-43) needs the LPIPS network weights, which are not part of this build: "
-                                  "run with --no-use_perceptual_loss (INTEGRATION.md)")
+    """Optional set-up check (a training script may call it before iteration 1): the reference enables the LPIPS term by default
+    (arguments/__init__.py:223-225: use_perceptual_loss = True, active after perceptual_loss_start_iter = 18 000); raise now rather
+    than 18 000 iterations into a run when no network is registered and the `lpips` package is absent."""
+    if getattr(opt, "use_perceptual_loss", False) and _LPIPS_FN is None:
+        try:
+            import lpips  # noqa: F401
+        except ImportError as ex:
+            raise NotImplementedError("opt.use_perceptual_loss is set but no LPIPS network is available: materialrefgs_amd.losses.set_lpips_fn(...) "
+                                      "or --no-use_perceptual_loss (INTEGRATION.md)") from ex
 
 
 def calculate_loss(viewpoint_camera, pc, render_pkg, opt, iteration, image_weight=None, bg_mask=None):
     """utils/loss_utils.py:142-228: same arguments, same keys in tb_dict (values are 0-d tensors, see module docstring)."""
-    check_loss_config(opt)      # at the FIRST call, whatever the iteration
+    use_perc = bool(getattr(opt, "use_perceptual_loss", False))
+    global _LPIPS_WARNED
+    if use_perc and _LPIPS_FN is None and not _LPIPS_WARNED:
+        # the reference's defaults reach this state (the term is on by default and becomes active at iteration 18 000): training runs
+        # as the reference does until then; say once what will happen at that iteration instead of failing at iteration 1
+        _LPIPS_WARNED = True
+        import warnings
+        warnings.warn(f"opt.use_perceptual_loss is set and no LPIPS network is registered (materialrefgs_amd.losses.set_lpips_fn): the loss "
+                      f"will raise once iteration > {getattr(opt, 'perceptual_loss_start_iter', '?')} unless the `lpips` package is importable")
     image = render_pkg["render"]
     gt_image = viewpoint_camera.original_image
     if not gt_image.is_cuda:
@@ -181,6 +219,11 @@ def calculate_loss(viewpoint_camera, pc, render_pkg, opt, iteration, image_weigh
     if use_dsmooth:
         tb_dict["loss_depth_smooth"] = first_order_edge_aware_loss(render_pkg["surf_depth"], gt_image)
         loss = loss + opt.lambda_depth_smooth * tb_dict["loss_depth_smooth"]
+    if use_perc and iteration > opt.perceptual_loss_start_iter:                         # :212-215
+        perc_loss = lpips_loss(image.unsqueeze(0), gt_image.unsqueeze(0))
+        loss = loss + opt.lambda_perceptual_loss * perc_loss
+        tb_dict["perceptual_loss"] = perc_loss.detach()
+        tb_dict["loss"] = loss.detach()
     if use_nsmooth or use_dsmooth:
         tb_dict["loss"] = loss.detach()
     return loss, tb_dict

@@ -65,11 +65,15 @@ class _Trace(torch.autograd.Function):
         n_rays, P = ray_o.shape[0], geom.shape[0]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         rgb, norm, aux, dpt, acc, dist = new(n_rays, 3), new(n_rays, 3), new(n_rays, 2), new(n_rays), new(n_rays), new(n_rays)
-        wet, state = new(P), new(L.mrgs_surfel_trace_state_floats(n_rays, ray_width))
+        # the replay record (4 KB per wavefront and pass: ~250 MB for an 800x800 view) only when a backward can follow
+        record = any(ctx.needs_input_grad)
+        state_floats = (L.mrgs_surfel_trace_state_floats if record else L.mrgs_surfel_trace_state_floats_norecord)(n_rays, ray_width)
+        wet, state = new(P), new(max(int(state_floats), 1))
         bg = (ctypes.c_float * 3)(*bg3)
         with torch.cuda.device(dev):
             _lib.check(L.mrgs_surfel_trace_forward(_ptr(blob), P, n_rays, ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
-                                                   _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(dist), _ptr(aux), _ptr(wet), _ptr(state), _stream(dev)))
+                                                   _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(dist), _ptr(aux), _ptr(wet), _ptr(state), state.numel(),
+                                                   _stream(dev)))
         ctx.save_for_backward(ray_o, ray_d, geom, attr, blob, rgb, dpt, acc, norm, aux, state)
         ctx.bg3, ctx.ray_width = bg3, ray_width
         ctx.mark_non_differentiable(wet, state)
@@ -90,7 +94,7 @@ class _Trace(torch.autograd.Function):
         bg = (ctypes.c_float * 3)(*ctx.bg3)
         with torch.cuda.device(dev):
             _lib.check(L.mrgs_surfel_trace_backward(_ptr(blob), P, n_rays, ctx.ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
-                                                    _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(aux), _ptr(state), _ptr(g_rgb), _ptr(g_dpt),
+                                                    _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(aux), _ptr(state), state.numel(), _ptr(g_rgb), _ptr(g_dpt),
                                                     _ptr(g_acc), _ptr(g_norm), _ptr(g_dist), _ptr(g_aux), _ptr(g_geom), _ptr(g_attr),
                                                     _ptr(g_o), _ptr(g_d), _stream(dev)))
         return g_o, g_d, g_geom, g_attr, None, None, None
@@ -159,8 +163,10 @@ class SurfelTracer(nn.Module):
     def __init__(self):
         super().__init__()
         self._blob = None
+        self._blob_saved = False         # a trace that a backward may follow holds self._blob: the next build / trace must not write into it
         self._ws = None
         self._n = 0
+        self._bg_host = {}               # settings.bg -> its three floats on the host (read back once per tensor, not once per trace)
         self.want_mid = True             # the per-depth record `mid` (41 MB for an 800x800 view): HardwareRendering reads it only for max_trace_depth > 0
         self.build_on_trace = False      # HardwareRendering sets it: build from the corners the record kernel writes (= get_disks')
 
@@ -177,17 +183,36 @@ class SurfelTracer(nn.Module):
         dev = vertices.device
         v = vertices.detach().contiguous().float()
         with torch.cuda.device(dev):
-            if self._blob is None or self._n != P or self._blob.device != dev:
+            # A blob that an earlier trace saved for its backward is left to that backward (its lists and its replay record were made for
+            # that hierarchy and for the records that trace wrote into it): this build gets a fresh one.
+            if self._blob is None or self._n != P or self._blob.device != dev or self._blob_saved:
                 self._blob = torch.empty(L.mrgs_surfel_bvh_bytes(P), dtype=torch.uint8, device=dev)
+                self._blob_saved = False
+            if self._ws is None or self._n != P or self._ws.device != dev:
                 self._ws = torch.empty(L.mrgs_surfel_bvh_ws_bytes(P), dtype=torch.uint8, device=dev)
-                self._n = P
+            self._n = P
+            if P == 0:
+                return self
             _lib.check(L.mrgs_surfel_bvh_build(_ptr(v), P, _ptr(self._blob), self._blob.numel(), _ptr(self._ws), self._ws.numel(), _stream(dev)))
         return self
+
+    def _background(self, bg):
+        """The three background floats on the host (the C ABI takes them by value).  Read back once per tensor (address + version): a
+        `.tolist()` per trace is a device-to-host synchronisation in the middle of the stream-ordered pipeline."""
+        if not bg.is_cuda:
+            return tuple(float(x) for x in bg.detach().reshape(-1)[:3].tolist())
+        key = _bg_key(bg)
+        ent = self._bg_host.get(key)
+        if ent is None or ent[1] is not bg:
+            if len(self._bg_host) > 64:
+                self._bg_host.clear()
+            ent = self._bg_host[key] = (tuple(float(x) for x in bg.detach().reshape(-1)[:3].tolist()), bg)   # holds bg: the address stays its own
+        return ent[0]
 
     def forward(self, ray_o, ray_d, v=None, means3D=None, grads3D=None, shs=None, colors_precomp=None, others_precomp=None, opacities=None,
                 scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
         ts = tracer_settings
-        if self._blob is None and not self.build_on_trace:
+        if self._blob is None and not self.build_on_trace and means3D is not None and means3D.shape[0] > 0:
             raise RuntimeError("build_acceleration_structure has not been called")
         if cov3D_precomp is not None or scales is None or rotations is None:
             raise NotImplementedError("the tracer intersects surfels from scales / rotations; cov3D_precomp is not supported")
@@ -202,8 +227,12 @@ class SurfelTracer(nn.Module):
         # computeColorFromSH of the rasterizer family (forward.cu:20-81, direction from the settings' camera position), the splat frame
         # and get_disks' corners: one launch (mrgs_surfel_trace_prep_forward)
         shs_pm3 = None if shs is None else (shs if shs.shape[-1] == 3 else shs.transpose(1, 2))
-        geom, attr, _quads = _Prep.apply(means, scales, rotations, opacities.reshape(P, 1), shs_pm3, colors_precomp, others_precomp,
-                                         ts.campos.reshape(3), ts.sh_degree, float(ts.scale_modifier))
+        if P == 0:       # an empty model (e.g. everything pruned): background everywhere, nothing to build or to differentiate
+            geom, attr = means3D.new_zeros((0, 16), dtype=torch.float32), means3D.new_zeros((0, 8), dtype=torch.float32)
+            self._n, self.build_on_trace = 0, False
+        else:
+            geom, attr, _quads = _Prep.apply(means, scales, rotations, opacities.reshape(P, 1), shs_pm3, colors_precomp, others_precomp,
+                                             ts.campos.reshape(3), ts.sh_degree, float(ts.scale_modifier))
         if self.build_on_trace:
             self.build_acceleration_structure(_quads, None)
             self.build_on_trace = False
@@ -211,8 +240,15 @@ class SurfelTracer(nn.Module):
             raise RuntimeError("the acceleration structure was built for a different number of surfels")
         o = ray_o.reshape(-1, 3).contiguous().float()
         d = ray_d.reshape(-1, 3).contiguous().float()
-        bg3 = tuple(float(x) for x in ts.bg.detach().reshape(-1)[:3].tolist())
+        bg3 = self._background(ts.bg)
+        will_save = torch.is_grad_enabled() and any(t.requires_grad for t in (o, d, geom, attr))
+        if self._blob_saved and P > 0:
+            # a second trace on one build (eval mode keeps the hierarchy): the trace writes the surfel records into the blob, which an
+            # earlier trace's backward still reads -- work on a copy of the hierarchy
+            self._blob = self._blob.clone()
+            self._blob_saved = False
         rgb, dpt, acc, norm, dist, aux, wet, state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
+        self._blob_saved = will_save
         self.last_state = state[:4 * o.shape[0]].reshape(-1, 4)      # diagnostics: sum w t^2, final T, hits blended, passes (negative: in a packet)
         self.last_lone = state[4 * o.shape[0]:4 * o.shape[0] + 1].view(torch.int32)
         r = lambda x, c: x.reshape(*shape, c)
@@ -221,6 +257,10 @@ class SurfelTracer(nn.Module):
         mid = torch.cat([ray_o.reshape(*shape, 3).float(), ray_d.reshape(*shape, 3).float(), dpt, acc, norm, aux, rgb], dim=-1).detach() \
             if self.want_mid else rgb.new_empty((*shape, 0))
         return rgb, dpt, acc, norm, dist, aux, mid, wet.reshape(P, 1)
+
+
+def _bg_key(bg):
+    return (bg.data_ptr(), bg._version, bg.device)
 
 
 def _depth_to_normal(view, depth):

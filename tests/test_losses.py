@@ -111,6 +111,54 @@ def test_hip_calculate_loss_matches_reference(tag, mode):
 
 
 @pytest.mark.gpu
+def test_perceptual_term_is_gated_by_iteration_and_pluggable():
+    """utils/loss_utils.py:212-215 with the reference's default options (use_perceptual_loss = True, start 18 000): before the start
+    iteration the loss is what it is without the term (a warning, once); after it the registered network's distance is added with
+    lambda_perceptual_loss and reported as tb_dict["perceptual_loss"]; with nothing registered (and no `lpips` package) it raises THEN."""
+    from materialrefgs_amd import losses
+    d = _dev(_inputs(CASES[0]))
+
+    class O:
+        pass
+    cam, pc, opt = O(), O(), O()
+    cam.original_image = d["gt"]
+    pc.get_xyz = torch.zeros(5, 3)
+    opt.lambda_dssim, opt.lambda_normal_render_depth, opt.normal_loss_start = 0.2, 0.0, 0
+    opt.lambda_dist, opt.dist_loss_start = 0.0, 3000
+    opt.lambda_normal_smooth = opt.lambda_depth_smooth = 0.0
+    opt.normal_smooth_from_iter, opt.normal_smooth_until_iter = 0, 18000
+    opt.use_perceptual_loss, opt.lambda_perceptual_loss, opt.perceptual_loss_start_iter = True, 0.1, 18000      # arguments/__init__.py:223-225
+    pkg = {"render": d["img"], "rend_normal": d["rn"], "surf_normal": d["sn"], "rend_dist": d["dist"]}
+    losses._LPIPS_WARNED = False
+    with pytest.warns(UserWarning, match="perceptual"):
+        early, tb = losses.calculate_loss(cam, pc, pkg, opt, 17999, None, None)
+    assert "perceptual_loss" not in tb
+    opt.use_perceptual_loss = False
+    plain, _ = losses.calculate_loss(cam, pc, pkg, opt, 17999, None, None)
+    assert float(early) == float(plain)
+    opt.use_perceptual_loss = True
+    have_lpips = True
+    try:
+        import lpips  # noqa: F401
+    except ImportError:
+        have_lpips = False
+    if not have_lpips:
+        with pytest.raises(NotImplementedError, match="set_lpips_fn"):
+            losses.calculate_loss(cam, pc, pkg, opt, 18001, None, None)
+    losses.set_lpips_fn(lambda x, y: (x - y).pow(2).mean((1, 2, 3)))
+    try:
+        img = d["img"].clone().requires_grad_(True)
+        late, tb = losses.calculate_loss(cam, pc, {**pkg, "render": img}, opt, 18001, None, None)
+        want = 4.0 * float((d["img"] - d["gt"]).pow(2).mean())
+        assert abs(float(tb["perceptual_loss"]) - want) < 1e-6 * max(1.0, want)
+        assert abs(float(late) - (float(plain) + 0.1 * want)) < 1e-6
+        late.backward()
+        assert torch.isfinite(img.grad).all() and float(img.grad.abs().max()) > 0
+    finally:
+        losses.set_lpips_fn(None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", CASES)
 def test_hip_l1_and_ssim_match_reference(tag):
     from materialrefgs_amd import losses
@@ -173,9 +221,10 @@ def test_image_weight_matches_reference_get_img_grad_weight(tag):
     np.testing.assert_allclose(w.numpy(), GOLD[f"{tag}_weight"], rtol=0, atol=1e-6)
 
 
-def test_edge_aware_terms_and_early_failure_of_the_perceptual_loss():
+def test_edge_aware_terms_and_the_set_up_check_of_the_perceptual_loss():
     """first_order_edge_aware_loss / smooth_loss (utils/loss_utils.py:121-125) on kornia's documented Sobel: zero for constants, the
-    known value of a ramp, damped by image edges; use_perceptual_loss fails at the first call, not at iteration 18 001."""
+    known value of a ramp, damped by image edges; check_loss_config (the optional set-up check) refuses use_perceptual_loss while no
+    LPIPS network is registered."""
     from types import SimpleNamespace
     from materialrefgs_amd import losses
     H, W = 12, 16
@@ -189,4 +238,11 @@ def test_edge_aware_terms_and_early_failure_of_the_perceptual_loss():
     edgy = torch.zeros(3, H, W, dtype=torch.float64); edgy[:, :, W // 2:] = 8.0
     assert float(losses.first_order_edge_aware_loss(ramp, edgy)) < float(losses.first_order_edge_aware_loss(ramp, const_img))
     with pytest.raises(NotImplementedError, match="no-use_perceptual_loss"):
-        losses.calculate_loss(None, None, {}, SimpleNamespace(use_perceptual_loss=True, perceptual_loss_start_iter=18000), 1)
+        losses.check_loss_config(SimpleNamespace(use_perceptual_loss=True, perceptual_loss_start_iter=18000))
+    losses.set_lpips_fn(lambda x, y: (x - y).abs().mean((1, 2, 3)))
+    try:
+        losses.check_loss_config(SimpleNamespace(use_perceptual_loss=True, perceptual_loss_start_iter=18000))      # a network is registered
+        x, y = torch.rand(1, 3, 8, 8, dtype=torch.float64), torch.rand(1, 3, 8, 8, dtype=torch.float64)
+        assert abs(float(losses.lpips_loss(x, y)) - 2.0 * float((x - y).abs().mean())) < 1e-12                    # images go in scaled to [-1, 1] (:43)
+    finally:
+        losses.set_lpips_fn(None)

@@ -466,6 +466,97 @@ def test_degenerate_ray_sets(gpu_device):
     assert torch.isfinite(L["means"].grad).all() and torch.isfinite(L["d"].grad[3]).all()
 
 
+@pytest.mark.gpu
+def test_empty_model_and_forward_only_state(gpu_device):
+    """(1) An empty surfel set (everything pruned) traces to the background instead of raising.  (2) Under torch.no_grad() the forward
+    allocates the state without the replay record (mrgs_surfel_trace_state_floats_norecord) and returns the same outputs.  (3) A state
+    without the record handed to the C backward makes it walk again: same gradients as with the record."""
+    from types import SimpleNamespace
+    from materialrefgs_amd import _lib
+    L = _lib.lib()
+    bg = torch.tensor([0.3, 0.6, 0.9])
+    empty = SimpleNamespace(means3D=torch.zeros(0, 3), scales=torch.zeros(0, 2), rotations=torch.zeros(0, 4), opacities=torch.zeros(0, 1))
+    o, d = _rays(130, 1)
+    hip, _ = _hip_trace(gpu_device, empty, torch.zeros(0, 3), torch.zeros(0, 2), o, d, bg)
+    assert torch.allclose(hip["rgb"].cpu(), bg.expand(130, 3)) and float(hip["acc"].abs().max()) == 0.0 and hip["wet"].shape == (0,)
+    assert float(hip["dpt"].abs().max()) == 0.0 and float(hip["norm"].abs().max()) == 0.0 and float(hip["dist"].abs().max()) == 0.0
+
+    sc, colors, others = _scene(900, 4, 40.0)
+    o, d = _rays(2048, 4)
+    full = L.mrgs_surfel_trace_state_floats(2048, 0)
+    small = L.mrgs_surfel_trace_state_floats_norecord(2048, 0)
+    assert 0 < small < full // 8
+    with_grad, Lg = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
+    with torch.no_grad():
+        no_grad, _ = _hip_trace(gpu_device, sc, colors, others, o, d, bg)
+    for k in ("rgb", "dpt", "acc", "norm", "dist", "aux", "wet"):
+        assert torch.equal(with_grad[k].detach(), no_grad[k]), k
+    # the autograd node of the no-grad trace kept nothing; the one with gradients kept the full state
+    state = with_grad["rgb"].grad_fn.saved_tensors[-1]
+    assert state.numel() == full
+    # C level: backward on a record-less state == backward on the recorded one
+    w = torch.randn(2048, 3, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    (with_grad["rgb"] * w).sum().backward()
+    replayed = {k: Lg[k].grad.clone() for k in ("means", "scales", "rotations", "opacities", "colors", "o", "d")}
+    import os
+    os.environ["MRGS_TRACE_NO_RECORD"] = "0"      # (the developer switch is read once per process; this test does not rely on it)
+    from materialrefgs_amd import surfel_tracing as st
+    keep = L.mrgs_surfel_trace_state_floats
+    try:
+        st._lib.lib().mrgs_surfel_trace_state_floats = L.mrgs_surfel_trace_state_floats_norecord     # force the small state with gradients on
+        walked, Lw = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
+    finally:
+        st._lib.lib().mrgs_surfel_trace_state_floats = keep
+    assert walked["rgb"].grad_fn.saved_tensors[-1].numel() == small
+    (walked["rgb"] * w).sum().backward()
+    for k, ref in replayed.items():
+        a = Lw[k].grad
+        assert float((a - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-12), k
+
+
+@pytest.mark.gpu
+def test_two_traces_on_one_hierarchy_keep_their_own_backward(gpu_device):
+    """a trace saves the hierarchy blob for its backward, and the trace call writes the surfel records into it.  A second
+    surfel set of the same size traced (or built) through the same SurfelTracer before the first backward ran must not change the first
+    one's gradients."""
+    from materialrefgs_amd.surfel_tracing import SurfelTracer, SurfelTracingSettings
+    dev = gpu_device
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    o, d = _rays(1024, 2)
+    eye = torch.eye(4, device=dev)
+    ts = SurfelTracingSettings(1, 1024, 1.0, 1.0, bg.to(dev), 1.0, eye, eye, 0, torch.zeros(3, device=dev), False, False)
+
+    def run(tr, sc, colors, others, build):
+        leaf = lambda t: t.to(dev).clone().requires_grad_(True)
+        Lf = dict(means=leaf(sc.means3D), scales=leaf(sc.scales), rotations=leaf(sc.rotations), opacities=leaf(sc.opacities), colors=leaf(colors))
+        if build:
+            tr.build_acceleration_structure(sto.quad_vertices(Lf["means"].detach(), Lf["scales"].detach(), Lf["rotations"].detach()).reshape(-1, 3), None)
+        out = tr(o.to(dev), d.to(dev), None, means3D=Lf["means"], grads3D=None, shs=None, colors_precomp=Lf["colors"], others_precomp=others.to(dev),
+                 opacities=Lf["opacities"], scales=Lf["scales"], rotations=Lf["rotations"], cov3D_precomp=None, tracer_settings=ts)
+        return out[0], Lf
+
+    from types import SimpleNamespace
+    A = _scene(700, 11, 45.0)
+    B = _scene(700, 12, 45.0)
+    # the same boxes with other contents (a hierarchy stays valid for it): what an eval-mode tracer (has_bvh) would be handed
+    B_same = (SimpleNamespace(means3D=A[0].means3D, scales=A[0].scales, rotations=A[0].rotations, opacities=A[0].opacities * 0.5), B[1], B[2])
+    w = torch.randn(1024, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    # reference: A alone
+    rgbA, LA = run(SurfelTracer(), *A, build=True)
+    (rgbA * w).sum().backward()
+    want = {k: v.grad.clone() for k, v in LA.items()}
+    for rebuild in (True, False):
+        tr = SurfelTracer()
+        rgb1, L1 = run(tr, *A, build=True)
+        blob1 = tr._blob
+        rgb2, L2 = run(tr, *(B if rebuild else B_same), build=rebuild)   # same P: second build, or second trace on the first hierarchy
+        assert tr._blob.data_ptr() != blob1.data_ptr()
+        (rgb2 * w).sum().backward()
+        (rgb1 * w).sum().backward()
+        for k in want:
+            assert torch.equal(L1[k].grad, want[k]) or float((L1[k].grad - want[k]).abs().max()) <= 1e-6 * float(want[k].abs().max()), (rebuild, k)
+
+
 def test_size_functions_of_the_c_abi_without_a_gpu():
     """mrgs_surfel_bvh_bytes / _ws_bytes / _trace_state_floats are pure host arithmetic: monotone, and large enough for what the header
     says they hold (64-wide nodes over ceil(P / 64) groups; per ray 4 state floats + a list slot; per block of 64 rays two 4 KB chunks)."""
