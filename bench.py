@@ -62,6 +62,11 @@ def algorithmic_bytes(kernel, P, R, HW, S):
         # list ids + cull bits (5 B), staged records (80 B + features), per-pixel outputs (color 3, feature S, others 7,
         # final_T 3, n_contrib 2)
         return (5 + 80 + 4 * S) * R + (60 + 4 * S) * HW
+    if kernel == "surfel_trace_fwd":
+        # P = surfels, R = blended hits of all rays, HW = rays.  Per ray: origin + direction in (24 B), rgb / dpt / acc / norm / dist / aux out
+        # (44 B), its four state words (16 B); per blended hit: the surfel's geometry and attribute records gathered (64 + 32 B) and its id in
+        # the replay record (4 B); per surfel: its records laid out in leaf order once (96 B read + 96 B written)
+        return 84 * HW + 100 * R + 192 * P
     raise KeyError(kernel)
 
 
@@ -130,7 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also skips grad_max_rel_err)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the C2heavy secondary line of the default C2 run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines of the default C2 run (C2heavy, C3full, C3trace)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no render: launch the ranks, check the world size and push one gradient bucket through the collective "
                          "(works without a GPU over gloo; the line it prints is NOT a benchmark result)")
@@ -246,15 +251,31 @@ def main():
         for t_, g_ in zip(surfel_params, summed):
             t_.grad = g_
 
+    parts = {}              # diagnostic steps only: torch event pairs around the parts of a surfel view (name -> [(start, end), ...])
+
+    def mark(name):
+        if not state.get("parts_on"):
+            return lambda: None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        def done():
+            e1.record()
+            parts.setdefault(name, []).append((e0, e1))
+        return done
+
     def step_surfel(i):
         view = (i * world + rank) % len(settings)
         for t_ in surfel_params:
             t_.grad = None
+        done = mark("env_prefilter_fwd")
         env.build_mips()                                       # every iteration in the reference (train_refnerf.py:1157-1163)
+        done()
+        done = mark("forward_total")
         if traced:
             out = render_surfel_with_envgs(hw_tracer, cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
         else:
             out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect))
+        done()
         state["R"] = rasterizer_mod.LAST_NUM_RENDERED
         if use_loss:
             loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)
@@ -267,7 +288,9 @@ def main():
         outs = [out["render"], out["rend_alpha"], out["rend_normal"], out["rend_dist"], out["surf_depth"], out["surf_normal"]]
         if "g" not in state:   # constant upstream gradients, built once (a loss would produce them in training)
             state["g"] = [torch.ones_like(outs[0])] + [torch.full_like(o, 0.1) for o in outs[1:]]
+        done = mark("backward_total")
         torch.autograd.backward(outs, state["g"])
+        done()
         if world > 1:
             reduce_surfel(view)
 
@@ -323,6 +346,60 @@ def main():
     L.mrgs_get_kernel_times(stage_times)
     L.mrgs_set_profiling(0)
 
+    # surfel workloads: torch events around the parts of a view and, with the tracer, around its two native calls (they run on torch's
+    # current stream); a few extra untimed steps
+    trace_ms = {}
+    if surfel_mode:
+        tr_ev = {"surfel_trace_fwd": [], "surfel_trace_bwd": []}
+        if traced:
+            from materialrefgs_amd import surfel_tracing as st_mod
+            orig_f, orig_b = st_mod._Trace.forward, st_mod._Trace.backward
+
+            def timed(name, fn):
+                def wrapper(ctx, *a):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    r = fn(ctx, *a)
+                    e1.record()
+                    tr_ev[name].append((e0, e1))
+                    return r
+                return staticmethod(wrapper)
+            st_mod._Trace.forward, st_mod._Trace.backward = timed("surfel_trace_fwd", orig_f), timed("surfel_trace_bwd", orig_b)
+        state["parts_on"] = True
+        for i in range(min(args.steps, 8)):
+            step(args.warmup + args.steps + 16 + i)
+        fence()
+        state["parts_on"] = False
+        if traced:
+            st_mod._Trace.forward, st_mod._Trace.backward = staticmethod(orig_f), staticmethod(orig_b)
+            ls = hw_tracer.tracer.last_state                       # per ray: sum w t^2, final T, hits blended, passes
+            state["trace_hits"] = int(ls[:, 2].sum().item())
+        for name, evs in list(parts.items()) + list(tr_ev.items()):
+            if evs:
+                trace_ms[name] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+
+    # First visits: a camera rendered for the first time has no work hint (the forward's queues come from the cull counts) and its
+    # backward orders by itself -- every camera once per training run, and again after each densification.  Timed per step between
+    # fences (so is the warm figure next to it: a fence per step takes the host's launch latency out of hiding, which `ms_per_step` of
+    # the back-to-back timed region does not pay).
+    def fenced_ms(first_index, n):
+        total = 0.0
+        for i in range(n):
+            fence()
+            t_ = time.perf_counter()
+            step(first_index + i)
+            fence()
+            total += time.perf_counter() - t_
+        return 1000.0 * total / n
+    n_cam = len(settings)
+    base_i = ((args.warmup + args.steps + 64) // n_cam + 1) * n_cam
+    warm_fenced = fenced_ms(base_i, n_cam)
+    rasterizer_mod.reset_work_hints()
+    cold_fenced = fenced_ms(base_i, n_cam)
+    for i in range(n_cam):                                      # leave the hints warm again
+        step(base_i + i)
+    fence()
+
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -333,7 +410,8 @@ def main():
     out = {
         "metric": "full-render fwd+bwd views/sec at 800x800/300k surfels; grad max-rel-err vs ref",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4),
+        "cold_ms_per_step": round(cold_fenced, 4), "warm_ms_per_step_fenced": round(warm_fenced, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "P": P, "H": H, "W": W, "S": S, "sh_degree": 3, "num_rendered": int(state["R"]),
                    "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
@@ -343,11 +421,16 @@ def main():
         stage_ms = {"preprocess_fwd": stage_times.preprocess_ms, "depth_sort_scan": stage_times.sort_ms,
                     "duplicate_tilesort_ranges": stage_times.duplicate_ms, "render_fwd": stage_times.render_fwd_ms,
                     "render_bwd": times.render_bwd_ms, "preprocess_bwd": stage_times.preprocess_bwd_ms}
-        # the backward blend is the dominant kernel of every workload (stage_ms of the diagnostic steps confirms it); its duration
-        # comes from the events of the timed region
+        stage_ms.update(trace_ms)
+        # the backward blend is the dominant kernel of the raster / shaded workloads (stage_ms confirms it); its duration comes from
+        # the events of the timed region.  With the tracer the two launches of its forward walk are longer (one "launch" = the mirror
+        # rays of one view); units there: rays, blended hits, surfels.
         dom = "render_bwd"
         dom_ms = stage_ms[dom]
         nbytes = algorithmic_bytes(dom, P, R, HW, S)
+        if traced and trace_ms.get("surfel_trace_fwd", 0.0) > dom_ms:
+            dom, dom_ms = "surfel_trace_fwd", trace_ms["surfel_trace_fwd"]
+            nbytes = algorithmic_bytes(dom, P, state["trace_hits"], HW, S)
         achieved = nbytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic (FETCH_SIZE / WRITE_SIZE passes) and the VALU issue rate (SQ pass) of the dominant kernel come from separate
         # rocprofv3 --pmc runs of this same command (tools/pmc_traffic.py, tools/pmc_sq.py), which stamp their JSON with the digest of
@@ -446,18 +529,27 @@ def main():
             except Exception as ex:      # incl. subprocess.TimeoutExpired
                 out["cpu_baseline_torch"] = {"error": type(ex).__name__}
         if world == 1 and args.workload == "C2" and not args.no_secondary:
-            # secondary line: the heavier scene (R ~ 6 P, heavy-tailed splat sizes), a fresh child process after everything here is done
+            # secondary lines, each a fresh child process after everything here is done: the heavier raster scene (R ~ 6 P, heavy-tailed
+            # splat sizes), the FULL render of BASELINE.md's path (render_surfel: rasterizer + deferred split-sum shading + all glue +
+            # the environment prefilter, C3full) and the last training stage (render_surfel + surfel-traced mirror rays, C3trace)
             import subprocess
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "C2heavy", "--steps", str(min(args.steps, 500)),
-                                "--warmup", str(min(args.warmup, 30)), "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True)
-            sec = None
-            for line in r.stdout.splitlines():
-                if line.startswith("{"):
-                    j = json.loads(line)
-                    sec = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                           "steps": j["steps"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
-                           "roofline_frac": j["roofline"]["frac"]}
-            out["secondary"] = sec if sec is not None else {"error": (r.stderr or r.stdout)[-300:]}
+
+            def child(workload, steps, warmup):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
+                                    "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True)
+                for line in r.stdout.splitlines():
+                    if line.startswith("{"):
+                        j = json.loads(line)
+                        return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                                "cold_ms_per_step": j.get("cold_ms_per_step"), "warm_ms_per_step_fenced": j.get("warm_ms_per_step_fenced"),
+                                "steps": j["steps"], "warmup": j["warmup"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
+                                "roofline": {k: j["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                                 "algorithmic_bytes_per_launch", "avg_launch_ms")},
+                                "roofline_frac": j["roofline"]["frac"]}
+                return {"error": (r.stderr or r.stdout)[-300:]}
+            out["secondary"] = child("C2heavy", min(args.steps, 500), min(args.warmup, 30))
+            out["secondary_full"] = child("C3full", 200, 24)
+            out["secondary_traced"] = child("C3trace", 100, 16)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -342,16 +342,19 @@ class HardwareRendering(nn.Module):
             start_from_first=start_from_first)
         with torch.no_grad():
             visibility_filter = wet[..., 0] > 0.0
-            if start_from_first:                                                             # + what projects into the image (:203-211)
-                # the reference writes K (R m + T) with Camera.R / Camera.T; the same projection through the camera's own
-                # world-to-view matrix (row-vector convention of scene/cameras.py), which does not depend on how R is stored
+            if start_from_first:                                                             # + what "projects into the image" (:203-211)
+                # The reference's expression, kept literally because `visibility_filter` is defined by it: Camera.R is the rotation as
+                # STORED (transposed, scene/cameras.py:30) and T [3] broadcasts against R m [P,3,1] along the LAST axis, so column 0 of
+                # the sum -- the one `[..., 0]` keeps -- is R m + T[0] (1, 1, 1).  Not the camera projection; a fixture produced by the
+                # reference's own code pins it (tests/test_reference_render.py).
                 _, _, K = camera.HWK
                 K = torch.as_tensor(K, dtype=torch.float32, device=means3D.device)
-                Wv = camera.world_view_transform.to(means3D.device).float()
-                cam = means3D.detach() @ Wv[:3, :3] + Wv[3, :3]
-                uvd = cam @ K.T
-                uv = uvd[..., :2] / uvd[..., 2:]
-                vis = (uvd[..., 2] >= 0.2) & (uv[..., 0] >= 0.0) & (uv[..., 0] <= camera.image_width) & (uv[..., 1] >= 0.0) & (uv[..., 1] <= camera.image_height)
+                R = torch.as_tensor(camera.R, dtype=torch.float32, device=means3D.device)
+                T = torch.as_tensor(camera.T, dtype=torch.float32, device=means3D.device)
+                uvd = (K @ (R @ means3D.detach()[..., None] + T))[..., 0]
+                uvd[..., :2] = uvd[..., :2] / uvd[..., 2:]
+                vis = (uvd[..., 2] >= 0.2) & (uvd[..., 0] >= 0.0) & (uvd[..., 0] <= camera.image_width) & (uvd[..., 1] >= 0.0) & \
+                      (uvd[..., 1] <= camera.image_height)
                 visibility_filter = visibility_filter | vis
         chw = lambda x: x.permute(2, 0, 1)
         out = {"viewspace_points": grads3D, "visibility_filter": visibility_filter.detach().clone(), "weight_accumulate": wet,

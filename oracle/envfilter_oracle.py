@@ -102,7 +102,10 @@ def specular_matrix(N, roughness, cutoff=0.99):
     return _SPEC_CACHE[key]
 
 
-def _specular_matrix(N, roughness, cutoff):
+def specular_weights(N, roughness, cosc):
+    """Un-normalised dense weights [6N^2 (output texel), 6N^2 (source texel)] of SpecularCubemapFwdKernel (cubemap.cu:238-290) for a
+    given cut-off cosine (ops.py hands the kernel the float32 value of __ndfBounds): out[..., :3] = W @ cube, out[..., 3] = W.sum(1)."""
+    cosc = np.float32(cosc)
     D = cube_to_dir(N)
     dots = D @ D.T                                        # [out t, src s] = dot(L_s, VNR_t)
     a2 = (roughness * roughness) ** 2
@@ -113,8 +116,11 @@ def _specular_matrix(N, roughness, cutoff):
     dd = (c * a2 - c) * c + 1.0
     ndf = a2 / (dd * dd * np.pi)
     W = np.maximum(dots, 0.0) * ndf * pixel_area(N)[None, :] / 4.0
-    cosc = np.float32(cos_cutoff(roughness, cutoff))
-    W = np.where((dots >= cosc) & bounds_mask(N, cosc), W, 0.0)
+    return np.where((dots >= cosc) & bounds_mask(N, cosc), W, 0.0)
+
+
+def _specular_matrix(N, roughness, cutoff):
+    W = specular_weights(N, roughness, cos_cutoff(roughness, cutoff))
     with np.errstate(invalid="ignore", divide="ignore"):
         return W / W.sum(1, keepdims=True)
 

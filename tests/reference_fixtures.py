@@ -1,0 +1,125 @@
+"""Loader of tests/golden/reference_render.npz -- the outputs of the REFERENCE'S OWN Python render functions (generator:
+tests/golden/gen_reference_render_vectors.py, which imports /root/reference in the build container; only its inputs and outputs are
+committed) -- and the small adapters the tests need: a camera object carrying the stored matrices, the surfel models rebuilt from the
+stored raw parameters, and the fixed upstream weights (drawn again from the generator's seeded CPU stream instead of being stored)."""
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "golden", "reference_render.npz")
+_DATA = None
+
+PARAM_NAMES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest", "_refl_strength", "_roughness", "_ori_color",
+               "_metalness", "_indirect_dc", "_indirect_rest")
+
+
+def data():
+    global _DATA
+    if _DATA is None:
+        _DATA = np.load(PATH)
+    return _DATA
+
+
+class FixtureCamera:
+    """What the render functions read of scene/cameras.py:Camera, with the matrices the reference's own Camera produced."""
+
+    def __init__(self, tag, device="cpu", dtype=torch.float32, _fields=None):
+        if _fields is not None:
+            self.__dict__.update(_fields)
+            return
+        d = data()
+        t = lambda k: torch.from_numpy(d[f"{tag}_{k}"].copy())
+        self.image_height, self.image_width = (int(x) for x in d[f"{tag}_HW"])
+        self.FoVx, self.FoVy = (float(x) for x in d[f"{tag}_FoV"])
+        self.znear, self.zfar = (float(x) for x in d[f"{tag}_znear_zfar"])
+        self.K = d[f"{tag}_K"].copy()                                  # float64, as a dataset reader builds it
+        self.world_view_transform = t("world_view_transform").to(device=device, dtype=dtype)
+        self.full_proj_transform = t("full_proj_transform").to(device=device, dtype=dtype)
+        self.camera_center = t("camera_center").to(device=device, dtype=dtype)
+        self.R, self.T = t("R").to(device), t("T").to(device)          # float32 tensors as Camera stores them (cameras.py:85-86)
+
+    @property
+    def HWK(self):
+        return (self.image_height, self.image_width, self.K)
+
+    def _replace(self, **kw):
+        return FixtureCamera(None, _fields={**self.__dict__, **kw})
+
+    def to(self, device):
+        return self._replace(world_view_transform=self.world_view_transform.to(device), full_proj_transform=self.full_proj_transform.to(device),
+                             camera_center=self.camera_center.to(device), R=self.R.to(device), T=self.T.to(device))
+
+    def get_image(self):
+        z = torch.zeros(3, self.image_height, self.image_width)
+        return z, z[:1]
+
+
+def surfel_model(tag, device="cpu", dtype=torch.float32, with_env=True, env_cls=None):
+    """A materialrefgs_amd.renderer.SurfelModel with the stored raw parameters as leaves (+ both environment maps when `env_cls`, the
+    product's EnvLight, is given; otherwise the two base cubemaps are returned as leaves for the CPU oracles)."""
+    from materialrefgs_amd.renderer import SurfelModel
+    d = data()
+    leaf = lambda k: torch.from_numpy(d[f"{tag}{k}"].copy()).to(device=device, dtype=dtype).requires_grad_(True)
+    pc = SurfelModel(leaf("_xyz"), leaf("_scaling"), leaf("_rotation"), leaf("_opacity"), leaf("_features_dc"), leaf("_features_rest"),
+                     refl_strength=leaf("_refl_strength"), roughness=leaf("_roughness"), ori_color=leaf("_ori_color"),
+                     indirect_dc=leaf("_indirect_dc"), indirect_rest=leaf("_indirect_rest"))
+    pc._metalness = leaf("_metalness")
+    bases = [torch.from_numpy(d[f"{tag}_env_base"].copy()), torch.from_numpy(d[f"{tag}_env2_base"].copy())]
+    if env_cls is None:
+        return pc, [b.to(dtype).requires_grad_(True) for b in bases]
+    res, mn = (int(x) for x in d["meta_env_res_min"])
+    envs = []
+    for b in bases:
+        env = env_cls(device=device, min_res=mn, max_res=res, trainable=True)
+        with torch.no_grad():
+            env.base.copy_(b)
+        envs.append(env)
+    pc.env_map, pc.env_map_2 = envs
+    return pc, envs
+
+
+def leaves(pc, envs):
+    """name -> leaf tensor, named as the fixture's gradient arrays are (`<tag>__grad__pc<name>`)."""
+    out = {k: getattr(pc, k) for k in PARAM_NAMES}
+    out["_env_base"] = envs[0] if torch.is_tensor(envs[0]) else envs[0].base
+    out["_env2_base"] = envs[1] if torch.is_tensor(envs[1]) else envs[1].base
+    return out
+
+
+def weights(tag, out):
+    """The fixed upstream weights of scenario `tag`, in the generator's order, from its seeded CPU stream (float32 draws)."""
+    d = data()
+    g = torch.Generator().manual_seed(int(d[f"{tag}__w_seed"]))
+    ws = {}
+    for k in d[f"{tag}__w_keys"]:
+        k = str(k)
+        shape = d[f"{tag}__out__{k}"].shape
+        ws[k] = torch.rand(shape, generator=g) * (0.01 if k == "surf_depth" else 1.0)
+    return ws
+
+
+def scalar(tag, out):
+    """sum_k <w_k, out_k> on out's device / dtype."""
+    total = 0
+    for k, w in weights(tag, out).items():
+        total = total + (out[k] * w.to(device=out[k].device, dtype=out[k].dtype)).sum()
+    return total
+
+
+def expected(tag, key):
+    return data()[f"{tag}__out__{key}"]
+
+
+def expected_grad(tag, name):
+    d = data()
+    k = f"{tag}__grad__{name}"
+    return d[k] if k in d.files else None
+
+
+def rel(a, b):
+    """max |a - b| / max |b| (tensor-level relative error)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    s = np.abs(b).max()
+    return float(np.abs(a - b).max() / s) if s > 0 else float(np.abs(a).max())

@@ -33,8 +33,11 @@ def test_tuple_layout_is_the_reference_order():
     assert t[13] is m._rotation and t[14] is m._opacity and t[15] is m._normal1 and t[16] is m._normal2 and t[17] is m.max_radii2D
     assert t[18] is m.xyz_gradient_accum and t[19] is m.denom and isinstance(t[20], dict) and t[21] == 1.7
     names = [g["name"] for g in m.optimizer.param_groups]
-    assert names == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "env", "env2", "refl_strength", "ori_color", "diffuse_color",
-                     "roughness", "metalness", "normal1", "normal2", "ind_dc", "ind_rest", "ind_asg"]       # training_setup :422-446
+    # both lists as the reference's own GaussianModel produced them (tests/golden/gen_reference_render_vectors.py: capture(), training_setup())
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_render.npz"))
+    assert names == [str(x) for x in gold["G_optimizer_groups"]]                                          # training_setup :422-446
+    assert list(ck.CAPTURE_FIELDS) + ["optimizer.state_dict", "spatial_lr_scale"] == [str(x) for x in gold["G_capture_fields"]]
     lr = {g["name"]: g["lr"] for g in m.optimizer.param_groups}
     assert abs(lr["xyz"] - 0.00016 * 1.7) < 1e-12 and abs(lr["f_rest"] - 0.0075 / 20) < 1e-12 and lr["env"] == 0.01
     assert m.optimizer.defaults["eps"] == 1e-15 and not m._normal1.requires_grad

@@ -22,11 +22,11 @@ def _model(P=7, seed=0):
 def test_attribute_order_is_the_reference_order():
     m = _model()
     names = mio.attribute_names({k: tuple(v.shape) for k, v in m.items()})
-    want = (["x", "y", "z", "nx", "ny", "nz", "nx2", "ny2", "nz2"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)] +
-            [f"ind_dc_{i}" for i in range(3)] + [f"ind_rest_{i}" for i in range(45)] + [f"ind_asg_{i}" for i in range(160)] +
-            ["opacity", "refl_strength", "metalness", "roughness"] + [f"ori_color_{i}" for i in range(3)] +
-            [f"diffuse_color_{i}" for i in range(3)] + [f"scale_{i}" for i in range(2)] + [f"rot_{i}" for i in range(4)])
+    # the list GaussianModel.construct_list_of_attributes() returned when the reference's own class was run
+    # (tests/golden/gen_reference_render_vectors.py -> reference_render.npz: G_attributes)
+    want = [str(x) for x in np.load(os.path.join(ROOT, "tests", "golden", "reference_render.npz"))["G_attributes"]]
     assert names == want and len(names) == 281
+    assert want[:9] == ["x", "y", "z", "nx", "ny", "nz", "nx2", "ny2", "nz2"] and want[-1] == "rot_3" and want[9 + 3 + 45 + 3 + 45] == "ind_asg_0"
 
 
 def test_ply_round_trip_and_byte_layout(tmp_path):
