@@ -47,6 +47,7 @@ WORKLOADS = {
     # BASELINE.json configs[3] with the traced reflection term: C4 size through render_surfel_with_envgs
     "C4trace": (1000000, 1600, 1600, 8, "C4-size shell scene through render_surfel_with_envgs: P=1000000, 1600x1600, render_surfel + surfel-traced mirror rays of all 2.56 M pixels (hierarchy rebuilt per view), fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
+    "tinyfull": (20000, 400, 400, 8, "tiny debug scene through render_surfel (not a benchmark configuration)"),
 }
 SCENE_KW = {"C2heavy": dict(radius_px=6.5, scale_sigma=0.8)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -136,6 +137,10 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also skips grad_max_rel_err)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines of the default C2 run (C2heavy, C3full, C3trace)")
+    ap.add_argument("--dump-grads", default=None, metavar="PATH",
+                    help="after the measurement render step --dump-step once more and let rank 0 save the (reduced) gradient tensors to PATH "
+                         "(.npz): tests/test_dist_gpu.py compares a 2-rank run with the sum of two single-rank runs")
+    ap.add_argument("--dump-step", type=int, default=0, help="step index of --dump-grads (rank r renders view (step * world + r) mod 8)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no render: launch the ranks, check the world size and push one gradient bucket through the collective "
                          "(works without a GPU over gloo; the line it prints is NOT a benchmark result)")
@@ -168,7 +173,7 @@ def main():
     L = _lib.lib()
 
     P, H, W, S, desc = WORKLOADS[args.workload]
-    scene_kw = dict(radius_px=7.0 * max(H, W) / 800.0 if args.workload == "tiny" else 7.0)
+    scene_kw = dict(radius_px=7.0 * max(H, W) / 800.0 if args.workload in ("tiny", "tinyfull") else 7.0)
     scene_kw.update(SCENE_KW.get(args.workload, {}))
     scene_cpu = make_shell_scene(P, S=S, seed=0, image_size=max(H, W), **scene_kw)
     scene = scene_cpu.to(dev)
@@ -182,7 +187,7 @@ def main():
             debug=False))
     g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
 
-    surfel_mode = args.workload in ("C3full", "C3train", "C4full", "C3trace", "C4trace")
+    surfel_mode = args.workload in ("C3full", "C3train", "C4full", "C3trace", "C4trace", "tinyfull")
     traced = args.workload in ("C3trace", "C4trace")
     use_loss = args.workload in ("C3train", "C4full")
     indirect = args.workload == "C4full"
@@ -190,19 +195,9 @@ def main():
         from types import SimpleNamespace
         from materialrefgs_amd.renderer import SurfelModel, render_surfel
         from materialrefgs_amd.shading import EnvLight
-        gen = torch.Generator().manual_seed(0)
-        rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
-        env = EnvLight(device=dev, trainable=True)
-        with torch.no_grad():
-            env.base.copy_(rnd(6, 128, 128, 3))
-        inv_sig = lambda x: torch.log(x / (1 - x))
-        pc = SurfelModel(scene.means3D.clone(), torch.log(scene.scales), scene.rotations.clone(),
-                         inv_sig(scene.opacities.clamp(1e-4, 1 - 1e-4)), scene.shs[:, :1].clone(), scene.shs[:, 1:].clone(),
-                         refl_strength=rnd(P, 1), roughness=rnd(P, 1), ori_color=rnd(P, 3), indirect_dc=rnd(P, 1, 3) * 0.1,
-                         indirect_rest=rnd(P, 15, 3) * 0.01, envmap=env)
-        surfel_params = pc.parameters() + [env.base]
-        for t_ in surfel_params:
-            t_.requires_grad_(True)
+        from materialrefgs_amd.synthetic import make_surfel_model
+        gen = torch.Generator().manual_seed(1)
+        pc, env, surfel_params = make_surfel_model(P, max(H, W), dev, seed=0, radius_px=scene_kw["radius_px"])
         pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False)
         bg_color = torch.zeros(3, device=dev)
         if traced:
@@ -311,7 +306,7 @@ def main():
             grads.append(g_feat)
         torch.autograd.backward(outs, grads)
         if world > 1:
-            reducer.reduce([params[k].grad for k in params] + [means2D.grad], params["means3D"], settings[view].campos, 3)
+            state["reduced"] = reducer.reduce([params[k].grad for k in params] + [means2D.grad], params["means3D"], settings[view].campos, 3)
 
     def fence():
         if world > 1:
@@ -400,6 +395,47 @@ def main():
         step(base_i + i)
     fence()
 
+    if args.dump_grads:
+        step(args.dump_step)
+        fence()
+        if rank == 0:
+            import numpy as np
+            if surfel_mode:
+                dump = {n: t_.grad.detach().cpu().numpy() for n, t_ in zip(surfel_names, surfel_params)}
+            elif world > 1:
+                dump = {n: t_.detach().cpu().numpy() for n, t_ in zip(grad_names, state["reduced"])}
+            else:
+                dump = {n: t_.grad.detach().cpu().numpy() for n, t_ in zip(grad_names, list(params.values()) + [means2D])}
+            np.savez(args.dump_grads, **dump)
+
+    # What one view-parallel step puts on the links and what every rank computes locally for it (materialrefgs_amd/dist.py), as a model
+    # for V = 8 ranks: bytes from the tensor shapes, the time of the local SH expansion measured here by feeding it 8 gathered rows.
+    def exchange_model(V=8):
+        if surfel_mode:
+            dense_floats = sum(int(t_.numel()) for t_ in surfel_params)
+            sh_floats = sum(int(t_.numel()) for n, t_ in zip(surfel_names, surfel_params) if n in mdist.SurfelGradReducer.SH_NAMES)
+            row = 6 * P + 3
+            gathered = torch.randn(V, row, device=dev)
+            fn = lambda: mdist.expand_surfel_sh_gradients(gathered, pc._xyz, pc._rotation, 3)
+        else:
+            dense_floats = sum(int(v.numel()) for v in params.values()) + int(means2D.numel())
+            sh_floats = int(params["sh"].numel())
+            row = 3 * P + 3
+            gathered = torch.randn(V, row, device=dev)
+            fn = lambda: mdist.expand_sh_gradients(gathered, params["means3D"], 16, 3)
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return {"V": V, "allgather_bytes_per_rank_sent": 4 * row, "allgather_bytes_per_rank_received": 4 * row * V,
+                "allreduce_bytes": 4 * (dense_floats - sh_floats), "dense_allreduce_bytes_avoided": 4 * dense_floats,
+                "floats_per_gaussian_on_the_wire": round((row - 3 + dense_floats - sh_floats) / P, 2),
+                "floats_per_gaussian_dense": round(dense_floats / P, 2), "sh_expand_ms_at_V": round(e0.elapsed_time(e1) / 10, 4)}
+    xmodel = exchange_model() if rank == 0 and torch.cuda.is_available() else None
+
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -453,6 +489,7 @@ def main():
             "cycles_per_inst_per_simd": sq["cycles_per_valu_inst_per_simd"], "peak": 4.0, "frac": round(4.0 / sq["cycles_per_valu_inst_per_simd"], 3),
             "insts_per_launch": sq["valu_insts_per_launch"], "source": sqj.get("measured_by", "profiles/pmc_sq.json")}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+        out["exchange_model"] = xmodel
 
         if world > 1:
             pass                         # the CPU baseline and the oracle comparison belong to the N = 1 run only
@@ -543,6 +580,7 @@ def main():
                         return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
                                 "cold_ms_per_step": j.get("cold_ms_per_step"), "warm_ms_per_step_fenced": j.get("warm_ms_per_step_fenced"),
                                 "steps": j["steps"], "warmup": j["warmup"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
+                                "exchange_model": j.get("exchange_model"),
                                 "roofline": {k: j["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                                                  "algorithmic_bytes_per_launch", "avg_launch_ms")},
                                 "roofline_frac": j["roofline"]["frac"]}

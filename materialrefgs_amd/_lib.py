@@ -149,6 +149,7 @@ SYMBOLS = {
     "mrgs_surfel_bvh_ws_bytes": (c_size_t, [c_int64]),
     "mrgs_surfel_trace_state_floats": (c_size_t, [c_int64, c_int32]),
     "mrgs_surfel_trace_state_floats_norecord": (c_size_t, [c_int64, c_int32]),
+    "mrgs_surfel_trace_state_layout": (ctypes.c_int, [c_int64, c_int32, ctypes.POINTER(c_size_t)]),
     "mrgs_mirror_rays_forward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap), c_void_p,
                                                 c_void_p, c_void_p, c_void_p]),
     "mrgs_mirror_rays_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap), c_void_p,

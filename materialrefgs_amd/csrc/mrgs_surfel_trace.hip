@@ -1238,6 +1238,17 @@ static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte
 size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).total; }
 size_t mrgs_surfel_trace_state_floats_norecord(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).rec_arena; }
 
+// Introspection for the tests: word offsets inside `state` of [0] the list of rays traced one per wavefront (its first word: their count),
+// [1] the list of packets handed to the second launch (first word: count), [2] the record header (word 0: chunks taken from the shared
+// pool, word 1: non-zero = the record overflowed / was not kept and the backward walks again), [3] the replay record, [4] the full size.
+int mrgs_surfel_trace_state_layout(int64_t n_rays, int32_t ray_width, size_t* offsets5)
+{
+    if (n_rays < 0 || !offsets5) return MRGS_E_BAD_ARG;
+    const StateLayout L = st_state(n_rays, (ray_width > 0 && n_rays % ray_width == 0) ? ray_width : 0);
+    offsets5[0] = L.lone; offsets5[1] = L.defer; offsets5[2] = L.rec_hdr; offsets5[3] = L.rec_arena; offsets5[4] = L.total;
+    return MRGS_OK;
+}
+
 // rays and blocks of rays are carried in 32-bit words (ray indices in the lists, `tile << 5 | packet` codes, the launch grid)
 static bool st_ray_count_supported(int64_t n_rays, int32_t ray_width)
 {

@@ -251,12 +251,27 @@ class SurfelTracer(nn.Module):
         self._blob_saved = will_save
         self.last_state = state[:4 * o.shape[0]].reshape(-1, 4)      # diagnostics: sum w t^2, final T, hits blended, passes (negative: in a packet)
         self.last_lone = state[4 * o.shape[0]:4 * o.shape[0] + 1].view(torch.int32)
+        self.last_state_all, self.last_ray_width = state, (int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)   # diagnostics (record_summary)
         r = lambda x, c: x.reshape(*shape, c)
         rgb, dpt, acc, norm, dist, aux = r(rgb, 3), r(dpt, 1), r(acc, 1), r(norm, 3), r(dist, 1), r(aux, 2)
         # stage 0 of the per-depth record (optix_utils.py:28-35); deeper stages do not exist at max_trace_depth = 0
         mid = torch.cat([ray_o.reshape(*shape, 3).float(), ray_d.reshape(*shape, 3).float(), dpt, acc, norm, aux, rgb], dim=-1).detach() \
             if self.want_mid else rgb.new_empty((*shape, 0))
         return rgb, dpt, acc, norm, dist, aux, mid, wet.reshape(P, 1)
+
+
+def record_summary(tracer):
+    """Diagnostics of the last trace of `tracer` (a SurfelTracer): rays traced one per wavefront, packets listed for the second launch,
+    chunks of the replay record taken from the shared pool, and whether the record is usable (False: the backward walks again)."""
+    st = tracer.last_state_all
+    n_rays = tracer.last_state.shape[0]
+    off = (ctypes.c_size_t * 5)()
+    _lib.check(_lib.lib().mrgs_surfel_trace_state_layout(n_rays, tracer.last_ray_width, off))
+    words = st.view(torch.int32)
+    have_hdr = st.numel() >= off[3]
+    pick = lambda i: int(words[i].item())
+    return {"rays": n_rays, "lone_rays": pick(off[0]), "listed_packets": pick(off[1]), "pool_chunks": pick(off[2]) if have_hdr else None,
+            "record_usable": have_hdr and st.numel() >= off[4] and pick(off[2] + 1) == 0}
 
 
 def _bg_key(bg):

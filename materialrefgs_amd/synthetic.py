@@ -117,3 +117,25 @@ def make_occluder_mesh(n_triangles: int = 1_000_000, seed: int = 0):
         vs.append(v); ts.append(t + off)
         off += len(v)
     return np.concatenate(vs), np.concatenate(ts)
+
+
+def make_surfel_model(P: int, image_size: int, device, seed: int = 0, radius_px: float = 7.0, env_res: int = 128, env_min: int = 16):
+    """The shell scene as a renderer.SurfelModel with random material parameters and a trainable EnvLight -- what bench.py's surfel
+    workloads (C3full, C3train, C3trace, C4*) and the full-size tests render.  Returns (pc, env, leaves): `leaves` are the raw parameter
+    tensors + env.base, all requiring gradients."""
+    from .renderer import SurfelModel
+    from .shading import EnvLight
+    scene = make_shell_scene(P, S=0, seed=seed, radius_px=radius_px, image_size=image_size).to(device)
+    gen = torch.Generator().manual_seed(seed)
+    rnd = lambda *sh: torch.randn(*sh, generator=gen).to(device)
+    env = EnvLight(device=device, min_res=env_min, max_res=env_res, trainable=True)
+    with torch.no_grad():
+        env.base.copy_(rnd(6, env_res, env_res, 3))
+    inv_sig = lambda x: torch.log(x / (1 - x))
+    pc = SurfelModel(scene.means3D.clone(), torch.log(scene.scales), scene.rotations.clone(), inv_sig(scene.opacities.clamp(1e-4, 1 - 1e-4)),
+                     scene.shs[:, :1].clone(), scene.shs[:, 1:].clone(), refl_strength=rnd(P, 1), roughness=rnd(P, 1), ori_color=rnd(P, 3),
+                     indirect_dc=rnd(P, 1, 3) * 0.1, indirect_rest=rnd(P, 15, 3) * 0.01, envmap=env)
+    leaves = pc.parameters() + [env.base]
+    for t in leaves:
+        t.requires_grad_(True)
+    return pc, env, leaves

@@ -1,0 +1,179 @@
+"""BASELINE.json's full sizes through the whole path (-m gpu): render_surfel with deferred shading at 300 000 surfels / 800x800 (C3full), the
+surfel tracer along every pixel's mirror ray at 300 000 / 640 000 rays (C3trace) and 1 000 000 / 2 560 000 rays (C4trace).  No CPU checker
+finishes at these sizes, so the tests use what the domain offers that does not depend on size: conservation of blend weight, determinism of
+the forward, linearity of the backward, a gradient on every leaf -- and, for the tracer, the DENSE STATEMENT ITSELF evaluated on the GPU for
+a sample of the rays (every sampled ray against every surfel: oracle/surfel_trace_oracle.trace_dense is plain torch and runs on any
+device).  The raster core at these sizes: tests/test_gpu_parity.py::test_full_size_properties."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from materialrefgs_amd.synthetic import make_surfel_model, orbit_camera  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+PIPE = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False, use_asg=False)
+SURFEL_KEYS = {"render", "refl_strength_map", "diffuse_map", "diffuse_map_ori", "specular_map", "base_color_map", "roughness_map", "viewspace_points",
+               "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal"}
+LOSS_MAPS = ("render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal")      # what calculate_loss reads (utils/loss_utils.py:147-166)
+
+
+def _weights(out, dev, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.rand(out[k].shape, generator=g).to(dev) * (0.01 if k == "surf_depth" else 1.0) for k in LOSS_MAPS]
+
+
+def test_render_surfel_at_c3_size(gpu_device):
+    """C3full: P = 300 000, 800 x 800, S = 8 material channels, deferred split-sum shading, environment prefilter rebuilt for the view."""
+    from materialrefgs_amd.renderer import render_surfel
+    dev = gpu_device
+    P, H, W = 300_000, 800, 800
+    pc, env, leaves = make_surfel_model(P, max(H, W), dev)
+    cam = orbit_camera(0, H, W).to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+
+    def render():
+        env.build_mips()
+        return render_surfel(cam, pc, PIPE, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+
+    out = render()
+    assert set(out) == SURFEL_KEYS
+    for k, v in out.items():
+        if torch.is_tensor(v) and v.dtype.is_floating_point:
+            assert torch.isfinite(v).all(), k
+    a = out["rend_alpha"]
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6 and 0.2 < float((a > 0.5).float().mean()) < 0.9
+    assert int(out["visibility_filter"].sum()) == int((out["radii"] > 0).sum()) > P // 3
+    # composition identities of render_surfel (gaussian_renderer/__init__.py:433-455) on the maps it returns
+    diffuse = (1 - out["refl_strength_map"]) * out["diffuse_map_ori"]
+    assert float((out["diffuse_map"] - diffuse).abs().max()) < 1e-6
+    want = diffuse + out["specular_map"] + bg[:, None, None] * (1 - a)
+    assert float((out["render"] - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    # a second render is bit-equal (no atomics in any forward kernel)
+    out2 = render()
+    for k in ("render", "specular_map", "rend_normal", "surf_depth", "surf_normal", "rend_dist", "roughness_map", "base_color_map"):
+        assert torch.equal(out[k], out2[k]), k
+    # the gradient reaches every leaf, incl. the environment cubemap through the prefilter, and is linear in the upstream gradient
+    ws = _weights(out, dev)
+    grads = []
+    for o, scale in ((out, 1.0), (out2, 2.0)):
+        for t in leaves:
+            t.grad = None
+        torch.autograd.backward([o[k] for k in LOSS_MAPS], [w * scale for w in ws])
+        vs = o["viewspace_points"].grad
+        grads.append([t.grad.clone() for t in leaves] + [vs.clone()])
+    names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color", "indirect_dc",
+             "indirect_rest", "env.base", "viewspace_points"]
+    for n, g1, g2 in zip(names, *grads):
+        assert torch.isfinite(g1).all(), n
+        if n in ("indirect_dc", "indirect_rest"):       # the blended indirect radiance only enters the image under opt.indirect (:423-430)
+            assert float(g1.abs().max()) == 0.0, n
+            continue
+        m = float(g1.abs().max())
+        assert m > 0.0, n
+        assert float((g2 - 2 * g1).abs().max()) <= 2e-4 * m, n      # fp32 atomics: the summation order differs between the two runs
+    # surfels that were culled receive exactly zero gradient
+    dead = out["radii"] == 0
+    assert float(grads[0][0][dead].abs().sum()) == 0.0
+
+
+def _dense_on_gpu(o, d, pc, cam, bg, chunk):
+    """oracle/surfel_trace_oracle.trace_dense for a sample of rays against ALL surfels, float64 on the GPU, `chunk` rays at a time; the
+    colours are computeColorFromSH from the camera position, the placeholder `others` of render_gaussians (optix_utils.py:173-177)."""
+    import surfel_trace_oracle as sto
+    from materialrefgs_amd.gs_utils import eval_sh
+    dt = torch.float64
+    with torch.no_grad():
+        means = pc.get_xyz.to(dt)
+        dirs = means - cam.camera_center.to(dt).reshape(1, 3)
+        dirs = dirs / dirs.norm(dim=1, keepdim=True)
+        colors = torch.clamp_min(eval_sh(pc.active_sh_degree, pc.get_features.to(dt).transpose(1, 2), dirs) + 0.5, 0.0)
+        others = torch.full((means.shape[0], 2), 0.01, dtype=dt, device=means.device)
+        outs = []
+        for s in range(0, o.shape[0], chunk):
+            r = sto.trace_dense(o[s:s + chunk].to(dt), d[s:s + chunk].to(dt), means, pc.get_scaling.to(dt), pc.get_rotation.to(dt), pc.get_opacity.to(dt),
+                                colors, others, bg.to(dt))
+            outs.append({k: r[k] for k in ("rgb", "dpt", "acc", "norm", "dist", "aux", "T", "hits")})
+        return {k: torch.cat([x[k] for x in outs]) for k in outs[0]}
+
+
+@pytest.mark.parametrize("P,H,W,sample", [(300_000, 800, 800, 1536), (1_000_000, 1600, 1600, 768)])
+def test_traced_mirror_rays_at_full_size(gpu_device, P, H, W, sample):
+    """C3trace / C4trace: render_surfel, then the same surfels traced along every pixel's mirror ray (render_surfel_with_envgs)."""
+    from materialrefgs_amd.renderer import _mirror_rays, render_surfel_with_envgs
+    from materialrefgs_amd.gs_utils import safe_normalize
+    from materialrefgs_amd.surfel_tracing import HardwareRendering, record_summary
+    dev = gpu_device
+    pc, env, leaves = make_surfel_model(P, max(H, W), dev)
+    cam = orbit_camera(0, H, W).to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    hw = HardwareRendering().train()
+
+    def render():
+        env.build_mips()
+        return render_surfel_with_envgs(hw, cam, pc, PIPE, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+
+    out = render()
+    ind = out["indirect_out"]
+    n_rays = H * W
+    for k in ("render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "specular", "roughness"):
+        assert torch.isfinite(ind[k]).all() and ind[k].shape[-2:] == (H, W), k
+    acc, wet = ind["rend_alpha"][0].double(), ind["weight_accumulate"][:, 0].double()
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-6
+    # every unit of blend weight a ray hands out lands on exactly one surfel: sum over surfels == sum over rays
+    assert abs(float(wet.sum()) - float(acc.sum())) <= 1e-4 * float(acc.sum())
+    # front-to-back compositing telescopes: acc = 1 - T_final on every ray (state word 1), and acc + T bg is what `render` adds up to
+    st = hw.tracer.last_state
+    assert st.shape == (n_rays, 4)
+    assert float((acc.reshape(-1) - (1.0 - st[:, 1].double())).abs().max()) < 2e-5
+    # all rays accounted for: walked in a packet (passes < 0), alone (listed), or in their block -- and the replay record held
+    rs = record_summary(hw.tracer)
+    assert rs["rays"] == n_rays and rs["record_usable"], rs
+    assert 0 <= rs["lone_rays"] <= n_rays // 4 and rs["listed_packets"] >= 0, rs
+    hits = st[:, 2]
+    assert float(hits.min()) >= 0 and float((hits > 0).float().mean()) > 0.3
+    assert bool(((hits == 0) == (acc.reshape(-1) == 0)).all())
+    # the dense statement itself for a sample of the rays (every one against all P surfels)
+    normal_map = safe_normalize(out["rend_normal"].permute(1, 2, 0) / out["rend_alpha"].permute(1, 2, 0).clamp_min(1e-6))
+    with torch.no_grad():
+        ray_o, ray_d = _mirror_rays(cam, normal_map, out["surf_depth"])
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randperm(n_rays, generator=g)[:sample].to(dev)
+    ref = _dense_on_gpu(ray_o.reshape(-1, 3)[idx], ray_d.reshape(-1, 3)[idx], pc, cam, bg, chunk=64 if P > 500_000 else 128)
+    flat = lambda x, c: x.permute(1, 2, 0).reshape(-1, c)[idx].double()
+    got = {"rgb": flat(ind["render"], 3), "dpt": flat(ind["surf_depth"], 1)[:, 0], "acc": flat(ind["rend_alpha"], 1)[:, 0],
+           "norm": flat(ind["rend_normal"], 3), "dist": flat(ind["rend_dist"], 1)[:, 0]}
+    same_hits = st[idx, 2].double() == ref["hits"].double()
+    assert float(same_hits.double().mean()) > 0.995               # a hit within rounding of the alpha / T thresholds (test_surfel_tracing.py)
+    for k, v in got.items():
+        err = (v - ref[k]).abs().reshape(sample, -1).max(dim=1).values
+        scale = max(float(ref[k].abs().max()), 1e-6)
+        bad = float(((err > 2e-4 * scale) & same_hits).double().mean())
+        assert bad < 2e-3, (k, float(err[same_hits].max()), scale, bad)
+    # determinism of the traced maps, linearity of the whole backward (raster + shading + tracer) in the upstream gradient
+    out2 = render()
+    for k in ("render", "rend_alpha", "surf_depth", "rend_normal"):
+        assert torch.equal(ind[k], out2["indirect_out"][k]), k
+    assert torch.equal(out["render"], out2["render"])
+    ws = _weights(out, dev)
+    grads = []
+    for o, scale in ((out, 1.0), (out2, 2.0)):
+        for t in leaves:
+            t.grad = None
+        torch.autograd.backward([o[k] for k in LOSS_MAPS], [w * scale for w in ws])
+        grads.append([t.grad.clone() for t in leaves] + [o["indirect_out"]["viewspace_points"].grad.clone()])
+    names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color", "indirect_dc",
+             "indirect_rest", "env.base", "traced viewspace_points"]
+    for n, g1, g2 in zip(names, *grads):
+        assert torch.isfinite(g1).all(), n
+        if n in ("indirect_dc", "indirect_rest"):
+            continue
+        m = float(g1.abs().max())
+        assert m > 0.0, n
+        assert float((g2 - 2 * g1).abs().max()) <= 5e-4 * m, n

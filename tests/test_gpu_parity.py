@@ -259,10 +259,10 @@ def test_mark_visible(gpu_device):
     np.testing.assert_array_equal(vis.cpu().numpy(), ro.mark_visible(pts, cam.world_view_transform, cam.full_proj_transform))
 
 
-@pytest.mark.parametrize("P,S,H,W", [(300000, 8, 800, 800), (1000000, 8, 1600, 1600)])
+@pytest.mark.parametrize("P,S,H,W", [(300000, 0, 800, 800), (300000, 8, 800, 800), (1000000, 8, 1600, 1600)])
 def test_full_size_properties(gpu_device, P, S, H, W):
-    """BASELINE.json's C3 size (300k surfels, 800x800, S=8) and the raster part of C4 (1M surfels, 1600x1600): size-independent
-    properties, no oracle needed."""
+    """BASELINE.json's C2 itself (300k surfels, 800x800, S=0: the S=0 instances of the blend kernels), the C3 size (S=8) and the raster
+    part of C4 (1M surfels, 1600x1600): size-independent properties, no oracle needed."""
     scene = make_shell_scene(P, S=S, seed=0, radius_px=7.0, image_size=max(H, W))
     cam = orbit_camera(0, H, W)
     hr = HipRender(scene, cam, gpu_device)

@@ -489,8 +489,9 @@ def test_empty_model_and_forward_only_state(gpu_device):
     with_grad, Lg = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
     with torch.no_grad():
         no_grad, _ = _hip_trace(gpu_device, sc, colors, others, o, d, bg)
-    for k in ("rgb", "dpt", "acc", "norm", "dist", "aux", "wet"):
+    for k in ("rgb", "dpt", "acc", "norm", "dist", "aux"):
         assert torch.equal(with_grad[k].detach(), no_grad[k]), k
+    assert float((with_grad["wet"].detach() - no_grad["wet"]).abs().max()) <= 1e-5 * float(no_grad["wet"].abs().max())   # summed with atomics
     # the autograd node of the no-grad trace kept nothing; the one with gradients kept the full state
     state = with_grad["rgb"].grad_fn.saved_tensors[-1]
     assert state.numel() == full
