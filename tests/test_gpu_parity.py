@@ -173,17 +173,27 @@ def test_forward_on_a_capacity_guess_matches_the_two_phase_forward(gpu_device):
     cam = orbit_camera(3, H, W)
     grads = upstream_grads(S, H, W)
     results = []
+    key = (gpu_device.index, 3000, H, W)                       # the guess is kept per (device, P, H, W)
+    paths = []
     for guess in (None, 10, "half", 10_000_000, "exact"):      # too small (twice), far too large, exact
         if guess is None:
-            rz._PAIR_GUESS.pop(gpu_device.index, None)
+            rz._PAIR_GUESS.pop(key, None)
         else:
-            rz._PAIR_GUESS[gpu_device.index] = results[0][0] if guess == "exact" else results[0][0] // 2 if guess == "half" else guess
+            rz._PAIR_GUESS[key] = results[0][0] if guess == "exact" else results[0][0] // 2 if guess == "half" else guess
         hr = HipRender(scene, cam, gpu_device)
+        paths.append(hr.fn.binning_pairs)
+        assert key in rz._PAIR_GUESS and rz._PAIR_GUESS[key] >= hr.num_rendered      # ... and refreshed by every forward
         pl = hr.export("point_list")
         rng = hr.export("ranges")
         results.append((hr.num_rendered, pl, rng, hr.color.detach().cpu().numpy(), hr.others.detach().cpu().numpy(), hr.backward(*grads)))
     ref = results[0]
     assert ref[0] > 1000
+    # the workspace was carved for the exact count where the guess was missing or too small, for the guess where it fitted
+    assert paths == [ref[0], ref[0], ref[0], 10_000_000, ref[0]], paths
+    # another image size or surfel count on the same device does not disturb this configuration's guess
+    rz._PAIR_GUESS[key] = ref[0]
+    HipRender(make_shell_scene(500, S=S, seed=1, radius_px=6.0, image_size=160), orbit_camera(3, 64, 64), gpu_device)
+    assert rz._PAIR_GUESS[key] == ref[0]
     for r in results[1:]:
         assert r[0] == ref[0]
         assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
@@ -199,15 +209,23 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     S, H, W = 4, 160, 120
     scene = make_shell_scene(3000, S=S, seed=11, radius_px=6.0, image_size=160)
     cam = orbit_camera(5, H, W)
-    rz._WORK_HINTS.clear()
+    rz.reset_work_hints()
     a = HipRender(scene, cam, gpu_device)                   # hint zero -> cull counts
-    hints = [h for k, h in rz._WORK_HINTS.items() if k[1] == H and k[2] == W]
-    assert len(hints) >= 1 and int(sum(int(h.sum()) for h in hints)) > 0      # the forward stored its measured work
-    b = HipRender(scene, cam, gpu_device)                   # ordered by the measured work (if the same camera tensors are reused)
-    for h in hints:
-        h.copy_(torch.randint(1, 4000, h.shape, device=h.device, dtype=torch.int32))
-    c = HipRender(scene, cam, gpu_device)                   # garbage hint: still only a schedule
-    for r in (b, c):
+    assert len(rz._WORK_HINTS) == 1
+    (hint, vm, pm, _versions, visits), = rz._WORK_HINTS.values()
+    assert vm is a.rs.viewmatrix and pm is a.rs.projmatrix                     # the entry keeps the camera's tensors alive
+    assert int(hint.sum()) > 0 and visits[0] == 1                              # the forward stored its measured work
+    b = HipRender(scene, cam, gpu_device, rs=a.rs)          # same camera tensors: ordered by the measured work, backward prepared
+    assert len(rz._WORK_HINTS) == 1 and visits[0] == 2 and b.fn.prepared_grad_ws is not None and a.fn.prepared_grad_ws is None
+    hint.copy_(torch.randint(1, 4000, hint.shape, device=hint.device, dtype=torch.int32))
+    c = HipRender(scene, cam, gpu_device, rs=a.rs)          # garbage hint: still only a schedule
+    # a camera whose matrices were written in place is a new camera: its old hint is not used
+    a.rs.viewmatrix.add_(0.0)
+    assert rz._hint_entry(a.rs, gpu_device) is None
+    # other camera tensors (even with equal values) get their own entry
+    d = HipRender(scene, cam, gpu_device)
+    assert len(rz._WORK_HINTS) == 2 and d.fn.prepared_grad_ws is None
+    for r in (b, c, d):
         assert r.num_rendered == a.num_rendered
         assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others) and torch.equal(r.feature, a.feature)
 
