@@ -218,6 +218,25 @@ int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float c
  * short rows, 64 for rows of hundreds of non-zeros. */
 int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const void* val, int32_t val_bytes,
                    const float* row_scale, const float* x, float* y, int32_t lanes_per_row, void* stream);
+/* Up to MRGS_SPMV_MAX_BATCH independent products of the kind above in ONE launch (`descs` is a host array): the levels of
+ * EnvLight.build_mips each way. */
+#define MRGS_SPMV_MAX_BATCH 8
+typedef struct MrgsSpmvDesc {
+    int32_t nrows, lanes_per_row, col_bytes, val_bytes;
+    const uint32_t* row_ptr;
+    const void* col;
+    const void* val;
+    const float* row_scale;
+    const float* x;
+    float* y;
+} MrgsSpmvDesc;
+int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream);
+/* cubemap_mip applied n_steps times below `in` [6,res_in,res_in,3] (scene/light.py:74-76): outs[k] = level k + 1 ([6, res_in >> (k+1), ., 3]),
+ * `outs` a host array of device pointers; bit-identical to n_steps calls of mrgs_cubemap_mip_forward, one launch per three levels.
+ * The backward chain g[k] += cubemap_mip.backward(g[k + 1]) for k = n_levels - 2 ... 0 in place (g[k]: [6, res0 >> k, ., 3], g a host
+ * array), one launch per level. */
+int mrgs_cubemap_mip_chain_forward(int32_t res_in, int32_t n_steps, const float* in, float* const* outs, void* stream);
+int mrgs_cubemap_mip_chain_backward(int32_t res0, int32_t n_levels, float* const* g, void* stream);
 /* cubemap_mip (scene/light_utils.py:66-81): forward = 2x2 box filter [6,2r,2r,3] -> [6,r,r,3]; backward = the reference's own
  * rule (seamless bilinear cube fetch of 0.25 * dout at the finer level's texel-centre directions), ACCUMULATED into g_fine. */
 int mrgs_cubemap_mip_forward(int32_t res_out, const float* in, float* out, void* stream);
@@ -249,9 +268,11 @@ int mrgs_indirect_blend_backward(int32_t H, int32_t W, const float* direct, cons
 
 /* g_features[8,H,W] of render_surfel's material map (refl, roughness, albedo[3], indirect[3]) assembled from the outputs of
  * mrgs_surfel_composite_backward (g_refl), mrgs_shade_specular_backward (g_refl, g_roughness [H,W]; g_albedo [H,W,3]) and, with the
- * visibility tracer, mrgs_indirect_blend_backward (g_indirect [H,W,3]; NULL = zeros). */
+ * visibility tracer, mrgs_indirect_blend_backward (g_indirect [H,W,3]; NULL = zeros).  In the same pass g_alpha [H,W] (NULL = skip) receives
+ * the sum of the up to three alpha gradients of those kernels (g_alpha_a / _b / _c, each [H,W] or NULL). */
 int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,
-                              const float* g_albedo_hwc, const float* g_indirect_hwc, float* g_features, void* stream);
+                              const float* g_albedo_hwc, const float* g_indirect_hwc, float* g_features, const float* g_alpha_a,
+                              const float* g_alpha_b, const float* g_alpha_c, float* g_alpha, void* stream);
 
 /* ---- per-gaussian inputs of the surfel renderer (fused glue) -----------------------------------------------------
  * One kernel instead of the ~50 torch kernels the reference runs per view before the rasterizer call: GaussianModel getters
@@ -292,7 +313,8 @@ typedef struct MrgsMapsFrame {
     float depth_ratio;
 } MrgsMapsFrame;
 int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
-                             float* normal_map, void* stream);
+                             float* normal_map, float* rend_alpha /*[1,H,W] = allmap[1], NULL = skip*/, float* rend_dist /*[1,H,W] = allmap[6]*/,
+                             void* stream);
 /* g_allmap[7,H,W] (fully written) from the upstream gradients of the four outputs and of rend_alpha = allmap[1:2] and
  * rend_dist = allmap[6:7], which are plain views in the reference ([1,H,W] each; any of the six may be NULL = zero). */
 int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,

@@ -59,6 +59,11 @@ class MrgsShadeFrame(ctypes.Structure):
                 ("roughness", MrgsStridedMap), ("lut", c_void_p), ("lut_res", c_int32)]
 
 
+class MrgsSpmvDesc(ctypes.Structure):
+    _fields_ = [("nrows", c_int32), ("lanes_per_row", c_int32), ("col_bytes", c_int32), ("val_bytes", c_int32), ("row_ptr", c_void_p),
+                ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p)]
+
+
 class MrgsSurfelParams(ctypes.Structure):
     _fields_ = [("P", c_int32)] + [(n, c_void_p) for n in ("xyz", "scaling_raw", "rotation_raw", "opacity_raw", "refl_raw", "rough_raw",
                                                              "ori_color_raw", "indirect_dc", "indirect_rest", "campos")]
@@ -113,7 +118,8 @@ SYMBOLS = {
     "mrgs_surfel_features_forward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_features_backward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p,
                                                      ctypes.POINTER(MrgsSurfelGrads), c_void_p]),
-    "mrgs_surfel_maps_forward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_surfel_maps_forward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     "mrgs_surfel_maps_backward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_composite_forward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -123,9 +129,12 @@ SYMBOLS = {
     "mrgs_cubemap_filter_count": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_filter_fill": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "mrgs_csr_spmv3_batched": (ctypes.c_int, [ctypes.POINTER(MrgsSpmvDesc), c_int32, c_void_p]),
+    "mrgs_cubemap_mip_chain_forward": (ctypes.c_int, [c_int32, c_int32, c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
+    "mrgs_cubemap_mip_chain_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_void_p), c_void_p]),
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_mip_backward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
-    "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_surfel_feature_grads": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 11),
     "mrgs_loss_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mrgs_loss_forward": (ctypes.c_int, [ctypes.POINTER(MrgsLossConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -83,13 +83,16 @@ __device__ __forceinline__ FdNormal fd_normal(const MapsFrameDev& f, const float
 
 __global__ void __launch_bounds__(256) surfel_maps_fwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, float* __restrict__ rend_normal,
                                                               float* __restrict__ surf_depth, float* __restrict__ surf_normal,
-                                                              float* __restrict__ normal_map)
+                                                              float* __restrict__ normal_map, float* __restrict__ rend_alpha,
+                                                              float* __restrict__ rend_dist)
 {
     const int HW = f.H * f.W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
     const int y = pix / f.W, x = pix - y * f.W;
     const float a = allmap[HW + pix];
+    if (rend_alpha) rend_alpha[pix] = a;                       // the reference's plain slices allmap[1:2], allmap[6:7] as tensors of their own
+    if (rend_dist) rend_dist[pix] = allmap[6 * HW + pix];
     const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
     float nw[3];
 #pragma unroll
@@ -270,10 +273,13 @@ __global__ void __launch_bounds__(256) surfel_composite_bwd_kernel(int HW, int s
 // would each pad to [8,H,W] and add up
 __global__ void __launch_bounds__(256) surfel_feature_grads_kernel(int HW, const float* __restrict__ g_refl_composite, const float* __restrict__ g_refl_shade,
                                                                    const float* __restrict__ g_rough, const float* __restrict__ g_albedo_hwc,
-                                                                   const float* __restrict__ g_indirect_hwc, float* __restrict__ g_features)
+                                                                   const float* __restrict__ g_indirect_hwc, float* __restrict__ g_features,
+                                                                   const float* __restrict__ g_alpha_a, const float* __restrict__ g_alpha_b,
+                                                                   const float* __restrict__ g_alpha_c, float* __restrict__ g_alpha)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
+    if (g_alpha) g_alpha[pix] = (g_alpha_a ? g_alpha_a[pix] : 0.0f) + (g_alpha_b ? g_alpha_b[pix] : 0.0f) + (g_alpha_c ? g_alpha_c[pix] : 0.0f);
     g_features[pix] = g_refl_composite[pix] + g_refl_shade[pix];
     g_features[HW + pix] = g_rough[pix];
 #pragma unroll
@@ -347,12 +353,12 @@ __global__ void __launch_bounds__(256) indirect_blend_bwd_kernel(int H, int W, c
 extern "C" {
 
 int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
-                             float* normal_map, void* stream)
+                             float* normal_map, float* rend_alpha, float* rend_dist, void* stream)
 {
     if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !rend_normal || !surf_depth) return MRGS_E_BAD_ARG;
     const int HW = fr->H * fr->W;
     hipLaunchKernelGGL(surfel_maps_fwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, to_dev(fr), allmap, rend_normal,
-                       surf_depth, surf_normal, normal_map);
+                       surf_depth, surf_normal, normal_map, rend_alpha, rend_dist);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
@@ -416,12 +422,13 @@ int mrgs_indirect_blend_backward(int32_t H, int32_t W, const float* direct, cons
 }
 
 int mrgs_surfel_feature_grads(int32_t H, int32_t W, const float* g_refl_composite, const float* g_refl_shade, const float* g_roughness,
-                              const float* g_albedo_hwc, const float* g_indirect_hwc, float* g_features, void* stream)
+                              const float* g_albedo_hwc, const float* g_indirect_hwc, float* g_features, const float* g_alpha_a,
+                              const float* g_alpha_b, const float* g_alpha_c, float* g_alpha, void* stream)
 {
     if (H <= 0 || W <= 0 || !g_refl_composite || !g_refl_shade || !g_roughness || !g_albedo_hwc || !g_features) return MRGS_E_BAD_ARG;
     const int HW = H * W;
     hipLaunchKernelGGL(surfel_feature_grads_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, g_refl_composite, g_refl_shade,
-                       g_roughness, g_albedo_hwc, g_indirect_hwc, g_features);
+                       g_roughness, g_albedo_hwc, g_indirect_hwc, g_features, g_alpha_a, g_alpha_b, g_alpha_c, g_alpha);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -216,42 +216,36 @@ __device__ __forceinline__ void texel_scatter(float* addr, const float v[3])
     }
 }
 
-// gradient of the fetch: scatter to the texels, return d/d dir and d/d level
+// gradient of the fetch: scatter to the texels (global atomics, lanes sharing a texel combined by texel_scatter; SCATTER = false leaves the
+// texels to the caller), return d/d dir and d/d level
+template <bool SCATTER = true>
 __device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu, f3 dir, const EnvSample& s, const Taps tp[2],
-                                              const float gL[3], f3& g_dir, float& g_level, float* __restrict__ lds_grad = nullptr)
+                                              const float gL[3], f3& g_dir, float& g_level)
 {
     float gu = 0.f, gv = 0.f;
     g_level = 0.f;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const float wk = k == 0 ? 1.f - s.f : s.f;
-        const int lk = k == 0 ? s.l0 : s.l1;
-        float* gt = m.grad[lk];
-        if (gt != nullptr) {   // privatised copy of this workgroup
-            const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
-            gt += (size_t)(wg % (unsigned)m.copies[lk]) * (size_t)(6 * m.res[lk] * m.res[lk] * 3);
-        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float g = gL[c] * wk;
             gu += g * s.du[k][c];
             gv += g * s.dv[k][c];
         }
-        // coarse levels: thousands of pixels land on each texel -> accumulate in the workgroup's LDS copy of the level (LDS
-        // float atomics), flushed once per workgroup; fine levels: global atomics, lanes sharing a texel combined in the wave
-        const int loff = lds_grad != nullptr ? m.lds_off[lk] : -1;
-        const bool in_lds = __builtin_amdgcn_readfirstlane(loff) >= 0 && __builtin_amdgcn_ballot_w64(loff < 0) == 0ull;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float wq = wk * tp[k].w[q];
-            const float vq[3] = {gL[0] * wq, gL[1] * wq, gL[2] * wq};
-            const bool live = gt != nullptr && wq != 0.f;
-            if (live && loff >= 0) {                       // this lane's level is LDS-resident
-                float* a = lds_grad + loff + tp[k].idx[q] * 3;
-                atomicAdd(a, vq[0]); atomicAdd(a + 1, vq[1]); atomicAdd(a + 2, vq[2]);
+        if constexpr (SCATTER) {
+            const int lk = k == 0 ? s.l0 : s.l1;
+            float* gt = m.grad[lk];
+            if (gt != nullptr) {   // privatised copy of this workgroup
+                const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
+                gt += (size_t)(wg % (unsigned)m.copies[lk]) * (size_t)(6 * m.res[lk] * m.res[lk] * 3);
             }
-            // wave-convergent: skipped only when no lane of the wave needs the global path
-            if (!in_lds) texel_scatter((live && loff < 0) ? gt + (size_t)tp[k].idx[q] * 3 : nullptr, vq);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float wq = wk * tp[k].w[q];
+                const float vq[3] = {gL[0] * wq, gL[1] * wq, gL[2] * wq};
+                texel_scatter((gt != nullptr && wq != 0.f) ? gt + (size_t)tp[k].idx[q] * 3 : nullptr, vq);     // wave-convergent
+            }
         }
     }
 #pragma unroll
@@ -269,6 +263,121 @@ __device__ __forceinline__ void env_fetch_bwd(const EnvMips& m, const FaceUV& fu
     default: g_dir = mk(-ga, -gb, gm); break;  // u = -x/|z|, v = -y/|z|
     }
     (void)dir;
+}
+
+// ---- texel-gradient accumulation of the deferred shading backward ----------------------------------------------------------
+// Measured on MI355X (tools/ubench/lds_atomic, tools/shade_stats.py): a scattered global float atomic costs the chip
+// ~1/25 ns, an LDS float atomic (ds_add_f32) ~3 cycles PER ACTIVE LANE of its CU's LDS (200 G/s chip-wide; integer compare-and-swap is
+// ten times faster), a VALU instruction 4 cycles per wave on one of four SIMDs -- so lanes are merged on the VALU first, then in LDS, and
+// only what is left leaves the CU:
+//   1. run_merge: neighbouring pixels mirror into the same texels in RUNS along a row (a 64 x 1 wave footprint touches ~9 distinct
+//      texel footprints of a 64 x 64 level on the bench scene, 49 lanes using it): a segmented sum over runs of equal key inside each
+//      16-lane row (four row_shr DPP steps) leaves one lane per run;
+//   2. levels that fit the workgroup's LDS (coarsest first, MRGS_SHADE_LDS_FLOATS) accumulate in a dense LDS copy;
+//   3. the finer levels go through a 4 096-entry LDS hash table (key = level | texel, CAS insert with linear probing, three float
+//      accumulators per entry): a 64 x 12-pixel tile touches ~35 footprints of the 64 x 64 level, 590 pixels using it.  The table is
+//      flushed with global atomics when half full (checked between tiles) and at the end; a lane that finds no slot in 8 probes adds
+//      straight to global memory.
+#define MRGS_SHADE_HASH_BITS 12
+#define MRGS_SHADE_HASH_SIZE (1 << MRGS_SHADE_HASH_BITS)
+#define MRGS_SHADE_KEY_NONE 0xffffffffu
+
+// Sum v over the run of consecutive lanes (inside a 16-lane row) that hold the same key; true in the lane that ends a run, which then
+// holds the run's total.  Hillis-Steele segmented scan: (v, head) o (v', head') = head' ? (v', 1) : (v + v', head).
+__device__ __forceinline__ bool run_merge(unsigned key, float v[3])
+{
+#define SHR(x, n, old) __builtin_amdgcn_update_dpp((int)(old), (int)(x), 0x110 + (n), 0xf, 0xf, false)
+    const unsigned prev = (unsigned)SHR(key, 1, ~key);                    // lane 0 of a row: no source -> old = ~key != key
+    int head = prev != key;
+    const int next_head = __builtin_amdgcn_update_dpp(1, head, 0x101, 0xf, 0xf, false);     // row_shl:1; lane 15 of a row: 1
+#pragma unroll
+    for (int d = 1; d <= 8; d <<= 1) {
+        const float m = head ? 0.f : 1.f;
+        float p0, p1, p2;
+        int ph;
+        if (d == 1) { p0 = __int_as_float(SHR(__float_as_int(v[0]), 1, 0)); p1 = __int_as_float(SHR(__float_as_int(v[1]), 1, 0)); p2 = __int_as_float(SHR(__float_as_int(v[2]), 1, 0)); ph = SHR(head, 1, 1); }
+        else if (d == 2) { p0 = __int_as_float(SHR(__float_as_int(v[0]), 2, 0)); p1 = __int_as_float(SHR(__float_as_int(v[1]), 2, 0)); p2 = __int_as_float(SHR(__float_as_int(v[2]), 2, 0)); ph = SHR(head, 2, 1); }
+        else if (d == 4) { p0 = __int_as_float(SHR(__float_as_int(v[0]), 4, 0)); p1 = __int_as_float(SHR(__float_as_int(v[1]), 4, 0)); p2 = __int_as_float(SHR(__float_as_int(v[2]), 4, 0)); ph = SHR(head, 4, 1); }
+        else { p0 = __int_as_float(SHR(__float_as_int(v[0]), 8, 0)); p1 = __int_as_float(SHR(__float_as_int(v[1]), 8, 0)); p2 = __int_as_float(SHR(__float_as_int(v[2]), 8, 0)); ph = SHR(head, 8, 1); }
+        v[0] = fmaf(p0, m, v[0]); v[1] = fmaf(p1, m, v[1]); v[2] = fmaf(p2, m, v[2]);
+        head |= ph;
+    }
+#undef SHR
+    return next_head != 0;
+}
+
+struct ShadeAcc {          // the workgroup's LDS accumulators
+    float* dense;          // coarse levels, EnvMips::lds_off
+    unsigned* keys;        // hash table of the finer levels
+    float* vals;
+    unsigned* count;       // entries taken so far (never reset: the kernel remembers its value at the last flush)
+};
+
+// one merged contribution (the lane ends a run; key = level << 24 | texel) into the workgroup's accumulators
+__device__ __forceinline__ void acc_add(const EnvMips& m, const ShadeAcc& A, int lk, int idx, const float v[3])
+{
+    const int loff = m.lds_off[lk];
+    if (loff >= 0) {
+        float* a = A.dense + loff + idx * 3;
+        atomicAdd(a, v[0]); atomicAdd(a + 1, v[1]); atomicAdd(a + 2, v[2]);
+        return;
+    }
+    const unsigned key = ((unsigned)lk << 24) | (unsigned)idx;
+    unsigned h = (key * 2654435761u) >> (32 - MRGS_SHADE_HASH_BITS);
+    int slot = -1;
+    for (int p = 0; p < 8; ++p) {
+        const unsigned old = atomicCAS(&A.keys[h], MRGS_SHADE_KEY_NONE, key);
+        if (old == MRGS_SHADE_KEY_NONE) atomicAdd(A.count, 1u);
+        if (old == MRGS_SHADE_KEY_NONE || old == key) { slot = (int)h; break; }
+        h = (h + 1) & (MRGS_SHADE_HASH_SIZE - 1);
+    }
+    if (slot >= 0) {
+        float* a = A.vals + slot * 3;
+        atomicAdd(a, v[0]); atomicAdd(a + 1, v[1]); atomicAdd(a + 2, v[2]);
+    } else {
+        float* g = m.grad[lk] + (size_t)(blockIdx.x % (unsigned)m.copies[lk]) * (size_t)(6 * m.res[lk] * m.res[lk] * 3) + (size_t)idx * 3;
+        atomicAdd(g, v[0]); atomicAdd(g + 1, v[1]); atomicAdd(g + 2, v[2]);
+    }
+}
+
+// the eight taps of one pixel's fetch: merged along the row, then accumulated (wave-convergent: every lane of the wave calls it)
+__device__ __forceinline__ void env_scatter_tile(const EnvMips& m, const ShadeAcc& A, const EnvSample& s, const Taps tp[2], const float gL[3])
+{
+    const bool any = gL[0] != 0.f || gL[1] != 0.f || gL[2] != 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float wk = k == 0 ? 1.f - s.f : s.f;
+        const int lk = k == 0 ? s.l0 : s.l1;
+        const bool lev = any && wk != 0.f && m.grad[lk] != nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float wq = wk * tp[k].w[q];
+            float v[3] = {gL[0] * wq, gL[1] * wq, gL[2] * wq};
+            const bool live = lev && tp[k].w[q] != 0.f;
+            const unsigned key = live ? (((unsigned)lk << 24) | (unsigned)tp[k].idx[q]) : MRGS_SHADE_KEY_NONE;
+            if (!live) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
+            const bool last = run_merge(key, v);
+            if (last && key != MRGS_SHADE_KEY_NONE) acc_add(m, A, lk, tp[k].idx[q], v);
+        }
+    }
+}
+
+// every entry of the hash table -> global memory, table emptied (all threads of the workgroup; barriers are the caller's)
+__device__ __forceinline__ void acc_flush_hash(const EnvMips& m, const ShadeAcc& A, int nthreads)
+{
+    for (int i = threadIdx.x; i < MRGS_SHADE_HASH_SIZE; i += nthreads) {
+        const unsigned key = A.keys[i];
+        if (key == MRGS_SHADE_KEY_NONE) continue;
+        const int lk = (int)(key >> 24), idx = (int)(key & 0xffffffu);
+        float* g = m.grad[lk] + (size_t)(blockIdx.x % (unsigned)m.copies[lk]) * (size_t)(6 * m.res[lk] * m.res[lk] * 3) + (size_t)idx * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float v = A.vals[i * 3 + c];
+            if (v != 0.f) atomicAdd(g + c, v);
+            A.vals[i * 3 + c] = 0.f;
+        }
+        A.keys[i] = MRGS_SHADE_KEY_NONE;
+    }
 }
 
 // ---- standalone environment lookup ---------------------------------------------------------------------
@@ -312,7 +421,7 @@ __global__ void __launch_bounds__(256) envmap_lookup_bwd_kernel(EnvMips m, long 
     }
     f3 gd;
     float glev;
-    env_fetch_bwd(m, fu, d, s, tp, gL, gd, glev);
+    env_fetch_bwd<true>(m, fu, d, s, tp, gL, gd, glev);
     if (valid && g_dirs) { g_dirs[3 * i] = gd.x; g_dirs[3 * i + 1] = gd.y; g_dirs[3 * i + 2] = gd.z; }
     if (valid && g_rough) g_rough[i] = use_mips ? glev * dl : 0.f;
 }
@@ -407,9 +516,8 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
 }
 
 // Persistent workgroups (one per CU, 12 waves): each keeps an LDS copy of the texel gradients of the coarse mip levels
-// (<= MRGS_SHADE_LDS_FLOATS floats: 32x32 and 16x16 cubemap levels = 90 KB), walks 64x12-pixel tiles of the image and flushes
-// the copy once at the end.  On those levels thousands of pixels hit every texel; global float atomics there ran at
-// ~40 G/s and bounded the kernel.
+// (<= MRGS_SHADE_LDS_FLOATS floats: 32x32 and 16x16 cubemap levels = 90 KB) and a hash table for the finer ones (64 KB), walks
+// 64x12-pixel tiles of the image and flushes both at the end (see "texel-gradient accumulation" above).
 #define MRGS_SHADE_BWD_THREADS 768
 #define MRGS_SHADE_LDS_FLOATS 23552
 __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_kernel(
@@ -419,9 +527,16 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
     float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/, int tiles_x, int ntiles, int lds_floats)
 {
     __shared__ float s_grad[MRGS_SHADE_LDS_FLOATS];
+    __shared__ unsigned s_keys[MRGS_SHADE_HASH_SIZE];
+    __shared__ float s_vals[MRGS_SHADE_HASH_SIZE * 3];
+    __shared__ unsigned s_count;
     for (int i = threadIdx.x; i < lds_floats; i += MRGS_SHADE_BWD_THREADS) s_grad[i] = 0.f;
+    for (int i = threadIdx.x; i < MRGS_SHADE_HASH_SIZE; i += MRGS_SHADE_BWD_THREADS) { s_keys[i] = MRGS_SHADE_KEY_NONE; s_vals[3 * i] = 0.f; s_vals[3 * i + 1] = 0.f; s_vals[3 * i + 2] = 0.f; }
+    if (threadIdx.x == 0) s_count = 0u;
     __syncthreads();
+    const ShadeAcc A = {s_grad, s_keys, s_vals, &s_count};
     const size_t HW = (size_t)H * W;
+    unsigned flushed_at = 0u;                              // value of the (never reset) entry counter at the last flush
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int x_ = (t % tiles_x) * 64 + (threadIdx.x & 63), y_ = (t / tiles_x) * (MRGS_SHADE_BWD_THREADS / 64) + (threadIdx.x >> 6);
         const bool valid = x_ < W && y_ < H;    // out-of-image lanes stay alive (the texel scatter is wave-convergent)
@@ -453,7 +568,7 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
         }
         f3 g_rn;
         float g_level;
-        env_fetch_bwd(m, fu, p.rn, s, tp, gL, g_rn, g_level, s_grad);
+        env_fetch_bwd<false>(m, fu, p.rn, s, tp, gL, g_rn, g_level);
         // safe_normalize backward (the 1e-20 clamp never binds for finite normals)
         const float rg = dot3(p.rn, g_rn);
         const f3 g_r = mk((g_rn.x - p.rn.x * rg) / p.rlen, (g_rn.y - p.rn.y * rg) / p.rlen, (g_rn.z - p.rn.z * rg) / p.rlen);
@@ -471,9 +586,18 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
             g_refl[pix] = gm;
             g_rough[pix] = g_rough_v;
         }
+        env_scatter_tile(m, A, s, tp, gL);
+        // between tiles: a hash table more than half full goes out
+        __syncthreads();
+        const unsigned taken = s_count;                    // same value in every thread: entries are only taken before the barrier above
+        if (taken - flushed_at > MRGS_SHADE_HASH_SIZE / 2) {
+            acc_flush_hash(m, A, MRGS_SHADE_BWD_THREADS);
+            flushed_at = taken;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // flush the LDS-resident levels into one of the level's global copies (untouched texels are skipped)
+    // flush: the hash table, then the LDS-resident levels into one of the level's global copies (untouched texels are skipped)
+    acc_flush_hash(m, A, MRGS_SHADE_BWD_THREADS);
     for (int l = 0; l < m.n; l++) {
         if (m.lds_off[l] < 0 || m.grad[l] == nullptr) continue;
         const int n = 6 * m.res[l] * m.res[l] * 3;
@@ -587,11 +711,11 @@ __global__ void __launch_bounds__(256) cubemap_filter_build_kernel(int N, int ki
 #define MRGS_SPMV_ROUNDS 4
 #endif
 template <int G, typename IDX, typename WT>
-__global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
-                                                        const WT* __restrict__ val, const float* __restrict__ row_scale,
-                                                        const float* __restrict__ x, float* __restrict__ y)
+__device__ __forceinline__ void csr_spmv3_body(int block, int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
+                                               const WT* __restrict__ val, const float* __restrict__ row_scale, const float* __restrict__ x,
+                                               float* __restrict__ y)
 {
-    const int gid = (blockIdx.x * 256 + threadIdx.x) / G, sub = threadIdx.x % G;
+    const int gid = (block * 256 + threadIdx.x) / G, sub = threadIdx.x % G;
     const int r = min(gid, nrows - 1);
     const uint32_t a = row_ptr[r], b = gid < nrows ? row_ptr[r + 1] : a;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -629,6 +753,37 @@ __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_
     }
 }
 
+template <int G, typename IDX, typename WT>
+__global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
+                                                        const WT* __restrict__ val, const float* __restrict__ row_scale,
+                                                        const float* __restrict__ x, float* __restrict__ y)
+{
+    csr_spmv3_body<G, IDX, WT>((int)blockIdx.x, nrows, row_ptr, col, val, row_scale, x, y);
+}
+
+// Several independent SpMVs in ONE launch (the levels of the environment prefilter: four launches of 9-18 us each were mostly the
+// latency of streaming each matrix with a fraction of the chip; together the matrices stream with every wave slot busy).  A workgroup
+// finds its product from a table in the kernel arguments (wave-uniform scan) and runs the body of its storage format.
+struct SpmvSeg { int nrows, fmt, first_block, pad; const uint32_t* row_ptr; const void* col; const void* val; const float* row_scale; const float* x; float* y; };
+struct SpmvBatch { int n; int total_blocks; SpmvSeg seg[MRGS_SPMV_MAX_BATCH]; };
+__global__ void __launch_bounds__(256) csr_spmv3_batched_kernel(SpmvBatch B)
+{
+    int i = 0;
+    for (int k = 1; k < B.n; ++k) i = ((int)blockIdx.x >= B.seg[k].first_block) ? k : i;
+    const SpmvSeg& S = B.seg[i];
+    const int blk = (int)blockIdx.x - S.first_block;
+    switch (S.fmt) {   // bit 2: 64 lanes per row (else 4); bit 1: 32-bit column indices (else 16); bit 0: fp32 weights (else 16-bit fixed point)
+    case 0: csr_spmv3_body<4, uint16_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
+    case 1: csr_spmv3_body<4, uint16_t, float>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
+    case 2: csr_spmv3_body<4, uint32_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
+    case 3: csr_spmv3_body<4, uint32_t, float>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
+    case 4: csr_spmv3_body<64, uint16_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
+    case 5: csr_spmv3_body<64, uint16_t, float>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
+    case 6: csr_spmv3_body<64, uint32_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
+    default: csr_spmv3_body<64, uint32_t, float>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
+    }
+}
+
 // 2x2 box mip of a [6, N, N, 3] cubemap (cubemap_mip.forward, scene/light_utils.py:68-69)
 __global__ void __launch_bounds__(256) cubemap_mip_fwd_kernel(int Nout, const float* __restrict__ in, float* __restrict__ out)
 {
@@ -660,6 +815,36 @@ __global__ void __launch_bounds__(256) cubemap_mip_bwd_kernel(int N, const float
             if (tp.w[q] != 0.f) a += tp.w[q] * dout[(size_t)tp.idx[q] * 3 + c];
         g_fine[(size_t)t * 3 + c] += 0.25f * a;
     }
+}
+
+// The whole box-mip chain below one level in ONE launch (cubemap_mip.forward applied `steps` <= 3 times, scene/light.py:74-76): a
+// thread owns one channel of one texel of the coarsest level and averages its 2^steps x 2^steps block bottom-up, writing every level on the
+// way -- the same 2x2 sums in the same order as the level-by-level kernel above, so the values are bit-identical to it.
+template <int LVL>
+__device__ __forceinline__ float mip_block(const float* __restrict__ in, int N0, int s, int y, int x, int c, float* const* outs)
+{
+    if constexpr (LVL == 0) {
+        return in[((size_t)(s * N0 + y) * N0 + x) * 3 + c];
+    } else {
+        const float p00 = mip_block<LVL - 1>(in, N0, s, 2 * y, 2 * x, c, outs), p01 = mip_block<LVL - 1>(in, N0, s, 2 * y, 2 * x + 1, c, outs);
+        const float p10 = mip_block<LVL - 1>(in, N0, s, 2 * y + 1, 2 * x, c, outs), p11 = mip_block<LVL - 1>(in, N0, s, 2 * y + 1, 2 * x + 1, c, outs);
+        const float v = 0.25f * (p00 + p01 + p10 + p11);
+        const int N = N0 >> LVL;
+        outs[LVL - 1][((size_t)(s * N + y) * N + x) * 3 + c] = v;
+        return v;
+    }
+}
+struct MipOuts { float* o[3]; };
+__global__ void __launch_bounds__(256) cubemap_mip_chain_fwd_kernel(int N0, int steps, const float* __restrict__ in, MipOuts outs)
+{
+    const int Nc = N0 >> steps;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 6 * Nc * Nc * 3) return;
+    const int c = i % 3, x = (i / 3) % Nc, y = (i / (3 * Nc)) % Nc, s = i / (3 * Nc * Nc);
+    float* const o[3] = {outs.o[0], outs.o[1], outs.o[2]};
+    if (steps == 1) mip_block<1>(in, N0, s, y, x, c, o);
+    else if (steps == 2) mip_block<2>(in, N0, s, y, x, c, o);
+    else mip_block<3>(in, N0, s, y, x, c, o);
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------
@@ -796,6 +981,68 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
         else { if (val_bytes == 2) SPMV(4, uint32_t, uint16_t); else SPMV(4, uint32_t, float); }
     }
 #undef SPMV
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream)
+{
+    if (!descs || n < 1 || n > MRGS_SPMV_MAX_BATCH) return MRGS_E_BAD_ARG;
+    SpmvBatch B;
+    B.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const MrgsSpmvDesc& d = descs[i];
+        if (d.nrows < 1 || !d.row_ptr || !d.col || !d.val || !d.x || !d.y || (d.col_bytes != 2 && d.col_bytes != 4) || (d.val_bytes != 2 && d.val_bytes != 4) ||
+            (d.val_bytes == 2 && !d.row_scale))
+            return MRGS_E_BAD_ARG;
+        const bool wide = d.lanes_per_row >= 64;
+        SpmvSeg& S = B.seg[i];
+        S.nrows = d.nrows;
+        S.fmt = (wide ? 4 : 0) | (d.col_bytes == 4 ? 2 : 0) | (d.val_bytes == 4 ? 1 : 0);
+        S.first_block = blocks;
+        S.pad = 0;
+        S.row_ptr = d.row_ptr; S.col = d.col; S.val = d.val; S.row_scale = d.row_scale; S.x = d.x; S.y = d.y;
+        blocks += (int)(((size_t)d.nrows * (wide ? 64 : 4) + 255) / 256);
+    }
+    B.total_blocks = blocks;
+    hipLaunchKernelGGL(csr_spmv3_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_cubemap_mip_chain_forward(int32_t res_in, int32_t n_steps, const float* in, float* const* outs, void* stream)
+{
+    if (res_in < 2 || n_steps < 1 || !in || !outs || (res_in >> n_steps) < 1 || ((res_in >> n_steps) << n_steps) != res_in) return MRGS_E_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const float* src = in;
+    int res = res_in, done = 0;
+    while (done < n_steps) {                                   // three levels per launch
+        const int steps = n_steps - done < 3 ? n_steps - done : 3;
+        MipOuts o = {{nullptr, nullptr, nullptr}};
+        for (int k = 0; k < steps; ++k) {
+            if (!outs[done + k]) return MRGS_E_BAD_ARG;
+            o.o[k] = outs[done + k];
+        }
+        const int Nc = res >> steps, n = 6 * Nc * Nc * 3;
+        hipLaunchKernelGGL(cubemap_mip_chain_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, res, steps, src, o);
+        src = outs[done + steps - 1];
+        res = Nc;
+        done += steps;
+    }
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_cubemap_mip_chain_backward(int32_t res0, int32_t n_levels, float* const* g, void* stream)
+{
+    if (res0 < 2 || n_levels < 1 || n_levels > MRGS_MAX_MIPS || !g || (res0 >> (n_levels - 1)) < 1) return MRGS_E_BAD_ARG;
+    for (int k = 0; k < n_levels; ++k) if (!g[k]) return MRGS_E_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // One launch per level, coarse to fine (3 x 6.7 us for 128..16).  Measured and dropped: the levels up to 64 x 64 in ONE workgroup behind
+    // barriers (152 us: 24 576 texels x the cross-face tap arithmetic on one CU) and one launch in which every level-0 texel gathers down
+    // the pyramid (84 us: 21 tap set-ups per texel, 12.8 k instructions) -- the tap set-up, not the launches, is the cost.
+    for (int k = n_levels - 2; k >= 0; --k) {
+        const int N = res0 >> k, n = 6 * N * N;
+        hipLaunchKernelGGL(cubemap_mip_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, N, g[k + 1], g[k]);
+    }
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -186,14 +186,15 @@ class _SurfelMaps(torch.autograd.Function):
         rn, sd = torch.empty((3, H, W), **o), torch.empty((1, H, W), **o)
         sn = torch.empty((3, H, W), **o) if want_surf_normal else None
         nm = torch.empty((H, W, 3), **o) if want_normal_map else None
+        ra_rd = torch.empty((2, 1, H, W), **o)      # the plain slices allmap[1:2] / allmap[6:7] of the reference, written by the same kernel
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), st))
+            _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), _p(ra_rd[0]), _p(ra_rd[1]), st))
         ctx.save_for_backward(allmap)
         ctx.fr = fr
         outs = (rn, sd, sn if sn is not None else rn.new_empty(0), nm if nm is not None else rn.new_empty(0))
         ctx.mark_non_differentiable(*[t for t in outs[2:] if t.numel() == 0])
-        return (*outs, allmap[1:2].clone(), allmap[6:7].clone())
+        return (*outs, ra_rd[0], ra_rd[1])
 
     @staticmethod
     def backward(ctx, g_rn, g_sd, g_sn, g_nm, g_ra, g_rd):
@@ -262,10 +263,21 @@ def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
         prefiltered=False, debug=getattr(pipe, "debug", False))
 
 
+_ZERO_POINTS = {}
+
+
 def _screenspace_points(pc):
     """screenspace_points of the reference (gaussian_renderer/__init__.py:229-233): a zero tensor whose .grad receives the
     2D-mean gradients.  A leaf here (the reference adds 0 and calls retain_grad(): same .grad, one kernel more)."""
-    return torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True)
+    xyz = pc.get_xyz
+    key = (xyz.device, xyz.shape[0], xyz.dtype)
+    z = _ZERO_POINTS.get(key)
+    if z is None:
+        if len(_ZERO_POINTS) > 8:
+            _ZERO_POINTS.clear()
+        z = _ZERO_POINTS[key] = torch.zeros_like(xyz)
+    # a new leaf over the shared zeros (nothing reads or writes its values: the rasterizer only routes a gradient to it): no fill per view
+    return z.detach().requires_grad_(True)
 
 
 def get_distance(scaling_modifier, means3D, viewpoint_camera, pc):
@@ -324,7 +336,8 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
         scales=scales, rotations=rotations, cov3D_precomp=None)
     rend_distance = rendered_features[8:9] if flag != "2dgs" else None
-    rendered_features = rendered_features[:8]
+    if rendered_features.shape[0] != 8:          # (a slice of the full range is still an autograd node: a zero fill and a copy of 8 maps)
+        rendered_features = rendered_features[:8]
 
     base_color = rendered_image
     refl_strength, roughness_map = rendered_features[:1], rendered_features[1:2]

@@ -493,7 +493,12 @@ def test_empty_model_and_forward_only_state(gpu_device):
         assert torch.equal(with_grad[k].detach(), no_grad[k]), k
     assert float((with_grad["wet"].detach() - no_grad["wet"]).abs().max()) <= 1e-5 * float(no_grad["wet"].abs().max())   # summed with atomics
     # the autograd node of the no-grad trace kept nothing; the one with gradients kept the full state
-    state = with_grad["rgb"].grad_fn.saved_tensors[-1]
+    def trace_node(t):
+        fn = t.grad_fn
+        while not hasattr(fn, "saved_tensors"):      # the tracer reshapes its outputs to the rays' shape: a view node sits on top
+            fn = fn.next_functions[0][0]
+        return fn
+    state = trace_node(with_grad["rgb"]).saved_tensors[-1]
     assert state.numel() == full
     # C level: backward on a record-less state == backward on the recorded one
     w = torch.randn(2048, 3, generator=torch.Generator().manual_seed(5)).to(gpu_device)
@@ -508,7 +513,7 @@ def test_empty_model_and_forward_only_state(gpu_device):
         walked, Lw = _hip_trace(gpu_device, sc, colors, others, o, d, bg, need_grad=True)
     finally:
         st._lib.lib().mrgs_surfel_trace_state_floats = keep
-    assert walked["rgb"].grad_fn.saved_tensors[-1].numel() == small
+    assert trace_node(walked["rgb"]).saved_tensors[-1].numel() == small
     (walked["rgb"] * w).sum().backward()
     for k, ref in replayed.items():
         a = Lw[k].grad
