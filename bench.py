@@ -328,6 +328,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    issued = time.perf_counter() - t0        # the host is done queueing (diagnostic: close to `elapsed` = the step is bound by the host's launches)
     fence()
     elapsed = time.perf_counter() - t0
     times = MrgsKernelTimes()
@@ -447,6 +448,7 @@ def main():
         "metric": "full-render fwd+bwd views/sec at 800x800/300k surfels; grad max-rel-err vs ref",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4),
+        "host_issue_ms_per_step": round(1000.0 * issued / args.steps, 4),
         "cold_ms_per_step": round(cold_fenced, 4), "warm_ms_per_step_fenced": round(warm_fenced, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "P": P, "H": H, "W": W, "S": S, "sh_degree": 3, "num_rendered": int(state["R"]),

@@ -124,6 +124,21 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
                            void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
                            float* out_color, float* out_feature, float* out_others, int64_t* num_rendered_host, void* stream);
 
+/* The same call in two halves, for callers that have more work to queue behind the rasterizer before they need the count (a renderer
+ * queues its per-pixel kernels; the host never sits between the tile scan and the blend): _begin queues both phases and returns at
+ * once, _finish waits until the count has reached the host and reports it -- MRGS_OK, or MRGS_E_WORKSPACE exactly as above (everything
+ * computed from the outputs is then undefined as well and the caller redoes the view).  A ticket is valid on the host thread that
+ * began it until MRGS_TICKET_RING (16) later begins on the same device; a stale one returns MRGS_E_BAD_ARG. */
+typedef struct MrgsRasterTicket {
+    int32_t device, slot;
+    uint64_t seq;
+    int64_t capacity_pairs;
+} MrgsRasterTicket;
+int mrgs_rasterize_forward_begin(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                                 void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
+                                 float* out_color, float* out_feature, float* out_others, MrgsRasterTicket* ticket, void* stream);
+int mrgs_rasterize_forward_finish(const MrgsRasterTicket* ticket, int64_t* num_rendered_host);
+
 /* Gradient outputs of mrgs_rasterize_backward, the tuple returned by RasterizeGaussiansBackwardCUDA
  * (rasterize_points.cu:146-252): all fully written by the call (no pre-zeroing needed). */
 typedef struct MrgsRasterGrads {
@@ -514,7 +529,7 @@ const char* mrgs_last_hip_error(void);
 const char* mrgs_version(void);
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 3
+#define MRGS_ABI_VERSION 4
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

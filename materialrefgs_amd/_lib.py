@@ -59,6 +59,10 @@ class MrgsShadeFrame(ctypes.Structure):
                 ("roughness", MrgsStridedMap), ("lut", c_void_p), ("lut_res", c_int32)]
 
 
+class MrgsRasterTicket(ctypes.Structure):
+    _fields_ = [("device", c_int32), ("slot", c_int32), ("seq", ctypes.c_uint64), ("capacity_pairs", c_int64)]
+
+
 class MrgsSpmvDesc(ctypes.Structure):
     _fields_ = [("nrows", c_int32), ("lanes_per_row", c_int32), ("col_bytes", c_int32), ("val_bytes", c_int32), ("row_ptr", c_void_p),
                 ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p)]
@@ -112,6 +116,10 @@ SYMBOLS = {
     "mrgs_rasterize_forward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_size_t,
                                               c_void_p, c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               ctypes.POINTER(c_int64), c_void_p]),
+    "mrgs_rasterize_forward_begin": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_size_t,
+                                                    c_void_p, c_size_t, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    ctypes.POINTER(MrgsRasterTicket), c_void_p]),
+    "mrgs_rasterize_forward_finish": (ctypes.c_int, [ctypes.POINTER(MrgsRasterTicket), ctypes.POINTER(c_int64)]),
     "mrgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                ctypes.POINTER(MrgsRasterGrads), c_void_p]),
@@ -191,7 +199,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 3   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 4   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

@@ -339,28 +339,31 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
 }
 
 namespace {
-// pinned, device-mapped landing slot + event for the asynchronous num_rendered read-back of mrgs_rasterize_forward (one per host thread:
-// the call waits for its own copy before it returns)
-struct ReadbackSlot {
-    uint32_t* host = nullptr;
-    uint32_t* dev = nullptr;    // device address of the same pinned words
-    hipEvent_t ev = nullptr;
-};
-// one slot per (host thread, device): the pinned words are mapped into the device that allocated them and the event belongs to it
+// pinned, device-mapped landing slots + events for the num_rendered read-back of mrgs_rasterize_forward[_begin]: a ring per (host thread,
+// device) -- the pinned words are mapped into the device that allocated them and the events belong to it.  A ticket names its slot and the
+// ring's sequence number at its begin; MRGS_TICKET_RING later begins reuse the slot and the ticket is stale.
 #define MRGS_MAX_DEVICES 64
-static thread_local ReadbackSlot g_slots[MRGS_MAX_DEVICES];
+#define MRGS_TICKET_RING 16
+struct ReadbackRing {
+    uint32_t* host = nullptr;   // MRGS_TICKET_RING x 16 words
+    uint32_t* dev = nullptr;    // device address of the same pinned words
+    hipEvent_t ev[MRGS_TICKET_RING] = {};
+    uint64_t seq[MRGS_TICKET_RING] = {};
+    uint64_t next = 1;
+};
+static thread_local ReadbackRing g_rings[MRGS_MAX_DEVICES];
 }   // namespace
 
-int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
-                           void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
-                           float* out_color, float* out_feature, float* out_others, int64_t* num_rendered_host, void* stream_)
+int mrgs_rasterize_forward_begin(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                                 void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
+                                 float* out_color, float* out_feature, float* out_others, MrgsRasterTicket* ticket, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = check_cfg(cfg, in);
     if (rc) return rc;
-    if (!num_rendered_host || !out_color || !out_others || (cfg->S > 0 && !out_feature) || !img_ws) return MRGS_E_BAD_ARG;
-    *num_rendered_host = 0;
-    if (cfg->P == 0) return zero_outputs(cfg, out_color, out_feature, out_others, stream);
+    if (!ticket || !out_color || !out_others || (cfg->S > 0 && !out_feature) || !img_ws) return MRGS_E_BAD_ARG;
+    ticket->device = -1; ticket->slot = -1; ticket->seq = 0; ticket->capacity_pairs = capacity_pairs;
+    if (cfg->P == 0) return zero_outputs(cfg, out_color, out_feature, out_others, stream);     // (device < 0: the count is 0)
     if (!geom_ws || !radii || !binning_ws || capacity_pairs < 1 || capacity_pairs >= (1ll << 30)) return MRGS_E_BAD_ARG;
     MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
     if (geom_bytes < g.total) return MRGS_E_WORKSPACE;
@@ -370,23 +373,49 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
     int device = 0;
     HIP_TRY(hipGetDevice(&device));
     if (device < 0 || device >= MRGS_MAX_DEVICES) return MRGS_E_UNSUPPORTED;
-    ReadbackSlot& g_slot = g_slots[device];
-    if (!g_slot.host) {
-        HIP_TRY(hipHostMalloc((void**)&g_slot.host, 64, hipHostMallocMapped | hipHostMallocPortable));
-        HIP_TRY(hipHostGetDevicePointer((void**)&g_slot.dev, g_slot.host, 0));
-        HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming));
+    ReadbackRing& ring = g_rings[device];
+    if (!ring.host) {
+        HIP_TRY(hipHostMalloc((void**)&ring.host, MRGS_TICKET_RING * 64, hipHostMallocMapped | hipHostMallocPortable));
+        HIP_TRY(hipHostGetDevicePointer((void**)&ring.dev, ring.host, 0));
+        for (int i = 0; i < MRGS_TICKET_RING; ++i) HIP_TRY(hipEventCreateWithFlags(&ring.ev[i], hipEventDisableTiming));
     }
-    rc = enqueue_geom(cfg, in, g, radii, stream, g_slot.dev, g_slot.ev);
+    const int slot = (int)(ring.next % MRGS_TICKET_RING);
+    ring.seq[slot] = ring.next;
+    ticket->device = device; ticket->slot = slot; ticket->seq = ring.next++;
+    uint32_t* slot_dev = ring.dev + 16 * slot;
+    rc = enqueue_geom(cfg, in, g, radii, stream, slot_dev, ring.ev[slot]);
     if (rc) return rc;
     // phase 2 is queued without waiting for the count: its kernels read it from g.counters; the count (and the error flag of phase 1)
     // reaches the pinned host slot through a kernel -- the tile scan, or on the radix path the first kernel of phase 2 -- with no
     // copy-engine transfer in the middle of the stream
-    rc = enqueue_render(cfg, in, g, b, img, capacity_pairs, g.counters, out_color, out_feature, out_others, stream, g_slot.dev, g_slot.ev);
+    return enqueue_render(cfg, in, g, b, img, capacity_pairs, g.counters, out_color, out_feature, out_others, stream, slot_dev, ring.ev[slot]);
+}
+
+int mrgs_rasterize_forward_finish(const MrgsRasterTicket* ticket, int64_t* num_rendered_host)
+{
+    if (!ticket || !num_rendered_host) return MRGS_E_BAD_ARG;
+    *num_rendered_host = 0;
+    if (ticket->device < 0) return MRGS_OK;                          // empty model: nothing was queued behind a count
+    if (ticket->device >= MRGS_MAX_DEVICES || ticket->slot < 0 || ticket->slot >= MRGS_TICKET_RING) return MRGS_E_BAD_ARG;
+    ReadbackRing& ring = g_rings[ticket->device];
+    if (!ring.host || ring.seq[ticket->slot] != ticket->seq) return MRGS_E_BAD_ARG;      // another thread's ticket, or the slot was reused
+    HIP_TRY(hipEventSynchronize(ring.ev[ticket->slot]));
+    int rc = check_counters(ring.host + 16 * ticket->slot, num_rendered_host);
     if (rc) return rc;
-    HIP_TRY(hipEventSynchronize(g_slot.ev));
-    rc = check_counters(g_slot.host, num_rendered_host);
+    return *num_rendered_host > ticket->capacity_pairs ? MRGS_E_WORKSPACE : MRGS_OK;
+}
+
+int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,
+                           void* binning_ws, size_t binning_bytes, int64_t capacity_pairs, void* img_ws, int32_t* radii,
+                           float* out_color, float* out_feature, float* out_others, int64_t* num_rendered_host, void* stream_)
+{
+    if (!num_rendered_host) return MRGS_E_BAD_ARG;
+    *num_rendered_host = 0;
+    MrgsRasterTicket ticket;
+    int rc = mrgs_rasterize_forward_begin(cfg, in, geom_ws, geom_bytes, binning_ws, binning_bytes, capacity_pairs, img_ws, radii, out_color,
+                                          out_feature, out_others, &ticket, stream_);
     if (rc) return rc;
-    return *num_rendered_host > capacity_pairs ? MRGS_E_WORKSPACE : MRGS_OK;
+    return mrgs_rasterize_forward_finish(&ticket, num_rendered_host);
 }
 
 int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,

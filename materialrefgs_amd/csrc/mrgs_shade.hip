@@ -44,25 +44,21 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y
 // direction -> (face, u, v) with u,v in [-1,1]; inverse of cube_to_dir (scene/light_utils.py:24-31)
 struct FaceUV { int face; float u, v, inv_ma; int axis; float sgn; };
 __device__ __forceinline__ FaceUV dir_to_face(f3 d)
-{
+{   // branch-free (selects): the callers inline it up to eight times per pixel
     FaceUV r;
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    if (ax >= ay && ax >= az) {
-        r.axis = 0; r.sgn = d.x >= 0.f ? 1.f : -1.f; r.inv_ma = 1.0f / ax;
-        r.face = d.x >= 0.f ? 0 : 1;
-        r.u = (d.x >= 0.f ? -d.z : d.z) * r.inv_ma;
-        r.v = -d.y * r.inv_ma;
-    } else if (ay >= az) {
-        r.axis = 1; r.sgn = d.y >= 0.f ? 1.f : -1.f; r.inv_ma = 1.0f / ay;
-        r.face = d.y >= 0.f ? 2 : 3;
-        r.u = d.x * r.inv_ma;
-        r.v = (d.y >= 0.f ? d.z : -d.z) * r.inv_ma;
-    } else {
-        r.axis = 2; r.sgn = d.z >= 0.f ? 1.f : -1.f; r.inv_ma = 1.0f / az;
-        r.face = d.z >= 0.f ? 4 : 5;
-        r.u = (d.z >= 0.f ? d.x : -d.x) * r.inv_ma;
-        r.v = -d.y * r.inv_ma;
-    }
+    const bool mx = ax >= ay && ax >= az, my = !mx && ay >= az;
+    const float ma = mx ? ax : (my ? ay : az), mc = mx ? d.x : (my ? d.y : d.z);
+    const bool pos = mc >= 0.f;
+    r.axis = mx ? 0 : (my ? 1 : 2);
+    r.sgn = pos ? 1.f : -1.f;
+    r.inv_ma = 1.0f / ma;
+    r.face = 2 * r.axis + (pos ? 0 : 1);
+    // x-major: u = -+z, v = -y; y-major: u = x, v = +-z; z-major: u = +-x, v = -y
+    const float un = mx ? (pos ? -d.z : d.z) : (my ? d.x : (pos ? d.x : -d.x));
+    const float vn = my ? (pos ? d.z : -d.z) : -d.y;
+    r.u = un * r.inv_ma;
+    r.v = vn * r.inv_ma;
     return r;
 }
 __device__ __forceinline__ f3 face_to_dir(int s, float x, float y)
@@ -137,7 +133,25 @@ __device__ __forceinline__ float mip_level(const EnvMips& m, float r, float& dle
     return (c - hi) / (1.0f - hi) + n2;
 }
 
+struct __attribute__((aligned(4))) Tex3 { float x, y, z; };     // one texel: a 12-byte load at 4-byte alignment
 struct EnvSample { float L[3]; float dlev[3]; float du[2][3], dv[2][3]; int l0, l1; float f; bool lev_in; };
+
+// per-lane level -> its resolution / texels by a select chain over the (scalar) kernel arguments: indexing the by-value struct with a
+// lane-dependent level is a memory round trip of its own in front of the texel loads
+__device__ __forceinline__ int level_res(const EnvMips& m, int l)
+{
+    int r = m.res[0];
+#pragma unroll
+    for (int i = 1; i < MRGS_MAX_MIPS; i++) r = (l == i) ? m.res[i] : r;
+    return r;
+}
+__device__ __forceinline__ const float* level_tex(const EnvMips& m, int l)
+{
+    const float* p = m.tex[0];
+#pragma unroll
+    for (int i = 1; i < MRGS_MAX_MIPS; i++) p = (l == i) ? m.tex[i] : p;
+    return p;
+}
 
 // trilinear seamless cube fetch (pre-sigmoid); fills what the backward needs
 __device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, float level, bool use_mips, EnvSample& s, Taps tp[2])
@@ -149,23 +163,34 @@ __device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, fl
     s.l1 = min(s.l0 + 1, top);
     s.f = lc - (float)s.l0;
     float v[2][3];
+    // the taps of both levels first, then all eight 12-byte texel loads in flight together (unconditional: a missing corner tap has
+    // index 0 and weight 0 -- behind a condition every load waited for the one before)
+    const int res0 = level_res(m, s.l0), res1 = level_res(m, s.l1);
+    tp[0] = cube_taps(fu, res0);
+    tp[1] = cube_taps(fu, res1);
+    const float* tex0 = level_tex(m, s.l0);
+    const float* tex1 = level_tex(m, s.l1);
+    float t[2][4][3];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const Tex3 v3 = *reinterpret_cast<const Tex3*>((k == 0 ? tex0 : tex1) + (size_t)tp[k].idx[q] * 3);
+            t[k][q][0] = v3.x; t[k][q][1] = v3.y; t[k][q][2] = v3.z;
+        }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const int l = k == 0 ? s.l0 : s.l1;
-        const int res = m.res[l];
-        tp[k] = cube_taps(fu, res);
-        const float* tex = m.tex[l];
-        float t[4][3];
+        const int res = k == 0 ? res0 : res1;
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) t[q][c] = tp[k].w[q] != 0.f ? tex[(size_t)tp[k].idx[q] * 3 + c] : 0.f;
+            for (int c = 0; c < 3; c++) t[k][q][c] = tp[k].w[q] != 0.f ? t[k][q][c] : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            v[k][c] = tp[k].w[0] * t[0][c] + tp[k].w[1] * t[1][c] + tp[k].w[2] * t[2][c] + tp[k].w[3] * t[3][c];
+            v[k][c] = tp[k].w[0] * t[k][0][c] + tp[k].w[1] * t[k][1][c] + tp[k].w[2] * t[k][2][c] + tp[k].w[3] * t[k][3][c];
             // d value / d fx, d value / d fy (bilinear; the corner renormalisation is treated as constant)
-            s.du[k][c] = ((1.f - tp[k].wy) * (t[1][c] - t[0][c]) + tp[k].wy * (t[3][c] - t[2][c])) * 0.5f * (float)res * tp[k].norm;
-            s.dv[k][c] = ((1.f - tp[k].wx) * (t[2][c] - t[0][c]) + tp[k].wx * (t[3][c] - t[1][c])) * 0.5f * (float)res * tp[k].norm;
+            s.du[k][c] = ((1.f - tp[k].wy) * (t[k][1][c] - t[k][0][c]) + tp[k].wy * (t[k][3][c] - t[k][2][c])) * 0.5f * (float)res * tp[k].norm;
+            s.dv[k][c] = ((1.f - tp[k].wx) * (t[k][2][c] - t[k][0][c]) + tp[k].wx * (t[k][3][c] - t[k][1][c])) * 0.5f * (float)res * tp[k].norm;
         }
     }
 #pragma unroll
@@ -313,10 +338,10 @@ struct ShadeAcc {          // the workgroup's LDS accumulators
     unsigned* count;       // entries taken so far (never reset: the kernel remembers its value at the last flush)
 };
 
-// one merged contribution (the lane ends a run; key = level << 24 | texel) into the workgroup's accumulators
-__device__ __forceinline__ void acc_add(const EnvMips& m, const ShadeAcc& A, int lk, int idx, const float v[3])
+// one merged contribution (the lane ends a run; key = level << 24 | texel) into the workgroup's accumulators; loff = the level's
+// offset in the dense LDS copy or < 0
+__device__ __forceinline__ void acc_add(const EnvMips& m, const ShadeAcc& A, int lk, int loff, int idx, const float v[3])
 {
-    const int loff = m.lds_off[lk];
     if (loff >= 0) {
         float* a = A.dense + loff + idx * 3;
         atomicAdd(a, v[0]); atomicAdd(a + 1, v[1]); atomicAdd(a + 2, v[2]);
@@ -340,15 +365,20 @@ __device__ __forceinline__ void acc_add(const EnvMips& m, const ShadeAcc& A, int
     }
 }
 
-// the eight taps of one pixel's fetch: merged along the row, then accumulated (wave-convergent: every lane of the wave calls it)
-__device__ __forceinline__ void env_scatter_tile(const EnvMips& m, const ShadeAcc& A, const EnvSample& s, const Taps tp[2], const float gL[3])
+// the eight taps of one pixel's fetch: merged along the row, then accumulated (wave-convergent: every lane of the wave calls it).
+// grad_mask: bit l = level l takes gradients (scalar, built once per kernel: the per-lane level must not index the argument struct here)
+__device__ __forceinline__ void env_scatter_tile(const EnvMips& m, unsigned grad_mask, const ShadeAcc& A, const EnvSample& s, const Taps tp[2],
+                                                 const float gL[3])
 {
     const bool any = gL[0] != 0.f || gL[1] != 0.f || gL[2] != 0.f;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const float wk = k == 0 ? 1.f - s.f : s.f;
         const int lk = k == 0 ? s.l0 : s.l1;
-        const bool lev = any && wk != 0.f && m.grad[lk] != nullptr;
+        const bool lev = any && wk != 0.f && ((grad_mask >> lk) & 1u);
+        int loff = m.lds_off[0];
+#pragma unroll
+        for (int i = 1; i < MRGS_MAX_MIPS; i++) loff = (lk == i) ? m.lds_off[i] : loff;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float wq = wk * tp[k].w[q];
@@ -356,8 +386,12 @@ __device__ __forceinline__ void env_scatter_tile(const EnvMips& m, const ShadeAc
             const bool live = lev && tp[k].w[q] != 0.f;
             const unsigned key = live ? (((unsigned)lk << 24) | (unsigned)tp[k].idx[q]) : MRGS_SHADE_KEY_NONE;
             if (!live) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
+#ifdef MRGS_X_NO_MERGE
+            const bool last = true;
+#else
             const bool last = run_merge(key, v);
-            if (last && key != MRGS_SHADE_KEY_NONE) acc_add(m, A, lk, tp[k].idx[q], v);
+#endif
+            if (last && key != MRGS_SHADE_KEY_NONE) acc_add(m, A, lk, loff, tp[k].idx[q], v);
         }
     }
 }
@@ -453,8 +487,38 @@ __device__ __forceinline__ void lut_fetch(const float* __restrict__ lut, int lre
     }
 }
 
-__device__ __forceinline__ void shade_setup(const ShadeCam& cam, int x, int y, const Map& albedo, const Map& normal, const Map& alpha,
-                                            const Map& refl, const Map& rough, const float* __restrict__ lut, int lres, ShadePix& p)
+// the camera of a launch in scalar registers: K^-1, Camera.R (c2w rotation), the w2c translation and the camera centre -R T
+struct ShadeCamS { float Kinv[9], R[9], t[3], ro[3]; };
+__device__ __forceinline__ float sreg(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ ShadeCamS shade_cam_load(const ShadeCam& cam)
+{
+    ShadeCamS c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { c.Kinv[i] = cam.Kinv[i]; c.R[i] = sreg(cam.R[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; i++) c.t[i] = sreg(cam.T[i]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) c.ro[i] = -(c.R[3 * i] * c.t[0] + c.R[3 * i + 1] * c.t[1] + c.R[3 * i + 2] * c.t[2]);
+    return c;
+}
+
+// the per-pixel inputs of the shading, fetched in one go (nine independent loads in flight)
+struct ShadeIn { float n[3], rough, refl, alpha, albedo[3]; };
+__device__ __forceinline__ ShadeIn shade_load(int x, int y, const Map& albedo, const Map& normal, const Map& alpha, const Map& refl, const Map& rough)
+{
+    ShadeIn in;
+    const long long o = (long long)y * normal.sh + (long long)x * normal.sw;
+    in.n[0] = normal.p[o]; in.n[1] = normal.p[o + normal.sc]; in.n[2] = normal.p[o + 2 * normal.sc];
+    in.rough = rough.p[(long long)y * rough.sh + (long long)x * rough.sw];
+    in.refl = refl.p[(long long)y * refl.sh + (long long)x * refl.sw];
+    in.alpha = alpha.p[(long long)y * alpha.sh + (long long)x * alpha.sw];
+    const long long oa = (long long)y * albedo.sh + (long long)x * albedo.sw;
+#pragma unroll
+    for (int c = 0; c < 3; c++) in.albedo[c] = albedo.p[oa + c * albedo.sc];
+    return in;
+}
+
+__device__ __forceinline__ void shade_setup(const ShadeCamS& cam, int x, int y, const ShadeIn& in, const float* __restrict__ lut, int lres, ShadePix& p)
 {
     // sample_camera_rays (utils/refl_utils.py:54-73): pixel centres at integer coordinates
     const float fx_ = (float)x, fy_ = (float)y;
@@ -462,26 +526,22 @@ __device__ __forceinline__ void shade_setup(const ShadeCam& cam, int x, int y, c
                      cam.Kinv[6] * fx_ + cam.Kinv[7] * fy_ + cam.Kinv[8]);
     // Camera.R is stored transposed (c2w); the reference re-transposes it: world = (pc - T) @ R^T^T ... = c2w * (pc - T)
     const float* R = cam.R;
-    const f3 t = mk(cam.T[0], cam.T[1], cam.T[2]);
-    const f3 q = mk(pc.x - t.x, pc.y - t.y, pc.z - t.z);
+    const f3 q = mk(pc.x - cam.t[0], pc.y - cam.t[1], pc.z - cam.t[2]);
     const f3 pw = mk(R[0] * q.x + R[1] * q.y + R[2] * q.z, R[3] * q.x + R[4] * q.y + R[5] * q.z, R[6] * q.x + R[7] * q.y + R[8] * q.z);
-    const f3 ro = mk(-(R[0] * t.x + R[1] * t.y + R[2] * t.z), -(R[3] * t.x + R[4] * t.y + R[5] * t.z), -(R[6] * t.x + R[7] * t.y + R[8] * t.z));
-    f3 rd = mk(pw.x - ro.x, pw.y - ro.y, pw.z - ro.z);
+    f3 rd = mk(pw.x - cam.ro[0], pw.y - cam.ro[1], pw.z - cam.ro[2]);
     const float inv = 1.0f / sqrtf(dot3(rd, rd));
     rd = mk(rd.x * inv, rd.y * inv, rd.z * inv);
     p.wo = mk(-rd.x, -rd.y, -rd.z);
-    const long long o = (long long)y * normal.sh + (long long)x * normal.sw;
-    p.n = mk(normal.p[o], normal.p[o + normal.sc], normal.p[o + 2 * normal.sc]);
+    p.n = mk(in.n[0], in.n[1], in.n[2]);
     p.ndv = dot3(p.wo, p.n);                                    // reflection(), :95-98
     p.r = mk(2.f * p.n.x * p.ndv - p.wo.x, 2.f * p.n.y * p.ndv - p.wo.y, 2.f * p.n.z * p.ndv - p.wo.z);
     p.rlen = fmaxf(sqrtf(dot3(p.r, p.r)), 1e-20f);              // safe_normalize
     p.rn = mk(p.r.x / p.rlen, p.r.y / p.rlen, p.r.z / p.rlen);
-    p.rough = rough.p[(long long)y * rough.sh + (long long)x * rough.sw];
-    p.refl = refl.p[(long long)y * refl.sh + (long long)x * refl.sw];
-    p.alpha = alpha.p[(long long)y * alpha.sh + (long long)x * alpha.sw];
-    const long long oa = (long long)y * albedo.sh + (long long)x * albedo.sw;
+    p.rough = in.rough;
+    p.refl = in.refl;
+    p.alpha = in.alpha;
 #pragma unroll
-    for (int c = 0; c < 3; c++) p.albedo[c] = albedo.p[oa + c * albedo.sc];
+    for (int c = 0; c < 3; c++) p.albedo[c] = in.albedo[c];
     p.u_in = p.ndv >= 0.f && p.ndv <= 1.f;
     p.v_in = p.rough >= 0.f && p.rough <= 1.f;
     p.u = fminf(fmaxf(p.ndv, 0.f), 1.f);
@@ -496,8 +556,10 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
+    const ShadeCamS cs = shade_cam_load(cam);
+    const ShadeIn in = shade_load(x, y, albedo, normal, alpha, refl, rough);
     ShadePix p;
-    shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
+    shade_setup(cs, x, y, in, lut, lres, p);
     const FaceUV fu = dir_to_face(p.rn);
     float dl;
     const float level = mip_level(m, p.rough, dl);
@@ -518,8 +580,13 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
 // Persistent workgroups (one per CU, 12 waves): each keeps an LDS copy of the texel gradients of the coarse mip levels
 // (<= MRGS_SHADE_LDS_FLOATS floats: 32x32 and 16x16 cubemap levels = 90 KB) and a hash table for the finer ones (64 KB), walks
 // 64x12-pixel tiles of the image and flushes both at the end (see "texel-gradient accumulation" above).
+#ifndef MRGS_SHADE_BWD_THREADS
 #define MRGS_SHADE_BWD_THREADS 768
+#endif
 #define MRGS_SHADE_LDS_FLOATS 23552
+#ifndef MRGS_SHADE_FLUSH_EVERY
+#define MRGS_SHADE_FLUSH_EVERY 1
+#endif
 __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_kernel(
     EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha, Map refl, Map rough, const float* __restrict__ lut, int lres,
     const float* __restrict__ g_specular, const float* __restrict__ g_direct, const float* __restrict__ g_weight,
@@ -537,28 +604,42 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
     const ShadeAcc A = {s_grad, s_keys, s_vals, &s_count};
     const size_t HW = (size_t)H * W;
     unsigned flushed_at = 0u;                              // value of the (never reset) entry counter at the last flush
+    int since_check = 0;
+    const ShadeCamS cs = shade_cam_load(cam);
+    unsigned grad_mask = 0u;
+#pragma unroll
+    for (int i = 0; i < MRGS_MAX_MIPS; i++) grad_mask |= (i < m.n && m.grad[i] != nullptr) ? (1u << i) : 0u;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int x_ = (t % tiles_x) * 64 + (threadIdx.x & 63), y_ = (t / tiles_x) * (MRGS_SHADE_BWD_THREADS / 64) + (threadIdx.x >> 6);
         const bool valid = x_ < W && y_ < H;    // out-of-image lanes stay alive (the texel scatter is wave-convergent)
         const int x = min(x_, W - 1), y = min(y_, H - 1);
+        const size_t pix = (size_t)y * W + x;
+        // every input of the pixel first: the maps and the upstream gradients are independent loads
+        const ShadeIn in = shade_load(x, y, albedo, normal, alpha, refl, rough);
+        float gs_[3], gd_[3], gw_[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            gs_[c] = (valid && g_specular) ? g_specular[c * HW + pix] : 0.f;
+            gd_[c] = (valid && g_direct) ? g_direct[c * HW + pix] : 0.f;
+            gw_[c] = (valid && g_weight) ? g_weight[pix * 3 + c] : 0.f;
+        }
         ShadePix p;
-        shade_setup(cam, x, y, albedo, normal, alpha, refl, rough, lut, lres, p);
+        shade_setup(cs, x, y, in, lut, lres, p);
         const FaceUV fu = dir_to_face(p.rn);
         float dl;
         const float level = mip_level(m, p.rough, dl);
         EnvSample s;
         Taps tp[2];
         env_fetch(m, fu, level, true, s, tp);
-        const size_t pix = (size_t)y * W + x;
         float gL[3], ga = 0.f, gm = 0.f, gfg0 = 0.f, gfg1 = 0.f, galb[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float light = sigmoidf(s.L[c]);
             const float base = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
             const float wgt = base * p.fg[0] + p.fg[1];
-            const float gs = (valid && g_specular) ? g_specular[c * HW + pix] : 0.f;
-            const float gd = ((valid && g_direct) ? g_direct[c * HW + pix] : 0.f) + gs * p.alpha * wgt;
-            const float gw = ((valid && g_weight) ? g_weight[pix * 3 + c] : 0.f) + gs * light * p.alpha;
+            const float gs = gs_[c];
+            const float gd = gd_[c] + gs * p.alpha * wgt;
+            const float gw = gw_[c] + gs * light * p.alpha;
             ga += gs * light * wgt;
             gL[c] = gd * light * (1.f - light);
             galb[c] = gw * p.refl * p.fg[0];
@@ -586,8 +667,10 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
             g_refl[pix] = gm;
             g_rough[pix] = g_rough_v;
         }
-        env_scatter_tile(m, A, s, tp, gL);
+        env_scatter_tile(m, grad_mask, A, s, tp, gL);
         // between tiles: a hash table more than half full goes out
+        if (++since_check < MRGS_SHADE_FLUSH_EVERY) continue;
+        since_check = 0;
         __syncthreads();
         const unsigned taken = s_count;                    // same value in every thread: entries are only taken before the barrier above
         if (taken - flushed_at > MRGS_SHADE_HASH_SIZE / 2) {

@@ -8,13 +8,15 @@ allmap f32[7,H,W])`, same gradient routing.  The native side is libmrgs.so (incl
 pybind `_C` module; there is no CPU or PyTorch fallback.
 """
 import ctypes
+import functools
+import threading
 from typing import NamedTuple
 
 import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
+from ._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs, MrgsRasterTicket
 
 
 _PAIR_GUESS = {}   # (device index, P, H, W) -> pair capacity to try first (previous count of that configuration + 25 %)
@@ -26,6 +28,7 @@ _PAIR_GUESS_MAX = 64
 _WORK_HINTS = {}
 _NO_HINT = bool(int(__import__("os").environ.get("MRGS_NO_WORK_HINT", "0")))   # developer switch for A/B timing
 _NO_PREPARE = bool(int(__import__("os").environ.get("MRGS_NO_PREPARE_BWD", "0")))   # developer switch: the backward orders / clears by itself
+_NO_DEFER = bool(int(__import__("os").environ.get("MRGS_NO_DEFER", "0")))   # developer switch: render functions wait for the pair count inside the rasterizer call
 _WORK_HINTS_MAX = 2048
 
 
@@ -132,6 +135,107 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
     return cfg, inp
 
 
+class RasterWorkspaceOverflow(RuntimeError):
+    """The pair count of a begun render did not fit the workspace carved from the guess: its outputs are undefined."""
+
+    def __init__(self, num_rendered):
+        super().__init__(f"libmrgs: {num_rendered} (tile, surfel) pairs did not fit the binning workspace sized from the previous view")
+        self.num_rendered = num_rendered
+
+
+_DEFER = threading.local()
+
+
+def _note_count(guess_key, num_rendered, hint_settings, dev):
+    """Bookkeeping once a view's pair count is known: the next view's workspace guess, this camera's work hint."""
+    if guess_key not in _PAIR_GUESS and len(_PAIR_GUESS) >= _PAIR_GUESS_MAX:
+        _PAIR_GUESS.pop(next(iter(_PAIR_GUESS)))
+    _PAIR_GUESS[guess_key] = max(int(num_rendered * 1.25) + 65536, 1)
+    if hint_settings is not None:
+        _work_hint(hint_settings, dev, count_visit=True)   # this camera's hint now holds measured work
+
+
+class _PendingCount:
+    """The pair count of a render begun with mrgs_rasterize_forward_begin.  finish() waits for it (once), does the bookkeeping and
+    raises RasterWorkspaceOverflow when the count did not fit; `ctx` (the autograd node of the render) gets its num_rendered then."""
+
+    def __init__(self, ticket, guess_key, hint_settings, dev):
+        self.ticket, self.guess_key, self.hint_settings, self.dev = ticket, guess_key, hint_settings, dev
+        self.value, self.overflow, self.ctx = None, False, None
+
+    def finish(self):
+        global LAST_NUM_RENDERED
+        if self.value is None:
+            R = ctypes.c_int64(0)
+            rc = _lib.lib().mrgs_rasterize_forward_finish(ctypes.byref(self.ticket), ctypes.byref(R))
+            if rc != _lib.MRGS_E_WORKSPACE:
+                _lib.check(rc)
+            self.value, self.overflow = int(R.value), rc == _lib.MRGS_E_WORKSPACE
+            _note_count(self.guess_key, self.value, None if self.overflow else self.hint_settings, self.dev)
+            LAST_NUM_RENDERED = self.value
+            if self.ctx is not None:
+                self.ctx.num_rendered = self.value
+        if self.overflow:
+            raise RasterWorkspaceOverflow(self.value)
+        return self.value
+
+
+class deferred_count:
+    """with deferred_count() as box: ... -- rasterizer calls inside only BEGIN their render (nothing on the host waits for the tile scan);
+    the caller queues whatever follows and calls box.finish() afterwards, which waits for the counts and raises RasterWorkspaceOverflow
+    if one did not fit (everything computed from that render is then undefined: redo the view outside the context).  Nested contexts
+    share the outermost box.  The first view of a (device, P, H, W) has no guess yet and runs the two-phase path at once."""
+
+    def __init__(self):
+        self.pending, self.outer = [], None
+
+    def __enter__(self):
+        self.outer = getattr(_DEFER, "box", None)
+        if self.outer is None:
+            _DEFER.box = self
+            return self
+        return self.outer
+
+    def __exit__(self, *exc):
+        if self.outer is None:
+            _DEFER.box = None
+        return False
+
+    def finish(self):
+        if self.outer is not None:            # an inner context: the outermost one finishes
+            return
+        pending, self.pending = self.pending, []
+        first = None
+        for p in pending:                     # every count is collected (bookkeeping) before the first overflow is reported
+            try:
+                p.finish()
+            except RasterWorkspaceOverflow as ex:
+                first = first or ex
+        if first is not None:
+            raise first
+
+
+def deferred_raster_count(render_fn):
+    """Decorator for the render functions: rasterizer counts are collected after the whole view has been queued; a view whose pair
+    count outgrew the guess is rendered again (synchronously sized)."""
+    if _NO_DEFER:
+        return render_fn
+
+    @functools.wraps(render_fn)
+    def wrapper(*args, **kw):
+        dc = deferred_count()
+        with dc:
+            out = render_fn(*args, **kw)
+        if dc.outer is not None:              # called from inside another render function: that one collects the counts
+            return out
+        try:
+            dc.finish()
+        except RasterWorkspaceOverflow:
+            return render_fn(*args, **kw)     # the guess is refreshed: the one-call path fits now (or the exact two-phase path runs)
+        return out
+    return wrapper
+
+
 def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
                               sh_rest=None, prepare_backward=False):
     """Counterpart of `_C.rasterize_gaussians` (rasterize_points.cu:41-144).  prepare_backward: also allocate the backward's gradient-row
@@ -166,33 +270,36 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         guess_key = (dev.index, P, H, W)
         guess = _PAIR_GUESS.get(guess_key)
         pairs = None            # pair count the binning workspace is carved for (what the backward must be given)
+        box = getattr(_DEFER, "box", None)
         if guess is not None and P > 0:
             # one call, no host round trip in the middle of the GPU work: the workspace is sized from the previous call's
-            # count and the kernels take the actual count from device memory (include/mrgs.h, mrgs_rasterize_forward)
+            # count and the kernels take the actual count from device memory (include/mrgs.h, mrgs_rasterize_forward[_begin])
             pairs = guess
             binning = torch.empty((L.mrgs_binning_bytes(pairs),), dtype=torch.uint8, device=dev)
-            rc = L.mrgs_rasterize_forward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
-                                          pairs, _ptr(img), _ptr(radii), _ptr(color), _ptr(feature), _ptr(others), ctypes.byref(R), st)
-            if rc == _lib.MRGS_E_WORKSPACE:
-                pairs = None    # the guess was too small: phase 2 is redone below on an exactly sized workspace
-            else:
-                _lib.check(rc)
+            ticket = MrgsRasterTicket()
+            _lib.check(L.mrgs_rasterize_forward_begin(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
+                                                      pairs, _ptr(img), _ptr(radii), _ptr(color), _ptr(feature), _ptr(others), ctypes.byref(ticket), st))
+            pending = _PendingCount(ticket, guess_key, raster_settings if inp.work_hint else None, dev)
+            if box is not None:
+                # a renderer queues its own kernels behind the rasterizer first and asks for the count at its end (deferred_count)
+                box.pending.append(pending)
+                return (pending, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
+            try:
+                num_rendered = pending.finish()
+            except RasterWorkspaceOverflow as ex:
+                num_rendered, pairs = ex.num_rendered, None    # the guess was too small: phase 2 is redone below on an exactly sized workspace
         else:
             _lib.check(L.mrgs_rasterize_forward_geom(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(radii),
                                                      ctypes.byref(R), st))
-        num_rendered = int(R.value)
+            num_rendered = int(R.value)
         LAST_NUM_RENDERED = num_rendered
         if pairs is None:
             pairs = num_rendered
             binning = torch.empty((L.mrgs_binning_bytes(pairs),), dtype=torch.uint8, device=dev)
             _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
                                                        _ptr(img), pairs, _ptr(color), _ptr(feature), _ptr(others), st))
-        if P > 0:
-            if guess_key not in _PAIR_GUESS and len(_PAIR_GUESS) >= _PAIR_GUESS_MAX:
-                _PAIR_GUESS.pop(next(iter(_PAIR_GUESS)))
-            _PAIR_GUESS[guess_key] = max(int(num_rendered * 1.25) + 65536, 1)
-            if inp.work_hint:
-                _work_hint(raster_settings, dev, count_visit=True)   # this camera's hint now holds measured work
+            if P > 0:
+                _note_count(guess_key, num_rendered, raster_settings if inp.work_hint else None, dev)
     return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
 
 
@@ -257,6 +364,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.prepared_grad_ws = grad_ws       # cleared by the forward, queues of the backward set up: good for ONE backward
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        if isinstance(num_rendered, _PendingCount):      # begun inside deferred_count(): the count arrives with the box's finish()
+            ctx.num_rendered, num_rendered.ctx = None, ctx
         ctx.binning_pairs = binning_pairs   # pair count binningBuffer is carved for (>= num_rendered)
         ctx.save_for_backward(colors_precomp, features, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer, contrib, sh_rest)

@@ -22,7 +22,7 @@ from . import _lib
 from ._lib import MrgsMapsFrame, MrgsSurfelGrads, MrgsSurfelParams
 
 from .gs_utils import build_scaling_rotation, eval_sh, flip_align_view, linear_to_srgb, safe_normalize
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, deferred_raster_count
 from .shading import (EnvLight, get_full_color_volume, get_full_color_volume_indirect, get_specular_color_surfel,
                       shade_and_composite_surfel)
 
@@ -290,6 +290,7 @@ def get_distance(scaling_modifier, means3D, viewpoint_camera, pc):
     return (normal_cam * centre_cam).sum(-1).abs().unsqueeze(-1)
 
 
+@deferred_raster_count
 def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour).  flag "pgsr"
     (arguments/config.py:1): the plane distance of get_distance rides as the one feature channel and comes back as "rend_distance"
@@ -315,6 +316,7 @@ def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, o
     return out
 
 
+@deferred_raster_count
 def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None,
                   wo_render_img=False, normal_img_map=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:225-483: per-gaussian material channels (S = 8: refl 1, roughness 1, albedo 3, indirect 3)
@@ -377,6 +379,7 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     return out
 
 
+@deferred_raster_count
 def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:521-749: every gaussian is shaded on its own (per-gaussian normal, mirror direction, split-sum
     weight, environment lookups: utils/refl_utils.py:426-484) and the rasterizer blends the shaded colour (`colors_precomp =
@@ -523,6 +526,7 @@ def render_indirect(indirect_renderer, viewpoint_camera, pc, pipe, bg_color, nor
                                               start_from_first=True)
 
 
+@deferred_raster_count
 def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
                              opt=None, wo_render_img=False, normal_img_map=None):
     """gaussian_renderer/__init__.py:486-520: render_surfel, then the same surfels traced along every pixel's mirror ray
@@ -542,6 +546,7 @@ def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_c
     return results
 
 
+@deferred_raster_count
 def render_surfel_with_envgs_sep(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
                                  opt=None, wo_render_img=False, normal_img_map=None):
     """gaussian_renderer/envgs_renderer.py:771-807: as render_surfel_with_envgs, but the mirror rays see the separate ENVIRONMENT surfel
@@ -558,6 +563,7 @@ def render_surfel_with_envgs_sep(indirect_renderer, env, viewpoint_camera, pc, p
     return results
 
 
+@deferred_raster_count
 def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False,
                    opt=None, wo_render_img=False, normal_img_map=None, flag="pgsr"):
     """gaussian_renderer/envgs_renderer.py:461-715, the last training stage (train_refnerf.py:1501-1504): render_surfel's material

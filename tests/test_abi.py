@@ -62,12 +62,12 @@ def test_struct_size_guard():
     from materialrefgs_amd import _lib
     from materialrefgs_amd._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
     L = _lib.lib()
-    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 3
+    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 4
     assert ctypes.sizeof(MrgsRasterConfig) == 4 + 11 * 4          # struct_size + 6 ints + 3 floats + 2 ints
     assert ctypes.sizeof(MrgsRasterInputs) == 8 + 15 * 8          # struct_size + 12 pointers + work_hint, shs_rest, bwd_grad_ws
     assert ctypes.sizeof(MrgsRasterGrads) == 8 + 10 * 8
     hdr = open(os.path.join(ROOT, "include", "mrgs.h")).read()
-    assert "#define MRGS_ABI_VERSION 3" in hdr
+    assert "#define MRGS_ABI_VERSION 4" in hdr
 
     class OldInputs(ctypes.Structure):                           # the struct as INTEGRATION.md printed it in round 2: 14 pointers, no size
         _fields_ = [(n, ctypes.c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales", "rotations",
@@ -157,3 +157,17 @@ def test_shim_renders_through_libmrgs(gpu_device):
     inside = cf["rho3d"] <= 8.5
     assert abs(allmap[1].cpu().numpy()[inside] - cf["alpha"][inside]).max() < 3e-5
     assert contrib.shape == (1, 96, 128) and contrib.dtype == torch.int32 and radii.dtype == torch.int32
+
+
+def test_raster_ticket_guards():
+    """mrgs_rasterize_forward_finish without a GPU: the ticket of an empty model reports 0 pairs, a ticket this thread never began is refused."""
+    from materialrefgs_amd import _lib
+    from materialrefgs_amd._lib import MrgsRasterTicket
+    L = _lib.lib()
+    R = ctypes.c_int64(7)
+    t = MrgsRasterTicket(-1, -1, 0, 0)
+    assert L.mrgs_rasterize_forward_finish(ctypes.byref(t), ctypes.byref(R)) == 0 and R.value == 0
+    for bad in (MrgsRasterTicket(0, 3, 12345, 10), MrgsRasterTicket(0, 99, 1, 10), MrgsRasterTicket(1000, 0, 1, 10)):
+        assert L.mrgs_rasterize_forward_finish(ctypes.byref(bad), ctypes.byref(R)) == 1        # MRGS_E_BAD_ARG
+    assert L.mrgs_rasterize_forward_finish(None, ctypes.byref(R)) == 1
+    assert ctypes.sizeof(MrgsRasterTicket) == 24

@@ -262,3 +262,51 @@ def test_pgsr_flag_adds_the_plane_distance_channel(gpu_device):
         assert float((b["rend_distance"] - alone).abs().max()) < 2e-5 * max(1.0, float(alone.abs().max())), fn.__name__
         for k in ("render", "rend_alpha", "rend_normal", "surf_depth"):
             assert float((a[k] - b[k]).abs().max()) < 2e-6, (fn.__name__, k)
+
+
+@pytest.mark.gpu
+def test_deferred_pair_count_and_its_overflow(gpu_device):
+    """The render functions only BEGIN the rasterizer (mrgs_rasterize_forward_begin) and collect the pair count after the whole view has been
+    queued (rasterizer.deferred_raster_count).  A view whose count outgrows the workspace guessed from the previous view is rendered again:
+    same maps bit for bit, same gradients, the count reported and the guess refreshed."""
+    from types import SimpleNamespace
+    from materialrefgs_amd import rasterizer as rz
+    from materialrefgs_amd.renderer import render_surfel
+    from materialrefgs_amd.synthetic import make_surfel_model, orbit_camera
+    dev = gpu_device
+    P, H, W = 20_000, 200, 200
+    pc, env, leaves = make_surfel_model(P, H, dev, radius_px=3.0)
+    cam = orbit_camera(1, H, W).to(dev)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False, use_asg=False)
+    bg = torch.zeros(3, device=dev)
+    key = (dev.index, P, H, W)
+
+    def render():
+        for t in leaves:
+            t.grad = None
+        env.build_mips()
+        out = render_surfel(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+        out["render"].sum().backward()
+        return out["render"].detach().clone(), [t.grad.clone() for t in leaves], rz.LAST_NUM_RENDERED, out
+
+    rz._PAIR_GUESS.pop(key, None)
+    img0, g0, R0, _ = render()                        # no guess yet: two-phase path, count read in the middle
+    assert R0 > 0 and rz._PAIR_GUESS[key] >= R0
+    img1, g1, R1, out1 = render()                     # deferred: begun inside render_surfel, finished at its end
+    assert R1 == R0 and torch.equal(img0, img1)
+    assert out1["render"].grad_fn is not None
+    rz._PAIR_GUESS[key] = max(R0 // 3, 1)             # a guess that cannot hold the view
+    img2, g2, R2, _ = render()
+    assert R2 == R0 and torch.equal(img0, img2) and rz._PAIR_GUESS[key] >= R0
+    for a, b, c in zip(g0, g1, g2):
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-4 * scale and float((a - c).abs().max()) <= 1e-4 * scale      # (atomics: summation order)
+    # the context by hand: nothing waits inside, finish() reports the overflow
+    rz._PAIR_GUESS[key] = max(R0 // 3, 1)
+    from materialrefgs_amd.renderer import render_initial
+    with rz.deferred_count() as box:
+        render_initial(cam, pc, pipe, bg)
+        assert len(box.pending) == 1 and box.pending[0].value is None
+    with pytest.raises(rz.RasterWorkspaceOverflow):
+        box.finish()
+    assert rz._PAIR_GUESS[key] >= R0
