@@ -430,8 +430,8 @@ int mrgs_surfel_trace_forward(void* blob, int64_t n_surfels, int64_t n_rays, int
 int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, int32_t ray_width, const float* ray_o, const float* ray_d, const float* geom,
                                const float* attr, const float* bg_host, const float* rgb, const float* dpt, const float* acc,
                                const float* norm, const float* aux, const float* state, size_t state_floats, const float* g_rgb, const float* g_dpt,
-                               const float* g_acc, const float* g_norm, const float* g_dist, const float* g_aux, float* g_geom,
-                               float* g_attr, float* g_ray_o, float* g_ray_d, void* stream);
+                               const float* g_acc, const float* g_norm, const float* g_dist, const float* g_aux /* any of the six g_* may be NULL = zeros */,
+                               float* g_geom, float* g_attr, float* g_ray_o, float* g_ray_d, void* stream);
 
 /* The per-surfel records of the tracer from the model's tensors, and the way back: what HardwareRendering.render_gaussians prepares
  * around the tracer call (gaussian_renderer/optix_utils.py:36-66 get_disks, :124-183) in one launch each.  scales [P,2] (multiplied by
@@ -447,6 +447,19 @@ int mrgs_surfel_trace_prep_backward(int64_t P, const float* means3D, const float
                                     float* g_means3D, float* g_scales, float* g_rotations, float* g_opacities, float* g_shs,
                                     float* g_colors_precomp, float* g_others, void* stream);
 
+/* The same records straight from the model's own tensors (GaussianModel's activations applied inside, scene/gaussian_model.py:56-78,
+ * 236-259): scaling_raw [P,2] (scales = exp), rotation_raw [P,4], opacity_raw [P] (opacities = sigmoid), the colour SH split as the model
+ * stores it -- features_dc [P,1,3], features_rest [P,15,3] -- and the gradients in the same layout: replaces the getters' ~12 torch
+ * kernels (incl. the cat of the two SH tensors) and their ~25 backward kernels per traced view. */
+int mrgs_surfel_trace_prep_raw_forward(int64_t P, const float* xyz, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                       const float* features_dc, const float* features_rest, int32_t sh_degree, const float* others,
+                                       const float* campos, float scale_modifier, float* geom, float* attr, float* quad_vertices, void* stream);
+int mrgs_surfel_trace_prep_raw_backward(int64_t P, const float* xyz, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                        const float* features_dc, const float* features_rest, int32_t sh_degree, const float* campos,
+                                        float scale_modifier, const float* g_geom, const float* g_attr, float* g_xyz, float* g_scaling_raw,
+                                        float* g_rotation_raw, float* g_opacity_raw, float* g_features_dc, float* g_features_rest, float* g_others,
+                                        void* stream);
+
 /* The mirror rays of a rendered view, as render_indirect / render_surfel_with_envgs set them up (gaussian_renderer/envgs_renderer.py:717-724,
  * __init__.py:496-505): origin = camera centre + surf_depth * un-normalised pixel ray + 1e-3 * direction, direction = unit mirror
  * direction of the view ray about `normal` ([H,W,3], any strides).  Kinv: inverse intrinsics on the host; R / T: device Camera.R /
@@ -455,6 +468,22 @@ int mrgs_mirror_rays_forward(int32_t H, int32_t W, const float* Kinv_host, const
                              const float* surf_depth, float* ray_o, float* ray_d, void* stream);
 int mrgs_mirror_rays_backward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* normal,
                               const float* g_ray_o, const float* g_ray_d, float* g_normal, float* g_surf_depth, void* stream);
+/* The same with the reflecting normal built inside from the BLENDED normal map and alpha, as render_surfel_with_envgs does
+ * (gaussian_renderer/__init__.py:493-495): normal = safe_normalize(rend_normal / clamp_min(alpha, 1e-6)); rend_normal [H,W,3] by strides
+ * (the [3,H,W] map is passed as strides (W, 1, H W)), alpha [H,W].  Backward: + g_alpha [H,W]. */
+int mrgs_mirror_rays_blended_forward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* rend_normal,
+                                     const float* alpha, const float* surf_depth, float* ray_o, float* ray_d, void* stream);
+int mrgs_mirror_rays_blended_backward(int32_t H, int32_t W, const float* Kinv_host, const float* R, const float* T, const MrgsStridedMap* rend_normal,
+                                      const float* alpha, const float* g_ray_o, const float* g_ray_d, float* g_rend_normal, float* g_alpha,
+                                      float* g_surf_depth, void* stream);
+/* out = a (1 - s) + s b per channel: the traced light blended into the rendered view (gaussian_renderer/__init__.py:517).  a / out / g_*
+ * [3,H,W] contiguous; b by element strides (channel, pixel: a [H,W,3] tensor seen as [3,H,W] is (1, 3)), s by its pixel stride; backward:
+ * g_a [3,H,W], g_b in b's layout, g_s [H,W], all fully written. */
+int mrgs_traced_blend_forward(int32_t H, int32_t W, const float* a, const float* b, int64_t b_channel_stride, int64_t b_pixel_stride, const float* s,
+                              int64_t s_pixel_stride, float* out, void* stream);
+int mrgs_traced_blend_backward(int32_t H, int32_t W, const float* a, const float* b, int64_t b_channel_stride, int64_t b_pixel_stride, const float* s,
+                               int64_t s_pixel_stride, const float* g_out, float* g_a, float* g_b, float* g_s, void* stream);
+
 
 /* ---- optimizer step -------------------------------------------------------------------------
  * torch.optim.Adam(l, lr=0.0, eps=1e-15).step() of GaussianModel.training_setup (scene/gaussian_model.py:417-453) for every

@@ -171,6 +171,14 @@ SYMBOLS = {
                                                 c_void_p, c_void_p, c_void_p]),
     "mrgs_mirror_rays_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap), c_void_p,
                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_mirror_rays_blended_forward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap),
+                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_mirror_rays_blended_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_float), c_void_p, c_void_p, ctypes.POINTER(MrgsStridedMap),
+                                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_traced_blend_forward": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mrgs_traced_blend_backward": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64] + [c_void_p] * 5),
+    "mrgs_surfel_trace_prep_raw_forward": (ctypes.c_int, [c_int64] + [c_void_p] * 6 + [c_int32] + [c_void_p] * 2 + [c_float] + [c_void_p] * 4),
+    "mrgs_surfel_trace_prep_raw_backward": (ctypes.c_int, [c_int64] + [c_void_p] * 6 + [c_int32, c_void_p, c_float] + [c_void_p] * 10),
     "mrgs_surfel_trace_prep_forward": (ctypes.c_int, [c_int64] + [c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 3 + [c_float] + [c_void_p] * 4),
     "mrgs_surfel_trace_prep_backward": (ctypes.c_int, [c_int64] + [c_void_p] * 4 + [c_int32, c_int32, c_void_p, c_float] + [c_void_p] * 10),
     "mrgs_surfel_bvh_build": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),

@@ -639,10 +639,13 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     float fA = 0, fM1 = 0, fM2 = 0, fT = 0, Qtot = 0, Qpre = 0, bgdot = 0;
     float go[3] = {0, 0, 0}, gdir[3] = {0, 0, 0};
     if (BWD) {
-        gc[0] = A.g_rgb[3 * r]; gc[1] = A.g_rgb[3 * r + 1]; gc[2] = A.g_rgb[3 * r + 2];
-        gd = A.g_dpt[r]; ga = A.g_acc[r]; gdist = A.g_dist[r];
-        gn[0] = A.g_norm[3 * r]; gn[1] = A.g_norm[3 * r + 1]; gn[2] = A.g_norm[3 * r + 2];
-        gx[0] = A.g_aux[2 * r]; gx[1] = A.g_aux[2 * r + 1];
+        // (an upstream gradient nobody supplied is a null pointer = zeros: no zero-filled maps on the way in)
+        if (A.g_rgb) { gc[0] = A.g_rgb[3 * r]; gc[1] = A.g_rgb[3 * r + 1]; gc[2] = A.g_rgb[3 * r + 2]; }
+        if (A.g_dpt) gd = A.g_dpt[r];
+        if (A.g_acc) ga = A.g_acc[r];
+        if (A.g_dist) gdist = A.g_dist[r];
+        if (A.g_norm) { gn[0] = A.g_norm[3 * r]; gn[1] = A.g_norm[3 * r + 1]; gn[2] = A.g_norm[3 * r + 2]; }
+        if (A.g_aux) { gx[0] = A.g_aux[2 * r]; gx[1] = A.g_aux[2 * r + 1]; }
         fA = A.acc[r]; fM1 = A.dpt[r]; fM2 = A.state[4 * r]; fT = A.state[4 * r + 1];
         bgdot = gc[0] * A.bg[0] + gc[1] * A.bg[1] + gc[2] * A.bg[2];
         Qtot = gc[0] * (A.rgb[3 * r] - fT * A.bg[0]) + gc[1] * (A.rgb[3 * r + 1] - fT * A.bg[1]) + gc[2] * (A.rgb[3 * r + 2] - fT * A.bg[2])
@@ -982,10 +985,12 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
         float fA = 0, fM1 = 0, fM2 = 0, fT = 0, Qtot = 0, Qpre = 0, bgdot = 0;
         float go0 = 0, go1 = 0, go2 = 0, gv0 = 0, gv1 = 0, gv2 = 0;         // per lane partial sums of the ray's own gradient
         if (BWD) {
-            gc0 = A.g_rgb[3 * r]; gc1 = A.g_rgb[3 * r + 1]; gc2 = A.g_rgb[3 * r + 2];
-            gd = A.g_dpt[r]; ga = A.g_acc[r]; gdist = A.g_dist[r];
-            gn0 = A.g_norm[3 * r]; gn1 = A.g_norm[3 * r + 1]; gn2 = A.g_norm[3 * r + 2];
-            gx0 = A.g_aux[2 * r]; gx1 = A.g_aux[2 * r + 1];
+            if (A.g_rgb) { gc0 = A.g_rgb[3 * r]; gc1 = A.g_rgb[3 * r + 1]; gc2 = A.g_rgb[3 * r + 2]; }
+            if (A.g_dpt) gd = A.g_dpt[r];
+            if (A.g_acc) ga = A.g_acc[r];
+            if (A.g_dist) gdist = A.g_dist[r];
+            if (A.g_norm) { gn0 = A.g_norm[3 * r]; gn1 = A.g_norm[3 * r + 1]; gn2 = A.g_norm[3 * r + 2]; }
+            if (A.g_aux) { gx0 = A.g_aux[2 * r]; gx1 = A.g_aux[2 * r + 1]; }
             fA = A.acc[r]; fM1 = A.dpt[r]; fM2 = A.state[4 * r]; fT = A.state[4 * r + 1];
             bgdot = gc0 * A.bg[0] + gc1 * A.bg[1] + gc2 * A.bg[2];
             Qtot = gc0 * (A.rgb[3 * r] - fT * A.bg[0]) + gc1 * (A.rgb[3 * r + 1] - fT * A.bg[1]) + gc2 * (A.rgb[3 * r + 2] - fT * A.bg[2])
@@ -1390,9 +1395,8 @@ int mrgs_surfel_trace_backward(void* blob, int64_t n_surfels, int64_t n_rays, in
     if (hipMemsetAsync(g_geom, 0, (size_t)n_surfels * 64, st) != hipSuccess || hipMemsetAsync(g_attr, 0, (size_t)n_surfels * 32, st) != hipSuccess)
         return MRGS_E_HIP;
     if (n_rays == 0) return MRGS_OK;
-    if (!blob || !ray_o || !ray_d || !geom || !attr || !bg_host || !rgb || !dpt || !acc || !norm || !aux || !state || !g_rgb || !g_dpt ||
-        !g_acc || !g_norm || !g_dist || !g_aux || !g_ray_o || !g_ray_d)
-        return MRGS_E_BAD_ARG;
+    if (!blob || !ray_o || !ray_d || !geom || !attr || !bg_host || !rgb || !dpt || !acc || !norm || !aux || !state || !g_ray_o || !g_ray_d)
+        return MRGS_E_BAD_ARG;                                  // (any of the six upstream gradients may be NULL = zeros)
     StArgs a;
     std::memset(&a, 0, sizeof(a));
     a.ray_o = ray_o; a.ray_d = ray_d; a.geom = (const float4*)geom; a.attr = (const float4*)attr;

@@ -519,6 +519,105 @@ def _mirror_rays(viewpoint_camera, normal_map, surf_depth):
     return _MirrorRays.apply(normal_map.reshape(H, W, 3).float(), surf_depth, Kinv, R, T)
 
 
+class _MirrorRaysBlended(torch.autograd.Function):
+    """mrgs_mirror_rays_blended_forward / _backward: the mirror rays straight from the rendered maps -- reflecting normal =
+    safe_normalize(rend_normal / clamp_min(rend_alpha, 1e-6)) (gaussian_renderer/__init__.py:493-495) built inside the ray kernel."""
+
+    @staticmethod
+    def forward(ctx, rend_normal, rend_alpha, surf_depth, Kinv, R, T):
+        L = _lib.lib()
+        H, W = rend_normal.shape[1], rend_normal.shape[2]
+        dev = rend_normal.device
+        rn = rend_normal.detach().float()
+        al = rend_alpha.detach().reshape(H, W).contiguous().float()
+        sd = surf_depth.detach().reshape(H, W).contiguous().float()
+        ray_o = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        ray_d = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        kinv = (ctypes.c_float * 9)(*Kinv)
+        m = _lib.MrgsStridedMap(rn.data_ptr(), rn.stride(1), rn.stride(2), rn.stride(0))        # [3,H,W] read as [H,W,3]
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_mirror_rays_blended_forward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(al), _p(sd), _p(ray_o), _p(ray_d),
+                                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.save_for_backward(rn, al, R, T)
+        ctx.Kinv, ctx.shapes = Kinv, (rend_alpha.shape, surf_depth.shape)
+        return ray_o, ray_d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        rn, al, R, T = ctx.saved_tensors
+        L = _lib.lib()
+        H, W = rn.shape[1], rn.shape[2]
+        dev = rn.device
+        z = lambda g: torch.zeros(H, W, 3, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
+        g_o, g_d = z(g_o), z(g_d)
+        g_n = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        g_al = torch.empty(H, W, dtype=torch.float32, device=dev)
+        g_sd = torch.empty(H, W, dtype=torch.float32, device=dev)
+        kinv = (ctypes.c_float * 9)(*ctx.Kinv)
+        m = _lib.MrgsStridedMap(rn.data_ptr(), rn.stride(1), rn.stride(2), rn.stride(0))
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_mirror_rays_blended_backward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(al), _p(g_o), _p(g_d), _p(g_n), _p(g_al),
+                                                           _p(g_sd), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return g_n.permute(2, 0, 1), g_al.reshape(ctx.shapes[0]), g_sd.reshape(ctx.shapes[1]), None, None, None
+
+
+_CAM_CONSTS = {}
+
+
+def _camera_consts(viewpoint_camera, dev):
+    """K^-1 (host tuple), Camera.R and Camera.T as device tensors, built once per camera object (three small uploads per view otherwise)."""
+    import numpy as np
+    H, W, K = viewpoint_camera.HWK
+    key = id(viewpoint_camera)
+    ent = _CAM_CONSTS.get(key)
+    if ent is None or ent[0] is not viewpoint_camera or ent[4] != dev:
+        Kinv = tuple(np.linalg.inv(np.asarray(K, dtype=np.float32)).astype(np.float32).reshape(-1).tolist())
+        R = torch.as_tensor(viewpoint_camera.R, dtype=torch.float32, device=dev).contiguous()
+        T = torch.as_tensor(viewpoint_camera.T, dtype=torch.float32, device=dev).contiguous()
+        if len(_CAM_CONSTS) > 4096:
+            _CAM_CONSTS.clear()
+        ent = _CAM_CONSTS[key] = (viewpoint_camera, Kinv, R, T, dev)      # holds the camera: its id stays its own
+    return ent[1], ent[2], ent[3]
+
+
+def _mirror_rays_blended(viewpoint_camera, rend_normal, rend_alpha, surf_depth):
+    """Mirror rays of every pixel from render_surfel's maps: rend_normal [3,H,W], rend_alpha [1,H,W], surf_depth [1,H,W]."""
+    Kinv, R, T = _camera_consts(viewpoint_camera, surf_depth.device)
+    return _MirrorRaysBlended.apply(rend_normal, rend_alpha, surf_depth, Kinv, R, T)
+
+
+class _TracedBlend(torch.autograd.Function):
+    """final * (1 - specular) + specular * traced (gaussian_renderer/__init__.py:517), one kernel each way; `traced` [3,H,W] and `specular`
+    [1,H,W] are read through their strides (the tracer's [H,W,C] tensors seen channel-first) and their gradients written the same way."""
+
+    @staticmethod
+    def forward(ctx, a, b, s):
+        a = a.detach().contiguous().float()
+        b, s = b.detach().float(), s.detach().float()
+        H, W = a.shape[1], a.shape[2]
+        if not (b.stride(1) == W * b.stride(2) and s.stride(1) == W * s.stride(2)):       # rows must follow each other: one pixel stride
+            b, s = b.contiguous(), s.contiguous()
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().mrgs_traced_blend_forward(H, W, _p(a), _p(b), b.stride(0), b.stride(2), _p(s), s.stride(2), _p(out),
+                                                            ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+        ctx.save_for_backward(a, b, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, s = ctx.saved_tensors
+        g = g.contiguous().float()
+        H, W = a.shape[1], a.shape[2]
+        ga = torch.empty_like(a)
+        gb = torch.empty_strided(b.shape, b.stride(), dtype=torch.float32, device=a.device)      # g_b in b's own layout
+        gs = torch.empty((1, H, W), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().mrgs_traced_blend_backward(H, W, _p(a), _p(b), b.stride(0), b.stride(2), _p(s), s.stride(2), _p(g), _p(ga), _p(gb), _p(gs),
+                                                             ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+        return ga, gb, gs
+
+
 def render_indirect(indirect_renderer, viewpoint_camera, pc, pipe, bg_color, normal_map=None, surf_depth=None):
     """gaussian_renderer/envgs_renderer.py:716-731: the surfel set `pc` seen along the mirror rays of a rendered view."""
     ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, surf_depth)
@@ -536,12 +635,12 @@ def render_surfel_with_envgs(indirect_renderer, viewpoint_camera, pc, pipe, bg_c
     # and the lines below fail with the reference's own KeyError
     results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt, wo_render_img, normal_img_map)
     final_image = results["render"]
-    alpha = results["rend_alpha"].permute(1, 2, 0)
-    normal_map = safe_normalize(results["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))
-    ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, results["surf_depth"])
+    # normal_map = safe_normalize(rend_normal / clamp_min(alpha, 1e-6)) (:493-495) is built inside the ray kernel
+    ray_o, ray_d = _mirror_rays_blended(viewpoint_camera, results["rend_normal"], results["rend_alpha"], results["surf_depth"])
     traced = indirect_renderer(viewpoint_camera, ray_o=ray_o, ray_d=ray_d, pcd=pc, pipe=pipe, bg_color=bg_color, start_from_first=False)
     specular = traced["specular"]
-    results["render"] = final_image * (1 - specular) + specular * traced["render"]
+    results["render"] = _TracedBlend.apply(final_image, traced["render"], specular) if final_image.is_cuda else \
+        final_image * (1 - specular) + specular * traced["render"]
     results["indirect_out"] = traced
     return results
 
@@ -553,9 +652,7 @@ def render_surfel_with_envgs_sep(indirect_renderer, env, viewpoint_camera, pc, p
     set `env`, and the blend weight is render_surfel's per-pixel "specular_weight" ([H,W,3], returned with opt.indirect)."""
     results = render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, srgb, opt, wo_render_img, normal_img_map)
     weight = results["specular_weight"].permute(2, 0, 1)
-    alpha = results["rend_alpha"].permute(1, 2, 0)
-    normal_map = safe_normalize(results["rend_normal"].permute(1, 2, 0) / alpha.clamp_min(1e-6))
-    ray_o, ray_d = _mirror_rays(viewpoint_camera, normal_map, results["surf_depth"])
+    ray_o, ray_d = _mirror_rays_blended(viewpoint_camera, results["rend_normal"], results["rend_alpha"], results["surf_depth"])
     traced = indirect_renderer.render_gaussians(viewpoint_camera, ray_o=ray_o, ray_d=ray_d, pcd=env, pipe=pipe, bg_color=bg_color, start_from_first=True)
     traced["specular"] = weight
     results["render"] = results["render"] * (1 - weight) + weight * traced["render"]

@@ -60,6 +60,7 @@ class _Trace(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ray_o, ray_d, geom, attr, blob, bg3, ray_width):
+        ctx.set_materialize_grads(False)
         L = _lib.lib()
         dev = ray_o.device
         n_rays, P = ray_o.shape[0], geom.shape[0]
@@ -85,10 +86,9 @@ class _Trace(torch.autograd.Function):
         L = _lib.lib()
         dev = ray_o.device
         n_rays, P = ray_o.shape[0], geom.shape[0]
-        z = lambda ref: torch.zeros_like(ref)
-        c = lambda g, ref: z(ref) if g is None else g.contiguous().float()
-        g_rgb, g_dpt, g_acc, g_norm, g_aux = c(g_rgb, rgb), c(g_dpt, dpt), c(g_acc, acc), c(g_norm, norm), c(g_aux, aux)
-        g_dist = c(g_dist, dpt)
+        # an output nobody took a gradient of arrives as None and goes down as a null pointer (= zeros): no zero-filled maps
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_rgb, g_dpt, g_acc, g_norm, g_aux, g_dist = c(g_rgb), c(g_dpt), c(g_acc), c(g_norm), c(g_aux), c(g_dist)
         g_geom, g_attr = torch.empty_like(geom), torch.empty_like(attr)
         g_o, g_d = torch.empty_like(ray_o), torch.empty_like(ray_d)
         bg = (ctypes.c_float * 3)(*ctx.bg3)
@@ -143,6 +143,50 @@ class _Prep(torch.autograd.Function):
                                                          _ptr(g_geom), _ptr(g_attr), _ptr(g_means), _ptr(g_scales), _ptr(g_rot), _ptr(g_op),
                                                          _ptr(g_shs), _ptr(g_colors), _ptr(g_others), _stream(dev)))
         return g_means, g_scales, g_rot, g_op, g_shs, g_colors, g_others, None, None, None
+
+
+class _PrepRaw(torch.autograd.Function):
+    """mrgs_surfel_trace_prep_raw_forward / _backward: the model's OWN tensors (raw scaling / rotation / opacity, the colour SH split into
+    _features_dc and _features_rest) -> geom [P,16], attr [P,8], quad corners, GaussianModel's activations applied inside
+    (scene/gaussian_model.py:56-78, 236-259) -- no getter kernels, no cat of the SH tensors, gradients in the model's layout."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, opacity, f_dc, f_rest, others, grads3D, campos, sh_degree, scale_modifier):
+        # grads3D: the reference's zero tensor added to the means (optix_utils.py:131-135) so that it receives dL/dmeans3D; here an input
+        # whose value is never read and whose gradient is the means' gradient
+        L = _lib.lib()
+        dev = xyz.device
+        P = xyz.shape[0]
+        f = lambda t: None if t is None else t.detach().contiguous().float()
+        xyz, scaling, rotation, opacity, f_dc, f_rest, others, campos = map(f, (xyz, scaling, rotation, opacity, f_dc, f_rest, others, campos))
+        geom = torch.empty(P, 16, dtype=torch.float32, device=dev)
+        attr = torch.empty(P, 8, dtype=torch.float32, device=dev)
+        quads = torch.empty(4 * P, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_surfel_trace_prep_raw_forward(P, _ptr(xyz), _ptr(scaling), _ptr(rotation), _ptr(opacity), _ptr(f_dc), _ptr(f_rest),
+                                                            int(sh_degree), _ptr(others), _ptr(campos), float(scale_modifier), _ptr(geom), _ptr(attr),
+                                                            _ptr(quads), _stream(dev)))
+        ctx.save_for_backward(xyz, scaling, rotation, opacity, f_dc, f_rest, campos)
+        ctx.cfg = (int(sh_degree), float(scale_modifier), others is not None)
+        ctx.mark_non_differentiable(quads)
+        return geom, attr, quads
+
+    @staticmethod
+    def backward(ctx, g_geom, g_attr, _g_quads):
+        xyz, scaling, rotation, opacity, f_dc, f_rest, campos = ctx.saved_tensors
+        degree, modifier, has_others = ctx.cfg
+        L = _lib.lib()
+        dev = xyz.device
+        P = xyz.shape[0]
+        z = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
+        g_geom, g_attr = z(g_geom, (P, 16)), z(g_attr, (P, 8))
+        outs = [torch.empty_like(t) for t in (xyz, scaling, rotation, opacity, f_dc, f_rest)]
+        g_others = torch.empty(P, 2, dtype=torch.float32, device=dev) if has_others else None
+        with torch.cuda.device(dev):
+            _lib.check(L.mrgs_surfel_trace_prep_raw_backward(P, _ptr(xyz), _ptr(scaling), _ptr(rotation), _ptr(opacity), _ptr(f_dc), _ptr(f_rest), degree,
+                                                             _ptr(campos), modifier, _ptr(g_geom), _ptr(g_attr), *[_ptr(t) for t in outs], _ptr(g_others),
+                                                             _stream(dev)))
+        return (*outs, g_others if ctx.needs_input_grad[6] else None, outs[0] if ctx.needs_input_grad[7] else None, None, None, None)
 
 
 def surfel_records(means3D, scales, rotations, opacities, colors, others, scale_modifier=1.0):
@@ -210,29 +254,39 @@ class SurfelTracer(nn.Module):
         return ent[0]
 
     def forward(self, ray_o, ray_d, v=None, means3D=None, grads3D=None, shs=None, colors_precomp=None, others_precomp=None, opacities=None,
-                scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
+                scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True, records=None):
+        """records (extension): (geom, attr, quads) already built by _PrepRaw from the model's raw tensors -- the getters' arguments
+        (scales, shs, ...) are not read then."""
         ts = tracer_settings
         if self._blob is None and not self.build_on_trace and means3D is not None and means3D.shape[0] > 0:
             raise RuntimeError("build_acceleration_structure has not been called")
-        if cov3D_precomp is not None or scales is None or rotations is None:
+        if records is None and (cov3D_precomp is not None or scales is None or rotations is None):
             raise NotImplementedError("the tracer intersects surfels from scales / rotations; cov3D_precomp is not supported")
         if ts.max_trace_depth != 0:
             raise NotImplementedError("max_trace_depth > 0 (bounces inside the tracer) is not built; every caller of the reference uses 0")
+        if records is not None:
+            _need_gpu(means3D, "means3D")
+            return self._trace(ray_o, ray_d, means3D.shape[0], records, ts)
         if (shs is None) == (colors_precomp is None):
             raise RuntimeError("Please provide exactly one of either SHs or precomputed colors!")
         _need_gpu(means3D, "means3D")
         P = means3D.shape[0]
-        shape = ray_o.shape[:-1]
         means = means3D if grads3D is None else means3D + grads3D          # the densification proxy receives d/d means3D
         # computeColorFromSH of the rasterizer family (forward.cu:20-81, direction from the settings' camera position), the splat frame
         # and get_disks' corners: one launch (mrgs_surfel_trace_prep_forward)
         shs_pm3 = None if shs is None else (shs if shs.shape[-1] == 3 else shs.transpose(1, 2))
         if P == 0:       # an empty model (e.g. everything pruned): background everywhere, nothing to build or to differentiate
-            geom, attr = means3D.new_zeros((0, 16), dtype=torch.float32), means3D.new_zeros((0, 8), dtype=torch.float32)
-            self._n, self.build_on_trace = 0, False
+            recs = (means3D.new_zeros((0, 16), dtype=torch.float32), means3D.new_zeros((0, 8), dtype=torch.float32), None)
         else:
-            geom, attr, _quads = _Prep.apply(means, scales, rotations, opacities.reshape(P, 1), shs_pm3, colors_precomp, others_precomp,
-                                             ts.campos.reshape(3), ts.sh_degree, float(ts.scale_modifier))
+            recs = _Prep.apply(means, scales, rotations, opacities.reshape(P, 1), shs_pm3, colors_precomp, others_precomp,
+                               ts.campos.reshape(3), ts.sh_degree, float(ts.scale_modifier))
+        return self._trace(ray_o, ray_d, P, recs, ts)
+
+    def _trace(self, ray_o, ray_d, P, records, ts):
+        geom, attr, _quads = records
+        shape = ray_o.shape[:-1]
+        if P == 0:
+            self._n, self.build_on_trace = 0, False
         if self.build_on_trace:
             self.build_acceleration_structure(_quads, None)
             self.build_on_trace = False
@@ -272,6 +326,52 @@ def record_summary(tracer):
     pick = lambda i: int(words[i].item())
     return {"rays": n_rays, "lone_rays": pick(off[0]), "listed_packets": pick(off[1]), "pool_chunks": pick(off[2]) if have_hdr else None,
             "record_usable": have_hdr and st.numel() >= off[4] and pick(off[2] + 1) == 0}
+
+
+_ZERO_LEAVES, _OTHERS = {}, {}
+
+
+def _zero_leaf(like):
+    """A leaf of zeros shaped like `like` whose .grad receives a gradient: a fresh tensor object over one shared, never written block of
+    zeros (no fill kernel per view)."""
+    key = (like.device, tuple(like.shape), like.dtype)
+    z = _ZERO_LEAVES.get(key)
+    if z is None:
+        if len(_ZERO_LEAVES) > 8:
+            _ZERO_LEAVES.clear()
+        z = _ZERO_LEAVES[key] = torch.zeros_like(like, requires_grad=False)
+    return z.detach().requires_grad_(True)
+
+
+def _const_others(P, device):
+    key = (device, P)
+    t = _OTHERS.get(key)
+    if t is None:
+        if len(_OTHERS) > 8:
+            _OTHERS.clear()
+        t = _OTHERS[key] = torch.full((P, 2), 0.01, device=device)
+    return t
+
+
+def _raw_model(pcd, pipe, override_color):
+    """(xyz, scaling, rotation, opacity, features_dc, features_rest) when `pcd` stores GaussianModel's raw tensors under their usual names
+    with the usual activations and the colour comes from its SH coefficients; None -> the getters are used."""
+    if override_color is not None or getattr(pipe, "convert_SHs_python", False):
+        return None
+    names = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+    if not all(hasattr(pcd, n) for n in names):
+        return None
+    ts = tuple(getattr(pcd, n) for n in names)
+    P = ts[0].shape[0]
+    if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts):
+        return None
+    if tuple(ts[1].shape) != (P, 2) or tuple(ts[2].shape) != (P, 4) or ts[3].numel() != P or tuple(ts[4].shape) != (P, 1, 3) or tuple(ts[5].shape) != (P, 15, 3):
+        return None
+    # a model with other activations than exp / sigmoid / normalize declares them (GaussianModel.setup_functions, scene/gaussian_model.py:56-78)
+    for attr, fn in (("scaling_activation", torch.exp), ("opacity_activation", torch.sigmoid), ("rotation_activation", torch.nn.functional.normalize)):
+        if getattr(pcd, attr, fn) is not fn:
+            return None
+    return ts
 
 
 def _bg_key(bg):
@@ -331,30 +431,43 @@ class HardwareRendering(nn.Module):
             self.tracer.build_on_trace = True
             self.has_bvh = not self.training
         v = None
-        means3D, opacities = pcd.get_xyz.contiguous(), pcd.get_opacity.contiguous()
-        grads3D = torch.zeros_like(means3D, requires_grad=True) + 0
-        try:
-            grads3D.retain_grad()
-        except RuntimeError:
-            pass
         if getattr(pipe, "compute_cov3D_python", False):
             raise NotImplementedError("compute_cov3D_python: the tracer takes scales / rotations")
-        scales, rotations = pcd.get_scaling.contiguous(), pcd.get_rotation.contiguous()
-        shs = colors_precomp = None
-        if override_color is None or (getattr(pcd, "render_reflection", False) and getattr(pcd, "feature_splatting", False)):
-            if getattr(pipe, "convert_SHs_python", False):
-                shs_view = pcd.get_features.transpose(1, 2).view(-1, 3, (pcd.max_sh_degree + 1) ** 2)
-                dirs = pcd.get_xyz - camera.camera_center.reshape(1, 3)
-                colors_precomp = torch.clamp_min(eval_sh(pcd.active_sh_degree, shs_view, dirs / dirs.norm(dim=1, keepdim=True)) + 0.5, 0.0)
-            else:
-                shs = pcd.get_features.contiguous()
+        raw = _raw_model(pcd, pipe, override_color)
+        if raw is not None:
+            # The model's own tensors go into the record kernel as they are (activations, SH colour and get_disks' corners inside; gradients
+            # come back in the model's layout): the reference's getters (:128-170) are ~12 torch kernels forward and ~25 backward per view.
+            means3D = raw[0]
+            P = means3D.shape[0]
+            grads3D = _zero_leaf(means3D)                                                 # receives dL/dmeans3D, as the reference's (:131-135)
+            others = _const_others(P, means3D.device)                                     # the reference's placeholder (:173-177)
+            recs = (means3D.new_zeros((0, 16)), means3D.new_zeros((0, 8)), None) if P == 0 else \
+                _PrepRaw.apply(*raw, others, grads3D, settings.campos.reshape(3), settings.sh_degree, float(settings.scale_modifier))
+            rgb, dpt, acc, norm, dist, aux, mid, wet = self.tracer(ray_o.contiguous(), ray_d.contiguous(), v, means3D=means3D, tracer_settings=settings,
+                                                                   start_from_first=start_from_first, records=recs)
         else:
-            colors_precomp = override_color.contiguous()
-        others = torch.full((means3D.shape[0], 2), 0.01, device=means3D.device)          # the reference's placeholder (:173-177)
-        rgb, dpt, acc, norm, dist, aux, mid, wet = self.tracer(
-            ray_o.contiguous(), ray_d.contiguous(), v, means3D=means3D, grads3D=grads3D, shs=shs, colors_precomp=colors_precomp,
-            others_precomp=others, opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None, tracer_settings=settings,
-            start_from_first=start_from_first)
+            means3D, opacities = pcd.get_xyz.contiguous(), pcd.get_opacity.contiguous()
+            grads3D = torch.zeros_like(means3D, requires_grad=True) + 0
+            try:
+                grads3D.retain_grad()
+            except RuntimeError:
+                pass
+            scales, rotations = pcd.get_scaling.contiguous(), pcd.get_rotation.contiguous()
+            shs = colors_precomp = None
+            if override_color is None or (getattr(pcd, "render_reflection", False) and getattr(pcd, "feature_splatting", False)):
+                if getattr(pipe, "convert_SHs_python", False):
+                    shs_view = pcd.get_features.transpose(1, 2).view(-1, 3, (pcd.max_sh_degree + 1) ** 2)
+                    dirs = pcd.get_xyz - camera.camera_center.reshape(1, 3)
+                    colors_precomp = torch.clamp_min(eval_sh(pcd.active_sh_degree, shs_view, dirs / dirs.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+                else:
+                    shs = pcd.get_features.contiguous()
+            else:
+                colors_precomp = override_color.contiguous()
+            others = torch.full((means3D.shape[0], 2), 0.01, device=means3D.device)          # the reference's placeholder (:173-177)
+            rgb, dpt, acc, norm, dist, aux, mid, wet = self.tracer(
+                ray_o.contiguous(), ray_d.contiguous(), v, means3D=means3D, grads3D=grads3D, shs=shs, colors_precomp=colors_precomp,
+                others_precomp=others, opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=None, tracer_settings=settings,
+                start_from_first=start_from_first)
         with torch.no_grad():
             visibility_filter = wet[..., 0] > 0.0
             if start_from_first:                                                             # + what "projects into the image" (:203-211)
@@ -372,7 +485,7 @@ class HardwareRendering(nn.Module):
                       (uvd[..., 1] <= camera.image_height)
                 visibility_filter = visibility_filter | vis
         chw = lambda x: x.permute(2, 0, 1)
-        out = {"viewspace_points": grads3D, "visibility_filter": visibility_filter.detach().clone(), "weight_accumulate": wet,
+        out = {"viewspace_points": grads3D, "visibility_filter": visibility_filter, "weight_accumulate": wet,      # (a fresh tensor already)
                "render": chw(rgb), "rend_alpha": chw(acc), "rend_normal": chw(norm), "rend_dist": chw(dist), "surf_depth": chw(dpt)}
         if start_from_first:
             out["surf_normal"] = chw(_depth_to_normal(camera, dpt[..., 0]) * acc.detach())

@@ -623,3 +623,88 @@ def test_fallback_paths_of_the_tracer(gpu_device, switch):
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,degree", [(3000, 3), (130, 1), (64, 0)])
+def test_raw_record_kernel_equals_the_getters_path(gpu_device, P, degree):
+    """mrgs_surfel_trace_prep_raw_*: the model's own tensors (raw scaling / rotation / opacity, split SH) against GaussianModel's getters in
+    torch float64 (exp / normalize / sigmoid / cat, scene/gaussian_model.py:56-78, 236-259) followed by the torch statement of the records:
+    same records and corners, every raw-parameter gradient and the gradient of the densification proxy (= the means' gradient)."""
+    from materialrefgs_amd.surfel_tracing import _PrepRaw, surfel_records, _zero_leaf
+    from materialrefgs_amd.gs_utils import eval_sh
+    dev = gpu_device
+    sc = make_shell_scene(P, seed=4)
+    g = torch.Generator().manual_seed(8)
+    raw = dict(xyz=sc.means3D, scaling=torch.log(sc.scales), rotation=sc.rotations * 0.6, opacity=torch.randn(P, 1, generator=g),
+               f_dc=sc.shs[:, :1] + 0.2 * torch.randn(P, 1, 3, generator=g), f_rest=0.3 * torch.randn(P, 15, 3, generator=g))
+    others = torch.full((P, 2), 0.01)
+    campos = torch.tensor([0.3, -2.0, 1.1])
+    mod = 0.9
+    Lh = {k: v.to(dev).float().clone().contiguous().requires_grad_(True) for k, v in raw.items()}
+    proxy = _zero_leaf(Lh["xyz"])
+    gh, ah, qh = _PrepRaw.apply(Lh["xyz"], Lh["scaling"], Lh["rotation"], Lh["opacity"], Lh["f_dc"], Lh["f_rest"], others.to(dev), proxy, campos.to(dev),
+                                degree, mod)
+    Lr = {k: v.double().clone().requires_grad_(True) for k, v in raw.items()}
+    shs = torch.cat([Lr["f_dc"], Lr["f_rest"]], dim=1)
+    d = Lr["xyz"] - campos.double().reshape(1, 3)
+    col = torch.clamp_min(eval_sh(degree, shs.transpose(1, 2), d / d.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+    scales, rot, op = torch.exp(Lr["scaling"]), torch.nn.functional.normalize(Lr["rotation"]), torch.sigmoid(Lr["opacity"])
+    gr, ar = surfel_records(Lr["xyz"], scales, rot, op, col, others.double(), mod)
+    qr = sto.quad_vertices(Lr["xyz"], scales, rot, mod).reshape(-1, 3)
+    assert float((gh.cpu().double()[:, :13] - gr[:, :13]).abs().max()) < 2e-5 * float(gr.abs().max())
+    assert float((ah.cpu().double()[:, :5] - ar[:, :5]).abs().max()) < 2e-6
+    assert float((qh.cpu().double() - qr.detach()).abs().max()) < 2e-6
+    wg, wa = torch.randn(P, 16, generator=g), torch.randn(P, 8, generator=g)
+    wg[:, 13:] = 0; wa[:, 5:] = 0
+    ((gh * wg.to(dev)).sum() + (ah * wa.to(dev)).sum()).backward()
+    ((gr * wg.double()).sum() + (ar * wa.double()).sum()).backward()
+    for k in raw:
+        a, b = Lh[k].grad.cpu().double(), Lr[k].grad
+        assert float((a - b).abs().max()) <= 3e-5 * max(float(b.abs().max()), 1e-12), k
+    assert torch.equal(proxy.grad, Lh["xyz"].grad)
+
+
+@pytest.mark.gpu
+def test_blended_mirror_rays_and_traced_blend(gpu_device):
+    """mrgs_mirror_rays_blended_* (reflecting normal = safe_normalize(rend_normal / clamp_min(alpha, 1e-6)) inside the ray kernel) and
+    mrgs_traced_blend_* against the torch expressions of render_surfel_with_envgs (gaussian_renderer/__init__.py:493-517) in float64, with the
+    tracer's strided [H,W,C] views and pixels of zero alpha."""
+    from materialrefgs_amd import renderer
+    from materialrefgs_amd.gs_utils import safe_normalize
+    from materialrefgs_amd.synthetic import orbit_camera
+    H, W = 37, 53
+    g = torch.Generator().manual_seed(4)
+    cam = orbit_camera(3, H, W)
+    rn0 = torch.randn(3, H, W, generator=g) * 0.7
+    al0 = torch.rand(1, H, W, generator=g)
+    al0[:, :4, :6] = 0.0
+    rn0[:, :4, :6] = 0.0
+    sd0 = torch.rand(1, H, W, generator=g) * 3 + 0.5
+    dev = gpu_device
+    rn, al, sd = (t.to(dev).clone().requires_grad_(True) for t in (rn0, al0, sd0))
+    oh, rh = renderer._mirror_rays_blended(cam.to(dev), rn, al, sd)
+    rn64, al64, sd64 = (t.double().clone().requires_grad_(True) for t in (rn0, al0, sd0))
+    nm = safe_normalize(rn64.permute(1, 2, 0) / al64.permute(1, 2, 0).clamp_min(1e-6))
+    orf, rr = renderer.mirror_rays_torch(cam, nm, sd64)
+    assert float((oh.cpu().double() - orf).detach().abs().max()) < 2e-5 and float((rh.cpu().double() - rr).detach().abs().max()) < 1e-5
+    wo, wr = torch.randn(H, W, 3, generator=g), torch.randn(H, W, 3, generator=g)
+    ((oh * wo.to(dev)).sum() + (rh * wr.to(dev)).sum()).backward()
+    ((orf * wo.double()).sum() + (rr * wr.double()).sum()).backward()
+    for a, b, name in ((rn, rn64, "rend_normal"), (sd, sd64, "surf_depth")):
+        assert float((a.grad.cpu().double() - b.grad).abs().max()) <= 5e-5 * float(b.grad.abs().max()), name
+    # the unit normal does not depend on alpha: the float64 gradient is rounding noise around zero, the kernel writes exact zeros
+    assert float(al64.grad.abs().max()) < 1e-9 and float(al.grad.abs().max()) == 0.0
+    # the blend: a [3,H,W] contiguous, traced / specular as channel-first views of [H,W,3] / [H,W,2]
+    a0, b0, s0 = torch.rand(3, H, W, generator=g), torch.rand(H, W, 3, generator=g), torch.rand(H, W, 2, generator=g)
+    a, b, s = (t.to(dev).clone().requires_grad_(True) for t in (a0, b0, s0))
+    out = renderer._TracedBlend.apply(a, b.permute(2, 0, 1), s[..., :1].permute(2, 0, 1))
+    a6, b6, s6 = (t.double().clone().requires_grad_(True) for t in (a0, b0, s0))
+    spec = s6[..., :1].permute(2, 0, 1)
+    ref = a6 * (1 - spec) + spec * b6.permute(2, 0, 1)
+    assert float((out.cpu().double() - ref).detach().abs().max()) < 1e-6
+    w = torch.randn(3, H, W, generator=g)
+    (out * w.to(dev)).sum().backward()
+    (ref * w.double()).sum().backward()
+    for x, y in ((a, a6), (b, b6), (s, s6)):
+        assert float((x.grad.cpu().double() - y.grad).abs().max()) <= 2e-6 * max(1.0, float(y.grad.abs().max()))
