@@ -440,6 +440,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     WS_END();
 }
 
+// Two list entries per step in the halves of packed fp32 instructions (mrgs_render_bwd_pairs.h): measured and left OFF.  At C2 it
+// issues 22 % fewer VALU instructions (109.2 M against 140.5 M per launch, SQ_INSTS_VALU) and 20 % fewer active VALU cycles, bit-identical
+// gradients -- and takes 0.266 ms instead of 0.244: it needs 142 VGPRs (three waves per SIMD instead of five) and the VALU then sits at
+// 0.74 busy instead of 1.0 (SQ_ACTIVE_INST_VALU x 4 / cycles / SIMDs); forced to four waves it spills (0.351 ms), with the next pair's
+// geometry fetched a step ahead it spills as well (0.299 ms); S = 8: 0.417 against 0.331 ms.  Build with EXTRA=-DMRGS_BWD_PAIRS to get it.
+#ifdef MRGS_BWD_PAIRS
+#ifndef MRGS_BWDP_WPE0
+#define MRGS_BWDP_WPE0 3
+#endif
+#ifndef MRGS_BWDP_WPE8
+#define MRGS_BWDP_WPE8 2
+#endif
+#include "mrgs_render_bwd_pairs.h"
+#define MRGS_BWD_KERNEL render_bwd_pairs_kernel
+#else
+#define MRGS_BWD_KERNEL render_bwd_kernel
+#endif
+
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const uint8_t* cflag, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,
                             float* grad_rec, bool forward_queues, hipStream_t stream)
@@ -453,8 +471,8 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV, GS)                                                                                                       \
-    hipLaunchKernelGGL((render_bwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.blend_state, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<render_bwd_kernel<SM, FVV>>())
+    hipLaunchKernelGGL((MRGS_BWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.blend_state, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<MRGS_BWD_KERNEL<SM, FVV>>())
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
