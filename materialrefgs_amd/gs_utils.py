@@ -98,3 +98,47 @@ def geom_transform_points(points: torch.Tensor, transf_matrix: torch.Tensor) -> 
     """Row-vector homogeneous transform with perspective divide (w + 1e-7)."""
     hom = torch.cat([points, torch.ones_like(points[:, :1])], dim=1) @ transf_matrix
     return hom[:, :3] / (hom[:, 3:] + 0.0000001)
+
+
+# ---- anisotropic spherical gaussians of the indirect term (pipe.use_asg, off by default) ------------------------------------------------
+def predefined_asg_axes(n_theta=4, n_phi=8, device=None):
+    """The fixed lobe frames of GaussianModel.asg_param (utils/graphics_utils.py:196-229, init_predefined_omega(4, 8)): per lobe the axis
+    omega on the upper hemisphere (theta at the centres of n_theta bands, phi at the centres of n_phi sectors), the tangent
+    omega_lambda = the same phi at theta + pi/2, and omega_mu = omega_lambda turned a quarter about omega (q p q^-1 with
+    q = (cos pi/4, sin pi/4 omega)), which for perpendicular unit vectors is omega x omega_lambda.  Three [n_theta n_phi, 3] tensors."""
+    import math
+    i = torch.arange(n_theta, dtype=torch.float32)
+    j = torch.arange(n_phi, dtype=torch.float32)
+    theta = (i * (0.5 * math.pi / n_theta) + 0.5 * math.pi / (2 * n_theta)).repeat_interleave(n_phi)
+    phi = (j * (2 * math.pi / n_phi) + 2 * math.pi / (2 * n_phi)).repeat(n_theta)
+    ball = lambda t, p: torch.stack([torch.cos(p) * torch.sin(t), torch.sin(p) * torch.sin(t), torch.cos(t)], dim=-1)
+    omega, lam = ball(theta, phi), ball(theta + 0.5 * math.pi, phi)
+    mu = torch.linalg.cross(omega, lam, dim=-1)
+    return tuple(t.to(device) if device is not None else t for t in (omega, lam, mu))
+
+
+def rotate_z_frame_inverse(n, v):
+    """rotation_between_z(n)^T v (utils/graphics_utils.py:121-153): v expressed in the frame whose z axis is the unit vector n, the frame
+    being the shortest rotation that takes z to n (Rodrigues with axis z x n; n = -z: minus the identity)."""
+    nx, ny, nz = n[..., 0], n[..., 1], n[..., 2]
+    c = (nz + 1).clamp_min(1e-7)
+    vx, vy, vz = v[..., 0], v[..., 1], v[..., 2]
+    # rows of R^T = columns of R = I + [a]x + [a]x^2 / (1 + n.z), a = (-n.y, n.x, 0)
+    ox = (1 - nx * nx / c) * vx + (-nx * ny / c) * vy + (-nx) * vz
+    oy = (-nx * ny / c) * vx + (1 - ny * ny / c) * vy + (-ny) * vz
+    oz = nx * vx + ny * vy + (1 - (nx * nx + ny * ny) / c) * vz
+    out = torch.stack([ox, oy, oz], dim=-1)
+    return torch.where((nz + 1 > 0)[..., None], out, -v)
+
+
+def asg_indirect(asg, axes, normals, reflection):
+    """Indirect radiance [P,3] from the per-gaussian lobes `asg` [P,32,5] = (amplitude 3, lambda, mu) along `reflection`, expressed in the
+    frame of `normals` (gaussian_renderer/__init__.py:312-336): sum over lobes of exp(a - 3) * relu(r . omega) *
+    exp(-softplus(la - 1) (r . omega_lambda)^2 - softplus(mu - 1) (r . omega_mu)^2), clamped at 0."""
+    omega, omega_la, omega_mu = axes
+    r = rotate_z_frame_inverse(normals, reflection)[:, None, :]                       # [P,1,3]
+    ep, la, mu = torch.split(asg, [3, 1, 1], dim=-1)
+    smooth = torch.relu((r * omega[None]).sum(dim=-1, keepdim=True))
+    la, mu = torch.nn.functional.softplus(la - 1), torch.nn.functional.softplus(mu - 1)
+    arg = -la * (omega_la[None] * r).sum(dim=-1, keepdim=True).pow(2) - mu * (omega_mu[None] * r).sum(dim=-1, keepdim=True).pow(2)
+    return (torch.exp(ep - 3) * smooth * torch.exp(arg)).sum(dim=1).clamp_min(0.0)

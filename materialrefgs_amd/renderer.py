@@ -42,6 +42,8 @@ class SurfelModel:
         self._indirect_dc = indirect_dc if indirect_dc is not None else z(P, 1, 3)
         self._indirect_rest = indirect_rest if indirect_rest is not None else z(P, 15, 3)
         self._metalness = z(P, 1)       # GaussianModel._metalness: the per-gaussian blend weight render_surfel2 rasterizes (get_specular)
+        self._indirect_asg = z(P, 32, 5)                                      # scene/gaussian_model.py:173 (read with pipe.use_asg only)
+        self._asg_axes = None
         self.env_map = envmap
         self.env_map_2 = None           # the second environment map render_volume shades with (GaussianModel.get_envmap_2)
         self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
@@ -62,6 +64,15 @@ class SurfelModel:
     get_specular = property(lambda s: torch.sigmoid(s._metalness))          # gaussian_model.py:309-311
     get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
     get_indirect = property(lambda s: torch.cat((s._indirect_dc, s._indirect_rest), dim=1))
+    get_asg = property(lambda s: s._indirect_asg)                            # gaussian_model.py:305-307
+
+    @property
+    def asg_param(self):                                                     # gaussian_model.py:77: init_predefined_omega(4, 8)
+        if self._asg_axes is None or self._asg_axes[0].device != self._xyz.device:
+            from .gs_utils import predefined_asg_axes
+            self._asg_axes = predefined_asg_axes(4, 8, self._xyz.device)
+        return self._asg_axes
+
     get_envmap = property(lambda s: s.env_map)
     get_envmap_2 = property(lambda s: s.env_map_2 if s.env_map_2 is not None else s.env_map)
 
@@ -290,6 +301,19 @@ def get_distance(scaling_modifier, means3D, viewpoint_camera, pc):
     return (normal_cam * centre_cam).sum(-1).abs().unsqueeze(-1)
 
 
+def _asg_indirect_of(pc, viewpoint_camera, scaling_modifier):
+    """pipe.use_asg (gaussian_renderer/__init__.py:312-336, 604-627; off by default, arguments/__init__.py:101): the indirect radiance of
+    every gaussian from its anisotropic-spherical-gaussian lobes along the mirror direction, in the frame of its facing normal.  Torch
+    ops on [P,32,.] tensors, as in the reference (an off-default branch: not fused)."""
+    from .gs_utils import asg_indirect
+    dir_pp = pc.get_xyz - viewpoint_camera.camera_center
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
+    w_o = -dir_pp_normalized
+    reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
+    return asg_indirect(pc.get_asg, pc.asg_param, normals, reflection)
+
+
 @deferred_raster_count
 def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour).  flag "pgsr"
@@ -331,6 +355,8 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     # activations, facing normal, mirror direction, indirect radiance along it and the feature concat (__init__.py:338-355):
     # one HIP kernel each way
     opacities, scales, rotations, features = surfel_features(pc, viewpoint_camera.camera_center)
+    if getattr(pipe, "use_asg", False):        # the lobes instead of the SH indirect term in channels 5..7 (:312-336)
+        features = torch.cat((features[:, :5], _asg_indirect_of(pc, viewpoint_camera, scaling_modifier)), dim=-1)
     if flag != "2dgs":          # "pgsr": + the plane distance as a ninth channel, back as "rend_distance" (:348-355, 411-413, 478-480)
         features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
 
@@ -389,8 +415,8 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     libmrgs.so; the per-gaussian elementwise glue is torch, as in the reference."""
     if opt is None:
         opt = SimpleNamespace(indirect=False)
-    if getattr(pipe, "use_asg", False) or getattr(pipe, "compute_cov3D_python", False):
-        raise NotImplementedError("render_volume: pipe.use_asg / pipe.compute_cov3D_python are not supported (reference defaults are False)")
+    if getattr(pipe, "compute_cov3D_python", False):
+        raise NotImplementedError("render_volume: pipe.compute_cov3D_python is not supported (reference default is False)")
     means2D = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
     means3D, opacity = pc.get_xyz, pc.get_opacity
@@ -401,8 +427,12 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
     w_o = -dir_pp_normalized
     reflection = 2 * torch.sum(normals * w_o, dim=1, keepdim=True) * normals - w_o
-    shs_indirect = pc.get_indirect.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
-    indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
+    if getattr(pipe, "use_asg", False):                                      # :604-627
+        from .gs_utils import asg_indirect
+        indirect = asg_indirect(pc.get_asg, pc.asg_param, normals, reflection)
+    else:
+        shs_indirect = pc.get_indirect.transpose(1, 2).reshape(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        indirect = torch.clamp_min(eval_sh(3, shs_indirect, reflection), 0.0)
     indirect_on = bool(getattr(opt, "indirect", False))
     if indirect_on:
         diffuse, specular, extra = get_full_color_volume_indirect(pc.get_envmap_2, means3D, ori_color, viewpoint_camera.HWK, viewpoint_camera.R,
@@ -667,19 +697,19 @@ def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color,
     channels plus (flag "pgsr", arguments/config.py:1) the per-gaussian blend weight and plane distance (S = 10), the mirror rays of the
     view traced through the ENVIRONMENT surfel set `env` (render_indirect, :659), and that traced light standing in for the blended
     indirect radiance where the mesh occludes the environment (get_specular_color_surfel4, utils/refl_utils.py:302-362, with its
-    `use_indirect_light_residual = False`).  `pipe.use_asg` (off by default, arguments/__init__.py:101) is not built.
+    `use_indirect_light_residual = False`).  `pipe.use_asg` (off by default, arguments/__init__.py:101): as in render_surfel.
     The reference binds `diff_surfel_rasterization2` here; its blending of feature channels is the vendored rasterizer's, which is what
     runs."""
     if opt is None:
         opt = SimpleNamespace(indirect=False)
-    if getattr(pipe, "use_asg", False):
-        raise NotImplementedError("pipe.use_asg: the anisotropic-spherical-gaussian indirect term is not built")
     means2D = _screenspace_points(pc)
     settings = _raster_settings(viewpoint_camera, pc, pipe, torch.zeros_like(bg_color), scaling_modifier)     # bg = 0 as at :483
     rasterizer = GaussianRasterizer(raster_settings=settings)
     means3D = pc.get_xyz
     shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)
     opacities, scales, rotations, features = surfel_features(pc, viewpoint_camera.camera_center)        # refl, rough, albedo 3, indirect 3
+    if getattr(pipe, "use_asg", False):
+        features = torch.cat((features[:, :5], _asg_indirect_of(pc, viewpoint_camera, scaling_modifier)), dim=-1)
     if flag != "2dgs":
         features = torch.cat((features, pc.get_specular, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(

@@ -485,6 +485,26 @@ def main():
     out = run_scenario(store, "A_volume_indirect", lambda: ref_gr.render_volume(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=True)), A)
     set_flavour("2dgs")
 
+    # ---- pipe.use_asg (off by default): the anisotropic-spherical-gaussian lobes instead of the SH indirect term (__init__.py:312-336,
+    # 604-627), with seeded lobe parameters (zeros otherwise, as GaussianModel creates them)
+    ga = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        pc._indirect_asg.copy_(torch.randn(P, 32, 5, generator=ga))
+    store["A_asg"] = pc._indirect_asg.detach().numpy().copy()
+    store["A_asg_axes"] = np.stack([t.numpy() for t in pc.asg_param])                     # init_predefined_omega(4, 8): [3,32,3]
+    pipe_asg = SimpleNamespace(**{**vars(pipe), "use_asg": True})
+    # (with opt.indirect and the occluder: the indirect channels only reach an output where the mirror ray is blocked)
+    for tag, fn, flav in (("A_surfel_asg", lambda: ref_gr.render_surfel(cam, pc, pipe_asg, bg, srgb=False, opt=SimpleNamespace(indirect=True)), "2dgs"),
+                          ("A_volume_asg", lambda: ref_gr.render_volume(cam, pc, pipe_asg, bg, srgb=False, opt=SimpleNamespace(indirect=True)), "pgsr")):
+        set_flavour(flav)
+        pc._indirect_asg.grad = None
+        run_scenario(store, tag, fn, A)
+        store[f"{tag}__grad__pc_indirect_asg"] = pc._indirect_asg.grad.detach().numpy().copy()
+    set_flavour("2dgs")
+    with torch.no_grad():
+        pc._indirect_asg.zero_()
+    pc._indirect_asg.grad = None
+
     # ---- the shading functions on their own (utils/refl_utils.py), fed with seeded maps
     g = torch.Generator().manual_seed(7)
     maps = dict(albedo=torch.rand(H, W, 3, generator=g), normal=torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1),

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Produces the profile artefacts of one code state on the MI355X box (run through gpurun from the repository root):
 #   tools/profile_round.sh <tag> [full]
+# (C3full / C3trace: kernel stats and SQ / LDS / FETCH / WRITE counter passes for every kernel: <tag>_pmc_C3full.json, <tag>_pmc_C3trace.json,
+#  reduced by tools/pmc_kernels.py)
 # -> gpurun_out/round/: <tag>_kernel_stats.csv (timeout 300 rocprofv3 --kernel-trace --stats of bench.py C2), the two HBM-traffic passes and the
 #    SQ pass (each counter set in its own run, kernel-trace only), their reductions (profiles/pmc_traffic.json, profiles/pmc_sq.json
 #    stamped with the digest of the kernel sources), and the un-profiled bench lines.  With "full" also the C3* / C4* workloads.
 # Copy what should be judged from gpurun_out/round/ into profiles/.
-TAG=${1:-r2}
+TAG=${1:-r3}
 FULL=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +28,16 @@ python tools/pmc_sq.py $S $O/${TAG}_pmc_sq_C2.json C2 profiles/pmc_sq.json > $O/
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $F | head -400 > $O/${TAG}_pmc_FETCH_SIZE_C2.csv
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $W | head -400 > $O/${TAG}_pmc_WRITE_SIZE_C2.csv
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
+# the full path (render_surfel with shading) and the traced view: kernel stats and the same counter passes, every kernel of the workload
+for W in C3full C3trace; do
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_$W -o ${TAG}_$W -- python3 $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled_$W.log 2>&1
+  cd $R
+  cp $(find $O/stats_$W -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
+  tools/pmc_pass.sh round/pmc_$W $W "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
+     "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS_ATOMIC GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_$W.log 2>&1
+  cp $O/pmc_$W/pmc_$W.json $O/${TAG}_pmc_$W.json
+done
 timeout 600 python bench.py > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
 if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C3 --steps 300 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_C3.json 2>> $O/bench_C2.err
@@ -37,10 +49,6 @@ if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C4trace --steps 30 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_C4trace.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 mirror > $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 primary >> $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
-  cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_trace -o ${TAG}_C3trace -- python3 $R/bench.py --workload C3trace --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_profiled_C3trace.log 2>&1
-  cd $R
-  cp $(find $O/stats_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_C3trace_kernel_stats.csv
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 tail -1 $O/${TAG}_bench_C2.json | cut -c1-600
