@@ -241,6 +241,21 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     }
 }
 
+// The intersection of two entries per step in packed fp32 instructions (mrgs_render_fwd_pairs.h): measured and left OFF.  Bit-identical
+// images, 74 VGPRs -- and 0.170 ms instead of 0.149 at C2 (S = 8: 0.218 against 0.166), 0.237 with the next pair's fields fetched a step
+// ahead (96 VGPRs, spills).  The forward's duration is the lifetime of its heaviest waves, which issue ONE dependent chain (intersection
+// -> reciprocal -> exponential -> alpha -> blend); a packed instruction carries two entries through that chain in lock step at a longer
+// latency per link, so the chain per two entries gets no shorter, and the compaction / transposition per chunk and the LDS latency at
+// the head of every step (the one-entry kernel fetches the next entry's geometry a step ahead) come on top.  Packed arithmetic pays
+// where the issue rate is the bound -- and there (the backward blend) it costs the occupancy that hides the latency.
+// Build with EXTRA=-DMRGS_FWD_PAIRS to get it.
+#ifdef MRGS_FWD_PAIRS
+#include "mrgs_render_fwd_pairs.h"
+#define MRGS_FWD_KERNEL render_fwd_pairs_kernel
+#else
+#define MRGS_FWD_KERNEL render_fwd_kernel
+#endif
+
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const uint8_t* qmask, uint8_t* cflag, const MrgsImgWs& img, float* out_color, float* out_feature, float* out_others, hipStream_t stream)
 {
@@ -250,8 +265,8 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
-    hipLaunchKernelGGL((render_fwd_kernel<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<render_fwd_kernel<SM, FVV>>())
+    hipLaunchKernelGGL((MRGS_FWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, FVV>>())
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
     if (cfg.S == 0) LAUNCH(0, false);
