@@ -230,10 +230,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     // the next entry; folding right after an entry's last use of accum_* is the same expression on the same operands, evaluated
     // earlier -- bit-identical -- and frees 8 + S registers across the gradient reduction, which is where the kernel's register
     // peak sits: 104 -> 96 VGPRs (5 waves per SIMD instead of 4) without feature channels, 140 -> 128 (4 instead of 3) with 8.
-    float accum_rec[3] = {0.f, 0.f, 0.f}, dL_dpixel[3] = {0.f, 0.f, 0.f};
-    float accum_rec_f[SF], dL_dpixel_f[SF];
+    // accum_dot: the reference's accum_rec recurrences of the colour, feature and normal channels (backward.cu:340-372) CONTRACTED with the
+    // pixel's upstream gradients.  dL/dalpha needs sum_ch (c_ch - accum_rec_ch) dL_dpixel_ch = q - A with q = sum_ch c_ch dL_dpixel_ch of
+    // this entry and A = sum_ch accum_rec_ch dL_dpixel_ch, and A obeys the same recurrence as every accum_rec_ch (A' = alpha q + (1 - alpha) A):
+    // one scalar recurrence instead of 3 + S + 3 of them -- 4 instructions per channel become 2 (+ 3 per group) and S + 5 registers go.
+    // Not the reference's summation order: the difference is rounding of the two sums (measured against the float64 evaluation of the
+    // reference's formulas in tests/test_truth_leg.py and in every default bench line, next to the literal fp32 reading).
+    float dL_dpixel[3] = {0.f, 0.f, 0.f};
+    float dL_dpixel_f[SF];
 #pragma unroll
-    for (int i = 0; i < SF; i++) { accum_rec_f[i] = 0.f; dL_dpixel_f[i] = 0.f; }
+    for (int i = 0; i < SF; i++) dL_dpixel_f[i] = 0.f;
+    float accum_dot = 0.f;
     float dL_dreg = 0.f, dL_ddepth = 0.f, dL_daccum = 0.f, dL_dnormal2D[3] = {0.f, 0.f, 0.f}, dL_dmedian_depth = 0.f;
     // A pixel nothing was blended into takes no part in any sum; its upstream gradients are not even read (they may
     // hold non-finite values, e.g. from a division by the zero accumulated alpha, and the entry body below multiplies
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 if (i < S) dL_dpixel_f[i] = dL_dpixels_f[(size_t)i * HW + pix];
         }
     }
-    float accum_depth_rec = 0.f, accum_alpha_rec = 0.f, accum_normal_rec[3] = {0.f, 0.f, 0.f};
+    float accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
     const float final_D = inside ? final_Ts[pix + HW] : 0.f;
     const float final_D2 = inside ? final_Ts[pix + 2 * HW] : 0.f;
     float last_dL_dT = 0.f;
@@ -336,23 +343,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             T = T * inv_1ma;                                   // backward.cu:330
             const float w = alpha * T;
             const float one_m_a = 1.0f - alpha;                // the next entry's (1 - last_alpha)
-            float dL_dalpha = 0.0f;
+            // q = sum over the colour, feature and normal channels of (the entry's value) x (the pixel's upstream gradient)
+            float q = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                dL_dalpha = fmaf(col[ch] - accum_rec[ch], dL_dpixel[ch], dL_dalpha);
+                q = fmaf(col[ch], dL_dpixel[ch], q);
                 g[MRGS_G_COL + ch] = w * dL_dpixel[ch];
-                accum_rec[ch] = fmaf(alpha, col[ch], one_m_a * accum_rec[ch]);      // backward.cu:340-342, for the next entry
             }
             if (S_MAX > 0) {
 #pragma unroll
                 for (int ch = 0; ch < S_MAX; ch++) {
                     // no branch on the runtime S (see the forward): slots beyond S read as 0 and have dL_dpixel_f = 0
                     const float f = (FV || ch < S) ? mrgs_staged_feature<FV>(sb, ch, j) : 0.0f;
-                    dL_dalpha = fmaf(f - accum_rec_f[ch], dL_dpixel_f[ch], dL_dalpha);
+                    q = fmaf(f, dL_dpixel_f[ch], q);
                     g[MRGS_G_FEAT + ch] = w * dL_dpixel_f[ch];
-                    accum_rec_f[ch] = fmaf(alpha, f, one_m_a * accum_rec_f[ch]);
                 }
             }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                q = fmaf(normal[ch], dL_dnormal2D[ch], q);
+                g[MRGS_G_NRM + ch] = w * dL_dnormal2D[ch];
+            }
+            float dL_dalpha = q - accum_dot;
+            accum_dot = fmaf(alpha, q, one_m_a * accum_dot);      // backward.cu:340-342 (all channels at once), for the next entry
             const float inv_cd = mrgs_rcp(c_d);
             const float m_d = mscale * (1.0f - MRGS_NEAR_N * inv_cd);
             const float dmd_dd = dmd_scale * inv_cd * inv_cd;
@@ -367,12 +380,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             accum_depth_rec = fmaf(alpha, c_d, one_m_a * accum_depth_rec);
             dL_dalpha = fmaf(1.0f - accum_alpha_rec, dL_daccum, dL_dalpha);
             accum_alpha_rec = fmaf(one_m_a, accum_alpha_rec, alpha);
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                dL_dalpha = fmaf(normal[ch] - accum_normal_rec[ch], dL_dnormal2D[ch], dL_dalpha);
-                g[MRGS_G_NRM + ch] = w * dL_dnormal2D[ch];
-                accum_normal_rec[ch] = fmaf(alpha, normal[ch], one_m_a * accum_normal_rec[ch]);
-            }
             dL_dalpha *= T;
             dL_dalpha = fmaf(-T_final * inv_1ma, bg_dot_dpixel, dL_dalpha);
             dL_dalpha = active ? dL_dalpha : 0.0f;
