@@ -230,10 +230,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     // the next entry; folding right after an entry's last use of accum_* is the same expression on the same operands, evaluated
     // earlier -- bit-identical -- and frees 8 + S registers across the gradient reduction, which is where the kernel's register
     // peak sits: 104 -> 96 VGPRs (5 waves per SIMD instead of 4) without feature channels, 140 -> 128 (4 instead of 3) with 8.
-    // accum_dot: the reference's accum_rec recurrences of the colour, feature and normal channels (backward.cu:340-372) CONTRACTED with the
-    // pixel's upstream gradients.  dL/dalpha needs sum_ch (c_ch - accum_rec_ch) dL_dpixel_ch = q - A with q = sum_ch c_ch dL_dpixel_ch of
-    // this entry and A = sum_ch accum_rec_ch dL_dpixel_ch, and A obeys the same recurrence as every accum_rec_ch (A' = alpha q + (1 - alpha) A):
-    // one scalar recurrence instead of 3 + S + 3 of them -- 4 instructions per channel become 2 (+ 3 per group) and S + 5 registers go.
+    // accum_dot: the reference's accum_rec recurrences (colour, feature and normal channels, depth, accumulated alpha: backward.cu:340-372;
+    // last_dL_dT: :436-437) CONTRACTED with the pixel's upstream gradients.  dL/dalpha needs sum_ch (c_ch - accum_rec_ch) dL_dpixel_ch = q - A
+    // with q = sum_ch c_ch dL_dpixel_ch of this entry and A = sum_ch accum_rec_ch dL_dpixel_ch, and A obeys the same recurrence as every
+    // accum_rec_ch (A' = alpha q + (1 - alpha) A): ONE scalar recurrence instead of 3 + S + 3 + 3 of them -- 4 instructions per channel
+    // become 2 and S + 8 registers go.
     // Not the reference's summation order: the difference is rounding of the two sums (measured against the float64 evaluation of the
     // reference's formulas in tests/test_truth_leg.py and in every default bench line, next to the literal fp32 reading).
     float dL_dpixel[3] = {0.f, 0.f, 0.f};
@@ -261,10 +262,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 if (i < S) dL_dpixel_f[i] = dL_dpixels_f[(size_t)i * HW + pix];
         }
     }
-    float accum_depth_rec = 0.f, accum_alpha_rec = 0.f;
     const float final_D = inside ? final_Ts[pix + HW] : 0.f;
     const float final_D2 = inside ? final_Ts[pix + 2 * HW] : 0.f;
-    float last_dL_dT = 0.f;
     const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
     const float dmd_scale = (MRGS_FAR_N * MRGS_NEAR_N) / (MRGS_FAR_N - MRGS_NEAR_N);
     const float bg_dot_dpixel = fmaf(bg[2], dL_dpixel[2], fmaf(bg[1], dL_dpixel[1], bg[0] * dL_dpixel[0]));
@@ -343,7 +342,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             T = T * inv_1ma;                                   // backward.cu:330
             const float w = alpha * T;
             const float one_m_a = 1.0f - alpha;                // the next entry's (1 - last_alpha)
-            // q = sum over the colour, feature and normal channels of (the entry's value) x (the pixel's upstream gradient)
+            // q = sum over every blended quantity of (the entry's value) x (the pixel's upstream gradient): colours, features, normal ...
             float q = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
@@ -364,22 +363,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 q = fmaf(normal[ch], dL_dnormal2D[ch], q);
                 g[MRGS_G_NRM + ch] = w * dL_dnormal2D[ch];
             }
-            float dL_dalpha = q - accum_dot;
-            accum_dot = fmaf(alpha, q, one_m_a * accum_dot);      // backward.cu:340-342 (all channels at once), for the next entry
             const float inv_cd = mrgs_rcp(c_d);
             const float m_d = mscale * (1.0f - MRGS_NEAR_N * inv_cd);
             const float dmd_dd = dmd_scale * inv_cd * inv_cd;
             float dL_dz = (active & (contributor == median_contributor - 1)) ? dL_dmedian_depth : 0.0f;
             const float final_A = 1.0f - T_final;              // recomputed per entry: one instruction for one register
             const float dL_dweight = fmaf(-2.0f * m_d, final_D, fmaf(m_d * m_d, final_A, final_D2)) * dL_dreg;
-            dL_dalpha += dL_dweight - last_dL_dT;
-            last_dL_dT = fmaf(dL_dweight, alpha, (1.0f - alpha) * last_dL_dT);
             const float dL_dmd = 2.0f * w * fmaf(m_d, final_A, -final_D) * dL_dreg;
             dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
-            dL_dalpha = fmaf(c_d - accum_depth_rec, dL_ddepth, dL_dalpha);
-            accum_depth_rec = fmaf(alpha, c_d, one_m_a * accum_depth_rec);
-            dL_dalpha = fmaf(1.0f - accum_alpha_rec, dL_daccum, dL_dalpha);
-            accum_alpha_rec = fmaf(one_m_a, accum_alpha_rec, alpha);
+            // ... and of the three single-channel recurrences of the same form: the depth (value c_d, gradient dL_ddepth), the accumulated
+            // alpha (value 1, gradient dL_daccum) and the distortion weight (value dL_dweight, "gradient" 1: last_dL_dT, backward.cu:436-437)
+            q = fmaf(c_d, dL_ddepth, q);
+            q += dL_daccum;
+            q += dL_dweight;
+            float dL_dalpha = q - accum_dot;
+            accum_dot = fmaf(alpha, q, one_m_a * accum_dot);      // backward.cu:340-372, 436-437 (every recurrence at once), for the next entry
             dL_dalpha *= T;
             dL_dalpha = fmaf(-T_final * inv_1ma, bg_dot_dpixel, dL_dalpha);
             dL_dalpha = active ? dL_dalpha : 0.0f;
