@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
 #endif
 #define MRGS_SHADE_LDS_FLOATS 23552
 #ifndef MRGS_SHADE_FLUSH_EVERY
-#define MRGS_SHADE_FLUSH_EVERY 1
+#define MRGS_SHADE_FLUSH_EVERY 4      // tiles between two looks at the hash table's fill (a barrier pair each: 69.8 us with 1, 62.5 with 4 or 8)
 #endif
 __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_kernel(
     EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha, Map refl, Map rough, const float* __restrict__ lut, int lres,
