@@ -246,22 +246,6 @@ typedef struct MrgsSpmvDesc {
     float* y;
 } MrgsSpmvDesc;
 int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream);
-/* The same products for operators whose vector fits a workgroup's LDS in PANELS of <= 6 144 texels (the long-row levels of the prefilter:
- * 16 x 16 and 32 x 32 cubemaps whole, a 64 x 64 face each): the gathers of x -- the bound of the kernel above -- are served from LDS.
- * Square operators with 16-bit column indices and 16-bit fixed-point weights (row_scale as above); the non-zeros of a row are grouped by
- * panel (column / panel_texels) in ascending panel order, panel_ptr[row * panels + f] is the first non-zero of `row` inside panel f
- * (panel_ptr[nrows * panels] = nnz).
- * rows_per_block: 16, 32, 48 or 64 (0 = 64) rows of a 1 024-thread workgroup.  One launch for up to MRGS_SPMV_MAX_BATCH products. */
-typedef struct MrgsSpmvLdsDesc {
-    int32_t nrows, panels, panel_texels, rows_per_block;
-    const uint32_t* panel_ptr;
-    const uint16_t* col;
-    const uint16_t* val;
-    const float* row_scale;
-    const float* x;
-    float* y;
-} MrgsSpmvLdsDesc;
-int mrgs_csr_spmv3_lds(const MrgsSpmvLdsDesc* descs, int32_t n, void* stream);
 /* cubemap_mip applied n_steps times below `in` [6,res_in,res_in,3] (scene/light.py:74-76): outs[k] = level k + 1 ([6, res_in >> (k+1), ., 3]),
  * `outs` a host array of device pointers; bit-identical to n_steps calls of mrgs_cubemap_mip_forward, one launch per three levels.
  * The backward chain g[k] += cubemap_mip.backward(g[k + 1]) for k = n_levels - 2 ... 0 in place (g[k]: [6, res0 >> k, ., 3], g a host

@@ -68,11 +68,6 @@ class MrgsSpmvDesc(ctypes.Structure):
                 ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p)]
 
 
-class MrgsSpmvLdsDesc(ctypes.Structure):
-    _fields_ = [("nrows", c_int32), ("panels", c_int32), ("panel_texels", c_int32), ("rows_per_block", c_int32), ("panel_ptr", c_void_p),
-                ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p)]
-
-
 class MrgsSurfelParams(ctypes.Structure):
     _fields_ = [("P", c_int32)] + [(n, c_void_p) for n in ("xyz", "scaling_raw", "rotation_raw", "opacity_raw", "refl_raw", "rough_raw",
                                                              "ori_color_raw", "indirect_dc", "indirect_rest", "campos")]
@@ -143,7 +138,6 @@ SYMBOLS = {
     "mrgs_cubemap_filter_fill": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mrgs_csr_spmv3_batched": (ctypes.c_int, [ctypes.POINTER(MrgsSpmvDesc), c_int32, c_void_p]),
-    "mrgs_csr_spmv3_lds": (ctypes.c_int, [ctypes.POINTER(MrgsSpmvLdsDesc), c_int32, c_void_p]),
     "mrgs_cubemap_mip_chain_forward": (ctypes.c_int, [c_int32, c_int32, c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
     "mrgs_cubemap_mip_chain_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_void_p), c_void_p]),
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),

@@ -845,6 +845,10 @@ __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_
     csr_spmv3_body<G, IDX, WT>((int)blockIdx.x, nrows, row_ptr, col, val, row_scale, x, y);
 }
 
+// (Tried in round 3 and removed: the long-row levels with their vector resident in LDS -- 16 x 16 / 32 x 32 cubemaps whole, a 64 x 64 face
+// as one of six panels, 16 bytes per texel, a workgroup per block of rows walking the panels its rows touch.  Correct, and 80-150 us per
+// call against 50 us for the streaming kernel below: one 1 024-thread workgroup per CU (or two of 512) in lock step through
+// stage / barrier / consume phases keeps fewer requests in flight than 2 500 independent 256-thread workgroups do, whatever the gathers cost.)
 // Several independent SpMVs in ONE launch (the levels of the environment prefilter: four launches of 9-18 us each were mostly the
 // latency of streaming each matrix with a fraction of the chip; together the matrices stream with every wave slot busy).  A workgroup
 // finds its product from a table in the kernel arguments (wave-uniform scan) and runs the body of its storage format.
@@ -865,117 +869,6 @@ __global__ void __launch_bounds__(256) csr_spmv3_batched_kernel(SpmvBatch B)
     case 5: csr_spmv3_body<64, uint16_t, float>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
     case 6: csr_spmv3_body<64, uint32_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
     default: csr_spmv3_body<64, uint32_t, float>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
-    }
-}
-
-// ---- the same products with the vector resident in LDS -----------------------------------------------------------------------------
-// csr_spmv3_batched_kernel streams its matrices at 2 TB/s and is NOT bound by that stream: every non-zero gathers 12 bytes of x at a
-// lane-private address, and the vector memory path serves about one such lane per cycle and CU (27.7 M gathers in 50 us on 256 CUs).  LDS
-// serves them an order of magnitude faster.  The long-row levels are small cubemaps: 16 x 16 (1 536 texels) and 32 x 32 (6 144) fit a
-// workgroup's LDS whole, a 64 x 64 face (4 096 texels) fits as one of six PANELS.  The non-zeros of a row are sorted by column, hence by
-// panel: `panel_ptr[row * F + f]` starts the non-zeros of `row` inside panel f.  A workgroup owns a block of rows, walks the panels its
-// rows touch -- panel into LDS (16 bytes per texel), barrier, every wave its rows' segments with a wave per row -- and keeps three partial
-// sums per row and lane in registers across the panels; one reduction and one store per row at the end.  Same weights (16-bit fixed point
-// with the row's scale), deterministic; the summation order inside a row differs from the kernel above (lane partition per panel).
-#define MRGS_SPMV_LDS_THREADS 1024
-#define MRGS_SPMV_LDS_TEXELS 6144                 // 96 KB of float4
-#define MRGS_SPMV_LDS_ROWS_PER_WAVE 4
-#define MRGS_SPMV_LDS_MAX_PANELS 8
-struct SpmvLdsSeg {
-    int nrows, panels, panel_texels, rows_per_block, first_block, pad;
-    const uint32_t* panel_ptr;          // [nrows * panels + 1]
-    const uint16_t* col;
-    const uint16_t* val;
-    const float* row_scale;
-    const float* x;
-    float* y;
-};
-struct SpmvLdsBatch { int n; SpmvLdsSeg seg[MRGS_SPMV_MAX_BATCH]; };
-__global__ void __launch_bounds__(MRGS_SPMV_LDS_THREADS) csr_spmv3_lds_kernel(SpmvLdsBatch B)
-{
-    __shared__ float4 s_x[MRGS_SPMV_LDS_TEXELS];
-    int i = 0;
-    for (int k = 1; k < B.n; ++k) i = ((int)blockIdx.x >= B.seg[k].first_block) ? k : i;
-    const SpmvLdsSeg& S = B.seg[i];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int block = (int)blockIdx.x - S.first_block;
-    const int rpw = S.rows_per_block / (MRGS_SPMV_LDS_THREADS / 64);          // rows of a wave (<= MRGS_SPMV_LDS_ROWS_PER_WAVE)
-    const int r0 = block * S.rows_per_block + wave * rpw;
-    const int F = S.panels, Tp = S.panel_texels;
-    float acc[MRGS_SPMV_LDS_ROWS_PER_WAVE][3];
-#pragma unroll
-    for (int r = 0; r < MRGS_SPMV_LDS_ROWS_PER_WAVE; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; acc[r][2] = 0.f; }
-    const int n_texels_total = S.nrows;                                         // square operators: as many columns as rows
-    // the segment bounds of the wave's rows in every panel, fetched in one go (a load and a barrier per panel cost 2 us each: 89 us)
-    uint32_t pp[MRGS_SPMV_LDS_ROWS_PER_WAVE][MRGS_SPMV_LDS_MAX_PANELS + 1];
-#pragma unroll
-    for (int r = 0; r < MRGS_SPMV_LDS_ROWS_PER_WAVE; ++r) {
-        const int row = r0 + r;
-        const bool have = r < rpw && row < S.nrows;
-#pragma unroll
-        for (int f = 0; f <= MRGS_SPMV_LDS_MAX_PANELS; ++f) pp[r][f] = (have && f <= F) ? S.panel_ptr[(size_t)row * F + f] : 0u;
-    }
-    // which panels does this workgroup need at all (bit f)?  One barrier for all of them.
-    unsigned need = 0u;
-#pragma unroll
-    for (int r = 0; r < MRGS_SPMV_LDS_ROWS_PER_WAVE; ++r)
-#pragma unroll
-        for (int f = 0; f < MRGS_SPMV_LDS_MAX_PANELS; ++f) need |= (f < F && pp[r][f + 1] > pp[r][f]) ? (1u << f) : 0u;
-    {
-        __shared__ unsigned s_need;
-        if (threadIdx.x == 0) s_need = 0u;
-        __syncthreads();
-        if (lane == 0 && need) atomicOr(&s_need, need);
-        __syncthreads();
-        need = s_need;
-    }
-#pragma unroll
-    for (int f = 0; f < MRGS_SPMV_LDS_MAX_PANELS; ++f) {
-        if (f >= F || !((need >> f) & 1u)) continue;                            // (workgroup-uniform)
-        __syncthreads();                                                         // everyone is done with the previous panel
-        const int t0 = f * Tp, nt = min(Tp, n_texels_total - t0);
-        for (int t = threadIdx.x; t < nt; t += MRGS_SPMV_LDS_THREADS) {
-            const Tex3 v = *reinterpret_cast<const Tex3*>(S.x + 3 * (size_t)(t0 + t));
-            s_x[t] = make_float4(v.x, v.y, v.z, 0.f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < MRGS_SPMV_LDS_ROWS_PER_WAVE; ++r) {
-            const int row = r0 + r;
-            if (r >= rpw || row >= S.nrows) continue;
-            const uint32_t a = pp[r][f], b = pp[r][f + 1];
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            uint32_t k = a + lane;
-            for (; k + 3 * 64 < b; k += 4 * 64) {                                // four (index, weight) pairs in flight per lane
-                uint32_t c[4];
-                float w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { c[u] = S.col[k + u * 64]; w[u] = (float)S.val[k + u * 64]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 v = s_x[(int)c[u] - t0];
-                    s0 = fmaf(w[u], v.x, s0); s1 = fmaf(w[u], v.y, s1); s2 = fmaf(w[u], v.z, s2);
-                }
-            }
-            for (; k < b; k += 64) {
-                const float w = (float)S.val[k];
-                const float4 v = s_x[(int)S.col[k] - t0];
-                s0 = fmaf(w, v.x, s0); s1 = fmaf(w, v.y, s1); s2 = fmaf(w, v.z, s2);
-            }
-            acc[r][0] += s0; acc[r][1] += s1; acc[r][2] += s2;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < MRGS_SPMV_LDS_ROWS_PER_WAVE; ++r) {
-        const int row = r0 + r;
-        if (r >= rpw || row >= S.nrows) continue;
-        float s0 = acc[r][0], s1 = acc[r][1], s2 = acc[r][2];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64); }
-        if (lane == 0) {
-            const float sc = S.row_scale[row];
-            S.y[3 * (size_t)row] = s0 * sc; S.y[3 * (size_t)row + 1] = s1 * sc; S.y[3 * (size_t)row + 2] = s2 * sc;
-        }
     }
 }
 
@@ -1201,29 +1094,6 @@ int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream)
     }
     B.total_blocks = blocks;
     hipLaunchKernelGGL(csr_spmv3_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B);
-    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
-}
-
-int mrgs_csr_spmv3_lds(const MrgsSpmvLdsDesc* descs, int32_t n, void* stream)
-{
-    if (!descs || n < 1 || n > MRGS_SPMV_MAX_BATCH) return MRGS_E_BAD_ARG;
-    SpmvLdsBatch B;
-    B.n = n;
-    int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        const MrgsSpmvLdsDesc& d = descs[i];
-        if (d.nrows < 1 || d.panels < 1 || d.panels > MRGS_SPMV_LDS_MAX_PANELS || d.panel_texels < 1 || d.panel_texels > MRGS_SPMV_LDS_TEXELS || !d.panel_ptr || !d.col || !d.val || !d.row_scale ||
-            !d.x || !d.y || (int64_t)d.panels * d.panel_texels < d.nrows || d.nrows > 65536)
-            return MRGS_E_BAD_ARG;
-        const int waves = MRGS_SPMV_LDS_THREADS / 64;
-        int rpb = d.rows_per_block > 0 ? d.rows_per_block : waves * MRGS_SPMV_LDS_ROWS_PER_WAVE;
-        if (rpb % waves != 0 || rpb / waves > MRGS_SPMV_LDS_ROWS_PER_WAVE) return MRGS_E_BAD_ARG;
-        SpmvLdsSeg& S = B.seg[i];
-        S.nrows = d.nrows; S.panels = d.panels; S.panel_texels = d.panel_texels; S.rows_per_block = rpb; S.first_block = blocks; S.pad = 0;
-        S.panel_ptr = d.panel_ptr; S.col = d.col; S.val = d.val; S.row_scale = d.row_scale; S.x = d.x; S.y = d.y;
-        blocks += (d.nrows + rpb - 1) / rpb;
-    }
-    hipLaunchKernelGGL(csr_spmv3_lds_kernel, dim3((unsigned)blocks), dim3(MRGS_SPMV_LDS_THREADS), 0, (hipStream_t)stream, B);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
