@@ -20,6 +20,12 @@
 
 // 1: single stage buffer, the copy of chunk c+1 is issued after chunk c has been blended (5.5 KB LDS per wave -> 7 waves
 //    per SIMD; the copy latency is covered by the other waves).  2: double buffer, copy overlapped inside the wave (11 KB).
+#ifndef MRGS_FWD_REFINE
+#define MRGS_FWD_REFINE 1
+#endif
+#ifndef MRGS_FWD_REFINE_LIVE
+#define MRGS_FWD_REFINE_LIVE 24
+#endif
 #ifndef MRGS_FWD_STAGES
 #define MRGS_FWD_STAGES 1
 #endif
@@ -30,13 +36,17 @@ extern "C" int mrgs_wave_stats_fwd(unsigned long long* host, int n)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stats_fwd), sizeof(unsigned long long) * n);
 }
+// timing experiment: only the items with at least this many list entries do their work (images are wrong, the duration of a
+// heavy wave WITHOUT its neighbours is what gets measured)
+__device__ int g_ws_min_total = 0;
+extern "C" int mrgs_wave_stats_min_total(int n) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_min_total), &n, sizeof(int)); }
 #endif
 
 template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
-    const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
+    const float4* __restrict__ rec, const float4* __restrict__ cull, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
     uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */,
     uint32_t* __restrict__ work_hint, int slots)
@@ -60,10 +70,14 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const int HW = H * W;
     const int pix = W * pyi + pxi;
 
+#ifdef MRGS_WAVE_STATS
+    const int total = (int)(range.y - range.x) >= g_ws_min_total ? (int)(range.y - range.x) : 0;
+#else
     const int total = (int)(range.y - range.x);
+#endif
 #ifdef MRGS_WAVE_STATS
     const unsigned long long ws_t0 = wall_clock64(), ws_c0 = __builtin_amdgcn_s_memtime();
-    unsigned ws_blend = 0;
+    unsigned ws_blend = 0, ws_le4 = 0, ws_le8 = 0, ws_le16 = 0, ws_blend_le8 = 0;
 #endif
     // heavy items first in line for issue slots (priority class chosen by blend_order_kernel)
     if (prio == 3u) __builtin_amdgcn_s_setprio(3);
@@ -87,10 +101,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const uint8_t* qm = qmask + range.x;
     uint8_t* cf = cflag + (size_t)range.x * 4 + quad;       // this quadrant's "blended by some pixel" flag of every list entry
     uint32_t id1 = 0, id2 = 0, q1 = 0, q2 = 0;
+    uint32_t idc = 0, idn = 0;       // ids of the chunk being blended / of the one staged behind it (MRGS_FWD_REFINE)
     uint64_t mask_cur;
     {
         uint32_t id0 = 0, q0 = 0;
         if (lane < total) { id0 = plist[lane]; q0 = qm[lane]; }
+        idc = id0;
         if (MRGS_CHUNK + lane < total) { id1 = plist[MRGS_CHUNK + lane]; q1 = qm[MRGS_CHUNK + lane]; }
         if (2 * MRGS_CHUNK + lane < total) { id2 = plist[2 * MRGS_CHUNK + lane]; q2 = qm[2 * MRGS_CHUNK + lane]; }
         const bool cand0 = (q0 >> quad) & 1u;
@@ -107,6 +123,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
+            idn = id1;
             id1 = id2; q1 = q2;
             id2 = 0; q2 = 0;
             if (base + 3 * MRGS_CHUNK + lane < total) { id2 = plist[base + 3 * MRGS_CHUNK + lane]; q2 = qm[base + 3 * MRGS_CHUNK + lane]; }
@@ -114,6 +131,25 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         if (MRGS_FWD_STAGES == 2) stage_next();
 
         uint64_t m = mask_cur;
+#if MRGS_FWD_REFINE
+        // Few pixels of the block still alive (a silhouette block late in its list): the cull that tile_ranges_kernel evaluated
+        // against the whole 8x8 block is evaluated again against the bounding rectangle of the LIVE pixels, all 64 entries of
+        // the chunk at once (lane = entry).  An entry it removes reaches alpha >= 1/255 at no live pixel, i.e. every lane would
+        // have failed the test below: same images, and the longest waves of the launch -- which set its duration, one
+        // issue slot per ~4 cycles each -- walk fewer entries.
+        {
+            const uint64_t live = __builtin_amdgcn_ballot_w64(!done);
+            if (m != 0ull && __builtin_popcountll(live) <= MRGS_FWD_REFINE_LIVE) {
+                const int r0 = __builtin_ctzll(live) >> 3, r1 = (63 - __builtin_clzll(live)) >> 3;
+                uint32_t cols = (uint32_t)(live | (live >> 32));
+                cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
+                const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols);
+                const CullConic cc = mrgs_cull_load(cull, idc);
+                const bool touch = mrgs_block_may_touch(cc, (float)(bx * 8 + c0), (float)(by * 8 + r0), (float)(c1 - c0), (float)(r1 - r0));
+                m &= __builtin_amdgcn_ballot_w64(touch);
+            }
+        }
+#endif
         work += (uint32_t)__builtin_popcountll(m);
         const StageBuf<SF>& sb = stage[c % MRGS_FWD_STAGES];
         uint64_t contributed = 0ull;          // bit j: some live pixel of the block is hit by entry base + j
@@ -128,9 +164,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             Hit h;
             const bool hit = mrgs_intersect(sg, px, py, h);
             const bool ok = hit & !done;
+#ifdef MRGS_WAVE_STATS
+            const int ws_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!done));     // how thin the wave runs near its end
+            ws_le4 += ws_live <= 4; ws_le8 += ws_live <= 8; ws_le16 += ws_live <= 16;
+#endif
             if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return;
 #ifdef MRGS_WAVE_STATS
-            ws_blend++;
+            ws_blend++; ws_blend_le8 += ws_live <= 8;
 #endif
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             contributed |= 1ull << j;          // (a superset of "blended": a pixel may terminate on it instead; the backward sorts that out)
@@ -198,6 +238,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         if (base + lane < total) cf[(size_t)(base + lane) * 4] = (uint8_t)((contributed >> lane) & 1ull);
         if (MRGS_FWD_STAGES == 1) stage_next();
         mask_cur = mask_nxt;
+        idc = idn;
     }
     mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
 
@@ -211,10 +252,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     if (lane == 0 && b < 65536) {
         unsigned long long* w = g_wave_stats_fwd + 8 * (size_t)b;
         w[0] = ws_t0; w[1] = wall_clock64(); w[2] = __builtin_amdgcn_s_memtime() - ws_c0;
-        w[3] = ((unsigned long long)(work - 3u * ws_blend) << 32) | ws_blend; w[4] = ((unsigned long long)0 << 32) | (unsigned)total;
+        w[3] = ((unsigned long long)(work - 3u * ws_blend) << 32) | ws_blend; w[4] = ((unsigned long long)ws_blend_le8 << 32) | (unsigned)total;
         w[6] = item_est[tile * 4 + quad];          // the estimate the queues were built from, next to the measured work
         w[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
-        w[7] = 0;
+        w[7] = ((unsigned long long)ws_le4 << 40) | ((unsigned long long)ws_le8 << 20) | ws_le16;   // entries tested with <= 4 / 8 / 16 live pixels
     }
 #endif
     if (inside) {
@@ -249,6 +290,14 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 // the head of every step (the one-entry kernel fetches the next entry's geometry a step ahead) come on top.  Packed arithmetic pays
 // where the issue rate is the bound -- and there (the backward blend) it costs the occupancy that hides the latency.
 // Build with EXTRA=-DMRGS_FWD_PAIRS to get it.
+// The same two entries per step in plain instructions -- both intersections side by side in one basic block, pinned in front of the first
+// blend's branch, so that they fill each other's latencies -- measured too: 0.157 ms against 0.146-0.149 (S = 8: 0.178 against 0.169), and
+// 0.148 against 0.134 with the max-ilp scheduler below.  The longest waves run alone on their SIMDs near the end (tools/wave_stats.py
+// fwd 1500: the heaviest wave takes 179 us with 690 waves on the chip, 192 us with all 10 000) and a lone wave pays ~8 cycles per
+// DEPENDENT instruction against ~3 with four independent ones in flight (tools/ubench/valu_ilp.hip) -- what helped is letting the
+// compiler order the instructions of ONE entry for latency (Makefile: -amdgpu-sched-strategy=max-ilp, 0.142 -> 0.134 ms; S = 8:
+// 0.163 -> 0.157), which finds the independent work inside the intersection and the twelve accumulations without the extra registers,
+// the exposed LDS reads after a skipped blend and the wasted second entry of an odd chunk that the two-entry loop brings.
 #ifdef MRGS_FWD_PAIRS
 #include "mrgs_render_fwd_pairs.h"
 #define MRGS_FWD_KERNEL render_fwd_pairs_kernel
@@ -266,7 +315,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
     hipLaunchKernelGGL((MRGS_FWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, FVV>>())
+                       g.rec, g.cull, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, FVV>>())
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
     if (cfg.S == 0) LAUNCH(0, false);

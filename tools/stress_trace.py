@@ -59,8 +59,8 @@ def one_case(seed, dev):
     bg = torch.rand(3, generator=g)
     mod = rf(0.7, 1.5)
     leaf = lambda t, dt, dv: t.to(dt).to(dv).clone().requires_grad_(True)
-    def run(hip):
-        dt, dv = (torch.float32, dev) if hip else (torch.float64, "cpu")
+    def run(hip, ref_dtype=torch.float64):
+        dt, dv = (torch.float32, dev) if hip else (ref_dtype, "cpu")
         L = dict(means=leaf(sc.means3D, dt, dv), scales=leaf(sc.scales, dt, dv), rot=leaf(sc.rotations, dt, dv), op=leaf(opac, dt, dv),
                  col=leaf(colors, dt, dv), oth=leaf(others, dt, dv), o=leaf(o, dt, dv), d=leaf(d, dt, dv))
         if hip:
@@ -76,9 +76,9 @@ def one_case(seed, dev):
             dd = L["d"].reshape(n, 3)
             ok = (dd.abs().sum(-1) > 0)
             safe_d = torch.where(ok[:, None], dd, torch.ones_like(dd))
-            r = sto.trace_dense(L["o"].reshape(n, 3), safe_d, L["means"], L["scales"], L["rot"], L["op"], L["col"], L["oth"], bg.double(), mod)
-            okf = ok.double()
-            out = dict(rgb=r["rgb"] * okf[:, None] + bg.double() * (1 - okf[:, None]), dpt=r["dpt"] * okf, acc=r["acc"] * okf, norm=r["norm"] * okf[:, None],
+            r = sto.trace_dense(L["o"].reshape(n, 3), safe_d, L["means"], L["scales"], L["rot"], L["op"], L["col"], L["oth"], bg.to(dt), mod)
+            okf = ok.to(dt)
+            out = dict(rgb=r["rgb"] * okf[:, None] + bg.to(dt) * (1 - okf[:, None]), dpt=r["dpt"] * okf, acc=r["acc"] * okf, norm=r["norm"] * okf[:, None],
                        dist=r["dist"] * okf, aux=r["aux"] * okf[:, None])
         return L, out
     Lh, oh = run(True)
@@ -106,7 +106,17 @@ def one_case(seed, dev):
             e = float("inf")
         if e > gworst:
             gworst, gname = e, k
-    return dict(seed=seed, P=P, kind=kind, rays=n, off=n_off, fwd_worst=worst, grad_worst=gworst, grad_of=gname, hits_max=int(0))
+    res = dict(seed=seed, P=P, kind=kind, rays=n, off=n_off, fwd_worst=worst, grad_worst=gworst, grad_of=gname, hits_max=int(0))
+    if gworst > 5e-3:
+        # how well conditioned is this gradient?  The same dense statement evaluated in float32 on the CPU, against its float64 self.
+        try:
+            L32, o32 = run(False, torch.float32)
+            sum((o32[k] * (up[k] * shp(k).float())).sum() for k in oh).backward()
+            a, b = L32[gname].grad.double(), Lr[gname].grad
+            res["dense_f32_vs_f64"] = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-9)
+        except Exception as ex:       # noqa: BLE001
+            res["dense_f32_error"] = repr(ex)[:200]
+    return res
 
 
 def main():

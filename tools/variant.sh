@@ -11,8 +11,9 @@ B=$(basename $F .hip)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -munsafe-fp-atomics"
 case $B in
   mrgs_preprocess) FLAGS="$FLAGS -ffp-contract=off -fno-slp-vectorize";;
-  mrgs_render_bwd) FLAGS="$FLAGS -ffp-contract=off -fno-slp-vectorize";;
-  mrgs_sort|mrgs_binning|mrgs_render_fwd|mrgs_bvh|mrgs_surfel_trace) FLAGS="$FLAGS -ffp-contract=off";;
+  mrgs_render_bwd) FLAGS="$FLAGS -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp";;
+  mrgs_render_fwd) FLAGS="$FLAGS -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp";;
+  mrgs_sort|mrgs_binning|mrgs_bvh|mrgs_surfel_trace) FLAGS="$FLAGS -ffp-contract=off";;
 esac
 /opt/rocm/bin/hipcc $FLAGS $X -c $C/$B.hip -o $O/${B}_$N.o
 OBJS=$(ls $C/*.o | grep -v "/$B.o")

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, numpy as np
 from materialrefgs_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'tools', 'scratch', 'libmrgs_stats.so')
+_lib.LIB_PATH = os.environ.get('MRGS_STATS_LIB', os.path.join(ROOT, 'tools', 'scratch', 'libmrgs_stats.so'))
 from helpers import HipRender
 from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera, upstream_grads
 
@@ -16,8 +16,12 @@ cam = orbit_camera(0, 800, 800)
 L = _lib.lib()
 nb = 65536
 buf = (ctypes.c_ulonglong * (8 * nb))()
-for rep in range(3):
-    hr = HipRender(sc, cam, dev); torch.cuda.synchronize()
+if FWD and len(sys.argv) > 3:
+    L.mrgs_wave_stats_min_total(ctypes.c_int(int(sys.argv[3])))
+rs = None
+for rep in range(4):
+    hr = HipRender(sc, cam, dev, rs=rs); torch.cuda.synchronize()
+    rs = hr.rs   # the same camera tensors again: from the second render on the work hint of this camera is warm, as in a training loop
     hr.backward(*upstream_grads(S, 800, 800)); torch.cuda.synchronize()
     (L.mrgs_wave_stats_fwd if FWD else L.mrgs_wave_stats)(buf, ctypes.c_int(8 * nb))
 a = np.array(buf[:], dtype=np.uint64).reshape(-1, 8)
@@ -78,3 +82,31 @@ for lo, hi in ((0, 50), (50, 100), (100, 150), (150, 200), (200, 300), (300, 400
     m = (act >= lo) & (act < hi)
     if m.sum():
         print(f"  active [{lo},{hi}): waves {m.sum()} duration mean {dur[m].mean():.1f} max {dur[m].max():.1f} us, end max {t1[m].max():.1f}, us per active iter {dur[m].sum() / max(act[m].sum(), 1):.3f}")
+
+if FWD:
+    # how thin the forward waves run: entries tested while only a few pixels of the block are still alive
+    le4 = (a[:, 7] >> np.uint64(40)).astype(np.float64); le8 = ((a[:, 7] >> np.uint64(20)) & np.uint64(0xfffff)).astype(np.float64)
+    le16 = (a[:, 7] & np.uint64(0xfffff)).astype(np.float64); bl8 = chunks   # upper word of w[4] in the forward build
+    tested = iters
+    print(f"entries tested {tested.sum():.0f}: with <=4 live px {le4.sum():.0f}  <=8 {le8.sum():.0f}  <=16 {le16.sum():.0f}; blended with <=8 live {bl8.sum():.0f} of {act.sum():.0f}")
+    o = np.argsort(-dur)[:200]
+    print(f"  200 longest waves: tested {tested[o].sum():.0f}  <=4 {le4[o].sum():.0f}  <=8 {le8[o].sum():.0f}  <=16 {le16[o].sum():.0f}  blended<=8 {bl8[o].sum():.0f} of {act[o].sum():.0f}")
+    for i in o[:10]:
+        print(f"   dur {dur[i]:.1f} tested {tested[i]:.0f} blended {act[i]:.0f} le4 {le4[i]:.0f} le8 {le8[i]:.0f} le16 {le16[i]:.0f} bl8 {bl8[i]:.0f}")
+    cost = iters + 3 * act; est = a[:, 6].astype(np.float64)
+    sc_, se_ = np.bincount(inv, weights=cost), np.bincount(inv, weights=est)
+    print(f"per SIMD: measured cost max/mean {sc_.max()/sc_.mean():.3f} p90/mean {np.percentile(sc_,90)/sc_.mean():.3f}; estimate max/mean {se_.max()/se_.mean():.3f}; "
+          f"corr(cost, finish) {np.corrcoef(sc_, last)[0,1]:.3f} corr(est, finish) {np.corrcoef(se_, last)[0,1]:.3f} corr(waves, finish) {np.corrcoef(cnt, last)[0,1]:.3f}")
+    print(f"estimate vs measured per wave: corr {np.corrcoef(est, cost)[0,1]:.4f}, sum est {est.sum():.0f} sum cost {cost.sum():.0f}, |diff| mean {np.abs(est-cost).mean():.1f}")
+    first = np.full(len(uk), 1e9); np.minimum.at(first, inv, t0)
+    print("first wave start per SIMD p0/50/100:", np.round(np.percentile(first, [0, 50, 100]), 1))
+    # cycles per cost unit on each SIMD
+    rate = (last - first) / sc_
+    print("us per cost unit per SIMD p10/50/90/max:", np.round(np.percentile(rate, [10, 50, 90, 100]), 4))
+    for q in (0, 1, 2, 3):
+        mq = (uk % 4) == q
+        print(f"  simd {q}: finish mean {last[mq].mean():.1f} cost mean {sc_[mq].mean():.0f}")
+    xs = uk // (4 * 16 * 2 * 8)
+    for x in range(8):
+        mx = xs == x
+        print(f"  xcc {x}: SIMDs {mx.sum()} finish mean {last[mx].mean():.1f} max {last[mx].max():.1f} cost mean {sc_[mx].mean():.0f} max {sc_[mx].max():.0f}")
