@@ -230,7 +230,11 @@ int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float c
 /* y[nrows,3] = A x for a CSR matrix A (row_ptr[nrows+1]).  The kernel is bound by streaming A from HBM, so A may be stored
  * compactly: col holds uint16 (col_bytes 2, <= 65536 columns) or uint32 (4) column indices; val holds fp32 weights (val_bytes 4,
  * row_scale may be NULL) or 16-bit fixed-point weights q (val_bytes 2) with weight = q * row_scale[row].  lanes_per_row: 4 for
- * short rows, 64 for rows of hundreds of non-zeros. */
+ * short rows, 64 for rows of hundreds of non-zeros.
+ * val_bytes 8 = BLOCKED rows (the long rows of these filters touch runs of consecutive texels): row_ptr counts blocks, col holds the
+ * uint16 block index (columns 4 b .. 4 b + 3), val four uint16 fixed-point weights per block (lowest column first; 0 where the row has
+ * no entry), weight = q * row_scale[row].  Needs col_bytes 2, lanes_per_row 64, nrows % 4 == 0 (square filters: x has nrows texels), x
+ * 16-byte and val 8-byte aligned; MRGS_E_BAD_ARG otherwise. */
 int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const void* val, int32_t val_bytes,
                    const float* row_scale, const float* x, float* y, int32_t lanes_per_row, void* stream);
 /* Up to MRGS_SPMV_MAX_BATCH independent products of the kind above in ONE launch (`descs` is a host array): the levels of

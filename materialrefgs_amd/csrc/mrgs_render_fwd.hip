@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     uint8_t* cf = cflag + (size_t)range.x * 4 + quad;       // this quadrant's "blended by some pixel" flag of every list entry
     uint32_t id1 = 0, id2 = 0, q1 = 0, q2 = 0;
     uint32_t idc = 0, idn = 0;       // ids of the chunk being blended / of the one staged behind it (MRGS_FWD_REFINE)
+
     uint64_t mask_cur;
     {
         uint32_t id0 = 0, q0 = 0;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
                 uint32_t cols = (uint32_t)(live | (live >> 32));
                 cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
                 const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols);
-                const CullConic cc = mrgs_cull_load(cull, idc);
+                const CullConic cc = mrgs_cull_load(cull, idc);     // (fetching it a chunk ahead into registers: no gain measured)
                 const bool touch = mrgs_block_may_touch(cc, (float)(bx * 8 + c0), (float)(by * 8 + r0), (float)(c1 - c0), (float)(r1 - r0));
                 m &= __builtin_amdgcn_ballot_w64(touch);
             }

@@ -837,6 +837,67 @@ __device__ __forceinline__ void csr_spmv3_body(int block, int nrows, const uint3
     }
 }
 
+// Blocked rows ("val_bytes == 8"): the long rows of the GGX / cosine filters touch runs of ~10-17 consecutive texels, so a row is stored
+// as blocks of four consecutive columns -- a 16-bit block index (column / 4) and four 16-bit fixed-point weights (zero where the row has
+// no entry; 0.88-0.93 of the slots are used) = 2.8 bytes per non-zero instead of 4, and ONE 48-byte gather of x (three 16-byte loads,
+// 4 texels x 3 channels) instead of four gathers of 12 bytes.  64 lanes per row, one block per lane and round.  row_ptr counts blocks.
+#ifndef MRGS_SPMV_BLK_ROUNDS
+#define MRGS_SPMV_BLK_ROUNDS 2      // measured in the batched prefilter launch: 2 rounds 43.5 us, 4 rounds 51.5 (66 VGPRs), 8 rounds 47.7; plain CSR 51.4
+#endif
+__device__ __forceinline__ void csr_spmv3_blk4_body(int block, int nrows, const uint32_t* __restrict__ row_ptr, const uint16_t* __restrict__ bcol,
+                                                    const uint2* __restrict__ bval, const float* __restrict__ row_scale,
+                                                    const float* __restrict__ x, float* __restrict__ y)
+{
+    const int gid = (block * 256 + threadIdx.x) / 64, sub = threadIdx.x % 64;
+    const int r = min(gid, nrows - 1);
+    const uint32_t a = row_ptr[r], b = gid < nrows ? row_ptr[r + 1] : a;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    auto consume = [&](uint32_t c, uint2 w, const float4& v0, const float4& v1, const float4& v2) {
+        const float w0 = (float)(w.x & 0xFFFFu), w1 = (float)(w.x >> 16), w2 = (float)(w.y & 0xFFFFu), w3 = (float)(w.y >> 16);
+        s0 = fmaf(w0, v0.x, s0); s1 = fmaf(w0, v0.y, s1); s2 = fmaf(w0, v0.z, s2);
+        s0 = fmaf(w1, v0.w, s0); s1 = fmaf(w1, v1.x, s1); s2 = fmaf(w1, v1.y, s2);
+        s0 = fmaf(w2, v1.z, s0); s1 = fmaf(w2, v1.w, s1); s2 = fmaf(w2, v2.x, s2);
+        s0 = fmaf(w3, v2.y, s0); s1 = fmaf(w3, v2.z, s1); s2 = fmaf(w3, v2.w, s2);
+    };
+    uint32_t k = a + sub;
+    // MRGS_SPMV_BLK_ROUNDS rounds in flight: a wave has only 64 x 10 bytes of the matrix per round, and the gather of x depends on it
+    for (; k + (MRGS_SPMV_BLK_ROUNDS - 1) * 64 < b; k += MRGS_SPMV_BLK_ROUNDS * 64) {
+        uint32_t c[MRGS_SPMV_BLK_ROUNDS];
+        uint2 w[MRGS_SPMV_BLK_ROUNDS];
+        float4 v[MRGS_SPMV_BLK_ROUNDS][3];
+#pragma unroll
+        for (int u = 0; u < MRGS_SPMV_BLK_ROUNDS; ++u) { c[u] = bcol[k + u * 64]; w[u] = bval[k + u * 64]; }
+#pragma unroll
+        for (int u = 0; u < MRGS_SPMV_BLK_ROUNDS; ++u) {
+            const float4* p = reinterpret_cast<const float4*>(x) + 3 * (size_t)c[u];
+            v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
+        }
+#pragma unroll
+        for (int u = 0; u < MRGS_SPMV_BLK_ROUNDS; ++u) consume(c[u], w[u], v[u][0], v[u][1], v[u][2]);
+    }
+    for (; k < b; k += 64) {
+        const uint32_t c0 = bcol[k];
+        const uint2 w0 = bval[k];
+        const float4* p0 = reinterpret_cast<const float4*>(x) + 3 * (size_t)c0;
+        const float4 a0 = p0[0], a1 = p0[1], a2 = p0[2];
+        consume(c0, w0, a0, a1, a2);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64);
+    }
+    if (sub == 0 && gid < nrows) {
+        const float sc = row_scale[r];
+        y[3 * (size_t)r] = s0 * sc; y[3 * (size_t)r + 1] = s1 * sc; y[3 * (size_t)r + 2] = s2 * sc;
+    }
+}
+__global__ void __launch_bounds__(256) csr_spmv3_blk4_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const uint16_t* __restrict__ bcol,
+                                                             const uint2* __restrict__ bval, const float* __restrict__ row_scale,
+                                                             const float* __restrict__ x, float* __restrict__ y)
+{
+    csr_spmv3_blk4_body((int)blockIdx.x, nrows, row_ptr, bcol, bval, row_scale, x, y);
+}
+
 template <int G, typename IDX, typename WT>
 __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_t* __restrict__ row_ptr, const IDX* __restrict__ col,
                                                         const WT* __restrict__ val, const float* __restrict__ row_scale,
@@ -860,7 +921,8 @@ __global__ void __launch_bounds__(256) csr_spmv3_batched_kernel(SpmvBatch B)
     for (int k = 1; k < B.n; ++k) i = ((int)blockIdx.x >= B.seg[k].first_block) ? k : i;
     const SpmvSeg& S = B.seg[i];
     const int blk = (int)blockIdx.x - S.first_block;
-    switch (S.fmt) {   // bit 2: 64 lanes per row (else 4); bit 1: 32-bit column indices (else 16); bit 0: fp32 weights (else 16-bit fixed point)
+    switch (S.fmt) {   // bit 2: 64 lanes per row (else 4); bit 1: 32-bit column indices (else 16); bit 0: fp32 weights (else 16-bit fixed point); 8: blocked rows
+    case 8: csr_spmv3_blk4_body(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint2*)S.val, S.row_scale, S.x, S.y); break;
     case 0: csr_spmv3_body<4, uint16_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
     case 1: csr_spmv3_body<4, uint16_t, float>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
     case 2: csr_spmv3_body<4, uint32_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint32_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
@@ -1055,9 +1117,15 @@ int mrgs_cubemap_filter_fill(int32_t res, int32_t kind, float roughness, float c
 int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int32_t col_bytes, const void* val, int32_t val_bytes,
                    const float* row_scale, const float* x, float* y, int32_t lanes_per_row, void* stream)
 {
-    if (nrows < 1 || !row_ptr || !col || !val || !x || !y || (col_bytes != 2 && col_bytes != 4) || (val_bytes != 2 && val_bytes != 4)) return MRGS_E_BAD_ARG;
-    if (val_bytes == 2 && !row_scale) return MRGS_E_BAD_ARG;
+    if (nrows < 1 || !row_ptr || !col || !val || !x || !y || (col_bytes != 2 && col_bytes != 4) || (val_bytes != 2 && val_bytes != 4 && val_bytes != 8)) return MRGS_E_BAD_ARG;
+    if (val_bytes != 4 && !row_scale) return MRGS_E_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (val_bytes == 8) {     // blocked rows: 16-bit block indices, 4 x 16-bit weights per block, x read in 16-byte pieces
+        if (col_bytes != 2 || lanes_per_row < 64 || (nrows & 3) || ((uintptr_t)x & 15u) || ((uintptr_t)val & 7u)) return MRGS_E_BAD_ARG;
+        hipLaunchKernelGGL(csr_spmv3_blk4_kernel, dim3((unsigned)(((size_t)nrows * 64 + 255) / 256)), dim3(256), 0, st, nrows, row_ptr, (const uint16_t*)col,
+                           (const uint2*)val, row_scale, x, y);
+        return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+    }
     const bool wide = lanes_per_row >= 64;
     const dim3 g(wide ? (unsigned)(((size_t)nrows * 64 + 255) / 256) : (unsigned)(((size_t)nrows * 4 + 255) / 256)), b(256);
 #define SPMV(G_, IDX_, WT_) hipLaunchKernelGGL((csr_spmv3_kernel<G_, IDX_, WT_>), g, b, 0, st, nrows, row_ptr, (const IDX_*)col, (const WT_*)val, row_scale, x, y)
@@ -1080,13 +1148,15 @@ int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream)
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         const MrgsSpmvDesc& d = descs[i];
-        if (d.nrows < 1 || !d.row_ptr || !d.col || !d.val || !d.x || !d.y || (d.col_bytes != 2 && d.col_bytes != 4) || (d.val_bytes != 2 && d.val_bytes != 4) ||
-            (d.val_bytes == 2 && !d.row_scale))
+        if (d.nrows < 1 || !d.row_ptr || !d.col || !d.val || !d.x || !d.y || (d.col_bytes != 2 && d.col_bytes != 4) ||
+            (d.val_bytes != 2 && d.val_bytes != 4 && d.val_bytes != 8) || (d.val_bytes != 4 && !d.row_scale))
             return MRGS_E_BAD_ARG;
+        const bool blk4 = d.val_bytes == 8;
+        if (blk4 && (d.col_bytes != 2 || d.lanes_per_row < 64 || (d.nrows & 3) || ((uintptr_t)d.x & 15u) || ((uintptr_t)d.val & 7u))) return MRGS_E_BAD_ARG;
         const bool wide = d.lanes_per_row >= 64;
         SpmvSeg& S = B.seg[i];
         S.nrows = d.nrows;
-        S.fmt = (wide ? 4 : 0) | (d.col_bytes == 4 ? 2 : 0) | (d.val_bytes == 4 ? 1 : 0);
+        S.fmt = blk4 ? 8 : ((wide ? 4 : 0) | (d.col_bytes == 4 ? 2 : 0) | (d.val_bytes == 4 ? 1 : 0));
         S.first_block = blocks;
         S.pad = 0;
         S.row_ptr = d.row_ptr; S.col = d.col; S.val = d.val; S.row_scale = d.row_scale; S.x = d.x; S.y = d.y;

@@ -48,6 +48,9 @@
 
 namespace {
 
+#ifndef ST_FWD_WAVES
+#define ST_FWD_WAVES 4                    // waves per SIMD the forward walking kernels are compiled for (register budget 512 / that)
+#endif
 constexpr int ST_K = 16;                  // hits gathered per pass
 constexpr int ST_THREADS = 256;
 constexpr int ST_MAX_PASSES = 256;        // 4096 hits per ray at most
@@ -925,7 +928,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
 // (no record, or it overflowed); 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same
 // order, no hierarchy.
 template <int MODE>
-__global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 4, 8))) void st_trace_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
+__global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : ST_FWD_WAVES, 8))) void st_trace_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
                                                               const unsigned long long* __restrict__ wide_vmask)
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
@@ -1184,7 +1187,7 @@ constexpr int ST_PACKET_BLOCKS = 2048;
 constexpr int ST_LONE_BLOCKS = 4096;
 
 template <int MODE>
-__global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 4, 8))) void st_trace_rest_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
+__global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : ST_FWD_WAVES, 8))) void st_trace_rest_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
                                                                    const unsigned long long* __restrict__ wide_vmask, const uint32_t* __restrict__ lone_list)
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];

@@ -55,6 +55,24 @@ def test_argument_validation_without_gpu():
     assert R.value == 0
 
 
+def test_blocked_spmv_argument_checks_without_gpu():
+    """val_bytes 8 (rows as blocks of four columns) needs 16-bit block indices, 64 lanes per row, a row count that is a multiple of 4
+    and aligned x / val: everything else is MRGS_E_BAD_ARG before anything is launched."""
+    from materialrefgs_amd import _lib
+    L = _lib.lib()
+    p = ctypes.c_void_p(0x1000)      # never dereferenced: the calls below are all refused
+    ok_args = dict(nrows=64, col_bytes=2, lanes=64, x=0x1000, val=0x1000)
+    def call(**kw):
+        a = dict(ok_args, **kw)
+        return L.mrgs_csr_spmv3(a["nrows"], p, p, a["col_bytes"], ctypes.c_void_p(a["val"]), 8, p, ctypes.c_void_p(a["x"]), p, a["lanes"], None)
+    assert call(col_bytes=4) == 1
+    assert call(lanes=4) == 1
+    assert call(nrows=66) == 1
+    assert call(x=0x1004) == 1
+    assert call(val=0x1004) == 1
+    assert L.mrgs_csr_spmv3(64, p, p, 2, p, 8, None, p, p, 64, None) == 1      # fixed-point weights need the row scales
+
+
 def test_struct_size_guard():
     """A caller built against another revision of include/mrgs.h -- e.g. the 14-pointer MrgsRasterInputs of the header before
     `bwd_grad_ws` was appended, which the forward ACTS on -- is refused with MRGS_E_BAD_ARG before anything is read (no GPU needed:

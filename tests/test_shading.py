@@ -363,6 +363,25 @@ def test_build_mips_prefilter_matches_dense_oracle(gpu_device):
     assert float(np.abs(env.base.grad.detach().cpu().double().numpy() - g_o).max()) <= 2e-5 * float(np.abs(g_o).max())
 
 
+@pytest.mark.gpu
+def test_blocked_filter_rows_equal_the_plain_csr(gpu_device, monkeypatch):
+    """The long-row filter levels stored as blocks of four columns (mrgs_csr_spmv3, val_bytes 8) against the same operator kept as one
+    (column, weight) pair per non-zero: same quantised weights, only the order of the sums differs."""
+    import materialrefgs_amd.shading as sh
+    g = torch.Generator().manual_seed(11)
+    for res, rough in ((16, 1.0), (32, 0.5)):
+        x = torch.randn(6, res, res, 3, generator=g).to(gpu_device)
+        monkeypatch.setattr(sh, "_NO_BLOCKED", True)
+        plain = sh.CubemapFilterOp(gpu_device, res, 0, rough, 0.99)
+        monkeypatch.setattr(sh, "_NO_BLOCKED", False)
+        blocked = sh.CubemapFilterOp(gpu_device, res, 0, rough, 0.99)
+        assert plain.val.dim() == 1 and blocked.val.dim() == 2 and blocked.val.shape[1] == 2
+        assert int(blocked.row_ptr[-1]) * 4 >= blocked.nnz and int(blocked.row_ptr[-1]) * 4 < 1.35 * blocked.nnz     # slots mostly used
+        for tr in (False, True):
+            a, b = plain.apply_matrix(x, transpose=tr), blocked.apply_matrix(x, transpose=tr)
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
 def test_envfilter_oracle_known_answers():
     """CPU: the dense restatement of renderutils' cubemap filters -- rows of the specular operator are normalised (a constant
     cubemap stays constant), the diffuse operator integrates cos / pi over the hemisphere (~1 for a constant map), the mip
