@@ -321,21 +321,40 @@ def main():
     # costs ~40 ms; the per-view Python glue allocates enough containers to trigger one every few dozen views.  Moving the
     # start-up objects to the permanent generation keeps collections proportional to what a view allocates.  (Before the warm-up, not
     # between it and the timed region: 40 ms of idle GPU in front of the first timed step lets the clocks fall back.)
+    # One process drives one GPU: autograd's per-device worker thread buys nothing here.  The backward of a full render is ~25
+    # Python-level nodes (0.6 ms of host work per view); on the worker thread they run on whatever core the scheduler woke it on, and
+    # the view, which is paced by the host, moves with that (C3full, identical runs on one box: 802 ... 1 009 views/s with the worker
+    # thread, 1 058 ... 1 073 with the backward on the calling thread).  The raw rasterizer's backward is ONE node and measures the
+    # same either way (C2: 1 916 ... 1 957), so torch's default stays there.  The line a training script adds once;
+    # MRGS_BENCH_MT_AUTOGRAD=1 restores torch's default for A/B runs.
+    if surfel_mode and not os.environ.get("MRGS_BENCH_MT_AUTOGRAD"):
+        torch.autograd.set_multithreading_enabled(False)
     import gc
     gc.collect()
     gc.freeze()
+    # (the warm-up runs with the same sampled event pairs as the timed region: the first timing events on a stream cost the runtime
+    # a one-time set-up that belongs in front of the measurement)
+    L.mrgs_set_profiling(0 if os.environ.get("MRGS_BENCH_NO_KERNEL_EVENTS") else 3)
     for i in range(args.warmup):
         step(i)
     fence()
     # HIP events around the dominant kernel (backward blend, feeds `roofline`) on every fourth launch of the timed region: an event
     # pair costs two ~6 us bubbles on the stream, which every-launch timing would charge to the throughput figure
-    L.mrgs_set_profiling(3)
+    L.mrgs_set_profiling(0 if os.environ.get("MRGS_BENCH_NO_KERNEL_EVENTS") else 3)
     t0 = time.perf_counter()
+    step_marks = [] if os.environ.get("MRGS_BENCH_STEP_TIMES") else None     # developer diagnostic: host time per step of the timed region
     for i in range(args.steps):
         step(args.warmup + i)
+        if step_marks is not None:
+            step_marks.append(time.perf_counter())
     issued = time.perf_counter() - t0        # the host is done queueing (diagnostic: close to `elapsed` = the step is bound by the host's launches)
     fence()
     elapsed = time.perf_counter() - t0
+    if step_marks is not None and rank == 0:
+        d = [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)]
+        order = sorted(range(len(d)), key=lambda k: -d[k])[:6]
+        print("host ms per step: median %.3f, longest %s, tail after the last step %.3f ms" %
+              (sorted(d)[len(d) // 2], [(k, round(d[k], 2)) for k in order], 1e3 * (elapsed - (step_marks[-1] - t0))), file=sys.stderr)
     times = MrgsKernelTimes()
     L.mrgs_get_kernel_times(times)
     # per-stage breakdown (diagnostic `stage_ms`): a few extra, untimed steps with an event pair around every stage
