@@ -293,22 +293,29 @@ def main():
         if world > 1:
             reduce_surfel(view)
 
+    _PHASES = [] if os.environ.get("MRGS_BENCH_STEP_TIMES") else None
+
     def step(i):
         if surfel_mode:
             return step_surfel(i)
         view = (i * world + rank) % len(settings)
         for t in list(params.values()) + [means2D]:
             t.grad = None
+        ta = time.perf_counter()
         rast = GaussianRasterizer(settings[view])
         contrib, color, feature, radii, allmap = rast(
             means3D=params["means3D"], means2D=means2D, opacities=params["opacity"], shs=params["sh"],
             features=params.get("features"), scales=params["scales"], rotations=params["rotations"])
         state["R"] = color.grad_fn.num_rendered
+        tb = time.perf_counter()
         outs, grads = [color, allmap], [g_color, g_others]
         if S > 0:
             outs.append(feature)
             grads.append(g_feat)
         torch.autograd.backward(outs, grads)
+        tc = time.perf_counter()
+        if _PHASES is not None:
+            _PHASES.append((ta, tb, tc))
         if world > 1:
             state["reduced"] = reducer.reduce([params[k].grad for k in params] + [means2D.grad], params["means3D"], settings[view].campos, 3)
 
@@ -353,6 +360,12 @@ def main():
     if step_marks is not None and rank == 0:
         d = [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)]
         order = sorted(range(len(d)), key=lambda k: -d[k])[:6]
+        if _PHASES:
+            ph = _PHASES[-len(d):]
+            med = lambda v: sorted(v)[len(v) // 2]
+            print("host phases (median us): forward incl. the wait for the count %.0f, backward %.0f, between steps %.0f" %
+                  (1e6 * med([b - a for a, b, c in ph]), 1e6 * med([c - b for a, b, c in ph]),
+                   1e6 * med([n[0] - p[2] for p, n in zip(ph[:-1], ph[1:])])), file=sys.stderr)
         print("host ms per step: median %.3f, longest %s, tail after the last step %.3f ms" %
               (sorted(d)[len(d) // 2], [(k, round(d[k], 2)) for k in order], 1e3 * (elapsed - (step_marks[-1] - t0))), file=sys.stderr)
     times = MrgsKernelTimes()
