@@ -844,6 +844,9 @@ __device__ __forceinline__ void csr_spmv3_body(int block, int nrows, const uint3
 #ifndef MRGS_SPMV_BLK_ROUNDS
 #define MRGS_SPMV_BLK_ROUNDS 2      // measured in the batched prefilter launch: 2 rounds 43.5 us, 4 rounds 51.5 (66 VGPRs), 8 rounds 47.7; plain CSR 51.4
 #endif
+// (Also measured: a wave owning 2 / 4 / 8 consecutive rows and walking their blocks as one range, products added to the row's accumulators
+// with 0/1 factors -- fewer, longer waves without the partly empty last round per row: 45.7 / 54.6 / 74.7 us against 42.6 for a row per
+// wave.  The launch wants MANY short waves; what holds it at 1.7 TB/s was not found.)
 __device__ __forceinline__ void csr_spmv3_blk4_body(int block, int nrows, const uint32_t* __restrict__ row_ptr, const uint16_t* __restrict__ bcol,
                                                     const uint2* __restrict__ bval, const float* __restrict__ row_scale,
                                                     const float* __restrict__ x, float* __restrict__ y)
