@@ -339,6 +339,10 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    # ... and the automatic collector stays off until the timed region is over: with nothing left to find, a generation-1/2 pass still
+    # costs ~0.12 ms of host time every ~25 views (it sat on step 19 of every 20-step run).  A training loop would collect between epochs.
+    if not os.environ.get("MRGS_BENCH_GC_ON"):
+        gc.disable()
     # (the warm-up runs with the same sampled event pairs as the timed region: the first timing events on a stream cost the runtime
     # a one-time set-up that belongs in front of the measurement)
     L.mrgs_set_profiling(0 if os.environ.get("MRGS_BENCH_NO_KERNEL_EVENTS") else 3)
@@ -357,6 +361,7 @@ def main():
     issued = time.perf_counter() - t0        # the host is done queueing (diagnostic: close to `elapsed` = the step is bound by the host's launches)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if step_marks is not None and rank == 0:
         d = [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)]
         order = sorted(range(len(d)), key=lambda k: -d[k])[:6]
@@ -366,6 +371,8 @@ def main():
             print("host phases (median us): forward incl. the wait for the count %.0f, backward %.0f, between steps %.0f" %
                   (1e6 * med([b - a for a, b, c in ph]), 1e6 * med([c - b for a, b, c in ph]),
                    1e6 * med([n[0] - p[2] for p, n in zip(ph[:-1], ph[1:])])), file=sys.stderr)
+        print("first 40 steps: " + " ".join("%.3f" % v for v in d[:40]), file=sys.stderr)
+        print("host ms per step by position: " + " ".join("%d-%d: %.3f" % (a, min(a + 20, len(d)), sum(d[a:a + 20]) / len(d[a:a + 20])) for a in range(0, len(d), 20)), file=sys.stderr)
         print("host ms per step: median %.3f, longest %s, tail after the last step %.3f ms" %
               (sorted(d)[len(d) // 2], [(k, round(d[k], 2)) for k in order], 1e3 * (elapsed - (step_marks[-1] - t0))), file=sys.stderr)
     times = MrgsKernelTimes()
