@@ -15,17 +15,22 @@
 //   * in the blend loop the stage is read with uniform-address ds_read_b128 (LDS broadcast), the next surfel's
 //     geometry being fetched while the current one is evaluated;
 //   * blockIdx -> (tile, quadrant) keeps the four quadrant-waves of a tile on one XCD (blocks are dealt
-//     round-robin to the 8 XCDs) so that the tile's records are fetched into one L2 only.
+//     round-robin to the 8 XCDs) so that the tile's records are fetched into one L2 only;
+//   * the launch lasts as long as its longest wave takes ALONE on a SIMD: late in a block's list, when few of
+//     its pixels are still alive, the block-level cull is evaluated again against the bounding box of the live pixels (below), and
+//     the file is compiled with LLVM's max-ilp scheduling strategy (a lone wave pays ~8 cycles per dependent instruction).
 #include "mrgs_blend_math.h"
 
-// 1: single stage buffer, the copy of chunk c+1 is issued after chunk c has been blended (5.5 KB LDS per wave -> 7 waves
-//    per SIMD; the copy latency is covered by the other waves).  2: double buffer, copy overlapped inside the wave (11 KB).
+// MRGS_FWD_REFINE: the cull against the live pixels' bounding box, for chunks that start with at most MRGS_FWD_REFINE_LIVE live pixels
+// (8 ... 40 measure the same, 64 = every chunk is 11 % slower than never).
 #ifndef MRGS_FWD_REFINE
 #define MRGS_FWD_REFINE 1
 #endif
 #ifndef MRGS_FWD_REFINE_LIVE
 #define MRGS_FWD_REFINE_LIVE 24
 #endif
+// MRGS_FWD_STAGES 1: single stage buffer, the copy of chunk c+1 is issued after chunk c has been blended (5.5 KB LDS per wave -> 7 waves
+//    per SIMD; the copy latency is covered by the other waves).  2: double buffer, copy overlapped inside the wave (11 KB).
 #ifndef MRGS_FWD_STAGES
 #define MRGS_FWD_STAGES 1
 #endif

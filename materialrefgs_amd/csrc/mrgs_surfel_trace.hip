@@ -429,6 +429,10 @@ __device__ __forceinline__ bool st_beam_surfel(const StBeam& B, const float4 g0,
     return uc - r1 <= umax + eps && uc + r1 >= umin - eps && vc - r2 <= vmax + eps && vc + r2 >= vmin - eps && sb + eps >= s_prev && sa - eps <= s_far;
 }
 
+// (Measured and dropped, round 3: touching the cache lines of the next remaining sibling with one LDS-DMA instruction whenever the walk
+// descends into a child -- 12 lines of boxes or the 32 lines of a leaf group, no registers -- so that the visit after this one would find
+// them cached: st_trace_kernel<0> 570 -> 590 us, st_trace_rest_kernel<0> 750 -> 789 us; the walk's visits are not waiting for misses that a
+// one-visit lead removes, and the extra instruction costs six more spilled registers in kernels that are at their budget.)
 __device__ __forceinline__ int st_gather_wide(const StWide& W, const float* __restrict__ boxes, const unsigned long long* __restrict__ vmask,
                                               const float4* __restrict__ leaf, uint32_t (*kb_id)[ST_THREADS], float (*kb_t)[ST_THREADS], int tid,
                                               float ox, float oy, float oz, float dx, float dy, float dz, float ivx, float ivy, float ivz,
