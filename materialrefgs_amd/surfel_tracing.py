@@ -378,6 +378,20 @@ def _bg_key(bg):
     return (bg.data_ptr(), bg._version, bg.device)
 
 
+_ZERO_MAPS = {}
+
+
+def _zero_map(like):
+    """A shared all-zero map of `like`'s shape (read-only by convention: it stands for a per-view torch.zeros_like whose value never changes)."""
+    key = (str(like.device), tuple(like.shape), like.dtype)
+    z = _ZERO_MAPS.get(key)
+    if z is None:
+        if len(_ZERO_MAPS) >= 8:
+            _ZERO_MAPS.pop(next(iter(_ZERO_MAPS)))
+        z = _ZERO_MAPS[key] = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+    return z
+
+
 def _depth_to_normal(view, depth):
     """depth_to_normal(view, depth) of utils/point_utils.py:26-37 for a depth map [H,W] through the maps kernel of render_surfel
     (`mrgs_surfel_maps_*`): an all-map whose expected depth is `depth` and whose alpha is 1 makes its surf_normal exactly that."""
@@ -490,7 +504,7 @@ class HardwareRendering(nn.Module):
         if start_from_first:
             out["surf_normal"] = chw(_depth_to_normal(camera, dpt[..., 0]) * acc.detach())
         else:
-            out["surf_normal"] = torch.zeros_like(chw(norm))
+            out["surf_normal"] = _zero_map(chw(norm))        # (the reference's zeros_like(:231); a constant, not filled per view)
         out["specular"] = chw(aux[..., :1])
         out["roughness"] = chw(aux[..., 1:2])
         return out
