@@ -352,6 +352,7 @@ def main():
     # HIP events around the dominant kernel (backward blend, feeds `roofline`) on every fourth launch of the timed region: an event
     # pair costs two ~6 us bubbles on the stream, which every-launch timing would charge to the throughput figure
     L.mrgs_set_profiling(0 if os.environ.get("MRGS_BENCH_NO_KERNEL_EVENTS") else 3)
+    mem0 = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev))
     t0 = time.perf_counter()
     step_marks = [] if os.environ.get("MRGS_BENCH_STEP_TIMES") else None     # developer diagnostic: host time per step of the timed region
     for i in range(args.steps):
@@ -363,6 +364,9 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     if step_marks is not None and rank == 0:
+        mem1 = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev))
+        print("device memory over the timed region (allocated, reserved) MiB: %.1f, %.1f -> %.1f, %.1f" %
+              (mem0[0] / 2**20, mem0[1] / 2**20, mem1[0] / 2**20, mem1[1] / 2**20), file=sys.stderr)
         d = [1e3 * (b - a) for a, b in zip([t0] + step_marks[:-1], step_marks)]
         order = sorted(range(len(d)), key=lambda k: -d[k])[:6]
         if _PHASES:
