@@ -382,6 +382,36 @@ def test_blocked_filter_rows_equal_the_plain_csr(gpu_device, monkeypatch):
             assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
 
 
+def test_block4_conversion_reproduces_the_csr_matrix():
+    """CubemapFilterOp._block4 (host side of the blocked prefilter rows, pure torch): every (row, column, weight) of a random CSR
+    matrix with 16-bit columns and weights comes back from the (block column, four weights) form, padding slots are zero, rows keep
+    their order and the block columns ascend inside a row."""
+    from materialrefgs_amd.shading import CubemapFilterOp
+    g = torch.Generator().manual_seed(5)
+    n = 96                                   # columns = rows (square filters), a multiple of 4
+    counts = torch.randint(0, 30, (n,), generator=g)
+    counts[7] = 0                            # an empty row
+    rows = torch.repeat_interleave(torch.arange(n), counts)
+    cols = torch.cat([torch.randperm(n, generator=g)[:int(c)] for c in counts]) if int(counts.sum()) else torch.zeros(0, dtype=torch.long)
+    q = torch.randint(1, 65536, (cols.shape[0],), generator=g)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(counts, 0)]).to(torch.int32)
+    bptr, bcol, packed = CubemapFilterOp._block4(ptr, (cols & 0xFFFF).to(torch.int16), (q & 0xFFFF).to(torch.int16), counts)
+    dense = torch.zeros(n, n, dtype=torch.long)
+    dense[rows, cols] = q
+    back = torch.zeros(n, n, dtype=torch.long)
+    bptr_l = bptr.long()
+    assert bptr_l[0] == 0 and bptr_l[-1] == bcol.shape[0] == packed.shape[0]
+    for r in range(n):
+        bc = (bcol[bptr_l[r]:bptr_l[r + 1]].long() & 0xFFFF)
+        assert bool((bc[1:] > bc[:-1]).all())
+        for k, b in zip(range(int(bptr_l[r]), int(bptr_l[r + 1])), bc.tolist()):
+            w = packed[k].long() & 0xFFFFFFFF
+            four = [int(w[0]) & 0xFFFF, int(w[0]) >> 16, int(w[1]) & 0xFFFF, int(w[1]) >> 16]
+            for j in range(4):
+                back[r, 4 * b + j] = four[j]
+    assert torch.equal(back, dense)
+
+
 def test_envfilter_oracle_known_answers():
     """CPU: the dense restatement of renderutils' cubemap filters -- rows of the specular operator are normalised (a constant
     cubemap stays constant), the diffuse operator integrates cos / pi over the hemisphere (~1 for a constant map), the mip
