@@ -1,7 +1,7 @@
 """Randomised sweep of the rasterizer parity check (tests/test_gpu_parity.py: compare_all) over scene sizes, image sizes, channel
 counts, SH degrees and views -- a one-off soak run for the GPU box, not part of the test suite.
 
-    python tools/stress_parity.py [n_cases] [seed]
+    python tools/stress_parity.py [n_cases] [seed] [i,j,k: run only these cases of the sequence]
 """
 import os
 import sys
@@ -18,6 +18,7 @@ from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera  # noqa: 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = set(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
 dev = torch.device("cuda:0")
 bad = 0
 t0 = time.time()
@@ -28,7 +29,10 @@ for i in range(n):
     deg = int(rng.integers(0, 4))
     rpx = float(rng.choice([1.5, 4.0, 7.0, 15.0, 40.0]))
     view = int(rng.integers(0, 8))
-    scene = make_shell_scene(P, S=S, seed=int(rng.integers(1 << 30)), radius_px=rpx, image_size=max(H, W))
+    scene_seed = int(rng.integers(1 << 30))
+    if only is not None and i not in only:
+        continue
+    scene = make_shell_scene(P, S=S, seed=scene_seed, radius_px=rpx, image_size=max(H, W))
     try:
         compare_all(scene, orbit_camera(view, H, W), dev, sh_degree=deg)
         status = "ok"
