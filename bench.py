@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- fwd+bwd views/s of the surfel rasterizer hot path on MI355X (BASELINE.json metric).
+"""bench.py -- full-render fwd+bwd views/s of the surfel renderer hot path on MI355X (BASELINE.json metric).
 
-A "step" is one full render of one view, forward AND backward, through the drop-in
-`materialrefgs_amd.rasterizer.GaussianRasterizer` (preprocess -> depth sort -> pair emission -> tile sort ->
-per-tile blend -> analytic backward), on the synthetic shell scene of SURVEY.md section 8d with the inputs
-resident in HBM.  Workload at N=1: C2 = BASELINE.json configs[1] (P=300000 surfels, 800x800, SH degree 3,
-S=0).  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank renders its own view
-of the step and the dense per-gaussian gradients are summed with ONE RCCL all-reduce ("weak" scaling).
+A "step" is one FULL render of one view, forward AND backward.  The number of record (default workload, C3full) is the reference's
+`render_surfel` (gaussian_renderer/__init__.py:225-483) at BASELINE.json's 800x800 / 300 000 surfels: per-gaussian material features ->
+the drop-in rasterizer with S = 8 material channels (preprocess -> binning -> per-tile blend) -> 2DGS map post-processing -> deferred
+split-sum shading (FG LUT + prefiltered cubemap, rebuilt for the view as the reference's training loop does) -> compositing, and the
+backward of all of it, on the synthetic shell scene of SURVEY.md section 8d with the inputs resident in HBM.  `--workload C2` is the
+rasterizer alone with S = 0 (BASELINE.json configs[1]); the default run reports it as `secondary_raster` next to C2heavy, the traced
+last training stage (C3trace) and BASELINE.json configs[3] (C4trace).  With --gpus N (one rank per GPU) every rank renders its own view
+of the step and the per-gaussian gradients are summed through the factored exchange of materialrefgs_amd/dist.py ("weak" scaling).
 
-Prints ONE JSON line (rank 0).  `roofline` is computed for the dominant kernel from HIP-event durations recorded
-on the launch stream during the timed region; `cpu_baseline` times the CPU oracle (a port, not the reference
-itself: the reference has no CPU path) on one view of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` is computed for the dominant kernel from HIP-event durations recorded on the launch stream
+during the timed region; `cpu_baseline` times the CPU checkers (a port: the reference has no CPU path) on one view of the same workload.
 """
 import argparse
 import json
@@ -132,11 +133,11 @@ def plumbing_only(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500)     # ~1 s timed region at C2
+    ap.add_argument("--steps", type=int, default=1000)     # ~1 s timed region at C3full
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C3full", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also skips grad_max_rel_err)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines of the default C2 run (C2heavy, C3full, C3trace)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines of the default run (C2, C2heavy, C3trace, C4trace)")
     ap.add_argument("--dump-grads", default=None, metavar="PATH",
                     help="after the measurement render step --dump-step once more and let rank 0 save the (reduced) gradient tensors to PATH "
                          "(.npz): tests/test_dist_gpu.py compares a 2-rank run with the sum of two single-rank runs")
@@ -239,6 +240,9 @@ def main():
     reducer = mdist.FactoredGradReducer([params[k].shape for k in params] + [means2D.shape], list(params.keys()).index("sh"), dev) \
         if world > 1 else None
     state = {"R": 0}
+    if reducer is not None and not os.environ.get("MRGS_BENCH_NO_EARLY_GATHER"):
+        # the all-gather of the colour-gradient factor starts in the middle of the rasterizer's backward (under the per-gaussian backward)
+        rasterizer_mod.set_after_blend_hook(lambda drgb: reducer.begin_early(drgb, state["campos"]))
 
     # render_surfel's parameter set: both SH families (96 of 111 floats per gaussian) travel factored (dist.SurfelGradReducer)
     surfel_names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color",
@@ -299,6 +303,7 @@ def main():
         if surfel_mode:
             return step_surfel(i)
         view = (i * world + rank) % len(settings)
+        state["campos"] = settings[view].campos
         for t in list(params.values()) + [means2D]:
             t.grad = None
         ta = time.perf_counter()
@@ -479,10 +484,37 @@ def main():
             fn()
         e1.record()
         torch.cuda.synchronize(dev)
-        return {"V": V, "allgather_bytes_per_rank_sent": 4 * row, "allgather_bytes_per_rank_received": 4 * row * V,
-                "allreduce_bytes": 4 * (dense_floats - sh_floats), "dense_allreduce_bytes_avoided": 4 * dense_floats,
+        expand_ms = e0.elapsed_time(e1) / 10
+        ag_row, ar_bytes = 4 * row, 4 * (dense_floats - sh_floats)
+        return {"V": V, "allgather_bytes_per_rank_sent": ag_row, "allgather_bytes_per_rank_received": ag_row * V,
+                "allreduce_bytes": ar_bytes, "dense_allreduce_bytes_avoided": 4 * dense_floats,
                 "floats_per_gaussian_on_the_wire": round((row - 3 + dense_floats - sh_floats) / P, 2),
-                "floats_per_gaussian_dense": round(dense_floats / P, 2), "sh_expand_ms_at_V": round(e0.elapsed_time(e1) / 10, 4)}
+                "floats_per_gaussian_dense": round(dense_floats / P, 2), "sh_expand_ms_at_V": round(expand_ms, 4),
+                "_ag_row": ag_row, "_ar_bytes": ar_bytes, "_expand_ms": expand_ms}
+
+    def predicted_scaling(xm, step_ms, overlap_ms):
+        """Step efficiency of the view-parallel step at V = 2 / 4 / 8 from the wire bytes and the measured local kernels (no multi-GPU
+        box was available to any round: a MODEL, every input of which is printed).  Links: the 8 GPUs of a node are fully connected, 7
+        xGMI links per GPU at ~153 GB/s each, counted as 76.8 GB/s per direction and derated to 80 %.  Both collectives go directly
+        between peers (every rank sends its all-gather row to each peer over that peer's link; the all-reduce as reduce-scatter +
+        all-gather of 1/V slices), so one link carries row + 2 x allreduce / V bytes per step and direction; ~10 us of latency per
+        collective phase.  The SH expansion needs the gathered rows (its time is measured here for 8 rows and scaled by V / 8: it is one
+        pass over V rows); the all-gather is issued as soon as the blend backward has produced the colour gradients
+        (rasterizer.set_after_blend_hook), i.e. `overlap_ms` of it (the per-gaussian backward that follows) is hidden."""
+        link = 76.8e9 * 0.8
+        tab = {}
+        for V in (2, 4, 8):
+            t_ag = xm["_ag_row"] / link * 1e3 + 0.010
+            t_ar = 2.0 * xm["_ar_bytes"] / V / link * 1e3 + 0.020
+            t_exp = xm["_expand_ms"] * V / 8.0
+            # the all-gather starts `overlap_ms` before the backward ends; the all-reduce follows it on the same links; the expansion runs
+            # on the compute stream as soon as the gather has landed, next to the all-reduce
+            exposed = max(t_ag - overlap_ms, 0.0) + max(t_ar, t_exp)
+            eff = step_ms / (step_ms + exposed)
+            tab[f"V{V}"] = {"allgather_ms": round(t_ag, 4), "allreduce_ms": round(t_ar, 4), "sh_expand_ms": round(t_exp, 4),
+                            "exposed_exchange_ms": round(exposed, 4), "efficiency": round(eff, 3), "speedup": round(V * eff, 2)}
+        return {"link_GBs_per_direction_derated": round(link / 1e9, 1), "single_gpu_step_ms": round(step_ms, 4),
+                "allgather_overlapped_with_preprocess_bwd_ms": round(overlap_ms, 4), **tab}
     xmodel = exchange_model() if rank == 0 and torch.cuda.is_available() else None
 
     if world > 1:
@@ -539,12 +571,62 @@ def main():
             "cycles_per_inst_per_simd": sq["cycles_per_valu_inst_per_simd"], "peak": 4.0, "frac": round(4.0 / sq["cycles_per_valu_inst_per_simd"], 3),
             "insts_per_launch": sq["valu_insts_per_launch"], "source": sqj.get("measured_by", "profiles/pmc_sq.json")}
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+        if xmodel is not None:
+            if world == 1:
+                # (render_surfel's second SH family comes out of the per-gaussian feature backward, after the rasterizer: no early start there)
+                xmodel["predicted_scaling"] = predicted_scaling(xmodel, 1000.0 * elapsed / args.steps,
+                                                                0.0 if surfel_mode else float(stage_ms.get("preprocess_bwd", 0.0)))
+            xmodel = {k: v for k, v in xmodel.items() if not k.startswith("_")}
         out["exchange_model"] = xmodel
+        if issued > 0.9 * elapsed:
+            # the host needed (nearly) the whole timed region to queue the work: the figure is then a host figure, not a GPU one
+            out["host_bound"] = True
+            print(f"bench.py: WARNING host_issue_ms_per_step {1000.0 * issued / args.steps:.4f} > 0.9 x ms_per_step {1000.0 * elapsed / args.steps:.4f}: "
+                  "the step is paced by the host's launches (Python), not by the GPU", file=sys.stderr)
 
         if world > 1:
             pass                         # the CPU baseline and the oracle comparison belong to the N = 1 run only
+        elif not args.no_cpu_baseline and surfel_mode and (traced or use_loss or indirect):
+            out["cpu_baseline"] = None   # CPU legs exist for the raster workloads and for C3full
         elif not args.no_cpu_baseline and surfel_mode:
-            out["cpu_baseline"] = None   # the C oracle covers the rasterizer only; use --workload C3 for its CPU baseline
+            # render_surfel of view 0 on the host cores through the checkers (oracle/render_oracle.py: per-gaussian glue in torch float64,
+            # the rasterizer in oracle/mrgs_oracle.c over OpenMP, map post-processing + split-sum shading + compositing in torch float64),
+            # forward and backward with the bench's upstream gradients.  The environment prefilter is NOT in the CPU figure: its checker is
+            # a dense (6 N^2)^2 float64 operator that does not exist at N = 128; the CPU leg shades with the levels the HIP prefilter
+            # produced.  The same pass gives the gradient parity of this very configuration (`grad_max_rel_err`).
+            from oracle import render_oracle
+            from oracle import raster_oracle as ro
+            import numpy as np
+            cam0 = cams[0]
+            for t_ in surfel_params:
+                t_.grad = None
+            env.build_mips()
+            out_h = render_surfel(cams_dev[0], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
+            keys = ["render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal"]
+            torch.autograd.backward([out_h[k] for k in keys], state["g"])
+            torch.cuda.synchronize(dev)
+            mips_cpu = [m.detach().cpu().double() for m in env.specular]
+            names11 = surfel_names[:11]
+            pc_o = SurfelModel(*[t_.detach().cpu().double().requires_grad_(True) for t_ in surfel_params[:6]],
+                               **{n: t_.detach().cpu().double().requires_grad_(True) for n, t_ in zip(names11[6:], surfel_params[6:11])})
+            t = time.perf_counter()
+            out_o = render_oracle.render_surfel_oracle(cam0, pc_o, None, None, pipe, bg_color.cpu(), srgb=False, mips=mips_cpu)
+            torch.autograd.backward([out_o[k] for k in keys], [g_.detach().cpu().double() for g_ in state["g"]])
+            cpu_s = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "views/s", "cores": ro.num_threads(), "kind": "port",
+                                   "sample": f"1 view fwd+bwd of the same workload ({args.workload}, view 0) through oracle/render_oracle.py: torch float64 "
+                                             f"glue + shading, oracle/mrgs_oracle.c rasterizer (OpenMP); environment prefilter excluded ({cpu_s:.1f} s)"}
+            errs, maps = {}, {}
+            for n, th, to in zip(names11, surfel_params[:11], pc_o.parameters()):
+                a, b = th.grad.detach().cpu().double().numpy(), to.grad.numpy()
+                errs[n] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+            for k in keys + ["specular_map", "diffuse_map", "roughness_map", "base_color_map", "refl_strength_map"]:
+                a, b = out_h[k].detach().cpu().double().numpy(), out_o[k].detach().numpy()
+                maps[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+            out["grad_max_rel_err"] = round(max(errs.values()), 8)
+            out["grad_rel_err"] = {k: float(f"{v:.3e}") for k, v in errs.items()}
+            out["map_rel_err"] = {k: float(f"{v:.3e}") for k, v in maps.items()}
+            out["num_rendered_matches_oracle"] = None
         elif not args.no_cpu_baseline:
             from oracle import raster_oracle as ro
             cam = cams[0]
@@ -615,29 +697,37 @@ def main():
                                              "unit": "forward views/s at C2/10"}
             except Exception as ex:      # incl. subprocess.TimeoutExpired
                 out["cpu_baseline_torch"] = {"error": type(ex).__name__}
-        if world == 1 and args.workload == "C2" and not args.no_secondary:
-            # secondary lines, each a fresh child process after everything here is done: the heavier raster scene (R ~ 6 P, heavy-tailed
-            # splat sizes), the FULL render of BASELINE.md's path (render_surfel: rasterizer + deferred split-sum shading + all glue +
-            # the environment prefilter, C3full) and the last training stage (render_surfel + surfel-traced mirror rays, C3trace)
+        if world == 1 and args.workload == "C3full" and not args.no_secondary:
+            # secondary lines, each a fresh child process after everything here is done: the rasterizer alone (C2 = BASELINE.json configs[1],
+            # with its own CPU leg, oracle gradient comparison and truth leg), the heavier raster scene (R ~ 6 P, heavy-tailed splat
+            # sizes), the last training stage (render_surfel + surfel-traced mirror rays, C3trace) and BASELINE.json configs[3] with the
+            # traced reflection term (C4trace: 1 M surfels, 1600 x 1600)
             import subprocess
 
-            def child(workload, steps, warmup):
+            def child(workload, steps, warmup, cpu_leg=False):
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup),
-                                    "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True)
+                                    "--no-secondary"] + ([] if cpu_leg else ["--no-cpu-baseline"]), capture_output=True, text=True)
                 for line in r.stdout.splitlines():
                     if line.startswith("{"):
                         j = json.loads(line)
-                        return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                                "cold_ms_per_step": j.get("cold_ms_per_step"), "warm_ms_per_step_fenced": j.get("warm_ms_per_step_fenced"),
-                                "steps": j["steps"], "warmup": j["warmup"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
-                                "exchange_model": j.get("exchange_model"),
-                                "roofline": {k: j["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
-                                                                                 "algorithmic_bytes_per_launch", "avg_launch_ms")},
-                                "roofline_frac": j["roofline"]["frac"]}
+                        d = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                             "host_issue_ms_per_step": j.get("host_issue_ms_per_step"),
+                             "cold_ms_per_step": j.get("cold_ms_per_step"), "warm_ms_per_step_fenced": j.get("warm_ms_per_step_fenced"),
+                             "steps": j["steps"], "warmup": j["warmup"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
+                             "exchange_model": j.get("exchange_model"),
+                             "roofline": {k: j["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                              "algorithmic_bytes_per_launch", "avg_launch_ms", "valu_issue")},
+                             "roofline_frac": j["roofline"]["frac"]}
+                        if cpu_leg:
+                            for k in ("cpu_baseline", "grad_max_rel_err", "grad_rel_err", "num_rendered_matches_oracle", "grad_err_vs_f64",
+                                      "hip_no_further_from_f64_than_literal_fp32", "cpu_baseline_torch"):
+                                d[k] = j.get(k)
+                        return d
                 return {"error": (r.stderr or r.stdout)[-300:]}
-            out["secondary"] = child("C2heavy", min(args.steps, 500), min(args.warmup, 30))
-            out["secondary_full"] = child("C3full", 200, 24)
+            out["secondary_raster"] = child("C2", max(args.steps, 200), min(args.warmup, 50), cpu_leg=not args.no_cpu_baseline)
+            out["secondary"] = child("C2heavy", min(max(args.steps, 100), 500), min(args.warmup, 30))
             out["secondary_traced"] = child("C3trace", 100, 16)
+            out["secondary_c4"] = child("C4trace", 30, 8)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -164,6 +164,19 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
                             const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws,
                             const MrgsRasterGrads* grads, void* stream);
 
+/* The same backward in two halves (no counterpart in the reference, which is single-process): _blend runs the per-tile blend backward
+ * (backward.cu:145-468) and, when dL_dRGB_masked [P,3] is given, writes the colour gradient of every surfel as the SH backward consumes
+ * it (zero where the forward clamped the channel, backward.cu:33-36, and for culled surfels) -- final at that point; _finish runs the
+ * per-gaussian backward (backward.cu:614-669) and fills `grads`.  A view-parallel step starts its all-gather of dL_dRGB_masked between
+ * the two calls (materialrefgs_amd/dist.py: FactoredGradReducer.begin_early), where it overlaps the second half.
+ * mrgs_rasterize_backward == _blend(..., NULL) followed by _finish. */
+int mrgs_rasterize_backward_blend(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                                  const void* binning_ws, const void* img_ws, int64_t num_rendered, const float* dL_dout_color,
+                                  const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws, float* dL_dRGB_masked,
+                                  void* stream);
+int mrgs_rasterize_backward_finish(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                                   const void* grad_ws, const MrgsRasterGrads* grads, void* stream);
+
 /* Replaces markVisible (rasterize_points.cu:254-273, rasterizer_impl.cu:56-68,143-155). present: uint8[P]. */
 int mrgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                       void* stream);
@@ -562,7 +575,7 @@ const char* mrgs_last_hip_error(void);
 const char* mrgs_version(void);
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 4
+#define MRGS_ABI_VERSION 5
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

@@ -123,6 +123,10 @@ SYMBOLS = {
     "mrgs_rasterize_backward": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                                ctypes.POINTER(MrgsRasterGrads), c_void_p]),
+    "mrgs_rasterize_backward_blend": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
+                                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_rasterize_backward_finish": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), ctypes.POINTER(MrgsRasterInputs), c_void_p, c_void_p,
+                                                      c_void_p, ctypes.POINTER(MrgsRasterGrads), c_void_p]),
     "mrgs_surfel_features_forward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_features_backward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p,
                                                      ctypes.POINTER(MrgsSurfelGrads), c_void_p]),
@@ -207,7 +211,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 4   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 5   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

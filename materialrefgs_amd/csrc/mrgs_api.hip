@@ -143,6 +143,7 @@ MrgsImgWs mrgs_carve_img(void* base, int H, int W)
     w.blend_state = c.take<uint32_t>(MRGS_BLEND_STATE_WORDS);
     w.final_T = c.take<float>(3 * hw);
     w.n_contrib = c.take<uint32_t>(2 * hw);
+    w.redo_list = c.take<uint32_t>(2 + hw);
     w.total = mrgs_align_up(c.used, 256);
     return w;
 }
@@ -418,22 +419,20 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
     return mrgs_rasterize_forward_finish(&ticket, num_rendered_host);
 }
 
-int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
-                            const void* binning_ws, const void* img_ws, int64_t R, const float* dL_dout_color,
-                            const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws, const MrgsRasterGrads* grads,
-                            void* stream_)
+// The backward in two halves: the blend backward (+ optionally the clamp-masked colour gradients of the visible surfels, which are final
+// once it has run) and the per-gaussian backward.  A view-parallel caller puts its all-gather of those colour gradients on the wire
+// between the two (materialrefgs_amd/dist.py), where it overlaps the second half.
+int mrgs_rasterize_backward_blend(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                                  const void* binning_ws, const void* img_ws, int64_t R, const float* dL_dout_color,
+                                  const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws, float* dL_dRGB_masked,
+                                  void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     int rc = check_cfg(cfg, in);
     if (rc) return rc;
-    if (!grads || grads->struct_size != sizeof(MrgsRasterGrads)) return MRGS_E_BAD_ARG;
-    if (cfg->P == 0) return MRGS_OK;   // every gradient tensor has zero elements
+    if (cfg->P == 0) return MRGS_OK;
     if (!radii || !geom_ws || !binning_ws || !img_ws || !grad_ws || !dL_dout_color || !dL_dout_others) return MRGS_E_BAD_ARG;
     if (cfg->S > 0 && !dL_dout_feature) return MRGS_E_BAD_ARG;
-    if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
-        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh) ||
-        ((in->shs_rest != nullptr) != (grads->dL_dsh_rest != nullptr)))
-        return MRGS_E_BAD_ARG;
     const int tiles_x = (cfg->W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg->H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
@@ -451,13 +450,52 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
         HIP_TRY(hipMemsetAsync(grad_rec, 0, mrgs_grad_bytes(cfg->P, cfg->S), stream));
     }
     t0.stop();
+    if (dL_dRGB_masked) mrgs_launch_color_grad_extract(*cfg, g, radii, grad_rec, in->shs != nullptr, dL_dRGB_masked, stream);
     STAGE_CHECK(cfg, stream);
+    return MRGS_OK;
+}
 
+int mrgs_rasterize_backward_finish(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                                   const void* grad_ws, const MrgsRasterGrads* grads, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg, in);
+    if (rc) return rc;
+    if (!grads || grads->struct_size != sizeof(MrgsRasterGrads)) return MRGS_E_BAD_ARG;
+    if (cfg->P == 0) return MRGS_OK;   // every gradient tensor has zero elements
+    if (!radii || !geom_ws || !grad_ws) return MRGS_E_BAD_ARG;
+    if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
+        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh) ||
+        ((in->shs_rest != nullptr) != (grads->dL_dsh_rest != nullptr)))
+        return MRGS_E_BAD_ARG;
+    MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);
     StageTimer t1(stream, ST_PREB);
-    mrgs_launch_preprocess_bwd(*cfg, *in, g, radii, grad_rec, *grads, stream);
+    mrgs_launch_preprocess_bwd(*cfg, *in, g, radii, (const float*)grad_ws, *grads, stream);
     t1.stop();
     STAGE_CHECK(cfg, stream);
     return MRGS_OK;
+}
+
+int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
+                            const void* binning_ws, const void* img_ws, int64_t R, const float* dL_dout_color,
+                            const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws, const MrgsRasterGrads* grads,
+                            void* stream_)
+{
+    // (argument checks of both halves before anything is queued)
+    int rc = check_cfg(cfg, in);
+    if (rc) return rc;
+    if (!grads || grads->struct_size != sizeof(MrgsRasterGrads)) return MRGS_E_BAD_ARG;
+    if (cfg->P == 0) return MRGS_OK;
+    if (!radii || !geom_ws || !binning_ws || !img_ws || !grad_ws || !dL_dout_color || !dL_dout_others) return MRGS_E_BAD_ARG;
+    if (cfg->S > 0 && !dL_dout_feature) return MRGS_E_BAD_ARG;
+    if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
+        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh) ||
+        ((in->shs_rest != nullptr) != (grads->dL_dsh_rest != nullptr)))
+        return MRGS_E_BAD_ARG;
+    rc = mrgs_rasterize_backward_blend(cfg, in, radii, geom_ws, binning_ws, img_ws, R, dL_dout_color, dL_dout_feature, dL_dout_others, grad_ws,
+                                       nullptr, stream_);
+    if (rc) return rc;
+    return mrgs_rasterize_backward_finish(cfg, in, radii, geom_ws, grad_ws, grads, stream_);
 }
 
 int mrgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

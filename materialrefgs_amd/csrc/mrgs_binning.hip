@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int G, int T, int Tpad,
 // work in every iteration but the last.  (One lane walking the tiles of its own surfel ran the wave for as many iterations as its
 // largest surfel has tiles, with a quarter of the lanes busy on average: 190 instructions per iteration, 10.6 M VALU instructions per
 // launch at C2.)
-#define EMIT_REC_WORDS 12                       // conic 8 | depth bits | rect.x | rect.y | first pair number
+#define EMIT_REC_WORDS 16                       // conic 12 | depth bits | rect.x | rect.y | first pair number
 #define EMIT_PAIRS_MAX (64 * (BIN_COOP_MIN - 1))
 #define EMIT_WAVE_BYTES (64 * EMIT_REC_WORDS * 4 + ((EMIT_PAIRS_MAX + 15) & ~15))
 __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_group, const uint32_t* __restrict__ tiles_touched,
@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
         uint4* rec4 = (uint4*)(wrec + lane * EMIT_REC_WORDS);
         rec4[0] = make_uint4(__float_as_uint(c.a.x), __float_as_uint(c.a.y), __float_as_uint(c.a.z), __float_as_uint(c.a.w));
         rec4[1] = make_uint4(__float_as_uint(c.b.x), __float_as_uint(c.b.y), __float_as_uint(c.b.z), __float_as_uint(c.b.w));
-        rec4[2] = make_uint4(dk, r.x, r.y, excl);
+        rec4[2] = make_uint4(__float_as_uint(c.c.x), __float_as_uint(c.c.y), __float_as_uint(c.c.z), __float_as_uint(c.c.w));
+        rec4[3] = make_uint4(dk, r.x, r.y, excl);
         for (uint32_t k = 0; k < small_n; k++) wown[excl + k] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -238,10 +239,11 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
             if (p < total) {
                 const int o = (int)wown[p];
                 const uint4* q4 = (const uint4*)(wrec + o * EMIT_REC_WORDS);
-                const uint4 qa = q4[0], qb = q4[1], qc = q4[2];
+                const uint4 qa = q4[0], qb = q4[1], qd = q4[2], qc = q4[3];
                 CullConic cc;
                 cc.a = make_float4(__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z), __uint_as_float(qa.w));
                 cc.b = make_float4(__uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z), __uint_as_float(qb.w));
+                cc.c = make_float4(__uint_as_float(qd.x), __uint_as_float(qd.y), __uint_as_float(qd.z), __uint_as_float(qd.w));
                 const int ox0 = qc.y & 0xFFFF, oy0 = qc.y >> 16, ow = (int)(qc.z & 0xFFFF) - ox0;
                 const int k = p - (int)qc.w, yy = k / ow;
                 emit(cc, qc.x, (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + o), (oy0 + yy) * tiles_x + ox0 + (k - yy * ow));
@@ -258,6 +260,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
             CullConic cc;
             cc.a = make_float4(rl(c.a.x, src), rl(c.a.y, src), rl(c.a.z, src), rl(c.a.w, src));
             cc.b = make_float4(rl(c.b.x, src), rl(c.b.y, src), rl(c.b.z, src), rl(c.b.w, src));
+            cc.c = make_float4(rl(c.c.x, src), rl(c.c.y, src), rl(c.c.z, src), 0.0f);
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dk, src);
             const uint32_t id = (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + src);
             for (int k = lane; k < sn; k += 64) {
@@ -561,7 +564,7 @@ int mrgs_bin_groups(int P) { const int g = (P + BIN_THREADS - 1) / BIN_THREADS; 
 int mrgs_bin_tpad(int T) { return (T + 255) & ~255; }
 // the LDS histogram / cursor array of a slice workgroup holds one word per tile (160 KiB per workgroup on gfx950, shared with the
 // emit kernel's per-wave staging)
-bool mrgs_bin_supported(int T) { return T <= 20480; }   // 80 KB of cursors + 72 KB of per-wave staging in tile_emit_kernel
+bool mrgs_bin_supported(int T) { return T <= 16384; }   // 64 KB of cursors + 88 KB of per-wave staging in tile_emit_kernel (up to 2 048 x 2 048 px)
 
 static int per_group(int P) { const int G = mrgs_bin_groups(P); return ((P + G - 1) / G + 63) & ~63; }
 

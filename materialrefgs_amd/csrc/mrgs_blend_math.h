@@ -6,8 +6,10 @@
 // include this header are compiled with -ffp-contract=off: every fused multiply-add below is written
 // explicitly, and oracle/mrgs_oracle.c mirrors the same fused expressions with fmaf(), which makes the
 // ill-conditioned part (cross product of the two pixel planes) bit-reproducible between CPU and GPU.
-// Two operations are NOT bit-reproducible and differ from the oracle by <= 1 ulp: the reciprocal
-// (v_rcp_f32 here, 1.0f/x there) and exp (v_exp_f32 with a compensated argument here, expf there).
+// Two operations are NOT bit-reproducible and differ from the oracle by a few ulp: the reciprocal (v_rcp_f32 here, the
+// IEEE quotient 1.0f / x there) and exp (v_exp_f32 with a compensated argument here, the correctly rounded exponential there).
+// The VALUES they feed move by ~1e-7; the DECISIONS they feed (alpha >= 1/255, depth >= 0.2, rho3d <= rho2d, T (1 - alpha) < 1e-4,
+// T > 0.5) are taken exactly all the same -- "Exact decisions" below.
 #pragma once
 #include "mrgs_internal.h"
 
@@ -89,27 +91,7 @@ __device__ __forceinline__ uint32_t mrgs_pull_item(uint32_t* __restrict__ qstate
     return item;
 }
 
-#ifdef MRGS_EXACT_RCP   // developer build: correctly rounded division, to tell 1-ulp effects of v_rcp_f32 from real differences
-__device__ __forceinline__ float mrgs_rcp(float x) { return 1.0f / x; }
-#else
 __device__ __forceinline__ float mrgs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#endif
-
-// 1 / p.z of the ray/splat intersection.  p.z cancels catastrophically for grazing surfels, s = p.xy / p.z feeds exp(-|s|^2 / 2), and
-// at a pixel where the resulting alpha sits on the 1/255 threshold one ulp of v_rcp_f32 can flip the surfel in or out of the blend: a
-// 1e-3 jump of ONE pixel, seen in 2 of 400 random scenes of tools/stress_parity.py (40 000 surfels on ~200 x 300 images) against the
-// oracle's IEEE division.  Building with EXTRA=-DMRGS_PZ_REFINED adds one Newton step, after which those scenes agree to 5e-7 as
-// well; it costs 2.3 % of the C2 step (the two instructions sit at the head of every entry's dependency chain), so it is not the
-// default -- the reference's own fmad contraction moves such pixels by more than that.
-#ifdef MRGS_PZ_REFINED
-__device__ __forceinline__ float mrgs_rcp_pz(float x)
-{
-    const float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(r, fmaf(-x, r, 1.0f), r);
-}
-#else
-__device__ __forceinline__ float mrgs_rcp_pz(float x) { return mrgs_rcp(x); }
-#endif
 
 // exp(x) for x <= 0 through v_exp_f32: 2^(x*log2e) with the rounding error of the product folded back in
 __device__ __forceinline__ float mrgs_exp(float x)
@@ -131,11 +113,42 @@ struct Hit {
     float inv_pz, sx, sy;           // intersection in splat coordinates, s = p.xy / p.z
     float rho3d, rho2d, dx, dy;
     float depth, G, alpha;
+    bool use3d;                     // rho3d <= rho2d: the ray/splat hit, not the low-pass disc, gives depth and gradients
 };
 
-// forward.cu:366-398 / backward.cu:296-328, branch-free: everything is evaluated and the reference's chain of
-// `continue`s collapses into the returned flag (a zero p.z gives inf/NaN operands, and every comparison with
-// NaN is false, so such pairs are rejected exactly as the reference rejects them).
+// ---- Exact decisions ---------------------------------------------------------------------------------------------------------
+// The reference divides (p.x / p.z, forward.cu:375) and calls expf; the fast path below multiplies by v_rcp_f32 and goes through
+// v_exp_f32.  alpha, depth and rho3d of a pair then sit within a few 1e-7 (relative) of the values the oracle computes with the IEEE
+// quotient and the correctly rounded exponential -- invisible in the images, except where such a value is compared with a threshold
+// and lands on the other side: a pair blended here and skipped there (or a pixel that terminates / takes its median depth one entry
+// earlier) is a 1e-3 ... 1e-2 jump of that pixel.  So the fast path never DECIDES anything it cannot be sure of:
+//   * a value within the error band of its threshold (the MRGS_*_LO / _HI / _EPS constants; each band is the worst-case distance of
+//     the fast value from the exact one, with slack) makes the pair AMBIGUOUS;
+//   * the backward re-evaluates an ambiguous pair on the spot with mrgs_intersect_exact (IEEE quotient, correctly rounded exp, the
+//     reference's thresholds) -- per lane, behind a wave-uniform branch that is taken for ~1e-6 of the pairs;
+//   * the forward, whose transmittance T is a PRODUCT of (1 - alpha) and therefore carries the accumulated difference of every
+//     earlier pair, marks the PIXEL instead, carries on, and renders marked pixels again at the end of the wave with exact arithmetic
+//     from the first list entry on (mrgs_render_fwd.hip: redo_pixel), which is the oracle's computation of that pixel.  A pixel is
+//     marked for an ambiguous pair it blends and for a transmittance within MRGS_T1_EPS / MRGS_T2_EPS of the 1e-4 / 0.5 tests.
+// Every decision of an unmarked pixel is then the one exact arithmetic takes; the values stay fast.
+// Bands.  v_rcp_f32 is within 1 ulp, s = p.xy * (1/p.z) then within 1.5 ulp (1.8e-7) of the exact product, rho3d within 4.2e-7
+// relative, the exponent -rho/2 within 2.1e-7 rho <= 2.4e-6 for rho <= 2 ln 255 (beyond that alpha < 1/255 whatever the opacity);
+// exp and the product with the opacity add ~2.5e-7: alpha within 2.7e-6 relative where it matters -> 4e-6.  depth = s . Tw.xy + Tw.z
+// moves by 1.8e-7 (|sx Tw.x| + |sy Tw.y|) -> 1e-4 absolute covers terms up to ~250 (the near plane is at 0.2).  rho3d <= rho2d only
+// matters for pairs that pass the alpha test, i.e. rho <= 11.1: 4.2e-7 x 11.1 = 4.7e-6 -> 2e-5 absolute.
+#define MRGS_ALPHA_LO (MRGS_ALPHA_MIN * (1.0f - 4e-6f))
+#define MRGS_ALPHA_HI (MRGS_ALPHA_MIN * (1.0f + 4e-6f))
+#define MRGS_NEAR_LO (MRGS_NEAR_N - 1e-4f)
+#define MRGS_NEAR_HI (MRGS_NEAR_N + 1e-4f)
+#define MRGS_RHO_EPS 2e-5f
+// transmittance: relative distance of the fast product from the exact one, measured over whole renders x 8
+#define MRGS_T1_EPS (MRGS_T_MIN * 2e-5f)
+#define MRGS_T2_EPS (0.5f * 8e-6f)
+
+// forward.cu:366-398 / backward.cu:296-328, branch-free: everything is evaluated and the reference's chain of `continue`s collapses
+// into flags (a zero p.z gives inf/NaN operands, and every comparison with NaN is false, so such pairs are rejected exactly as the
+// reference rejects them).  Returns "may be a hit": the reference's tests with every threshold moved to the far side of its band
+// and the depth test passed by either candidate depth -- a superset of the exact hits; mrgs_hit_decide narrows it down.
 __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, float py, Hit& h)
 {
     const float Twx = s.g1.z, Twy = s.g1.w, Twz = s.g2.x;
@@ -144,7 +157,7 @@ __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, fl
     const float ppx = fmaf(h.ky, h.lz, -(h.kz * h.ly));
     const float ppy = fmaf(h.kz, h.lx, -(h.kx * h.lz));
     const float ppz = fmaf(h.kx, h.ly, -(h.ky * h.lx));
-    h.inv_pz = mrgs_rcp_pz(ppz);
+    h.inv_pz = mrgs_rcp(ppz);
     h.sx = ppx * h.inv_pz;
     h.sy = ppy * h.inv_pz;
     h.rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);
@@ -152,9 +165,75 @@ __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, fl
     h.dy = s.g2.z - py;
     h.rho2d = MRGS_FILTER_INV_SQUARE * fmaf(h.dx, h.dx, h.dy * h.dy);
     const float rho = fminf(h.rho3d, h.rho2d);
-    h.depth = (h.rho3d <= h.rho2d) ? fmaf(h.sx, Twx, fmaf(h.sy, Twy, Twz)) : Twz;
+    const float d3 = fmaf(h.sx, Twx, fmaf(h.sy, Twy, Twz));
+    h.use3d = h.rho3d <= h.rho2d;
+    h.depth = h.use3d ? d3 : Twz;
     const float power = -0.5f * rho;
     h.G = mrgs_exp(power);
+    h.alpha = fminf(0.99f, s.g2.w * h.G);
+    // (Twz is the same for every lane: its test is scalar)
+    return (ppz != 0.0f) & (!(d3 < MRGS_NEAR_LO) | !(Twz < MRGS_NEAR_LO)) & !(power > 0.0f) & !(h.alpha < MRGS_ALPHA_LO);
+}
+
+// Second half of the test for a lane mrgs_intersect let through.  Returns the fast decision -- which is the exact one unless
+// `ambiguous` comes back set: a value inside its band (the band's lower half counts as a hit meanwhile).
+__device__ __forceinline__ bool mrgs_hit_decide(const Hit& h, bool may_hit, bool& ambiguous)
+{
+    const bool hit = may_hit & !(h.depth < MRGS_NEAR_LO);
+    ambiguous = (hit & ((h.alpha < MRGS_ALPHA_HI) | (h.depth < MRGS_NEAR_HI))) | (may_hit & (fabsf(h.rho3d - h.rho2d) < MRGS_RHO_EPS));
+    return hit;
+}
+
+// exp(x), x <= 0, correctly rounded to fp32: 2^(x log2 e) in double -- argument reduced to [-1/2, 1/2], Taylor series of degree 13
+// (remainder 4e-18) -- and one rounding.  The double value is within ~1e-15 of the true one, so the result differs from the
+// correctly rounded one only when the true value lies that close to the midpoint of two floats (2e-8 of all arguments); the oracle
+// rounds glibc's double exp the same way.
+__device__ __forceinline__ float mrgs_exp_cr(float x)
+{
+    const double t = (double)x * 1.4426950408889634074;
+    const double n = __builtin_rint(t);
+    const double z = (t - n) * 0.69314718055994530942;
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, z, 1.0 / 479001600.0);
+    p = __builtin_fma(p, z, 1.0 / 39916800.0);
+    p = __builtin_fma(p, z, 1.0 / 3628800.0);
+    p = __builtin_fma(p, z, 1.0 / 362880.0);
+    p = __builtin_fma(p, z, 1.0 / 40320.0);
+    p = __builtin_fma(p, z, 1.0 / 5040.0);
+    p = __builtin_fma(p, z, 1.0 / 720.0);
+    p = __builtin_fma(p, z, 1.0 / 120.0);
+    p = __builtin_fma(p, z, 1.0 / 24.0);
+    p = __builtin_fma(p, z, 1.0 / 6.0);
+    p = __builtin_fma(p, z, 0.5);
+    p = __builtin_fma(p, z, 1.0);
+    p = __builtin_fma(p, z, 1.0);
+    // below 2^-1000 the result is far under the smallest float anyway (and ldexp's int argument stays in range)
+    const int e = n < -1000.0 ? -1000 : (int)n;
+    return (float)__builtin_ldexp(p, e);
+}
+
+// The pair again as the oracle evaluates it (oracle/mrgs_oracle.c: intersect): same expression tree, the IEEE quotient for 1 / p.z,
+// the correctly rounded exponential, the reference's thresholds in the reference's order.  Fills h, returns the hit.
+__device__ __forceinline__ bool mrgs_intersect_exact(const SurfelGeom& s, float px, float py, Hit& h)
+{
+    const float Twx = s.g1.z, Twy = s.g1.w, Twz = s.g2.x;
+    h.kx = fmaf(px, Twx, -s.g0.x); h.ky = fmaf(px, Twy, -s.g0.y); h.kz = fmaf(px, Twz, -s.g0.z);
+    h.lx = fmaf(py, Twx, -s.g0.w); h.ly = fmaf(py, Twy, -s.g1.x); h.lz = fmaf(py, Twz, -s.g1.y);
+    const float ppx = fmaf(h.ky, h.lz, -(h.kz * h.ly));
+    const float ppy = fmaf(h.kz, h.lx, -(h.kx * h.lz));
+    const float ppz = fmaf(h.kx, h.ly, -(h.ky * h.lx));
+    h.inv_pz = 1.0f / ppz;                      // correctly rounded (the translation unit is not built with fast-math)
+    h.sx = ppx * h.inv_pz;
+    h.sy = ppy * h.inv_pz;
+    h.rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);
+    h.dx = s.g2.y - px;
+    h.dy = s.g2.z - py;
+    h.rho2d = MRGS_FILTER_INV_SQUARE * fmaf(h.dx, h.dx, h.dy * h.dy);
+    const float rho = fminf(h.rho3d, h.rho2d);
+    h.use3d = h.rho3d <= h.rho2d;
+    h.depth = h.use3d ? fmaf(h.sx, Twx, fmaf(h.sy, Twy, Twz)) : Twz;
+    const float power = -0.5f * rho;
+    h.G = mrgs_exp_cr(power);
     h.alpha = fminf(0.99f, s.g2.w * h.G);
     return (ppz != 0.0f) & !(h.depth < MRGS_NEAR_N) & !(power > 0.0f) & !(h.alpha < MRGS_ALPHA_MIN);
 }
@@ -166,38 +245,50 @@ __device__ __forceinline__ void mrgs_block_pixel(int block_x, int block_y, int l
     pyi = block_y * 8 + (lane >> 3);
 }
 
-// Block-level cull (record float4 #5, #6, written by preprocess).  A surfel can reach alpha >= 1/255 only inside the
-// ellipse d^T [[A,B],[B,C]] d <= 1 around (ex, ey) -- the exact pixel-space level set rho3d <= tau, tau = 2 ln(255 opacity)
-// -- or inside the low-pass disc of radius r around mean2D.  A surfel is skipped for a whole pixel block only when the
-// block's rectangle of pixel centres misses both, i.e. when every lane would have failed the alpha test anyway: exact
-// per-pixel results are unaffected.  The minimum of the (convex) quadratic over the rectangle is taken on its four edges
-// unless the centre lies inside; A = B = C = 0 encodes "not an ellipse, always a candidate".
-struct CullConic { float4 a, b; };
-__device__ __forceinline__ float mrgs_edge_min(float qa, float qb, float qc, float X, float lo, float hi)
-{   // min over t in [lo,hi] of qa X^2 + 2 qb X t + qc t^2
-    const float t = fminf(fmaxf(-qb * X * mrgs_rcp(qc), lo), hi);   // NaN (qc = 0) falls back to lo
-    return fmaf(qa * X, X, fmaf(2.0f * qb * X, t, qc * t * t));
+// Block-level cull (MrgsGeomWs::cull, three float4 per surfel, written by preprocess).  A surfel can reach alpha >= 1/255 only
+// inside the ellipse d^T [[A,B],[B,C]] d <= 1 around (ex, ey) -- the exact pixel-space level set rho3d <= tau, tau = 2 ln(255 opacity)
+// -- or inside the low-pass disc of radius r around mean2D.  A surfel is skipped for a whole pixel block only when the block's
+// rectangle of pixel centres misses both, i.e. when every lane would have failed the alpha test anyway: exact per-pixel results are
+// unaffected.  The minimum of the (convex) quadratic over the rectangle is taken on its four edges unless the centre lies inside.
+// The quadratic is NEVER evaluated as A x^2 + 2 B x y + C y^2: a grazing surfel's ellipse is a needle (det / (A C) down to 1e-8), the
+// three terms are ~1e7 each and cancel to ~1, and fp32 returns noise -- round 4's soak found two scenes in 2 000 where a pair with
+// alpha = 5.7/255 was culled that way.  On an edge x = X the form is a completed square,
+//      q(X, t) = (det / C) X^2 + C (t - t0)^2,   t0 = -(B / C) X,
+// two non-negative terms whose coefficients det / C, det / A, B / C, B / A are formed in fp64 by the preprocess; what is left of the
+// rounding (the centre and t0 are stored / formed in fp32) is taken off the distances before they are squared, so the value returned
+// is a LOWER bound of the true minimum.  A = 0 encodes "not an ellipse, always a candidate".
+struct CullConic { float4 a, b, c; };    // a = ex, ey, A, C | b = B/C, B/A, det/C, det/A | c = mean2D.xy, r^2 of the disc, unused
+__device__ __forceinline__ float mrgs_edge_min(float D, float Q, float slope, float X, float lo, float hi, float errX)
+{   // lower bound of min over t in [lo, hi] of D X^2 + Q (t - t0)^2, t0 = -slope X; X known to +- errX
+    const float Xs = fmaxf(fabsf(X) - errX, 0.0f);
+    const float t0 = -slope * X;
+    const float tc = fminf(fmaxf(t0, lo), hi);
+    const float dt = fmaxf(fabsf(tc - t0) - (fabsf(slope) * errX + 4e-7f * fabsf(t0)), 0.0f);
+    return fmaf(D * Xs, Xs, Q * dt * dt);
 }
 __device__ __forceinline__ bool mrgs_block_may_touch(const CullConic& c, float x0, float y0, float w, float h)
 {
+    // the centre is an fp32 rounding of the fp64 one, and it can lie far outside the image: the rectangle grows by that much
+    const float ex_err = 2e-7f * fabsf(c.a.x) + 1e-5f, ey_err = 2e-7f * fabsf(c.a.y) + 1e-5f;
     const float dx0 = x0 - c.a.x, dx1 = dx0 + w, dy0 = y0 - c.a.y, dy1 = dy0 + h;
-    const float A = c.a.z, B = c.a.w, C = c.b.x;
-    const bool inside = (dx0 <= 0.0f) & (dx1 >= 0.0f) & (dy0 <= 0.0f) & (dy1 >= 0.0f);
-    float g = mrgs_edge_min(A, B, C, dx0, dy0, dy1);
-    g = fminf(g, mrgs_edge_min(A, B, C, dx1, dy0, dy1));
-    g = fminf(g, mrgs_edge_min(C, B, A, dy0, dx0, dx1));
-    g = fminf(g, mrgs_edge_min(C, B, A, dy1, dx0, dx1));
-    const bool ellipse = inside | (g <= 1.01f);
+    const float A = c.a.z, C = c.a.w;
+    const bool inside = (dx0 <= ex_err) & (dx1 >= -ex_err) & (dy0 <= ey_err) & (dy1 >= -ey_err);
+    float g = mrgs_edge_min(c.b.z, C, c.b.x, dx0, dy0 - ey_err, dy1 + ey_err, ex_err);
+    g = fminf(g, mrgs_edge_min(c.b.z, C, c.b.x, dx1, dy0 - ey_err, dy1 + ey_err, ex_err));
+    g = fminf(g, mrgs_edge_min(c.b.w, A, c.b.y, dy0, dx0 - ex_err, dx1 + ex_err, ey_err));
+    g = fminf(g, mrgs_edge_min(c.b.w, A, c.b.y, dy1, dx0 - ex_err, dx1 + ex_err, ey_err));
+    const bool ellipse = inside | !(g > 1.01f) | (A == 0.0f);      // (1 %: the fp32 evaluation of rho3d itself is noisy for grazing surfels)
     // disc: squared distance from mean2D to the rectangle
-    const float ex = fmaxf(fmaxf(x0 - c.b.y, c.b.y - (x0 + w)), 0.0f), ey = fmaxf(fmaxf(y0 - c.b.z, c.b.z - (y0 + h)), 0.0f);
-    const bool disc = fmaf(ex, ex, ey * ey) <= c.b.w;
+    const float ex = fmaxf(fmaxf(x0 - c.c.x, c.c.x - (x0 + w)), 0.0f), ey = fmaxf(fmaxf(y0 - c.c.y, c.c.y - (y0 + h)), 0.0f);
+    const bool disc = fmaf(ex, ex, ey * ey) <= c.c.z;
     return ellipse | disc;
 }
 __device__ __forceinline__ CullConic mrgs_cull_never()
 {
     CullConic c;
-    c.a = make_float4(1e30f, 1e30f, 1e30f, 0.0f);
-    c.b = make_float4(1e30f, 0.0f, 0.0f, -1.0f);
+    c.a = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+    c.b = make_float4(0.0f, 0.0f, 1e30f, 1e30f);
+    c.c = make_float4(1e30f, 0.0f, -1.0f, 0.0f);
     return c;
 }
 __device__ __forceinline__ CullConic mrgs_cull_load(const float4* __restrict__ rec /* MrgsGeomWs::cull */, uint32_t gid)
@@ -205,6 +296,7 @@ __device__ __forceinline__ CullConic mrgs_cull_load(const float4* __restrict__ r
     CullConic c;
     c.a = rec[(size_t)gid * MRGS_CULL_F4];
     c.b = rec[(size_t)gid * MRGS_CULL_F4 + 1];
+    c.c = rec[(size_t)gid * MRGS_CULL_F4 + 2];
     return c;
 }
 

@@ -15,11 +15,11 @@
 //   [0] Tu.xyz, Tv.x   [1] Tv.yz, Tw.xy   [2] Tw.z, mean2D.xy, opacity   (geometry)
 //   [3] normal.xyz, rgb.r   [4] rgb.gb, depth, 0                          (appearance)
 // (the reference keeps these in five separate arrays: transMat, means2D, normal_opacity, rgb; forward.cu:350-357,427)
-// The cull conic (mrgs_blend_math.h) lives in its own array, 2 x float4 per gaussian: it is gathered once per list entry
-// by tile_ranges_kernel and never by the blend kernels.
-//   [0] ellipse centre.xy, A, B   [1] C, mean2D.xy, disc r^2
+// The cull conic (mrgs_blend_math.h) lives in its own array, 3 x float4 per gaussian: it is gathered once per (tile, surfel) pair
+// by the emission kernel and by the forward blend only for its live-pixel cull.
+//   [0] ellipse centre.xy, A, C   [1] B/C, B/A, det/C, det/A   [2] mean2D.xy, disc r^2, 0
 #define MRGS_REC_F4 5
-#define MRGS_CULL_F4 2
+#define MRGS_CULL_F4 3
 
 // Packed per-gaussian gradient accumulator of the blend backward (one row per gaussian so that the
 // atomics of one (tile, gaussian) pair land in one or two cache lines):
@@ -73,6 +73,8 @@ struct MrgsImgWs {
     uint32_t* blend_state;                // MRGS_BLEND_STATE_WORDS
     float* final_T;      // [3][H*W]: T, M1, M2
     uint32_t* n_contrib; // [2][H*W]: last, median
+    uint32_t* redo_list; // [2 + H*W]: [0] count (cleared by the forward's ordering launch), [2 + i] pixel index of the i-th pixel whose
+                         // decisions the forward blend could not take for sure (mrgs_blend_math.h "Exact decisions")
     size_t total;
 };
 
@@ -141,6 +143,8 @@ void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
                                 hipStream_t stream);
 void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g,
                                 const int32_t* radii, const float* grad_rec, const MrgsRasterGrads& out, hipStream_t stream);
+void mrgs_launch_color_grad_extract(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const int32_t* radii, const float* grad_rec, bool from_sh,
+                                    float* out, hipStream_t stream);
 void mrgs_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t stream);
 
 void mrgs_launch_duplicate(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const uint32_t* order, uint32_t* tile_key,

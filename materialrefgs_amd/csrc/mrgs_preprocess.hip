@@ -370,8 +370,11 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         //    an exact conic.  When it is an ellipse it is stored centred and normalised, d^T [[A,B],[B,C]] d <= 1; otherwise
         //    (splat crossing the camera plane) A = B = C = 0, which every block passes.  Evaluated in fp64.
         //  * rho2d: a disc of radius sqrt(tau/2) around mean2D.
-        float4 cull_a = make_float4(1e30f, 1e30f, 1e30f, 0.0f);   // never a candidate: opacity < 1/255 can never pass
-        float4 cull_b = make_float4(1e30f, 0.0f, 0.0f, -1.0f);
+        //  The ellipse leaves here as (centre, A, C | B/C, B/A, det/C, det/A): the block test evaluates it as a completed square per
+        //  rectangle edge (mrgs_block_may_touch), never as A x^2 + 2 B x y + C y^2, whose terms cancel for the needle of a grazing surfel.
+        float4 cull_a = make_float4(1e30f, 1e30f, 1e30f, 1e30f);   // never a candidate: opacity < 1/255 can never pass
+        float4 cull_b = make_float4(0.0f, 0.0f, 1e30f, 1e30f);
+        float4 cull_c = make_float4(1e30f, 0.0f, -1.0f, 0.0f);
         const float oa = 255.0f * opa;
         if (!(oa < 0.999f)) {
             const float lg = logf(oa);
@@ -387,23 +390,27 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             const double Qy1 = c1[0] * c2[0] + c1[1] * c2[1] - tau * c1[2] * c2[2];
             const double Q11 = c2[0] * c2[0] + c2[1] * c2[1] - tau * c2[2] * c2[2];
             const double det = Qxx * Qyy - Qxy * Qxy;
-            float ea = 0.0f, eb = 0.0f, ec = 0.0f, ex0 = 0.0f, ey0 = 0.0f;   // default: not an ellipse -> always a candidate
+            // default: not an ellipse -> always a candidate (A = 0).  det is itself a difference of fp64 products: below 1e-9 of them
+            // it has fewer than ~7 digits left and the needle is treated as "no ellipse"
+            cull_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            cull_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (Qxx > 0.0 && Qyy > 0.0 && det > 1e-9 * Qxx * Qyy) {
                 const double xc = -(Qyy * Qx1 - Qxy * Qy1) / det, yc = -(Qxx * Qy1 - Qxy * Qx1) / det;
                 const double fp = Q11 + Qx1 * xc + Qy1 * yc;
                 if (fp < 0.0) {
                     const double sc_ = -1.0 / fp;
-                    ea = (float)(Qxx * sc_); eb = (float)(Qxy * sc_); ec = (float)(Qyy * sc_);
-                    ex0 = (float)xc; ey0 = (float)yc;
-                } else {   // empty level set (cannot happen for a visible splat; stay conservative)
-                    ea = 0.0f; eb = 0.0f; ec = 0.0f;
-                }
-                const float chk = ea + eb + ec + ex0 + ey0;
-                if (!(chk - chk == 0.0f)) { ea = 0.0f; eb = 0.0f; ec = 0.0f; ex0 = 0.0f; ey0 = 0.0f; }   // inf / NaN: never cull
+                    const double A = Qxx * sc_, B = Qxy * sc_, C = Qyy * sc_, dn = det * sc_ * sc_;
+                    cull_a = make_float4((float)xc, (float)yc, (float)A, (float)C);
+                    cull_b = make_float4((float)(B / C), (float)(B / A), (float)(dn / C), (float)(dn / A));
+                    const float chk = cull_a.x + cull_a.y + cull_a.z + cull_a.w + cull_b.x + cull_b.y + cull_b.z + cull_b.w;
+                    if (!(chk - chk == 0.0f) || !(cull_a.z > 0.0f)) {      // inf / NaN / underflow: never cull
+                        cull_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        cull_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                }   // else: empty level set (cannot happen for a visible splat; stay conservative)
             }
             const float rr = sqrtf(0.5f * (float)tau) + 0.05f;
-            cull_a = make_float4(ex0, ey0, ea, eb);
-            cull_b = make_float4(ec, cx, cy, rr * rr);
+            cull_c = make_float4(cx, cy, rr * rr, 0.0f);
         }
         float4* r4 = rec + (size_t)idx * MRGS_REC_F4;
         r4[0] = make_float4(T[0], T[1], T[2], T[3]);
@@ -413,6 +420,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         r4[4] = make_float4(rgb[1], rgb[2], pvz, 0.0f);
         cull[(size_t)idx * MRGS_CULL_F4] = cull_a;
         cull[(size_t)idx * MRGS_CULL_F4 + 1] = cull_b;
+        cull[(size_t)idx * MRGS_CULL_F4 + 2] = cull_c;
         out_radius = iradius;
         out_tiles = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
         out_key = __float_as_uint(pvz);
@@ -747,6 +755,32 @@ void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
                        in.viewmatrix, in.projmatrix, in.campos, radii, g.clamped, g.rec, grad_rec, MRGS_GRAD_STRIDE(cfg.S),
                        out.dL_dmeans2D, out.dL_dcolors, out.dL_dfeatures, out.dL_dopacity, out.dL_dmeans3D, out.dL_dtransMat,
                        out.dL_dsh, out.dL_dscales, out.dL_drotations, in.shs_rest, out.dL_dsh_rest);
+}
+
+// dL/dRGB of every surfel as the SH backward consumes it (backward.cu:33-36: zero where the forward clamped the channel; zero for culled
+// surfels), straight from the gradient rows the blend backward has just finished: the factor a view-parallel step all-gathers
+// (dL/dsh_v[p][k][c] = B_k(dir_v(p)) dRGB_v[p][c], materialrefgs_amd/dist.py) exists before the per-gaussian backward runs.
+__global__ void __launch_bounds__(256) color_grad_extract_kernel(int P, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+                                                                 const float* __restrict__ grad_rec, int gstride, int from_sh, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    if (radii[idx] > 0) {
+        const float* gr = grad_rec + (size_t)idx * gstride + MRGS_G_COL;
+        const uint32_t cl = from_sh ? clamped[idx] : 0u;
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = ((cl >> c) & 1u) ? 0.0f : gr[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[3 * (size_t)idx + c] = v[c];
+}
+
+void mrgs_launch_color_grad_extract(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const int32_t* radii, const float* grad_rec, bool from_sh,
+                                    float* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(color_grad_extract_kernel, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, radii, g.clamped, grad_rec,
+                       MRGS_GRAD_STRIDE(cfg.S), from_sh ? 1 : 0, out);
 }
 
 // checkFrustum, rasterizer_impl.cu:56-68

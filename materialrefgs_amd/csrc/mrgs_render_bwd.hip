@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     // prefetched (surfel id, cull bits) of the two chunks ahead, one register each: the four cull bits ride in bits 28-31
     // (P < 2^26: the gradient rows are addressed with 32-bit byte offsets)
     uint32_t idq1 = 0, idq2 = 0;
-    uint64_t mask_cur;
+    uint64_t mask_cur, exact_cur;            // entries of the current chunk to walk / to evaluate with the oracle's arithmetic (flag bit 1)
     {
         uint32_t id0 = 0, q0 = 0;
         if (c_top * MRGS_CHUNK + lane < max_contrib) { id0 = plist[c_top * MRGS_CHUNK + lane]; q0 = qm[(size_t)(c_top * MRGS_CHUNK + lane) * 4]; }
@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (c_top >= 2) idq2 = plist[(c_top - 2) * MRGS_CHUNK + lane] | ((uint32_t)qm[(size_t)((c_top - 2) * MRGS_CHUNK + lane) * 4] << 28);
         const bool cand0 = q0 & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
+        exact_cur = __builtin_amdgcn_ballot_w64((q0 & 2u) != 0u);
         mrgs_stage_async<S_MAX, SF, FV>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
     }
@@ -297,9 +298,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         const int base = c * MRGS_CHUNK;
         mrgs_stage_wait();                    // chunk c has landed
         WS_CHUNK();
-        uint64_t mask_nxt = 0ull;
+        uint64_t mask_nxt = 0ull, exact_nxt = 0ull;
         auto stage_next = [&]() {
             const bool cand1 = (idq1 >> 28) & 1u;
+            exact_nxt = __builtin_amdgcn_ballot_w64(((idq1 >> 29) & 1u) != 0u);
             const uint32_t id1 = idq1 & 0x0FFFFFFFu;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
             mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (MRGS_BWD_STAGES == 2) stage_next();
 
         uint64_t mask = mask_cur;
+        const uint64_t exact_mask = exact_cur;
         const StageBuf<SF>& sb = stage[c % MRGS_BWD_STAGES];
 
         // One list entry.  The body is branch-free across lanes: a lane that does not contribute (no hit, outside the
@@ -321,12 +324,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         auto blend_entry = [&](const SurfelGeom& sg, int j) {
             const int contributor = base + j;           // 0-based list position; the forward's contributor is position+1
             Hit h;
-            const bool hit = mrgs_intersect(sg, px, py, h);
-            const bool active = hit & inside & (contributor < last_contributor);
+            bool active;
+            // The forward took this pair's decision exactly (mrgs_blend_math.h "Exact decisions") and flagged the entries where the
+            // fast values could not tell for some pixel of the block (bit 1 of the entry's flag byte, ~1e-6 of the pairs): those are
+            // evaluated as the oracle does, by every lane; for all others the fast evaluation IS the exact decision, no band to look at.
+            if (__builtin_expect((exact_mask >> j) & 1ull, 0)) active = mrgs_intersect_exact(sg, px, py, h);
+            else active = mrgs_intersect(sg, px, py, h) & !(h.depth < MRGS_NEAR_LO);
+            active = active & inside & (contributor < last_contributor);
             const uint64_t amask = __builtin_amdgcn_ballot_w64(active);
             WS_ITER(amask != 0ull);
             if (amask == 0ull) return;
-            const bool use3d = h.rho3d <= h.rho2d;
+            const bool use3d = h.use3d;
             const bool a3 = active & use3d;
             const float4 a0 = sb.rec[3][j], a1 = sb.rec[4][j];
             const float normal[3] = {a0.x, a0.y, a0.z};
@@ -440,28 +448,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         }
         if (MRGS_BWD_STAGES == 1) stage_next();
         mask_cur = mask_nxt;
+        exact_cur = exact_nxt;
     }
     mrgs_stage_wait();   // do not retire the wave with LDS-DMA still in flight
     WS_END();
 }
 
-// Two list entries per step in the halves of packed fp32 instructions (mrgs_render_bwd_pairs.h): measured and left OFF.  At C2 it
-// issues 22 % fewer VALU instructions (109.2 M against 140.5 M per launch, SQ_INSTS_VALU) and 20 % fewer active VALU cycles, bit-identical
-// gradients -- and takes 0.266 ms instead of 0.244: it needs 142 VGPRs (three waves per SIMD instead of five) and the VALU then sits at
-// 0.74 busy instead of 1.0 (SQ_ACTIVE_INST_VALU x 4 / cycles / SIMDs); forced to four waves it spills (0.351 ms), with the next pair's
-// geometry fetched a step ahead it spills as well (0.299 ms); S = 8: 0.417 against 0.331 ms.  Build with EXTRA=-DMRGS_BWD_PAIRS to get it.
-#ifdef MRGS_BWD_PAIRS
-#ifndef MRGS_BWDP_WPE0
-#define MRGS_BWDP_WPE0 3
-#endif
-#ifndef MRGS_BWDP_WPE8
-#define MRGS_BWDP_WPE8 2
-#endif
-#include "mrgs_render_bwd_pairs.h"
-#define MRGS_BWD_KERNEL render_bwd_pairs_kernel
-#else
 #define MRGS_BWD_KERNEL render_bwd_kernel
-#endif
 
 void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
                             const uint8_t* cflag, const MrgsImgWs& img, const float* dL_dpix, const float* dL_dpix_f, const float* dL_dothers,

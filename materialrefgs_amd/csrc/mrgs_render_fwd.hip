@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     const float4* __restrict__ rec, const float4* __restrict__ cull, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
     uint32_t* __restrict__ item_work, const uint32_t* __restrict__ item_est /* read by the MRGS_WAVE_STATS build only */,
-    uint32_t* __restrict__ work_hint, int slots)
+    uint32_t* __restrict__ work_hint, int slots, uint32_t* __restrict__ redo_list)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
 
     bool done = !inside;
+    uint64_t redo = 0ull;            // pixels (lanes) with a decision inside its error band
+    int cf_end = 0;                  // list entries whose cflag this wave has written
     uint32_t work = 0;
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         work += (uint32_t)__builtin_popcountll(m);
         const StageBuf<SF>& sb = stage[c % MRGS_FWD_STAGES];
         uint64_t contributed = 0ull;          // bit j: some live pixel of the block is hit by entry base + j
+        uint64_t unsure = 0ull;               // bit j: ... and for some live pixel the hit itself is a decision inside its error band
 
         // One list entry (forward.cu:358-442).  Branch-free across lanes: a lane that does not blend this entry (no hit,
         // pixel already terminated, or terminating right now) runs the accumulation with alpha = 0 -- every sum gets
@@ -168,19 +171,27 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         // below their LDS latency sat on the critical path of the longest waves, which set the duration of this kernel)
         auto blend_entry = [&](const SurfelGeom& sg, const float4& a0, const float2& a1, int j) {
             Hit h;
-            const bool hit = mrgs_intersect(sg, px, py, h);
-            const bool ok = hit & !done;
+            const bool may_hit = mrgs_intersect(sg, px, py, h) & !done;
 #ifdef MRGS_WAVE_STATS
             const int ws_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!done));     // how thin the wave runs near its end
             ws_le4 += ws_live <= 4; ws_le8 += ws_live <= 8; ws_le16 += ws_live <= 16;
 #endif
-            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) return;
+            if (__builtin_amdgcn_ballot_w64(may_hit) == 0ull) return;
 #ifdef MRGS_WAVE_STATS
             ws_blend++; ws_blend_le8 += ws_live <= 8;
 #endif
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             contributed |= 1ull << j;          // (a superset of "blended": a pixel may terminate on it instead; the backward sorts that out)
+            bool ambiguous;
+            const bool ok = mrgs_hit_decide(h, may_hit, ambiguous);
+            // (the backward evaluates such an entry with the oracle's arithmetic for the whole block: flag bit 1)
+            unsure |= (uint64_t)(__builtin_amdgcn_ballot_w64(ambiguous) != 0ull) << j;
             const float test_T = T * (1.0f - h.alpha);
+            // a decision the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, after the list
+            // (mrgs_blend_math.h "Exact decisions"; redo_pixel below)
+            const bool near_t1 = fabsf(test_T - MRGS_T_MIN) < MRGS_T1_EPS, near_t2 = fabsf(T - 0.5f) < MRGS_T2_EPS;
+            ambiguous |= ok & (near_t1 | near_t2);
+            redo |= __builtin_amdgcn_ballot_w64(ambiguous);
             const bool term = ok & (test_T < MRGS_T_MIN);     // forward.cu:400-404: the pixel stops BEFORE blending this entry
             done |= term;
             const bool upd = ok & !(test_T < MRGS_T_MIN);
@@ -241,7 +252,8 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         }
         // the backward walks exactly the entries flagged here: for every other entry all of its gradient terms are zeros
         // (no pixel of the block blended it), so skipping it there is bit-identical and saves the staging and the intersection
-        if (base + lane < total) cf[(size_t)(base + lane) * 4] = (uint8_t)((contributed >> lane) & 1ull);
+        if (base + lane < total) cf[(size_t)(base + lane) * 4] = (uint8_t)(((contributed >> lane) & 1ull) | (((unsure >> lane) & 1ull) << 1));
+        cf_end = base + MRGS_CHUNK;
         if (MRGS_FWD_STAGES == 1) stage_next();
         mask_cur = mask_nxt;
         idc = idn;
@@ -286,29 +298,166 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         out_others[pix + 5 * HW] = median_depth;
         out_others[pix + 6 * HW] = distortion;
     }
+
+    // ---- marked pixels (mrgs_blend_math.h "Exact decisions"): listed for render_fwd_redo_kernel, which renders them again with the
+    // oracle's arithmetic and overwrites what was written above.  ~1e-4 of the pixels.  The backward walks flagged list entries only
+    // and the redo may blend entries this wave never reached: the flags it did not write are cleared here, the redo then only sets.
+#ifdef MRGS_FWD_REDO_ALL   // developer build: every pixel goes through the exact path (what the margins are measured against)
+    redo = ~0ull;
+#endif
+    redo &= __builtin_amdgcn_ballot_w64(inside);
+    if (redo != 0ull) {
+        for (int e = cf_end + lane; e < total; e += MRGS_CHUNK) cf[(size_t)e * 4] = 0;
+        if ((redo >> lane) & 1ull) redo_list[2 + atomicAdd(&redo_list[0], 1u)] = (uint32_t)pix;
+    }
 }
 
-// The intersection of two entries per step in packed fp32 instructions (mrgs_render_fwd_pairs.h): measured and left OFF.  Bit-identical
-// images, 74 VGPRs -- and 0.170 ms instead of 0.149 at C2 (S = 8: 0.218 against 0.166), 0.237 with the next pair's fields fetched a step
-// ahead (96 VGPRs, spills).  The forward's duration is the lifetime of its heaviest waves, which issue ONE dependent chain (intersection
-// -> reciprocal -> exponential -> alpha -> blend); a packed instruction carries two entries through that chain in lock step at a longer
-// latency per link, so the chain per two entries gets no shorter, and the compaction / transposition per chunk and the LDS latency at
-// the head of every step (the one-entry kernel fetches the next entry's geometry a step ahead) come on top.  Packed arithmetic pays
-// where the issue rate is the bound -- and there (the backward blend) it costs the occupancy that hides the latency.
-// Build with EXTRA=-DMRGS_FWD_PAIRS to get it.
-// The same two entries per step in plain instructions -- both intersections side by side in one basic block, pinned in front of the first
-// blend's branch, so that they fill each other's latencies -- measured too: 0.157 ms against 0.146-0.149 (S = 8: 0.178 against 0.169), and
-// 0.148 against 0.134 with the max-ilp scheduler below.  The longest waves run alone on their SIMDs near the end (tools/wave_stats.py
-// fwd 1500: the heaviest wave takes 179 us with 690 waves on the chip, 192 us with all 10 000) and a lone wave pays ~8 cycles per
-// DEPENDENT instruction against ~3 with four independent ones in flight (tools/ubench/valu_ilp.hip) -- what helped is letting the
-// compiler order the instructions of ONE entry for latency (Makefile: -amdgpu-sched-strategy=max-ilp, 0.142 -> 0.134 ms; S = 8:
-// 0.163 -> 0.157), which finds the independent work inside the intersection and the twelve accumulations without the extra registers,
-// the exposed LDS reads after a skipped blend and the wasted second entry of an odd chunk that the two-entry loop brings.
-#ifdef MRGS_FWD_PAIRS
-#include "mrgs_render_fwd_pairs.h"
-#define MRGS_FWD_KERNEL render_fwd_pairs_kernel
-#else
+// One marked pixel per wave, the lanes turned sideways: lane l evaluates list entry base + l against THAT pixel as the oracle does
+// (IEEE quotient, correctly rounded exp, the reference's thresholds: mrgs_intersect_exact); the transmittance -- the one quantity whose
+// rounding sequence decides anything -- is multiplied up serially in list order, one rounding per blended entry exactly as
+// forward.cu:400-441 does; the sums (which decide nothing) are formed per lane and folded across the wave at the end.  Lane 0
+// overwrites the pixel's outputs; entries the pixel blends are flagged for the backward like those of the main kernel.
+// A kernel of its own, not a tail of render_fwd_kernel: there its 100+ registers would be the main kernel's (measured: 68 -> 118 VGPRs,
+// or 28 spilled values and a scratch allocation per wave with the occupancy pinned -- +40 us on the 127 us launch either way).
+template <int S_MAX>
+__global__ void __launch_bounds__(64) render_fwd_redo_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, uint8_t* cflag, int S, int W, int H, int tiles_x,
+    const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
+    const uint32_t* __restrict__ redo_list)
+{
+    constexpr int SF = S_MAX > 0 ? S_MAX : 1;
+    const int lane = threadIdx.x;
+    const int HW = H * W;
+    const uint32_t count = redo_list[0];
+    const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const int pix = (int)redo_list[2 + it];
+        const int pyi = pix / W, pxi = pix - pyi * W;
+        const int tile = (pyi >> 4) * tiles_x + (pxi >> 4), quad = ((pyi >> 3) & 1) * 2 + ((pxi >> 3) & 1);
+        const uint2 range = ranges[tile];
+        const int total = (int)(range.y - range.x);
+        const uint32_t* plist = point_list + range.x;
+        const float qx = (float)pxi, qy = (float)pyi;
+        float xT = 1.0f, xM1 = 0.f, xM2 = 0.f, xmed = 0.f;          // wave-uniform running values of the pixel
+        uint32_t xlast = 0, xmedc = 0;
+        float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sD = 0.f, sDist = 0.f;   // this lane's share of the sums
+        float sF[SF];
+#pragma unroll
+        for (int i = 0; i < SF; i++) sF[i] = 0.f;
+        for (int base = 0; base < total; base += MRGS_CHUNK) {
+            const int e = base + lane;
+            const bool valid = e < total;
+            const uint32_t gid = plist[valid ? e : 0];
+            const float4* src = rec + (size_t)gid * MRGS_REC_F4;
+            SurfelGeom sg;
+            sg.g0 = src[0]; sg.g1 = src[1]; sg.g2 = src[2];
+            Hit h;
+            const bool hit = mrgs_intersect_exact(sg, qx, qy, h) & valid;
+            const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
+            const float oma = 1.0f - h.alpha;
+            // T in front of every hit of the chunk: the serial product, one float multiplication per hit in list order
+            float Tb = 0.f, run = xT;
+            for (uint64_t mm_ = hm; mm_ != 0ull; mm_ &= mm_ - 1) {
+                const int jj = __builtin_ctzll(mm_);
+                Tb = lane == jj ? run : Tb;
+                run = run * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(oma), jj));
+            }
+            // the first hit that would take T below 1e-4 ends the pixel and is not blended (forward.cu:400-404); the products
+            // formed behind it are not used
+            const uint64_t tm = __builtin_amdgcn_ballot_w64(hit & (Tb * oma < MRGS_T_MIN));
+            const uint64_t bm = tm != 0ull ? hm & ((1ull << __builtin_ctzll(tm)) - 1ull) : hm;
+            const bool bl = (bm >> lane) & 1ull;
+            if (tm != 0ull) xT = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(Tb), __builtin_ctzll(tm)));
+            else xT = run;
+            const float w = bl ? h.alpha * Tb : 0.0f;
+            const float depth = bl ? h.depth : 1.0f;
+            const float m_ = mscale * (1.0f - MRGS_NEAR_N * (1.0f / depth));
+            const float mw = m_ * w, mmw = m_ * m_ * w;
+            // M1, M2 in front of this lane's entry: carry of the chunks before + exclusive prefix inside the chunk
+            float i1 = mw, i2 = mmw;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float u1 = __shfl_up(i1, d, 64), u2 = __shfl_up(i2, d, 64);
+                if (lane >= d) { i1 += u1; i2 += u2; }
+            }
+            const float pM1 = xM1 + (i1 - mw), pM2 = xM2 + (i2 - mmw);
+            xM1 += __shfl(i1, 63, 64);
+            xM2 += __shfl(i2, 63, 64);
+            sDist = fmaf(fmaf(-2.0f * m_, pM1, fmaf(m_ * m_, 1.0f - Tb, pM2)), w, sDist);
+            sD = fmaf(depth, w, sD);
+            const float4 a0 = src[3], a1 = src[4];
+            sN0 = fmaf(a0.x, w, sN0); sN1 = fmaf(a0.y, w, sN1); sN2 = fmaf(a0.z, w, sN2);
+            sC0 = fmaf(a0.w, w, sC0); sC1 = fmaf(a1.x, w, sC1); sC2 = fmaf(a1.y, w, sC2);
+            if (S_MAX > 0) {
+                const float* fsrc = features + (size_t)gid * S;
+#pragma unroll
+                for (int ch = 0; ch < S_MAX; ch++)
+                    if (ch < S) sF[ch] = fmaf(fsrc[ch], w, sF[ch]);
+            }
+            if (bm != 0ull) xlast = (uint32_t)(base + 64 - __builtin_clzll(bm));
+            const uint64_t medm = __builtin_amdgcn_ballot_w64(bl & (Tb > 0.5f));          // forward.cu:417-420
+            if (medm != 0ull) {
+                const int jm = 63 - __builtin_clzll(medm);
+                xmedc = (uint32_t)(base + jm + 1);
+                xmed = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.depth), jm));
+            }
+            // flags for the backward: bit 0 = blended by some pixel, bit 1 = the FAST evaluation of this pair cannot be sure of the hit
+            // (the main kernel flagged the entries it walked; this pixel may go further than its wave did).  Bits are only ever set here.
+            if (valid) {
+                Hit hf;
+                bool amb;
+                const bool mh = mrgs_intersect(sg, qx, qy, hf);
+                (void)mrgs_hit_decide(hf, mh, amb);
+                const bool in_reach = tm == 0ull || lane <= __builtin_ctzll(tm);
+                const uint32_t fl = (bl ? 1u : 0u) | ((amb && in_reach) ? 3u : 0u);
+                // (the four quadrant bytes of a list entry are one aligned word; marked pixels of one block may meet on a byte)
+                if (fl) atomicOr(reinterpret_cast<uint32_t*>(cflag) + range.x + e, fl << (8 * quad));
+            }
+            if (tm != 0ull) break;
+        }
+        auto wave_sum = [&](float v) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            return v;
+        };
+        sC0 = wave_sum(sC0); sC1 = wave_sum(sC1); sC2 = wave_sum(sC2);
+        sN0 = wave_sum(sN0); sN1 = wave_sum(sN1); sN2 = wave_sum(sN2);
+        sD = wave_sum(sD); sDist = wave_sum(sDist);
+        if (S_MAX > 0) {
+#pragma unroll
+            for (int ch = 0; ch < S_MAX; ch++) sF[ch] = wave_sum(sF[ch]);
+        }
+        if (lane == 0) {
+            final_T[pix] = xT;
+            final_T[pix + HW] = xM1;
+            final_T[pix + 2 * HW] = xM2;
+            n_contrib[pix] = xlast;
+            n_contrib[pix + HW] = xmedc;
+            out_color[pix] = fmaf(xT, bg[0], sC0);
+            out_color[pix + HW] = fmaf(xT, bg[1], sC1);
+            out_color[pix + 2 * HW] = fmaf(xT, bg[2], sC2);
+            if (S_MAX > 0) {
+#pragma unroll
+                for (int ch = 0; ch < S_MAX; ch++)
+                    if (ch < S) out_feature[(size_t)ch * HW + pix] = sF[ch];
+            }
+            out_others[pix + 0 * HW] = sD;
+            out_others[pix + 1 * HW] = 1.0f - xT;
+            out_others[pix + 2 * HW] = sN0;
+            out_others[pix + 3 * HW] = sN1;
+            out_others[pix + 4 * HW] = sN2;
+            out_others[pix + 5 * HW] = xmed;
+            out_others[pix + 6 * HW] = sDist;
+        }
+    }
+}
+
 #define MRGS_FWD_KERNEL render_fwd_kernel
+#ifdef MRGS_FWD_REDO_ALL
+#define MRGS_REDO_BLOCKS 8192
+#else
+#define MRGS_REDO_BLOCKS 512
 #endif
 
 void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, const uint32_t* plist,
@@ -321,7 +470,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV)                                                                                                           \
     hipLaunchKernelGGL((MRGS_FWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, g.cull, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, FVV>>())
+                       g.rec, g.cull, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, FVV>>(), img.redo_list)
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
     if (cfg.S == 0) LAUNCH(0, false);
@@ -332,4 +481,12 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     else if (cfg.S == 24 && fv_ok) LAUNCH(24, true);
     else LAUNCH(24, false);
 #undef LAUNCH
+    // the marked pixels again, exactly (an empty list most of the time: the launch is there for the count it reads on the device)
+#define REDO(SM) hipLaunchKernelGGL((render_fwd_redo_kernel<SM>), dim3(MRGS_REDO_BLOCKS), block, 0, stream, img.ranges, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, \
+                                    g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.redo_list)
+    if (cfg.S == 0) REDO(0);
+    else if (cfg.S <= 8) REDO(8);
+    else if (cfg.S <= 12) REDO(12);
+    else REDO(24);
+#undef REDO
 }

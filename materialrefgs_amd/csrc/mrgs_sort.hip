@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ qstate, const uint32_t* __restrict__ census,
                                                            uint32_t* __restrict__ cu_state, int forward, uint32_t* __restrict__ zero_this,
                                                            float4* __restrict__ bulk_zero, size_t bulk_zero_f4, const uint32_t* __restrict__ hint,
-                                                           uint32_t* __restrict__ qstate_twin)
+                                                           uint32_t* __restrict__ qstate_twin, uint32_t* __restrict__ redo_count)
 {
     // workgroups beyond the eight that order the lists only clear a buffer for the kernel that follows (the gradient rows of
     // the blend backward, 24 MB at P = 300k): the ordering occupies 8 CUs for ~10 us, the clear runs beside it on the others
@@ -590,6 +590,7 @@ __global__ void __launch_bounds__(1024) blend_order_kernel(const uint32_t* __res
     }
     if (zero_this != nullptr)
         for (int i = tid + 1024 * x; i < 4 * ntiles; i += 8 * 1024) zero_this[i] = 0u;
+    if (redo_count != nullptr && x == 0 && tid == 0) redo_count[0] = 0u;     // the forward blend's list of marked pixels: empty
     // forward: every (tile, quadrant) is an item (idle ones still write their pixels: key = work + 1); backward: only those
     // with work
     const uint32_t idle = forward ? 1u : 0u;
@@ -727,11 +728,11 @@ void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int n
     if (backward)
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
                            img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr,
-                           (float4*)bulk_zero, f4, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                           (float4*)bulk_zero, f4, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
                            img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work,
-                           (float4*)bulk_zero, f4, fwd_hint, bulk_zero ? img.blend_state + MRGS_QS_BWD : (uint32_t*)nullptr);
+                           (float4*)bulk_zero, f4, fwd_hint, bulk_zero ? img.blend_state + MRGS_QS_BWD : (uint32_t*)nullptr, img.redo_list);
 }
 
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,

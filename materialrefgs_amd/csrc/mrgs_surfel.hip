@@ -29,7 +29,7 @@ __device__ __constant__ float cSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
 
 // 64 consecutive rows of L floats <-> LDS tile, 16 bytes per lane and instruction (the run starts 16-byte aligned because
 // the first row index is a multiple of 64); partial waves take the scalar path
-template <int L>
+template <int L, int STRIDE = REST_STRIDE>
 __device__ __forceinline__ void tile_load(float* __restrict__ tile, const float* __restrict__ src, int nrows, int lane)
 {
     if (nrows == 64) {
@@ -44,15 +44,15 @@ __device__ __forceinline__ void tile_load(float* __restrict__ tile, const float*
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int e = 4 * t + i;
-                    tile[(e / L) * REST_STRIDE + (e % L)] = a[i];
+                    tile[(e / L) * STRIDE + (e % L)] = a[i];
                 }
             }
         }
     } else {
-        for (int e = lane; e < nrows * L; e += 64) tile[(e / L) * REST_STRIDE + (e % L)] = src[e];
+        for (int e = lane; e < nrows * L; e += 64) tile[(e / L) * STRIDE + (e % L)] = src[e];
     }
 }
-template <int L>
+template <int L, int STRIDE = REST_STRIDE>
 __device__ __forceinline__ void tile_store(const float* __restrict__ tile, float* __restrict__ dst, int nrows, int lane)
 {
     if (nrows == 64) {
@@ -66,13 +66,13 @@ __device__ __forceinline__ void tile_store(const float* __restrict__ tile, float
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int e = 4 * t + i;
-                    a[i] = tile[(e / L) * REST_STRIDE + (e % L)];
+                    a[i] = tile[(e / L) * STRIDE + (e % L)];
                 }
                 d4[t] = make_float4(a[0], a[1], a[2], a[3]);
             }
         }
     } else {
-        for (int e = lane; e < nrows * L; e += 64) dst[e] = tile[(e / L) * REST_STRIDE + (e % L)];
+        for (int e = lane; e < nrows * L; e += 64) dst[e] = tile[(e / L) * STRIDE + (e % L)];
     }
 }
 
@@ -295,13 +295,24 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
 // dL/dsh[k][c] of view v = B_k(dir_v) * dRGB_v[c] (backward.cu:22-141), so instead of all-reducing 48 floats per gaussian the
 // ranks all-gather 3 and every rank evaluates sum_v B_k(dir_v(p)) dRGB_v[p][c] itself.  gathered: V rows of `row_stride` floats,
 // row v = [dRGB_v (P x 3) | campos_v (3)].
+// Stores: a lane's 3 M floats are one 12 M-byte row, i.e. written lane by lane the wave's 64 rows take 48 scalar store instructions of
+// 64 different cache lines each (0.7 TB/s, 133 us for 300 k gaussians -- a third of the whole exchange at V = 8).  For M = 16 the rows go
+// through a per-wave LDS tile (row stride 49 floats: lane-private rows without bank conflicts) and leave as 16-byte pieces of the wave's
+// contiguous 12 KB run, as in preprocess_bwd.
+#define EXP_L 48
+#define EXP_STRIDE 49
+template <bool TILE>
 __global__ void __launch_bounds__(256) sh_grad_expand_kernel(int P, int M, int D, int V, const float* __restrict__ means3D,
                                                              const float* __restrict__ gathered, long long row_stride,
                                                              float* __restrict__ out)
 {
+    __shared__ float s_tile[TILE ? 4 : 1][TILE ? 64 * EXP_STRIDE : 1];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+    const int lane = threadIdx.x & 63, row0 = idx - lane;
+    const bool in_range = idx < P;
+    if (!TILE && !in_range) return;
+    const size_t i3 = 3 * (size_t)(in_range ? idx : 0);
+    const float p[3] = {means3D[i3], means3D[i3 + 1], means3D[i3 + 2]};
     float acc[16][3];
 #pragma unroll
     for (int k = 0; k < 16; k++) { acc[k][0] = 0.0f; acc[k][1] = 0.0f; acc[k][2] = 0.0f; }
@@ -309,7 +320,7 @@ __global__ void __launch_bounds__(256) sh_grad_expand_kernel(int P, int M, int D
     for (int v = 0; v < V; v++) {
         const float* row = gathered + (size_t)v * row_stride;
         const float* cam = row + 3 * (size_t)P;
-        const float g[3] = {row[3 * (size_t)idx], row[3 * (size_t)idx + 1], row[3 * (size_t)idx + 2]};
+        const float g[3] = {row[i3], row[i3 + 1], row[i3 + 2]};
         if (g[0] == 0.0f && g[1] == 0.0f && g[2] == 0.0f) continue;     // not visible in that view
         const float d[3] = {p[0] - cam[0], p[1] - cam[1], p[2] - cam[2]};
         const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -320,6 +331,17 @@ __global__ void __launch_bounds__(256) sh_grad_expand_kernel(int P, int M, int D
             const float b = k < ncoef ? B[k] : 0.0f;
             acc[k][0] += b * g[0]; acc[k][1] += b * g[1]; acc[k][2] += b * g[2];
         }
+    }
+    if (TILE) {       // M == 16
+        float* tile = s_tile[threadIdx.x >> 6];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) tile[lane * EXP_STRIDE + 3 * k + c] = acc[k][c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (row0 < P) tile_store<EXP_L, EXP_STRIDE>(tile, out + (size_t)row0 * EXP_L, min(64, P - row0), lane);
+        return;
     }
     float* o = out + (size_t)idx * M * 3;
     for (int k = 0; k < M; k++) {
@@ -339,10 +361,13 @@ __global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D
                                                                     long long row_stride, float* __restrict__ g_dc, float* __restrict__ g_rest,
                                                                     float* __restrict__ g_ind_dc, float* __restrict__ g_ind_rest)
 {
+    __shared__ float s_tile[4][64 * REST_STRIDE];       // the wave's 64 rows of 45 "rest" floats, first one family, then the other
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const float p[3] = {xyz[3 * (size_t)idx], xyz[3 * (size_t)idx + 1], xyz[3 * (size_t)idx + 2]};
-    const float4 q = reinterpret_cast<const float4*>(rotation_raw)[idx];
+    const int lane = threadIdx.x & 63, row0 = idx - lane;
+    const bool in_range = idx < P;
+    const size_t ic = (size_t)(in_range ? idx : 0);
+    const float p[3] = {xyz[3 * ic], xyz[3 * ic + 1], xyz[3 * ic + 2]};
+    const float4 q = reinterpret_cast<const float4*>(rotation_raw)[ic];
     float a[16][3], b[16][3];
 #pragma unroll
     for (int k = 0; k < 16; k++) { a[k][0] = a[k][1] = a[k][2] = 0.0f; b[k][0] = b[k][1] = b[k][2] = 0.0f; }
@@ -350,9 +375,9 @@ __global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D
     for (int v = 0; v < V; v++) {
         const float* row = gathered + (size_t)v * row_stride;
         const float* cam = row + 6 * (size_t)P;
-        const float g[3] = {row[3 * (size_t)idx], row[3 * (size_t)idx + 1], row[3 * (size_t)idx + 2]};
+        const float g[3] = {row[3 * ic], row[3 * ic + 1], row[3 * ic + 2]};
         const float* ri = row + 3 * (size_t)P;
-        const float h[3] = {ri[3 * (size_t)idx], ri[3 * (size_t)idx + 1], ri[3 * (size_t)idx + 2]};
+        const float h[3] = {ri[3 * ic], ri[3 * ic + 1], ri[3 * ic + 2]};
         const bool has_g = (g[0] != 0.0f) | (g[1] != 0.0f) | (g[2] != 0.0f), has_h = (h[0] != 0.0f) | (h[1] != 0.0f) | (h[2] != 0.0f);
         if (!has_g && !has_h) continue;
         const Frame f = make_frame(p, q, cam);
@@ -371,17 +396,33 @@ __global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D
             for (int k = 0; k < 16; k++) { b[k][0] += B[k] * h[0]; b[k][1] += B[k] * h[1]; b[k][2] += B[k] * h[2]; }
         }
     }
+    if (in_range) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        g_dc[3 * (size_t)idx + c] = a[0][c];
-        g_ind_dc[3 * (size_t)idx + c] = b[0][c];
+        for (int c = 0; c < 3; c++) {
+            g_dc[3 * (size_t)idx + c] = a[0][c];
+            g_ind_dc[3 * (size_t)idx + c] = b[0][c];
+        }
     }
-    float* o1 = g_rest + (size_t)idx * 45;
-    float* o2 = g_ind_rest + (size_t)idx * 45;
+    // the two [P,15,3] tensors: a lane's row is 180 bytes, written lane by lane the wave's 64 rows are 45 scalar stores of 64 cache lines
+    // each; through the per-wave tile they leave as 16-byte pieces of one contiguous 11.5 KB run
+    float* tile = s_tile[threadIdx.x >> 6];
+    const int nrows = min(64, P - row0);
 #pragma unroll
     for (int k = 1; k < 16; k++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) { o1[3 * (k - 1) + c] = a[k][c]; o2[3 * (k - 1) + c] = b[k][c]; }
+        for (int c = 0; c < 3; c++) tile[lane * REST_STRIDE + 3 * (k - 1) + c] = a[k][c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (row0 < P) tile_store<REST_L>(tile, g_rest + (size_t)row0 * REST_L, nrows, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) tile[lane * REST_STRIDE + 3 * (k - 1) + c] = b[k][c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (row0 < P) tile_store<REST_L>(tile, g_ind_rest + (size_t)row0 * REST_L, nrows, lane);
 }
 
 }   // namespace
@@ -406,8 +447,13 @@ int mrgs_sh_grad_expand(int32_t P, int32_t M, int32_t D, int32_t V, const float*
     if (P < 0 || M < 1 || D < 0 || D > 3 || V < 1 || row_stride < 3 * (int64_t)P + 3) return MRGS_E_BAD_ARG;
     if (P == 0) return MRGS_OK;
     if (!means3D || !gathered || !dL_dsh) return MRGS_E_BAD_ARG;
-    hipLaunchKernelGGL(sh_grad_expand_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, D, V, means3D, gathered,
-                       (long long)row_stride, dL_dsh);
+    // 16-byte pieces need the output 16-byte aligned (torch allocations are)
+    if (M == 16 && ((uintptr_t)dL_dsh & 15u) == 0)
+        hipLaunchKernelGGL(sh_grad_expand_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, D, V, means3D, gathered,
+                           (long long)row_stride, dL_dsh);
+    else
+        hipLaunchKernelGGL(sh_grad_expand_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, M, D, V, means3D, gathered,
+                           (long long)row_stride, dL_dsh);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

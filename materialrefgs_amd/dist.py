@@ -93,6 +93,27 @@ class FactoredGradReducer:
         P = self.sh_shape[0]
         self.row = torch.empty(3 * P + 3, dtype=torch.float32, device=device)
         self.gathered = None
+        self._early = None
+
+    def _gather(self, world, group):
+        P = self.sh_shape[0]
+        if self.gathered is None or self.gathered.shape[0] != world:
+            self.gathered = torch.empty((world, 3 * P + 3), dtype=torch.float32, device=self.row.device)
+        return dist.all_gather_into_tensor(self.gathered.view(-1), self.row, group=group, async_op=True)   # flat output: gloo insists
+
+    def begin_early(self, dRGB: torch.Tensor, campos: torch.Tensor, group=None):
+        """Start the all-gather of this view's factor BEFORE its backward has finished: `dRGB` [P,3] is the clamp-masked colour gradient
+        the rasterizer hands out between the blend backward and the per-gaussian backward (rasterizer.set_after_blend_hook;
+        mrgs_rasterize_backward_blend).  The collective is issued behind what the current stream holds at this moment, so it runs next
+        to the per-gaussian backward queued afterwards; the following reduce() picks the gathered rows up instead of gathering
+        dL/dsh[:, 0, :] / SH_C0 (the same numbers to one rounding)."""
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1:
+            return
+        P = self.sh_shape[0]
+        self.row[:3 * P].view(P, 3).copy_(dRGB)
+        self.row[3 * P:].copy_(campos.reshape(-1))
+        self._early = self._gather(world, group)
 
     def reduce(self, tensors: Sequence[Optional[torch.Tensor]], means3D: torch.Tensor, campos: torch.Tensor, sh_degree: int, group=None):
         """Returns the summed gradients in the order of `tensors` (views into internal buffers)."""
@@ -104,14 +125,14 @@ class FactoredGradReducer:
         if world == 1:
             views = self.small.views()
             return views[:self.sh_index] + [sh] + views[self.sh_index:]
-        if sh is None:
-            self.row[:3 * P].zero_()
-        else:
-            torch.div(sh[:, 0, :], SH_C0, out=self.row[:3 * P].view(P, 3))
-        self.row[3 * P:].copy_(campos.reshape(-1))
-        if self.gathered is None or self.gathered.shape[0] != world:
-            self.gathered = torch.empty((world, 3 * P + 3), dtype=torch.float32, device=self.row.device)
-        w1 = dist.all_gather_into_tensor(self.gathered.view(-1), self.row, group=group, async_op=True)   # flat output: gloo insists
+        w1, self._early = self._early, None
+        if w1 is None:
+            if sh is None:
+                self.row[:3 * P].zero_()
+            else:
+                torch.div(sh[:, 0, :], SH_C0, out=self.row[:3 * P].view(P, 3))
+            self.row[3 * P:].copy_(campos.reshape(-1))
+            w1 = self._gather(world, group)
         w2 = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         w1.wait()
         sh_sum = self.expand_fn(self.gathered, means3D, M, sh_degree)

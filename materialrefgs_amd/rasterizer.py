@@ -77,6 +77,7 @@ def reset_work_hints():
     """Forget every camera's measured work (the next render of each camera is a first visit again).  A training loop calls this after
     densification / pruning changed the surfel set; bench.py uses it to time first visits."""
     _WORK_HINTS.clear()
+    _CAM_COPIES.clear()
 
 
 _ZERO_CONTRIB = {}
@@ -92,6 +93,17 @@ def _zero_contrib(dev, H, W):
             _ZERO_CONTRIB.clear()
         t = _ZERO_CONTRIB[key] = torch.zeros((1, H, W), dtype=torch.int32, device=dev)
     return t
+
+
+_AFTER_BLEND_HOOK = [None]
+
+
+def set_after_blend_hook(fn):
+    """fn(dL_dRGB_masked [P,3]) is called in the middle of every rasterizer backward, after the blend backward has been queued and
+    before the per-gaussian backward: the clamp-masked colour gradient of every surfel (= dL/dsh[:, 0, :] / SH_C0 for SH colours,
+    dL/dcolors_precomp otherwise) is final at that point of the stream.  A view-parallel training step registers
+    dist.FactoredGradReducer.begin_early here so that its all-gather runs under the per-gaussian backward.  None removes the hook."""
+    _AFTER_BLEND_HOOK[0] = fn
 
 
 LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (bench.py reads it for the roofline figure)
@@ -110,6 +122,29 @@ def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+_CAM_COPIES = {}     # (data_ptr, strides, dtype) of a camera matrix as the caller holds it -> (that tensor, its version, contiguous fp32 copy)
+_CAM_COPIES_MAX = 4096
+
+
+def _camera_f32c(t):
+    """Contiguous fp32 form of a camera tensor, THE SAME tensor for every render of the same camera.  The reference's Camera builds
+    `world_view_transform = torch.tensor(...).transpose(0, 1).cuda()` (scene/cameras.py:77): a transposed view, not contiguous, so a
+    plain .contiguous() would hand the rasterizer a fresh copy (a fresh address) on every render -- and the per-camera work hints,
+    which are keyed by the matrices' addresses, would never see the same camera twice.  The copy is cached per source tensor (address,
+    strides, dtype; the entry keeps the source alive, so the address cannot be reused) and redone when the source was written in place."""
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    key = (t.data_ptr(), tuple(t.stride()), t.dtype, t.device.index)
+    ent = _CAM_COPIES.get(key)
+    if ent is not None and ent[1] == t._version and ent[0].shape == t.shape:
+        return ent[2]
+    if ent is None and len(_CAM_COPIES) >= _CAM_COPIES_MAX:
+        _CAM_COPIES.pop(next(iter(_CAM_COPIES)))
+    c = _f32c(t)
+    _CAM_COPIES[key] = (t, t._version, c)
+    return c
 
 
 def _stream(device):
@@ -324,9 +359,21 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
              "dL_dsh_rest": torch.empty((P, M - 1, 3), **opts) if sh_rest is not None else None}
         grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_[1:]])
         grad_ws = prepared_grad_ws if prepared_grad_ws is not None else torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
-        _lib.check(L.mrgs_rasterize_backward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
-                                             num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),
-                                             _ptr(grad_ws), ctypes.byref(grads), st))
+        hook = _AFTER_BLEND_HOOK[0]
+        if hook is None or P == 0:
+            _lib.check(L.mrgs_rasterize_backward(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                                 num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),
+                                                 _ptr(grad_ws), ctypes.byref(grads), st))
+        else:
+            # two halves: the colour gradients are final after the blend backward; whatever the hook queues on another stream (a
+            # view-parallel step: the all-gather of this factor, dist.FactoredGradReducer.begin_early) overlaps the per-gaussian backward
+            drgb = torch.empty((P, 3), **opts)
+            _lib.check(L.mrgs_rasterize_backward_blend(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                                       num_rendered, _ptr(grad_out_color), _ptr(grad_out_feature), _ptr(grad_out_others),
+                                                       _ptr(grad_ws), _ptr(drgb), st))
+            hook(drgb)
+            _lib.check(L.mrgs_rasterize_backward_finish(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(grad_ws),
+                                                        ctypes.byref(grads), st))
     return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dfeatures"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dtransMat"],
             g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dsh_rest"])
 
@@ -347,8 +394,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D, sh, colors_precomp, features = _f32c(means3D), _f32c(sh), _f32c(colors_precomp), _f32c(features)
         sh_rest = None if sh_rest is None else _f32c(sh_rest)
         opacities, scales, rotations, cov3Ds_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
-        rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_f32c(raster_settings.viewmatrix),
-                                      projmatrix=_f32c(raster_settings.projmatrix), campos=_f32c(raster_settings.campos))
+        rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_camera_f32c(raster_settings.viewmatrix),
+                                      projmatrix=_camera_f32c(raster_settings.projmatrix), campos=_camera_f32c(raster_settings.campos))
         args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest, any(ctx.needs_input_grad) and not _NO_PREPARE and means3D.is_cuda and _hint_is_warm(rs, means3D.device))
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted

@@ -252,10 +252,38 @@ class _SurfelComposite(torch.autograd.Function):
         return g_base, g_refl, g_spec, g_alpha, None, None
 
 
-def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=True, return_normal_map=False):
+def pgsr_unbiased_depth(allmap, rend_distance, viewpoint_camera):
+    """The eighth all-map channel of the "pgsr" flavour (`allmap[7:8]`, gaussian_renderer/__init__.py:64-69 with the shipped
+    arguments/config.py FLAG): the depth at which the pixel's ray meets the blended PLANE, from the blended plane distance and the blended
+    view-space normal -- distance / -(normal . ray), ray = K^-1 (x, y, 1).  PARITY UNPINNED: the reference takes the channel from
+    `diff_surfel_rasterization2`, which is not in its tree; this is the published PGSR definition (Chen et al. 2024,
+    "unbiased depth": D / (N . K^-1 p~) with the sign of a camera-facing normal), applied to what this rasterizer blends: `rend_distance`
+    = sum w |n . c| (get_distance, :30-40) and allmap[2:5] = sum w n, both un-normalised sums, so the accumulated alpha cancels.  The
+    ray goes through pixel (x, y) of the rasterizer's own image plane (principal point (W - 1) / 2, the ndc2pix of forward.cu:114-118),
+    so the depth is consistent with where the surfels were splatted.  Empty pixels give 0 / 0; callers apply nan_to_num as the
+    reference does."""
+    H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+    fx = W / (2.0 * math.tan(viewpoint_camera.FoVx * 0.5))
+    fy = H / (2.0 * math.tan(viewpoint_camera.FoVy * 0.5))
+    dev, dt = allmap.device, allmap.dtype
+    rx = (torch.arange(W, device=dev, dtype=dt) - 0.5 * (W - 1)) / fx
+    ry = (torch.arange(H, device=dev, dtype=dt) - 0.5 * (H - 1)) / fy
+    n_dot_ray = allmap[2] * rx[None, :] + allmap[3] * ry[:, None] + allmap[4]
+    return rend_distance / (-n_dot_ray).unsqueeze(0)
+
+
+def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=True, return_normal_map=False,
+                                            rend_distance=None):
     """gaussian_renderer/__init__.py:42-90, one HIP kernel each way (`mrgs_surfel_maps_*`).  With `return_normal_map` the
-    dictionary also holds render_surfel's `normal_map` [H,W,3] = render_normal / max(alpha, 1e-6) (:419-421)."""
-    fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
+    dictionary also holds render_surfel's `normal_map` [H,W,3] = render_normal / max(alpha, 1e-6) (:419-421).
+    `rend_distance` (the "pgsr" flavour's blended plane distance): surf_depth is then the flavour's unbiased depth
+    (`nan_to_num(allmap[7])`, :64-69; pgsr_unbiased_depth) instead of the expected / median mix, and surf_normal its finite differences."""
+    if rend_distance is not None:
+        # the fused kernel takes surf_depth = nan_to_num(median channel) at depth_ratio 1: the unbiased depth rides in that slot
+        allmap = torch.cat((allmap[:5], pgsr_unbiased_depth(allmap, rend_distance, viewpoint_camera), allmap[6:7]), dim=0)
+        fr = _maps_frame(viewpoint_camera, 1.0)
+    else:
+        fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
     rn, sd, sn, nm, ra, rd = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map))
     out = {"render_alpha": ra, "render_normal": rn, "render_depth_median": None, "render_depth_expected": None,
            "render_dist": rd, "surf_depth": sd, "surf_normal": sn if return_depth_normal else None}
@@ -318,8 +346,8 @@ def _asg_indirect_of(pc, viewpoint_camera, scaling_modifier):
 def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, srgb=False, opt=None, flag="2dgs"):
     """gaussian_renderer/__init__.py:94-220: diffuse-only surfel rendering (S = 0 in the 2dgs flavour).  flag "pgsr"
     (arguments/config.py:1): the plane distance of get_distance rides as the one feature channel and comes back as "rend_distance"
-    (:170-176, 215-218) -- blended by the vendored rasterizer's rule; the pgsr flavour's unbiased-depth all-map channel is not
-    reproduced."""
+    (:170-176, 215-218) -- blended by the vendored rasterizer's rule -- and surf_depth / surf_normal come from the flavour's unbiased
+    depth (pgsr_unbiased_depth; parity unpinned)."""
     means2D = _screenspace_points(pc)
     dist_feature = get_distance(scaling_modifier, pc.get_xyz, viewpoint_camera, pc) if flag != "2dgs" else None
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
@@ -327,7 +355,8 @@ def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, o
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=pc.get_xyz, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=dist_feature, opacities=pc.get_opacity,
         scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
-    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe)
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe,
+                                                  rend_distance=rendered_features[0:1] if flag != "2dgs" else None)
     final_image = rendered_image
     if srgb:
         final_image = linear_to_srgb(final_image)
@@ -372,7 +401,7 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     albedo, indirect_light = rendered_features[2:5], rendered_features[5:8]
 
     reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img),
-                                                  return_normal_map=(not wo_render_img))
+                                                  return_normal_map=(not wo_render_img), rend_distance=rend_distance)
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
     geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": render_normal, "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
@@ -453,7 +482,7 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     render_roughness, render_refl_strength = rendered_features[:1], rendered_features[1:2]
     render_diffuse_color, render_specular_color = rendered_features[2:5], rendered_features[5:8]
     render_ori_color = rendered_features[8:11]
-    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe)
+    reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, rend_distance=rendered_features[-1:] if flag != "2dgs" else None)
     render_alpha = reg["render_alpha"]
     if srgb:
         render_diffuse_color, render_specular_color = linear_to_srgb(render_diffuse_color), linear_to_srgb(render_specular_color)
@@ -719,7 +748,7 @@ def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color,
     refl_strength, roughness_map, albedo = rendered_features[:1], rendered_features[1:2], rendered_features[2:5]
     blend_weight = rendered_features[8:9]
     reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img),
-                                                  return_normal_map=True)
+                                                  return_normal_map=True, rend_distance=rendered_features[-1:] if flag != "2dgs" else None)
     render_alpha = reg["render_alpha"]
     geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"],

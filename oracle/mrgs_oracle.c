@@ -21,7 +21,10 @@
  *     exactly where materialrefgs_amd/csrc/mrgs_blend_math.h fuses them.  nvcc fuses the reference's own build too
  *     (-fmad=true is its default), in a pattern that cannot be known here; choosing one fixed pattern on both sides
  *     makes the ill-conditioned ray/splat cross product bit-reproducible.  The GPU's reciprocal (v_rcp_f32) and exp
- *     (v_exp_f32) are 1-ulp approximations; here they are 1.0f/x and R_EXP(x).
+ *     (v_exp_f32) are approximations good to a few ulp; here they are the IEEE quotient 1.0f/x and the correctly rounded
+ *     exponential R_EXP(x).  The kernels take every DECISION (alpha >= 1/255, depth >= 0.2, rho3d <= rho2d, T (1 - alpha) < 1e-4,
+ *     T > 0.5) with exactly these two operations wherever the fast value is within its error band of the threshold
+ *     (mrgs_blend_math.h, "Exact decisions"), so contributor counters and the set of blended pairs are compared bit for bit.
  * Deviations, all documented in DESIGN.md:
  *   - rR_SQRT(x) is evaluated as 1.0f/R_SQRT(x) (CUDA's rsqrtf is a 2-ulp approximation that cannot be restated);
  *   - per-gaussian gradient sums (the reference's fp32 atomicAdd, whose order is nondeterministic) are
@@ -54,7 +57,14 @@ typedef double real;
 #else
 typedef float real;
 #define R_SQRT sqrtf
+#ifdef MRGS_ORACLE_LITERAL
 #define R_EXP expf
+#else
+/* the bit-level checker takes exp CORRECTLY ROUNDED (glibc's double exp, < 1 ulp of a double, rounded once): a definition the HIP
+ * kernels can meet bit for bit where a decision hangs on it (mrgs_blend_math.h: mrgs_exp_cr), which "whatever this libm's expf
+ * returns" is not (glibc's expf is within 0.502 ulp, i.e. not always the correctly rounded value) */
+#define R_EXP(x) ((float)exp((double)(x)))
+#endif
 #define R_CEIL ceilf
 #define R_FMIN fminf
 #endif

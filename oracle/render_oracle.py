@@ -91,13 +91,15 @@ def sample_camera_rays_unnormalize(H, W, K, R, T):
 
 
 def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=False, indirect=False, mesh=None, variant="fused",
-                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None):
+                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None, mips=None, flag="2dgs"):
     """`pc`: a SurfelModel on the CPU (float64 leaves recommended); `env_base`: [6,N,N,3] pre-sigmoid texels (leaf);
     `mesh`: (vertices, triangles) for opt.indirect.  Returns the reference's dictionary (CPU tensors, autograd attached).
     `visibility_bits` [H,W]: use these bits instead of the own trace in the blend (the trace result is still returned under
     "visibility_traced"): visibility is a step function of the mirror ray, a pixel on a silhouette flips with the last bit of the
     ray set-up, and a test that wants to compare GRADIENTS first checks the two bit maps against each other and then removes
-    that source of difference."""
+    that source of difference.
+    `mips`: prefiltered specular levels to shade with instead of building them from `env_base` (bench.py's CPU leg at 128^2 texels, where
+    the dense float64 operators of envfilter_oracle -- (6 N^2)^2 entries -- do not fit; the environment then receives no gradient)."""
     from materialrefgs_amd.shading import load_fg_lut
     dt = pc._xyz.dtype
     H, W = cam.image_height, cam.image_width
@@ -105,8 +107,14 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
     means2D = torch.zeros_like(pc._xyz, requires_grad=True)                                           # :229-233
     opacities, scales, rotations, features = go.surfel_features_reference(pc, cam.camera_center.to(dt))   # :338-355
     shs = pc.get_features
+    if flag != "2dgs":            # "pgsr": + the plane distance as the last channel (:352-357)
+        features = torch.cat((features, go.get_distance(pc, cam)), dim=-1)
     color, feat, allmap, radii = _OracleRaster.apply(pc.get_xyz, means2D, opacities, shs, features, scales, rotations, cam,
                                                      pc.active_sh_degree, variant)                   # :359-370
+    rend_distance = None
+    if flag != "2dgs":
+        rend_distance = feat[-1:]
+        allmap = go.pgsr_allmap8(allmap, rend_distance, cam)
     base_color = color
     refl_strength, roughness = feat[:1], feat[1:2]                                                    # :372-378 ("2dgs")
     albedo, indirect_light = feat[2:5], feat[5:8]
@@ -114,7 +122,8 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
     reg = go.compute_2dgs_normal_and_regularizations_reference(allmap, cam_dt, pipe)                  # :392
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
     normal_map = render_normal.permute(1, 2, 0) / render_alpha.permute(1, 2, 0).clamp_min(1e-6)       # :419-421
-    *mips, _diffuse_tex = _OracleBuildMips.apply(env_base, env_min_res, min_roughness, max_roughness)
+    if mips is None:
+        *mips, _diffuse_tex = _OracleBuildMips.apply(env_base, env_min_res, min_roughness, max_roughness)
     _H, _W, K = cam.HWK
     R32, T32 = cam.R.float(), cam.T.float()
     a_hw, r_hw, ro_hw = render_alpha.permute(1, 2, 0), refl_strength.permute(1, 2, 0), roughness.permute(1, 2, 0)
@@ -151,6 +160,8 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
            "specular_map": specular, "base_color_map": albedo, "roughness_map": roughness, "viewspace_points": means2D,
            "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha, "rend_normal": render_normal,
            "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
+    if rend_distance is not None:
+        out["rend_distance"] = rend_distance
     if indirect:
         out.update(extra)
         out["indirect_color"] = diffuse + extra["indirect_color"] + background                        # :449-452
@@ -158,8 +169,9 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
 
 
 def render_volume_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=False, indirect=False, mesh=None, variant="fused",
-                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None):
-    """gaussian_renderer/__init__.py:521-749 (`render_volume`, SH-indirect branch) with utils/refl_utils.py:426-484 for the
+                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None, flag="pgsr"):
+    """gaussian_renderer/__init__.py:521-749 (`render_volume`, SH-indirect branch; it only runs under the shipped "pgsr" flag, so that is
+    the default here: plane distance as the last feature channel, surf_depth from the flavour's eighth all-map channel) with utils/refl_utils.py:426-484 for the
     per-gaussian shading, INCLUDING the reference's `fg[0]` indexing (appendix B-27: every gaussian gets the split-sum table value of
     gaussian 0).  `pc`: SurfelModel on the CPU; `env_base`: the texels of pc.get_envmap_2."""
     from materialrefgs_amd.gs_utils import eval_sh
@@ -204,8 +216,12 @@ def render_volume_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
         specular = direct_light * specular_weight
         features = torch.cat((roughness, refl, diffuse, specular, ori_color), dim=-1)
     colors_precomp = specular + diffuse
+    if flag != "2dgs":
+        features = torch.cat((features, go.get_distance(pc, cam)), dim=-1)                           # :657-661
     color, feat, allmap, radii = _OracleRaster.apply(means3D, means2D, opacity, colors_precomp, features, pc.get_scaling, pc.get_rotation, cam,
                                                      pc.active_sh_degree, variant, True)
+    if flag != "2dgs":
+        allmap = go.pgsr_allmap8(allmap, feat[-1:], cam)
     cam_dt = cam._replace(world_view_transform=cam.world_view_transform.to(dt), full_proj_transform=cam.full_proj_transform.to(dt))
     reg = go.compute_2dgs_normal_and_regularizations_reference(allmap, cam_dt, pipe)
     full_color, d_map, s_map = color, feat[2:5], feat[5:8]
@@ -218,4 +234,6 @@ def render_volume_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
            "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
     if indirect:
         out.update({"visibility": feat[11:12], "indirect_light": feat[12:15], "direct_light": feat[15:18], "visibility_traced": traced})
+    if flag != "2dgs":
+        out["rend_distance"] = feat[-1:]
     return out

@@ -292,14 +292,23 @@ ref_ru_ops._get_plugin = lambda: _RenderutilsPlugin()
 class _Rasterizer2StandIn(ref_rast.GaussianRasterizer):
     """`diff_surfel_rasterization2.GaussianRasterizer` (the "pgsr" flavour arguments/config.py ships; NOT in the reference tree, its
     arithmetic cannot be read).  Stand-in: the vendored rasterizer, with the flavour's eighth all-map channel ("unbiased depth",
-    gaussian_renderer/__init__.py:66-69) defined as the expected depth allmap[0] / allmap[1] -- so that surf_depth is the 2dgs flavour's
-    at depth_ratio 0, which is also what this repository's flag="pgsr" does.  What the pgsr fixtures pin is therefore the reference's
-    PYTHON glue of that flavour (get_distance, the extra feature channels and their order, "rend_distance", and render_volume, which
-    only runs under this flag: its 2dgs branch calls torch.cat on a tensor, :658-659) -- not the un-vendored rasterizer."""
+    gaussian_renderer/__init__.py:66-69) DEFINED as in the PGSR paper: blended plane distance / -(blended view-space normal . pixel ray),
+    ray = ((x - (W-1)/2) / fx, (y - (H-1)/2) / fy, 1) -- the plane distance being the LAST feature channel in every caller of the flavour
+    (:173-176, 352-357, 657-661; envgs_renderer.py:349-352).  What the pgsr fixtures pin is therefore the reference's PYTHON glue of that
+    flavour (get_distance, the extra feature channels and their order, "rend_distance", nan_to_num and depth_to_normal of the eighth
+    channel, and render_volume, which only runs under this flag: its 2dgs branch calls torch.cat on a tensor, :658-659) -- not the
+    un-vendored rasterizer, whose own rule for that channel stays unpinned."""
 
     def forward(self, *args, **kwargs):
         contrib, color, feature, radii, allmap = super().forward(*args, **kwargs)
-        return contrib, color, feature, radii, torch.cat([allmap, torch.nan_to_num(allmap[0:1] / allmap[1:2], 0, 0)], dim=0)
+        rs = self.raster_settings
+        H, W = int(rs.image_height), int(rs.image_width)
+        fx, fy = W / (2.0 * rs.tanfovx), H / (2.0 * rs.tanfovy)
+        xs = (torch.arange(W, dtype=allmap.dtype) - 0.5 * (W - 1)) / fx
+        ys = (torch.arange(H, dtype=allmap.dtype) - 0.5 * (H - 1)) / fy
+        n_dot_ray = allmap[2] * xs[None, :] + allmap[3] * ys[:, None] + allmap[4]
+        unbiased = feature[-1:] / (-n_dot_ray)[None]
+        return contrib, color, feature, radii, torch.cat([allmap, unbiased], dim=0)
 
 
 def set_flavour(flag):

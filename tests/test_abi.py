@@ -80,12 +80,12 @@ def test_struct_size_guard():
     from materialrefgs_amd import _lib
     from materialrefgs_amd._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
     L = _lib.lib()
-    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 4
+    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 5
     assert ctypes.sizeof(MrgsRasterConfig) == 4 + 11 * 4          # struct_size + 6 ints + 3 floats + 2 ints
     assert ctypes.sizeof(MrgsRasterInputs) == 8 + 15 * 8          # struct_size + 12 pointers + work_hint, shs_rest, bwd_grad_ws
     assert ctypes.sizeof(MrgsRasterGrads) == 8 + 10 * 8
     hdr = open(os.path.join(ROOT, "include", "mrgs.h")).read()
-    assert "#define MRGS_ABI_VERSION 4" in hdr
+    assert "#define MRGS_ABI_VERSION 5" in hdr
 
     class OldInputs(ctypes.Structure):                           # the struct as INTEGRATION.md printed it in round 2: 14 pointers, no size
         _fields_ = [(n, ctypes.c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales", "rotations",
@@ -135,6 +135,24 @@ def test_python_wrapper_validation():
         rast(means3D=m, means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 16, 3))
     with pytest.raises(RuntimeError, match="CUDA tensor"):   # CHECK_INPUT: CPU tensors are rejected, no CPU fallback
         rast(means3D=m, means2D=m, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.ones(4, 2), rotations=torch.ones(4, 4))
+
+
+def test_camera_matrix_copies_are_cached_per_source_tensor():
+    """rasterizer._camera_f32c: a non-contiguous camera matrix (the reference's transposed views, scene/cameras.py:77) maps to ONE
+    contiguous copy for as long as it is not written in place -- the address the work hints are keyed by."""
+    import torch
+    from materialrefgs_amd import rasterizer as rz
+    rz.reset_work_hints()
+    m = torch.arange(16, dtype=torch.float32).reshape(4, 4)
+    assert rz._camera_f32c(m) is m                                  # already contiguous fp32: itself
+    t = m.transpose(0, 1)
+    c1, c2 = rz._camera_f32c(t), rz._camera_f32c(m.transpose(0, 1))      # a new view object of the same storage and strides
+    assert c1 is c2 and c1.is_contiguous() and torch.equal(c1, t)
+    m.add_(1.0)                                                     # written in place: copied again
+    c3 = rz._camera_f32c(t)
+    assert c3 is not c1 and torch.equal(c3, t)
+    d = rz._camera_f32c(t.double())
+    assert d.dtype == torch.float32 and torch.equal(d, t)
 
 
 def test_diff_surfel_rasterization_shim_resolves_to_the_hip_rasterizer():

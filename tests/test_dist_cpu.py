@@ -88,7 +88,15 @@ def _worker_factored(rank, world, port, q):
     grads = [torch.randn(P, 3, generator=gen), sh_grad, torch.randn(P, 1, generator=gen), None]
     from oracle import dist_oracle   # the product expands in libmrgs.so only; on CPU tensors the test supplies the checker
     red = mdist.FactoredGradReducer([torch.Size(s) for s in shapes], 1, "cpu", expand_fn=dist_oracle.expand_sh_gradients)
-    out = red.reduce(grads, means3D, campos, deg)
+    out = [o.clone() for o in red.reduce(grads, means3D, campos, deg)]
+    # the same step with the all-gather started early, from the factor itself (what the rasterizer hands out between its blend
+    # backward and its per-gaussian backward): the reduce() that follows must pick the gathered rows up and give the same sums
+    red.begin_early(drgb, campos)
+    assert red._early is not None
+    out_early = red.reduce(grads, means3D, campos, deg)
+    assert red._early is None
+    for a, b in zip(out, out_early):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
     q.put((rank, [o.clone().numpy() for o in out], [None if g is None else g.numpy() for g in grads]))
     dist.barrier()
     dist.destroy_process_group()

@@ -6,7 +6,9 @@ Bar:
   * blended maps: |hip - oracle| <= 2e-5 * max|oracle| per map; the distortion channel is held to an ABSOLUTE 5e-6 instead,
     because the reference's one-pass formula (m^2 A + M2 - 2 m M1, forward.cu:412) subtracts O(1) terms to produce a
     value of order 1e-5: its result carries the rounding noise of the O(1) terms whatever the implementation;
-  * per-pixel contributor counters equal except for at most 1e-5 of the pixels (1-ulp exp differences at the thresholds);
+  * per-pixel contributor counters (last, median) BIT-EXACT: every decision of the blend -- alpha >= 1/255, depth >= 0.2, rho3d <= rho2d,
+    T (1 - alpha) < 1e-4, T > 0.5 -- is taken with the oracle's arithmetic wherever the fast value is within its error band of the
+    threshold (mrgs_blend_math.h "Exact decisions"), so no pixel of any map may sit outside the tolerances either;
   * gradients: max|hip - oracle| / max|oracle| <= 1e-4 per tensor (BASELINE.json north star).
 """
 import math
@@ -44,9 +46,8 @@ def _map_ok(a, b, tol, absolute=False):
 
 
 def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, check_grads=True, pixel_allowance=0):
-    """`pixel_allowance`: number of pixels that may sit outside the map tolerances (the randomised soak allows ONE: a surfel whose
-    alpha lands on the 1/255 threshold at that pixel is blended on one side and skipped on the other -- one ulp of v_rcp_f32 /
-    v_exp_f32); such a pixel must still be within 5e-3 of the map's maximum (the pair's weight is <= 1/255)."""
+    """`pixel_allowance`: number of pixels that may sit outside the map tolerances.  Zero everywhere in the suite since round 4 (the
+    kernels take the blend's decisions exactly); the parameter remains for developer builds that switch that off."""
     from oracle import raster_oracle as ro
     H, W = cam.image_height, cam.image_width
     S = scene.features.shape[1]
@@ -67,7 +68,7 @@ def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp
     np.testing.assert_array_equal(hr.export("ranges").astype(np.uint32), orc.ranges)
     # ---- maps
     nc_bad = int((hr.export("n_contrib").astype(np.uint32) != orc.n_contrib).sum())
-    assert nc_bad <= max(1, int(1e-5 * orc.n_contrib.size)) + 2 * pixel_allowance, nc_bad
+    assert nc_bad <= 2 * pixel_allowance, nc_bad
     others = hr.others.detach().cpu().numpy()
     checks = [("color", hr.color.detach().cpu().numpy(), orc.color, MAP_TOL, False)]
     if S:
@@ -230,6 +231,57 @@ def test_work_hints_only_change_the_schedule(gpu_device):
         assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others) and torch.equal(r.feature, a.feature)
 
 
+def test_backward_in_two_halves_hands_out_the_colour_factor(gpu_device):
+    """mrgs_rasterize_backward_blend / _finish through rasterizer.set_after_blend_hook: the hook sees dL/dRGB of every surfel, clamp
+    mask applied (= dL/dsh[:, 0, :] / SH_C0, the factor a view-parallel step all-gathers), in the middle of the backward; the gradients
+    are those of the one-call backward."""
+    from materialrefgs_amd import rasterizer as rz
+    from materialrefgs_amd.dist import SH_C0
+    S, H, W = 3, 120, 160
+    scene = make_shell_scene(4000, S=S, seed=31, radius_px=6.0, image_size=160)
+    cam = orbit_camera(4, H, W)
+    g = upstream_grads(S, H, W)
+    ref = HipRender(scene, cam, gpu_device).backward(*g)
+    seen = []
+    rz.set_after_blend_hook(lambda d: seen.append(d.clone()))
+    try:
+        got = HipRender(scene, cam, gpu_device).backward(*g)
+    finally:
+        rz.set_after_blend_hook(None)
+    assert len(seen) == 1 and tuple(seen[0].shape) == (4000, 3)
+    for k in ref:
+        assert rel_err(got[k], ref[k]) <= 1e-5, k            # (atomics reorder the blend's sums)
+    factor = got["sh"][:, 0, :] / SH_C0
+    assert rel_err(seen[0].cpu().numpy(), factor) <= 1e-6
+    assert float(np.abs(factor).max()) > 0 and (np.abs(factor).sum(1) == 0).any()       # culled surfels: exact zeros
+
+
+def test_transposed_camera_matrices_reach_the_warm_path(gpu_device):
+    """The reference's Camera keeps `world_view_transform` / `full_proj_transform` as TRANSPOSED views (scene/cameras.py:77-79), i.e.
+    not contiguous.  The rasterizer must hand the same contiguous copy to every render of that camera, or the per-camera work hints
+    (keyed by the matrices' addresses) never repeat: the second render of such a camera is warm and has its backward prepared."""
+    from helpers import raster_settings
+    from materialrefgs_amd import rasterizer as rz
+    H, W = 96, 128
+    scene = make_shell_scene(2000, S=0, seed=4, radius_px=6.0, image_size=128)
+    cam = orbit_camera(1, H, W)
+    rs0 = raster_settings(cam, gpu_device)
+    # as scene/cameras.py builds them: row-major data of the transposed matrix, viewed through .transpose(0, 1)
+    vm = rs0.viewmatrix.t().contiguous().transpose(0, 1)
+    pm = rs0.projmatrix.t().contiguous().transpose(0, 1)
+    assert not vm.is_contiguous() and torch.equal(vm, rs0.viewmatrix)
+    rs = rs0._replace(viewmatrix=vm, projmatrix=pm)
+    rz.reset_work_hints()
+    a = HipRender(scene, cam, gpu_device, rs=rs)
+    n_hints = len(rz._WORK_HINTS)
+    b = HipRender(scene, cam, gpu_device, rs=rs)
+    assert len(rz._WORK_HINTS) == n_hints == 1                      # one camera, one entry
+    assert a.fn.prepared_grad_ws is None and b.fn.prepared_grad_ws is not None
+    assert torch.equal(a.color, b.color)
+    ref = HipRender(scene, cam, gpu_device, rs=rs0)
+    assert torch.equal(ref.color, a.color)
+
+
 @pytest.mark.parametrize("P,M,deg", [(3000, 16, 3), (4096, 16, 2), (777, 4, 1), (64, 9, 2)])
 def test_split_sh_layout_is_bit_identical(gpu_device, P, M, deg):
     """shs = (features_dc [P,1,3], features_rest [P,M-1,3]) -- GaussianModel's own tensors -- gives the images and gradients of the
@@ -317,6 +369,15 @@ def test_full_size_properties(gpu_device, P, S, H, W):
         assert float(np.abs(g1["means3D"][dead]).sum()) == 0
 
 
+@pytest.mark.parametrize("S", [0, 8])
+def test_full_size_against_oracle(gpu_device, S):
+    """BASELINE.json's configuration itself against the C oracle, every bar of compare_all: 300 000 surfels, 800 x 800, S = 0 (C2) and
+    S = 8 (the rasterizer call of C3) -- bit-exact binning state and contributor counters, maps, all gradients.  The oracle needs the host
+    cores for this (OpenMP over tiles: ~10 s on the GPU box's cores, a few minutes on eight), hence a gpu test of its own and view 0 only."""
+    scene = make_shell_scene(300000, S=S, seed=0, radius_px=7.0, image_size=800)
+    compare_all(scene, orbit_camera(0, 800, 800), gpu_device)
+
+
 def test_medium_scene_against_oracle(gpu_device):
     """50k surfels at 400x400 with S=8: the largest case the oracle finishes in a few seconds on 8 cores."""
     scene = make_shell_scene(50000, S=8, seed=7, radius_px=7.0, image_size=400)
@@ -350,7 +411,7 @@ def test_factored_sh_gradient_equals_the_sum_over_views(gpu_device):
     assert float(out_deg1[:, 4:].abs().max()) == 0.0 and float((out_deg1[:, :4] - out_cpu[:, :4]).abs().max()) <= 2e-6 * scale
 
 
-def _soak_cases(n, seed):
+def _soak_cases(n, seed, only=None):
     """The generator of tools/stress_parity.py with a fixed seed: scene sizes 1 ... 40 000, 17 ... 420 px, 0 ... 24 channels,
     SH degree 0 ... 3, splat radii 1.5 ... 40 px."""
     rng = np.random.default_rng(seed)
@@ -363,16 +424,24 @@ def _soak_cases(n, seed):
         rpx = float(rng.choice([1.5, 4.0, 7.0, 15.0, 40.0]))
         view = int(rng.integers(0, 8))
         out.append((P, S, H, W, deg, rpx, view, int(rng.integers(1 << 30))))
-    return out
+    return out if only is None else [out[i] for i in only]
 
 
-@pytest.mark.parametrize("case", _soak_cases(20, 0), ids=lambda c: f"P{c[0]}-S{c[1]}-{c[2]}x{c[3]}-d{c[4]}-r{c[5]}")
+# Scenes of the 2 000-scene run `tools/stress_parity.py 2000 10000` that had a pixel outside the bars before round 4: 63 ... 1657 a pair
+# whose alpha sat within a few ulp of 1/255 (v_rcp_f32 / v_exp_f32 against the oracle's quotient and exp; now decided exactly), 283 / 828
+# contributor counters off by one (the same, at T (1 - alpha) = 1e-4), 329 / 1460 a pair with alpha = 3/255 ... 6/255 dropped by the
+# block-level cull (a grazing surfel's needle-shaped conic evaluated as A x^2 + 2 B x y + C y^2 in fp32; now a completed square).
+_FORMERLY_OFF = [63, 193, 283, 329, 771, 828, 1385, 1460, 1657]
+
+
+@pytest.mark.parametrize("case", _soak_cases(20, 0) + _soak_cases(2000, 10000, _FORMERLY_OFF),
+                         ids=lambda c: f"P{c[0]}-S{c[1]}-{c[2]}x{c[3]}-d{c[4]}-r{c[5]}-s{c[7]}")
 def test_randomised_soak_fixed_seed(gpu_device, case):
-    """Twenty fixed scenes of the randomised soak run (tools/stress_parity.py runs hundreds), full bit-exact binning state, maps
-    and gradients, with the documented allowance of one threshold pixel per scene."""
+    """Twenty fixed scenes of the randomised soak run (tools/stress_parity.py runs thousands) and nine that used to have one pixel
+    outside the bars: full bit-exact binning state and contributor counters, maps and gradients, NO pixel allowance."""
     P, S, H, W, deg, rpx, view, seed = case
     scene = make_shell_scene(P, S=S, seed=seed, radius_px=rpx, image_size=max(H, W))
-    compare_all(scene, orbit_camera(view, H, W), gpu_device, sh_degree=deg, pixel_allowance=1)
+    compare_all(scene, orbit_camera(view, H, W), gpu_device, sh_degree=deg)
 
 
 @pytest.mark.parametrize("P,H,W,rpx", [(6000, 64, 64, 40.0),      # every tile holds ~6 000 pairs: tile_sort_big_kernel, keys in LDS
@@ -381,7 +450,7 @@ def test_dense_tiles_take_the_big_sort_path(gpu_device, P, H, W, rpx):
     """Tiles whose segment exceeds the per-tile sort kernel (4 096 keys) go through the device-side list of oversized tiles
     (mrgs_binning.hip); point_list / ranges / n_contrib must stay bit-exact and the images within the usual bars."""
     scene = make_shell_scene(P, S=2, seed=77, radius_px=rpx, image_size=max(H, W))
-    hr = compare_all(scene, orbit_camera(3, H, W), gpu_device, check_grads=(P <= 6000), pixel_allowance=1)
+    hr = compare_all(scene, orbit_camera(3, H, W), gpu_device, check_grads=(P <= 6000))
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     assert hr.num_rendered / tiles > (4096 if P <= 6000 else 16384)
 
@@ -391,7 +460,7 @@ def test_image_with_more_tiles_than_the_slice_histograms_hold(gpu_device):
     same bit-exact binning state."""
     H = W = 3200
     scene = make_shell_scene(3000, S=0, seed=5, radius_px=30.0, image_size=W)
-    compare_all(scene, orbit_camera(2, H, W), gpu_device, check_grads=False, pixel_allowance=1)
+    compare_all(scene, orbit_camera(2, H, W), gpu_device, check_grads=False)
 
 
 def test_backward_prepared_by_the_forward_equals_the_self_contained_backward(gpu_device):
