@@ -240,7 +240,7 @@ def main():
     reducer = mdist.FactoredGradReducer([params[k].shape for k in params] + [means2D.shape], list(params.keys()).index("sh"), dev) \
         if world > 1 else None
     state = {"R": 0}
-    if reducer is not None and not os.environ.get("MRGS_BENCH_NO_EARLY_GATHER"):
+    if reducer is not None and not surfel_mode and not os.environ.get("MRGS_BENCH_NO_EARLY_GATHER"):
         # the all-gather of the colour-gradient factor starts in the middle of the rasterizer's backward (under the per-gaussian backward)
         rasterizer_mod.set_after_blend_hook(lambda drgb: reducer.begin_early(drgb, state["campos"]))
 

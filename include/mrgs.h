@@ -7,7 +7,12 @@
  * pointer is a DEVICE pointer unless its name ends in _host.  The library never allocates or frees device
  * memory: the caller owns the outputs and the three opaque workspaces (sizes from mrgs_*_bytes), exactly as
  * the reference's geomBuffer / binningBuffer / imgBuffer tensors are owned by Python
- * (rasterize_points.cu:95-103, diff_surfel_rasterization/__init__.py:101).  All work is enqueued on the
+ * (rasterize_points.cu:95-103, diff_surfel_rasterization/__init__.py:101).  ONE exception, host memory: the forward calls that
+ * report the pair count without a blocking copy (mrgs_rasterize_forward, _begin / _finish) read it from a pinned, device-mapped
+ * slot; the library allocates a ring of MRGS_TICKET_RING (16) such 64-byte slots per (host thread, device) with hipHostMalloc on
+ * first use and keeps it for the life of the process.  Consequence: a ticket of mrgs_rasterize_forward_begin is finished on the
+ * SAME host thread that began it (the ring is thread-local; another thread's _finish returns MRGS_E_BAD_ARG) -- a host that
+ * finishes renders on a worker thread begins them there too, or uses the _geom / _render pair.  All work is enqueued on the
  * caller's hipStream_t (pass torch.cuda.current_stream().cuda_stream); calls on distinct streams/devices are
  * independent.  Return value: 0 on success, otherwise an MRGS_E_* code (mrgs_strerror gives the text);
  * nothing throws across the ABI.
@@ -223,7 +228,9 @@ typedef struct MrgsShadeFrame {
 int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, float* specular, float* direct_light,
                                 float* specular_weight, void* stream);
 /* Gradients w.r.t. the five maps (dense, fully written: g_albedo[H,W,3], g_normal[H,W,3], g_alpha[H,W], g_refl[H,W],
- * g_roughness[H,W]) and, through mips->grad, w.r.t. the cubemap texels.  Any of the three upstream gradients may be NULL. */
+ * g_roughness[H,W]) and, through mips->grad, w.r.t. the cubemap texels.  Any of the three upstream gradients may be NULL.
+ * A level that receives gradients must have fewer than 2^24 texels (res < 1673; the reference's EnvLight uses 16 ... 128, at most
+ * 512): larger ones return MRGS_E_UNSUPPORTED. */
 int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* g_specular, const float* g_direct_light,
                                  const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
                                  float* g_roughness, void* stream);

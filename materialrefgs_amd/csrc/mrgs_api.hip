@@ -560,6 +560,7 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
     case 9: HIP_TRY(hipMemcpyAsync(dst, img.final_T, sizeof(float) * 3 * hw, hipMemcpyDeviceToDevice, stream)); break;
     case 10: HIP_TRY(hipMemcpyAsync(dst, img.n_contrib, sizeof(uint32_t) * 2 * hw, hipMemcpyDeviceToDevice, stream)); break;
     case 11: HIP_TRY(hipMemcpyAsync(dst, g.order[sorted_buf(32)], sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, stream)); break;
+    case 12: HIP_TRY(hipMemcpyAsync(dst, img.redo_list, sizeof(uint32_t) * (2 + hw), hipMemcpyDeviceToDevice, stream)); break;   // [0] count, [2..] marked pixels
     default: return MRGS_E_BAD_ARG;
     }
     HIP_TRY(hipGetLastError());

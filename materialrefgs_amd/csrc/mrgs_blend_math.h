@@ -147,9 +147,9 @@ struct Hit {
 
 // forward.cu:366-398 / backward.cu:296-328, branch-free: everything is evaluated and the reference's chain of `continue`s collapses
 // into flags (a zero p.z gives inf/NaN operands, and every comparison with NaN is false, so such pairs are rejected exactly as the
-// reference rejects them).  Returns "may be a hit": the reference's tests with every threshold moved to the far side of its band
-// and the depth test passed by either candidate depth -- a superset of the exact hits; mrgs_hit_decide narrows it down.
-__device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, float py, Hit& h)
+// reference rejects them).  The fast evaluation: fills h and hands back the three quantities the hit test looks at.
+struct HitTest { float ppz, d3, power; };
+__device__ __forceinline__ HitTest mrgs_intersect_fast(const SurfelGeom& s, float px, float py, Hit& h)
 {
     const float Twx = s.g1.z, Twy = s.g1.w, Twz = s.g2.x;
     h.kx = fmaf(px, Twx, -s.g0.x); h.ky = fmaf(px, Twy, -s.g0.y); h.kz = fmaf(px, Twz, -s.g0.z);
@@ -171,8 +171,15 @@ __device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, fl
     const float power = -0.5f * rho;
     h.G = mrgs_exp(power);
     h.alpha = fminf(0.99f, s.g2.w * h.G);
-    // (Twz is the same for every lane: its test is scalar)
-    return (ppz != 0.0f) & (!(d3 < MRGS_NEAR_LO) | !(Twz < MRGS_NEAR_LO)) & !(power > 0.0f) & !(h.alpha < MRGS_ALPHA_LO);
+    return HitTest{ppz, d3, power};
+}
+
+// "May be a hit": the reference's tests with every threshold moved to the far side of its band and the depth test passed by either
+// candidate depth -- a superset of the exact hits; mrgs_hit_decide narrows it down.  (Twz is the same for every lane: its test is scalar.)
+__device__ __forceinline__ bool mrgs_intersect(const SurfelGeom& s, float px, float py, Hit& h)
+{
+    const HitTest t = mrgs_intersect_fast(s, px, py, h);
+    return (t.ppz != 0.0f) & (!(t.d3 < MRGS_NEAR_LO) | !(s.g2.x < MRGS_NEAR_LO)) & !(t.power > 0.0f) & !(h.alpha < MRGS_ALPHA_LO);
 }
 
 // Second half of the test for a lane mrgs_intersect let through.  Returns the fast decision -- which is the exact one unless
@@ -184,12 +191,57 @@ __device__ __forceinline__ bool mrgs_hit_decide(const Hit& h, bool may_hit, bool
     return hit;
 }
 
+// The same two steps on LANE MASKS, for the forward blend: every comparison is one v_cmp whose result lands in a scalar register pair
+// (the ballot of a single comparison is free), all the logic on them is scalar ALU work next to the vector pipe, and a mask becomes a
+// per-lane predicate again with inverse_ballot where a select needs one.  Written with per-lane bools the compiler keeps loop-carried
+// flags in vector registers and rebuilds masks with v_cndmask / v_cmp_ne pairs: 17 vector instructions more per blended entry, +40 % on
+// the launch (measured when the ambiguity tests went in).  All 64 lanes of the blend waves are active.
+#define MRGS_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
+#define MRGS_LANES(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+__device__ __forceinline__ uint64_t mrgs_intersect_mask(const SurfelGeom& s, float px, float py, Hit& h)
+{
+    const HitTest t = mrgs_intersect_fast(s, px, py, h);
+    const uint64_t tw_ok = s.g2.x < MRGS_NEAR_LO ? 0ull : ~0ull;
+    return MRGS_BALLOT(t.ppz != 0.0f) & (~MRGS_BALLOT(t.d3 < MRGS_NEAR_LO) | tw_ok) & ~MRGS_BALLOT(t.power > 0.0f) & ~MRGS_BALLOT(h.alpha < MRGS_ALPHA_LO);
+}
+__device__ __forceinline__ uint64_t mrgs_hit_decide_mask(const Hit& h, uint64_t may_hit, uint64_t& ambiguous)
+{
+    const uint64_t hit = may_hit & ~MRGS_BALLOT(h.depth < MRGS_NEAR_LO);
+    ambiguous = (hit & (MRGS_BALLOT(h.alpha < MRGS_ALPHA_HI) | MRGS_BALLOT(h.depth < MRGS_NEAR_HI))) |
+                (may_hit & MRGS_BALLOT(fabsf(h.rho3d - h.rho2d) < MRGS_RHO_EPS));
+    return hit;
+}
+
 // exp(x), x <= 0, correctly rounded to fp32: 2^(x log2 e) in double -- argument reduced to [-1/2, 1/2], Taylor series of degree 13
 // (remainder 4e-18) -- and one rounding.  The double value is within ~1e-15 of the true one, so the result differs from the
 // correctly rounded one only when the true value lies that close to the midpoint of two floats (2e-8 of all arguments); the oracle
 // rounds glibc's double exp the same way.
+// TABLE: the coefficients come from a constant table through VOLATILE loads instead of literals -- for the branches inside the blend
+// loops that run for one pair in a million: plain literals are loop invariants the compiler materialises in front of the loop (ten
+// more vector registers held across the backward's entry body, three of them spilled at S = 0).  The redo kernel, where this function
+// is the main path, keeps the literals (a round trip to memory per batch otherwise: 24 -> 36 us for the kernel).
+__device__ const double mrgs_exp_cr_tab[16] = {1.4426950408889634074, 0.69314718055994530942, 1.0 / 6227020800.0, 1.0 / 479001600.0,
+                                               1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0,
+                                               1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+__device__ __forceinline__ float mrgs_exp_cr_finish(double p, double n)
+{
+    // below 2^-1000 the result is far under the smallest float anyway (and ldexp's int argument stays in range)
+    const int e = n < -1000.0 ? -1000 : (int)n;
+    return (float)__builtin_ldexp(p, e);
+}
+template <bool TABLE>
 __device__ __forceinline__ float mrgs_exp_cr(float x)
 {
+    if (TABLE) {
+        const volatile double* c = mrgs_exp_cr_tab;
+        const double t = (double)x * c[0];
+        const double n = __builtin_rint(t);
+        const double z = (t - n) * c[1];
+        double p = c[2];
+#pragma unroll
+        for (int i = 3; i < 16; i++) p = __builtin_fma(p, z, c[i]);
+        return mrgs_exp_cr_finish(p, n);
+    }
     const double t = (double)x * 1.4426950408889634074;
     const double n = __builtin_rint(t);
     const double z = (t - n) * 0.69314718055994530942;
@@ -207,13 +259,12 @@ __device__ __forceinline__ float mrgs_exp_cr(float x)
     p = __builtin_fma(p, z, 0.5);
     p = __builtin_fma(p, z, 1.0);
     p = __builtin_fma(p, z, 1.0);
-    // below 2^-1000 the result is far under the smallest float anyway (and ldexp's int argument stays in range)
-    const int e = n < -1000.0 ? -1000 : (int)n;
-    return (float)__builtin_ldexp(p, e);
+    return mrgs_exp_cr_finish(p, n);
 }
 
 // The pair again as the oracle evaluates it (oracle/mrgs_oracle.c: intersect): same expression tree, the IEEE quotient for 1 / p.z,
 // the correctly rounded exponential, the reference's thresholds in the reference's order.  Fills h, returns the hit.
+template <bool COLD = false>      // COLD: called from a rarely taken branch of a hot loop (see mrgs_exp_cr)
 __device__ __forceinline__ bool mrgs_intersect_exact(const SurfelGeom& s, float px, float py, Hit& h)
 {
     const float Twx = s.g1.z, Twy = s.g1.w, Twz = s.g2.x;
@@ -233,7 +284,7 @@ __device__ __forceinline__ bool mrgs_intersect_exact(const SurfelGeom& s, float 
     h.use3d = h.rho3d <= h.rho2d;
     h.depth = h.use3d ? fmaf(h.sx, Twx, fmaf(h.sy, Twy, Twz)) : Twz;
     const float power = -0.5f * rho;
-    h.G = mrgs_exp_cr(power);
+    h.G = mrgs_exp_cr<COLD>(power);
     h.alpha = fminf(0.99f, s.g2.w * h.G);
     return (ppz != 0.0f) & !(h.depth < MRGS_NEAR_N) & !(power > 0.0f) & !(h.alpha < MRGS_ALPHA_MIN);
 }

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
 
-    bool done = !inside;
+    uint64_t done = ~__builtin_amdgcn_ballot_w64(inside);   // lanes (pixels) that take no more entries: a lane MASK in scalar registers
     uint64_t redo = 0ull;            // pixels (lanes) with a decision inside its error band
     int cf_end = 0;                  // list entries whose cflag this wave has written
     uint32_t work = 0;
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     }
 
     for (int base = 0, c = 0; base < total; base += MRGS_CHUNK, c++) {
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;   // every pixel of the block has terminated (forward.cu:342-344, per wave)
+        if (~done == 0ull) break;             // every pixel of the block has terminated (forward.cu:342-344, per wave)
         mrgs_stage_wait();                    // chunk c has landed
         uint64_t mask_nxt = 0ull;
         auto stage_next = [&]() {
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         // have failed the test below: same images, and the longest waves of the launch -- which set its duration, one
         // issue slot per ~4 cycles each -- walk fewer entries.
         {
-            const uint64_t live = __builtin_amdgcn_ballot_w64(!done);
+            const uint64_t live = ~done;
             if (m != 0ull && __builtin_popcountll(live) <= MRGS_FWD_REFINE_LIVE) {
                 const int r0 = __builtin_ctzll(live) >> 3, r1 = (63 - __builtin_clzll(live)) >> 3;
                 uint32_t cols = (uint32_t)(live | (live >> 32));
@@ -171,30 +171,29 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         // below their LDS latency sat on the critical path of the longest waves, which set the duration of this kernel)
         auto blend_entry = [&](const SurfelGeom& sg, const float4& a0, const float2& a1, int j) {
             Hit h;
-            const bool may_hit = mrgs_intersect(sg, px, py, h) & !done;
+            const uint64_t may_hit = mrgs_intersect_mask(sg, px, py, h) & ~done;
 #ifdef MRGS_WAVE_STATS
-            const int ws_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!done));     // how thin the wave runs near its end
+            const int ws_live = __builtin_popcountll(~done);     // how thin the wave runs near its end
             ws_le4 += ws_live <= 4; ws_le8 += ws_live <= 8; ws_le16 += ws_live <= 16;
 #endif
-            if (__builtin_amdgcn_ballot_w64(may_hit) == 0ull) return;
+            if (may_hit == 0ull) return;
 #ifdef MRGS_WAVE_STATS
             ws_blend++; ws_blend_le8 += ws_live <= 8;
 #endif
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             contributed |= 1ull << j;          // (a superset of "blended": a pixel may terminate on it instead; the backward sorts that out)
-            bool ambiguous;
-            const bool ok = mrgs_hit_decide(h, may_hit, ambiguous);
+            uint64_t ambiguous;
+            const uint64_t ok = mrgs_hit_decide_mask(h, may_hit, ambiguous);
             // (the backward evaluates such an entry with the oracle's arithmetic for the whole block: flag bit 1)
-            unsure |= (uint64_t)(__builtin_amdgcn_ballot_w64(ambiguous) != 0ull) << j;
+            if (ambiguous != 0ull) unsure |= 1ull << j;
             const float test_T = T * (1.0f - h.alpha);
-            // a decision the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, after the list
-            // (mrgs_blend_math.h "Exact decisions"; redo_pixel below)
-            const bool near_t1 = fabsf(test_T - MRGS_T_MIN) < MRGS_T1_EPS, near_t2 = fabsf(T - 0.5f) < MRGS_T2_EPS;
-            ambiguous |= ok & (near_t1 | near_t2);
-            redo |= __builtin_amdgcn_ballot_w64(ambiguous);
-            const bool term = ok & (test_T < MRGS_T_MIN);     // forward.cu:400-404: the pixel stops BEFORE blending this entry
-            done |= term;
-            const bool upd = ok & !(test_T < MRGS_T_MIN);
+            // a decision the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, after the launch
+            // (mrgs_blend_math.h "Exact decisions"; render_fwd_redo_kernel below)
+            redo |= ambiguous | (ok & (MRGS_BALLOT(fabsf(test_T - MRGS_T_MIN) < MRGS_T1_EPS) | MRGS_BALLOT(fabsf(T - 0.5f) < MRGS_T2_EPS)));
+            const uint64_t below = MRGS_BALLOT(test_T < MRGS_T_MIN);
+            done |= ok & below;                               // forward.cu:400-404: the pixel stops BEFORE blending this entry
+            const uint64_t upd_mask = ok & ~below;
+            const bool upd = MRGS_LANES(upd_mask);
             const float alpha = upd ? h.alpha : 0.0f;
             const float depth = upd ? h.depth : 1.0f;
             const float w = alpha * T;
@@ -207,7 +206,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             M1 = fmaf(m_, w, M1);
             M2 = fmaf(mm, w, M2);
             const uint32_t contributor = (uint32_t)(base + j + 1);
-            const bool med = upd & (T > 0.5f);
+            const bool med = MRGS_LANES(upd_mask & MRGS_BALLOT(T > 0.5f));
             median_depth = med ? depth : median_depth;
             median_contributor = med ? contributor : median_contributor;
             N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
@@ -319,14 +318,33 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
 // overwrites the pixel's outputs; entries the pixel blends are flagged for the backward like those of the main kernel.
 // A kernel of its own, not a tail of render_fwd_kernel: there its 100+ registers would be the main kernel's (measured: 68 -> 118 VGPRs,
 // or 28 spilled values and a scratch allocation per wave with the occupancy pinned -- +40 us on the 127 us launch either way).
+// inclusive prefix sum over the 64 lanes in DPP adds: Hillis-Steele inside the 16-lane rows (a lane whose source falls outside its row adds
+// 0), then lane 15 / lane 31 of the rows before into the rows behind.  Every lane of the wave must be active.
+__device__ __forceinline__ float wave_inclusive_sum(float v)
+{
+    v = mrgs_dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = mrgs_dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = mrgs_dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = mrgs_dpp_add<0x118, 0xf>(v);   // row_shr:8
+    v = mrgs_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = mrgs_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 template <int S_MAX>
 __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, uint8_t* cflag, int S, int W, int H, int tiles_x,
-    const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask, uint8_t* cflag, int S, int W, int H,
+    int tiles_x, const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
     const uint32_t* __restrict__ redo_list)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
+    // list entries that pass the block-level cull of the pixel's quadrant, in list order: (surfel, list position).  The cull is
+    // conservative for the exact arithmetic too (its conic is padded by 1e-4 of tau + 1e-3 and tested with 1 % slack), and ~60 % of a
+    // tile's list misses any given quadrant: the exact evaluation, whose dependent loads and double-precision exp set this kernel's
+    // duration (the longest marked list: 1 300 entries at C2), runs on full batches of 64 candidates instead of on every list entry
+    constexpr int QCAP = 384, REFILL = 4;      // a refill scans 4 x 64 list entries with all their loads in flight together
+    __shared__ uint32_t q_id[QCAP], q_pos[QCAP];
     const int lane = threadIdx.x;
     const int HW = H * W;
     const uint32_t count = redo_list[0];
@@ -338,6 +356,7 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
         const uint2 range = ranges[tile];
         const int total = (int)(range.y - range.x);
         const uint32_t* plist = point_list + range.x;
+        const uint8_t* qm = qmask + range.x;
         const float qx = (float)pxi, qy = (float)pyi;
         float xT = 1.0f, xM1 = 0.f, xM2 = 0.f, xmed = 0.f;          // wave-uniform running values of the pixel
         uint32_t xlast = 0, xmedc = 0;
@@ -345,24 +364,71 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
         float sF[SF];
 #pragma unroll
         for (int i = 0; i < SF; i++) sF[i] = 0.f;
-        for (int base = 0; base < total; base += MRGS_CHUNK) {
-            const int e = base + lane;
-            const bool valid = e < total;
-            const uint32_t gid = plist[valid ? e : 0];
-            const float4* src = rec + (size_t)gid * MRGS_REC_F4;
+        int nq = 0, qh = 0, next = 0;             // the queue holds nq candidates from q_*[qh] on
+        bool ended = false, pre_ok = false;
+        uint32_t pre_gid = 0;
+        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0, p4 = p0;
+        while (!ended && (next < total || nq > 0)) {
+            if (nq < MRGS_CHUNK && next < total) {
+                // refill: what is left (< 64) moves to the front, then the candidates of the next 256 list entries are appended in order
+                const uint32_t keep_id = q_id[qh + lane], keep_pos = q_pos[qh + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < nq) { q_id[lane] = keep_id; q_pos[lane] = keep_pos; }
+                qh = 0;
+                bool cand[REFILL];
+                uint32_t id[REFILL];
+#pragma unroll
+                for (int k = 0; k < REFILL; k++) {
+                    const int e = next + k * MRGS_CHUNK + lane;
+                    cand[k] = e < total && ((qm[e < total ? e : 0] >> quad) & 1u);
+                    id[k] = plist[e < total ? e : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < REFILL; k++) {
+                    const uint64_t cm = __builtin_amdgcn_ballot_w64(cand[k]);
+                    if (cand[k]) {
+                        const int at = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                        q_id[at] = id[k]; q_pos[at] = (uint32_t)(next + k * MRGS_CHUNK + lane);
+                    }
+                    nq += __builtin_popcountll(cm);
+                }
+                next += REFILL * MRGS_CHUNK;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (nq < MRGS_CHUNK && next < total) continue;       // sparse stretch of the list: scan on before a partial batch is evaluated
+            }
+            const int n = nq < MRGS_CHUNK ? nq : MRGS_CHUNK;
+            const bool valid = lane < n;
+            const uint32_t gid = valid ? q_id[qh + lane] : 0u;
+            const int e = valid ? (int)q_pos[qh + lane] : 0;
+            // this batch's records: fetched while the batch before was evaluated when the queue held them then already
+            float4 r0, r1, r2, r3, r4;
+            if (pre_gid == gid && pre_ok) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; }
+            else { const float4* src = rec + (size_t)gid * MRGS_REC_F4; r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4]; }
+            {   // ... and the next one's are requested now
+                const int rest = nq - n;
+                pre_ok = rest > 0;                                                    // (wave-uniform)
+                pre_gid = lane < rest ? q_id[qh + n + lane] : 0u;
+                if (pre_ok) { const float4* nx = rec + (size_t)pre_gid * MRGS_REC_F4; p0 = nx[0]; p1 = nx[1]; p2 = nx[2]; p3 = nx[3]; p4 = nx[4]; }
+            }
             SurfelGeom sg;
-            sg.g0 = src[0]; sg.g1 = src[1]; sg.g2 = src[2];
+            sg.g0 = r0; sg.g1 = r1; sg.g2 = r2;
             Hit h;
             const bool hit = mrgs_intersect_exact(sg, qx, qy, h) & valid;
             const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
             const float oma = 1.0f - h.alpha;
-            // T in front of every hit of the chunk: the serial product, one float multiplication per hit in list order
-            float Tb = 0.f, run = xT;
-            for (uint64_t mm_ = hm; mm_ != 0ull; mm_ &= mm_ - 1) {
-                const int jj = __builtin_ctzll(mm_);
-                Tb = lane == jj ? run : Tb;
-                run = run * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(oma), jj));
+            // T in front of every hit of the batch: the serial product, one float multiplication per hit in list order -- formed by every
+            // lane for itself (lane l multiplies the factors of lanes 0 .. l-1 in that order, 1.0 for a lane without a hit: the same
+            // roundings as one running product), so that the dependent chain is 64 multiplications and nothing else
+            const float fac = hit ? oma : 1.0f;
+            float Tb = xT;
+#pragma unroll
+            for (int i = 0; i < MRGS_CHUNK - 1; i++) {
+                const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fac), i));
+                Tb = Tb * (lane > i ? d : 1.0f);
             }
+            const float run = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(Tb * fac), MRGS_CHUNK - 1));
             // the first hit that would take T below 1e-4 ends the pixel and is not blended (forward.cu:400-404); the products
             // formed behind it are not used
             const uint64_t tm = __builtin_amdgcn_ballot_w64(hit & (Tb * oma < MRGS_T_MIN));
@@ -374,32 +440,27 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
             const float depth = bl ? h.depth : 1.0f;
             const float m_ = mscale * (1.0f - MRGS_NEAR_N * (1.0f / depth));
             const float mw = m_ * w, mmw = m_ * m_ * w;
-            // M1, M2 in front of this lane's entry: carry of the chunks before + exclusive prefix inside the chunk
-            float i1 = mw, i2 = mmw;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float u1 = __shfl_up(i1, d, 64), u2 = __shfl_up(i2, d, 64);
-                if (lane >= d) { i1 += u1; i2 += u2; }
-            }
+            // M1, M2 in front of this lane's entry: carry of the batches before + exclusive prefix inside the batch
+            const float i1 = wave_inclusive_sum(mw), i2 = wave_inclusive_sum(mmw);
             const float pM1 = xM1 + (i1 - mw), pM2 = xM2 + (i2 - mmw);
-            xM1 += __shfl(i1, 63, 64);
-            xM2 += __shfl(i2, 63, 64);
+            xM1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(i1), 63));
+            xM2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(i2), 63));
             sDist = fmaf(fmaf(-2.0f * m_, pM1, fmaf(m_ * m_, 1.0f - Tb, pM2)), w, sDist);
             sD = fmaf(depth, w, sD);
-            const float4 a0 = src[3], a1 = src[4];
+            const float4 a0 = r3, a1 = r4;
             sN0 = fmaf(a0.x, w, sN0); sN1 = fmaf(a0.y, w, sN1); sN2 = fmaf(a0.z, w, sN2);
             sC0 = fmaf(a0.w, w, sC0); sC1 = fmaf(a1.x, w, sC1); sC2 = fmaf(a1.y, w, sC2);
-            if (S_MAX > 0) {
+            if (S_MAX > 0 && __builtin_amdgcn_ballot_w64(bl) != 0ull) {
                 const float* fsrc = features + (size_t)gid * S;
 #pragma unroll
                 for (int ch = 0; ch < S_MAX; ch++)
                     if (ch < S) sF[ch] = fmaf(fsrc[ch], w, sF[ch]);
             }
-            if (bm != 0ull) xlast = (uint32_t)(base + 64 - __builtin_clzll(bm));
+            if (bm != 0ull) xlast = (uint32_t)__builtin_amdgcn_readlane(e, 63 - __builtin_clzll(bm)) + 1u;
             const uint64_t medm = __builtin_amdgcn_ballot_w64(bl & (Tb > 0.5f));          // forward.cu:417-420
             if (medm != 0ull) {
                 const int jm = 63 - __builtin_clzll(medm);
-                xmedc = (uint32_t)(base + jm + 1);
+                xmedc = (uint32_t)__builtin_amdgcn_readlane(e, jm) + 1u;
                 xmed = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.depth), jm));
             }
             // flags for the backward: bit 0 = blended by some pixel, bit 1 = the FAST evaluation of this pair cannot be sure of the hit
@@ -414,7 +475,9 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
                 // (the four quadrant bytes of a list entry are one aligned word; marked pixels of one block may meet on a byte)
                 if (fl) atomicOr(reinterpret_cast<uint32_t*>(cflag) + range.x + e, fl << (8 * quad));
             }
-            if (tm != 0ull) break;
+            ended = tm != 0ull;
+            qh += n;
+            nq -= n;
         }
         auto wave_sum = [&](float v) {
 #pragma unroll
@@ -450,6 +513,7 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
             out_others[pix + 5 * HW] = xmed;
             out_others[pix + 6 * HW] = sDist;
         }
+        __builtin_amdgcn_wave_barrier();        // the next pixel's queue starts empty (nq = 0): nothing of this one is read again
     }
 }
 
@@ -482,7 +546,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     else LAUNCH(24, false);
 #undef LAUNCH
     // the marked pixels again, exactly (an empty list most of the time: the launch is there for the count it reads on the device)
-#define REDO(SM) hipLaunchKernelGGL((render_fwd_redo_kernel<SM>), dim3(MRGS_REDO_BLOCKS), block, 0, stream, img.ranges, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, \
+#define REDO(SM) hipLaunchKernelGGL((render_fwd_redo_kernel<SM>), dim3(MRGS_REDO_BLOCKS), block, 0, stream, img.ranges, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, \
                                     g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.redo_list)
     if (cfg.S == 0) REDO(0);
     else if (cfg.S <= 8) REDO(8);

@@ -1072,6 +1072,9 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
     if (rc) return rc;
     if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || !g_albedo || !g_normal || !g_alpha || !g_refl || !g_roughness)
         return MRGS_E_BAD_ARG;
+    // the scatter keys pack (level << 24 | texel index): a level with 6 res^2 >= 2^24 texels (res >= 1673) would alias into the level bits
+    for (int l = 0; l < m.n; l++)
+        if (m.grad[l] != nullptr && 6ll * m.res[l] * m.res[l] >= (1ll << 24)) return MRGS_E_UNSUPPORTED;
     ShadeCam cam;
     for (int i = 0; i < 9; i++) cam.Kinv[i] = fr->Kinv[i];
     cam.R = fr->R; cam.T = fr->T;

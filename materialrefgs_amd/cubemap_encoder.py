@@ -12,9 +12,6 @@ import torch.nn as nn
 
 from . import _lib
 
-_interp_to_id = {"nearest": 0, "linear": 1}
-
-
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t.numel() else None
 
@@ -55,67 +52,77 @@ class _cubemap_encode(torch.autograd.Function):
 cubemap_encode = _cubemap_encode.apply
 
 
-class CubemapEncoder(nn.Module):
-    def __init__(self, output_dim=6, resolution=256, interpolation='linear'):
-        super().__init__()
-        self.input_dim = 3
-        self.resolution = resolution
-        self.output_dim = output_dim
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
-        self.seamless = 1
-        self.params = nn.ParameterDict({
-            'Cubemap_texture': nn.Parameter(torch.rand(6, self.output_dim, resolution, resolution) * 10 - 5),
-            'Cubemap_failv': nn.Parameter(torch.zeros(self.output_dim)),
-        })
-        self.n_elems = 6 * self.output_dim * resolution * resolution + self.output_dim
+def _fetch(dirs, texture, fail_value, nearest, seamless):
+    """[B,3] directions -> [B,C] texels of one [6,C,L,L] cubemap (the raw function returns channel-major [C,B])."""
+    return cubemap_encode(dirs, texture, fail_value, 0 if nearest else 1, 1 if seamless else 0).t()
 
-    def __repr__(self):
-        return (f"CubemapEncoder: input_dim={self.input_dim} output_dim={self.output_dim} resolution={self.resolution} -> {self.n_elems} "
-                f"interpolation={self.interpolation} seamless={self.seamless}")
+
+class _CubeModule(nn.Module):
+    """What the two modules share: the sampling switches.  `interpolation` is "linear" or "nearest"; `seamless` (on, as in the
+    reference) lets bilinear taps cross cube edges.  The contractual surface towards the reference's callers and checkpoints is the
+    constructor signature and the parameter names (`params.Cubemap_texture`, `params.Cubemap_failv`; `params_list.<i>`, `fail_value`:
+    they are the state_dict keys of scene/gaussian_model.py's env_map) -- everything else here is this module's own."""
+
+    def __init__(self, interpolation):
+        super().__init__()
+        if interpolation not in ("linear", "nearest"):
+            raise KeyError(interpolation)
+        self.interpolation = interpolation
+        self.seamless = True
+
+    @property
+    def n_elems(self):
+        return sum(p.numel() for p in self.parameters())
+
+    def extra_repr(self):
+        return f"{self.interpolation}, seamless={bool(self.seamless)}, {self.n_elems} parameters"
+
+
+class CubemapEncoder(_CubeModule):
+    """One [6, output_dim, resolution, resolution] cubemap; forward(dirs[..., 3]) -> sigmoid of the fetched texel, [..., 3]."""
+
+    def __init__(self, output_dim=6, resolution=256, interpolation='linear'):
+        super().__init__(interpolation)
+        self.output_dim, self.resolution = int(output_dim), int(resolution)
+        texels = torch.empty(6, self.output_dim, self.resolution, self.resolution).uniform_(-5.0, 5.0)     # pre-sigmoid: U(-5, 5)
+        self.params = nn.ParameterDict({'Cubemap_texture': nn.Parameter(texels), 'Cubemap_failv': nn.Parameter(torch.zeros(self.output_dim))})
+
+    def extra_repr(self):
+        return f"{self.output_dim} x {self.resolution}^2 x 6, " + super().extra_repr()
 
     def forward(self, inputs):
-        pre_shape = inputs.shape[:-1]
-        outputs = cubemap_encode(inputs.reshape(-1, 3), self.params['Cubemap_texture'], self.params['Cubemap_failv'], self.interp_id,
-                                 self.seamless).permute(1, 0)
-        return torch.sigmoid(outputs).reshape(*pre_shape, 3)      # (the reference hard-codes 3 channels here, :109)
+        flat = inputs.reshape(-1, 3)
+        texel = _fetch(flat, self.params['Cubemap_texture'], self.params['Cubemap_failv'], self.interpolation == "nearest", self.seamless)
+        return torch.sigmoid(texel).reshape(*inputs.shape[:-1], 3)      # three channels, as the reference's reshape fixes them (:109)
 
 
-class MipCubemapEncoder(nn.Module):
+def mip_resolutions(num_levels, base_resolution, per_level_scale):
+    """Side lengths of the levels: ceil(base * scale^i), i = 0 .. num_levels-1 (default 4, 16, 64, 256)."""
+    return [int(np.ceil(float(base_resolution) * float(per_level_scale) ** i)) for i in range(num_levels)]
+
+
+class MipCubemapEncoder(_CubeModule):
+    """A pyramid of cubemaps fetched along the same direction; the per-level features are concatenated ([B, levels * level_dim]) or
+    summed ([B, level_dim])."""
+
     def __init__(self, num_levels=4, level_dim=6, per_level_scale=4, base_resolution=4, interpolation='linear', concat=True):
-        super().__init__()
-        self.input_dim = 3
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.base_resolution = base_resolution
-        self.concat = concat
-        self.output_dim = num_levels * level_dim if concat else level_dim
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
-        self.seamless = 1
-        params_list, L, n_elems = [], float(base_resolution), 0
-        for _ in range(num_levels):
-            iL = int(np.ceil(L))
-            params_list.append(nn.Parameter(torch.empty(6, self.level_dim, iL, iL)))
-            n_elems += 6 * self.level_dim * iL * iL
-            L = L * per_level_scale
-        self.params_list = nn.ParameterList(params_list)
+        super().__init__(interpolation)
+        self.num_levels, self.level_dim, self.concat = int(num_levels), int(level_dim), bool(concat)
+        self.per_level_scale, self.base_resolution = per_level_scale, base_resolution
+        self.output_dim = self.num_levels * self.level_dim if self.concat else self.level_dim
+        self.params_list = nn.ParameterList([nn.Parameter(torch.empty(6, self.level_dim, r, r))
+                                             for r in mip_resolutions(self.num_levels, base_resolution, per_level_scale)])
         self.fail_value = nn.Parameter(torch.zeros(self.level_dim))
-        self.n_elems = n_elems + self.level_dim
         self.reset_parameters()
 
-    def reset_parameters(self):
-        std = 1e-4
-        for ii in range(self.num_levels):
-            self.params_list[ii].data.uniform_(-std, std)
+    def reset_parameters(self, amplitude=1e-4):
+        for level in self.params_list:
+            nn.init.uniform_(level, -amplitude, amplitude)
 
-    def __repr__(self):
-        return (f"MipCubemapEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"base_resolution={self.base_resolution} -> {self.n_elems} per_level_scale={self.per_level_scale:.4f} "
-                f"interpolation={self.interpolation} seamless={self.seamless}")
+    def extra_repr(self):
+        return f"levels {[int(p.shape[-1]) for p in self.params_list]} x {self.level_dim}, concat={self.concat}, " + super().extra_repr()
 
     def forward(self, inputs):
-        outputs = [cubemap_encode(inputs, self.params_list[ii], self.fail_value, self.interp_id, self.seamless) for ii in range(self.num_levels)]
-        outputs = torch.cat(outputs, dim=0) if self.concat else sum(outputs)
-        return outputs.permute(1, 0)      # CxN -> NxC
+        nearest = self.interpolation == "nearest"
+        per_level = [_fetch(inputs, level, self.fail_value, nearest, self.seamless) for level in self.params_list]
+        return torch.cat(per_level, dim=1) if self.concat else torch.stack(per_level).sum(0)

@@ -16,7 +16,8 @@ EXPORT = {"depths": (0, torch.float32, lambda P, R, T, H, W: (P,)),
           "ranges": (8, torch.int32, lambda P, R, T, H, W: (T, 2)),
           "final_T": (9, torch.float32, lambda P, R, T, H, W: (3, H, W)),
           "n_contrib": (10, torch.int32, lambda P, R, T, H, W: (2, H, W)),
-          "order": (11, torch.int32, lambda P, R, T, H, W: (P,))}
+          "order": (11, torch.int32, lambda P, R, T, H, W: (P,)),
+          "redo_list": (12, torch.int32, lambda P, R, T, H, W: (2 + H * W,))}
 
 
 def raster_settings(cam, device, sh_degree=3, scale_modifier=1.0, bg=None, debug=False):

@@ -90,9 +90,25 @@ def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp
         go = orc.backward(*g)
         names = ["means3D", "means2D", "opacity", "scales", "rotations"] + (["features"] if S else []) + \
                 (["sh"] if colors_precomp is None else ["colors"])
+        legs = None
         for k in names:
             e = rel_err(gh[k].reshape(go[k].shape), go[k])
-            assert e <= GRAD_TOL, (k, e)
+            if e <= GRAD_TOL:
+                continue
+            # Above the bar: either a real difference or a sum no fp32 evaluation can hold to 1e-4 -- per-pixel terms of order 1e2 that
+            # cancel to 1e-3 (a lone surfel seen edge-on: soak case 1289 of seed 10000, where the oracle's own two fp32 readings sit 3e-3
+            # from the float64 value of the same formulas).  The truth leg decides (tests/test_truth_leg.py): the
+            # kernels may be no further from the float64 evaluation than the literal fp32 reading of the reference is (x 1.5).
+            if legs is None:
+                legs = {}
+                for v in ("lit32", "f64"):
+                    o = ro.render_scene(scene, cam, sh_degree=sh_degree, scale_modifier=scale_modifier, colors_precomp=colors_precomp, bg=bg, variant=v)
+                    legs[v] = o.backward(*g)
+                    o.close()
+            e_hip = rel_err(gh[k].reshape(go[k].shape), legs["f64"][k])
+            e_lit = rel_err(legs["lit32"][k], legs["f64"][k])
+            assert e_hip <= 1.5 * e_lit and e_lit > 0.5 * GRAD_TOL, (k, e, e_hip, e_lit)
+            print(f"note: {k}: {e:.2e} from the fp32 oracle, {e_hip:.2e} from float64 where the literal fp32 reading is {e_lit:.2e} from it (ill-conditioned sum)")
     orc.close()
     return hr
 
@@ -253,7 +269,9 @@ def test_backward_in_two_halves_hands_out_the_colour_factor(gpu_device):
         assert rel_err(got[k], ref[k]) <= 1e-5, k            # (atomics reorder the blend's sums)
     factor = got["sh"][:, 0, :] / SH_C0
     assert rel_err(seen[0].cpu().numpy(), factor) <= 1e-6
-    assert float(np.abs(factor).max()) > 0 and (np.abs(factor).sum(1) == 0).any()       # culled surfels: exact zeros
+    assert float(np.abs(factor).max()) > 0
+    dead = got["means3D"].__abs__().sum(1) == 0                 # surfels that received no gradient at all (culled, or never blended)
+    assert float(np.abs(seen[0].cpu().numpy()[dead]).sum()) == 0.0
 
 
 def test_transposed_camera_matrices_reach_the_warm_path(gpu_device):

@@ -169,8 +169,8 @@ def test_render_volume_oracle_keeps_the_fg0_indexing_of_the_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("indirect,srgb", [(False, False), (False, True), (True, False)])
-def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb):
+@pytest.mark.parametrize("indirect,srgb,flag", [(False, False, "2dgs"), (False, True, "2dgs"), (True, False, "2dgs"), (False, False, "pgsr")])
+def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb, flag):
     from materialrefgs_amd.raytracing import RayTracer
     from materialrefgs_amd.renderer import render_volume
     from oracle import render_oracle
@@ -187,11 +187,11 @@ def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb):
         mesh = (np.concatenate([v1, v2]), np.concatenate([t1, t2 + len(v1)]))
         pc_h.ray_tracer = RayTracer(*mesh)
     env.build_mips()
-    out_h = render_volume(cam.to(gpu_device), pc_h, pipe, bg.to(gpu_device), srgb=srgb, opt=SimpleNamespace(indirect=indirect))
+    out_h = render_volume(cam.to(gpu_device), pc_h, pipe, bg.to(gpu_device), srgb=srgb, opt=SimpleNamespace(indirect=indirect), flag=flag)
     # visibility per gaussian: take the product's bits into the checker after comparing them with the checker's own trace
     vis_bits = None
     if indirect:
-        probe = render_oracle.render_volume_oracle(cam, pc_o, base_o.detach(), 8, pipe, bg, indirect=True, mesh=mesh)
+        probe = render_oracle.render_volume_oracle(cam, pc_o, base_o.detach(), 8, pipe, bg, indirect=True, mesh=mesh, flag=flag)
         traced = probe["visibility_traced"].reshape(-1)
         # the product's per-gaussian visibility is not returned as such; recover it from a second call of its shading function
         from materialrefgs_amd.shading import get_full_color_volume_indirect
@@ -204,7 +204,7 @@ def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb):
         vis_bits = ex["visibility"].reshape(-1).cpu()
         assert float((vis_bits.double() != traced).double().mean()) < 5e-3
         assert 0.02 < float((traced == 0).double().mean()) < 0.98
-    out_o = render_oracle.render_volume_oracle(cam, pc_o, base_o, 8, pipe, bg, srgb=srgb, indirect=indirect, mesh=mesh, visibility_bits=vis_bits)
+    out_o = render_oracle.render_volume_oracle(cam, pc_o, base_o, 8, pipe, bg, srgb=srgb, indirect=indirect, mesh=mesh, visibility_bits=vis_bits, flag=flag)
     assert torch.equal(out_h["radii"].cpu(), out_o["radii"])
     keys = VOL_KEYS + (("visibility", "indirect_light", "direct_light") if indirect else ())
     for k in keys:
@@ -238,8 +238,8 @@ def test_render_volume_matches_the_composed_oracle(gpu_device, indirect, srgb):
 @pytest.mark.gpu
 def test_pgsr_flag_adds_the_plane_distance_channel(gpu_device):
     """arguments/config.py:1 ships FLAG = "pgsr": every render function rasterizes get_distance (gaussian_renderer/__init__.py:30-40) as
-    its last feature channel and returns it as "rend_distance" (:215-218, 411-413, 478-480, 744-746).  The other maps do not change,
-    and the channel equals a separate rasterization of that one quantity."""
+    its last feature channel and returns it as "rend_distance" (:215-218, 411-413, 478-480, 744-746), and takes surf_depth from the
+    flavour's unbiased depth.  The other maps do not change, and the channel equals a separate rasterization of that one quantity."""
     from materialrefgs_amd import renderer
     from materialrefgs_amd.rasterizer import GaussianRasterizer
     dev = gpu_device
@@ -252,16 +252,26 @@ def test_pgsr_flag_adds_the_plane_distance_channel(gpu_device):
     d = renderer.get_distance(1.0, pc.get_xyz, cam, pc)
     assert d.shape == (P, 1) and float(d.min()) >= 0
     rast = GaussianRasterizer(raster_settings=renderer._raster_settings(cam, pc, pipe, bg, 1.0))
-    alone = rast(means3D=pc.get_xyz, means2D=torch.zeros_like(pc.get_xyz), shs=pc.get_features, opacities=pc.get_opacity, scales=pc.get_scaling,
-                 rotations=pc.get_rotation, features=d)[2]
+    _, _, alone, _, allmap = rast(means3D=pc.get_xyz, means2D=torch.zeros_like(pc.get_xyz), shs=pc.get_features, opacities=pc.get_opacity,
+                                  scales=pc.get_scaling, rotations=pc.get_rotation, features=d)
+    # the flavour's unbiased depth, stated here from its definition: blended distance / -(blended view-space normal . pixel ray)
+    import math
+    fx, fy = W / (2 * math.tan(cam.FoVx / 2)), H / (2 * math.tan(cam.FoVy / 2))
+    rx = (torch.arange(W, device=dev) - (W - 1) / 2) / fx
+    ry = (torch.arange(H, device=dev) - (H - 1) / 2) / fy
+    unbiased = torch.nan_to_num(alone / -(allmap[2] * rx[None, :] + allmap[3] * ry[:, None] + allmap[4])[None], 0, 0)
+    assert float(unbiased.max()) > 1.0
     for fn, kw in ((renderer.render_initial, {}), (renderer.render_surfel, {"opt": SimpleNamespace(indirect=False)}),
                    (renderer.render_volume, {"opt": SimpleNamespace(indirect=False)})):
         a = fn(cam, pc, pipe, bg, srgb=False, **kw)
         b = fn(cam, pc, pipe, bg, srgb=False, flag="pgsr", **kw)
         assert "rend_distance" not in a and b["rend_distance"].shape == (1, H, W), fn.__name__
         assert float((b["rend_distance"] - alone).abs().max()) < 2e-5 * max(1.0, float(alone.abs().max())), fn.__name__
-        for k in ("render", "rend_alpha", "rend_normal", "surf_depth"):
+        for k in ("render", "rend_alpha", "rend_normal"):
             assert float((a[k] - b[k]).abs().max()) < 2e-6, (fn.__name__, k)
+        # surf_depth of the flavour = nan_to_num of its eighth all-map channel (gaussian_renderer/__init__.py:64-69), not the 2dgs mix
+        assert float((b["surf_depth"] - unbiased).abs().max()) < 2e-5 * float(unbiased.abs().max()), fn.__name__
+        assert float((a["surf_depth"] - b["surf_depth"]).abs().max()) > 1e-3
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Produces the profile artefacts of one code state on the MI355X box (run through gpurun from the repository root):
 #   tools/profile_round.sh <tag> [full]
-# (C3full / C3trace: kernel stats and SQ / LDS / FETCH / WRITE counter passes for every kernel: <tag>_pmc_C3full.json, <tag>_pmc_C3trace.json,
+# (C3full / C3trace / C4trace: kernel stats and SQ / LDS / FETCH / WRITE counter passes for every kernel: <tag>_pmc_C3full.json, <tag>_pmc_C3trace.json, <tag>_pmc_C4trace.json,
 #  reduced by tools/pmc_kernels.py)
 # -> gpurun_out/round/: <tag>_kernel_stats.csv (timeout 300 rocprofv3 --kernel-trace --stats of bench.py C2), the two HBM-traffic passes and the
 #    SQ pass (each counter set in its own run, kernel-trace only), their reductions (profiles/pmc_traffic.json, profiles/pmc_sq.json
@@ -13,12 +13,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o $TAG -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o $TAG -- python3 $R/bench.py --workload C2 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o pmc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o pmc --output-format csv -- python3 $R/bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-  -d $O/pmc_sq -o pmc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1
+  -d $O/pmc_sq -o pmc --output-format csv -- python3 $R/bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_sq.log 2>&1
 cd $R
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 S=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1)
@@ -29,16 +29,17 @@ grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $W | head -400 > $O/${TAG}_pmc_WRITE_SIZE_C2.csv
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
 # the full path (render_surfel with shading) and the traced view: kernel stats and the same counter passes, every kernel of the workload
-for W in C3full C3trace; do
+for W in C3full C3trace C4trace; do
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_$W -o ${TAG}_$W -- python3 $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled_$W.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_$W -o ${TAG}_$W -- python3 $R/bench.py --workload $W --steps $([ $W = C4trace ] && echo 8 || echo 20) --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled_$W.log 2>&1
   cd $R
   cp $(find $O/stats_$W -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
   tools/pmc_pass.sh round/pmc_$W $W "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
      "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS_ATOMIC GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_$W.log 2>&1
   cp $O/pmc_$W/pmc_$W.json $O/${TAG}_pmc_$W.json
 done
-timeout 600 python bench.py > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
+timeout 1500 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench_default.err
+timeout 600 python bench.py --workload C2 --steps 1500 --no-secondary > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
 if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C3 --steps 300 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_C3.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C3full --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3full.json 2>> $O/bench_C2.err
