@@ -65,8 +65,8 @@ typedef struct MrgsRasterConfig {
  * Camera: viewmatrix[16], projmatrix[16] (row-vector convention tensors, read as stored), campos[3], bg[3]. */
 typedef struct MrgsRasterInputs {
     uint64_t struct_size;  /* = sizeof(MrgsRasterInputs); checked like MrgsRasterConfig::struct_size.  The struct has grown optional
-                              trailing pointers (work_hint, shs_rest, bwd_grad_ws) which the calls ACT on: a shorter struct from an older
-                              header would make the library read them past its end */
+                              trailing fields (work_hint, shs_rest, bwd_grad_ws, hint_flags) which the calls ACT on: a shorter struct from
+                              an older header would make the library read them past its end */
     const float* bg;
     const float* means3D;
     const float* shs;
@@ -94,7 +94,14 @@ typedef struct MrgsRasterInputs {
                               backward needs no launch before its blend kernel.  BACKWARD call: pass the same pointer (and the same
                               grad_ws) to say that this was done; NULL, or a pointer other than grad_ws, makes the backward order and clear
                               by itself.  Valid for ONE backward per forward.  Results do not depend on it. */
+    uint32_t hint_flags;   /* MRGS_HINT_REUSE_ORDER: the forward skips the ordering of its blend waves and deals them as the last
+                              ordering of this camera did -- the dealt queues live in the work_hint buffer, behind the per-block work
+                              (mrgs_work_hint_bytes covers both).  Only with work_hint set, and only after a forward WITHOUT the flag has
+                              run on the same buffer; the caller (the Python wrapper: every visit of a camera but the first two and every
+                              sixteenth) is responsible for that.  A schedule only: results do not depend on it. */
+    uint32_t reserved_;
 } MrgsRasterInputs;
+#define MRGS_HINT_REUSE_ORDER 1u
 
 /* Workspace sizes.  geom <-> geomBuffer (GeometryState, rasterizer_impl.cu:157-172), img <-> imgBuffer
  * (ImageState, :174-181), binning <-> binningBuffer (BinningState, :183-196; sized from num_rendered). */

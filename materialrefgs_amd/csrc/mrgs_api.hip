@@ -141,6 +141,7 @@ MrgsImgWs mrgs_carve_img(void* base, int H, int W)
     w.fwd_assign = c.take<uint32_t>(8 * (per_list + MRGS_MAX_SIMD_QUEUES));
     w.bwd_assign = c.take<uint32_t>(8 * (per_list + MRGS_MAX_SIMD_QUEUES));
     w.blend_state = c.take<uint32_t>(MRGS_BLEND_STATE_WORDS);
+    w.q_bwd = w.blend_state + MRGS_QS_BWD;
     w.final_T = c.take<float>(3 * hw);
     w.n_contrib = c.take<uint32_t>(2 * hw);
     w.redo_list = c.take<uint32_t>(2 + hw);
@@ -202,6 +203,26 @@ static int check_cfg(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in)
     return MRGS_OK;
 }
 
+MrgsHintLayout mrgs_hint_layout(int H, int W)
+{
+    const size_t tiles = (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y);
+    const size_t nt = tiles > 0 ? tiles : 1, per_list = (nt + 7) / 8 * 4;
+    MrgsHintLayout l;
+    l.work = 0;
+    l.blend_state = mrgs_align_up(4 * nt, 64);
+    l.fwd_assign = mrgs_align_up(l.blend_state + MRGS_BLEND_STATE_WORDS, 64);
+    l.total_words = mrgs_align_up(l.fwd_assign + 8 * (per_list + MRGS_MAX_SIMD_QUEUES), 64);
+    return l;
+}
+// with a per-camera hint buffer the blend kernels' queue state and the forward's dealt queues live in it (see MrgsHintLayout)
+static void img_use_hint(MrgsImgWs& img, const MrgsRasterInputs* in, int H, int W)
+{
+    if (in->work_hint == nullptr) return;
+    const MrgsHintLayout l = mrgs_hint_layout(H, W);
+    img.blend_state = in->work_hint + l.blend_state;
+    img.fwd_assign = in->work_hint + l.fwd_assign;
+}
+
 extern "C" {
 
 size_t mrgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return mrgs_carve_geom(nullptr, P, H, W).total; }
@@ -210,7 +231,7 @@ size_t mrgs_binning_bytes(int64_t R) { return mrgs_carve_bin(nullptr, R).total; 
 size_t mrgs_work_hint_bytes(int32_t H, int32_t W)
 {
     if (H <= 0 || W <= 0) return 0;
-    return 4 * (size_t)((W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X) * ((H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y) * sizeof(uint32_t);
+    return mrgs_hint_layout(H, W).total_words * sizeof(uint32_t);
 }
 size_t mrgs_grad_bytes(int32_t P, int32_t S) { return mrgs_align_up((size_t)(P > 0 ? P : 1) * MRGS_GRAD_STRIDE(S) * sizeof(float), 256); }
 
@@ -252,9 +273,13 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
 
     StageTimer t0(stream, ST_DUP);
     int cur = 0;
+    bool reuse_order = false;
     if (g.tile_mat != nullptr) {
         // pairs into their tile's segment (one LDS atomic each), per-tile LDS sort -> point_list, cull bits, ranges, work estimates
-        if (R > 0) mrgs_launch_tile_emit_sort(*cfg, g, b, img, R, stream);
+        // MRGS_HINT_REUSE_ORDER: the queues dealt at an earlier visit of this camera serve again (they are in the hint buffer); what the
+        // ordering launch did besides ordering moves into the tile sort
+        reuse_order = R > 0 && in->work_hint != nullptr && (in->hint_flags & MRGS_HINT_REUSE_ORDER) != 0u;
+        if (R > 0) mrgs_launch_tile_emit_sort(*cfg, g, b, img, R, reuse_order, in->bwd_grad_ws, in->bwd_grad_ws ? mrgs_grad_bytes(cfg->P, cfg->S) : 0, stream);
         else HIP_TRY(hipMemsetAsync(img.ranges, 0, img.ranges_est_bytes, stream));   // nothing visible: the ranges read as empty
         STAGE_CHECK(cfg, stream);
     } else {
@@ -271,8 +296,9 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
         mrgs_launch_tile_ranges(b.tile_key[cur], b.plist[cur], R, R_dev, g.cull, b.qmask, img, tiles_x, ntiles, stream);
     }
     // (with MrgsRasterInputs::bwd_grad_ws the ordering launch also prepares the backward: rows cleared, queues copied)
-    mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, in->bwd_grad_ws, in->bwd_grad_ws ? mrgs_grad_bytes(cfg->P, cfg->S) : 0, in->work_hint,
-                            stream);
+    if (!reuse_order)
+        mrgs_launch_blend_order(img, g.counters + 16, ntiles, 0, in->bwd_grad_ws, in->bwd_grad_ws ? mrgs_grad_bytes(cfg->P, cfg->S) : 0, in->work_hint,
+                                stream);
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
@@ -333,6 +359,7 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
     if (cfg->P == 0) return zero_outputs(cfg, out_color, out_feature, out_others, stream);
     if (!geom_ws || !binning_ws) return MRGS_E_BAD_ARG;
     MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
+    img_use_hint(img, in, cfg->H, cfg->W);
     MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(binning_ws, R);
     if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
@@ -369,6 +396,7 @@ int mrgs_rasterize_forward_begin(const MrgsRasterConfig* cfg, const MrgsRasterIn
     MrgsGeomWs g = mrgs_carve_geom(geom_ws, cfg->P, cfg->H, cfg->W);
     if (geom_bytes < g.total) return MRGS_E_WORKSPACE;
     MrgsImgWs img = mrgs_carve_img(img_ws, cfg->H, cfg->W);
+    img_use_hint(img, in, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(binning_ws, capacity_pairs);
     if (binning_bytes < b.total) return MRGS_E_WORKSPACE;
     int device = 0;
@@ -437,6 +465,7 @@ int mrgs_rasterize_backward_blend(const MrgsRasterConfig* cfg, const MrgsRasterI
     MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);
     MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
     MrgsImgWs img = mrgs_carve_img(const_cast<void*>(img_ws), cfg->H, cfg->W);
+    img_use_hint(img, in, cfg->H, cfg->W);
     const int cur = plist_buf(g, tiles_x * tiles_y);
     float* grad_rec = (float*)grad_ws;
 

@@ -382,8 +382,27 @@ __global__ void __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu
                                                                int64_t capacity, const unsigned long long* __restrict__ pairs,
                                                                uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask,
                                                                uint2* __restrict__ ranges, uint32_t* __restrict__ item_est,
-                                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ census)
+                                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ census,
+                                                               uint32_t* __restrict__ reuse_state, uint32_t* __restrict__ reuse_bwd, uint32_t* __restrict__ redo_count,
+                                                               uint32_t* __restrict__ item_work,
+                                                               float4* __restrict__ bulk_zero, size_t bulk_zero_f4)
 {
+    // No ordering launch follows when the forward reuses the queues dealt at an earlier visit of the camera (reuse_state = the forward's queue state in the camera's hint buffer, reuse_bwd = the backward's in this render's workspace):
+    // its side jobs are done here -- tickets of both blend kernels back to zero, the backward's queue shape = the forward's, the work
+    // records of this tile's four items cleared, and this workgroup's share of the coming backward's gradient rows zeroed
+    if (reuse_state != nullptr) {
+        const int t = (int)blockIdx.x, T_ = (int)gridDim.x;
+        for (int w = t * BS_THREADS + (int)threadIdx.x; w < 8 * MRGS_MAX_SIMD_QUEUES; w += T_ * BS_THREADS) {
+            reuse_state[MRGS_QS_FWD + MRGS_QS_TICKET + w] = 0u;
+            reuse_bwd[MRGS_QS_TICKET + w] = 0u;
+        }
+        if (t == 0 && threadIdx.x < 16) reuse_bwd[threadIdx.x] = reuse_state[MRGS_QS_FWD + threadIdx.x];     // COUNT[8] | PASSES[8]
+        if (t == 0 && threadIdx.x == 16) redo_count[0] = 0u;         // (the list of marked pixels of the MRGS_FWD_REDO_INLINE=0 build)
+        if (threadIdx.x < 4) item_work[t * 4 + threadIdx.x] = 0u;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t per = (bulk_zero_f4 + T_ - 1) / T_, z0 = per * t, z1 = z0 + per < bulk_zero_f4 ? z0 + per : bulk_zero_f4;
+        for (size_t i = z0 + threadIdx.x; i < z1; i += BS_THREADS) bulk_zero[i] = z;
+    }
     __shared__ unsigned long long s_tmp[SORT_SMALL_CAP];          // the keys in bucket order
     __shared__ uint32_t s_cnt[BS_NB + BS_NB / BS_OWN];             // counts -> bucket starts -> bucket ends (padded index: bs_pad)
     __shared__ uint32_t s_lo[BS_THREADS / 64], s_hi[BS_THREADS / 64], s_wsum[BS_THREADS / 64], s_q[4];
@@ -589,7 +608,7 @@ void mrgs_launch_tile_count_scan(const MrgsRasterConfig& cfg, const MrgsGeomWs& 
 }
 
 void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const MrgsBinWs& b, const MrgsImgWs& img, int64_t capacity,
-                                hipStream_t stream)
+                                bool reuse_order, void* bulk_zero, size_t bulk_zero_bytes, hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
     const int T = tiles_x * tiles_y, Tpad = mrgs_bin_tpad(T), G = mrgs_bin_groups(cfg.P);
@@ -598,7 +617,9 @@ void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g
                        g.rect, g.depth_key[0], g.cull, tiles_x, T, Tpad, g.tile_mat, g.tile_loc, g.chunk_base, g.counters, capacity, pairs,
                        g.counters + 16, g.counters + 6);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(BS_THREADS), 0, stream, T, g.tile_cnt, g.tile_loc, g.chunk_base, g.counters, capacity,
-                       pairs, b.plist[0], b.qmask, img.ranges, img.item_est, g.big_list, g.counters + 16);
+                       pairs, b.plist[0], b.qmask, img.ranges, img.item_est, g.big_list, g.counters + 16,
+                       reuse_order ? img.blend_state : (uint32_t*)nullptr, img.q_bwd, img.redo_list, img.item_work, (float4*)(reuse_order ? bulk_zero : nullptr),
+                       reuse_order && bulk_zero ? bulk_zero_bytes / sizeof(float4) : (size_t)0);
     hipLaunchKernelGGL(tile_sort_big_kernel, dim3(32), dim3(SORT_BIG_THREADS), (size_t)SORT_BIG_CAP * 8, stream, g.tile_cnt, g.tile_loc, g.chunk_base,
                        g.counters, capacity, pairs, b.plist[0], b.qmask, img.item_est, g.big_list);
 }

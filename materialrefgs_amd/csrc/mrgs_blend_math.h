@@ -141,9 +141,17 @@ struct Hit {
 #define MRGS_NEAR_LO (MRGS_NEAR_N - 1e-4f)
 #define MRGS_NEAR_HI (MRGS_NEAR_N + 1e-4f)
 #define MRGS_RHO_EPS 2e-5f
-// transmittance: relative distance of the fast product from the exact one, measured over whole renders x 8
-#define MRGS_T1_EPS (MRGS_T_MIN * 2e-5f)
-#define MRGS_T2_EPS (0.5f * 8e-6f)
+// transmittance: the fast product of (1 - alpha) against the exact one.  T > 0.5: every earlier alpha is below 0.5, the relative
+// difference is at most sum alpha_i / (1 - alpha_i) x 2.7e-6 <= 2 ln 2 x 2.7e-6 = 3.7e-6 (measured over 1.4 M pixels: 5.5e-7) -> 4e-6.
+// T (1 - alpha) < 1e-4: the same sum over a whole list has no useful bound (5e-5 if every pair sat at its worst case); measured over the
+// same pixels (tools/margin_stats.py: fast against -DMRGS_FWD_REDO_ALL) the largest difference at T <= 1e-3 is 5.2e-6, the 99.99th
+// percentile 1.9e-6 -> 1.5e-5.  A wider band only marks more pixels (each costs its wave ~6 us of exact rendering).
+#ifndef MRGS_T1_EPS
+#define MRGS_T1_EPS (MRGS_T_MIN * 1.5e-5f)
+#endif
+#ifndef MRGS_T2_EPS
+#define MRGS_T2_EPS (0.5f * 4e-6f)
+#endif
 
 // forward.cu:366-398 / backward.cu:296-328, branch-free: everything is evaluated and the reference's chain of `continue`s collapses
 // into flags (a zero p.z gives inf/NaN operands, and every comparison with NaN is false, so such pairs are rejected exactly as the

@@ -70,7 +70,10 @@ struct MrgsImgWs {
     uint32_t* item_work; // [4 * tiles] cost of each forward wave's walk (item = tile * 4 + quadrant) = work of its backward wave
     uint32_t* order_items, *order_work;   // [8][per_list] scratch of blend_order_kernel (items of an XCD list by decreasing work)
     uint32_t* fwd_assign, *bwd_assign;    // [8][per_list + 128] item handed to ticket t of SIMD queue q at [t * NQ + q]
-    uint32_t* blend_state;                // MRGS_BLEND_STATE_WORDS
+    uint32_t* blend_state;                // MRGS_BLEND_STATE_WORDS: forward queue state | (backward queue state) | CU numbering -- in the camera's
+                                          // hint buffer when the caller passed one (mrgs_api.hip: img_use_hint)
+    uint32_t* q_bwd;                      // queue state of the backward blend: always in THIS render's workspace (two renders of one camera
+                                          // may have their backwards pending at the same time)
     float* final_T;      // [3][H*W]: T, M1, M2
     uint32_t* n_contrib; // [2][H*W]: last, median
     uint32_t* redo_list; // [2 + H*W]: [0] count (cleared by the forward's ordering launch), [2 + i] pixel index of the i-th pixel whose
@@ -88,6 +91,11 @@ struct MrgsBinWs {
     size_t total;
 };
 
+// Per-camera hint buffer (MrgsRasterInputs::work_hint), uint32 words: [0, 4 T) work of every (tile, quadrant) at the last visit |
+// blend_state (MRGS_BLEND_STATE_WORDS: queue state of both blend kernels + CU numbering) | fwd_assign (the dealt queues).  With a hint
+// buffer the last two live THERE instead of in the per-call image workspace, so that a later visit can reuse them (MRGS_HINT_REUSE_ORDER).
+struct MrgsHintLayout { size_t work, blend_state, fwd_assign, total_words; };
+MrgsHintLayout mrgs_hint_layout(int H, int W);
 MrgsGeomWs mrgs_carve_geom(void* base, int P, int H, int W);
 MrgsImgWs mrgs_carve_img(void* base, int H, int W);
 MrgsBinWs mrgs_carve_bin(void* base, int64_t R);
@@ -136,8 +144,10 @@ int mrgs_bin_groups(int P);
 int mrgs_bin_tpad(int T);
 bool mrgs_bin_supported(int T);
 void mrgs_launch_tile_count_scan(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, uint32_t* host_slot, hipStream_t stream);
+// reuse_order: no ordering launch follows -- the tile sort's workgroups reset the queue tickets, copy the forward's queue shape to the
+// backward's, clear item_work and (bulk_zero) the gradient rows of the coming backward
 void mrgs_launch_tile_emit_sort(const MrgsRasterConfig& cfg, const MrgsGeomWs& g, const MrgsBinWs& b, const MrgsImgWs& img, int64_t capacity,
-                                hipStream_t stream);
+                                bool reuse_order, void* bulk_zero, size_t bulk_zero_bytes, hipStream_t stream);
 
 void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g, int32_t* radii,
                                 hipStream_t stream);

@@ -184,7 +184,7 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #endif
 template <int S_MAX, bool FV>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? MRGS_BWD_WPE0 : S_MAX <= 8 ? MRGS_BWD_WPE8 : 2, 8))) render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ q_bwd, const uint32_t* __restrict__ cu_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     WS_ENTRY();
-    const uint32_t item = mrgs_pull_item(blend_state + MRGS_QS_BWD, blend_state + MRGS_CS_BASE, bwd_assign, ntiles, b & 7, b >> 3, lane, slots WS_DBG);
+    const uint32_t item = mrgs_pull_item(q_bwd, cu_state, bwd_assign, ntiles, b & 7, b >> 3, lane, slots WS_DBG);
     if (item == 0xFFFFFFFFu) return;
     const int tile = (int)((item & 0x1FFFFFFFu) >> 2), quad = (int)(item & 3u);
     const uint32_t prio = (item >> 29) & 3u;
@@ -469,7 +469,7 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
 #define LAUNCH(SM, FVV, GS)                                                                                                       \
-    hipLaunchKernelGGL((MRGS_BWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.blend_state, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+    hipLaunchKernelGGL((MRGS_BWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.q_bwd, img.blend_state + MRGS_CS_BASE, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
                        g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<MRGS_BWD_KERNEL<SM, FVV>>())
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);

@@ -19,6 +19,8 @@
 //   * the launch lasts as long as its longest wave takes ALONE on a SIMD: late in a block's list, when few of
 //     its pixels are still alive, the block-level cull is evaluated again against the bounding box of the live pixels (below), and
 //     the file is compiled with LLVM's max-ilp scheduling strategy (a lone wave pays ~8 cycles per dependent instruction).
+#include <type_traits>
+
 #include "mrgs_blend_math.h"
 
 // MRGS_FWD_REFINE: the cull against the live pixels' bounding box, for chunks that start with at most MRGS_FWD_REFINE_LIVE live pixels
@@ -47,8 +49,229 @@ __device__ int g_ws_min_total = 0;
 extern "C" int mrgs_wave_stats_min_total(int n) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_min_total), &n, sizeof(int)); }
 #endif
 
+// One marked pixel per wave, the lanes turned sideways: lane l evaluates list entry base + l against THAT pixel as the oracle does
+// (IEEE quotient, correctly rounded exp, the reference's thresholds: mrgs_intersect_exact); the transmittance -- the one quantity whose
+// rounding sequence decides anything -- is multiplied up serially in list order, one rounding per blended entry exactly as
+// forward.cu:400-441 does; the sums (which decide nothing) are formed per lane and folded across the wave at the end.  Lane 0
+// overwrites the pixel's outputs; entries the pixel blends are flagged for the backward like those of the main kernel.
+// Called from the tail of the forward kernel (MRGS_FWD_REDO_INLINE, the default: the forward's occupancy is pinned, so what this code
+// needs beyond the main loop's registers is spilled around it, in code that runs for one wave in a hundred) or from a launch of its own.
+// inclusive prefix sum over the 64 lanes in DPP adds: Hillis-Steele inside the 16-lane rows (a lane whose source falls outside its row adds
+// 0), then lane 15 / lane 31 of the rows before into the rows behind.  Every lane of the wave must be active.
+__device__ __forceinline__ float wave_inclusive_sum(float v)
+{
+    v = mrgs_dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = mrgs_dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = mrgs_dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = mrgs_dpp_add<0x118, 0xf>(v);   // row_shr:8
+    v = mrgs_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = mrgs_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+constexpr int MRGS_REDO_QCAP = 384, MRGS_REDO_REFILL = 4;      // queue entries; a refill scans 4 x 64 list entries with all their loads in flight
+template <int S_MAX>
+__device__ __forceinline__ void mrgs_redo_pixel(
+    int pix, int lane, uint32_t* __restrict__ q_id, uint32_t* __restrict__ q_pos /* LDS, MRGS_REDO_QCAP words each */,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask, uint8_t* cflag, int S, int W, int H,
+    int tiles_x, const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others)
+{
+    constexpr int SF = S_MAX > 0 ? S_MAX : 1;
+    constexpr int QCAP = MRGS_REDO_QCAP, REFILL = MRGS_REDO_REFILL;
+    (void)QCAP;
+    const int HW = H * W;
+    const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
+    const int pyi = pix / W, pxi = pix - pyi * W;
+    const int tile = (pyi >> 4) * tiles_x + (pxi >> 4), quad = ((pyi >> 3) & 1) * 2 + ((pxi >> 3) & 1);
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const uint32_t* plist = point_list + range.x;
+    const uint8_t* qm = qmask + range.x;
+    const float qx = (float)pxi, qy = (float)pyi;
+    float xT = 1.0f, xM1 = 0.f, xM2 = 0.f, xmed = 0.f;          // wave-uniform running values of the pixel
+    uint32_t xlast = 0, xmedc = 0;
+    float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sD = 0.f, sDist = 0.f;   // this lane's share of the sums
+    float sF[SF];
+#pragma unroll
+    for (int i = 0; i < SF; i++) sF[i] = 0.f;
+    int nq = 0, qh = 0, next = 0;             // the queue holds nq candidates from q_*[qh] on
+    bool ended = false, pre_ok = false;
+    uint32_t pre_gid = 0;
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0, p4 = p0;
+    while (!ended && (next < total || nq > 0)) {
+        if (nq < MRGS_CHUNK && next < total) {
+            // refill: what is left (< 64) moves to the front, then the candidates of the next 256 list entries are appended in order
+            const uint32_t keep_id = q_id[qh + lane], keep_pos = q_pos[qh + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nq) { q_id[lane] = keep_id; q_pos[lane] = keep_pos; }
+            qh = 0;
+            bool cand[REFILL];
+            uint32_t id[REFILL];
+#pragma unroll
+            for (int k = 0; k < REFILL; k++) {
+                const int e = next + k * MRGS_CHUNK + lane;
+                cand[k] = e < total && ((qm[e < total ? e : 0] >> quad) & 1u);
+                id[k] = plist[e < total ? e : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < REFILL; k++) {
+                const uint64_t cm = __builtin_amdgcn_ballot_w64(cand[k]);
+                if (cand[k]) {
+                    const int at = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    q_id[at] = id[k]; q_pos[at] = (uint32_t)(next + k * MRGS_CHUNK + lane);
+                }
+                nq += __builtin_popcountll(cm);
+            }
+            next += REFILL * MRGS_CHUNK;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (nq < MRGS_CHUNK && next < total) continue;       // sparse stretch of the list: scan on before a partial batch is evaluated
+        }
+        const int n = nq < MRGS_CHUNK ? nq : MRGS_CHUNK;
+        const bool valid = lane < n;
+        const uint32_t gid = valid ? q_id[qh + lane] : 0u;
+        const int e = valid ? (int)q_pos[qh + lane] : 0;
+        // this batch's records: fetched while the batch before was evaluated when the queue held them then already
+        float4 r0, r1, r2, r3, r4;
+        if (pre_gid == gid && pre_ok) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; }
+        else { const float4* src = rec + (size_t)gid * MRGS_REC_F4; r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4]; }
+        {   // ... and the next one's are requested now
+            const int rest = nq - n;
+            pre_ok = rest > 0;                                                    // (wave-uniform)
+            pre_gid = lane < rest ? q_id[qh + n + lane] : 0u;
+            if (pre_ok) { const float4* nx = rec + (size_t)pre_gid * MRGS_REC_F4; p0 = nx[0]; p1 = nx[1]; p2 = nx[2]; p3 = nx[3]; p4 = nx[4]; }
+        }
+        SurfelGeom sg;
+        sg.g0 = r0; sg.g1 = r1; sg.g2 = r2;
+        Hit h;
+        const bool hit = mrgs_intersect_exact(sg, qx, qy, h) & valid;
+        const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
+        const float oma = 1.0f - h.alpha;
+        // T in front of every hit of the batch: the serial product, one float multiplication per hit in list order -- formed by every
+        // lane for itself (lane l multiplies the factors of lanes 0 .. l-1 in that order, 1.0 for a lane without a hit: the same
+        // roundings as one running product), so that the dependent chain is 64 multiplications and nothing else
+        const float fac = hit ? oma : 1.0f;
+        float Tb = xT;
+#pragma unroll
+        for (int i = 0; i < MRGS_CHUNK - 1; i++) {
+            const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fac), i));
+            Tb = Tb * (lane > i ? d : 1.0f);
+        }
+        const float run = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(Tb * fac), MRGS_CHUNK - 1));
+        // the first hit that would take T below 1e-4 ends the pixel and is not blended (forward.cu:400-404); the products
+        // formed behind it are not used
+        const uint64_t tm = __builtin_amdgcn_ballot_w64(hit & (Tb * oma < MRGS_T_MIN));
+        const uint64_t bm = tm != 0ull ? hm & ((1ull << __builtin_ctzll(tm)) - 1ull) : hm;
+        const bool bl = (bm >> lane) & 1ull;
+        if (tm != 0ull) xT = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(Tb), __builtin_ctzll(tm)));
+        else xT = run;
+        const float w = bl ? h.alpha * Tb : 0.0f;
+        const float depth = bl ? h.depth : 1.0f;
+        const float m_ = mscale * (1.0f - MRGS_NEAR_N * (1.0f / depth));
+        const float mw = m_ * w, mmw = m_ * m_ * w;
+        // M1, M2 in front of this lane's entry: carry of the batches before + exclusive prefix inside the batch
+        const float i1 = wave_inclusive_sum(mw), i2 = wave_inclusive_sum(mmw);
+        const float pM1 = xM1 + (i1 - mw), pM2 = xM2 + (i2 - mmw);
+        xM1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(i1), 63));
+        xM2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(i2), 63));
+        sDist = fmaf(fmaf(-2.0f * m_, pM1, fmaf(m_ * m_, 1.0f - Tb, pM2)), w, sDist);
+        sD = fmaf(depth, w, sD);
+        const float4 a0 = r3, a1 = r4;
+        sN0 = fmaf(a0.x, w, sN0); sN1 = fmaf(a0.y, w, sN1); sN2 = fmaf(a0.z, w, sN2);
+        sC0 = fmaf(a0.w, w, sC0); sC1 = fmaf(a1.x, w, sC1); sC2 = fmaf(a1.y, w, sC2);
+        if (S_MAX > 0 && __builtin_amdgcn_ballot_w64(bl) != 0ull) {
+            const float* fsrc = features + (size_t)gid * S;
+#pragma unroll
+            for (int ch = 0; ch < S_MAX; ch++)
+                if (ch < S) sF[ch] = fmaf(fsrc[ch], w, sF[ch]);
+        }
+        if (bm != 0ull) xlast = (uint32_t)__builtin_amdgcn_readlane(e, 63 - __builtin_clzll(bm)) + 1u;
+        const uint64_t medm = __builtin_amdgcn_ballot_w64(bl & (Tb > 0.5f));          // forward.cu:417-420
+        if (medm != 0ull) {
+            const int jm = 63 - __builtin_clzll(medm);
+            xmedc = (uint32_t)__builtin_amdgcn_readlane(e, jm) + 1u;
+            xmed = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.depth), jm));
+        }
+        // flags for the backward: bit 0 = blended by some pixel, bit 1 = the FAST evaluation of this pair cannot be sure of the hit
+        // (the main kernel flagged the entries it walked; this pixel may go further than its wave did).  Bits are only ever set here.
+        if (valid) {
+            Hit hf;
+            bool amb;
+            const bool mh = mrgs_intersect(sg, qx, qy, hf);
+            (void)mrgs_hit_decide(hf, mh, amb);
+            const bool in_reach = tm == 0ull || lane <= __builtin_ctzll(tm);
+            const uint32_t fl = (bl ? 1u : 0u) | ((amb && in_reach) ? 3u : 0u);
+            // (the four quadrant bytes of a list entry are one aligned word; marked pixels of one block may meet on a byte)
+            if (fl) atomicOr(reinterpret_cast<uint32_t*>(cflag) + range.x + e, fl << (8 * quad));
+        }
+        ended = tm != 0ull;
+        qh += n;
+        nq -= n;
+    }
+    auto wave_sum = [&](float v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        return v;
+    };
+    sC0 = wave_sum(sC0); sC1 = wave_sum(sC1); sC2 = wave_sum(sC2);
+    sN0 = wave_sum(sN0); sN1 = wave_sum(sN1); sN2 = wave_sum(sN2);
+    sD = wave_sum(sD); sDist = wave_sum(sDist);
+    if (S_MAX > 0) {
+#pragma unroll
+        for (int ch = 0; ch < S_MAX; ch++) sF[ch] = wave_sum(sF[ch]);
+    }
+    if (lane == 0) {
+        final_T[pix] = xT;
+        final_T[pix + HW] = xM1;
+        final_T[pix + 2 * HW] = xM2;
+        n_contrib[pix] = xlast;
+        n_contrib[pix + HW] = xmedc;
+        out_color[pix] = fmaf(xT, bg[0], sC0);
+        out_color[pix + HW] = fmaf(xT, bg[1], sC1);
+        out_color[pix + 2 * HW] = fmaf(xT, bg[2], sC2);
+        if (S_MAX > 0) {
+#pragma unroll
+            for (int ch = 0; ch < S_MAX; ch++)
+                if (ch < S) out_feature[(size_t)ch * HW + pix] = sF[ch];
+        }
+        out_others[pix + 0 * HW] = sD;
+        out_others[pix + 1 * HW] = 1.0f - xT;
+        out_others[pix + 2 * HW] = sN0;
+        out_others[pix + 3 * HW] = sN1;
+        out_others[pix + 4 * HW] = sN2;
+        out_others[pix + 5 * HW] = xmed;
+        out_others[pix + 6 * HW] = sDist;
+    }
+}
+
+// The marked pixels of a launch, one per wave (see mrgs_redo_pixel).  The forward kernel renders its own marked pixels at the end of its
+// wave by default (MRGS_FWD_REDO_INLINE): measured, the separate launch's duration -- the longest marked list, walked by a wave that is
+// alone on its SIMD -- is fully exposed on the stream (26 us at C2), while inside the forward the same work extends a handful of waves
+// of which few are among the last to finish.
+template <int S_MAX>
+__global__ void __launch_bounds__(64) render_fwd_redo_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask, uint8_t* cflag, int S, int W, int H,
+    int tiles_x, const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
+    const uint32_t* __restrict__ redo_list)
+{
+    __shared__ uint32_t q_id[MRGS_REDO_QCAP], q_pos[MRGS_REDO_QCAP];
+    const int lane = threadIdx.x;
+    const uint32_t count = redo_list[0];
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        mrgs_redo_pixel<S_MAX>((int)redo_list[2 + it], lane, q_id, q_pos, ranges, point_list, qmask, cflag, S, W, H, tiles_x, rec, features, bg, final_T,
+                               n_contrib, out_color, out_feature, out_others);
+        __builtin_amdgcn_wave_barrier();        // the next pixel's queue starts empty: nothing of this one is read again
+    }
+}
+
+#ifndef MRGS_FWD_REDO_INLINE
+#define MRGS_FWD_REDO_INLINE 1
+#endif
 template <int S_MAX, bool FV>
-__global__ void __launch_bounds__(64) render_fwd_kernel(
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 7 : S_MAX <= 12 ? 5 : 4, 8))) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float4* __restrict__ cull, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -169,6 +392,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
         // replaced.  The results are bit-identical to skipping the entry.
         // (a0, a1: normal and color of the entry, fetched together with its geometry one entry ahead -- inside the branch
         // below their LDS latency sat on the critical path of the longest waves, which set the duration of this kernel)
+        // MEDIAN: some live pixel of the block may still have T > 0.5 in this chunk (T only falls).  Dense blocks are past that after
+        // their first chunk or two, and the entry body then carries neither the T > 0.5 test and its band nor the median selects.
+        const bool median_live = (MRGS_BALLOT(T > 0.5f - MRGS_T2_EPS) & ~done) != 0ull;      // wave-uniform, per chunk
         auto blend_entry = [&](const SurfelGeom& sg, const float4& a0, const float2& a1, int j) {
             Hit h;
             const uint64_t may_hit = mrgs_intersect_mask(sg, px, py, h) & ~done;
@@ -183,14 +409,31 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             contributed |= 1ull << j;          // (a superset of "blended": a pixel may terminate on it instead; the backward sorts that out)
             uint64_t ambiguous;
-            const uint64_t ok = mrgs_hit_decide_mask(h, may_hit, ambiguous);
-            // (the backward evaluates such an entry with the oracle's arithmetic for the whole block: flag bit 1)
-            if (ambiguous != 0ull) unsure |= 1ull << j;
+            uint64_t ok = mrgs_hit_decide_mask(h, may_hit, ambiguous);
+            if (__builtin_expect(ambiguous != 0ull, 0)) {
+                // a hit inside its error band (~1e-6 of the pairs): the lanes concerned evaluate the pair again as the oracle does, and
+                // the entry is flagged for the backward, which then does the same for the whole block (flag bit 1)
+                unsure |= 1ull << j;
+                const bool amb_lane = MRGS_LANES(ambiguous);
+                Hit hx;
+                bool hit_x = false;
+                if (amb_lane) hit_x = mrgs_intersect_exact<true>(sg, px, py, hx);
+                ok = (ok & ~ambiguous) | (__builtin_amdgcn_ballot_w64(hit_x) & ambiguous);
+                h.alpha = amb_lane ? hx.alpha : h.alpha;
+                h.depth = amb_lane ? hx.depth : h.depth;
+            }
             const float test_T = T * (1.0f - h.alpha);
-            // a decision the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, after the launch
-            // (mrgs_blend_math.h "Exact decisions"; render_fwd_redo_kernel below)
-            redo |= ambiguous | (ok & (MRGS_BALLOT(fabsf(test_T - MRGS_T_MIN) < MRGS_T1_EPS) | MRGS_BALLOT(fabsf(T - 0.5f) < MRGS_T2_EPS)));
-            const uint64_t below = MRGS_BALLOT(test_T < MRGS_T_MIN);
+            // a TRANSMITTANCE the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, at the end of the
+            // wave (mrgs_blend_math.h "Exact decisions"; mrgs_redo_pixel)
+            // (the two transmittance tests as two comparisons each, against the near and the far edge of the band: between them the
+            // pixel is marked, and what the fast path does with a marked pixel does not matter)
+            const uint64_t below = MRGS_BALLOT(test_T < MRGS_T_MIN - MRGS_T1_EPS);
+            uint64_t t_high = 0ull, t_band = 0ull;
+            if (median_live) {
+                t_high = MRGS_BALLOT(T > 0.5f + MRGS_T2_EPS);
+                t_band = MRGS_BALLOT(T > 0.5f - MRGS_T2_EPS) & ~t_high;
+            }
+            redo |= ok & ((MRGS_BALLOT(test_T < MRGS_T_MIN + MRGS_T1_EPS) & ~below) | t_band);
             done |= ok & below;                               // forward.cu:400-404: the pixel stops BEFORE blending this entry
             const uint64_t upd_mask = ok & ~below;
             const bool upd = MRGS_LANES(upd_mask);
@@ -206,9 +449,11 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
             M1 = fmaf(m_, w, M1);
             M2 = fmaf(mm, w, M2);
             const uint32_t contributor = (uint32_t)(base + j + 1);
-            const bool med = MRGS_LANES(upd_mask & MRGS_BALLOT(T > 0.5f));
-            median_depth = med ? depth : median_depth;
-            median_contributor = med ? contributor : median_contributor;
+            if (median_live) {
+                const bool med = MRGS_LANES(upd_mask & t_high);
+                median_depth = med ? depth : median_depth;
+                median_contributor = med ? contributor : median_contributor;
+            }
             N0 = fmaf(a0.x, w, N0); N1 = fmaf(a0.y, w, N1); N2 = fmaf(a0.z, w, N2);
             C0 = fmaf(a0.w, w, C0); C1 = fmaf(a1.x, w, C1); C2 = fmaf(a1.y, w, C2);
             if (S_MAX > 0) {
@@ -307,213 +552,22 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(
     redo &= __builtin_amdgcn_ballot_w64(inside);
     if (redo != 0ull) {
         for (int e = cf_end + lane; e < total; e += MRGS_CHUNK) cf[(size_t)e * 4] = 0;
+#if MRGS_FWD_REDO_INLINE
+        // (the list staging buffer is free by now: the candidate queue of the redo lives there)
+        uint32_t* q = reinterpret_cast<uint32_t*>(&stage[0]);
+        static_assert(sizeof(StageBuf<SF>) >= 2 * MRGS_REDO_QCAP * sizeof(uint32_t), "the redo's queue must fit the staging buffer");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while (redo != 0ull) {
+            const int p = __builtin_ctzll(redo);
+            redo &= redo - 1;
+            mrgs_redo_pixel<S_MAX>(__builtin_amdgcn_readlane(pix, p), lane, q, q + MRGS_REDO_QCAP, ranges, point_list, qmask, cflag, S, W, H, tiles_x, rec, features,
+                                   bg, final_T, n_contrib, out_color, out_feature, out_others);
+            __builtin_amdgcn_wave_barrier();
+        }
+#else
         if ((redo >> lane) & 1ull) redo_list[2 + atomicAdd(&redo_list[0], 1u)] = (uint32_t)pix;
-    }
-}
-
-// One marked pixel per wave, the lanes turned sideways: lane l evaluates list entry base + l against THAT pixel as the oracle does
-// (IEEE quotient, correctly rounded exp, the reference's thresholds: mrgs_intersect_exact); the transmittance -- the one quantity whose
-// rounding sequence decides anything -- is multiplied up serially in list order, one rounding per blended entry exactly as
-// forward.cu:400-441 does; the sums (which decide nothing) are formed per lane and folded across the wave at the end.  Lane 0
-// overwrites the pixel's outputs; entries the pixel blends are flagged for the backward like those of the main kernel.
-// A kernel of its own, not a tail of render_fwd_kernel: there its 100+ registers would be the main kernel's (measured: 68 -> 118 VGPRs,
-// or 28 spilled values and a scratch allocation per wave with the occupancy pinned -- +40 us on the 127 us launch either way).
-// inclusive prefix sum over the 64 lanes in DPP adds: Hillis-Steele inside the 16-lane rows (a lane whose source falls outside its row adds
-// 0), then lane 15 / lane 31 of the rows before into the rows behind.  Every lane of the wave must be active.
-__device__ __forceinline__ float wave_inclusive_sum(float v)
-{
-    v = mrgs_dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = mrgs_dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = mrgs_dpp_add<0x114, 0xf>(v);   // row_shr:4
-    v = mrgs_dpp_add<0x118, 0xf>(v);   // row_shr:8
-    v = mrgs_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = mrgs_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-template <int S_MAX>
-__global__ void __launch_bounds__(64) render_fwd_redo_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask, uint8_t* cflag, int S, int W, int H,
-    int tiles_x, const float4* __restrict__ rec, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_feature, float* __restrict__ out_others,
-    const uint32_t* __restrict__ redo_list)
-{
-    constexpr int SF = S_MAX > 0 ? S_MAX : 1;
-    // list entries that pass the block-level cull of the pixel's quadrant, in list order: (surfel, list position).  The cull is
-    // conservative for the exact arithmetic too (its conic is padded by 1e-4 of tau + 1e-3 and tested with 1 % slack), and ~60 % of a
-    // tile's list misses any given quadrant: the exact evaluation, whose dependent loads and double-precision exp set this kernel's
-    // duration (the longest marked list: 1 300 entries at C2), runs on full batches of 64 candidates instead of on every list entry
-    constexpr int QCAP = 384, REFILL = 4;      // a refill scans 4 x 64 list entries with all their loads in flight together
-    __shared__ uint32_t q_id[QCAP], q_pos[QCAP];
-    const int lane = threadIdx.x;
-    const int HW = H * W;
-    const uint32_t count = redo_list[0];
-    const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
-    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const int pix = (int)redo_list[2 + it];
-        const int pyi = pix / W, pxi = pix - pyi * W;
-        const int tile = (pyi >> 4) * tiles_x + (pxi >> 4), quad = ((pyi >> 3) & 1) * 2 + ((pxi >> 3) & 1);
-        const uint2 range = ranges[tile];
-        const int total = (int)(range.y - range.x);
-        const uint32_t* plist = point_list + range.x;
-        const uint8_t* qm = qmask + range.x;
-        const float qx = (float)pxi, qy = (float)pyi;
-        float xT = 1.0f, xM1 = 0.f, xM2 = 0.f, xmed = 0.f;          // wave-uniform running values of the pixel
-        uint32_t xlast = 0, xmedc = 0;
-        float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sD = 0.f, sDist = 0.f;   // this lane's share of the sums
-        float sF[SF];
-#pragma unroll
-        for (int i = 0; i < SF; i++) sF[i] = 0.f;
-        int nq = 0, qh = 0, next = 0;             // the queue holds nq candidates from q_*[qh] on
-        bool ended = false, pre_ok = false;
-        uint32_t pre_gid = 0;
-        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0, p4 = p0;
-        while (!ended && (next < total || nq > 0)) {
-            if (nq < MRGS_CHUNK && next < total) {
-                // refill: what is left (< 64) moves to the front, then the candidates of the next 256 list entries are appended in order
-                const uint32_t keep_id = q_id[qh + lane], keep_pos = q_pos[qh + lane];
-                __builtin_amdgcn_wave_barrier();
-                if (lane < nq) { q_id[lane] = keep_id; q_pos[lane] = keep_pos; }
-                qh = 0;
-                bool cand[REFILL];
-                uint32_t id[REFILL];
-#pragma unroll
-                for (int k = 0; k < REFILL; k++) {
-                    const int e = next + k * MRGS_CHUNK + lane;
-                    cand[k] = e < total && ((qm[e < total ? e : 0] >> quad) & 1u);
-                    id[k] = plist[e < total ? e : 0];
-                }
-#pragma unroll
-                for (int k = 0; k < REFILL; k++) {
-                    const uint64_t cm = __builtin_amdgcn_ballot_w64(cand[k]);
-                    if (cand[k]) {
-                        const int at = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                        q_id[at] = id[k]; q_pos[at] = (uint32_t)(next + k * MRGS_CHUNK + lane);
-                    }
-                    nq += __builtin_popcountll(cm);
-                }
-                next += REFILL * MRGS_CHUNK;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (nq < MRGS_CHUNK && next < total) continue;       // sparse stretch of the list: scan on before a partial batch is evaluated
-            }
-            const int n = nq < MRGS_CHUNK ? nq : MRGS_CHUNK;
-            const bool valid = lane < n;
-            const uint32_t gid = valid ? q_id[qh + lane] : 0u;
-            const int e = valid ? (int)q_pos[qh + lane] : 0;
-            // this batch's records: fetched while the batch before was evaluated when the queue held them then already
-            float4 r0, r1, r2, r3, r4;
-            if (pre_gid == gid && pre_ok) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; }
-            else { const float4* src = rec + (size_t)gid * MRGS_REC_F4; r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4]; }
-            {   // ... and the next one's are requested now
-                const int rest = nq - n;
-                pre_ok = rest > 0;                                                    // (wave-uniform)
-                pre_gid = lane < rest ? q_id[qh + n + lane] : 0u;
-                if (pre_ok) { const float4* nx = rec + (size_t)pre_gid * MRGS_REC_F4; p0 = nx[0]; p1 = nx[1]; p2 = nx[2]; p3 = nx[3]; p4 = nx[4]; }
-            }
-            SurfelGeom sg;
-            sg.g0 = r0; sg.g1 = r1; sg.g2 = r2;
-            Hit h;
-            const bool hit = mrgs_intersect_exact(sg, qx, qy, h) & valid;
-            const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
-            const float oma = 1.0f - h.alpha;
-            // T in front of every hit of the batch: the serial product, one float multiplication per hit in list order -- formed by every
-            // lane for itself (lane l multiplies the factors of lanes 0 .. l-1 in that order, 1.0 for a lane without a hit: the same
-            // roundings as one running product), so that the dependent chain is 64 multiplications and nothing else
-            const float fac = hit ? oma : 1.0f;
-            float Tb = xT;
-#pragma unroll
-            for (int i = 0; i < MRGS_CHUNK - 1; i++) {
-                const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fac), i));
-                Tb = Tb * (lane > i ? d : 1.0f);
-            }
-            const float run = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(Tb * fac), MRGS_CHUNK - 1));
-            // the first hit that would take T below 1e-4 ends the pixel and is not blended (forward.cu:400-404); the products
-            // formed behind it are not used
-            const uint64_t tm = __builtin_amdgcn_ballot_w64(hit & (Tb * oma < MRGS_T_MIN));
-            const uint64_t bm = tm != 0ull ? hm & ((1ull << __builtin_ctzll(tm)) - 1ull) : hm;
-            const bool bl = (bm >> lane) & 1ull;
-            if (tm != 0ull) xT = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(Tb), __builtin_ctzll(tm)));
-            else xT = run;
-            const float w = bl ? h.alpha * Tb : 0.0f;
-            const float depth = bl ? h.depth : 1.0f;
-            const float m_ = mscale * (1.0f - MRGS_NEAR_N * (1.0f / depth));
-            const float mw = m_ * w, mmw = m_ * m_ * w;
-            // M1, M2 in front of this lane's entry: carry of the batches before + exclusive prefix inside the batch
-            const float i1 = wave_inclusive_sum(mw), i2 = wave_inclusive_sum(mmw);
-            const float pM1 = xM1 + (i1 - mw), pM2 = xM2 + (i2 - mmw);
-            xM1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(i1), 63));
-            xM2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(i2), 63));
-            sDist = fmaf(fmaf(-2.0f * m_, pM1, fmaf(m_ * m_, 1.0f - Tb, pM2)), w, sDist);
-            sD = fmaf(depth, w, sD);
-            const float4 a0 = r3, a1 = r4;
-            sN0 = fmaf(a0.x, w, sN0); sN1 = fmaf(a0.y, w, sN1); sN2 = fmaf(a0.z, w, sN2);
-            sC0 = fmaf(a0.w, w, sC0); sC1 = fmaf(a1.x, w, sC1); sC2 = fmaf(a1.y, w, sC2);
-            if (S_MAX > 0 && __builtin_amdgcn_ballot_w64(bl) != 0ull) {
-                const float* fsrc = features + (size_t)gid * S;
-#pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) sF[ch] = fmaf(fsrc[ch], w, sF[ch]);
-            }
-            if (bm != 0ull) xlast = (uint32_t)__builtin_amdgcn_readlane(e, 63 - __builtin_clzll(bm)) + 1u;
-            const uint64_t medm = __builtin_amdgcn_ballot_w64(bl & (Tb > 0.5f));          // forward.cu:417-420
-            if (medm != 0ull) {
-                const int jm = 63 - __builtin_clzll(medm);
-                xmedc = (uint32_t)__builtin_amdgcn_readlane(e, jm) + 1u;
-                xmed = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.depth), jm));
-            }
-            // flags for the backward: bit 0 = blended by some pixel, bit 1 = the FAST evaluation of this pair cannot be sure of the hit
-            // (the main kernel flagged the entries it walked; this pixel may go further than its wave did).  Bits are only ever set here.
-            if (valid) {
-                Hit hf;
-                bool amb;
-                const bool mh = mrgs_intersect(sg, qx, qy, hf);
-                (void)mrgs_hit_decide(hf, mh, amb);
-                const bool in_reach = tm == 0ull || lane <= __builtin_ctzll(tm);
-                const uint32_t fl = (bl ? 1u : 0u) | ((amb && in_reach) ? 3u : 0u);
-                // (the four quadrant bytes of a list entry are one aligned word; marked pixels of one block may meet on a byte)
-                if (fl) atomicOr(reinterpret_cast<uint32_t*>(cflag) + range.x + e, fl << (8 * quad));
-            }
-            ended = tm != 0ull;
-            qh += n;
-            nq -= n;
-        }
-        auto wave_sum = [&](float v) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            return v;
-        };
-        sC0 = wave_sum(sC0); sC1 = wave_sum(sC1); sC2 = wave_sum(sC2);
-        sN0 = wave_sum(sN0); sN1 = wave_sum(sN1); sN2 = wave_sum(sN2);
-        sD = wave_sum(sD); sDist = wave_sum(sDist);
-        if (S_MAX > 0) {
-#pragma unroll
-            for (int ch = 0; ch < S_MAX; ch++) sF[ch] = wave_sum(sF[ch]);
-        }
-        if (lane == 0) {
-            final_T[pix] = xT;
-            final_T[pix + HW] = xM1;
-            final_T[pix + 2 * HW] = xM2;
-            n_contrib[pix] = xlast;
-            n_contrib[pix + HW] = xmedc;
-            out_color[pix] = fmaf(xT, bg[0], sC0);
-            out_color[pix + HW] = fmaf(xT, bg[1], sC1);
-            out_color[pix + 2 * HW] = fmaf(xT, bg[2], sC2);
-            if (S_MAX > 0) {
-#pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++)
-                    if (ch < S) out_feature[(size_t)ch * HW + pix] = sF[ch];
-            }
-            out_others[pix + 0 * HW] = sD;
-            out_others[pix + 1 * HW] = 1.0f - xT;
-            out_others[pix + 2 * HW] = sN0;
-            out_others[pix + 3 * HW] = sN1;
-            out_others[pix + 4 * HW] = sN2;
-            out_others[pix + 5 * HW] = xmed;
-            out_others[pix + 6 * HW] = sDist;
-        }
-        __builtin_amdgcn_wave_barrier();        // the next pixel's queue starts empty (nq = 0): nothing of this one is read again
+#endif
     }
 }
 
@@ -545,6 +599,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     else if (cfg.S == 24 && fv_ok) LAUNCH(24, true);
     else LAUNCH(24, false);
 #undef LAUNCH
+#if !MRGS_FWD_REDO_INLINE
     // the marked pixels again, exactly (an empty list most of the time: the launch is there for the count it reads on the device)
 #define REDO(SM) hipLaunchKernelGGL((render_fwd_redo_kernel<SM>), dim3(MRGS_REDO_BLOCKS), block, 0, stream, img.ranges, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, \
                                     g.rec, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.redo_list)
@@ -553,4 +608,5 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     else if (cfg.S <= 12) REDO(12);
     else REDO(24);
 #undef REDO
+#endif
 }

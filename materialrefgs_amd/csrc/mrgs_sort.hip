@@ -727,12 +727,12 @@ void mrgs_launch_blend_order(const MrgsImgWs& img, const uint32_t* census, int n
     const unsigned extra = f4 ? (unsigned)((f4 + 8191) / 8192 < 504 ? (f4 + 8191) / 8192 : 504) : 0u;
     if (backward)
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_work, ntiles, img.order_items, img.order_work,
-                           img.bwd_assign, img.blend_state + MRGS_QS_BWD, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr,
+                           img.bwd_assign, img.q_bwd, census, img.blend_state + MRGS_CS_BASE, 0, (uint32_t*)nullptr,
                            (float4*)bulk_zero, f4, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(blend_order_kernel, dim3(8 + extra), dim3(1024), 0, stream, img.item_est, ntiles, img.order_items, img.order_work,
                            img.fwd_assign, img.blend_state + MRGS_QS_FWD, census, img.blend_state + MRGS_CS_BASE, 1, img.item_work,
-                           (float4*)bulk_zero, f4, fwd_hint, bulk_zero ? img.blend_state + MRGS_QS_BWD : (uint32_t*)nullptr, img.redo_list);
+                           (float4*)bulk_zero, f4, fwd_hint, bulk_zero ? img.q_bwd : (uint32_t*)nullptr, img.redo_list);
 }
 
 void mrgs_launch_tile_ranges(const uint32_t* tile_key, const uint32_t* plist, int64_t R, const uint32_t* R_dev, const float4* rec,

@@ -219,6 +219,12 @@ def test_forward_on_a_capacity_guess_matches_the_two_phase_forward(gpu_device):
             assert rel_err(r[5][k], ref[5][k]) <= 1e-5, k
 
 
+def raster_settings_of(render):
+    """Fresh camera tensors with the values of an earlier render's settings (a new camera as far as the hint cache is concerned)."""
+    rs = render.rs
+    return rs._replace(viewmatrix=rs.viewmatrix.clone(), projmatrix=rs.projmatrix.clone())
+
+
 def test_work_hints_only_change_the_schedule(gpu_device):
     """MrgsRasterInputs::work_hint (per-camera work of the previous visit) reorders the blend waves and nothing else: first visit
     (hint all zero), second visit (hint from the first) and a visit with a deliberately wrong hint give identical images."""
@@ -234,7 +240,8 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     assert int(hint.sum()) > 0 and visits[0] == 1                              # the forward stored its measured work
     b = HipRender(scene, cam, gpu_device, rs=a.rs)          # same camera tensors: ordered by the measured work, backward prepared
     assert len(rz._WORK_HINTS) == 1 and visits[0] == 2 and b.fn.prepared_grad_ws is not None and a.fn.prepared_grad_ws is None
-    hint.copy_(torch.randint(1, 4000, hint.shape, device=hint.device, dtype=torch.int32))
+    n_work = 4 * ((W + 15) // 16) * ((H + 15) // 16)      # the per-(tile, quadrant) work; the dealt queues of the camera lie behind it
+    hint[:n_work].copy_(torch.randint(1, 4000, (n_work,), device=hint.device, dtype=torch.int32))
     c = HipRender(scene, cam, gpu_device, rs=a.rs)          # garbage hint: still only a schedule
     # a camera whose matrices were written in place is a new camera: its old hint is not used
     a.rs.viewmatrix.add_(0.0)
@@ -245,6 +252,21 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     for r in (b, c, d):
         assert r.num_rendered == a.num_rendered
         assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others) and torch.equal(r.feature, a.feature)
+    # from its third visit on a camera's forward deals its waves as its last ordering did (MRGS_HINT_REUSE_ORDER: no ordering launch,
+    # the tile sort resets the queues and clears the prepared backward's gradient rows): same images, same gradients
+    g = upstream_grads(S, H, W)
+    ref = a.backward(*g)
+    rz.reset_work_hints()
+    rs = raster_settings_of(a)
+    runs = [HipRender(scene, cam, gpu_device, rs=rs) for _ in range(5)]
+    assert rz._hint_flags(rs, gpu_device) == rz._lib.MRGS_HINT_REUSE_ORDER
+    for k, r in enumerate(runs):
+        assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others), k
+        assert (r.fn.prepared_grad_ws is not None) == (k >= 1), k
+    for r in (runs[2], runs[4]):
+        got = r.backward(*g)
+        for name in ref:
+            assert rel_err(got[name], ref[name]) <= 1e-5, name
 
 
 def test_backward_in_two_halves_hands_out_the_colour_factor(gpu_device):
