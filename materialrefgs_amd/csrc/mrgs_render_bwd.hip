@@ -328,8 +328,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             // The forward took this pair's decision exactly (mrgs_blend_math.h "Exact decisions") and flagged the entries where the
             // fast values could not tell for some pixel of the block (bit 1 of the entry's flag byte, ~1e-6 of the pairs): those are
             // evaluated as the oracle does, by every lane; for all others the fast evaluation IS the exact decision, no band to look at.
-            if (__builtin_expect((exact_mask >> j) & 1ull, 0)) active = mrgs_intersect_exact<true>(sg, px, py, h);
-            else active = mrgs_intersect(sg, px, py, h) & !(h.depth < MRGS_NEAR_LO);
+            active = mrgs_intersect(sg, px, py, h) & !(h.depth < MRGS_NEAR_LO);
+            if (__builtin_expect((exact_mask >> j) & 1ull, 0)) active = mrgs_intersect_exact<true>(sg, px, py, h);     // (falls through otherwise)
             active = active & inside & (contributor < last_contributor);
             const uint64_t amask = __builtin_amdgcn_ballot_w64(active);
             WS_ITER(amask != 0ull);

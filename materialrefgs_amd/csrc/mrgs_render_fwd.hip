@@ -409,22 +409,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             work += 3u;   // an entry some pixel blends costs the backward about four times an entry that only gets tested
             contributed |= 1ull << j;          // (a superset of "blended": a pixel may terminate on it instead; the backward sorts that out)
             uint64_t ambiguous;
-            uint64_t ok = mrgs_hit_decide_mask(h, may_hit, ambiguous);
-            if (__builtin_expect(ambiguous != 0ull, 0)) {
-                // a hit inside its error band (~1e-6 of the pairs): the lanes concerned evaluate the pair again as the oracle does, and
-                // the entry is flagged for the backward, which then does the same for the whole block (flag bit 1)
-                unsure |= 1ull << j;
-                const bool amb_lane = MRGS_LANES(ambiguous);
-                Hit hx;
-                bool hit_x = false;
-                if (amb_lane) hit_x = mrgs_intersect_exact<true>(sg, px, py, hx);
-                ok = (ok & ~ambiguous) | (__builtin_amdgcn_ballot_w64(hit_x) & ambiguous);
-                h.alpha = amb_lane ? hx.alpha : h.alpha;
-                h.depth = amb_lane ? hx.depth : h.depth;
-            }
+            const uint64_t ok = mrgs_hit_decide_mask(h, may_hit, ambiguous);
+            // (an entry whose hit is ambiguous for some pixel: the backward evaluates it with the oracle's arithmetic for the whole
+            // block, flag bit 1.  Resolving it here for the lanes concerned instead of marking their pixels was measured: the exact
+            // evaluation as a cold branch of the entry body costs the loop 5 us, the ~20 more marked pixels 3)
+            if (ambiguous != 0ull) unsure |= 1ull << j;
             const float test_T = T * (1.0f - h.alpha);
-            // a TRANSMITTANCE the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, at the end of the
-            // wave (mrgs_blend_math.h "Exact decisions"; mrgs_redo_pixel)
+            // a decision the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, at the end of the wave
+            // (mrgs_blend_math.h "Exact decisions"; mrgs_redo_pixel).  Three quarters of the marks are transmittance bands.
             // (the two transmittance tests as two comparisons each, against the near and the far edge of the band: between them the
             // pixel is marked, and what the fast path does with a marked pixel does not matter)
             const uint64_t below = MRGS_BALLOT(test_T < MRGS_T_MIN - MRGS_T1_EPS);
@@ -433,7 +425,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 t_high = MRGS_BALLOT(T > 0.5f + MRGS_T2_EPS);
                 t_band = MRGS_BALLOT(T > 0.5f - MRGS_T2_EPS) & ~t_high;
             }
-            redo |= ok & ((MRGS_BALLOT(test_T < MRGS_T_MIN + MRGS_T1_EPS) & ~below) | t_band);
+            // (a T (1 - alpha) inside the band of the 1e-4 test is not looked for here: it does not end the pixel -- `below` is the near
+            // edge of the band --, becomes the pixel's T, and nothing but a terminating entry can follow it: the pixel's FINAL T lies in
+            // the band exactly when some entry's did, and is tested once, after the list)
+            redo |= ambiguous | (ok & t_band);
             done |= ok & below;                               // forward.cu:400-404: the pixel stops BEFORE blending this entry
             const uint64_t upd_mask = ok & ~below;
             const bool upd = MRGS_LANES(upd_mask);
@@ -549,6 +544,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 #ifdef MRGS_FWD_REDO_ALL   // developer build: every pixel goes through the exact path (what the margins are measured against)
     redo = ~0ull;
 #endif
+    redo |= MRGS_BALLOT(T < MRGS_T_MIN + MRGS_T1_EPS);
     redo &= __builtin_amdgcn_ballot_w64(inside);
     if (redo != 0ull) {
         for (int e = cf_end + lane; e < total; e += MRGS_CHUNK) cf[(size_t)e * 4] = 0;
