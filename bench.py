@@ -358,13 +358,30 @@ def main():
     # pair costs two ~6 us bubbles on the stream, which every-launch timing would charge to the throughput figure
     L.mrgs_set_profiling(0 if os.environ.get("MRGS_BENCH_NO_KERNEL_EVENTS") else 3)
     mem0 = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev))
+    wait0 = rasterizer_mod.COUNT_WAIT_SECONDS
     t0 = time.perf_counter()
     step_marks = [] if os.environ.get("MRGS_BENCH_STEP_TIMES") else None     # developer diagnostic: host time per step of the timed region
+    host_prof = None
+    if os.environ.get("MRGS_BENCH_CPROFILE"):        # developer diagnostic: where the host's time per step goes (the figures of this run are then not results)
+        import cProfile
+        host_prof = cProfile.Profile()
+        host_prof.enable()
     for i in range(args.steps):
         step(args.warmup + i)
         if step_marks is not None:
             step_marks.append(time.perf_counter())
-    issued = time.perf_counter() - t0        # the host is done queueing (diagnostic: close to `elapsed` = the step is bound by the host's launches)
+    if host_prof is not None:
+        host_prof.disable()
+        import pstats
+        with open(os.environ["MRGS_BENCH_CPROFILE"], "w") as f_:
+            st_ = pstats.Stats(host_prof, stream=f_)
+            st_.sort_stats("tottime").print_stats(70)
+            st_.sort_stats("cumulative").print_stats(70)
+    issued = time.perf_counter() - t0        # the host is done queueing
+    # ... of which it spent this long blocked on the GPU (every view waits once for its pair count, which the GPU produces after the
+    # previous view's backward): what is left is the host's own work per step, the figure that says whether Python paces the step
+    waited = rasterizer_mod.COUNT_WAIT_SECONDS - wait0
+    host_work = issued - waited
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -529,6 +546,7 @@ def main():
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "timed_region_s": round(elapsed, 4),
         "host_issue_ms_per_step": round(1000.0 * issued / args.steps, 4),
+        "host_wait_ms_per_step": round(1000.0 * waited / args.steps, 4), "host_work_ms_per_step": round(1000.0 * host_work / args.steps, 4),
         "cold_ms_per_step": round(cold_fenced, 4), "warm_ms_per_step_fenced": round(warm_fenced, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "P": P, "H": H, "W": W, "S": S, "sh_degree": 3, "num_rendered": int(state["R"]),
@@ -578,10 +596,10 @@ def main():
                                                                 0.0 if surfel_mode else float(stage_ms.get("preprocess_bwd", 0.0)))
             xmodel = {k: v for k, v in xmodel.items() if not k.startswith("_")}
         out["exchange_model"] = xmodel
-        if issued > 0.9 * elapsed:
-            # the host needed (nearly) the whole timed region to queue the work: the figure is then a host figure, not a GPU one
-            out["host_bound"] = True
-            print(f"bench.py: WARNING host_issue_ms_per_step {1000.0 * issued / args.steps:.4f} > 0.9 x ms_per_step {1000.0 * elapsed / args.steps:.4f}: "
+        out["host_bound"] = bool(host_work > 0.9 * elapsed)
+        if out["host_bound"]:
+            # the host's own work (queueing, not waiting for the GPU) filled (nearly) the whole timed region: the figure is then a host figure
+            print(f"bench.py: WARNING host_work_ms_per_step {1000.0 * host_work / args.steps:.4f} > 0.9 x ms_per_step {1000.0 * elapsed / args.steps:.4f}: "
                   "the step is paced by the host's launches (Python), not by the GPU", file=sys.stderr)
 
         if world > 1:
@@ -597,11 +615,27 @@ def main():
             from oracle import render_oracle
             from oracle import raster_oracle as ro
             import numpy as np
+            import materialrefgs_amd.renderer as renderer_mod
             cam0 = cams[0]
             for t_ in surfel_params:
                 t_.grad = None
             env.build_mips()
-            out_h = render_surfel(cams_dev[0], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
+            # Both rasterizers get the SAME per-gaussian inputs: the product's own fp32 activations / feature rows (captured from inside
+            # render_surfel).  Evaluated in float64 on the CPU they differ from the fp32 kernel's in the last bit, and one ulp of an
+            # opacity moves a handful of the image's 640 000 pixels across the alpha = 1/255 and T = 1e-4 tests -- a comparison of
+            # inputs, not of renderers.  The per-gaussian glue has its own parity tests (tests/test_shading.py, test_reference_render.py).
+            stash, glue = {}, renderer_mod.surfel_features
+            def capturing(pc_, campos_):
+                o = glue(pc_, campos_)
+                for t_ in o:
+                    t_.retain_grad()
+                stash["o"] = o
+                return o
+            renderer_mod.surfel_features = capturing
+            try:
+                out_h = render_surfel(cams_dev[0], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
+            finally:
+                renderer_mod.surfel_features = glue
             keys = ["render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal"]
             torch.autograd.backward([out_h[k] for k in keys], state["g"])
             torch.cuda.synchronize(dev)
@@ -609,23 +643,36 @@ def main():
             names11 = surfel_names[:11]
             pc_o = SurfelModel(*[t_.detach().cpu().double().requires_grad_(True) for t_ in surfel_params[:6]],
                                **{n: t_.detach().cpu().double().requires_grad_(True) for n, t_ in zip(names11[6:], surfel_params[6:11])})
+            inter_names = ["opacities", "scales", "rotations", "features"]
+            inter_o = [t_.detach().cpu().double().requires_grad_(True) for t_ in stash["o"]]
             t = time.perf_counter()
-            out_o = render_oracle.render_surfel_oracle(cam0, pc_o, None, None, pipe, bg_color.cpu(), srgb=False, mips=mips_cpu)
+            out_o = render_oracle.render_surfel_oracle(cam0, pc_o, None, None, pipe, bg_color.cpu(), srgb=False, mips=mips_cpu, raster_inputs=tuple(inter_o))
             torch.autograd.backward([out_o[k] for k in keys], [g_.detach().cpu().double() for g_ in state["g"]])
             cpu_s = time.perf_counter() - t
             out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "views/s", "cores": ro.num_threads(), "kind": "port",
-                                   "sample": f"1 view fwd+bwd of the same workload ({args.workload}, view 0) through oracle/render_oracle.py: torch float64 "
-                                             f"glue + shading, oracle/mrgs_oracle.c rasterizer (OpenMP); environment prefilter excluded ({cpu_s:.1f} s)"}
+                                   "sample": f"1 view fwd+bwd of the same workload ({args.workload}, view 0) through oracle/render_oracle.py: oracle/mrgs_oracle.c "
+                                             f"rasterizer (OpenMP) + torch float64 map post-processing, split-sum shading and compositing; per-gaussian glue "
+                                             f"and environment prefilter excluded ({cpu_s:.1f} s)"}
             errs, maps = {}, {}
-            for n, th, to in zip(names11, surfel_params[:11], pc_o.parameters()):
-                a, b = th.grad.detach().cpu().double().numpy(), to.grad.numpy()
+            pairs = [(n, th.grad, to.grad) for n, th, to in zip(inter_names, stash["o"], inter_o)]
+            pairs += [(n, surfel_params[surfel_names.index(n)].grad, getattr(pc_o, "_" + n).grad) for n in ("features_dc", "features_rest")]
+            for n, gh_, go_ in pairs:
+                a, b = gh_.detach().cpu().double().numpy(), go_.numpy()
                 errs[n] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
             for k in keys + ["specular_map", "diffuse_map", "roughness_map", "base_color_map", "refl_strength_map"]:
                 a, b = out_h[k].detach().cpu().double().numpy(), out_o[k].detach().numpy()
                 maps[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
             out["grad_max_rel_err"] = round(max(errs.values()), 8)
             out["grad_rel_err"] = {k: float(f"{v:.3e}") for k, v in errs.items()}
+            out["grad_rel_err_note"] = ("gradients w.r.t. the rasterizer's per-gaussian inputs (activated opacity / scale / rotation, the 8 material "
+                                        "channels) and the colour SH, through rasterizer + maps + shading + compositing, identical fp32 inputs on both sides")
             out["map_rel_err"] = {k: float(f"{v:.3e}") for k, v in maps.items()}
+            # two maps are ill-conditioned functions of what the rasterizer blends, in the reference's formulas as much as here: rend_dist
+            # (m^2 A + M2 - 2 m M1, forward.cu:412: O(1) terms cancel to a value of order 1e-5; the tests hold it to an ABSOLUTE 5e-6) and
+            # surf_normal (normalised cross product of finite differences of neighbouring surface points, utils/point_utils.py:26-39)
+            out["rend_dist_abs_err"] = float(f"{np.abs(out_h['rend_dist'].detach().cpu().double().numpy() - out_o['rend_dist'].detach().numpy()).max():.3e}")
+            sn_h, sn_o = out_h["surf_normal"].detach().cpu().double().numpy(), out_o["surf_normal"].detach().numpy()
+            out["surf_normal_frac_pixels_over_1e-4"] = float(f"{(np.abs(sn_h - sn_o).max(axis=0) > 1e-4).mean():.3e}")
             out["num_rendered_matches_oracle"] = None
         elif not args.no_cpu_baseline:
             from oracle import raster_oracle as ro
@@ -711,7 +758,7 @@ def main():
                     if line.startswith("{"):
                         j = json.loads(line)
                         d = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                             "host_issue_ms_per_step": j.get("host_issue_ms_per_step"),
+                             "host_issue_ms_per_step": j.get("host_issue_ms_per_step"), "host_work_ms_per_step": j.get("host_work_ms_per_step"),
                              "cold_ms_per_step": j.get("cold_ms_per_step"), "warm_ms_per_step_fenced": j.get("warm_ms_per_step_fenced"),
                              "steps": j["steps"], "warmup": j["warmup"], "num_rendered": j["config"]["num_rendered"], "stage_ms": j["stage_ms"],
                              "exchange_model": j.get("exchange_model"),

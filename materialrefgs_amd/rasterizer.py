@@ -10,6 +10,7 @@ pybind `_C` module; there is no CPU or PyTorch fallback.
 import ctypes
 import functools
 import threading
+import time
 from typing import NamedTuple
 
 import torch
@@ -124,6 +125,7 @@ def set_after_blend_hook(fn):
 
 
 LAST_NUM_RENDERED = 0   # diagnostics: num_rendered of the most recent forward (bench.py reads it for the roofline figure)
+COUNT_WAIT_SECONDS = 0.0   # diagnostics: host time spent waiting (on the GPU) for pair counts; bench.py takes it out of its host-issue figure
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -216,10 +218,12 @@ class _PendingCount:
         self.value, self.overflow, self.ctx = None, False, None
 
     def finish(self):
-        global LAST_NUM_RENDERED
+        global LAST_NUM_RENDERED, COUNT_WAIT_SECONDS
         if self.value is None:
             R = ctypes.c_int64(0)
+            t0 = time.perf_counter()
             rc = _lib.lib().mrgs_rasterize_forward_finish(ctypes.byref(self.ticket), ctypes.byref(R))
+            COUNT_WAIT_SECONDS += time.perf_counter() - t0
             if rc != _lib.MRGS_E_WORKSPACE:
                 _lib.check(rc)
             self.value, self.overflow = int(R.value), rc == _lib.MRGS_E_WORKSPACE

@@ -91,7 +91,7 @@ def sample_camera_rays_unnormalize(H, W, K, R, T):
 
 
 def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=False, indirect=False, mesh=None, variant="fused",
-                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None, mips=None, flag="2dgs"):
+                         min_roughness=0.08, max_roughness=0.5, lut=None, visibility_bits=None, mips=None, flag="2dgs", raster_inputs=None):
     """`pc`: a SurfelModel on the CPU (float64 leaves recommended); `env_base`: [6,N,N,3] pre-sigmoid texels (leaf);
     `mesh`: (vertices, triangles) for opt.indirect.  Returns the reference's dictionary (CPU tensors, autograd attached).
     `visibility_bits` [H,W]: use these bits instead of the own trace in the blend (the trace result is still returned under
@@ -99,13 +99,19 @@ def render_surfel_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
     ray set-up, and a test that wants to compare GRADIENTS first checks the two bit maps against each other and then removes
     that source of difference.
     `mips`: prefiltered specular levels to shade with instead of building them from `env_base` (bench.py's CPU leg at 128^2 texels, where
-    the dense float64 operators of envfilter_oracle -- (6 N^2)^2 entries -- do not fit; the environment then receives no gradient)."""
+    the dense float64 operators of envfilter_oracle -- (6 N^2)^2 entries -- do not fit; the environment then receives no gradient).
+    `raster_inputs` = (opacities, scales, rotations, features): use THESE per-gaussian tensors instead of evaluating the glue of :338-355
+    (bench.py hands over the product's own fp32 activations, so that both rasterizers see identical inputs: activations evaluated in
+    float64 here and in fp32 there differ in the last bit, which moves a handful of threshold pixels of a 640 000-pixel image)."""
     from materialrefgs_amd.shading import load_fg_lut
     dt = pc._xyz.dtype
     H, W = cam.image_height, cam.image_width
     lut = load_fg_lut("cpu") if lut is None else lut
     means2D = torch.zeros_like(pc._xyz, requires_grad=True)                                           # :229-233
-    opacities, scales, rotations, features = go.surfel_features_reference(pc, cam.camera_center.to(dt))   # :338-355
+    if raster_inputs is not None:
+        opacities, scales, rotations, features = raster_inputs
+    else:
+        opacities, scales, rotations, features = go.surfel_features_reference(pc, cam.camera_center.to(dt))   # :338-355
     shs = pc.get_features
     if flag != "2dgs":            # "pgsr": + the plane distance as the last channel (:352-357)
         features = torch.cat((features, go.get_distance(pc, cam)), dim=-1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/scratch_pmc.sh <outdir-name> <workload> "<counters pass1>" ["<counters pass2>" ...]
+# usage: tools/pmc_pass.sh <outdir-name> <workload> "<counters pass1>" ["<counters pass2>" ...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1; W=$2; shift 2
 mkdir -p $O
@@ -11,4 +11,12 @@ for C in "$@"; do
 done
 cd $R
 python tools/pmc_kernels.py $O/pmc_$W.json $(find $O -name "*counter_collection.csv") --min-calls 4
+# the FETCH_SIZE / WRITE_SIZE passes (if among the sets) -> profiles/pmc_traffic.json entry of this workload (bench.py's roofline.traffic)
+i=0; FP=; WP=
+for C in "$@"; do
+  i=$((i+1))
+  [ "$C" = "FETCH_SIZE" ] && FP=$(find $O/pass$i -name "*counter_collection.csv" | head -1)
+  [ "$C" = "WRITE_SIZE" ] && WP=$(find $O/pass$i -name "*counter_collection.csv" | head -1)
+done
+[ -n "$FP" ] && [ -n "$WP" ] && python tools/pmc_traffic.py $W $FP $WP > $O/pmc_traffic_$W.log 2>&1
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete

@@ -38,6 +38,7 @@ for W in C3full C3trace C4trace; do
      "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS_ATOMIC GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_$W.log 2>&1
   cp $O/pmc_$W/pmc_$W.json $O/${TAG}_pmc_$W.json
 done
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
 timeout 1500 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --workload C2 --steps 1500 --no-secondary > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
 if [ "$FULL" = "full" ]; then
