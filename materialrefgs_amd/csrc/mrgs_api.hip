@@ -590,6 +590,10 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
     case 10: HIP_TRY(hipMemcpyAsync(dst, img.n_contrib, sizeof(uint32_t) * 2 * hw, hipMemcpyDeviceToDevice, stream)); break;
     case 11: HIP_TRY(hipMemcpyAsync(dst, g.order[sorted_buf(32)], sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, stream)); break;
     case 12: HIP_TRY(hipMemcpyAsync(dst, img.redo_list, sizeof(uint32_t) * (2 + hw), hipMemcpyDeviceToDevice, stream)); break;   // [0] count, [2..] marked pixels
+    case 13: {      // the quadrant masks of the tile lists (one byte per list entry: which 8x8 blocks of its tile the surfel's box touches)
+        MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
+        if (R > 0) HIP_TRY(hipMemcpyAsync(dst, b.qmask, sizeof(uint8_t) * R, hipMemcpyDeviceToDevice, stream));
+    } break;
     default: return MRGS_E_BAD_ARG;
     }
     HIP_TRY(hipGetLastError());

@@ -17,7 +17,8 @@ EXPORT = {"depths": (0, torch.float32, lambda P, R, T, H, W: (P,)),
           "final_T": (9, torch.float32, lambda P, R, T, H, W: (3, H, W)),
           "n_contrib": (10, torch.int32, lambda P, R, T, H, W: (2, H, W)),
           "order": (11, torch.int32, lambda P, R, T, H, W: (P,)),
-          "redo_list": (12, torch.int32, lambda P, R, T, H, W: (2 + H * W,))}
+          "redo_list": (12, torch.int32, lambda P, R, T, H, W: (2 + H * W,)),
+          "qmask": (13, torch.uint8, lambda P, R, T, H, W: (R,))}
 
 
 def raster_settings(cam, device, sh_degree=3, scale_modifier=1.0, bg=None, debug=False):
@@ -75,7 +76,7 @@ class HipRender:
         R = self.num_rendered
         pairs = self.fn.binning_pairs      # what the binning workspace is carved for (>= R when the forward ran on a guess)
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        shape = shp(self.P, pairs if name == "point_list" else R, T, self.H, self.W)
+        shape = shp(self.P, pairs if name in ("point_list", "qmask") else R, T, self.H, self.W)
         out = torch.zeros(shape, dtype=dtype, device=self.dev)
         cfg = MrgsRasterConfig(self.P, self.S, 0, 0, self.H, self.W, 0.0, 0.0, 1.0, 0, 0)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t.numel() else None
@@ -84,7 +85,7 @@ class HipRender:
                                                     ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
         torch.cuda.synchronize(self.dev)
         out = out.cpu().numpy()
-        return out[:R] if name == "point_list" else out
+        return out[:R] if name in ("point_list", "qmask") else out
 
     def backward(self, g_color, g_feat, g_others):
         outs, grads = [self.color, self.others], [g_color.to(self.dev), g_others.to(self.dev)]
