@@ -249,6 +249,40 @@ def lib():
 MRGS_E_WORKSPACE = 5
 
 
+# ---- launch plumbing (host time per call matters: a full render is ~30 native calls a view) -----------------------------------------
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+_current_device = torch._C._cuda_getDevice                 # int
+_raw_stream = torch._C._cuda_getCurrentRawStream           # (device index) -> the hipStream_t of torch's current stream, as an int
+
+
+def guard(dev):
+    """`with guard(dev):` -- torch.cuda.device(dev) only when `dev` is not already the current device (the usual case: one process, one
+    GPU), otherwise nothing: the device context costs ~4 us a time, a view enters it ~25 times."""
+    idx = dev.index
+    return _NO_GUARD if (idx is None or idx == _current_device()) else torch.cuda.device(dev)
+
+
+def stream_ptr(dev):
+    """torch's current stream on `dev` as the integer handle the C ABI's `void* stream` arguments take (ctypes converts)."""
+    idx = dev.index
+    return _raw_stream(_current_device() if idx is None else idx)
+
+
+def f32c(t):
+    """detached float32 contiguous view of `t` (itself when it already is one: the common case costs two attribute reads)."""
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
+    return t.detach().to(torch.float32).contiguous()
+
+
 def check(rc):
     if rc != 0:
         L = lib()

@@ -117,31 +117,66 @@ __global__ void __launch_bounds__(256) surfel_maps_fwd_kernel(MapsFrameDev f, co
     }
 }
 
-// gradient of the loss w.r.t. the finite-difference operands of the normal at interior pixel (cx, cy)
-__device__ __forceinline__ void fd_normal_bwd(const MapsFrameDev& f, const float* __restrict__ allmap, const float* __restrict__ g_sn, int HW,
-                                              int cx, int cy, float (&g_dx)[3], float (&g_dy)[3])
-{
-    const int c = cy * f.W + cx;
-    const FdNormal r = fd_normal(f, allmap, HW, cx, cy);
-    const float a = allmap[HW + c];
-    const float g_nn[3] = {g_sn[c] * a, g_sn[HW + c] * a, g_sn[2 * HW + c] * a};
-    const float dot = r.nn[0] * g_nn[0] + r.nn[1] * g_nn[1] + r.nn[2] * g_nn[2];
-    float g_n[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) g_n[i] = (g_nn[i] - r.nn[i] * dot) / r.len;
-    cross3(r.dy, g_n, g_dx);      // n = dx x dy
-    cross3(g_n, r.dx, g_dy);
-}
-
+// One 32x8 tile of pixels per workgroup.  A pixel's surf_depth feeds the finite-difference normals of its four neighbours, and each of
+// those needs four surface points: evaluated per pixel that is 16 points (a division with its nan_to_num each) and four normalised cross
+// products, of which neighbouring pixels repeat 15 / 3.  Here the tile computes every point once (tile + 2 pixels of halo, LDS), then
+// every centre's (g_dx, g_dy) once (tile + 1 pixel of halo, LDS; zero where the centre is no interior pixel: adding zero is exact, so the
+// sums below equal the per-pixel evaluation's term by term), then a pixel adds up its four neighbours' terms in the order it always did.
+constexpr int MB_TX = 32, MB_TY = 8;
+constexpr int MB_PW = MB_TX + 4, MB_PH = MB_TY + 4, MB_CW = MB_TX + 2, MB_CH = MB_TY + 2;
 __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, const float* __restrict__ g_rn,
                                                               const float* __restrict__ g_sd, const float* __restrict__ g_sn,
                                                               const float* __restrict__ g_nm, const float* __restrict__ g_alpha,
                                                               const float* __restrict__ g_dist, float* __restrict__ g_allmap)
 {
+    __shared__ float s_pt[3][MB_PH * MB_PW];
+    __shared__ float s_g[6][MB_CH * MB_CW];
     const int HW = f.H * f.W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
-    const int y = pix / f.W, x = pix - y * f.W;
+    const int x0 = blockIdx.x * MB_TX, y0 = blockIdx.y * MB_TY;
+    const int tid = threadIdx.x;
+    if (g_sn != nullptr) {
+        for (int i = tid; i < MB_PH * MB_PW; i += 256) {
+            const int px = x0 - 2 + i % MB_PW, py = y0 - 2 + i / MB_PW;
+            float p[3] = {0.0f, 0.0f, 0.0f};
+            if (px >= 0 && px < f.W && py >= 0 && py < f.H) point_at(f, allmap, HW, px, py, p);
+            s_pt[0][i] = p[0]; s_pt[1][i] = p[1]; s_pt[2][i] = p[2];
+        }
+        __syncthreads();
+        for (int i = tid; i < MB_CH * MB_CW; i += 256) {
+            const int lx = i % MB_CW, ly = i / MB_CW;
+            const int cx = x0 - 1 + lx, cy = y0 - 1 + ly;
+            float gdx[3] = {0.0f, 0.0f, 0.0f}, gdy[3] = {0.0f, 0.0f, 0.0f};
+            if (cx >= 1 && cx < f.W - 1 && cy >= 1 && cy < f.H - 1) {
+                const int c = cy * f.W + cx;
+                const int q = (ly + 1) * MB_PW + (lx + 1);              // the centre in the point tile
+                FdNormal r;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    r.dx[k] = s_pt[k][q + MB_PW] - s_pt[k][q - MB_PW];  // rows difference (fd_normal)
+                    r.dy[k] = s_pt[k][q + 1] - s_pt[k][q - 1];
+                }
+                cross3(r.dx, r.dy, r.n);
+                r.len = fmaxf(sqrtf(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2]), 1e-12f);
+#pragma unroll
+                for (int k = 0; k < 3; k++) r.nn[k] = r.n[k] / r.len;
+                const float a = allmap[HW + c];
+                const float g_nn[3] = {g_sn[c] * a, g_sn[HW + c] * a, g_sn[2 * HW + c] * a};
+                const float dot = r.nn[0] * g_nn[0] + r.nn[1] * g_nn[1] + r.nn[2] * g_nn[2];
+                float g_n[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) g_n[k] = (g_nn[k] - r.nn[k] * dot) / r.len;
+                cross3(r.dy, g_n, gdx);      // n = dx x dy
+                cross3(g_n, r.dx, gdy);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s_g[k][i] = gdx[k]; s_g[3 + k][i] = gdy[k]; }
+        }
+        __syncthreads();
+    }
+    const int lx = tid % MB_TX, ly = tid / MB_TX;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= f.W || y >= f.H) return;
+    const int pix = y * f.W + x;
     const float a = allmap[HW + pix];
     const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
     float g_nw[3] = {0.0f, 0.0f, 0.0f};
@@ -168,30 +203,16 @@ __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, co
     // surf_depth: own upstream gradient + the finite-difference normals of the four neighbours this pixel's point feeds
     float g_depth = g_sd != nullptr ? g_sd[pix] : 0.0f;
     if (g_sn != nullptr) {
+        const int c = (ly + 1) * MB_CW + (lx + 1);                  // this pixel in the centre tile
         float gp[3] = {0.0f, 0.0f, 0.0f};
-        float gdx[3], gdy[3];
-        const bool xin = x >= 1 && x < f.W - 1;
-        if (xin && y - 1 >= 1 && y - 1 < f.H - 1) {            // c = p - e_y: p is c's "row below" point (+dx)
-            fd_normal_bwd(f, allmap, g_sn, HW, x, y - 1, gdx, gdy);
 #pragma unroll
-            for (int i = 0; i < 3; i++) gp[i] += gdx[i];
-        }
-        if (xin && y + 1 >= 1 && y + 1 < f.H - 1) {            // c = p + e_y: -dx
-            fd_normal_bwd(f, allmap, g_sn, HW, x, y + 1, gdx, gdy);
+        for (int i = 0; i < 3; i++) gp[i] += s_g[i][c - MB_CW];     // c = p - e_y: p is c's "row below" point (+dx)
 #pragma unroll
-            for (int i = 0; i < 3; i++) gp[i] -= gdx[i];
-        }
-        const bool yin = y >= 1 && y < f.H - 1;
-        if (yin && x - 1 >= 1 && x - 1 < f.W - 1) {            // c = p - e_x: +dy
-            fd_normal_bwd(f, allmap, g_sn, HW, x - 1, y, gdx, gdy);
+        for (int i = 0; i < 3; i++) gp[i] -= s_g[i][c + MB_CW];     // c = p + e_y: -dx
 #pragma unroll
-            for (int i = 0; i < 3; i++) gp[i] += gdy[i];
-        }
-        if (yin && x + 1 >= 1 && x + 1 < f.W - 1) {            // c = p + e_x: -dy
-            fd_normal_bwd(f, allmap, g_sn, HW, x + 1, y, gdx, gdy);
+        for (int i = 0; i < 3; i++) gp[i] += s_g[3 + i][c - 1];     // c = p - e_x: +dy
 #pragma unroll
-            for (int i = 0; i < 3; i++) gp[i] -= gdy[i];
-        }
+        for (int i = 0; i < 3; i++) gp[i] -= s_g[3 + i][c + 1];     // c = p + e_x: -dy
         float d[3];
         ray_dir(f, x, y, d);
         g_depth += gp[0] * d[0] + gp[1] * d[1] + gp[2] * d[2];
@@ -367,9 +388,8 @@ int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, cons
                               float* g_allmap, void* stream)
 {
     if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !g_allmap) return MRGS_E_BAD_ARG;
-    const int HW = fr->H * fr->W;
-    hipLaunchKernelGGL(surfel_maps_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, to_dev(fr), allmap, g_rend_normal,
-                       g_surf_depth, g_surf_normal, g_normal_map, g_rend_alpha, g_rend_dist, g_allmap);
+    hipLaunchKernelGGL(surfel_maps_bwd_kernel, dim3((fr->W + MB_TX - 1) / MB_TX, (fr->H + MB_TY - 1) / MB_TY), dim3(256), 0, (hipStream_t)stream,
+                       to_dev(fr), allmap, g_rend_normal, g_surf_depth, g_surf_normal, g_normal_map, g_rend_alpha, g_rend_dist, g_allmap);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

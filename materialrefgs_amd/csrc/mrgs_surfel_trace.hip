@@ -924,7 +924,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         A.norm[3 * r] = N[0]; A.norm[3 * r + 1] = N[1]; A.norm[3 * r + 2] = N[2];
         A.aux[2 * r] = X[0]; A.aux[2 * r + 1] = X[1];
 #ifdef ST_PROFILE
-        blended = prof.nodes; passes = prof.tests; M2 = (float)(wall_clock64() - prof_t0); T = (float)(prof_t0 & 0xFFFFFF);   // 100 MHz ticks
+        blended = prof.nodes; passes = prof.tests; M2 = (float)(wall_clock64() - prof_t0); T = (float)prof.lanes;   // 100 MHz ticks
 #endif
         reinterpret_cast<float4*>(A.state)[r] = make_float4(M2, T, (float)blended, (float)(packet >= 0 ? -passes : passes));   // sign: walked in a packet
     } else {

@@ -26,8 +26,8 @@ class _cubemap_encode(torch.autograd.Function):
         fail_value = fail_value.detach().float().contiguous()
         C, L, B = embeddings.shape[1], embeddings.shape[2], inputs.shape[0]
         outputs = torch.empty([C, B], dtype=torch.float32, device=embeddings.device)
-        with torch.cuda.device(embeddings.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(embeddings.device).cuda_stream)
+        with _lib.guard(embeddings.device):
+            st = _lib.stream_ptr(embeddings.device)
             _lib.check(_lib.lib().mrgs_cubemap_encode_forward(_p(inputs), _p(embeddings), _p(fail_value), _p(outputs), int(interpolation),
                                                               int(enable_seamless), B, C, L, st))
         ctx.save_for_backward(inputs, embeddings)
@@ -42,8 +42,8 @@ class _cubemap_encode(torch.autograd.Function):
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.empty_like(inputs)
         grad_fail = torch.zeros([C], dtype=embeddings.dtype, device=embeddings.device)
-        with torch.cuda.device(embeddings.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(embeddings.device).cuda_stream)
+        with _lib.guard(embeddings.device):
+            st = _lib.stream_ptr(embeddings.device)
             _lib.check(_lib.lib().mrgs_cubemap_encode_backward(_p(grad_outputs), _p(inputs), _p(embeddings), _p(grad_embeddings), _p(grad_inputs),
                                                                _p(grad_fail), ctx.params[0], ctx.params[1], B, C, L, st))
         return grad_inputs, grad_embeddings, grad_fail, None, None

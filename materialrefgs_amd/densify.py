@@ -30,8 +30,8 @@ def compact_rows(tensors: Sequence[torch.Tensor], keep: torch.Tensor) -> Tuple[L
             raise ValueError("compact_rows: tensors must have 4-byte elements, live on the mask's device and share dim 0 with it")
         src.append(t.detach().contiguous())
     lib = _lib.lib()
-    with torch.cuda.device(dev):
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with _lib.guard(dev):
+        st = _lib.stream_ptr(dev)
         ws = torch.empty(lib.mrgs_compact_ws_bytes(n), dtype=torch.uint8, device=dev)
         cnt = torch.empty(1, dtype=torch.int64, device=dev)
         _lib.check(lib.mrgs_compact_count(n, ctypes.c_void_p(k8.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),

@@ -45,12 +45,12 @@ class _FusedLoss(torch.autograd.Function):
         rd = _f32(rend_dist) if use_d else None
         wt = _f32(image_weight) if (use_n and image_weight is not None) else None
         lib = _lib.lib()
-        with torch.cuda.device(image.device):
+        with _lib.guard(image.device):
             ws = torch.empty(lib.mrgs_loss_ws_bytes(H, W, C), dtype=torch.uint8, device=image.device)
             terms = torch.empty(16, dtype=torch.float32, device=image.device)
             loss = torch.empty((), dtype=torch.float32, device=image.device)   # its own tensor: a view of `terms` as a second output
             #                                                                    ties both outputs into a cycle only the GC can free
-            st = ctypes.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)
+            st = _lib.stream_ptr(image.device)
             _lib.check(lib.mrgs_loss_forward(ctypes.byref(cfg), _p(img), _p(g), _p(rn), _p(sn), _p(rd), _p(wt), _p(ws), ws.numel(),
                                              _p(terms), _p(loss), st))
         ctx.cfg = cfg
@@ -74,8 +74,8 @@ class _FusedLoss(torch.autograd.Function):
         g_rn = torch.empty_like(rn) if use_n else None
         g_sn = torch.empty_like(sn) if use_n else None
         g_d = torch.empty((cfg.H, cfg.W), dtype=torch.float32, device=img.device) if use_d else None
-        with torch.cuda.device(img.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(img.device).cuda_stream)
+        with _lib.guard(img.device):
+            st = _lib.stream_ptr(img.device)
             _lib.check(_lib.lib().mrgs_loss_backward(ctypes.byref(cfg), _p(img), _p(g), _p(rn), _p(sn), _p(wt), _p(ws), _p(gl), _p(g_img),
                                                      _p(g_rn), _p(g_sn), _p(g_d), st))
         return (g_img.view(shp_i), None, g_rn.view(shp_rn) if use_n else None, g_sn.view(shp_sn) if use_n else None,

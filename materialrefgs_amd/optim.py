@@ -58,8 +58,8 @@ class Adam(torch.optim.Optimizer):
             arr = (_lib.MrgsAdamTensor * len(items))()
             for i, (p, g, m, v, lr, step) in enumerate(items):
                 arr[i] = _lib.MrgsAdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, step)
-            with torch.cuda.device(dev):
-                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            with _lib.guard(dev):
+                stream = _lib.stream_ptr(dev)
                 _lib.check(lib.mrgs_adam_step(arr, len(items), beta1, beta2, eps, stream))
             del items          # the gradient copies (if any) stay alive until the launch is queued on the same stream
         return loss

@@ -134,7 +134,7 @@ def cpu_deep_copy_tuple(input_tuple):
 
 
 def _ptr(t):
-    return None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else (t.data_ptr() or None)      # (an int, NULL for an empty tensor: ctypes converts it for the `void*` parameters and struct fields)
 
 
 def _f32c(t):
@@ -167,7 +167,7 @@ def _camera_f32c(t):
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return _lib.stream_ptr(device)
 
 
 def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None,
@@ -307,12 +307,12 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
     S_ = features.shape[1] if features.dim() == 2 else 0
     grad_ws = None
     if prepare_backward and means3D.shape[0] > 0:
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             grad_ws = torch.empty((L.mrgs_grad_bytes(means3D.shape[0], S_),), dtype=torch.uint8, device=dev)
     cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
                                 sh_rest, grad_ws)
     P, S = cfg.P, cfg.S
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         st = _stream(dev)
         contrib = _zero_contrib(dev, H, W)   # allocated, never written
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -369,7 +369,7 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
     cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
                                 sh_rest, prepared_grad_ws)
     P, S, M = cfg.P, cfg.S, cfg.M
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         st = _stream(dev)
         opts = dict(dtype=torch.float32, device=dev)
         g = {"dL_dmeans2D": torch.empty((P, 3), **opts), "dL_dcolors": torch.empty((P, 3), **opts),
@@ -511,7 +511,7 @@ class GaussianRasterizer(nn.Module):
             positions = _f32c(positions)
             P = positions.shape[0]
             present = torch.zeros((P,), dtype=torch.uint8, device=positions.device)
-            with torch.cuda.device(positions.device):
+            with _lib.guard(positions.device):
                 _lib.check(_lib.lib().mrgs_mark_visible(P, _ptr(positions), _ptr(_f32c(rs.viewmatrix)), _ptr(_f32c(rs.projmatrix)),
                                                         _ptr(present), _stream(positions.device)))
             visible = present.bool()

@@ -48,8 +48,8 @@ class RayTracer:
         depth = torch.empty(N, dtype=torch.float32, device=rays_o.device)
         ids = torch.empty(N, dtype=torch.int32, device=rays_o.device) if return_faceids else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
-        with torch.cuda.device(rays_o.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(rays_o.device).cuda_stream)
+        with _lib.guard(rays_o.device):
+            st = _lib.stream_ptr(rays_o.device)
             _lib.check(_lib.lib().mrgs_bvh_trace(p(self.blob), self.n_triangles, N, p(rays_o), p(rays_d), p(positions), p(face_normals),
                                                  p(depth), p(ids), st))
         positions, face_normals, depth = positions.view(*prefix, 3), face_normals.view(*prefix, 3), depth.view(*prefix)
@@ -72,8 +72,8 @@ class RayTracer:
         vis = torch.empty((H, W, 1), dtype=torch.float32, device=nm.device)
         m_n = _lib.MrgsStridedMap(nm.data_ptr(), nm.stride(0), nm.stride(1), nm.stride(2))
         m_a = _lib.MrgsStridedMap(al.data_ptr(), al.stride(0), al.stride(1), al.stride(2) if al.dim() > 2 else 0)
-        with torch.cuda.device(nm.device):
-            st = ctypes.c_void_p(torch.cuda.current_stream(nm.device).cuda_stream)
+        with _lib.guard(nm.device):
+            st = _lib.stream_ptr(nm.device)
             _lib.check(_lib.lib().mrgs_bvh_visibility(ctypes.c_void_p(self.blob.data_ptr()), self.n_triangles, H, W, kin,
                                                       ctypes.c_void_p(Rc.data_ptr()), ctypes.c_void_p(Tc.data_ptr()), ctypes.byref(m_n),
                                                       ctypes.byref(m_a), ctypes.c_void_p(sd.data_ptr()), ctypes.c_void_p(vis.data_ptr()), st))

@@ -95,11 +95,10 @@ class SurfelModel:
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()      # (an int: ctypes converts it for the `void*` parameters and struct fields)
 
 
-def _c(t):
-    return t.detach().to(torch.float32).contiguous()
+_c = _lib.f32c
 
 
 class _SurfelFeatures(torch.autograd.Function):
@@ -117,8 +116,8 @@ class _SurfelFeatures(torch.autograd.Function):
         prm = MrgsSurfelParams(P, *[_p(t) for t in ts])
         o = dict(dtype=torch.float32, device=dev)
         op, sc, rot, feat = torch.empty((P, 1), **o), torch.empty((P, 2), **o), torch.empty((P, 4), **o), torch.empty((P, 8), **o)
-        with torch.cuda.device(dev):
-            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _lib.guard(dev):
+            st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_forward(ctypes.byref(prm), _p(op), _p(sc), _p(rot), _p(feat), st))
         ctx.save_for_backward(*ts)
         return op, sc, rot, feat
@@ -132,8 +131,8 @@ class _SurfelFeatures(torch.autograd.Function):
         outs = [torch.empty_like(t) for t in ts[:9]]
         grads = MrgsSurfelGrads(*[_p(t) for t in outs])
         gs = [None if g is None else _c(g) for g in (g_op, g_sc, g_rot, g_feat)]
-        with torch.cuda.device(dev):
-            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _lib.guard(dev):
+            st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads), st))
         return (*outs, None)
 
@@ -198,8 +197,8 @@ class _SurfelMaps(torch.autograd.Function):
         sn = torch.empty((3, H, W), **o) if want_surf_normal else None
         nm = torch.empty((H, W, 3), **o) if want_normal_map else None
         ra_rd = torch.empty((2, 1, H, W), **o)      # the plain slices allmap[1:2] / allmap[6:7] of the reference, written by the same kernel
-        with torch.cuda.device(dev):
-            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _lib.guard(dev):
+            st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), _p(ra_rd[0]), _p(ra_rd[1]), st))
         ctx.save_for_backward(allmap)
         ctx.fr = fr
@@ -213,8 +212,8 @@ class _SurfelMaps(torch.autograd.Function):
         dev = allmap.device
         g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm, g_ra, g_rd)]
         g_allmap = torch.empty_like(allmap)
-        with torch.cuda.device(dev):
-            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _lib.guard(dev):
+            st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(ctx.fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]),
                                                             _p(g_allmap), st))
         return g_allmap, None, None, None
@@ -229,8 +228,8 @@ class _SurfelComposite(torch.autograd.Function):
         base, refl, spec, alpha, bg = _c(base), _c(refl), _c(spec), _c(alpha), _c(bg)
         H, W, dev = base.shape[1], base.shape[2], base.device
         render, diffuse = torch.empty_like(base), torch.empty_like(base)
-        with torch.cuda.device(dev):
-            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _lib.guard(dev):
+            st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_composite_forward(H, W, int(bool(srgb)), _p(base), _p(refl), _p(spec), _p(alpha), _p(bg),
                                                                 _p(render), _p(diffuse), st))
         ctx.save_for_backward(base, refl, spec, bg)
@@ -245,8 +244,8 @@ class _SurfelComposite(torch.autograd.Function):
         g_diffuse = None if g_diffuse is None else _c(g_diffuse)
         g_base, g_spec = torch.empty_like(base), torch.empty_like(spec)
         g_refl, g_alpha = torch.empty_like(refl), torch.empty_like(refl)
-        with torch.cuda.device(dev):
-            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _lib.guard(dev):
+            st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_composite_backward(H, W, ctx.srgb, _p(base), _p(refl), _p(spec), _p(bg), _p(g_render), _p(g_diffuse),
                                                                  _p(g_base), _p(g_refl), _p(g_spec), _p(g_alpha), st))
         return g_base, g_refl, g_spec, g_alpha, None, None
@@ -541,9 +540,9 @@ class _MirrorRays(torch.autograd.Function):
         ray_d = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
         kinv = (ctypes.c_float * 9)(*Kinv)
         m = _lib.MrgsStridedMap(nm.data_ptr(), nm.stride(0), nm.stride(1), nm.stride(2))
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_mirror_rays_forward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(sd), _p(ray_o), _p(ray_d),
-                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                                  _lib.stream_ptr(dev)))
         ctx.save_for_backward(nm, R, T)
         ctx.Kinv, ctx.depth_shape = Kinv, surf_depth.shape
         return ray_o, ray_d
@@ -560,9 +559,9 @@ class _MirrorRays(torch.autograd.Function):
         g_sd = torch.empty(H, W, dtype=torch.float32, device=dev)
         kinv = (ctypes.c_float * 9)(*ctx.Kinv)
         m = _lib.MrgsStridedMap(nm.data_ptr(), nm.stride(0), nm.stride(1), nm.stride(2))
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_mirror_rays_backward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(g_o), _p(g_d), _p(g_n), _p(g_sd),
-                                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                                   _lib.stream_ptr(dev)))
         return g_n, g_sd.reshape(ctx.depth_shape), None, None, None
 
 
@@ -594,9 +593,9 @@ class _MirrorRaysBlended(torch.autograd.Function):
         ray_d = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
         kinv = (ctypes.c_float * 9)(*Kinv)
         m = _lib.MrgsStridedMap(rn.data_ptr(), rn.stride(1), rn.stride(2), rn.stride(0))        # [3,H,W] read as [H,W,3]
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_mirror_rays_blended_forward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(al), _p(sd), _p(ray_o), _p(ray_d),
-                                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                                          _lib.stream_ptr(dev)))
         ctx.save_for_backward(rn, al, R, T)
         ctx.Kinv, ctx.shapes = Kinv, (rend_alpha.shape, surf_depth.shape)
         return ray_o, ray_d
@@ -614,9 +613,9 @@ class _MirrorRaysBlended(torch.autograd.Function):
         g_sd = torch.empty(H, W, dtype=torch.float32, device=dev)
         kinv = (ctypes.c_float * 9)(*ctx.Kinv)
         m = _lib.MrgsStridedMap(rn.data_ptr(), rn.stride(1), rn.stride(2), rn.stride(0))
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_mirror_rays_blended_backward(H, W, kinv, _p(R), _p(T), ctypes.byref(m), _p(al), _p(g_o), _p(g_d), _p(g_n), _p(g_al),
-                                                           _p(g_sd), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                                           _p(g_sd), _lib.stream_ptr(dev)))
         return g_n.permute(2, 0, 1), g_al.reshape(ctx.shapes[0]), g_sd.reshape(ctx.shapes[1]), None, None, None
 
 
@@ -657,9 +656,9 @@ class _TracedBlend(torch.autograd.Function):
         if not (b.stride(1) == W * b.stride(2) and s.stride(1) == W * s.stride(2)):       # rows must follow each other: one pixel stride
             b, s = b.contiguous(), s.contiguous()
         out = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with _lib.guard(a.device):
             _lib.check(_lib.lib().mrgs_traced_blend_forward(H, W, _p(a), _p(b), b.stride(0), b.stride(2), _p(s), s.stride(2), _p(out),
-                                                            ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+                                                            _lib.stream_ptr(a.device)))
         ctx.save_for_backward(a, b, s)
         return out
 
@@ -671,9 +670,9 @@ class _TracedBlend(torch.autograd.Function):
         ga = torch.empty_like(a)
         gb = torch.empty_strided(b.shape, b.stride(), dtype=torch.float32, device=a.device)      # g_b in b's own layout
         gs = torch.empty((1, H, W), dtype=torch.float32, device=a.device)
-        with torch.cuda.device(a.device):
+        with _lib.guard(a.device):
             _lib.check(_lib.lib().mrgs_traced_blend_backward(H, W, _p(a), _p(b), b.stride(0), b.stride(2), _p(s), s.stride(2), _p(g), _p(ga), _p(gb), _p(gs),
-                                                             ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)))
+                                                             _lib.stream_ptr(a.device)))
         return ga, gb, gs
 
 

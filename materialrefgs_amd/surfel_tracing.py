@@ -43,11 +43,11 @@ class SurfelTracingSettings(NamedTuple):
 
 
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()      # (an int: ctypes converts it for the `void*` parameters and struct fields)
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.stream_ptr(dev)
 
 
 def _need_gpu(t, what):
@@ -71,7 +71,7 @@ class _Trace(torch.autograd.Function):
         state_floats = (L.mrgs_surfel_trace_state_floats if record else L.mrgs_surfel_trace_state_floats_norecord)(n_rays, ray_width)
         wet, state = new(P), new(max(int(state_floats), 1))
         bg = (ctypes.c_float * 3)(*bg3)
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_surfel_trace_forward(_ptr(blob), P, n_rays, ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
                                                    _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(dist), _ptr(aux), _ptr(wet), _ptr(state), state.numel(),
                                                    _stream(dev)))
@@ -92,7 +92,7 @@ class _Trace(torch.autograd.Function):
         g_geom, g_attr = torch.empty_like(geom), torch.empty_like(attr)
         g_o, g_d = torch.empty_like(ray_o), torch.empty_like(ray_d)
         bg = (ctypes.c_float * 3)(*ctx.bg3)
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_surfel_trace_backward(_ptr(blob), P, n_rays, ctx.ray_width, _ptr(ray_o), _ptr(ray_d), _ptr(geom), _ptr(attr), bg, _ptr(rgb),
                                                     _ptr(dpt), _ptr(acc), _ptr(norm), _ptr(aux), _ptr(state), state.numel(), _ptr(g_rgb), _ptr(g_dpt),
                                                     _ptr(g_acc), _ptr(g_norm), _ptr(g_dist), _ptr(g_aux), _ptr(g_geom), _ptr(g_attr),
@@ -115,7 +115,7 @@ class _Prep(torch.autograd.Function):
         attr = torch.empty(P, 8, dtype=torch.float32, device=dev)
         quads = torch.empty(4 * P, 3, dtype=torch.float32, device=dev)
         M = 0 if shs is None else shs.shape[1]
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_surfel_trace_prep_forward(P, _ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs), M, int(sh_degree),
                                                         _ptr(colors), _ptr(others), _ptr(campos), float(scale_modifier), _ptr(geom), _ptr(attr),
                                                         _ptr(quads), _stream(dev)))
@@ -138,7 +138,7 @@ class _Prep(torch.autograd.Function):
         g_shs = new(P, M, 3) if shs is not None else None
         g_colors = new(P, 3) if has_colors else None
         g_others = new(P, 2) if has_others else None
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_surfel_trace_prep_backward(P, _ptr(means), _ptr(scales), _ptr(rotations), _ptr(shs), M, degree, _ptr(campos), modifier,
                                                          _ptr(g_geom), _ptr(g_attr), _ptr(g_means), _ptr(g_scales), _ptr(g_rot), _ptr(g_op),
                                                          _ptr(g_shs), _ptr(g_colors), _ptr(g_others), _stream(dev)))
@@ -162,7 +162,7 @@ class _PrepRaw(torch.autograd.Function):
         geom = torch.empty(P, 16, dtype=torch.float32, device=dev)
         attr = torch.empty(P, 8, dtype=torch.float32, device=dev)
         quads = torch.empty(4 * P, 3, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_surfel_trace_prep_raw_forward(P, _ptr(xyz), _ptr(scaling), _ptr(rotation), _ptr(opacity), _ptr(f_dc), _ptr(f_rest),
                                                             int(sh_degree), _ptr(others), _ptr(campos), float(scale_modifier), _ptr(geom), _ptr(attr),
                                                             _ptr(quads), _stream(dev)))
@@ -182,7 +182,7 @@ class _PrepRaw(torch.autograd.Function):
         g_geom, g_attr = z(g_geom, (P, 16)), z(g_attr, (P, 8))
         outs = [torch.empty_like(t) for t in (xyz, scaling, rotation, opacity, f_dc, f_rest)]
         g_others = torch.empty(P, 2, dtype=torch.float32, device=dev) if has_others else None
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             _lib.check(L.mrgs_surfel_trace_prep_raw_backward(P, _ptr(xyz), _ptr(scaling), _ptr(rotation), _ptr(opacity), _ptr(f_dc), _ptr(f_rest), degree,
                                                              _ptr(campos), modifier, _ptr(g_geom), _ptr(g_attr), *[_ptr(t) for t in outs], _ptr(g_others),
                                                              _stream(dev)))
@@ -226,7 +226,7 @@ class SurfelTracer(nn.Module):
         L = _lib.lib()
         dev = vertices.device
         v = vertices.detach().contiguous().float()
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             # A blob that an earlier trace saved for its backward is left to that backward (its lists and its replay record were made for
             # that hierarchy and for the records that trace wrote into it): this build gets a fresh one.
             if self._blob is None or self._n != P or self._blob.device != dev or self._blob_saved:
