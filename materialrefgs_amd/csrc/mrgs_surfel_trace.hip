@@ -26,7 +26,9 @@
 //    and slope in the rays' own frame), a ballot names the children to enter, the nearest first (wave-min of the near depths).  At the
 //    bottom lane c tests surfel c's own square against the beam; the surviving surfels are visited one by one, their record broadcast
 //    from lane c (v_readlane), every lane evaluating the exact hit for ITS ray and inserting into its own sorted 16-entry buffer
-//    (LDS, [slot][lane]).  Blocks that do not run together split into 4x4 quadrants, then 2x2 groups.
+//    (LDS, [slot][lane]).  Blocks that do not run together split into 4x4 quadrants, then 2x2 groups; such a packet spreads the
+//    exact tests over all 64 lanes, 64 / R candidates a step (st_gather_group).  The wave-wide minima / maxima / sums of the walk
+//    (nearest child, far bound, beam) are DPP butterflies, not __shfl_xor (= ds_bpermute) ones.
 //  * ONE RAY, ONE WAVE (st_trace_lone_rays): what is left over walks with the lanes turned sideways -- 64 children, then the 64
 //    surfels of a leaf group, against the one ray -- instead of alone in a lane (a dependent ~1 us gather per step).
 //  * 16-NEAREST PASSES: a ray gathers its 16 nearest not-yet-blended hits, blends them front to back, and continues behind the last
@@ -48,6 +50,9 @@
 
 namespace {
 
+#ifndef ST_GROUP_GATHER
+#define ST_GROUP_GATHER 1                 // packets smaller than the wave test 64 / R candidates per step (st_gather_group); 0: one per step (A/B)
+#endif
 #ifndef ST_FWD_WAVES
 #define ST_FWD_WAVES 4                    // waves per SIMD the forward walking kernels are compiled for (register budget 512 / that)
 #endif
@@ -269,28 +274,34 @@ __device__ __forceinline__ StHit st_hit(const float4 g0, const float4 g1, const 
     return h;
 }
 
-struct StProf { int nodes, tests, lanes; };     // developer counters (-DST_PROFILE writes them into `state`)
+struct StProf { int nodes, tests, lanes; unsigned t_fetch, t_cand; };     // developer counters (-DST_PROFILE writes them into `state`)
 
 // wave-wide reductions; the result is handed back through v_readfirstlane so that the compiler keeps it in a scalar register
 // (after the butterfly every lane holds the same value, which it cannot know: the beam's ~40 numbers would sit in vector registers)
 __device__ __forceinline__ float st_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+// DPP butterflies: xor 1, xor 2 inside the quads, rotations by 4 and 8 inside the 16-lane rows, then lane 15 / lane 31 of the rows before
+// into the rows behind (row_bcast) -- lane 63 ends up with the result of all 64.  Six dependent VALU instructions; the __shfl_xor
+// butterfly these replace goes through ds_bpermute, six dependent ~120-cycle LDS round trips (measured: a packet wave spends 500 of these
+// reductions a view -- nearest child, far bound, beams, packet tests -- i.e. ~40 % of its 470 us in them).  Masked-out rows take `old`.
+#define ST_DPP(OLD, V, CTRL, RM) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(OLD), __float_as_int(V), CTRL, RM, 0xf, false))
+__device__ __forceinline__ float st_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __device__ __forceinline__ float wave_sum_f(float v)
 {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-    return st_uniform(v);
+    v += ST_DPP(0.0f, v, 0xb1, 0xf); v += ST_DPP(0.0f, v, 0x4e, 0xf); v += ST_DPP(0.0f, v, 0x124, 0xf); v += ST_DPP(0.0f, v, 0x128, 0xf);
+    v += ST_DPP(0.0f, v, 0x142, 0xa); v += ST_DPP(0.0f, v, 0x143, 0xc);
+    return st_lane63(v);
 }
 __device__ __forceinline__ float wave_max_f(float v)
 {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return st_uniform(v);
+    v = fmaxf(v, ST_DPP(v, v, 0xb1, 0xf)); v = fmaxf(v, ST_DPP(v, v, 0x4e, 0xf)); v = fmaxf(v, ST_DPP(v, v, 0x124, 0xf)); v = fmaxf(v, ST_DPP(v, v, 0x128, 0xf));
+    v = fmaxf(v, ST_DPP(v, v, 0x142, 0xa)); v = fmaxf(v, ST_DPP(v, v, 0x143, 0xc));
+    return st_lane63(v);
 }
 __device__ __forceinline__ float wave_min_f(float v)
 {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fminf(v, __shfl_xor(v, s));
-    return st_uniform(v);
+    v = fminf(v, ST_DPP(v, v, 0xb1, 0xf)); v = fminf(v, ST_DPP(v, v, 0x4e, 0xf)); v = fminf(v, ST_DPP(v, v, 0x124, 0xf)); v = fminf(v, ST_DPP(v, v, 0x128, 0xf));
+    v = fminf(v, ST_DPP(v, v, 0x142, 0xa)); v = fminf(v, ST_DPP(v, v, 0x143, 0xc));
+    return st_lane63(v);
 }
 
 // ---- the wave-wide hierarchy -------------------------------------------------------------------------------------------------
@@ -538,6 +549,164 @@ __device__ __forceinline__ int st_gather_wide(const StWide& W, const float* __re
     return n;
 }
 
+// The same walk for a packet SMALLER than the wave -- a 4x4 quadrant (R = 16 rays) or a 2x2 group (R = 4) --, with the exact tests at
+// the bottom spread over all 64 lanes: lane l = g R + i tests the g-th surviving surfel of the leaf group against ray i of the packet, so
+// one step evaluates 64 / R candidates (measured on the mirror rays of a rendered view, 95 % of whose waves are such packets: a candidate
+// hits 6 of a packet's ~20 rays, i.e. in st_gather_wide's layout two lanes in three idled through every hit evaluation, and a candidate
+// cost the wave 1.5 us).  The surfel's record crosses from the lane that loaded it by ds_bpermute, the ray's data from the lane that
+// owns it (once per walk).  Hits go into the owning lane's LDS column as before; lanes that hit for the SAME ray take turns, ordered by
+// their rank among them (per-ray ranks from one ballot), so a step costs as many insertion rounds as its busiest ray has hits.  The
+// buffers end up holding the same 16 nearest (t, id) keys in the same order whatever the order of insertion: outputs and the record are
+// those of the one-candidate-a-step walk bit for bit.  kb_n: entries in every column (the owners' `n` of st_gather_wide, shared here).
+__device__ __forceinline__ int st_gather_group(const StWide& W, const float* __restrict__ boxes, const unsigned long long* __restrict__ vmask,
+                                               const float4* __restrict__ leaf, uint32_t (*kb_id)[ST_THREADS], float (*kb_t)[ST_THREADS],
+                                               uint32_t* kb_n, int tid, int pk, bool tiled, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               float prev_t, uint32_t prev_id, bool first_pass, bool on, StProf& prof)
+{
+    if (__ballot(on) == 0) return 0;
+    const int lane = tid & 63, wbase = tid & ~63;
+    float s0, dm;
+    const StBeam B = st_make_beam(on, ox, oy, oz, dx, dy, dz, s0, dm);
+    const float s_prev = wave_min_f(on ? s0 + prev_t * dm : INFINITY);
+    float s_far = INFINITY;
+    // the gather layout: lane = grp * R + i; `own` = the lane that owns ray i of packet pk (st_assign_packets' numbering)
+    const bool quad_pk = pk <= 4;
+    const int shift = quad_pk ? 4 : 2, G = 64 >> shift;
+    const int grp = lane >> shift, i = lane & ((1 << shift) - 1);
+    int own;
+    if (quad_pk) {
+        const int q = pk - 1;
+        own = tiled ? 8 * (4 * (q >> 1) + (i >> 2)) + 4 * (q & 1) + (i & 3) : 16 * q + i;
+    } else {
+        const int q = (pk - 5) >> 2, g2 = (pk - 5) & 3;
+        own = tiled ? 8 * (4 * (q >> 1) + 2 * (g2 >> 1) + (i >> 1)) + 4 * (q & 1) + 2 * (g2 & 1) + (i & 1) : 16 * q + 4 * g2 + i;
+    }
+    auto from = [](int src_lane, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v))); };
+    const float rox = from(own, ox), roy = from(own, oy), roz = from(own, oz), rdx = from(own, dx), rdy = from(own, dy), rdz = from(own, dz);
+    const float rprev_t = from(own, prev_t);
+    const uint32_t rprev_id = (uint32_t)__builtin_amdgcn_ds_bpermute(own << 2, (int)prev_id);
+    const bool ron = __builtin_amdgcn_ds_bpermute(own << 2, (int)on) != 0;
+    const int col = wbase + own;
+    const unsigned long long sib = (quad_pk ? 0x0001000100010001ull : 0x1111111111111111ull) << i;      // the lanes that share my ray
+    const unsigned long long below = (1ull << lane) - 1ull;
+    kb_n[tid] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned long long mask[SW_MAX_LEVELS] = {0, 0, 0, 0};
+    int node[SW_MAX_LEVELS] = {0, 0, 0, 0};
+    float near1 = 0.f, near2 = 0.f, near3 = 0.f;
+    float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0, rec3 = rec0;
+    int l = W.n - 1;
+    bool fresh = true;
+    for (;;) {
+        if (fresh) {
+#ifdef ST_PROFILE
+            const unsigned long long tf0 = wall_clock64();
+#endif
+            ++prof.nodes;
+            const int nd = __builtin_amdgcn_readfirstlane(W.off[l] + node[l]);
+            bool h;
+            if (l == 0) {
+                const float4* g = leaf + ((size_t)node[0] * 64 + lane) * 4;
+                rec0 = g[0]; rec1 = g[1]; rec2 = g[2]; rec3 = g[3];
+                h = st_beam_surfel(B, rec0, rec1, rec2, rec3.x, s_prev, s_far);
+            } else {
+                const float* bx = boxes + (size_t)nd * 384 + lane;
+                const float lo[3] = {bx[0], bx[64], bx[128]}, hi[3] = {bx[192], bx[256], bx[320]};
+                float nd_depth;
+                h = st_beam_box(B, lo, hi, s_prev, s_far, nd_depth);
+                if (l == 1) near1 = nd_depth; else if (l == 2) near2 = nd_depth; else near3 = nd_depth;
+            }
+            mask[l] = __ballot(h) & vmask[nd];
+            fresh = false;
+#ifdef ST_PROFILE
+            prof.t_fetch += (unsigned)(wall_clock64() - tf0);
+#endif
+        }
+        if (mask[l] == 0) {
+            if (l == W.n - 1) break;
+            ++l;
+            continue;
+        }
+        if (l > 0) {                                                          // nearest remaining child first
+            const float mine = l == 1 ? near1 : l == 2 ? near2 : near3;
+            const float key = ((mask[l] >> lane) & 1ull) ? mine : INFINITY;
+            const float nearest = wave_min_f(key);
+            if (nearest > s_far) { mask[l] = 0; continue; }
+            const int c = __builtin_ctzll(__ballot(key == nearest));
+            mask[l] &= ~(1ull << c);
+            node[l - 1] = node[l] * 64 + c;
+            --l;
+            fresh = true;
+            continue;
+        }
+        unsigned long long m = mask[0];
+        mask[0] = 0;
+#ifdef ST_PROFILE
+        const unsigned long long tc0 = wall_clock64();
+#endif
+        while (m) {
+            // the next G survivors, one per lane group
+            int c = 0;
+            bool have = false;
+            for (int k = 0; k < G && m; ++k) {
+                const int ck = __builtin_ctzll(m);
+                m &= m - 1;
+                if (grp == k) { c = ck; have = true; }
+#ifdef ST_PROFILE
+                ++prof.tests;
+#endif
+            }
+            const float4 h0 = make_float4(from(c, rec0.x), from(c, rec0.y), from(c, rec0.z), from(c, rec0.w));
+            const float4 h1 = make_float4(from(c, rec1.x), from(c, rec1.y), from(c, rec1.z), from(c, rec1.w));
+            const float4 h2 = make_float4(from(c, rec2.x), from(c, rec2.y), from(c, rec2.z), from(c, rec2.w));
+            const float opac = from(c, rec3.x);
+            const uint32_t id = __float_as_uint(from(c, rec3.y));
+            const StHit h = st_hit(h0, h1, h2, opac, rox, roy, roz, rdx, rdy, rdz);
+            const bool take = have && ron && h.ok && (first_pass || h.t > rprev_t || (h.t == rprev_t && id > rprev_id));
+            const unsigned long long takers = __ballot(take);
+#ifdef ST_PROFILE
+            prof.lanes += __popcll(__ballot(have && ron && h.ok));
+#endif
+            if (takers == 0) continue;
+            const int rank = __popcll(takers & sib & below);                 // takers of my ray in the lane groups before mine
+            for (int k = 0;; ++k) {
+                const bool now = take && rank == k;
+                if (__ballot(now) == 0) break;                                // (ranks are dense per ray)
+                if (now) {
+                    uint32_t n = kb_n[col];
+                    bool ins = true;
+                    if (n == ST_K) {
+                        const float lt = kb_t[ST_K - 1][col];
+                        ins = h.t < lt || (h.t == lt && id < kb_id[ST_K - 1][col]);
+                    }
+                    if (ins) {
+                        int pos = n < ST_K ? (int)n++ : ST_K - 1;
+                        while (pos > 0) {
+                            const float pt = kb_t[pos - 1][col];
+                            const uint32_t pid = kb_id[pos - 1][col];
+                            if (pt < h.t || (pt == h.t && pid < id)) break;
+                            kb_t[pos][col] = pt; kb_id[pos][col] = pid;
+                            --pos;
+                        }
+                        kb_t[pos][col] = h.t; kb_id[pos][col] = id;
+                        kb_n[col] = n;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+#ifdef ST_PROFILE
+        prof.t_cand += (unsigned)(wall_clock64() - tc0);
+#endif
+        s_far = wave_max_f(on ? (kb_n[tid] == ST_K ? s0 + kb_t[ST_K - 1][tid] * dm : INFINITY) : -INFINITY) * (1.0f + 1e-5f) + 1e-30f;
+    }
+    return on ? (int)kb_n[tid] : 0;
+}
+
 // Rays "run together" when their directions stay within a cone of ~5.7 degrees about their mean (1 - cos <= 0.005 for a block or a quadrant, 0.001 = 2.6 degrees for a 2x2 group: wider beams of grazing rays sweep thousands of surfels; measured on mirror rays off a rendered view: 16 ms at 25 degrees, 9.5 at 11 before and 3.65 -> 1.9 at 11 -> 4.4 after the rays left over got waves of their own) and their origins within 2 % of the
 // scene's extent of their centre.  `on` selects the rays asked about; the answer is wave-uniform.
 __device__ __forceinline__ bool st_run_together(float extent, float cone, bool on, float ox, float oy, float oz, float dx, float dy, float dz)
@@ -629,7 +798,7 @@ constexpr uint32_t ST_REC_DEFERRED = 0xFFFFFFFEu;   // in the last slot of a blo
 template <int MODE>
 __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
                                               const unsigned long long* __restrict__ wide_vmask, uint32_t (*kb_id)[ST_THREADS],
-                                              float (*kb_t)[ST_THREADS], uint32_t* tab, int tid, int64_t tile, int only_packet, uint32_t rec_row)
+                                              float (*kb_t)[ST_THREADS], uint32_t* kb_n, uint32_t* tab, int tid, int64_t tile, int only_packet, uint32_t rec_row)
 {
     constexpr bool BWD = MODE != 0;
     int64_t r = tile * 64 + (tid & 63);
@@ -723,7 +892,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    StProf prof = {0, 0, 0};
+    StProf prof = {0, 0, 0, 0u, 0u};
     for (int pass = 0; pass < ST_MAX_PASSES; ++pass) {
         if (__ballot(want) == 0) break;
         int n = 0;
@@ -742,8 +911,10 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
             for (uint32_t left = packets_present; left; left &= left - 1) {          // wave-uniform: one walk per packet
                 const int pk = __builtin_ctz(left);
                 const bool mine = want && packet == pk;
-                const int got = st_gather_wide(A.wide, wide_boxes, wide_vmask, leaf_ro, kb_id, kb_t, tid, ox, oy, oz, dx, dy, dz, ivx, ivy, ivz, prev_t,
-                                               prev_id, pass == 0, mine, prof);
+                const int got = (pk == 0 || ST_GROUP_GATHER == 0)
+                    ? st_gather_wide(A.wide, wide_boxes, wide_vmask, leaf_ro, kb_id, kb_t, tid, ox, oy, oz, dx, dy, dz, ivx, ivy, ivz, prev_t, prev_id, pass == 0, mine, prof)
+                    : st_gather_group(A.wide, wide_boxes, wide_vmask, leaf_ro, kb_id, kb_t, kb_n, tid, pk, A.ray_width > 0, ox, oy, oz, dx, dy, dz, prev_t, prev_id,
+                                      pass == 0, mine, prof);
                 if (mine) n = got;
             }
         }
@@ -924,7 +1095,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         A.norm[3 * r] = N[0]; A.norm[3 * r + 1] = N[1]; A.norm[3 * r + 2] = N[2];
         A.aux[2 * r] = X[0]; A.aux[2 * r + 1] = X[1];
 #ifdef ST_PROFILE
-        blended = prof.nodes; passes = prof.tests; M2 = (float)(wall_clock64() - prof_t0); T = (float)prof.lanes;   // 100 MHz ticks
+        blended = (int)prof.t_fetch; passes = prof.tests; M2 = (float)(wall_clock64() - prof_t0); T = (float)prof.t_cand;   // 100 MHz ticks
 #endif
         reinterpret_cast<float4*>(A.state)[r] = make_float4(M2, T, (float)blended, (float)(packet >= 0 ? -passes : passes));   // sign: walked in a packet
     } else {
@@ -942,12 +1113,13 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
     __shared__ float kb_t[MODE == 2 ? 1 : ST_K][ST_THREADS];                 // (the replay needs no depths: it recomputes them)
+    __shared__ uint32_t kb_n[MODE == 2 ? 1 : ST_THREADS];
     __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
     const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6);
     if (wave >= A.n_tiles) return;
-    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)wave, -1, wave);
+    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)wave, -1, wave);
 }
 
 // ---- rays that run with nobody: one WAVE per ray --------------------------------------------------------------------------------
@@ -1201,6 +1373,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
     __shared__ float kb_t[MODE == 2 ? 1 : ST_K][ST_THREADS];
+    __shared__ uint32_t kb_n[MODE == 2 ? 1 : ST_THREADS];
     __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     __shared__ unsigned long long slot[ST_THREADS / 64][ST_K];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
@@ -1217,7 +1390,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
     for (uint32_t item = blockIdx.x * (ST_THREADS / 64) + (tid >> 6); item < count; item += stride) {
         const uint32_t code = A.defer_list[16 + item];
         if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
-        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
+        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
     }
 }
 

@@ -56,8 +56,7 @@ def main():
     for name, sel in (("whole-block packets", full), ("smaller packets", ~full)):
         if sel.sum() == 0:
             continue
-        print(f"{mode} {name}: {int(sel.sum())} waves, rays per wave {nl[sel].mean():.1f}; per wave: visits {nodes[sel].mean():.1f}, candidates {tests[sel].mean():.1f}, "
-              f"lanes hit per candidate {(lanes[sel].sum() / tests[sel].sum().clamp_min(1)):.2f}, wall {ticks[sel].mean() / 100:.1f} us "
-              f"({ticks[sel].sum() / tests[sel].sum().clamp_min(1) * 10:.0f} ns per candidate, {ticks[sel].sum() / (tests[sel] + nodes[sel]).sum() * 10:.0f} ns per candidate or visit)")
+        print(f"{mode} {name}: {int(sel.sum())} waves, rays per wave {nl[sel].mean():.1f}; per wave: candidates {tests[sel].mean():.1f}, wall {ticks[sel].mean() / 100:.1f} us, "
+              f"of it node / leaf fetch + beam test {nodes[sel].mean() / 100:.1f} us, candidate loops {lanes[sel].mean() / 100:.1f} us")
 
 main()
