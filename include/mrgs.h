@@ -339,10 +339,11 @@ typedef struct MrgsSurfelGrads {   /* gradients w.r.t. the raw parameters, same 
 /* outputs: opacity[P,1], scales[P,2], rotations[P,4] (unit), features[P,8] -- exactly what GaussianRasterizer is fed */
 int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, float* scales, float* rotations, float* features,
                                  void* stream);
-/* upstream gradients of the four outputs (any may be NULL = zero); d_xyz holds only the part that flows through the view and
- * mirror directions (the rasterizer's own dL/dmeans3D is added by the caller / autograd) */
+/* upstream gradients of the four outputs (any may be NULL = zero).  d_xyz = the part that flows through the view and mirror directions
+ * + g_xyz_upstream [P,3] (NULL = zero): what reached the centres some other way -- the rasterizer's own dL/dmeans3D --, so that the
+ * caller's sum of the two is no kernel of its own (ABI 6; must not alias d_xyz) */
 int mrgs_surfel_features_backward(const MrgsSurfelParams* p, const float* g_opacity, const float* g_scales, const float* g_rotations,
-                                  const float* g_features, const MrgsSurfelGrads* grads, void* stream);
+                                  const float* g_features, const MrgsSurfelGrads* grads, const float* g_xyz_upstream, void* stream);
 
 /* ---- per-pixel maps of the surfel renderer (fused glue) ------------------------------------------------------------
  * compute_2dgs_normal_and_regularizations (gaussian_renderer/__init__.py:42-90) + depths_to_points / depth_to_normal
@@ -360,12 +361,12 @@ typedef struct MrgsMapsFrame {
 } MrgsMapsFrame;
 int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
                              float* normal_map, float* rend_alpha /*[1,H,W] = allmap[1], NULL = skip*/, float* rend_dist /*[1,H,W] = allmap[6]*/,
-                             void* stream);
+                             float* rend_alpha2 /*a second copy of rend_alpha for a second consumer (ABI 6), NULL = skip*/, void* stream);
 /* g_allmap[7,H,W] (fully written) from the upstream gradients of the four outputs and of rend_alpha = allmap[1:2] and
- * rend_dist = allmap[6:7], which are plain views in the reference ([1,H,W] each; any of the six may be NULL = zero). */
+ * rend_dist = allmap[6:7], which are plain views in the reference ([1,H,W] each; any of the seven may be NULL = zero). */
 int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
                               const float* g_surf_normal, const float* g_normal_map, const float* g_rend_alpha, const float* g_rend_dist,
-                              float* g_allmap, void* stream);
+                              const float* g_rend_alpha2 /*gradient of the second copy (ABI 6), NULL = zero*/, float* g_allmap, void* stream);
 
 /* render_surfel compositing (gaussian_renderer/__init__.py:436-445): diffuse = (1 - refl) * base, render =
  * [linear_to_srgb]((diffuse + specular)) + bg * (1 - alpha).  base_color / specular / render / diffuse [3,H,W],
@@ -591,7 +592,7 @@ const char* mrgs_last_hip_error(void);
 const char* mrgs_version(void);
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 5
+#define MRGS_ABI_VERSION 6
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

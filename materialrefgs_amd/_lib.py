@@ -132,11 +132,11 @@ SYMBOLS = {
                                                       c_void_p, ctypes.POINTER(MrgsRasterGrads), c_void_p]),
     "mrgs_surfel_features_forward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_features_backward": (ctypes.c_int, [ctypes.POINTER(MrgsSurfelParams), c_void_p, c_void_p, c_void_p, c_void_p,
-                                                     ctypes.POINTER(MrgsSurfelGrads), c_void_p]),
+                                                     ctypes.POINTER(MrgsSurfelGrads), c_void_p, c_void_p]),
     "mrgs_surfel_maps_forward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                c_void_p]),
+                                                c_void_p, c_void_p]),
     "mrgs_surfel_maps_backward": (ctypes.c_int, [ctypes.POINTER(MrgsMapsFrame), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                 c_void_p, c_void_p, c_void_p]),
+                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_surfel_composite_forward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                      c_void_p, c_void_p]),
     "mrgs_surfel_composite_backward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -214,7 +214,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 5   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 6   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

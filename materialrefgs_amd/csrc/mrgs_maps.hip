@@ -84,7 +84,7 @@ __device__ __forceinline__ FdNormal fd_normal(const MapsFrameDev& f, const float
 __global__ void __launch_bounds__(256) surfel_maps_fwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, float* __restrict__ rend_normal,
                                                               float* __restrict__ surf_depth, float* __restrict__ surf_normal,
                                                               float* __restrict__ normal_map, float* __restrict__ rend_alpha,
-                                                              float* __restrict__ rend_dist)
+                                                              float* __restrict__ rend_dist, float* __restrict__ rend_alpha2)
 {
     const int HW = f.H * f.W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(256) surfel_maps_fwd_kernel(MapsFrameDev f, co
     const int y = pix / f.W, x = pix - y * f.W;
     const float a = allmap[HW + pix];
     if (rend_alpha) rend_alpha[pix] = a;                       // the reference's plain slices allmap[1:2], allmap[6:7] as tensors of their own
+    if (rend_alpha2) rend_alpha2[pix] = a;                     // (a second copy for a second consumer: its gradient comes back on its own pointer)
     if (rend_dist) rend_dist[pix] = allmap[6 * HW + pix];
     const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
     float nw[3];
@@ -127,7 +128,8 @@ constexpr int MB_PW = MB_TX + 4, MB_PH = MB_TY + 4, MB_CW = MB_TX + 2, MB_CH = M
 __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, const float* __restrict__ allmap, const float* __restrict__ g_rn,
                                                               const float* __restrict__ g_sd, const float* __restrict__ g_sn,
                                                               const float* __restrict__ g_nm, const float* __restrict__ g_alpha,
-                                                              const float* __restrict__ g_dist, float* __restrict__ g_allmap)
+                                                              const float* __restrict__ g_dist, const float* __restrict__ g_alpha2,
+                                                              float* __restrict__ g_allmap)
 {
     __shared__ float s_pt[3][MB_PH * MB_PW];
     __shared__ float s_g[6][MB_CH * MB_CW];
@@ -181,6 +183,7 @@ __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, co
     const float nv[3] = {allmap[2 * HW + pix], allmap[3 * HW + pix], allmap[4 * HW + pix]};
     float g_nw[3] = {0.0f, 0.0f, 0.0f};
     float g_a = g_alpha != nullptr ? g_alpha[pix] : 0.0f;      // rend_alpha is a plain view of allmap[1]
+    if (g_alpha2 != nullptr) g_a += g_alpha2[pix];
     if (g_rn != nullptr) {
 #pragma unroll
         for (int j = 0; j < 3; j++) g_nw[j] = g_rn[j * HW + pix];
@@ -374,22 +377,22 @@ __global__ void __launch_bounds__(256) indirect_blend_bwd_kernel(int H, int W, c
 extern "C" {
 
 int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
-                             float* normal_map, float* rend_alpha, float* rend_dist, void* stream)
+                             float* normal_map, float* rend_alpha, float* rend_dist, float* rend_alpha2, void* stream)
 {
     if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !rend_normal || !surf_depth) return MRGS_E_BAD_ARG;
     const int HW = fr->H * fr->W;
     hipLaunchKernelGGL(surfel_maps_fwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, to_dev(fr), allmap, rend_normal,
-                       surf_depth, surf_normal, normal_map, rend_alpha, rend_dist);
+                       surf_depth, surf_normal, normal_map, rend_alpha, rend_dist, rend_alpha2);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
 int mrgs_surfel_maps_backward(const MrgsMapsFrame* fr, const float* allmap, const float* g_rend_normal, const float* g_surf_depth,
                               const float* g_surf_normal, const float* g_normal_map, const float* g_rend_alpha, const float* g_rend_dist,
-                              float* g_allmap, void* stream)
+                              const float* g_rend_alpha2, float* g_allmap, void* stream)
 {
     if (!fr || fr->H <= 0 || fr->W <= 0 || !allmap || !g_allmap) return MRGS_E_BAD_ARG;
     hipLaunchKernelGGL(surfel_maps_bwd_kernel, dim3((fr->W + MB_TX - 1) / MB_TX, (fr->H + MB_TY - 1) / MB_TY), dim3(256), 0, (hipStream_t)stream,
-                       to_dev(fr), allmap, g_rend_normal, g_surf_depth, g_surf_normal, g_normal_map, g_rend_alpha, g_rend_dist, g_allmap);
+                       to_dev(fr), allmap, g_rend_normal, g_surf_depth, g_surf_normal, g_normal_map, g_rend_alpha, g_rend_dist, g_rend_alpha2, g_allmap);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256) surfel_features_fwd_kernel(MrgsSurfelPara
 
 __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelParams prm, const float* __restrict__ g_opacity,
                                                                   const float* __restrict__ g_scales, const float* __restrict__ g_rotations,
-                                                                  const float* __restrict__ g_features, MrgsSurfelGrads out)
+                                                                  const float* __restrict__ g_features, MrgsSurfelGrads out,
+                                                                  const float* __restrict__ g_xyz_upstream)
 {
     __shared__ float s_rest[4][64 * REST_STRIDE];
     const int P = prm.P;
@@ -272,7 +273,8 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
     // v = d / |d|
     const float v_dot = f.v[0] * d_v[0] + f.v[1] * d_v[1] + f.v[2] * d_v[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) out.d_xyz[3 * (size_t)idx + i] = (d_v[i] - f.v[i] * v_dot) / f.dlen;
+    for (int i = 0; i < 3; i++)           // + what reached the centres some other way (the rasterizer's dL/dmeans3D): one sum here instead of a kernel of its own
+        out.d_xyz[3 * (size_t)idx + i] = (g_xyz_upstream ? g_xyz_upstream[3 * (size_t)idx + i] : 0.0f) + (d_v[i] - f.v[i] * v_dot) / f.dlen;
 
     // ---- activations ----
     const float so = sigmoidf(prm.opacity_raw[idx]);
@@ -471,7 +473,7 @@ int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, floa
 }
 
 int mrgs_surfel_features_backward(const MrgsSurfelParams* p, const float* g_opacity, const float* g_scales, const float* g_rotations,
-                                  const float* g_features, const MrgsSurfelGrads* grads, void* stream)
+                                  const float* g_features, const MrgsSurfelGrads* grads, const float* g_xyz_upstream, void* stream)
 {
     if (!p || p->P < 0 || !grads) return MRGS_E_BAD_ARG;
     if (p->P == 0) return MRGS_OK;
@@ -482,7 +484,7 @@ int mrgs_surfel_features_backward(const MrgsSurfelParams* p, const float* g_opac
         !grads->d_ori_color || !grads->d_indirect_dc || !grads->d_indirect_rest)
         return MRGS_E_BAD_ARG;
     hipLaunchKernelGGL(surfel_features_bwd_kernel, dim3((p->P + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, g_opacity, g_scales,
-                       g_rotations, g_features, *grads);
+                       g_rotations, g_features, *grads, g_xyz_upstream);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

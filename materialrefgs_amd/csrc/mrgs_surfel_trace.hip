@@ -1131,21 +1131,19 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
 // (sorted); new hits are merged by rank (rank = entries in front of me, counted with one v_readlane sweep over the other side);
 // blending is lane-parallel too: transmittance and the running sums are 16-lane scans, the pixel sums wave reductions, every hit's
 // gradient is written by its own lane.
+// (Hillis-Steele inside the 16-lane DPP row: row_shr:1/2/4/8 with the identity for lanes whose source falls outside the row -- the same
+// products / sums in the same order as the __shfl_up form these replace, without its five ds_bpermute round trips)
 __device__ __forceinline__ float scan16_mul_excl(float v, int lane)          // exclusive prefix product over lanes 0..15 (others: don't care)
 {
     float inc = v;
-#pragma unroll
-    for (int s = 1; s < 16; s <<= 1) { const float o = __shfl_up(inc, s); if (lane >= s) inc *= o; }
-    const float prev = __shfl_up(inc, 1);
-    return lane == 0 ? 1.0f : prev;
+    inc *= ST_DPP(1.0f, inc, 0x111, 0xf); inc *= ST_DPP(1.0f, inc, 0x112, 0xf); inc *= ST_DPP(1.0f, inc, 0x114, 0xf); inc *= ST_DPP(1.0f, inc, 0x118, 0xf);
+    return ST_DPP(1.0f, inc, 0x111, 0xf);
 }
 __device__ __forceinline__ float scan16_add_excl(float v, int lane)
 {
     float inc = v;
-#pragma unroll
-    for (int s = 1; s < 16; s <<= 1) { const float o = __shfl_up(inc, s); if (lane >= s) inc += o; }
-    const float prev = __shfl_up(inc, 1);
-    return lane == 0 ? 0.0f : prev;
+    inc += ST_DPP(0.0f, inc, 0x111, 0xf); inc += ST_DPP(0.0f, inc, 0x112, 0xf); inc += ST_DPP(0.0f, inc, 0x114, 0xf); inc += ST_DPP(0.0f, inc, 0x118, 0xf);
+    return ST_DPP(0.0f, inc, 0x111, 0xf);
 }
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
 {
@@ -1336,9 +1334,8 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
             Aw += sw; M1 += wave_sum_f(w * t); M2 += wave_sum_f(w * t * t);
             // transmittance behind the blended hits
             const float keep = bl ? 1.0f - alpha : 1.0f;
-            float prod = keep;
-#pragma unroll
-            for (int sft = 1; sft < 16; sft <<= 1) prod *= __shfl_xor(prod, sft);
+            float prod = keep;          // product over the row's 16 lanes: inside the quads, then the neighbouring quads by rotation
+            prod *= ST_DPP(1.0f, prod, 0xb1, 0xf); prod *= ST_DPP(1.0f, prod, 0x4e, 0xf); prod *= ST_DPP(1.0f, prod, 0x124, 0xf); prod *= ST_DPP(1.0f, prod, 0x128, 0xf);
             T *= st_uniform(prod);
             blended += n_bl;
             if (stop || nb < ST_K) done = true;

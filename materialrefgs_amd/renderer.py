@@ -106,7 +106,7 @@ class _SurfelFeatures(torch.autograd.Function):
     features[P,8]) in one kernel each way (checker: oracle/glue_oracle.py, the reference's own chain of torch ops)."""
 
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos):
+    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos, pass_xyz=False):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not xyz.is_cuda:
             raise RuntimeError("surfel_features needs CUDA(HIP) tensors: the per-gaussian glue runs in libmrgs.so, there is no CPU path")
@@ -120,27 +120,34 @@ class _SurfelFeatures(torch.autograd.Function):
             st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_forward(ctypes.byref(prm), _p(op), _p(sc), _p(rot), _p(feat), st))
         ctx.save_for_backward(*ts)
+        if pass_xyz:
+            # the centres as a fifth output (the input itself): whoever consumes THEM -- the rasterizer -- sends its gradient through this
+            # node, whose backward kernel adds it to its own: one sum inside a kernel instead of autograd's accumulation kernel
+            return op, sc, rot, feat, xyz
         return op, sc, rot, feat
 
     @staticmethod
-    def backward(ctx, g_op, g_sc, g_rot, g_feat):
+    def backward(ctx, g_op, g_sc, g_rot, g_feat, g_xyz=None):
         ts = ctx.saved_tensors
         P, dev = ts[0].shape[0], ts[0].device
         L = _lib.lib()
         prm = MrgsSurfelParams(P, *[_p(t) for t in ts])
         outs = [torch.empty_like(t) for t in ts[:9]]
         grads = MrgsSurfelGrads(*[_p(t) for t in outs])
-        gs = [None if g is None else _c(g) for g in (g_op, g_sc, g_rot, g_feat)]
+        gs = [None if g is None else _c(g) for g in (g_op, g_sc, g_rot, g_feat, g_xyz)]
         with _lib.guard(dev):
             st = _lib.stream_ptr(dev)
-            _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads), st))
-        return (*outs, None)
+            _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads),
+                                                       _p(gs[4]), st))
+        return (*outs, None, None)
 
 
-def surfel_features(pc, camera_center):
-    """(opacity[P,1], scales[P,2], rotations[P,4], features[P,8]) for `render_surfel` from the raw parameters of `pc`."""
+def surfel_features(pc, camera_center, pass_xyz=False):
+    """(opacity[P,1], scales[P,2], rotations[P,4], features[P,8]) for `render_surfel` from the raw parameters of `pc`; with `pass_xyz`
+    also the centres [P,3] as an output of the same node (hand THOSE to the rasterizer: its dL/dmeans3D is then summed with this node's
+    own gradient of the centres inside the backward kernel)."""
     return _SurfelFeatures.apply(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._refl_strength, pc._roughness, pc._ori_color,
-                                 pc._indirect_dc, pc._indirect_rest, camera_center)
+                                 pc._indirect_dc, pc._indirect_rest, camera_center, bool(pass_xyz))
 
 
 _MAPS_FRAME_CACHE = {}
@@ -186,7 +193,7 @@ class _SurfelMaps(torch.autograd.Function):
     backward kernel instead of two extra [7,H,W] accumulation kernels."""
 
     @staticmethod
-    def forward(ctx, allmap, fr, want_surf_normal, want_normal_map):
+    def forward(ctx, allmap, fr, want_surf_normal, want_normal_map, twin_alpha=False):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not allmap.is_cuda:
             raise RuntimeError("the fused map kernels need CUDA(HIP) tensors: there is no CPU path")
@@ -196,27 +203,33 @@ class _SurfelMaps(torch.autograd.Function):
         rn, sd = torch.empty((3, H, W), **o), torch.empty((1, H, W), **o)
         sn = torch.empty((3, H, W), **o) if want_surf_normal else None
         nm = torch.empty((H, W, 3), **o) if want_normal_map else None
-        ra_rd = torch.empty((2, 1, H, W), **o)      # the plain slices allmap[1:2] / allmap[6:7] of the reference, written by the same kernel
+        # the plain slices allmap[1:2] / allmap[6:7] of the reference, written by the same kernel; with `twin_alpha` a second copy of the
+        # alpha map for a second consumer (render_surfel's shading), whose gradient then comes back on a pointer of its own instead of
+        # through autograd's accumulation kernel
+        ra_rd = torch.empty((3 if twin_alpha else 2, 1, H, W), **o)
         with _lib.guard(dev):
             st = _lib.stream_ptr(dev)
-            _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), _p(ra_rd[0]), _p(ra_rd[1]), st))
+            _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), _p(ra_rd[0]), _p(ra_rd[1]),
+                                                           _p(ra_rd[2]) if twin_alpha else None, st))
         ctx.save_for_backward(allmap)
         ctx.fr = fr
         outs = (rn, sd, sn if sn is not None else rn.new_empty(0), nm if nm is not None else rn.new_empty(0))
         ctx.mark_non_differentiable(*[t for t in outs[2:] if t.numel() == 0])
+        if twin_alpha:
+            return (*outs, ra_rd[0], ra_rd[1], ra_rd[2])
         return (*outs, ra_rd[0], ra_rd[1])
 
     @staticmethod
-    def backward(ctx, g_rn, g_sd, g_sn, g_nm, g_ra, g_rd):
+    def backward(ctx, g_rn, g_sd, g_sn, g_nm, g_ra, g_rd, g_ra2=None):
         (allmap,) = ctx.saved_tensors
         dev = allmap.device
-        g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm, g_ra, g_rd)]
+        g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm, g_ra, g_rd, g_ra2)]
         g_allmap = torch.empty_like(allmap)
         with _lib.guard(dev):
             st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(ctx.fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]),
-                                                            _p(g_allmap), st))
-        return g_allmap, None, None, None
+                                                            _p(g[6]), _p(g_allmap), st))
+        return g_allmap, None, None, None, None
 
 
 class _SurfelComposite(torch.autograd.Function):
@@ -272,7 +285,7 @@ def pgsr_unbiased_depth(allmap, rend_distance, viewpoint_camera):
 
 
 def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=True, return_normal_map=False,
-                                            rend_distance=None):
+                                            rend_distance=None, twin_alpha=False):
     """gaussian_renderer/__init__.py:42-90, one HIP kernel each way (`mrgs_surfel_maps_*`).  With `return_normal_map` the
     dictionary also holds render_surfel's `normal_map` [H,W,3] = render_normal / max(alpha, 1e-6) (:419-421).
     `rend_distance` (the "pgsr" flavour's blended plane distance): surf_depth is then the flavour's unbiased depth
@@ -283,11 +296,13 @@ def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, retu
         fr = _maps_frame(viewpoint_camera, 1.0)
     else:
         fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
-    rn, sd, sn, nm, ra, rd = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map))
+    rn, sd, sn, nm, ra, rd, *twin = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map), bool(twin_alpha))
     out = {"render_alpha": ra, "render_normal": rn, "render_depth_median": None, "render_depth_expected": None,
            "render_dist": rd, "surf_depth": sd, "surf_normal": sn if return_depth_normal else None}
     if return_normal_map:
         out["normal_map"] = nm
+    if twin_alpha:
+        out["render_alpha_twin"] = twin[0]      # the same map for a second consumer (see _SurfelMaps)
     return out
 
 
@@ -382,7 +397,8 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
 
     # activations, facing normal, mirror direction, indirect radiance along it and the feature concat (__init__.py:338-355):
     # one HIP kernel each way
-    opacities, scales, rotations, features = surfel_features(pc, viewpoint_camera.camera_center)
+    # (the centres come back as an output of the same node: the rasterizer's dL/dmeans3D joins the node's own in its backward kernel)
+    opacities, scales, rotations, features, means3D = surfel_features(pc, viewpoint_camera.camera_center, pass_xyz=True)
     if getattr(pipe, "use_asg", False):        # the lobes instead of the SH indirect term in channels 5..7 (:312-336)
         features = torch.cat((features[:, :5], _asg_indirect_of(pc, viewpoint_camera, scaling_modifier)), dim=-1)
     if flag != "2dgs":          # "pgsr": + the plane distance as a ninth channel, back as "rend_distance" (:348-355, 411-413, 478-480)
@@ -400,7 +416,8 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     albedo, indirect_light = rendered_features[2:5], rendered_features[5:8]
 
     reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img),
-                                                  return_normal_map=(not wo_render_img), rend_distance=rend_distance)
+                                                  return_normal_map=(not wo_render_img), rend_distance=rend_distance,
+                                                  twin_alpha=(not wo_render_img))
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
     geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": render_normal, "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
@@ -417,7 +434,7 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     tracer = getattr(pc, "ray_tracer", None) if indirect else None
     final_image, diffuse_map, specular, extra_dict = shade_and_composite_surfel(
         pc.get_envmap, base_color, rendered_features, viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, reg["normal_map"],
-        render_alpha, bg_color, srgb, ray_tracer=tracer, surf_depth=reg["surf_depth"])
+        reg["render_alpha_twin"], bg_color, srgb, ray_tracer=tracer, surf_depth=reg["surf_depth"])   # (the shading's own copy of the alpha map)
     if srgb:
         albedo = linear_to_srgb(albedo)
         specular = linear_to_srgb(specular)
