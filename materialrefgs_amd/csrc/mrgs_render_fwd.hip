@@ -271,7 +271,16 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
 #define MRGS_FWD_REDO_INLINE 1
 #endif
 template <int S_MAX, bool FV>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? 7 : S_MAX <= 12 ? 5 : 4, 8))) render_fwd_kernel(
+// Waves per SIMD the register allocator is held to.  Round 4 (after the exact-decision logic joined the loop), forward blend stage in ms at
+// C2 / C3full: S = 0 at 7 / 6 / 5 / 4 waves 0.172 / 0.170 / 0.176 / 0.174 (72 / 80 / 95 / 96 VGPRs, 21 / 14 / 0 / 0 spilled); S = 8 at 6 / 5 / 4
+// waves 0.203 / 0.204 / 0.195 (105 VGPRs and no spills at 4).
+#ifndef MRGS_FWD_WAVES_S0
+#define MRGS_FWD_WAVES_S0 6
+#endif
+#ifndef MRGS_FWD_WAVES_S8
+#define MRGS_FWD_WAVES_S8 4
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? MRGS_FWD_WAVES_S0 : S_MAX <= 12 ? MRGS_FWD_WAVES_S8 : 4, 8))) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ fwd_assign, uint32_t* __restrict__ blend_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
     const float4* __restrict__ rec, const float4* __restrict__ cull, const float* __restrict__ features, const float* __restrict__ bg, float* __restrict__ final_T,

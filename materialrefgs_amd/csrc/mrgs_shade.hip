@@ -846,7 +846,10 @@ __device__ __forceinline__ void csr_spmv3_body(int block, int nrows, const uint3
 #endif
 // (Also measured: a wave owning 2 / 4 / 8 consecutive rows and walking their blocks as one range, products added to the row's accumulators
 // with 0/1 factors -- fewer, longer waves without the partly empty last round per row: 45.7 / 54.6 / 74.7 us against 42.6 for a row per
-// wave.  The launch wants MANY short waves; what holds it at 1.7 TB/s was not found.)
+// wave.  Round 4: a wave owning 2 / 4 / 8 rows strided by the wave count, software-pipelined ACROSS rows -- the next row's extent fetched
+// two rows ahead, its first round of (index, weights) one row ahead, so that a row starts with its gathers instead of three dependent
+// round trips: the same time at 2 rows, +5 us (forward) and +15 us (transposed call) at 4, +16 us (forward) at 8, bit-identical sums.  The launch wants MANY short waves;
+// what holds it at 1.7 TB/s was not found.)
 __device__ __forceinline__ void csr_spmv3_blk4_body(int block, int nrows, const uint32_t* __restrict__ row_ptr, const uint16_t* __restrict__ bcol,
                                                     const uint2* __restrict__ bval, const float* __restrict__ row_scale,
                                                     const float* __restrict__ x, float* __restrict__ y)

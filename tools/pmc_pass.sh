@@ -19,4 +19,5 @@ for C in "$@"; do
   [ "$C" = "WRITE_SIZE" ] && WP=$(find $O/pass$i -name "*counter_collection.csv" | head -1)
 done
 [ -n "$FP" ] && [ -n "$WP" ] && python tools/pmc_traffic.py $W $FP $WP > $O/pmc_traffic_$W.log 2>&1
+[ "$W" = "C3full" ] && python tools/pmc_sq_from_pass.py $W $O/pmc_$W.json >> $O/pmc_traffic_$W.log 2>&1     # the blend kernels' VALU issue figures -> profiles/pmc_sq.json
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +4M -delete

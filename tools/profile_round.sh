@@ -23,7 +23,7 @@ cd $R
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 S=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1)
 cp profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null; cp profiles/pmc_sq.json $O/pmc_sq.json 2>/dev/null
-python tools/pmc_traffic.py C2 $F $W > $O/pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python tools/pmc_traffic.py C2 $F $W > $O/pmc_traffic.log 2>&1 && cp profiles/pmc_traffic.json $O/pmc_traffic.json; cp profiles/pmc_sq.json $O/pmc_sq.json
 python tools/pmc_sq.py $S $O/${TAG}_pmc_sq_C2.json C2 profiles/pmc_sq.json > $O/pmc_sq_reduce.log 2>&1 && cp profiles/pmc_sq.json $O/pmc_sq.json
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $F | head -400 > $O/${TAG}_pmc_FETCH_SIZE_C2.csv
 grep -E "render_|preprocess_|radix|scan_tiles|duplicate|tile_ranges|blend_order|tile_sort|emit" $W | head -400 > $O/${TAG}_pmc_WRITE_SIZE_C2.csv
@@ -38,7 +38,7 @@ for W in C3full C3trace C4trace; do
      "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS_ATOMIC GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_$W.log 2>&1
   cp $O/pmc_$W/pmc_$W.json $O/${TAG}_pmc_$W.json
 done
-cp profiles/pmc_traffic.json $O/pmc_traffic.json
+cp profiles/pmc_traffic.json $O/pmc_traffic.json; cp profiles/pmc_sq.json $O/pmc_sq.json
 timeout 1500 python bench.py > $O/${TAG}_bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --workload C2 --steps 1500 --no-secondary > $O/${TAG}_bench_C2.json 2> $O/bench_C2.err
 if [ "$FULL" = "full" ]; then
