@@ -375,7 +375,10 @@ int mrgs_surfel_composite_forward(int32_t H, int32_t W, int32_t srgb, const floa
                                   const float* alpha, const float* bg, float* render, float* diffuse, void* stream);
 int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const float* base_color, const float* refl_strength,
                                    const float* specular, const float* bg, const float* g_render, const float* g_diffuse, float* g_base,
-                                   float* g_refl, float* g_specular, float* g_alpha, void* stream);
+                                   float* g_refl, float* g_specular, float* g_alpha,
+                                   float* zero_fill /*ABI 6: zero_floats floats cleared by the same launch (what the caller's next kernel
+                                   accumulates into, e.g. mrgs_shade_specular_backward's texel gradients), NULL / 0 = nothing*/,
+                                   int64_t zero_floats, void* stream);
 
 /* ---- training loss of one view (fused) ---------------------------------------------------
  * Replaces calculate_loss (utils/loss_utils.py:142-228) = (1 - lambda_dssim) * l1_loss (:22-23) + lambda_dssim * (1 - ssim)

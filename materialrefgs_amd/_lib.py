@@ -140,7 +140,7 @@ SYMBOLS = {
     "mrgs_surfel_composite_forward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                      c_void_p, c_void_p]),
     "mrgs_surfel_composite_backward": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mrgs_cubemap_filter_count": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "mrgs_cubemap_filter_fill": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),

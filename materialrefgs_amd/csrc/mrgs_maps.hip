@@ -270,9 +270,13 @@ __global__ void __launch_bounds__(256) surfel_composite_bwd_kernel(int HW, int s
                                                                    const float* __restrict__ spec, const float* __restrict__ bg,
                                                                    const float* __restrict__ g_render, const float* __restrict__ g_diffuse,
                                                                    float* __restrict__ g_base, float* __restrict__ g_refl,
-                                                                   float* __restrict__ g_spec, float* __restrict__ g_alpha)
+                                                                   float* __restrict__ g_spec, float* __restrict__ g_alpha,
+                                                                   float* __restrict__ zero_fill, long long zero_floats)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x;
+    // a side job for the caller's next kernel: clear a buffer it accumulates into (the shading backward's texel gradients), in the
+    // same launch instead of a fill of its own; the grid is sized for whichever of the two is larger
+    for (long long i = (long long)pix; i < zero_floats; i += (long long)gridDim.x * 256) zero_fill[i] = 0.0f;
     if (pix >= HW) return;
     const float k = 1.0f - refl[pix];
     float ga = 0.0f, gr = 0.0f;
@@ -408,13 +412,14 @@ int mrgs_surfel_composite_forward(int32_t H, int32_t W, int32_t srgb, const floa
 
 int mrgs_surfel_composite_backward(int32_t H, int32_t W, int32_t srgb, const float* base_color, const float* refl_strength,
                                    const float* specular, const float* bg, const float* g_render, const float* g_diffuse, float* g_base,
-                                   float* g_refl, float* g_specular, float* g_alpha, void* stream)
+                                   float* g_refl, float* g_specular, float* g_alpha, float* zero_fill, int64_t zero_floats, void* stream)
 {
     if (H <= 0 || W <= 0 || !base_color || !refl_strength || !specular || !bg || !g_base || !g_refl || !g_specular || !g_alpha)
         return MRGS_E_BAD_ARG;
+    if (zero_floats < 0 || (zero_floats > 0 && !zero_fill)) return MRGS_E_BAD_ARG;
     const int HW = H * W;
     hipLaunchKernelGGL(surfel_composite_bwd_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, srgb, base_color,
-                       refl_strength, specular, bg, g_render, g_diffuse, g_base, g_refl, g_specular, g_alpha);
+                       refl_strength, specular, bg, g_render, g_diffuse, g_base, g_refl, g_specular, g_alpha, zero_fill, (long long)zero_floats);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

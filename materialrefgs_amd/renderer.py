@@ -260,7 +260,7 @@ class _SurfelComposite(torch.autograd.Function):
         with _lib.guard(dev):
             st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_composite_backward(H, W, ctx.srgb, _p(base), _p(refl), _p(spec), _p(bg), _p(g_render), _p(g_diffuse),
-                                                                 _p(g_base), _p(g_refl), _p(g_spec), _p(g_alpha), st))
+                                                                 _p(g_base), _p(g_refl), _p(g_spec), _p(g_alpha), None, 0, st))
         return g_base, g_refl, g_spec, g_alpha, None, None
 
 
@@ -306,11 +306,26 @@ def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, retu
     return out
 
 
+_BLACK = {}
+
+
+def _black_like(bg_color):
+    """A zero background of bg_color's shape / device / dtype, shared between renders (read-only: nothing writes a background): the
+    reference fills a fresh one per render."""
+    key = (bg_color.device, bg_color.dtype, tuple(bg_color.shape))
+    t = _BLACK.get(key)
+    if t is None:
+        if len(_BLACK) > 16:
+            _BLACK.clear()
+        t = _BLACK[key] = torch.zeros_like(bg_color)
+    return t
+
+
 def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
     return GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
-        bg=torch.zeros_like(bg_color),                      # the rasterizer always composites over black (__init__.py:247)
+        bg=_black_like(bg_color),                           # the rasterizer always composites over black (__init__.py:247)
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
         prefiltered=False, debug=getattr(pipe, "debug", False))
@@ -639,19 +654,29 @@ class _MirrorRaysBlended(torch.autograd.Function):
 _CAM_CONSTS = {}
 
 
+def _fingerprint(x):
+    """What a cached constant was built from: the bytes of a host array (a few dozen), address and version counter of a tensor."""
+    if torch.is_tensor(x):
+        return (x.data_ptr(), x._version, tuple(x.shape))
+    import numpy as np
+    return np.asarray(x).tobytes()
+
+
 def _camera_consts(viewpoint_camera, dev):
-    """K^-1 (host tuple), Camera.R and Camera.T as device tensors, built once per camera object (three small uploads per view otherwise)."""
+    """K^-1 (host tuple), Camera.R and Camera.T as device tensors, built once per camera object AND pose: an entry is only reused while
+    R, T and the intrinsics are what it was built from (a pose refinement or a resolution change on the same object rebuilds it)."""
     import numpy as np
     H, W, K = viewpoint_camera.HWK
     key = id(viewpoint_camera)
+    stamp = (_fingerprint(viewpoint_camera.R), _fingerprint(viewpoint_camera.T), _fingerprint(K), int(H), int(W))
     ent = _CAM_CONSTS.get(key)
-    if ent is None or ent[0] is not viewpoint_camera or ent[4] != dev:
+    if ent is None or ent[0] is not viewpoint_camera or ent[4] != dev or ent[5] != stamp:
         Kinv = tuple(np.linalg.inv(np.asarray(K, dtype=np.float32)).astype(np.float32).reshape(-1).tolist())
         R = torch.as_tensor(viewpoint_camera.R, dtype=torch.float32, device=dev).contiguous()
         T = torch.as_tensor(viewpoint_camera.T, dtype=torch.float32, device=dev).contiguous()
         if len(_CAM_CONSTS) > 4096:
             _CAM_CONSTS.clear()
-        ent = _CAM_CONSTS[key] = (viewpoint_camera, Kinv, R, T, dev)      # holds the camera: its id stays its own
+        ent = _CAM_CONSTS[key] = (viewpoint_camera, Kinv, R, T, dev, stamp)      # holds the camera: its id stays its own
     return ent[1], ent[2], ent[3]
 
 
@@ -748,7 +773,7 @@ def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color,
     if opt is None:
         opt = SimpleNamespace(indirect=False)
     means2D = _screenspace_points(pc)
-    settings = _raster_settings(viewpoint_camera, pc, pipe, torch.zeros_like(bg_color), scaling_modifier)     # bg = 0 as at :483
+    settings = _raster_settings(viewpoint_camera, pc, pipe, _black_like(bg_color), scaling_modifier)     # bg = 0 as at :483
     rasterizer = GaussianRasterizer(raster_settings=settings)
     means3D = pc.get_xyz
     shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)

@@ -207,3 +207,27 @@ def test_raster_ticket_guards():
         assert L.mrgs_rasterize_forward_finish(ctypes.byref(bad), ctypes.byref(R)) == 1        # MRGS_E_BAD_ARG
     assert L.mrgs_rasterize_forward_finish(None, ctypes.byref(R)) == 1
     assert ctypes.sizeof(MrgsRasterTicket) == 24
+
+
+def test_camera_constants_follow_an_in_place_pose_change():
+    """renderer._camera_consts caches K^-1 / R / T per camera object; a pose refined in place (same object, same arrays) or new
+    intrinsics must not be served from the cache."""
+    from types import SimpleNamespace
+    import numpy as np
+    import torch
+    from materialrefgs_amd import renderer
+    K = np.array([[500.0, 0, 32], [0, 500.0, 24], [0, 0, 1]], dtype=np.float32)
+    cam = SimpleNamespace(R=np.eye(3, dtype=np.float32), T=np.array([0.0, 0.0, 3.0], dtype=np.float32), HWK=(48, 64, K))
+    dev = torch.device("cpu")
+    k0, r0, t0 = renderer._camera_consts(cam, dev)
+    k1, r1, t1 = renderer._camera_consts(cam, dev)
+    assert r1 is r0 and t1 is t0 and k1 == k0                      # unchanged camera: the cached tensors
+    cam.T[2] = 5.0                                                 # in place
+    _, _, t2 = renderer._camera_consts(cam, dev)
+    assert float(t2[2]) == 5.0
+    cam.R[:] = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1]], dtype=np.float32)
+    _, r3, _ = renderer._camera_consts(cam, dev)
+    assert float(r3[0, 1]) == 1.0 and float(r3[0, 0]) == 0.0
+    K[0, 0] = 250.0
+    k4, _, _ = renderer._camera_consts(cam, dev)
+    assert abs(k4[0] - 1.0 / 250.0) < 1e-9
