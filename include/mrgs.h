@@ -128,8 +128,9 @@ int mrgs_rasterize_forward_render(const MrgsRasterConfig* cfg, const MrgsRasterI
  * `capacity_pairs` (a guess, e.g. the previous call's count plus a margin; binning_bytes >= mrgs_binning_bytes(capacity_pairs)),
  * phase 2 is queued right behind phase 1 and takes the actual pair count from device memory, and the call returns once the
  * count has reached the host (the GPU keeps working).  Returns MRGS_OK with *num_rendered_host set when the count fitted.
- * Returns MRGS_E_WORKSPACE with *num_rendered_host set when it did not: the outputs are then undefined and the caller redoes
- * phase 2 with mrgs_rasterize_forward_render on a workspace of mrgs_binning_bytes(*num_rendered_host).
+ * Returns MRGS_E_WORKSPACE with *num_rendered_host set when it did not: the outputs are then those of an EMPTY render (every tile
+ * list reads as empty: background colour, zero maps -- finite, so that work queued behind the call runs on defined data) and the
+ * caller redoes phase 2 with mrgs_rasterize_forward_render on a workspace of mrgs_binning_bytes(*num_rendered_host).
  * mrgs_rasterize_backward must be given the pair count the binning workspace was carved for (capacity_pairs here).
  * Same reference interface as the two calls above (rasterize_points.cu:41-144). */
 int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, void* geom_ws, size_t geom_bytes,

@@ -198,6 +198,7 @@ class RasterWorkspaceOverflow(RuntimeError):
 
 
 _DEFER = threading.local()
+_TICKET_RING = 16          # MRGS_TICKET_RING of csrc/mrgs_api.hip (include/mrgs.h: mrgs_rasterize_forward_begin)
 
 
 def _note_count(guess_key, num_rendered, hint_settings, dev):
@@ -338,6 +339,14 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
             pending = _PendingCount(ticket, guess_key, raster_settings if inp.work_hint else None, dev)
             if box is not None:
                 # a renderer queues its own kernels behind the rasterizer first and asks for the count at its end (deferred_count)
+                # (the library keeps _TICKET_RING landing slots per thread and device: a box that begins more renders than that collects
+                # its oldest counts now -- a wait, but no ticket ever goes stale; an overflow among them stays on record for box.finish())
+                waiting = [q for q in box.pending if q.value is None]
+                for q in waiting[:max(0, len(waiting) - (_TICKET_RING - 3))]:
+                    try:
+                        q.finish()
+                    except RasterWorkspaceOverflow:
+                        pass
                 box.pending.append(pending)
                 return (pending, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
             try:

@@ -525,3 +525,21 @@ def test_backward_prepared_by_the_forward_equals_the_self_contained_backward(gpu
     for k, a in first.items():
         b = hr.leaves[k].grad
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-20), k
+
+
+def test_more_begun_renders_than_ticket_slots_in_one_box(gpu_device):
+    """A render function may begin any number of rasterizer calls before it asks for their pair counts (deferred_count): the library
+    keeps 16 landing slots per thread and device, the wrapper collects its oldest counts before a ticket would go stale."""
+    from materialrefgs_amd.rasterizer import deferred_count
+    scene = make_shell_scene(800, S=0, seed=5, radius_px=6.0, image_size=64)
+    cam = orbit_camera(1, 64, 64)
+    first = HipRender(scene, cam, gpu_device)              # (outside a box: sizes the workspace guess)
+    ref = first.color.detach().clone()
+    renders = []
+    with deferred_count() as box:
+        for _ in range(40):
+            renders.append(HipRender(scene, cam, gpu_device, rs=first.rs))
+    box.finish()
+    for r in renders:
+        assert r.num_rendered == first.num_rendered
+        assert torch.equal(r.color.detach(), ref)

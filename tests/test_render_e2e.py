@@ -320,3 +320,47 @@ def test_deferred_pair_count_and_its_overflow(gpu_device):
     with pytest.raises(rz.RasterWorkspaceOverflow):
         box.finish()
     assert rz._PAIR_GUESS[key] >= R0
+
+
+@pytest.mark.gpu
+def test_overflowed_view_is_an_empty_render_and_the_traced_view_recovers(gpu_device):
+    """What is queued behind a rasterizer whose pair guess was too small runs on a DEFINED image: the tile sort leaves every list empty
+    (csrc/mrgs_binning.hip), so the blend writes the background -- no NaN rays into the tracer, no undefined maps into the shading.  The
+    render function then redoes the view; through the traced view (hierarchy build + mirror rays + trace behind the rasterizer) that
+    costs two views' time, not a walk of garbage rays."""
+    import time
+    from types import SimpleNamespace
+    from materialrefgs_amd import rasterizer as rz
+    from materialrefgs_amd.renderer import render_initial, render_surfel_with_envgs
+    from materialrefgs_amd.surfel_tracing import HardwareRendering
+    from materialrefgs_amd.synthetic import make_surfel_model, orbit_camera
+    dev = gpu_device
+    P, H, W = 20_000, 200, 200
+    pc, env, leaves = make_surfel_model(P, H, dev, radius_px=3.0)
+    cam = orbit_camera(1, H, W).to(dev)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=False, convert_SHs_python=False, use_asg=False)
+    bg = torch.zeros(3, device=dev)
+    key = (dev.index, P, H, W)
+    env.build_mips()
+    with torch.no_grad():
+        good = render_initial(cam, pc, pipe, bg)
+        R0 = rz.LAST_NUM_RENDERED
+        rz._PAIR_GUESS[key] = max(R0 // 3, 1)
+        with rz.deferred_count() as box:
+            bad = render_initial(cam, pc, pipe, bg)
+        torch.cuda.synchronize(dev)
+        for k in ("render", "rend_alpha", "rend_normal", "surf_depth"):
+            assert torch.isfinite(bad[k]).all(), k
+        assert float(bad["rend_alpha"].abs().max()) == 0.0 and float(good["rend_alpha"].max()) > 0.5       # an empty render, not garbage
+        with pytest.raises(rz.RasterWorkspaceOverflow):
+            box.finish()
+        tracer = HardwareRendering().train()
+        opt = SimpleNamespace(indirect=False)
+        ref = render_surfel_with_envgs(tracer, cam, pc, pipe, bg, srgb=False, opt=opt)["render"].clone()
+        torch.cuda.synchronize(dev)
+        rz._PAIR_GUESS[key] = max(R0 // 3, 1)
+        t0 = time.perf_counter()
+        again = render_surfel_with_envgs(tracer, cam, pc, pipe, bg, srgb=False, opt=opt)["render"]
+        torch.cuda.synchronize(dev)
+        assert time.perf_counter() - t0 < 5.0
+        assert torch.isfinite(again).all() and float((again - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
