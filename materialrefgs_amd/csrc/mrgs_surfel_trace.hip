@@ -848,6 +848,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     // rays that run with nobody are only listed here; the second launch gives each a wave of its own
     const bool lone = !done && packet < 0;
     bool deferred = false;                          // this block's packets are the second launch's
+    uint32_t my_row = rec_row;                      // the row of the chunk table this lane's record lives in
     if (only_packet < 0) {
         const uint32_t dm = packets_present & ~1u;
         if (MODE == 0) {
@@ -869,10 +870,19 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                     uint32_t i = 0;
                     for (uint32_t left = dm; left; left &= left - 1) A.defer_list[16 + base + i++] = ((uint32_t)tile << 5) | (uint32_t)__builtin_ctz(left);
                     A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 1] = ST_REC_DEFERRED;
+                    A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 2] = base;     // where its packets' rows start (the block's own row holds no record)
                 }
             }
         } else {
             deferred = dm != 0 && A.defer_list != nullptr && A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 1] == ST_REC_DEFERRED;
+            if (MODE == 2 && deferred) {
+                // The replay needs no walk, so nothing ties it to the forward's one-wave-per-packet split: every lane replays ITS packet's
+                // record (row n_tiles + first listed item of the block + the packet's rank among the block's packets) and the whole block
+                // is one wave again -- 64 busy lanes and one LDS gradient table instead of up to 16 waves of 4-16 rays each.
+                const uint32_t base = A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 2];
+                if (packet >= 1) my_row = A.n_tiles + base + (uint32_t)__popc(dm & ((1u << packet) - 1u));
+                deferred = false;
+            }
         }
     } else {
         packets_present = 1u << only_packet;
@@ -898,12 +908,13 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         int n = 0;
         if (MODE == 2) {
             if (pass >= ST_REC_PASSES - 1) break;
-            const uint32_t chunk = A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + pass];
-            if (chunk >= ST_REC_DEFERRED) break;
-            const uint32_t* src = A.rec_arena + (size_t)chunk * (ST_K * 64) + (tid & 63);
+            const uint32_t chunk = want ? A.rec_chunks[(size_t)my_row * ST_REC_PASSES + pass] : ST_REC_NONE;
+            const bool has = chunk < ST_REC_DEFERRED;                          // (a lane whose packet recorded no further pass: n = 0 ends it below)
+            if (__ballot(has) == 0) break;
+            const uint32_t* src = A.rec_arena + (size_t)(has ? chunk : 0u) * (ST_K * 64) + (tid & 63);
 #pragma unroll
             for (int j = 0; j < ST_K; ++j) {
-                const uint32_t id = src[j * 64];
+                const uint32_t id = has ? src[j * 64] : ST_REC_NONE;
                 kb_id[j][tid] = id;
                 if (id != ST_REC_NONE) n = j + 1;
             }
@@ -1381,6 +1392,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
         return;
     }
     if (A.defer_list == nullptr) return;
+    if (MODE == 2) return;                                     // the replay of listed packets rides in their blocks' waves of the first launch
     const uint32_t listed = A.defer_list[0];
     const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
     const uint32_t stride = ST_PACKET_BLOCKS * (ST_THREADS / 64);
