@@ -844,7 +844,19 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                   fabsf(dz) < 1e30f && (dx != 0.0f || dy != 0.0f || dz != 0.0f));
     const bool no_ray = done;                       // sees the background; written by the first launch
     uint32_t packets_present = 0;
-    const int packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
+    int packet;
+    if (only_packet >= 1) {
+        // a listed packet: the first launch found its rays running together (and its block / quadrant not): its rays are the valid rays of
+        // its lanes -- no need to repeat the ~200 wave-wide reductions of the assignment for the whole block
+        const int ln = tid & 63;
+        const bool tiled = A.ray_width > 0;
+        const int quad = tiled ? ((ln >> 2) & 1) + 2 * (ln >> 5) : ln >> 4;
+        const int sub = tiled ? ((ln >> 1) & 1) + 2 * ((ln >> 4) & 1) : (ln >> 2) & 3;
+        const bool member = only_packet <= 4 ? quad == only_packet - 1 : (quad == ((only_packet - 5) >> 2) && sub == ((only_packet - 5) & 3));
+        packet = (member && !done) ? only_packet : -1;
+    } else {
+        packet = st_assign_packets(A, wide_boxes, wide_vmask, !done, tid & 63, ox, oy, oz, dx, dy, dz, packets_present);
+    }
     // rays that run with nobody are only listed here; the second launch gives each a wave of its own
     const bool lone = !done && packet < 0;
     bool deferred = false;                          // this block's packets are the second launch's
