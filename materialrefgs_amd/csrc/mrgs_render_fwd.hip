@@ -152,10 +152,12 @@ __device__ __forceinline__ void mrgs_redo_pixel(
         // T in front of every hit of the batch: the serial product, one float multiplication per hit in list order -- formed by every
         // lane for itself (lane l multiplies the factors of lanes 0 .. l-1 in that order, 1.0 for a lane without a hit: the same
         // roundings as one running product), so that the dependent chain is 64 multiplications and nothing else
+        // (only the lanes WITH a hit carry a factor other than 1.0, and a multiplication by 1.0 is exact: walking the set bits of the hit
+        // mask gives the same roundings as walking all 63 lanes, in a sixth of the steps)
         const float fac = hit ? oma : 1.0f;
         float Tb = xT;
-#pragma unroll
-        for (int i = 0; i < MRGS_CHUNK - 1; i++) {
+        for (uint64_t left = hm & 0x7FFFFFFFFFFFFFFFull; left != 0ull; left &= left - 1ull) {
+            const int i = __builtin_ctzll(left);
             const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fac), i));
             Tb = Tb * (lane > i ? d : 1.0f);
         }
