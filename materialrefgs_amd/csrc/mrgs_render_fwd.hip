@@ -431,15 +431,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             // (the two transmittance tests as two comparisons each, against the near and the far edge of the band: between them the
             // pixel is marked, and what the fast path does with a marked pixel does not matter)
             const uint64_t below = MRGS_BALLOT(test_T < MRGS_T_MIN - MRGS_T1_EPS);
-            uint64_t t_high = 0ull, t_band = 0ull;
-            if (median_live) {
-                t_high = MRGS_BALLOT(T > 0.5f + MRGS_T2_EPS);
-                t_band = MRGS_BALLOT(T > 0.5f - MRGS_T2_EPS) & ~t_high;
-            }
             // (a T (1 - alpha) inside the band of the 1e-4 test is not looked for here: it does not end the pixel -- `below` is the near
             // edge of the band --, becomes the pixel's T, and nothing but a terminating entry can follow it: the pixel's FINAL T lies in
             // the band exactly when some entry's did, and is tested once, after the list)
-            redo |= ambiguous | (ok & t_band);
+            redo |= ambiguous;
             done |= ok & below;                               // forward.cu:400-404: the pixel stops BEFORE blending this entry
             const uint64_t upd_mask = ok & ~below;
             const bool upd = MRGS_LANES(upd_mask);
@@ -455,7 +450,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             M1 = fmaf(m_, w, M1);
             M2 = fmaf(mm, w, M2);
             const uint32_t contributor = (uint32_t)(base + j + 1);
-            if (median_live) {
+            if (median_live) {       // (ONE block for everything the T > 0.5 test feeds: T is still the transmittance in front of this entry)
+                const uint64_t t_high = MRGS_BALLOT(T > 0.5f + MRGS_T2_EPS);
+                const uint64_t t_band = MRGS_BALLOT(T > 0.5f - MRGS_T2_EPS) & ~t_high;
+                redo |= ok & t_band;
                 const bool med = MRGS_LANES(upd_mask & t_high);
                 median_depth = med ? depth : median_depth;
                 median_contributor = med ? contributor : median_contributor;
