@@ -242,6 +242,13 @@ int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* f
 int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* g_specular, const float* g_direct_light,
                                  const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
                                  float* g_roughness, void* stream);
+/* The same backward as render_surfel needs it (ABI 6): the per-pixel gradients leave as the gradient of the rasterizer's [8,H,W]
+ * feature map -- g_features = (g_refl + g_refl_composite, g_roughness, g_albedo[3], 0, 0, 0), channel-major, fully written -- and as
+ * the TOTAL alpha gradient g_alpha[H,W] = g_alpha_composite + this kernel's, with mrgs_surfel_composite_backward's g_refl / g_alpha
+ * as the two inputs (what mrgs_surfel_feature_grads assembles from five maps in a launch of its own).  g_normal[H,W,3] as above. */
+int mrgs_shade_specular_backward_features(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* g_specular,
+                                          const float* g_direct_light, const float* g_specular_weight, const float* g_refl_composite,
+                                          const float* g_alpha_composite, float* g_normal, float* g_features, float* g_alpha, void* stream);
 
 /* ---- environment prefilter: EnvLight.build_mips (scene/light.py:72-86) ------------------------------------------------
  * renderutils' specular_cubemap / diffuse_cubemap (scene/renderutils/c_src/cubemap.cu:110-354, ops.py:390-459) are fixed linear

@@ -205,6 +205,8 @@ SYMBOLS = {
                                                    c_void_p, c_void_p]),
     "mrgs_shade_specular_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_shade_specular_backward_features": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
+                                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_debug_export": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p]),
     "mrgs_set_profiling": (ctypes.c_int, [c_int32]),

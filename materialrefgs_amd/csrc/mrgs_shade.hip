@@ -591,7 +591,11 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
     EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha, Map refl, Map rough, const float* __restrict__ lut, int lres,
     const float* __restrict__ g_specular, const float* __restrict__ g_direct, const float* __restrict__ g_weight,
     float* __restrict__ g_albedo /*[H,W,3]*/, float* __restrict__ g_normal /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/,
-    float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/, int tiles_x, int ntiles, int lds_floats)
+    float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/, int tiles_x, int ntiles, int lds_floats,
+    // render_surfel's form (g_features != nullptr): the per-pixel gradients leave as the rasterizer's [8,H,W] feature-map gradient
+    // (refl + the compositing backward's share, roughness, albedo, zeros for the indirect radiance) and as the TOTAL alpha gradient
+    // (+ the compositing backward's) -- what mrgs_surfel_feature_grads would assemble from five maps in a launch of its own
+    float* __restrict__ g_features, const float* __restrict__ g_refl_composite, const float* __restrict__ g_alpha_composite)
 {
     __shared__ float s_grad[MRGS_SHADE_LDS_FLOATS];
     __shared__ unsigned s_keys[MRGS_SHADE_HASH_SIZE];
@@ -661,11 +665,19 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
         const float g_rough_v = (p.v_in ? gfg0 * p.dfg_dv[0] + gfg1 * p.dfg_dv[1] : 0.f) + g_level * dl;
         if (valid) {
             g_normal[pix * 3] = gn.x; g_normal[pix * 3 + 1] = gn.y; g_normal[pix * 3 + 2] = gn.z;
+            if (g_features != nullptr) {
+                g_alpha[pix] = g_alpha_composite[pix] + ga;
+                g_features[pix] = g_refl_composite[pix] + gm;
+                g_features[HW + pix] = g_rough_v;
 #pragma unroll
-            for (int c = 0; c < 3; c++) g_albedo[pix * 3 + c] = galb[c];
-            g_alpha[pix] = ga;
-            g_refl[pix] = gm;
-            g_rough[pix] = g_rough_v;
+                for (int c = 0; c < 3; c++) { g_features[(2 + c) * HW + pix] = galb[c]; g_features[(5 + c) * HW + pix] = 0.0f; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) g_albedo[pix * 3 + c] = galb[c];
+                g_alpha[pix] = ga;
+                g_refl[pix] = gm;
+                g_rough[pix] = g_rough_v;
+            }
         }
         env_scatter_tile(m, grad_mask, A, s, tp, gL);
         // between tiles: a hash table more than half full goes out
@@ -1066,15 +1078,16 @@ int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* f
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
-int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
-                                 const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
-                                 float* g_roughness, void* stream)
+static int shade_specular_backward_impl(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
+                                        const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
+                                        float* g_roughness, float* g_features, const float* g_refl_composite, const float* g_alpha_composite,
+                                        void* stream)
 {
     EnvMips m;
     int rc = make_mips(mips, m);
     if (rc) return rc;
-    if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || !g_albedo || !g_normal || !g_alpha || !g_refl || !g_roughness)
-        return MRGS_E_BAD_ARG;
+    if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || !g_normal || !g_alpha) return MRGS_E_BAD_ARG;
+    if (g_features ? (!g_refl_composite || !g_alpha_composite) : (!g_albedo || !g_refl || !g_roughness)) return MRGS_E_BAD_ARG;
     // the scatter keys pack (level << 24 | texel index): a level with 6 res^2 >= 2^24 texels (res >= 1673) would alias into the level bits
     for (int l = 0; l < m.n; l++)
         if (m.grad[l] != nullptr && 6ll * m.res[l] * m.res[l] >= (1ll << 24)) return MRGS_E_UNSUPPORTED;
@@ -1100,8 +1113,26 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
     const dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(MRGS_SHADE_BWD_THREADS);
     hipLaunchKernelGGL(shade_specular_bwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
                        to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, g_specular, g_direct_light,
-                       g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness, tiles_x, ntiles, lds_floats);
+                       g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness, tiles_x, ntiles, lds_floats, g_features, g_refl_composite,
+                       g_alpha_composite);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
+                                 const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
+                                 float* g_roughness, void* stream)
+{
+    return shade_specular_backward_impl(mips, fr, g_specular, g_direct_light, g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness,
+                                        nullptr, nullptr, nullptr, stream);
+}
+
+int mrgs_shade_specular_backward_features(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
+                                          const float* g_specular_weight, const float* g_refl_composite, const float* g_alpha_composite,
+                                          float* g_normal, float* g_features, float* g_alpha, void* stream)
+{
+    if (!g_features) return MRGS_E_BAD_ARG;
+    return shade_specular_backward_impl(mips, fr, g_specular, g_direct_light, g_specular_weight, nullptr, g_normal, g_alpha, nullptr, nullptr,
+                                        g_features, g_refl_composite, g_alpha_composite, stream);
 }
 
 int mrgs_cubemap_filter_count(int32_t res, int32_t kind, float roughness, float cos_cutoff, uint32_t* row_count, float* row_wsum, void* stream)
