@@ -235,6 +235,11 @@ typedef struct MrgsShadeFrame {
  * specular[3,H,W] = direct_light * alpha * specular_weight, direct_light[3,H,W], specular_weight[H,W,3]. */
 int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, float* specular, float* direct_light,
                                 float* specular_weight, void* stream);
+/* ... and render_surfel's compositing in the same pass (ABI 6; mrgs_surfel_composite_forward's arithmetic on the specular just computed):
+ * diffuse[3,H,W] = (1 - refl) base_color, render[3,H,W] = [linear_to_srgb](diffuse + specular) + bg (1 - alpha). */
+int mrgs_shade_specular_forward_composite(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* base_color, const float* bg,
+                                          int32_t srgb, float* specular, float* direct_light, float* specular_weight, float* render,
+                                          float* diffuse, void* stream);
 /* Gradients w.r.t. the five maps (dense, fully written: g_albedo[H,W,3], g_normal[H,W,3], g_alpha[H,W], g_refl[H,W],
  * g_roughness[H,W]) and, through mips->grad, w.r.t. the cubemap texels.  Any of the three upstream gradients may be NULL.
  * A level that receives gradients must have fewer than 2^24 texels (res < 1673; the reference's EnvLight uses 16 ... 128, at most

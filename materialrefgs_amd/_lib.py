@@ -203,6 +203,8 @@ SYMBOLS = {
                                                    c_void_p]),
     "mrgs_shade_specular_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
                                                    c_void_p, c_void_p]),
+    "mrgs_shade_specular_forward_composite": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p, c_int32,
+                                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_shade_specular_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_shade_specular_backward_features": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,

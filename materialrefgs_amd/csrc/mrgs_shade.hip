@@ -549,10 +549,19 @@ __device__ __forceinline__ void shade_setup(const ShadeCamS& cam, int x, int y, 
     lut_fetch(lut, lres, p.u, p.v, p.fg, p.dfg_du, p.dfg_dv);
 }
 
+__device__ __forceinline__ float shade_lin2srgb(float x)        // linear_to_srgb (utils/general_utils / mrgs_maps.hip: the same expression)
+{
+    const float eps = 1.1920928955078125e-07f;
+    return x <= 0.0031308f ? (323.0f / 25.0f) * x : (211.0f * powf(fmaxf(x, eps), 5.0f / 12.0f) - 11.0f) / 200.0f;
+}
+
 __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha,
                                                                  Map refl, Map rough, const float* __restrict__ lut, int lres,
                                                                  float* __restrict__ specular /*[3,H,W]*/, float* __restrict__ direct /*[3,H,W]*/,
-                                                                 float* __restrict__ weight /*[H,W,3]*/)
+                                                                 float* __restrict__ weight /*[H,W,3]*/,
+                                                                 // render_surfel's compositing in the same pass (render != nullptr; mrgs_surfel_composite_forward)
+                                                                 const float* __restrict__ base /*[3,H,W]*/, const float* __restrict__ bg, int srgb,
+                                                                 float* __restrict__ render /*[3,H,W]*/, float* __restrict__ diffuse /*[3,H,W]*/)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
@@ -573,7 +582,15 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
         const float wgt = (0.04f * (1.f - p.refl) + p.albedo[c] * p.refl) * p.fg[0] + p.fg[1];
         direct[c * HW + pix] = light;
         weight[pix * 3 + c] = wgt;
-        specular[c * HW + pix] = light * p.alpha * wgt;
+        const float spec = light * p.alpha * wgt;
+        specular[c * HW + pix] = spec;
+        if (render != nullptr) {     // diffuse = (1 - refl) base, render = [srgb](diffuse + specular) + bg (1 - alpha)  (gaussian_renderer/__init__.py:436-445)
+            const float d = (1.0f - p.refl) * base[c * HW + pix];
+            float v = d + spec;
+            if (srgb) v = shade_lin2srgb(v);
+            render[c * HW + pix] = v + bg[c] * (1.0f - p.alpha);
+            diffuse[c * HW + pix] = d;
+        }
     }
 }
 
@@ -1061,8 +1078,8 @@ int mrgs_envmap_lookup_backward(const MrgsEnvMips* mips, int64_t N, const float*
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
-int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, float* specular, float* direct_light, float* specular_weight,
-                                void* stream)
+static int shade_specular_forward_impl(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, float* specular, float* direct_light, float* specular_weight,
+                                       const float* base_color, const float* bg, int srgb, float* render, float* diffuse, void* stream)
 {
     EnvMips m;
     int rc = make_mips(mips, m);
@@ -1074,8 +1091,22 @@ int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* f
     cam.R = fr->R; cam.T = fr->T;
     const dim3 grid((fr->W + 63) / 64, (fr->H + 3) / 4), block(256);
     hipLaunchKernelGGL(shade_specular_fwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
-                       to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, specular, direct_light, specular_weight);
+                       to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, specular, direct_light, specular_weight,
+                       base_color, bg, srgb, render, diffuse);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, float* specular, float* direct_light, float* specular_weight,
+                                void* stream)
+{
+    return shade_specular_forward_impl(mips, fr, specular, direct_light, specular_weight, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int mrgs_shade_specular_forward_composite(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* base_color, const float* bg, int32_t srgb,
+                                          float* specular, float* direct_light, float* specular_weight, float* render, float* diffuse, void* stream)
+{
+    if (!base_color || !bg || !render || !diffuse) return MRGS_E_BAD_ARG;
+    return shade_specular_forward_impl(mips, fr, specular, direct_light, specular_weight, base_color, bg, srgb ? 1 : 0, render, diffuse, stream);
 }
 
 static int shade_specular_backward_impl(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
