@@ -1020,6 +1020,25 @@ __device__ __forceinline__ float mip_block(const float* __restrict__ in, int N0,
     }
 }
 struct MipOuts { float* o[3]; };
+// Three levels with FOUR lanes per texel of the coarsest one (a DPP quad): each lane averages a 4x4 quarter of the texel's 8x8 block
+// bottom-up (16 loads in flight instead of 64 behind each other), lane 0 of the quad folds the four level-2 values in the level-by-level
+// kernel's order ((p00 + p01) + p10) + p11 -- bit-identical to it (10 -> 5 us for the 128..16 chain).
+__global__ void __launch_bounds__(256) cubemap_mip_chain3_fwd_kernel(int N0, const float* __restrict__ in, MipOuts outs)
+{
+    const int Nc = N0 >> 3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < 6 * Nc * Nc * 3 * 4;
+    const int q = t & 3, i = live ? t >> 2 : 0;
+    const int c = i % 3, x = (i / 3) % Nc, y = (i / (3 * Nc)) % Nc, s = i / (3 * Nc * Nc);
+    float* const o[3] = {outs.o[0], outs.o[1], outs.o[2]};
+    // my level-2 texel: (2 y + q / 2, 2 x + q % 2); its level-1 texels and their level-0 blocks below
+    const int y2 = 2 * y + (q >> 1), x2 = 2 * x + (q & 1);
+    const float v2 = live ? mip_block<2>(in, N0, s, y2, x2, c, o) : 0.0f;       // writes levels 1 and 2
+    const float p01 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0x55, 0xf, 0xf, false));   // quad_perm [1,1,1,1]
+    const float p10 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0xAA, 0xf, 0xf, false));   // [2,2,2,2]
+    const float p11 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0xFF, 0xf, 0xf, false));   // [3,3,3,3]
+    if (live && q == 0) o[2][((size_t)(s * Nc + y) * Nc + x) * 3 + c] = 0.25f * (v2 + p01 + p10 + p11);
+}
 __global__ void __launch_bounds__(256) cubemap_mip_chain_fwd_kernel(int N0, int steps, const float* __restrict__ in, MipOuts outs)
 {
     const int Nc = N0 >> steps;
@@ -1252,7 +1271,8 @@ int mrgs_cubemap_mip_chain_forward(int32_t res_in, int32_t n_steps, const float*
             o.o[k] = outs[done + k];
         }
         const int Nc = res >> steps, n = 6 * Nc * Nc * 3;
-        hipLaunchKernelGGL(cubemap_mip_chain_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, res, steps, src, o);
+        if (steps == 3) hipLaunchKernelGGL(cubemap_mip_chain3_fwd_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, st, res, src, o);
+        else hipLaunchKernelGGL(cubemap_mip_chain_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, res, steps, src, o);
         src = outs[done + steps - 1];
         res = Nc;
         done += steps;

@@ -556,3 +556,25 @@ def test_surfel_factored_sh_exchange_equals_the_dense_sum(gpu_device):
     for n, t in zip(names, got):
         scale = float(dense[n].abs().max())
         assert float((t - dense[n]).abs().max()) < 3e-5 * scale, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,steps", [(128, 3), (64, 3), (32, 2), (16, 1)])
+def test_mip_chain_in_one_launch_equals_the_level_by_level_kernel(gpu_device, res, steps):
+    """mrgs_cubemap_mip_chain_forward (three levels per launch; four lanes per coarsest texel for a full three-level chain) writes the very
+    values mrgs_cubemap_mip_forward produces level by level: the same 2x2 sums in the same order."""
+    import ctypes
+    from materialrefgs_amd import _lib
+    from materialrefgs_amd.shading import _mip_forward
+    g = torch.Generator().manual_seed(res + steps)
+    base = torch.randn(6, res, res, 3, generator=g).to(gpu_device)
+    ref, cur = [], base
+    for _ in range(steps):
+        cur = _mip_forward(cur)
+        ref.append(cur)
+    outs = [torch.empty_like(r) for r in ref]
+    ptrs = (ctypes.c_void_p * steps)(*[t.data_ptr() for t in outs])
+    _lib.check(_lib.lib().mrgs_cubemap_mip_chain_forward(res, steps, base.data_ptr(), ptrs, _lib.stream_ptr(gpu_device)))
+    torch.cuda.synchronize(gpu_device)
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
