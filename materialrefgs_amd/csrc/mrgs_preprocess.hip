@@ -198,6 +198,42 @@ __device__ __forceinline__ void wave_rows_store_split(const float* __restrict__ 
     }
 }
 
+// Split layout, the common case (64 rows, 15 higher-order coefficients = 45 floats a row, 16-byte aligned tensors): NO transposition.
+// A row of the DC tensor is 3 floats and a row of the rest tensor 45 -- both strides are odd, so a verbatim copy of the wave's two
+// contiguous runs (768 B + 11 520 B) already gives every lane a bank-conflict-free row of its own: lane l reads word 3 l + c resp.
+// 45 l + c, 32 lanes on 32 banks.  The copy is 16-byte global accesses against linear ds_write_b128 / ds_read_b128.  (Rounds 1-4 laid
+// the rows out at stride 49 as the unsplit tensor's 48-float rows need, and the 16-byte pieces of 45-float rows then landed 4 words
+// apart on 8 of the 32 banks: 4.7-way conflicts on the wave's 96 transposing ds instructions, 3.4 M conflict cycles per launch of the
+// backward at P = 300 k -- tools/lds_bank_model.py.)  Tile: [0, 192) the DC rows, [192, 3072) the rest rows.
+#define SH_LIN_REST 192
+__device__ __forceinline__ bool wave_rows_linear_ok(const void* dc, const void* rest, int nrows, int Lr)
+{
+    return Lr == 45 && nrows == 64 && ((((uintptr_t)dc) | ((uintptr_t)rest)) & 15u) == 0;
+}
+__device__ __forceinline__ void wave_rows_load_linear(float* __restrict__ tile, const float* __restrict__ dc, const float* __restrict__ rest, int lane)
+{
+    const float4* dc4 = reinterpret_cast<const float4*>(dc);            // 48 float4
+    const float4* r4 = reinterpret_cast<const float4*>(rest);           // 720 float4
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 d = lane < 48 ? dc4[lane] : zero;
+    float4 v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = (k * 64 + lane < 720) ? r4[k * 64 + lane] : zero;
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    if (lane < 48) t4[lane] = d;
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        if (k * 64 + lane < 720) t4[SH_LIN_REST / 4 + k * 64 + lane] = v[k];
+}
+__device__ __forceinline__ void wave_rows_store_linear(const float* __restrict__ tile, float* __restrict__ dc, float* __restrict__ rest, int lane)
+{
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    if (lane < 48) reinterpret_cast<float4*>(dc)[lane] = t4[lane];
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+        if (k * 64 + lane < 720) reinterpret_cast<float4*>(rest)[k * 64 + lane] = t4[SH_LIN_REST / 4 + k * 64 + lane];
+}
+
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, int W, int H, int tiles_x, int tiles_y, float scale_modifier, const float* __restrict__ means3D,
@@ -210,14 +246,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
 {
     // SPLIT (shs = DC [P,1,3], shs_rest = [P,M-1,3]): the rows of the two tensors are staged through a per-wave LDS tile in the unsplit
     // row layout; 180-byte rows cannot be fetched per lane with 16-byte loads the way the 192-byte rows of the unsplit tensor are
-    __shared__ float s_sh[SPLIT ? 4 * 64 * SH_LDS_STRIDE : 1];
+    __shared__ __attribute__((aligned(16))) float s_sh[SPLIT ? 4 * 64 * SH_LDS_STRIDE : 1];
+    bool sh_linear = false;                 // (wave-uniform) the wave's tile is the verbatim copy: wave_rows_load_linear
     if (SPLIT) {
         const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
         const int row0 = blockIdx.x * blockDim.x + wave_ * 64;
         const int nrows = min(64, P - row0);
-        if (nrows > 0 && colors_precomp == nullptr)
-            wave_rows_load_split(s_sh + wave_ * 64 * SH_LDS_STRIDE, shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * (M - 1) * 3, nrows, (M - 1) * 3,
-                                 lane_);
+        if (nrows > 0 && colors_precomp == nullptr) {
+            sh_linear = wave_rows_linear_ok(shs, shs_rest, nrows, (M - 1) * 3);
+            if (sh_linear) wave_rows_load_linear(s_sh + wave_ * 64 * SH_LDS_STRIDE, shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * 45, lane_);
+            else wave_rows_load_split(s_sh + wave_ * 64 * SH_LDS_STRIDE, shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * (M - 1) * 3, nrows, (M - 1) * 3,
+                                      lane_);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -342,8 +382,11 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
                 }
             };
             if (SPLIT) {
-                const float* row = s_sh + (size_t)threadIdx.x * SH_LDS_STRIDE;
-                shade([&](int i, int c) { return row[i * 3 + c]; });
+                const float* wt = s_sh + (threadIdx.x >> 6) * 64 * SH_LDS_STRIDE;       // this wave's tile
+                const int ln = threadIdx.x & 63;
+                const float* dcp = sh_linear ? wt + ln * 3 : wt + ln * SH_LDS_STRIDE;
+                const float* row = sh_linear ? wt + SH_LIN_REST + ln * 45 - 3 : wt + ln * SH_LDS_STRIDE;
+                shade([&](int i, int c) { return i == 0 ? dcp[c] : row[i * 3 + c]; });
             } else if (M == 16) {
                 float row[48];
                 const float4* sh4 = reinterpret_cast<const float4*>(sh);   // 192-byte rows of a 16-byte aligned tensor
@@ -479,7 +522,7 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations, const float* __restrict__ shs_rest, float* __restrict__ dL_dsh_rest)
 {
-    __shared__ float s_sh[MRGS_PREB_WAVES][64 * SH_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_sh[MRGS_PREB_WAVES][64 * SH_LDS_STRIDE];
     const int idx_ = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = M * 3;
@@ -487,9 +530,13 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
     const bool sh_staged = M > 0 && L <= SH_ROW_MAX;
     const int row0 = blockIdx.x * blockDim.x + wave * 64;
     const int nrows = min(64, P - row0);
+    // (wave-uniform) split layout in its common shape: the tile is the verbatim copy of the two tensors' runs (wave_rows_load_linear)
+    const bool sh_linear = sh_staged && shs != nullptr && shs_rest != nullptr && dL_dsh_rest != nullptr &&
+                           wave_rows_linear_ok(shs, shs_rest, nrows, L - 3) && wave_rows_linear_ok(dL_dsh, dL_dsh_rest, nrows, L - 3);
     if (sh_staged && shs != nullptr && nrows > 0) {
-        // (shs_rest: split layout, shs = DC rows; the tile holds the rows in the unsplit layout either way)
-        if (shs_rest != nullptr) wave_rows_load_split(s_sh[wave], shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * (L - 3), nrows, L - 3, lane);
+        // (shs_rest: split layout, shs = DC rows; otherwise the tile holds the rows in the unsplit layout either way)
+        if (sh_linear) wave_rows_load_linear(s_sh[wave], shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * 45, lane);
+        else if (shs_rest != nullptr) wave_rows_load_split(s_sh[wave], shs + (size_t)row0 * 3, shs_rest + (size_t)row0 * (L - 3), nrows, L - 3, lane);
         else wave_rows_load(s_sh[wave], shs + (size_t)row0 * L, nrows, L, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -637,10 +684,13 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
 
     // SH backward (backward.cu:22-141), also zero-fills dL_dsh for culled gaussians / unused degrees
     if (M > 0) {
+        // this lane's row: coefficient 0 (DC) at dsh0[c], coefficient i >= 1 at dsh[i * 3 + c] (one pointer unless the tile is linear)
         float* tile = &s_sh[wave][lane * SH_LDS_STRIDE];
-        float* dsh = sh_staged ? tile : dL_dsh + (size_t)idx * M * 3;
+        float* dsh = sh_linear ? &s_sh[wave][SH_LIN_REST + lane * 45 - 3] : sh_staged ? tile : dL_dsh + (size_t)idx * M * 3;
+        float* dsh0 = sh_linear ? &s_sh[wave][lane * 3] : dsh;
         if (live && shs != nullptr) {
-            const float* sh = sh_staged ? tile : shs + (size_t)idx * M * 3;
+            const float* sh = sh_staged ? dsh : shs + (size_t)idx * M * 3;
+            const float* sh0 = sh_staged ? dsh0 : sh;
             const f3 dir_orig = {means3D[3 * (size_t)idx] - campos[0], means3D[3 * (size_t)idx + 1] - campos[1],
                                  means3D[3 * (size_t)idx + 2] - campos[2]};
             const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
@@ -655,9 +705,9 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
                 // the coefficients of this channel are read before its gradients overwrite them (in-place tile)
                 float shv[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++) shv[i] = (i < ncoef && i < M) ? sh[i * 3 + c] : 0.0f;
+                for (int i = 0; i < 16; i++) shv[i] = (i < ncoef && i < M) ? (i == 0 ? sh0[c] : sh[i * 3 + c]) : 0.0f;
 #define SH(i) shv[i]
-#define DSH(i) dsh[(i) * 3 + c]
+#define DSH(i) ((i) == 0 ? dsh0 : dsh + (i) * 3)[c]
                 float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
                 DSH(0) = kSH_C0 * dRGB[c];
                 if (D > 0) {
@@ -702,20 +752,22 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
 #undef DSH
                 ddx[c] = dRGBdx; ddy[c] = dRGBdy; ddz[c] = dRGBdz;
             }
-            for (int i = ncoef; i < M; i++) { dsh[i * 3] = 0.0f; dsh[i * 3 + 1] = 0.0f; dsh[i * 3 + 2] = 0.0f; }
+            for (int i = ncoef; i < M; i++) { dsh[i * 3] = 0.0f; dsh[i * 3 + 1] = 0.0f; dsh[i * 3 + 2] = 0.0f; }      // (ncoef >= 1: never the DC row)
             const f3 dd = {(ddx[0] * dRGB[0] + ddx[1] * dRGB[1]) + ddx[2] * dRGB[2],
                            (ddy[0] * dRGB[0] + ddy[1] * dRGB[1]) + ddy[2] * dRGB[2],
                            (ddz[0] * dRGB[0] + ddz[1] * dRGB[1]) + ddz[2] * dRGB[2]};
             const f3 dm = dnormvdv(dir_orig, dd);
             dm3[0] += dm.x; dm3[1] += dm.y; dm3[2] += dm.z;
         } else if (in_range || sh_staged) {
-            for (int i = 0; i < M * 3; i++) dsh[i] = 0.0f;
+            for (int i = 0; i < 3; i++) dsh0[i] = 0.0f;
+            for (int i = 3; i < M * 3; i++) dsh[i] = 0.0f;
         }
         if (sh_staged) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (nrows > 0) {
-                if (dL_dsh_rest != nullptr) wave_rows_store_split(s_sh[wave], dL_dsh + (size_t)row0 * 3, dL_dsh_rest + (size_t)row0 * (L - 3), nrows, L - 3, lane);
+                if (sh_linear) wave_rows_store_linear(s_sh[wave], dL_dsh + (size_t)row0 * 3, dL_dsh_rest + (size_t)row0 * 45, lane);
+                else if (dL_dsh_rest != nullptr) wave_rows_store_split(s_sh[wave], dL_dsh + (size_t)row0 * 3, dL_dsh_rest + (size_t)row0 * (L - 3), nrows, L - 3, lane);
                 else wave_rows_store(s_sh[wave], dL_dsh + (size_t)row0 * L, nrows, L, lane);
             }
         }

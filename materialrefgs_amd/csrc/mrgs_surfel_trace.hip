@@ -53,6 +53,9 @@ namespace {
 #ifndef ST_GROUP_GATHER
 #define ST_GROUP_GATHER 1                 // packets smaller than the wave test 64 / R candidates per step (st_gather_group); 0: one per step (A/B)
 #endif
+#ifndef ST_REPLAY_MERGE
+#define ST_REPLAY_MERGE 1                 // the replaying backward merges neighbouring lanes that hold the same surfel BEFORE the LDS collection; 0: after (A/B)
+#endif
 #ifndef ST_FWD_WAVES
 #define ST_FWD_WAVES 4                    // waves per SIMD the forward walking kernels are compiled for (register budget 512 / that)
 #endif
@@ -239,14 +242,21 @@ struct StArgs {
     // the forward's record of what every wave gathered, pass by pass (ids, [slot][lane] like the LDS buffer): the backward replays it
     // instead of walking the hierarchy again.  hdr[0] chunks drawn from the pool, hdr[1] overflow flag (then the backward traces).
     uint32_t *rec_hdr, *rec_chunks, *rec_arena;
-    unsigned long long* lone_rec;         // [lone_cap][ST_LONE_REC_PASSES][ST_K] sorted (t, id) keys of the rays traced one per wavefront, or nullptr
-    uint32_t lone_cap;
+    unsigned long long* lone_rec;         // [8][lone_cap][ST_LONE_REC_PASSES][ST_K] sorted (t, id) keys of the rays traced one per wavefront, or nullptr
+    uint32_t lone_cap;                    // per region
     uint32_t rec_pool;                    // chunks in the shared pool (behind the n_tiles * ST_REC_STATIC owned ones)
     uint32_t rec_static;                  // n_tiles * ST_REC_STATIC: where the pool starts
     uint32_t n_tiles;                     // waves of the first launch (one 8x8 block of rays each)
-    uint32_t* defer_list;                 // [0] count, [16..] (tile << 5 | packet): the packets traced by the second launch, one per wave
-    uint32_t defer_cap;
-    uint32_t* lone_list;                  // [0] count, [16..] indices of the rays that walk alone (behind the per-ray state)
+    // Both lists are kept per REGION: block b of a launch runs on XCD b % 8 (observed dispatch order -- used for speed only, nothing below is
+    // wrong under another placement), the first launch gives XCD x the x-th eighth of the blocks of rays in a blocky order (st_tile_of_wave),
+    // and what it lists goes to sub-list x, which the second launch hands to the blocks with b % 8 == x again: the waves resident on one
+    // XCD at a time trace neighbouring rays and share the subtrees and leaf records their L2 holds (round 5; before, consecutive blocks of
+    // rays went round the eight L2s and every L2 saw the whole hierarchy: 4.2 GB fetched by the second launch of a C4-size view).
+    uint32_t* defer_list;                 // [x] count of region x, [16 + x * defer_cap ..] (tile << 5 | packet): the packets traced by the second launch, one per wave
+    uint32_t defer_cap;                   // per region
+    uint32_t* lone_list;                  // [x] count of region x, [16 + x * lone_list_cap ..] indices of the rays that walk alone (behind the per-ray state)
+    uint32_t lone_list_cap;               // per region (= the rays of a region: never full)
+    uint32_t region_blocks;               // blocks of the first launch per region
     float cone, cone_quad, cone_group;    // 1 - cos of the half-angle within which the directions of a block / quadrant / 2x2 group must stay
     const float4* attr;                   // [P][2]: (rgb, others.x) (others.y, -, -, -)
     float bg[3];
@@ -798,7 +808,8 @@ constexpr uint32_t ST_REC_DEFERRED = 0xFFFFFFFEu;   // in the last slot of a blo
 template <int MODE>
 __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
                                               const unsigned long long* __restrict__ wide_vmask, uint32_t (*kb_id)[ST_THREADS],
-                                              float (*kb_t)[ST_THREADS], uint32_t* kb_n, uint32_t* tab, int tid, int64_t tile, int only_packet, uint32_t rec_row)
+                                              float (*kb_t)[ST_THREADS], uint32_t* kb_n, uint32_t* tab, int tid, int64_t tile, int only_packet, uint32_t rec_row,
+                                              uint32_t region)
 {
     constexpr bool BWD = MODE != 0;
     int64_t r = tile * 64 + (tid & 63);
@@ -868,16 +879,17 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
             if (lm) {
                 const int first = __builtin_ctzll(lm), lane = tid & 63;
                 uint32_t base = 0;
-                if (lane == first) base = atomicAdd(A.lone_list, (uint32_t)__popcll(lm));
+                if (lane == first) base = atomicAdd(A.lone_list + region, (uint32_t)__popcll(lm));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-                if (lone) A.lone_list[16 + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                if (lone) A.lone_list[16 + (size_t)region * A.lone_list_cap + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
             }
             if (dm != 0 && A.defer_list != nullptr) {
                 const uint32_t cnt = (uint32_t)__popc(dm);
                 uint32_t base = 0;
-                if ((tid & 63) == 0) base = atomicAdd(A.defer_list, cnt);
+                if ((tid & 63) == 0) base = atomicAdd(A.defer_list + region, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                deferred = base + cnt <= A.defer_cap;                      // else: the list is full and the block walks its packets itself
+                deferred = base + cnt <= A.defer_cap;                      // else: the region's list is full and the block walks its packets itself
+                base += region * A.defer_cap;                              // the item's index over all regions (its row of the chunk table: n_tiles + index)
                 if (deferred && (tid & 63) == 0) {
                     uint32_t i = 0;
                     for (uint32_t left = dm; left; left &= left - 1) A.defer_list[16 + base + i++] = ((uint32_t)tile << 5) | (uint32_t)__builtin_ctz(left);
@@ -1018,25 +1030,31 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                     go[0] += dpx - dnum * nx; go[1] += dpy - dnum * ny; go[2] += dpz - dnum * nz;
                     gdir[0] += t * dpx + dden * nx; gdir[1] += t * dpy + dden * ny; gdir[2] += t * dpz + dden * nz;
                 }
-                bool placed = false;
-                if (MODE == 2 && act) {
-                    int slot = (int)(((id * 2654435761u) >> 16) % (uint32_t)ST_TAB);
-                    for (int probe = 0; probe < 4 && !placed; ++probe) {
-                        const uint32_t old = atomicCAS(&tab[slot * 19 + 18], ST_REC_NONE, id);
-                        if (old == ST_REC_NONE || old == id) placed = true;
-                        else slot = slot + 1 == ST_TAB ? 0 : slot + 1;
-                    }
-                    if (placed) {
-                        float* row = reinterpret_cast<float*>(tab) + slot * 19;
-#pragma unroll
-                        for (int k = 0; k < 18; ++k) atomicAdd(row + k, gv[k]);
-                    }
-                }
-                if (MODE != 2 || __ballot(act && !placed) != 0) {
-                const bool act_g = act && !placed;                          // (what is collected in LDS takes no part in the merge below)
                 // merge with the horizontal, then the vertical neighbour of the 8x8 block when both hold the same surfel: the lower
-                // lane of a pair carries the sum, the upper one is done (DPP moves: quad_perm [1,0,3,2] = lane ^ 1, [2,3,0,1] = lane ^ 2, row_ror:8 = lane ^ 8)
-                bool live = act_g;
+                // lane of a pair carries the sum, the upper one is done (DPP moves: quad_perm [1,0,3,2] = lane ^ 1, [2,3,0,1] = lane ^ 2, row_ror:8 = lane ^ 8).
+                // The replay merges FIRST and collects in LDS what is left (ST_REPLAY_MERGE, round 5): neighbouring rays hold the same surfel
+                // at the same rank more often than not, and up to eight lanes adding to one LDS row are eight serialised ds_add_f32 per term
+                // (688 k / 2.78 M conflict cycles per launch at C3 / C4 size with the LDS pipe the busiest unit of the kernel).
+                bool live = act;
+                bool placed = false;
+                auto collect = [&]() {
+                    if (MODE == 2 && live) {
+                        int slot = (int)(((id * 2654435761u) >> 16) % (uint32_t)ST_TAB);
+                        for (int probe = 0; probe < 4 && !placed; ++probe) {
+                            const uint32_t old = atomicCAS(&tab[slot * 19 + 18], ST_REC_NONE, id);
+                            if (old == ST_REC_NONE || old == id) placed = true;
+                            else slot = slot + 1 == ST_TAB ? 0 : slot + 1;
+                        }
+                        if (placed) {
+                            float* row = reinterpret_cast<float*>(tab) + slot * 19;
+#pragma unroll
+                            for (int k = 0; k < 18; ++k) atomicAdd(row + k, gv[k]);
+                        }
+                    }
+                };
+                if (!ST_REPLAY_MERGE) collect();
+                if (MODE != 2 || ST_REPLAY_MERGE || __ballot(act && !placed) != 0) {
+                live = act && !placed;                                      // (what is collected in LDS already takes no part in the merge below)
                 {
                     const uint32_t pid = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, 0xB1, 0xf, 0xf, true);
                     const bool plive = __builtin_amdgcn_update_dpp(0, (int)live, 0xB1, 0xf, 0xf, true) != 0;
@@ -1076,7 +1094,8 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                     }
                     live = live && !(merge && !lower);
                 }
-                if (live) {
+                if (ST_REPLAY_MERGE) collect();
+                if (live && !placed) {
                     float* gg = A.g_geom + (size_t)id * 16;
 #pragma unroll
                     for (int k = 0; k < 13; ++k) atomicAdd(gg + k, gv[k]);
@@ -1127,6 +1146,24 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     }
 }
 
+// Wave v of the first launch -> its 8x8 block of rays.  Image-shaped ray sets are walked in supertiles of 16 x 16 blocks (128 x 128 rays),
+// row-major inside a supertile and over the supertiles: the ~500 waves an XCD holds at a time then cover a compact patch of the image
+// whose mirror rays meet a compact part of the scene, instead of a 20-ray-high strip across the whole width.  Other ray sets: identity.
+constexpr uint32_t ST_SUPER = 16;
+__device__ __forceinline__ int64_t st_tile_of_wave(const StArgs& A, uint32_t v)
+{
+    if (v >= A.n_tiles) return -1;
+    if (A.ray_width <= 0) return (int64_t)v;
+    const uint32_t tiles_x = (uint32_t)(A.ray_width + 7) >> 3, tiles_y = A.n_tiles / tiles_x;
+    const uint32_t band = tiles_x * ST_SUPER;                                   // blocks of a full row of supertiles
+    const uint32_t sy = v / band, in_band = v - sy * band;
+    const uint32_t hB = min(ST_SUPER, tiles_y - sy * ST_SUPER);
+    const uint32_t sx = in_band / (ST_SUPER * hB), in_super = in_band - sx * ST_SUPER * hB;
+    const uint32_t wB = min(ST_SUPER, tiles_x - sx * ST_SUPER);
+    const uint32_t ly = in_super / wB, lx = in_super - ly * wB;
+    return (int64_t)(sy * ST_SUPER + ly) * tiles_x + sx * ST_SUPER + lx;
+}
+
 // first launch: one wave per block of rays.  MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again
 // (no record, or it overflowed); 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same
 // order, no hierarchy.
@@ -1140,9 +1177,12 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
     __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
-    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6);
-    if (wave >= A.n_tiles) return;
-    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)wave, -1, wave);
+    // XCD b % 8 takes the (b % 8)-th eighth of the blocks of rays, in the blocky order of st_tile_of_wave
+    const uint32_t region = blockIdx.x & 7u;
+    const uint32_t wave = (region * A.region_blocks + (blockIdx.x >> 3)) * (ST_THREADS / 64) + (tid >> 6);
+    const int64_t tile = st_tile_of_wave(A, wave);
+    if (tile < 0) return;
+    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, tile, -1, (uint32_t)tile, region);
 }
 
 // ---- rays that run with nobody: one WAVE per ray --------------------------------------------------------------------------------
@@ -1177,12 +1217,13 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 template <bool BWD>
 __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4* __restrict__ leaf, const float* __restrict__ boxes,
                                                    const unsigned long long* __restrict__ vmask, const uint32_t* __restrict__ lone_list,
-                                                   unsigned long long* slot, int lane, uint32_t first_item, uint32_t item_stride)
+                                                   unsigned long long* slot, int lane, uint32_t region, uint32_t first_item, uint32_t item_stride)
 {
-    const uint32_t count = lone_list[0];
+    const uint32_t listed = lone_list[region];
+    const uint32_t count = listed < A.lone_list_cap ? listed : A.lone_list_cap;
     const StWide& W = A.wide;
     for (uint32_t item = first_item; item < count; item += item_stride) {
-        const int64_t r = lone_list[16 + item];
+        const int64_t r = lone_list[16 + (size_t)region * A.lone_list_cap + item];
         const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
         const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
         const float ivx = 1.0f / dx, ivy = 1.0f / dy, ivz = 1.0f / dz;
@@ -1209,7 +1250,7 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
         bool done = false;
         // the forward keeps the sorted hits of the first ST_LONE_REC_PASSES passes of every listed ray (128 bytes a pass); a backward whose
         // ray needed no more than that replays them instead of walking the hierarchy again (the walk was 0.3 of the backward's 0.9 ms)
-        unsigned long long* rec = (A.lone_rec != nullptr && item < A.lone_cap) ? A.lone_rec + (size_t)item * (ST_LONE_REC_PASSES * ST_K) : nullptr;
+        unsigned long long* rec = (A.lone_rec != nullptr && item < A.lone_cap) ? A.lone_rec + ((size_t)region * A.lone_cap + item) * (ST_LONE_REC_PASSES * ST_K) : nullptr;
         const bool replay = BWD && rec != nullptr && A.state[4 * r + 3] <= (float)ST_LONE_REC_PASSES;
         for (int pass = 0; pass < ST_MAX_PASSES && !done; ++pass) {
             // ---- gather: the ST_K smallest keys above prev_key, sorted, one per lane 0..ST_K-1 ----
@@ -1384,7 +1425,7 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
 
 // second launch: the first ST_PACKET_BLOCKS blocks give every listed packet a wave, the blocks behind them every listed single ray.
 // One launch for both: each kind ends in a tail of a few long waves, and the two tails overlap instead of following each other.
-constexpr int ST_PACKET_BLOCKS = 2048;
+constexpr int ST_PACKET_BLOCKS = 2048;      // (multiples of 8: b % 8 of a block is its region in both halves of the grid)
 constexpr int ST_LONE_BLOCKS = 4096;
 
 template <int MODE>
@@ -1398,20 +1439,24 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
     __shared__ unsigned long long slot[ST_THREADS / 64][ST_K];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
+    // the blocks with b % 8 == x (XCD x) walk region x's lists front to back: what the first launch's waves on that XCD listed, in their order
+    const uint32_t region = blockIdx.x & 7u;
     if (blockIdx.x >= ST_PACKET_BLOCKS) {
-        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], tid & 63,
-                                      (blockIdx.x - ST_PACKET_BLOCKS) * (ST_THREADS / 64) + (tid >> 6), ST_LONE_BLOCKS * (ST_THREADS / 64));
+        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], tid & 63, region,
+                                      ((blockIdx.x - ST_PACKET_BLOCKS) >> 3) * (ST_THREADS / 64) + (tid >> 6), (ST_LONE_BLOCKS / 8) * (ST_THREADS / 64));
         return;
     }
     if (A.defer_list == nullptr) return;
     if (MODE == 2) return;                                     // the replay of listed packets rides in their blocks' waves of the first launch
-    const uint32_t listed = A.defer_list[0];
+    const uint32_t listed = A.defer_list[region];
     const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
-    const uint32_t stride = ST_PACKET_BLOCKS * (ST_THREADS / 64);
-    for (uint32_t item = blockIdx.x * (ST_THREADS / 64) + (tid >> 6); item < count; item += stride) {
+    const uint32_t stride = (ST_PACKET_BLOCKS / 8) * (ST_THREADS / 64);
+    for (uint32_t local = (blockIdx.x >> 3) * (ST_THREADS / 64) + (tid >> 6); local < count; local += stride) {
+        const uint32_t item = region * A.defer_cap + local;
         const uint32_t code = A.defer_list[16 + item];
         if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
-        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item);
+        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item,
+                            region);
     }
 }
 
@@ -1440,32 +1485,35 @@ size_t mrgs_surfel_bvh_bytes(int64_t n_surfels)
     return st_blob(n_surfels).total;
 }
 
-struct StateLayout { int64_t grid, n_tiles; size_t lone, defer, rec_hdr, rec_chunks, rec_arena, lone_rec, total; uint32_t pool, defer_cap, lone_cap; };
+struct StateLayout { int64_t grid, n_tiles; size_t lone, defer, rec_hdr, rec_chunks, rec_arena, lone_rec, total; uint32_t pool, defer_cap, lone_cap, lone_list_cap, region_blocks; };
 
 static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte words
 {
     StateLayout L;
     L.n_tiles = (n_rays + 63) / 64;
     if (ray_width > 0 && n_rays % ray_width == 0) L.n_tiles = (int64_t)((ray_width + 7) / 8) * ((n_rays / ray_width + 7) / 8);
-    L.grid = (L.n_tiles * 64 + ST_THREADS - 1) / ST_THREADS;
-    L.defer_cap = (uint32_t)(4 * L.n_tiles + 1024);
+    // eight regions (StArgs): the first launch is region_blocks blocks per region, every list has a part per region
+    L.region_blocks = (uint32_t)((L.n_tiles * 64 + 8 * ST_THREADS - 1) / (8 * ST_THREADS));
+    L.grid = 8 * (int64_t)L.region_blocks;
+    L.defer_cap = (uint32_t)((4 * L.n_tiles + 1024 + 7) / 8);       // per region
     L.pool = (uint32_t)(3 * L.n_tiles + 64);
-    L.lone = (size_t)4 * n_rays;                                     // [0] count, [16..] ray indices
-    L.defer = L.lone + 16 + (size_t)n_rays;                          // [0] count, [16..] packets of the second launch
-    L.rec_hdr = L.defer + 16 + L.defer_cap;
+    L.lone_list_cap = L.region_blocks * ST_THREADS;                  // per region: every ray of the region
+    L.lone = (size_t)4 * n_rays;                                     // [x] count of region x, [16..] ray indices, region by region
+    L.defer = L.lone + 16 + (size_t)8 * L.lone_list_cap;             // [x] count of region x, [16..] packets of the second launch, region by region
+    L.rec_hdr = L.defer + 16 + (size_t)8 * L.defer_cap;
     L.rec_chunks = L.rec_hdr + 16;                                   // one row per block of rays, then one per listed packet
-    L.rec_arena = L.rec_chunks + ((size_t)L.n_tiles + L.defer_cap) * ST_REC_PASSES;
+    L.rec_arena = L.rec_chunks + ((size_t)L.n_tiles + (size_t)8 * L.defer_cap) * ST_REC_PASSES;
     L.lone_rec = (L.rec_arena + ((size_t)L.n_tiles * ST_REC_STATIC + L.pool) * (ST_K * 64) + 1) & ~(size_t)1;      // 8-byte keys
-    L.lone_cap = (uint32_t)(2 * L.n_tiles + 1024);
-    L.total = L.lone_rec + (size_t)L.lone_cap * ST_LONE_REC_PASSES * ST_K * 2;
+    L.lone_cap = (uint32_t)((2 * L.n_tiles + 1024 + 7) / 8);        // per region
+    L.total = L.lone_rec + (size_t)8 * L.lone_cap * ST_LONE_REC_PASSES * ST_K * 2;
     return L;
 }
 
 size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).total; }
 size_t mrgs_surfel_trace_state_floats_norecord(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).rec_arena; }
 
-// Introspection for the tests: word offsets inside `state` of [0] the list of rays traced one per wavefront (its first word: their count),
-// [1] the list of packets handed to the second launch (first word: count), [2] the record header (word 0: chunks taken from the shared
+// Introspection for the tests: word offsets inside `state` of [0] the lists of rays traced one per wavefront (first eight words: their counts per
+// region), [1] the lists of packets handed to the second launch (first eight words: counts per region), [2] the record header (word 0: chunks taken from the shared
 // pool, word 1: non-zero = the record overflowed / was not kept and the backward walks again), [3] the replay record, [4] the full size.
 int mrgs_surfel_trace_state_layout(int64_t n_rays, int32_t ray_width, size_t* offsets5)
 {
@@ -1576,6 +1624,8 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     a.lone_list = words + SL.lone;
     a.defer_list = words + SL.defer;
     a.defer_cap = SL.defer_cap;
+    a.lone_list_cap = SL.lone_list_cap;
+    a.region_blocks = SL.region_blocks;
     a.rec_hdr = words + SL.rec_hdr;
     a.rec_chunks = words + SL.rec_chunks;
     a.rec_arena = words + SL.rec_arena;
@@ -1593,7 +1643,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
         // `wet` sums (zeros): ONE launch instead of six memsets of 4-5 us each
         const bool keep = !(no_record || !have_arena);
         if (!keep) a.rec_arena = nullptr;
-        const size_t n_ff = (size_t)SL.defer_cap + ((size_t)SL.n_tiles + SL.defer_cap) * ST_REC_PASSES + 16;   // defer list .. end of rec_chunks (the header between them is rewritten)
+        const size_t n_ff = (size_t)8 * SL.defer_cap + ((size_t)SL.n_tiles + (size_t)8 * SL.defer_cap) * ST_REC_PASSES + 16;   // defer lists .. end of rec_chunks (the header between them is rewritten)
         const size_t n_init = n_ff > (size_t)n_surfels ? n_ff : (size_t)n_surfels;
         hipLaunchKernelGGL(st_init_kernel, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, st, a.lone_list, words + SL.defer, a.rec_hdr, n_ff,
                            keep ? 0u : 0x01010101u, a.wet, (size_t)n_surfels);
