@@ -47,6 +47,9 @@ WORKLOADS = {
     "C3trace": (300000, 800, 800, 8, "C3 shell scene through render_surfel_with_envgs: render_surfel + surfel-traced mirror rays of all 800x800 pixels (hierarchy rebuilt per view), fwd+bwd"),
     # BASELINE.json configs[3] with the traced reflection term: C4 size through render_surfel_with_envgs
     "C4trace": (1000000, 1600, 1600, 8, "C4-size shell scene through render_surfel_with_envgs: P=1000000, 1600x1600, render_surfel + surfel-traced mirror rays of all 2.56 M pixels (hierarchy rebuilt per view), fwd+bwd"),
+    # C3full in the flavour the reference SHIPS (arguments/config.py:1 FLAG = "pgsr"): + the plane distance as a ninth rasterized channel,
+    # surf_depth / surf_normal from the flavour's unbiased depth (gaussian_renderer/__init__.py:64-69, 348-357); parity of allmap[7] unpinned
+    "C3full-pgsr": (300000, 800, 800, 8, "C3 shell scene through render_surfel(flag='pgsr'): P=300000, 800x800, S=8+1 (plane distance) + deferred BRDF shading, fwd+bwd"),
     "tiny": (20000, 400, 400, 8, "tiny debug scene (not a benchmark configuration)"),
     "tinyfull": (20000, 400, 400, 8, "tiny debug scene through render_surfel (not a benchmark configuration)"),
 }
@@ -192,7 +195,8 @@ def main():
             debug=False))
     g_color, g_feat, g_others = upstream_grads(S, H, W, device=dev)
 
-    surfel_mode = args.workload in ("C3full", "C3train", "C4full", "C3trace", "C4trace", "tinyfull")
+    surfel_mode = args.workload in ("C3full", "C3full-pgsr", "C3train", "C4full", "C3trace", "C4trace", "tinyfull")
+    flavour = "pgsr" if args.workload.endswith("-pgsr") else "2dgs"
     traced = args.workload in ("C3trace", "C4trace")
     use_loss = args.workload in ("C3train", "C4full")
     indirect = args.workload == "C4full"
@@ -248,6 +252,13 @@ def main():
     surfel_names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color",
                     "indirect_dc", "indirect_rest", "env_base"]
     surfel_reducer = mdist.SurfelGradReducer([t_.shape for t_ in surfel_params], surfel_names, dev) if (surfel_mode and world > 1) else None
+    if surfel_reducer is not None and not traced and not os.environ.get("MRGS_BENCH_NO_EARLY_GATHER"):
+        # both factors of the SH exchange leave the backward as soon as they are final: the colour factor between the rasterizer's blend
+        # backward and its per-gaussian backward, the indirect-radiance factor after the per-gaussian glue's backward.  (Not with the
+        # traced term: the tracer evaluates the same colour SH a second time, and the sum of two clamp-masked terms is what reduce() reads.)
+        import materialrefgs_amd.renderer as renderer_mod
+        rasterizer_mod.set_after_blend_hook(lambda drgb: surfel_reducer.begin_early_rgb(drgb, state["campos"]))
+        renderer_mod.set_after_features_hook(lambda d_ind: surfel_reducer.begin_early_ind(d_ind))
 
     def reduce_surfel(view):
         summed = surfel_reducer.reduce([t_.grad for t_ in surfel_params], pc._xyz, pc._rotation, cams_dev[view].camera_center, pc.active_sh_degree)
@@ -268,6 +279,7 @@ def main():
 
     def step_surfel(i):
         view = (i * world + rank) % len(settings)
+        state["campos"] = cams_dev[view].camera_center
         for t_ in surfel_params:
             t_.grad = None
         done = mark("env_prefilter_fwd")
@@ -277,7 +289,7 @@ def main():
         if traced:
             out = render_surfel_with_envgs(hw_tracer, cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=False))
         else:
-            out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect))
+            out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect), flag=flavour)
         done()
         state["R"] = rasterizer_mod.LAST_NUM_RENDERED
         if use_loss:
@@ -486,28 +498,43 @@ def main():
             dense_floats = sum(int(t_.numel()) for t_ in surfel_params)
             sh_floats = sum(int(t_.numel()) for n, t_ in zip(surfel_names, surfel_params) if n in mdist.SurfelGradReducer.SH_NAMES)
             row = 6 * P + 3
-            gathered = torch.randn(V, row, device=dev)
-            fn = lambda: mdist.expand_surfel_sh_gradients(gathered, pc._xyz, pc._rotation, 3)
+            g_rgb, g_ind = torch.randn(V, 3 * P + 3, device=dev), torch.randn(V, 3 * P, device=dev)
+            fn = lambda: mdist.expand_surfel_sh_gradient_rows(g_rgb, g_ind, pc._xyz, pc._rotation, 3, family="rgb")
+            fn_b = lambda: mdist.expand_surfel_sh_gradient_rows(g_rgb, g_ind, pc._xyz, pc._rotation, 3, family="ind")
         else:
             dense_floats = sum(int(v.numel()) for v in params.values()) + int(means2D.numel())
             sh_floats = int(params["sh"].numel())
             row = 3 * P + 3
             gathered = torch.randn(V, row, device=dev)
             fn = lambda: mdist.expand_sh_gradients(gathered, params["means3D"], 16, 3)
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        expand_ms = e0.elapsed_time(e1) / 10
+        def timed(f):
+            f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                f()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / 10
+        expand_ms = timed(fn)
         ag_row, ar_bytes = 4 * row, 4 * (dense_floats - sh_floats)
-        return {"V": V, "allgather_bytes_per_rank_sent": ag_row, "allgather_bytes_per_rank_received": ag_row * V,
-                "allreduce_bytes": ar_bytes, "dense_allreduce_bytes_avoided": 4 * dense_floats,
-                "floats_per_gaussian_on_the_wire": round((row - 3 + dense_floats - sh_floats) / P, 2),
-                "floats_per_gaussian_dense": round(dense_floats / P, 2), "sh_expand_ms_at_V": round(expand_ms, 4),
-                "_ag_row": ag_row, "_ar_bytes": ar_bytes, "_expand_ms": expand_ms}
+        m = {"V": V, "allgather_bytes_per_rank_sent": ag_row, "allgather_bytes_per_rank_received": ag_row * V,
+             "allreduce_bytes": ar_bytes, "dense_allreduce_bytes_avoided": 4 * dense_floats,
+             "floats_per_gaussian_on_the_wire": round((row - 3 + dense_floats - sh_floats) / P, 2),
+             "floats_per_gaussian_dense": round(dense_floats / P, 2), "sh_expand_ms_at_V": round(expand_ms, 4),
+             "_ag_row": ag_row, "_ar_bytes": ar_bytes, "_expand_ms": expand_ms}
+        if surfel_mode:
+            # the two factors travel apart (dist.SurfelGradReducer.begin_early_rgb / _ind) and are expanded apart; the per-gaussian glue's
+            # backward (the kernel between the two hand-outs) is timed here on a graph of its own
+            import materialrefgs_amd.renderer as renderer_mod
+            expand_b_ms = timed(fn_b)
+            o_ = renderer_mod.surfel_features(pc, cams_dev[0].camera_center, pass_xyz=True)
+            gs_ = [torch.ones_like(t_) for t_ in o_]
+            leaves_ = [t_ for t_ in surfel_params[:11]]
+            feat_bwd_ms = timed(lambda: torch.autograd.grad(o_, leaves_, gs_, retain_graph=True, allow_unused=True))
+            m.update({"allgather_rows_bytes": [4 * (3 * P + 3), 4 * 3 * P], "sh_expand_ms_at_V": [round(expand_ms, 4), round(expand_b_ms, 4)],
+                      "surfel_features_bwd_ms": round(feat_bwd_ms, 4), "_expand_b_ms": expand_b_ms, "_feat_bwd_ms": feat_bwd_ms})
+        return m
 
     def predicted_scaling(xm, step_ms, overlap_ms):
         """Step efficiency of the view-parallel step at V = 2 / 4 / 8 from the wire bytes and the measured local kernels (no multi-GPU
@@ -521,12 +548,24 @@ def main():
         link = 76.8e9 * 0.8
         tab = {}
         for V in (2, 4, 8):
-            t_ag = xm["_ag_row"] / link * 1e3 + 0.010
             t_ar = 2.0 * xm["_ar_bytes"] / V / link * 1e3 + 0.020
-            t_exp = xm["_expand_ms"] * V / 8.0
-            # the all-gather starts `overlap_ms` before the backward ends; the all-reduce follows it on the same links; the expansion runs
-            # on the compute stream as soon as the gather has landed, next to the all-reduce
-            exposed = max(t_ag - overlap_ms, 0.0) + max(t_ar, t_exp)
+            if "_expand_b_ms" in xm:
+                # render_surfel's exchange (dist.SurfelGradReducer): the colour factor's gather starts `overlap_ms` before the backward ends
+                # (after the blend backward: the rasterizer's per-gaussian backward and the glue's backward follow), the indirect factor's
+                # gather at its end; links: gather 1 (what is left of it), gather 2, then reduce-scatter + all-gather of the dense bucket;
+                # compute stream: expansion 1 when gather 1 has landed, expansion 2 when gather 2 has landed and expansion 1 is done
+                t_ag1, t_ag2 = 4 * (3 * P + 3) / link * 1e3 + 0.010, 4 * 3 * P / link * 1e3 + 0.010
+                t_e1, t_e2 = xm["_expand_ms"] * V / 8.0, xm["_expand_b_ms"] * V / 8.0
+                left1 = max(t_ag1 - overlap_ms, 0.0)
+                links_done = left1 + t_ag2 + t_ar
+                compute_done = max(left1 + t_e1, left1 + t_ag2) + t_e2
+                exposed, t_ag, t_exp = max(links_done, compute_done), t_ag1 + t_ag2, t_e1 + t_e2
+            else:
+                t_ag = xm["_ag_row"] / link * 1e3 + 0.010
+                t_exp = xm["_expand_ms"] * V / 8.0
+                # the all-gather starts `overlap_ms` before the backward ends; the all-reduce follows it on the same links; the expansion
+                # runs on the compute stream as soon as the gather has landed, next to the all-reduce
+                exposed = max(t_ag - overlap_ms, 0.0) + max(t_ar, t_exp)
             eff = step_ms / (step_ms + exposed)
             tab[f"V{V}"] = {"allgather_ms": round(t_ag, 4), "allreduce_ms": round(t_ar, 4), "sh_expand_ms": round(t_exp, 4),
                             "exposed_exchange_ms": round(exposed, 4), "efficiency": round(eff, 3), "speedup": round(V * eff, 2)}
@@ -591,9 +630,17 @@ def main():
         out["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
         if xmodel is not None:
             if world == 1:
-                # (render_surfel's second SH family comes out of the per-gaussian feature backward, after the rasterizer: no early start there)
-                xmodel["predicted_scaling"] = predicted_scaling(xmodel, 1000.0 * elapsed / args.steps,
-                                                                0.0 if surfel_mode else float(stage_ms.get("preprocess_bwd", 0.0)))
+                # (render_surfel: the colour factor leaves after the blend backward -- the rasterizer's per-gaussian backward and the glue's
+                #  backward run under its gather --, the indirect factor after the glue's backward; not with the traced term, see above)
+                ov = float(stage_ms.get("preprocess_bwd", 0.0))
+                if surfel_mode:
+                    ov = 0.0 if traced else ov + float(xmodel.get("_feat_bwd_ms", 0.0))
+                xmodel["predicted_scaling"] = predicted_scaling(xmodel, 1000.0 * elapsed / args.steps, ov)
+                # the model's bottom line at top level (the driver's record keeps top-level keys): speed-up of V ranks over one
+                out["predicted_scaling_model"] = {k: v["speedup"] for k, v in xmodel["predicted_scaling"].items() if k.startswith("V")}
+                out["predicted_scaling_model"]["note"] = ("MODEL, not a measurement (no multi-GPU box was available to any round): wire bytes of "
+                                                          "materialrefgs_amd/dist.py over 7 point-to-point xGMI links at 61 GB/s per direction, local "
+                                                          "kernels measured here; inputs under exchange_model")
             xmodel = {k: v for k, v in xmodel.items() if not k.startswith("_")}
         out["exchange_model"] = xmodel
         out["host_bound"] = bool(host_work > 0.9 * elapsed)
@@ -604,7 +651,7 @@ def main():
 
         if world > 1:
             pass                         # the CPU baseline and the oracle comparison belong to the N = 1 run only
-        elif not args.no_cpu_baseline and surfel_mode and (traced or use_loss or indirect):
+        elif not args.no_cpu_baseline and surfel_mode and (traced or use_loss or indirect or flavour != "2dgs"):
             out["cpu_baseline"] = None   # CPU legs exist for the raster workloads and for C3full
         elif not args.no_cpu_baseline and surfel_mode:
             # render_surfel of view 0 on the host cores through the checkers (oracle/render_oracle.py: per-gaussian glue in torch float64,
@@ -646,6 +693,7 @@ def main():
             inter_names = ["opacities", "scales", "rotations", "features"]
             inter_o = [t_.detach().cpu().double().requires_grad_(True) for t_ in stash["o"]]
             t = time.perf_counter()
+            R_hip = int(rasterizer_mod.LAST_NUM_RENDERED)
             out_o = render_oracle.render_surfel_oracle(cam0, pc_o, None, None, pipe, bg_color.cpu(), srgb=False, mips=mips_cpu, raster_inputs=tuple(inter_o))
             torch.autograd.backward([out_o[k] for k in keys], [g_.detach().cpu().double() for g_ in state["g"]])
             cpu_s = time.perf_counter() - t
@@ -673,7 +721,7 @@ def main():
             out["rend_dist_abs_err"] = float(f"{np.abs(out_h['rend_dist'].detach().cpu().double().numpy() - out_o['rend_dist'].detach().numpy()).max():.3e}")
             sn_h, sn_o = out_h["surf_normal"].detach().cpu().double().numpy(), out_o["surf_normal"].detach().numpy()
             out["surf_normal_frac_pixels_over_1e-4"] = float(f"{(np.abs(sn_h - sn_o).max(axis=0) > 1e-4).mean():.3e}")
-            out["num_rendered_matches_oracle"] = None
+            out["num_rendered_matches_oracle"] = bool(render_oracle.LAST_NUM_RENDERED == R_hip)
         elif not args.no_cpu_baseline:
             from oracle import raster_oracle as ro
             cam = cams[0]
@@ -775,6 +823,7 @@ def main():
             out["secondary"] = child("C2heavy", min(max(args.steps, 100), 500), min(args.warmup, 30))
             out["secondary_traced"] = child("C3trace", 100, 16)
             out["secondary_c4"] = child("C4trace", 30, 8)
+            out["secondary_pgsr"] = child("C3full-pgsr", 200, 16)        # the flavour the reference ships (arguments/config.py:1)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

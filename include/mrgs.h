@@ -83,7 +83,14 @@ typedef struct MrgsRasterInputs {
                               forward orders its blend waves by the work each (tile, quadrant) took the last time this buffer was
                               passed (falling back to the cull count where it holds 0) and stores the work of this call.  A training
                               loop revisits the same cameras, so the previous visit predicts where rays terminate early far better than
-                              any count available before the blend.  NULL: cull counts only.  Results do not depend on it. */
+                              any count available before the blend.  NULL: cull counts only.  Results do not depend on its CONTENTS.
+                              The buffer also carries the blend kernels' queue state, tickets and the forward's dealt queues
+                              (MrgsHintLayout), so (a) renders that share one buffer -- the same camera -- are issued on ONE stream, one
+                              after the other (two forwards of one camera on two streams would hand every item out once ACROSS both
+                              kernels; renders with different buffers, or without one, are independent on any streams), and (b) a
+                              backward that names a prepared workspace (bwd_grad_ws below) is given the SAME buffer its forward was
+                              given, not rewritten in between by anything but this library: a fresh or zeroed buffer there makes every
+                              wave pull item 0.  The Python wrapper keeps the forward's tensor in the autograd node for that reason. */
     const float* shs_rest; /* optional: split SH layout.  When set, `shs` holds the DC coefficients [P,1,3] and shs_rest the higher orders
                               [P,M-1,3] (M = 2..16) -- the two tensors GaussianModel stores (_features_dc / _features_rest,
                               scene/gaussian_model.py:401-402), which the reference concatenates for every render (get_features,
@@ -93,7 +100,8 @@ typedef struct MrgsRasterInputs {
                               spare workgroups of its ordering launch and the backward's work queues are set up as a copy of its own -- and the
                               backward needs no launch before its blend kernel.  BACKWARD call: pass the same pointer (and the same
                               grad_ws) to say that this was done; NULL, or a pointer other than grad_ws, makes the backward order and clear
-                              by itself.  Valid for ONE backward per forward.  Results do not depend on it. */
+                              by itself.  Valid for ONE backward per forward, with the forward's work_hint buffer (above).  Results do not
+                              depend on it. */
     uint32_t hint_flags;   /* MRGS_HINT_REUSE_ORDER: the forward skips the ordering of its blend waves and deals them as the last
                               ordering of this camera did -- the dealt queues live in the work_hint buffer, behind the per-block work
                               (mrgs_work_hint_bytes covers both).  Only with work_hint set, and only after a forward WITHOUT the flag has
@@ -371,6 +379,14 @@ typedef struct MrgsMapsFrame {
     int32_t H, W;
     float view_rot[9], ray_matrix[9], ray_origin[3];
     float depth_ratio;
+    /* ABI 7, the "pgsr" flavour (arguments/config.py:1; gaussian_renderer/__init__.py:64-69): with rend_distance set ([H,W], the blended
+     * plane distance = the flavour's last feature channel) surf_depth is nan_to_num(rend_distance / -(n . ray)), n = allmap[2:5],
+     * ray = ((x - (W - 1) / 2) / pgsr_fx, (y - (H - 1) / 2) / pgsr_fy, 1) -- the depth where the pixel's ray meets the blended plane
+     * (allmap[7] of the flavour's rasterizer, which is not in the reference's tree: parity unpinned) -- and surf_normal its finite
+     * differences; depth_ratio is then not read.  The backward writes the map's gradient to g_rend_distance ([H,W], may be NULL). */
+    float pgsr_fx, pgsr_fy;
+    const float* rend_distance;
+    float* g_rend_distance;
 } MrgsMapsFrame;
 int mrgs_surfel_maps_forward(const MrgsMapsFrame* fr, const float* allmap, float* rend_normal, float* surf_depth, float* surf_normal,
                              float* normal_map, float* rend_alpha /*[1,H,W] = allmap[1], NULL = skip*/, float* rend_dist /*[1,H,W] = allmap[6]*/,
@@ -586,6 +602,14 @@ int mrgs_sh_grad_expand(int32_t P, int32_t M, int32_t D, int32_t V, const float*
 int mrgs_sh_grad_expand_surfel(int32_t P, int32_t D, int32_t V, const float* xyz, const float* rotation_raw, const float* gathered,
                                int64_t row_stride, float* g_features_dc, float* g_features_rest, float* g_indirect_dc, float* g_indirect_rest,
                                void* stream);
+/* The same expansion with the three parts of a rank's row in buffers of their own (V rows each, strides in floats): dRGB_v is final after
+ * the blend backward and dIND_v only after the per-gaussian backward, so a view-parallel step gathers them at different times
+ * (materialrefgs_amd/dist.py: SurfelGradReducer.begin_early_rgb / begin_early_ind) and expands from where the two all-gathers left them.
+ * rgb_rows NULL or ind_rows NULL (not both): that family is left out and its two output tensors are not touched (they may be NULL) --
+ * one call per family, each as soon as its rows have arrived.  ABI 7. */
+int mrgs_sh_grad_expand_surfel_rows(int32_t P, int32_t D, int32_t V, const float* xyz, const float* rotation_raw, const float* rgb_rows,
+                                    int64_t rgb_stride, const float* ind_rows, int64_t ind_stride, const float* campos_rows, int64_t campos_stride,
+                                    float* g_features_dc, float* g_features_rest, float* g_indirect_dc, float* g_indirect_rest, void* stream);
 
 /* Introspection used by the parity tests: copies of internal state in the reference's layouts.
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
@@ -607,9 +631,20 @@ int mrgs_get_kernel_times(MrgsKernelTimes* out);
 const char* mrgs_strerror(int code);
 const char* mrgs_last_hip_error(void);
 const char* mrgs_version(void);
+/* A second stream beside the caller's, for work that depends on nothing the caller's stream will produce for a while (the environment
+ * prefilter of a view: six latency-bound SpMVs and the mip chain, which only the shading reads -- next to the issue-bound blend kernels;
+ * scene/light.py:72-86 is called once per iteration, train_refnerf.py:1157-1163).  The library keeps ONE side stream per
+ * device (any host thread may fork or join).  fork: everything queued on `main_stream` so far happens-before whatever is queued on the returned stream afterwards (pass it
+ * as the `stream` of the calls to overlap); join: everything queued on the side stream so far happens-before whatever is queued on
+ * `main_stream` afterwards.  Two event records and two stream waits, no host synchronisation.  Buffers the side work reads or writes
+ * must stay allocated until the join has been queued (a caching allocator would hand them to the main stream's next kernels otherwise).
+ * ABI 7. */
+int mrgs_side_stream_fork(void* main_stream, void** side_stream);
+int mrgs_side_stream_join(void* main_stream);
+
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 6
+#define MRGS_ABI_VERSION 7
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

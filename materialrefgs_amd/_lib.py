@@ -83,7 +83,7 @@ class MrgsSurfelGrads(ctypes.Structure):
 
 class MrgsMapsFrame(ctypes.Structure):
     _fields_ = [("H", c_int32), ("W", c_int32), ("view_rot", c_float * 9), ("ray_matrix", c_float * 9), ("ray_origin", c_float * 3),
-                ("depth_ratio", c_float)]
+                ("depth_ratio", c_float), ("pgsr_fx", c_float), ("pgsr_fy", c_float), ("rend_distance", c_void_p), ("g_rend_distance", c_void_p)]
 
 
 class MrgsLossConfig(ctypes.Structure):
@@ -194,6 +194,10 @@ SYMBOLS = {
     "mrgs_sh_grad_expand": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mrgs_sh_grad_expand_surfel": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p]),
+    "mrgs_sh_grad_expand_surfel_rows": (ctypes.c_int, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                                       c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_side_stream_fork": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "mrgs_side_stream_join": (ctypes.c_int, [c_void_p]),
     "mrgs_compact_ws_bytes": (c_size_t, [c_int64]),
     "mrgs_compact_count": (ctypes.c_int, [c_int64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mrgs_compact_rows": (ctypes.c_int, [c_int64, c_void_p, c_void_p, ctypes.POINTER(MrgsCompactTensor), c_int32, c_void_p]),
@@ -218,7 +222,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 6   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 7   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

@@ -635,6 +635,60 @@ int mrgs_get_kernel_times(MrgsKernelTimes* out)
     return MRGS_OK;
 }
 
+// ---- a second stream next to the caller's (mrgs.h: mrgs_side_stream_fork / _join) ---------------------------------------------------
+// One non-blocking side stream per device (shared by the host threads: a backward may fork on autograd's worker thread and be joined from
+// the thread that called backward()) and a ring of events without timing, created on first use and kept.  fork: the side stream waits
+// for what the caller's stream holds NOW; join: the caller's stream waits for what the side stream holds now.
+namespace {
+#define MRGS_SIDE_EVENTS 32
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[MRGS_SIDE_EVENTS] = {};
+    unsigned next = 0;
+};
+SideStream g_side[MRGS_MAX_DEVICES];
+std::mutex g_side_mutex;
+static int side_of(SideStream** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MRGS_MAX_DEVICES) return MRGS_E_UNSUPPORTED;
+    SideStream& s = g_side[dev];
+    if (s.stream == nullptr) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (int i = 0; i < MRGS_SIDE_EVENTS; i++) HIP_TRY(hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming));
+    }
+    *out = &s;
+    return MRGS_OK;
+}
+}   // namespace
+
+int mrgs_side_stream_fork(void* main_stream, void** side_stream)
+{
+    if (!side_stream) return MRGS_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    SideStream* s = nullptr;
+    int rc = side_of(&s);
+    if (rc) return rc;
+    hipEvent_t e = s->ev[s->next++ % MRGS_SIDE_EVENTS];
+    HIP_TRY(hipEventRecord(e, (hipStream_t)main_stream));
+    HIP_TRY(hipStreamWaitEvent(s->stream, e, 0));
+    *side_stream = (void*)s->stream;
+    return MRGS_OK;
+}
+
+int mrgs_side_stream_join(void* main_stream)
+{
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    SideStream* s = nullptr;
+    int rc = side_of(&s);
+    if (rc) return rc;
+    hipEvent_t e = s->ev[s->next++ % MRGS_SIDE_EVENTS];
+    HIP_TRY(hipEventRecord(e, s->stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)main_stream, e, 0));
+    return MRGS_OK;
+}
+
 const char* mrgs_strerror(int code)
 {
     switch (code) {

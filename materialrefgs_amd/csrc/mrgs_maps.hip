@@ -19,7 +19,27 @@ struct MapsFrameDev {
     float M[9];      // rays_d(x, y) = M * (x, y, 1)
     float o[3];      // rays_o
     float depth_ratio;
+    // "pgsr" flavour (MrgsMapsFrame::rend_distance set): surf_depth is the flavour's unbiased depth
+    const float* rd;     // blended plane distance [H*W], or nullptr
+    float* g_rd;         // backward: its gradient [H*W] (fully written)
+    float fx, fy;        // focal lengths in pixels of the rasterizer's image plane (principal point ((W - 1) / 2, (H - 1) / 2))
 };
+
+// allmap[7] of the "pgsr" flavour (gaussian_renderer/__init__.py:64-69; PARITY UNPINNED, see renderer.pgsr_unbiased_depth for the
+// definition): the depth at which the pixel's ray meets the blended plane, rend_distance / -(n . ray), n = allmap[2:5] (view space),
+// ray = ((x - (W - 1) / 2) / fx, (y - (H - 1) / 2) / fy, 1).
+struct Unbiased { float ray[3], ndr, v; };
+__device__ __forceinline__ Unbiased unbiased_depth(const MapsFrameDev& f, const float* __restrict__ allmap, int HW, int pix)
+{
+    Unbiased u;
+    const int y = pix / f.W, x = pix - y * f.W;
+    u.ray[0] = ((float)x - 0.5f * (float)(f.W - 1)) / f.fx;
+    u.ray[1] = ((float)y - 0.5f * (float)(f.H - 1)) / f.fy;
+    u.ray[2] = 1.0f;
+    u.ndr = allmap[2 * HW + pix] * u.ray[0] + allmap[3 * HW + pix] * u.ray[1] + allmap[4 * HW + pix];
+    u.v = f.rd[pix] / (-u.ndr);
+    return u;
+}
 
 __device__ __forceinline__ float nan_to_num0(float x)
 {   // torch.nan_to_num(x, 0, 0): nan -> 0, +inf -> 0, -inf -> lowest finite
@@ -32,6 +52,7 @@ __device__ __forceinline__ bool is_finite(float x) { return (x - x) == 0.0f; }
 
 __device__ __forceinline__ float surf_depth_at(const MapsFrameDev& f, const float* __restrict__ allmap, int HW, int pix)
 {
+    if (f.rd != nullptr) return nan_to_num0(unbiased_depth(f, allmap, HW, pix).v);       // (empty pixels: 0 / -0 -> 0, as the reference's nan_to_num)
     const float a = allmap[HW + pix];
     const float de = nan_to_num0(allmap[pix] / a);
     float sd = de * (1.0f - f.depth_ratio);
@@ -200,8 +221,9 @@ __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, co
         }
         if (a >= 1e-6f) g_a -= s * inv * inv;            // clamp_min passes the gradient where x >= min
     }
+    float g_nv[3];                                             // gradient of the view-space normal sums allmap[2:5]
 #pragma unroll
-    for (int i = 0; i < 3; i++) g_allmap[(2 + i) * HW + pix] = f.V[i] * g_nw[0] + f.V[3 + i] * g_nw[1] + f.V[6 + i] * g_nw[2];
+    for (int i = 0; i < 3; i++) g_nv[i] = f.V[i] * g_nw[0] + f.V[3 + i] * g_nw[1] + f.V[6 + i] * g_nw[2];
 
     // surf_depth: own upstream gradient + the finite-difference normals of the four neighbours this pixel's point feeds
     float g_depth = g_sd != nullptr ? g_sd[pix] : 0.0f;
@@ -220,6 +242,28 @@ __global__ void __launch_bounds__(256) surfel_maps_bwd_kernel(MapsFrameDev f, co
         ray_dir(f, x, y, d);
         g_depth += gp[0] * d[0] + gp[1] * d[1] + gp[2] * d[2];
     }
+    if (f.rd != nullptr) {
+        // "pgsr": surf_depth = nan_to_num(rd / -(n . ray)) -- its gradient goes to the plane-distance map and to the normal sums (zero
+        // where the quotient is not finite: nan_to_num passes nothing there), none to the expected / median depth channels
+        const Unbiased u = unbiased_depth(f, allmap, HW, pix);
+        float g_rd = 0.0f;
+        if (is_finite(u.v)) {
+            g_rd = g_depth / (-u.ndr);
+            const float k = g_depth * f.rd[pix] / (u.ndr * u.ndr);
+#pragma unroll
+            for (int i = 0; i < 3; i++) g_nv[i] += k * u.ray[i];
+        }
+        if (f.g_rd != nullptr) f.g_rd[pix] = g_rd;
+#pragma unroll
+        for (int i = 0; i < 3; i++) g_allmap[(2 + i) * HW + pix] = g_nv[i];
+        g_allmap[pix] = 0.0f;
+        g_allmap[HW + pix] = g_a;
+        g_allmap[5 * HW + pix] = 0.0f;
+        g_allmap[6 * HW + pix] = g_dist != nullptr ? g_dist[pix] : 0.0f;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) g_allmap[(2 + i) * HW + pix] = g_nv[i];
     const float d0 = allmap[pix];
     const float q = d0 / a;
     float g0 = 0.0f;
@@ -325,6 +369,7 @@ MapsFrameDev to_dev(const MrgsMapsFrame* fr)
     for (int i = 0; i < 9; i++) { f.V[i] = fr->view_rot[i]; f.M[i] = fr->ray_matrix[i]; }
     for (int i = 0; i < 3; i++) f.o[i] = fr->ray_origin[i];
     f.depth_ratio = fr->depth_ratio;
+    f.rd = fr->rend_distance; f.g_rd = fr->g_rend_distance; f.fx = fr->pgsr_fx; f.fy = fr->pgsr_fy;
     return f;
 }
 

@@ -358,9 +358,13 @@ __global__ void __launch_bounds__(256) sh_grad_expand_kernel(int P, int M, int D
 // make_frame(...).r of this file (d indirect_sh[p][k][c] = B_k(r_v(p)) g_v[p][c], clamp already folded into g) -- and both
 // directions can be rebuilt from replicated parameters (xyz, rotation) and the rank's camera centre.  gathered row v =
 // [dRGB_v (P x 3) | dIND_v (P x 3) | campos_v (3)]; outputs are the four split tensors of the model (dc [P,1,3], rest [P,15,3]).
+// (the three parts of a row by pointer and stride of their own: a view-parallel step gathers the two factors at different times --
+// mrgs_sh_grad_expand_surfel_rows -- or as one row, mrgs_sh_grad_expand_surfel)
 __global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D, int V, const float* __restrict__ xyz,
-                                                                    const float* __restrict__ rotation_raw, const float* __restrict__ gathered,
-                                                                    long long row_stride, float* __restrict__ g_dc, float* __restrict__ g_rest,
+                                                                    const float* __restrict__ rotation_raw, const float* __restrict__ rgb_rows,
+                                                                    long long rgb_stride, const float* __restrict__ ind_rows, long long ind_stride,
+                                                                    const float* __restrict__ cam_rows, long long cam_stride,
+                                                                    float* __restrict__ g_dc, float* __restrict__ g_rest,
                                                                     float* __restrict__ g_ind_dc, float* __restrict__ g_ind_rest)
 {
     __shared__ float s_tile[4][64 * REST_STRIDE];       // the wave's 64 rows of 45 "rest" floats, first one family, then the other
@@ -374,12 +378,20 @@ __global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D
 #pragma unroll
     for (int k = 0; k < 16; k++) { a[k][0] = a[k][1] = a[k][2] = 0.0f; b[k][0] = b[k][1] = b[k][2] = 0.0f; }
     const int ncoef = (D + 1) * (D + 1);
+    // (rgb_rows == nullptr / ind_rows == nullptr: that family is left out, its two output tensors untouched -- the step expands each
+    // family when ITS all-gather has landed)
+    const bool fam_a = rgb_rows != nullptr, fam_b = ind_rows != nullptr;
     for (int v = 0; v < V; v++) {
-        const float* row = gathered + (size_t)v * row_stride;
-        const float* cam = row + 6 * (size_t)P;
-        const float g[3] = {row[3 * ic], row[3 * ic + 1], row[3 * ic + 2]};
-        const float* ri = row + 3 * (size_t)P;
-        const float h[3] = {ri[3 * ic], ri[3 * ic + 1], ri[3 * ic + 2]};
+        const float* cam = cam_rows + (size_t)v * cam_stride;
+        float g[3] = {0.0f, 0.0f, 0.0f}, h[3] = {0.0f, 0.0f, 0.0f};
+        if (fam_a) {
+            const float* row = rgb_rows + (size_t)v * rgb_stride;
+            g[0] = row[3 * ic]; g[1] = row[3 * ic + 1]; g[2] = row[3 * ic + 2];
+        }
+        if (fam_b) {
+            const float* ri = ind_rows + (size_t)v * ind_stride;
+            h[0] = ri[3 * ic]; h[1] = ri[3 * ic + 1]; h[2] = ri[3 * ic + 2];
+        }
         const bool has_g = (g[0] != 0.0f) | (g[1] != 0.0f) | (g[2] != 0.0f), has_h = (h[0] != 0.0f) | (h[1] != 0.0f) | (h[2] != 0.0f);
         if (!has_g && !has_h) continue;
         const Frame f = make_frame(p, q, cam);
@@ -401,30 +413,34 @@ __global__ void __launch_bounds__(256) sh_grad_expand_surfel_kernel(int P, int D
     if (in_range) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            g_dc[3 * (size_t)idx + c] = a[0][c];
-            g_ind_dc[3 * (size_t)idx + c] = b[0][c];
+            if (fam_a) g_dc[3 * (size_t)idx + c] = a[0][c];
+            if (fam_b) g_ind_dc[3 * (size_t)idx + c] = b[0][c];
         }
     }
     // the two [P,15,3] tensors: a lane's row is 180 bytes, written lane by lane the wave's 64 rows are 45 scalar stores of 64 cache lines
     // each; through the per-wave tile they leave as 16-byte pieces of one contiguous 11.5 KB run
     float* tile = s_tile[threadIdx.x >> 6];
     const int nrows = min(64, P - row0);
+    if (fam_a) {
 #pragma unroll
-    for (int k = 1; k < 16; k++)
+        for (int k = 1; k < 16; k++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) tile[lane * REST_STRIDE + 3 * (k - 1) + c] = a[k][c];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (row0 < P) tile_store<REST_L>(tile, g_rest + (size_t)row0 * REST_L, nrows, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+            for (int c = 0; c < 3; c++) tile[lane * REST_STRIDE + 3 * (k - 1) + c] = a[k][c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (row0 < P) tile_store<REST_L>(tile, g_rest + (size_t)row0 * REST_L, nrows, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (fam_b) {
 #pragma unroll
-    for (int k = 1; k < 16; k++)
+        for (int k = 1; k < 16; k++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) tile[lane * REST_STRIDE + 3 * (k - 1) + c] = b[k][c];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (row0 < P) tile_store<REST_L>(tile, g_ind_rest + (size_t)row0 * REST_L, nrows, lane);
+            for (int c = 0; c < 3; c++) tile[lane * REST_STRIDE + 3 * (k - 1) + c] = b[k][c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (row0 < P) tile_store<REST_L>(tile, g_ind_rest + (size_t)row0 * REST_L, nrows, lane);
+    }
 }
 
 }   // namespace
@@ -439,7 +455,23 @@ int mrgs_sh_grad_expand_surfel(int32_t P, int32_t D, int32_t V, const float* xyz
     if (P == 0) return MRGS_OK;
     if (!xyz || !rotation_raw || !gathered || !g_features_dc || !g_features_rest || !g_indirect_dc || !g_indirect_rest) return MRGS_E_BAD_ARG;
     hipLaunchKernelGGL(sh_grad_expand_surfel_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, V, xyz, rotation_raw, gathered,
-                       (long long)row_stride, g_features_dc, g_features_rest, g_indirect_dc, g_indirect_rest);
+                       (long long)row_stride, gathered + 3 * (size_t)P, (long long)row_stride, gathered + 6 * (size_t)P, (long long)row_stride,
+                       g_features_dc, g_features_rest, g_indirect_dc, g_indirect_rest);
+    return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
+}
+
+int mrgs_sh_grad_expand_surfel_rows(int32_t P, int32_t D, int32_t V, const float* xyz, const float* rotation_raw, const float* rgb_rows,
+                                    int64_t rgb_stride, const float* ind_rows, int64_t ind_stride, const float* campos_rows, int64_t campos_stride,
+                                    float* g_features_dc, float* g_features_rest, float* g_indirect_dc, float* g_indirect_rest, void* stream)
+{
+    if (P < 0 || D < 0 || D > 3 || V < 1 || (rgb_rows && rgb_stride < 3 * (int64_t)P) || (ind_rows && ind_stride < 3 * (int64_t)P) || campos_stride < 3)
+        return MRGS_E_BAD_ARG;
+    if (P == 0) return MRGS_OK;
+    if (!xyz || !rotation_raw || (!rgb_rows && !ind_rows) || !campos_rows) return MRGS_E_BAD_ARG;
+    if ((rgb_rows && (!g_features_dc || !g_features_rest)) || (ind_rows && (!g_indirect_dc || !g_indirect_rest))) return MRGS_E_BAD_ARG;
+    hipLaunchKernelGGL(sh_grad_expand_surfel_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, V, xyz, rotation_raw, rgb_rows,
+                       (long long)rgb_stride, ind_rows, (long long)ind_stride, campos_rows, (long long)campos_stride, g_features_dc, g_features_rest,
+                       g_indirect_dc, g_indirect_rest);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

@@ -56,6 +56,12 @@ namespace {
 #ifndef ST_REPLAY_MERGE
 #define ST_REPLAY_MERGE 1                 // the replaying backward merges neighbouring lanes that hold the same surfel BEFORE the LDS collection; 0: after (A/B)
 #endif
+#ifndef ST_REST_SCHED
+#define ST_REST_SCHED 0                   // second launch of the forward: 0 = items by ticket, own region first; 1 = every list strided over all waves (A/B)
+#endif
+#ifndef ST_REST_LONE_FIRST
+#define ST_REST_LONE_FIRST 0
+#endif
 #ifndef ST_FWD_WAVES
 #define ST_FWD_WAVES 4                    // waves per SIMD the forward walking kernels are compiled for (register budget 512 / that)
 #endif
@@ -248,10 +254,11 @@ struct StArgs {
     uint32_t rec_static;                  // n_tiles * ST_REC_STATIC: where the pool starts
     uint32_t n_tiles;                     // waves of the first launch (one 8x8 block of rays each)
     // Both lists are kept per REGION: block b of a launch runs on XCD b % 8 (observed dispatch order -- used for speed only, nothing below is
-    // wrong under another placement), the first launch gives XCD x the x-th eighth of the blocks of rays in a blocky order (st_tile_of_wave),
-    // and what it lists goes to sub-list x, which the second launch hands to the blocks with b % 8 == x again: the waves resident on one
-    // XCD at a time trace neighbouring rays and share the subtrees and leaf records their L2 holds (round 5; before, consecutive blocks of
-    // rays went round the eight L2s and every L2 saw the whole hierarchy: 4.2 GB fetched by the second launch of a C4-size view).
+    // wrong under another placement), the first launch gives XCD x every eighth 64 x 64 patch of the rays (st_tile_of_wave), and what it
+    // lists goes to sub-list x, which the second launch hands to the blocks with b % 8 == x again: the waves resident on one XCD at a time
+    // trace neighbouring rays and share the subtrees and leaf records their L2 holds (round 5; before, consecutive blocks of four 8x8 ray
+    // blocks went round the eight L2s, an XCD's resident waves were spread over half the image and every L2 saw the whole hierarchy:
+    // 4.2 GB fetched by the second launch of a C4-size view).
     uint32_t* defer_list;                 // [x] count of region x, [16 + x * defer_cap ..] (tile << 5 | packet): the packets traced by the second launch, one per wave
     uint32_t defer_cap;                   // per region
     uint32_t* lone_list;                  // [x] count of region x, [16 + x * lone_list_cap ..] indices of the rays that walk alone (behind the per-ray state)
@@ -1146,22 +1153,36 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     }
 }
 
-// Wave v of the first launch -> its 8x8 block of rays.  Image-shaped ray sets are walked in supertiles of 16 x 16 blocks (128 x 128 rays),
-// row-major inside a supertile and over the supertiles: the ~500 waves an XCD holds at a time then cover a compact patch of the image
-// whose mirror rays meet a compact part of the scene, instead of a 20-ray-high strip across the whole width.  Other ray sets: identity.
-constexpr uint32_t ST_SUPER = 16;
-__device__ __forceinline__ int64_t st_tile_of_wave(const StArgs& A, uint32_t v)
+// Wave w of region x of the first launch -> its 8x8 block of rays.  The blocks of rays are grouped into SUPERTILES of 8 x 8 blocks (64 x 64
+// rays, 64 waves), supertile s belongs to region s % 8 and a region walks its supertiles in order: the ~500 waves an XCD holds at a time
+// cover eight compact patches of the image -- whose mirror rays meet eight compact parts of the scene -- while every XCD gets every
+// eighth patch of the WHOLE image, i.e. an equal share of the work.  (Measured on the way, round 5: eight contiguous bands of the image, one
+// per XCD, are 29 % SLOWER than the round-robin of blocks they replaced -- a view's rays that hit nothing sit in its corners and the
+// launch lasts as long as the band through the middle.)  Ray sets that are no image: runs of 64 blocks.
+#ifndef ST_SUPER_EDGE
+#define ST_SUPER_EDGE 8
+#endif
+constexpr uint32_t ST_SUPER = ST_SUPER_EDGE;
+__host__ __device__ __forceinline__ uint32_t st_supertiles(int64_t n_tiles, int32_t ray_width)
 {
-    if (v >= A.n_tiles) return -1;
-    if (A.ray_width <= 0) return (int64_t)v;
+    if (ray_width <= 0) return (uint32_t)((n_tiles + ST_SUPER * ST_SUPER - 1) / (ST_SUPER * ST_SUPER));
+    const uint32_t tiles_x = (uint32_t)(ray_width + 7) >> 3, tiles_y = (uint32_t)(n_tiles / tiles_x);
+    return ((tiles_x + ST_SUPER - 1) / ST_SUPER) * ((tiles_y + ST_SUPER - 1) / ST_SUPER);
+}
+__device__ __forceinline__ int64_t st_tile_of_wave(const StArgs& A, uint32_t region, uint32_t w)
+{
+    constexpr uint32_t per = ST_SUPER * ST_SUPER;
+    const uint32_t s = (w / per) * 8u + region, t = w % per;
+    if (A.ray_width <= 0) {
+        const uint64_t tile = (uint64_t)s * per + t;
+        return tile < A.n_tiles ? (int64_t)tile : -1;
+    }
     const uint32_t tiles_x = (uint32_t)(A.ray_width + 7) >> 3, tiles_y = A.n_tiles / tiles_x;
-    const uint32_t band = tiles_x * ST_SUPER;                                   // blocks of a full row of supertiles
-    const uint32_t sy = v / band, in_band = v - sy * band;
-    const uint32_t hB = min(ST_SUPER, tiles_y - sy * ST_SUPER);
-    const uint32_t sx = in_band / (ST_SUPER * hB), in_super = in_band - sx * ST_SUPER * hB;
-    const uint32_t wB = min(ST_SUPER, tiles_x - sx * ST_SUPER);
-    const uint32_t ly = in_super / wB, lx = in_super - ly * wB;
-    return (int64_t)(sy * ST_SUPER + ly) * tiles_x + sx * ST_SUPER + lx;
+    const uint32_t sxn = (tiles_x + ST_SUPER - 1) / ST_SUPER;
+    const uint32_t sy = s / sxn, sx = s - sy * sxn;
+    const uint32_t ty = sy * ST_SUPER + t / ST_SUPER, tx = sx * ST_SUPER + t % ST_SUPER;
+    if (tx >= tiles_x || ty >= tiles_y) return -1;
+    return (int64_t)ty * tiles_x + tx;
 }
 
 // first launch: one wave per block of rays.  MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again
@@ -1177,10 +1198,9 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
     __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x;
-    // XCD b % 8 takes the (b % 8)-th eighth of the blocks of rays, in the blocky order of st_tile_of_wave
+    // XCD b % 8 takes every eighth supertile of the ray set (st_tile_of_wave)
     const uint32_t region = blockIdx.x & 7u;
-    const uint32_t wave = (region * A.region_blocks + (blockIdx.x >> 3)) * (ST_THREADS / 64) + (tid >> 6);
-    const int64_t tile = st_tile_of_wave(A, wave);
+    const int64_t tile = st_tile_of_wave(A, region, (blockIdx.x >> 3) * (ST_THREADS / 64) + (tid >> 6));
     if (tile < 0) return;
     st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, tile, -1, (uint32_t)tile, region);
 }
@@ -1219,6 +1239,7 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
                                                    const unsigned long long* __restrict__ vmask, const uint32_t* __restrict__ lone_list,
                                                    unsigned long long* slot, int lane, uint32_t region, uint32_t first_item, uint32_t item_stride)
 {
+    // item_stride == 0: the one item `first_item` (the forward's second launch hands items out by ticket); otherwise every item_stride-th
     const uint32_t listed = lone_list[region];
     const uint32_t count = listed < A.lone_list_cap ? listed : A.lone_list_cap;
     const StWide& W = A.wide;
@@ -1420,17 +1441,41 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
                 A.g_ray_d[3 * r] = v0; A.g_ray_d[3 * r + 1] = v1; A.g_ray_d[3 * r + 2] = v2;
             }
         }
+        if (item_stride == 0u) break;
     }
 }
 
-// second launch: the first ST_PACKET_BLOCKS blocks give every listed packet a wave, the blocks behind them every listed single ray.
-// One launch for both: each kind ends in a tail of a few long waves, and the two tails overlap instead of following each other.
-constexpr int ST_PACKET_BLOCKS = 2048;      // (multiples of 8: b % 8 of a block is its region in both halves of the grid)
-constexpr int ST_LONE_BLOCKS = 4096;
+// second launch: every listed packet and every listed single ray gets a wave.  One launch for both: each kind ends in a tail of a few long
+// waves, and the two tails overlap instead of following each other.
+// FORWARD (MODE 0): ST_REST_BLOCKS blocks of persistent waves.  A wave of XCD x (block b, x = b % 8) takes the next packet of region x's
+// list by ticket -- what the first launch's waves on that XCD listed, front to back, so that the waves an XCD holds at a time trace
+// neighbouring rays (StArgs) --, and when that list is exhausted it goes on with the lists of the other regions, then with the single rays
+// the same way.  The lists of the regions differ: what gets listed are silhouettes and grazing normals, which sit in a few dozen of an
+// 800 x 800 view's 169 supertiles, and a static "XCD x walks list x" ran 40 % longer than the region-blind stride of round 4 while
+// fetching a third of its bytes (measured, round 5) -- with the tickets the XCDs that finish early take over the tail of the others.
+// A ticket is one L2 atomic per ~150 us walk.  BACKWARD (MODE 1 / 2): no walk to keep local (the replay reads records), and the state
+// is not the backward's to write: every list is strided over all waves of the launch.
+constexpr int ST_REST_BLOCKS = 2048;
+
+// hdr[0..7] counts of the eight region lists (final: written by the launch before), hdr[8..15] tickets (zeroed by st_init_kernel).  `k`:
+// regions this wave has found exhausted (tickets only grow: they stay exhausted).  Wave-uniform result.
+__device__ __forceinline__ bool st_next_item(uint32_t* hdr, uint32_t cap, uint32_t own, int lane, uint32_t& k, uint32_t& region, uint32_t& local)
+{
+    for (; k < 8u; ++k) {
+        const uint32_t r = (own + k) & 7u;
+        const uint32_t listed = hdr[r];
+        const uint32_t n = listed < cap ? listed : cap;
+        uint32_t t = n;
+        if (lane == 0 && ld_agent_u(hdr + 8 + r) < n) t = atomicAdd(hdr + 8 + r, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t < n) { region = r; local = t; return true; }
+    }
+    return false;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : ST_FWD_WAVES, 8))) void st_trace_rest_kernel(StArgs A, const float4* __restrict__ leaf_ro, const float* __restrict__ wide_boxes,
-                                                                   const unsigned long long* __restrict__ wide_vmask, const uint32_t* __restrict__ lone_list)
+                                                                   const unsigned long long* __restrict__ wide_vmask, uint32_t* __restrict__ lone_list)
 {
     __shared__ uint32_t kb_id[ST_K][ST_THREADS];
     __shared__ float kb_t[MODE == 2 ? 1 : ST_K][ST_THREADS];
@@ -1438,26 +1483,46 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
     __shared__ uint32_t tab[MODE == 2 ? ST_THREADS / 64 : 1][MODE == 2 ? ST_TAB_WORDS : 1];
     __shared__ unsigned long long slot[ST_THREADS / 64][ST_K];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
-    const int tid = threadIdx.x;
-    // the blocks with b % 8 == x (XCD x) walk region x's lists front to back: what the first launch's waves on that XCD listed, in their order
-    const uint32_t region = blockIdx.x & 7u;
-    if (blockIdx.x >= ST_PACKET_BLOCKS) {
-        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], tid & 63, region,
-                                      ((blockIdx.x - ST_PACKET_BLOCKS) >> 3) * (ST_THREADS / 64) + (tid >> 6), (ST_LONE_BLOCKS / 8) * (ST_THREADS / 64));
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (MODE == 0 && ST_REST_SCHED == 0) {
+        const uint32_t own = blockIdx.x & 7u;
+        uint32_t k = 0, region = 0, local = 0;
+#if ST_REST_LONE_FIRST
+        while (st_next_item(lone_list, A.lone_list_cap, own, lane, k, region, local))
+            st_trace_lone_rays<false>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, local, 0u);
+        k = 0;
+#endif
+        if (A.defer_list != nullptr) {
+            while (st_next_item(A.defer_list, A.defer_cap, own, lane, k, region, local)) {
+                const uint32_t item = region * A.defer_cap + local;
+                const uint32_t code = A.defer_list[16 + item];
+                if (code == ST_REC_NONE) continue;                 // a slot of a block that found the list full
+                st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item, region);
+            }
+        }
+#if !ST_REST_LONE_FIRST
+        k = 0;
+        while (st_next_item(lone_list, A.lone_list_cap, own, lane, k, region, local))
+            st_trace_lone_rays<false>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, local, 0u);
+#endif
         return;
     }
-    if (A.defer_list == nullptr) return;
-    if (MODE == 2) return;                                     // the replay of listed packets rides in their blocks' waves of the first launch
-    const uint32_t listed = A.defer_list[region];
-    const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
-    const uint32_t stride = (ST_PACKET_BLOCKS / 8) * (ST_THREADS / 64);
-    for (uint32_t local = (blockIdx.x >> 3) * (ST_THREADS / 64) + (tid >> 6); local < count; local += stride) {
-        const uint32_t item = region * A.defer_cap + local;
-        const uint32_t code = A.defer_list[16 + item];
-        if (code == ST_REC_NONE) continue;                     // a slot of a block that found the list full
-        st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item,
-                            region);
+    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6), stride = ST_REST_BLOCKS * (ST_THREADS / 64);
+    if (MODE != 2 && A.defer_list != nullptr) {                    // (MODE 2: the replay of listed packets rides in their blocks' waves of the first launch)
+        for (uint32_t region = 0; region < 8u; ++region) {
+            const uint32_t listed = A.defer_list[region];
+            const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
+            for (uint32_t local = wave; local < count; local += stride) {
+                const uint32_t item = region * A.defer_cap + local;
+                const uint32_t code = A.defer_list[16 + item];
+                if (code == ST_REC_NONE) continue;
+                st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item,
+                                    region);
+            }
+        }
     }
+    for (uint32_t region = 0; region < 8u; ++region)
+        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, wave, stride);
 }
 
 }   // namespace
@@ -1492,12 +1557,12 @@ static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte
     StateLayout L;
     L.n_tiles = (n_rays + 63) / 64;
     if (ray_width > 0 && n_rays % ray_width == 0) L.n_tiles = (int64_t)((ray_width + 7) / 8) * ((n_rays / ray_width + 7) / 8);
-    // eight regions (StArgs): the first launch is region_blocks blocks per region, every list has a part per region
-    L.region_blocks = (uint32_t)((L.n_tiles * 64 + 8 * ST_THREADS - 1) / (8 * ST_THREADS));
+    // eight regions (StArgs): the first launch is region_blocks blocks per region (whole supertiles), every list has a part per region
+    L.region_blocks = ((st_supertiles(L.n_tiles, (ray_width > 0 && n_rays % ray_width == 0) ? ray_width : 0) + 7u) / 8u) * (ST_SUPER * ST_SUPER * 64u / ST_THREADS);
     L.grid = 8 * (int64_t)L.region_blocks;
     L.defer_cap = (uint32_t)((4 * L.n_tiles + 1024 + 7) / 8);       // per region
     L.pool = (uint32_t)(3 * L.n_tiles + 64);
-    L.lone_list_cap = L.region_blocks * ST_THREADS;                  // per region: every ray of the region
+    L.lone_list_cap = (uint32_t)(n_rays < (int64_t)L.region_blocks * ST_THREADS ? n_rays : (int64_t)L.region_blocks * ST_THREADS);   // per region: every ray of the region
     L.lone = (size_t)4 * n_rays;                                     // [x] count of region x, [16..] ray indices, region by region
     L.defer = L.lone + 16 + (size_t)8 * L.lone_list_cap;             // [x] count of region x, [16..] packets of the second launch, region by region
     L.rec_hdr = L.defer + 16 + (size_t)8 * L.defer_cap;
@@ -1619,7 +1684,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     const StateLayout SL = st_state(n_rays, a.ray_width);
     if (state_floats < SL.rec_arena) return MRGS_E_WORKSPACE;
     const bool have_arena = state_floats >= SL.total;       // a state without the replay record (forward-only callers): the backward walks again
-    const dim3 grid((unsigned)SL.grid), rgrid(ST_PACKET_BLOCKS + ST_LONE_BLOCKS);
+    const dim3 grid((unsigned)SL.grid), rgrid(ST_REST_BLOCKS);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
     a.lone_list = words + SL.lone;
     a.defer_list = words + SL.defer;

@@ -22,6 +22,33 @@ import torch
 import torch.distributed as dist
 
 SH_C0 = 0.28209479177387814
+_MAX_SHARDS = 64
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def sum_reduce_scatter_gather(buf: torch.Tensor, group=None):
+    """In-place sum of `buf` (length a multiple of the world size) over all ranks as an EXPLICIT reduce-scatter followed by an
+    all-gather of the reduced shards, queued back to back; returns a handle whose wait() orders the caller's stream (host, for gloo)
+    behind both.  Why not dist.all_reduce: on the 8-GPU node every pair of GPUs has its own xGMI link, and with the two halves spelled
+    out every rank sends 1/V of the bucket to each peer and receives 1/V from each, twice -- (V - 1) / V of the bucket per link and
+    direction in total, whatever algorithm the library would pick for an all-reduce of this size (a ring all-reduce moves the same
+    bytes through ONE link per rank, 7x the time on this topology; the scaling model of bench.py assumes the direct form)."""
+    world = dist.get_world_size(group)
+    assert buf.is_contiguous() and buf.numel() % world == 0
+    rank = dist.get_rank(group)
+    n = buf.numel() // world
+    shard = torch.empty(n, dtype=buf.dtype, device=buf.device)
+    w = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    if dist.get_backend(group) != "nccl":
+        w.wait()          # gloo runs its operations on worker threads: the gather must not start before the scatter has finished
+    # (RCCL: both collectives are queued on the process group's own stream, in this order; `shard` is kept alive by the work object)
+    w2 = dist.all_gather_into_tensor(buf, shard, group=group, async_op=True)
+    del rank
+    return w2
 
 
 class GradBucket:
@@ -33,7 +60,15 @@ class GradBucket:
         self.offsets = [0]
         for n in self.numels:
             self.offsets.append(self.offsets[-1] + n)
-        self.flat = torch.zeros(self.offsets[-1], dtype=dtype, device=device)
+        # (room behind the last tensor so that the bucket can be cut into `world` equal shards for any world <= _MAX_SHARDS:
+        #  sum_reduce_scatter_gather)
+        self._store = torch.zeros(self.offsets[-1] + _MAX_SHARDS, dtype=dtype, device=device)
+        self.flat = self._store[:self.offsets[-1]]
+
+    def padded(self, world: int):
+        """The bucket as a tensor whose length is a multiple of `world` (the tail beyond the packed tensors is zeros nobody reads)."""
+        n = self.offsets[-1]
+        return self._store[:(n + world - 1) // world * world]
 
     def pack(self, tensors: Sequence[Optional[torch.Tensor]]):
         assert len(tensors) == len(self.shapes)
@@ -56,9 +91,10 @@ def allreduce_gradients(bucket: GradBucket, tensors: Sequence[Optional[torch.Ten
     """Sum (or mean) the per-view gradients over all ranks with one collective; returns views into the bucket."""
     flat = bucket.pack(tensors)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        world = dist.get_world_size(group)
+        sum_reduce_scatter_gather(bucket.padded(world), group).wait()
         if average:
-            flat.div_(dist.get_world_size(group))
+            flat.div_(world)
     return bucket.views()
 
 
@@ -94,6 +130,7 @@ class FactoredGradReducer:
         self.row = torch.empty(3 * P + 3, dtype=torch.float32, device=device)
         self.gathered = None
         self._early = None
+        self._early_void = False     # begin_early was called twice in one step: the early row is not the whole factor (see there)
 
     def _gather(self, world, group):
         P = self.sh_shape[0]
@@ -110,6 +147,16 @@ class FactoredGradReducer:
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         if world == 1:
             return
+        if self._early is not None:
+            # A second rasterizer backward before reduce() (two renders share the SH tensor in one step, or a step was abandoned before
+            # its reduce): the row of the first call is NOT the whole factor any more -- dL/dsh then sums two rank-one terms with different
+            # directions -- so the early gather is dropped (after it has finished with the buffers) and reduce() gathers dL/dsh[:, 0, :] / SH_C0 as
+            # without the hook: exact for one camera per step, and the only form that exists for several.
+            self._early.wait()
+            self._early, self._early_void = None, True
+            return
+        if getattr(self, "_early_void", False):
+            return
         P = self.sh_shape[0]
         self.row[:3 * P].view(P, 3).copy_(dRGB)
         self.row[3 * P:].copy_(campos.reshape(-1))
@@ -125,7 +172,7 @@ class FactoredGradReducer:
         if world == 1:
             views = self.small.views()
             return views[:self.sh_index] + [sh] + views[self.sh_index:]
-        w1, self._early = self._early, None
+        w1, self._early, self._early_void = self._early, None, False
         if w1 is None:
             if sh is None:
                 self.row[:3 * P].zero_()
@@ -133,7 +180,8 @@ class FactoredGradReducer:
                 torch.div(sh[:, 0, :], SH_C0, out=self.row[:3 * P].view(P, 3))
             self.row[3 * P:].copy_(campos.reshape(-1))
             w1 = self._gather(world, group)
-        w2 = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        del flat
+        w2 = sum_reduce_scatter_gather(self.small.padded(world), group)
         w1.wait()
         sh_sum = self.expand_fn(self.gathered, means3D, M, sh_degree)
         w2.wait()
@@ -160,6 +208,32 @@ def expand_surfel_sh_gradients(gathered: torch.Tensor, xyz: torch.Tensor, rotati
     return out
 
 
+def expand_surfel_sh_gradient_rows(gathered_rgb: torch.Tensor, gathered_ind: Optional[torch.Tensor], xyz: torch.Tensor, rotation_raw: torch.Tensor,
+                                   sh_degree: int, family: str = "both"):
+    """expand_surfel_sh_gradients from the two buffers the two all-gathers fill: gathered_rgb [V, 3P + 3] rows [dRGB_v | campos_v],
+    gathered_ind [V, 3P] rows dIND_v (mrgs_sh_grad_expand_surfel_rows); no CPU path.  family "rgb" / "ind": only that family's two tensors
+    (dc [P,1,3], rest [P,15,3]) -- a step expands each family when its gather has landed; "both": all four."""
+    V, P = gathered_rgb.shape[0], xyz.shape[0]
+    assert gathered_rgb.shape == (V, 3 * P + 3) and gathered_rgb.is_contiguous()
+    assert family == "rgb" or (gathered_ind.shape == (V, 3 * P) and gathered_ind.is_contiguous())
+    if not xyz.is_cuda:
+        raise RuntimeError("expand_surfel_sh_gradient_rows needs CUDA(HIP) tensors: the expansion runs in libmrgs.so, there is no CPU path")
+    from . import _lib
+    o = dict(dtype=torch.float32, device=xyz.device)
+    a = [torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o)] if family != "ind" else [None, None]
+    b = [torch.empty((P, 1, 3), **o), torch.empty((P, 15, 3), **o)] if family != "rgb" else [None, None]
+    x3, q4 = xyz.detach().float().contiguous(), rotation_raw.detach().float().contiguous()
+    cam = gathered_rgb[:, 3 * P:]
+    ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(xyz.device):
+        st = ctypes.c_void_p(torch.cuda.current_stream(xyz.device).cuda_stream)
+        _lib.check(_lib.lib().mrgs_sh_grad_expand_surfel_rows(
+            P, int(sh_degree), V, ptr(x3), ptr(q4), ptr(gathered_rgb) if family != "ind" else None, gathered_rgb.stride(0),
+            ptr(gathered_ind) if family != "rgb" else None, gathered_ind.stride(0) if family != "rgb" else 0, ptr(cam), gathered_rgb.stride(0),
+            ptr(a[0]), ptr(a[1]), ptr(b[0]), ptr(b[1]), st))
+    return [t for t in a + b if t is not None]
+
+
 class SurfelGradReducer:
     """View-parallel gradient sum for render_surfel's parameter set (BASELINE config 5).  `names` labels the gradient tensors in the
     order they are passed and must contain "xyz", "rotation", "features_dc", "features_rest", "indirect_dc", "indirect_rest"; the four
@@ -175,31 +249,96 @@ class SurfelGradReducer:
         self.dense_pos = [i for i in range(len(self.names)) if i not in self.sh_pos]
         self.dense = GradBucket([shapes[i] for i in self.dense_pos], device)
         self.P = int(shapes[self.names.index("xyz")][0])
-        self.row = torch.empty(6 * self.P + 3, dtype=torch.float32, device=device)
-        self.gathered = None
+        # the two factors travel apart (they are final at different times of a backward): [dRGB | campos] and [dIND]
+        self.row_rgb = torch.empty(3 * self.P + 3, dtype=torch.float32, device=device)
+        self.row_ind = torch.empty(3 * self.P, dtype=torch.float32, device=device)
+        self.gathered_rgb = self.gathered_ind = None
+        self._early_rgb = self._early_ind = None
+        self._void = False
+
+    def _buffers(self, world):
+        if self.gathered_rgb is None or self.gathered_rgb.shape[0] != world:
+            self.gathered_rgb = torch.empty((world, 3 * self.P + 3), dtype=torch.float32, device=self.row_rgb.device)
+            self.gathered_ind = torch.empty((world, 3 * self.P), dtype=torch.float32, device=self.row_rgb.device)
+
+    def _world(self, group):
+        return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def begin_early_rgb(self, dRGB: torch.Tensor, campos: torch.Tensor, group=None):
+        """Start the all-gather of this view's colour factor in the middle of the backward: `dRGB` [P,3] is what the rasterizer hands out
+        between its blend backward and its per-gaussian backward (rasterizer.set_after_blend_hook) -- final there, because render_surfel
+        rasterizes the colour SH exactly once.  The collective runs next to the per-gaussian backward, the per-gaussian glue's backward
+        and whatever follows.  A second call before reduce() (two rasterizations in one step share the SH tensors: the sum of two rank-one
+        terms is not one row) voids the early path for this step: reduce() then gathers dL/dfeatures_dc[:, 0, :] / SH_C0 as without hooks."""
+        world = self._world(group)
+        if world == 1:
+            return
+        if self._early_rgb is not None or self._void:
+            if self._early_rgb is not None:
+                self._early_rgb.wait()
+            self._early_rgb, self._void = None, True
+            return
+        P = self.P
+        self._buffers(world)
+        self.row_rgb[:3 * P].view(P, 3).copy_(dRGB)
+        self.row_rgb[3 * P:].copy_(campos.reshape(-1))
+        self._early_rgb = dist.all_gather_into_tensor(self.gathered_rgb.view(-1), self.row_rgb, group=group, async_op=True)
+
+    def begin_early_ind(self, d_indirect_dc: torch.Tensor, group=None):
+        """The second factor, dIND = dL/dindirect_dc[:, 0, :] / SH_C0, as soon as the per-gaussian glue's backward has produced it
+        (renderer.set_after_features_hook): its all-gather runs under the packing of the dense bucket and the first collective."""
+        world = self._world(group)
+        if world == 1:
+            return
+        if self._early_ind is not None or self._void:
+            if self._early_ind is not None:
+                self._early_ind.wait()
+            self._early_ind, self._void = None, True
+            return
+        P = self.P
+        self._buffers(world)
+        torch.div(d_indirect_dc.reshape(P, 3), SH_C0, out=self.row_ind.view(P, 3))
+        self._early_ind = dist.all_gather_into_tensor(self.gathered_ind.view(-1), self.row_ind, group=group, async_op=True)
 
     def reduce(self, tensors: Sequence[Optional[torch.Tensor]], xyz: torch.Tensor, rotation_raw: torch.Tensor, campos: torch.Tensor,
                sh_degree: int, group=None):
         """Returns the summed gradients in the order of `tensors`."""
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        world = self._world(group)
         if world == 1:
             return list(tensors)
         P = self.P
-        flat = self.dense.pack([tensors[i] for i in self.dense_pos])
-        for k, name in enumerate(("features_dc", "indirect_dc")):
+        self._buffers(world)
+        w_rgb, w_ind, void = self._early_rgb, self._early_ind, self._void
+        self._early_rgb = self._early_ind = None
+        self._void = False
+        if void:                     # (whatever was started early has been waited for in begin_early_*)
+            w_rgb = w_ind = None
+
+        def seg(name, out):
             t = tensors[self.names.index(name)]
-            seg = self.row[3 * P * k:3 * P * (k + 1)]
             if t is None:
-                seg.zero_()
+                out.zero_()
             else:
-                torch.div(t[:, 0, :], SH_C0, out=seg.view(P, 3))
-        self.row[6 * P:].copy_(campos.reshape(-1))
-        if self.gathered is None or self.gathered.shape[0] != world:
-            self.gathered = torch.empty((world, 6 * P + 3), dtype=torch.float32, device=self.row.device)
-        w1 = dist.all_gather_into_tensor(self.gathered.view(-1), self.row, group=group, async_op=True)
-        w2 = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        w1.wait()
-        sh = self.expand_fn(self.gathered, xyz, rotation_raw, sh_degree)
+                torch.div(t[:, 0, :], SH_C0, out=out.view(P, 3))
+        if w_rgb is None:
+            seg("features_dc", self.row_rgb[:3 * P])
+            self.row_rgb[3 * P:].copy_(campos.reshape(-1))
+            w_rgb = dist.all_gather_into_tensor(self.gathered_rgb.view(-1), self.row_rgb, group=group, async_op=True)
+        if w_ind is None:
+            seg("indirect_dc", self.row_ind)
+            w_ind = dist.all_gather_into_tensor(self.gathered_ind.view(-1), self.row_ind, group=group, async_op=True)
+        self.dense.pack([tensors[i] for i in self.dense_pos])
+        w2 = sum_reduce_scatter_gather(self.dense.padded(world), group)
+        w_rgb.wait()
+        if self.expand_fn is expand_surfel_sh_gradients:
+            # each family as soon as ITS rows are there: the first expansion runs under the second gather and the dense exchange
+            sh = expand_surfel_sh_gradient_rows(self.gathered_rgb, None, xyz, rotation_raw, sh_degree, family="rgb")
+            w_ind.wait()
+            sh = sh + expand_surfel_sh_gradient_rows(self.gathered_rgb, self.gathered_ind, xyz, rotation_raw, sh_degree, family="ind")
+        else:       # (an injected checker takes the rows in one piece: [dRGB | dIND | campos])
+            w_ind.wait()
+            rows = torch.cat((self.gathered_rgb[:, :3 * P], self.gathered_ind, self.gathered_rgb[:, 3 * P:]), dim=1).contiguous()
+            sh = self.expand_fn(rows, xyz, rotation_raw, sh_degree)
         w2.wait()
         out = [None] * len(self.names)
         for i, v in zip(self.dense_pos, self.dense.views()):

@@ -30,31 +30,37 @@ _WORK_HINTS = {}
 _NO_HINT = bool(int(__import__("os").environ.get("MRGS_NO_WORK_HINT", "0")))   # developer switch for A/B timing
 _NO_PREPARE = bool(int(__import__("os").environ.get("MRGS_NO_PREPARE_BWD", "0")))   # developer switch: the backward orders / clears by itself
 _NO_DEFER = bool(int(__import__("os").environ.get("MRGS_NO_DEFER", "0")))   # developer switch: render functions wait for the pair count inside the rasterizer call
-_WORK_HINTS_MAX = 2048
+_WORK_HINTS_MAX = 2048                    # cameras ...
+_WORK_HINTS_MAX_BYTES = 256 << 20         # ... and device bytes the cache may pin (a buffer is ~100 KB at 800x800, ~340 KB at 1600x1600), least recently used first out
+_WORK_HINTS_BYTES = [0]
 
 
-def _hint_key(raster_settings, device):
+def _hint_key(raster_settings, device, P):
+    # P: the hint orders the blend waves of ONE surfel set seen from one camera; after densification / pruning, or for another model
+    # rendered through the same camera object, the deal would be balanced for a different scene (results would still be right)
     vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
-    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr())
+    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr(), int(P))
 
 
-def _hint_entry(raster_settings, device):
-    """The (hint buffer, viewmatrix, projmatrix, versions, visits) entry of this camera, or None when it was never rendered or when its
-    matrices were written in place since."""
-    ent = _WORK_HINTS.get(_hint_key(raster_settings, device))
+def _hint_entry(raster_settings, device, P):
+    """The (hint buffer, viewmatrix, projmatrix, versions, visits) entry of this camera and surfel count, or None when it was never
+    rendered or when its matrices were written in place since."""
+    key = _hint_key(raster_settings, device, P)
+    ent = _WORK_HINTS.get(key)
     if ent is None:
         return None
     vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
     if ent[3] != (vm._version, pm._version):
         return None
+    _WORK_HINTS[key] = _WORK_HINTS.pop(key)      # most recently used last (dicts keep insertion order)
     return ent
 
 
-def _hint_is_warm(raster_settings, device):
+def _hint_is_warm(raster_settings, device, P):
     """True when this camera was rendered before, i.e. its hint holds measured work.  Only then may the forward set up the backward's
     queues (they are a copy of its own): built from the cull counts alone they balance the backward a third worse than the
     backward's own ordering by what the forward waves walked."""
-    ent = _hint_entry(raster_settings, device)
+    ent = _hint_entry(raster_settings, device, P)
     return ent is not None and ent[4][0] > 0
 
 
@@ -62,30 +68,35 @@ _REORDER_EVERY = 16     # visits of a camera between two orderings of its blend 
 _NO_REUSE = bool(int(__import__("os").environ.get("MRGS_NO_REUSE_ORDER", "0")))   # developer switch for A/B timing
 
 
-def _hint_flags(raster_settings, device):
+def _hint_flags(raster_settings, device, P):
     """MRGS_HINT_REUSE_ORDER for this forward: the camera's hint buffer holds the queues an ordering launch dealt at its second visit or
     later (from measured work), and the forward deals its waves the same way again instead of ordering them anew -- the ordering is 15 us
     of a 0.5 ms view and changes little from one visit to the next.  Every _REORDER_EVERY-th visit orders again."""
     if _NO_HINT or _NO_REUSE:
         return 0
-    ent = _hint_entry(raster_settings, device)
+    ent = _hint_entry(raster_settings, device, P)
     if ent is None:
         return 0
     visits = ent[4][0]
     return _lib.MRGS_HINT_REUSE_ORDER if (visits >= 2 and visits % _REORDER_EVERY != 0) else 0
 
 
-def _work_hint(raster_settings, device, count_visit=False):
+def _work_hint(raster_settings, device, P, count_visit=False):
     if _NO_HINT:
         return None
-    ent = _hint_entry(raster_settings, device)
+    ent = _hint_entry(raster_settings, device, P)
     if ent is None:
-        if len(_WORK_HINTS) >= _WORK_HINTS_MAX:
-            _WORK_HINTS.pop(next(iter(_WORK_HINTS)))
         n = _lib.lib().mrgs_work_hint_bytes(int(raster_settings.image_height), int(raster_settings.image_width)) // 4
+        key = _hint_key(raster_settings, device, P)
+        old = _WORK_HINTS.pop(key, None)              # (stale: its matrices were written in place)
+        if old is not None:
+            _WORK_HINTS_BYTES[0] -= old[0].numel() * 4
+        while _WORK_HINTS and (len(_WORK_HINTS) >= _WORK_HINTS_MAX or _WORK_HINTS_BYTES[0] + 4 * n > _WORK_HINTS_MAX_BYTES):
+            _WORK_HINTS_BYTES[0] -= _WORK_HINTS.pop(next(iter(_WORK_HINTS)))[0].numel() * 4      # (a render in flight keeps its buffer alive through its ctx)
         vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
         ent = (torch.zeros(max(int(n), 1), dtype=torch.int32, device=device), vm, pm, (vm._version, pm._version), [0])
-        _WORK_HINTS[_hint_key(raster_settings, device)] = ent
+        _WORK_HINTS[key] = ent
+        _WORK_HINTS_BYTES[0] += ent[0].numel() * 4
     if count_visit:
         ent[4][0] += 1
     return ent[0]
@@ -95,6 +106,7 @@ def reset_work_hints():
     """Forget every camera's measured work (the next render of each camera is a first visit again).  A training loop calls this after
     densification / pruning changed the surfel set; bench.py uses it to time first visits."""
     _WORK_HINTS.clear()
+    _WORK_HINTS_BYTES[0] = 0
     _CAM_COPIES.clear()
 
 
@@ -170,9 +182,18 @@ def _stream(device):
     return _lib.stream_ptr(device)
 
 
+_RESOLVE = object()
+
+
 def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None,
-                     bwd_grad_ws=None):
+                     bwd_grad_ws=None, work_hint=_RESOLVE):
+    """work_hint: the camera's hint buffer (or None) -- the BACKWARD passes the very tensor its forward used (the queue state, the tickets
+    and the forward's item assignment live in it: a buffer resolved anew at backward time could be a fresh, zeroed one after
+    reset_work_hints(), an eviction or an in-place pose change, and a prepared backward would then pull item 0 in every wave); the
+    forward leaves it out and gets the cache's.  Returns (cfg, inp, hint tensor)."""
     P = means3D.shape[0]
+    if work_hint is _RESOLVE:
+        work_hint = _work_hint(raster_settings, means3D.device, P) if means3D.is_cuda else None
     S = features.shape[1] if features.dim() == 2 else 0
     M = sh.shape[1] if sh.numel() != 0 else 0
     if sh_rest is not None:       # split layout: sh = DC [P,1,3], sh_rest = [P,M-1,3]
@@ -184,9 +205,9 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
     inp = MrgsRasterInputs(_ptr(raster_settings.bg), _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(features),
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
                            _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
-                           _ptr(_work_hint(raster_settings, means3D.device)) if means3D.is_cuda else None, _ptr(sh_rest),
-                           _ptr(bwd_grad_ws), _hint_flags(raster_settings, means3D.device) if means3D.is_cuda else 0, 0)
-    return cfg, inp
+                           _ptr(work_hint), _ptr(sh_rest),
+                           _ptr(bwd_grad_ws), _hint_flags(raster_settings, means3D.device, P) if means3D.is_cuda else 0, 0)
+    return cfg, inp, work_hint
 
 
 class RasterWorkspaceOverflow(RuntimeError):
@@ -207,7 +228,7 @@ def _note_count(guess_key, num_rendered, hint_settings, dev):
         _PAIR_GUESS.pop(next(iter(_PAIR_GUESS)))
     _PAIR_GUESS[guess_key] = max(int(num_rendered * 1.25) + 65536, 1)
     if hint_settings is not None:
-        _work_hint(hint_settings, dev, count_visit=True)   # this camera's hint now holds measured work
+        _work_hint(hint_settings, dev, guess_key[1], count_visit=True)   # this camera's hint now holds measured work (guess_key[1] = P)
 
 
 class _PendingCount:
@@ -310,8 +331,8 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
     if prepare_backward and means3D.shape[0] > 0:
         with _lib.guard(dev):
             grad_ws = torch.empty((L.mrgs_grad_bytes(means3D.shape[0], S_),), dtype=torch.uint8, device=dev)
-    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                                sh_rest, grad_ws)
+    cfg, inp, hint = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                                      sh_rest, grad_ws)
     P, S = cfg.P, cfg.S
     with _lib.guard(dev):
         st = _stream(dev)
@@ -336,7 +357,7 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
             ticket = MrgsRasterTicket()
             _lib.check(L.mrgs_rasterize_forward_begin(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), geom.numel(), _ptr(binning), binning.numel(),
                                                       pairs, _ptr(img), _ptr(radii), _ptr(color), _ptr(feature), _ptr(others), ctypes.byref(ticket), st))
-            pending = _PendingCount(ticket, guess_key, raster_settings if inp.work_hint else None, dev)
+            pending = _PendingCount(ticket, guess_key, raster_settings if hint is not None else None, dev)
             if box is not None:
                 # a renderer queues its own kernels behind the rasterizer first and asks for the count at its end (deferred_count)
                 # (the library keeps _TICKET_RING landing slots per thread and device: a box that begins more renders than that collects
@@ -348,7 +369,7 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
                     except RasterWorkspaceOverflow:
                         pass
                 box.pending.append(pending)
-                return (pending, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
+                return (pending, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws, hint
             try:
                 num_rendered = pending.finish()
             except RasterWorkspaceOverflow as ex:
@@ -364,19 +385,22 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
             _lib.check(L.mrgs_rasterize_forward_render(ctypes.byref(cfg), ctypes.byref(inp), _ptr(geom), _ptr(binning), binning.numel(),
                                                        _ptr(img), pairs, _ptr(color), _ptr(feature), _ptr(others), st))
             if P > 0:
-                _note_count(guess_key, num_rendered, raster_settings if inp.work_hint else None, dev)
-    return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws
+                _note_count(guess_key, num_rendered, raster_settings if hint is not None else None, dev)
+    return (num_rendered, pairs), contrib, color, feature, others, radii, geom, binning, img, grad_ws, hint
 
 
 def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp,
                                grad_out_color, grad_out_feature, grad_out_others, sh, opacities, geom, num_rendered, binning, img,
-                               sh_rest=None, prepared_grad_ws=None):
+                               sh_rest=None, prepared_grad_ws=None, work_hint=_RESOLVE):
     """Counterpart of `_C.rasterize_gaussians_backward` (rasterize_points.cu:146-252).  prepared_grad_ws: the workspace the forward of
-    this render was given (cleared, queues set up) -- valid for one backward."""
+    this render was given (cleared, queues set up) -- valid for one backward.  work_hint: the hint buffer that forward used (its ctx
+    keeps it); a prepared backward without it takes the non-prepared path (it orders and clears by itself)."""
     L = _lib.lib()
     dev = means3D.device
-    cfg, inp = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                                sh_rest, prepared_grad_ws)
+    if prepared_grad_ws is not None and (work_hint is _RESOLVE or work_hint is None):
+        prepared_grad_ws = None            # the forward's queues cannot be named: never guess them
+    cfg, inp, _ = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
+                                   sh_rest, prepared_grad_ws, work_hint)
     P, S, M = cfg.P, cfg.S, cfg.M
     with _lib.guard(dev):
         st = _stream(dev)
@@ -426,7 +450,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         opacities, scales, rotations, cov3Ds_precomp = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_camera_f32c(raster_settings.viewmatrix),
                                       projmatrix=_camera_f32c(raster_settings.projmatrix), campos=_camera_f32c(raster_settings.campos))
-        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest, any(ctx.needs_input_grad) and not _NO_PREPARE and means3D.is_cuda and _hint_is_warm(rs, means3D.device))
+        args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest,
+                any(ctx.needs_input_grad) and not _NO_PREPARE and means3D.is_cuda and _hint_is_warm(rs, means3D.device, means3D.shape[0]))
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted
             try:
@@ -437,8 +462,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ex
         else:
             out = _rasterize_forward_native(*args)
-        (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer, grad_ws = out
+        (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer, grad_ws, hint = out
         ctx.prepared_grad_ws = grad_ws       # cleared by the forward, queues of the backward set up: good for ONE backward
+        ctx.work_hint = hint                 # the buffer those queues live in: the backward is handed this very tensor (never a re-resolved one)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         if isinstance(num_rendered, _PendingCount):      # begun inside deferred_count(): the count arrives with the box's finish()
@@ -466,7 +492,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_depth = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
         prepared, ctx.prepared_grad_ws = ctx.prepared_grad_ws, None
         args = (rs, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp, _f32c(grad_out_color),
-                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest, prepared)
+                _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest, prepared,
+                ctx.work_hint)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])
             try:

@@ -101,6 +101,16 @@ def _p(t):
 _c = _lib.f32c
 
 
+_AFTER_FEATURES_HOOK = [None]
+
+
+def set_after_features_hook(fn):
+    """fn(dL_dindirect_dc [P,1,3]) is called at the end of the per-gaussian glue's backward (the last kernel of a render_surfel backward):
+    the second rank-one factor of a view-parallel step's SH exchange is final there (dist.SurfelGradReducer.begin_early_ind; the first one
+    leaves the rasterizer earlier, rasterizer.set_after_blend_hook).  None removes the hook."""
+    _AFTER_FEATURES_HOOK[0] = fn
+
+
 class _SurfelFeatures(torch.autograd.Function):
     """mrgs_surfel_features_forward/backward (include/mrgs.h): raw GaussianModel parameters -> (opacity, scales, rotations,
     features[P,8]) in one kernel each way (checker: oracle/glue_oracle.py, the reference's own chain of torch ops)."""
@@ -139,6 +149,8 @@ class _SurfelFeatures(torch.autograd.Function):
             st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads),
                                                        _p(gs[4]), st))
+        if _AFTER_FEATURES_HOOK[0] is not None:
+            _AFTER_FEATURES_HOOK[0](outs[7])
         return (*outs, None, None)
 
 
@@ -193,12 +205,15 @@ class _SurfelMaps(torch.autograd.Function):
     backward kernel instead of two extra [7,H,W] accumulation kernels."""
 
     @staticmethod
-    def forward(ctx, allmap, fr, want_surf_normal, want_normal_map, twin_alpha=False):
+    def forward(ctx, allmap, fr, want_surf_normal, want_normal_map, twin_alpha=False, rend_distance=None):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not allmap.is_cuda:
             raise RuntimeError("the fused map kernels need CUDA(HIP) tensors: there is no CPU path")
         allmap = _c(allmap)
         H, W, dev = fr.H, fr.W, allmap.device
+        # "pgsr": the blended plane distance [1,H,W]; surf_depth is then the flavour's unbiased depth, formed inside the kernels (fr.pgsr_fx/fy)
+        rd = None if rend_distance is None else _c(rend_distance)
+        fr.rend_distance, fr.g_rend_distance = _p(rd), None
         o = dict(dtype=torch.float32, device=dev)
         rn, sd = torch.empty((3, H, W), **o), torch.empty((1, H, W), **o)
         sn = torch.empty((3, H, W), **o) if want_surf_normal else None
@@ -211,7 +226,7 @@ class _SurfelMaps(torch.autograd.Function):
             st = _lib.stream_ptr(dev)
             _lib.check(_lib.lib().mrgs_surfel_maps_forward(ctypes.byref(fr), _p(allmap), _p(rn), _p(sd), _p(sn), _p(nm), _p(ra_rd[0]), _p(ra_rd[1]),
                                                            _p(ra_rd[2]) if twin_alpha else None, st))
-        ctx.save_for_backward(allmap)
+        ctx.save_for_backward(allmap, *(() if rd is None else (rd,)))
         ctx.fr = fr
         outs = (rn, sd, sn if sn is not None else rn.new_empty(0), nm if nm is not None else rn.new_empty(0))
         ctx.mark_non_differentiable(*[t for t in outs[2:] if t.numel() == 0])
@@ -221,15 +236,18 @@ class _SurfelMaps(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rn, g_sd, g_sn, g_nm, g_ra, g_rd, g_ra2=None):
-        (allmap,) = ctx.saved_tensors
+        allmap, *rest = ctx.saved_tensors
         dev = allmap.device
         g = [None if (t is None or t.numel() == 0) else _c(t) for t in (g_rn, g_sd, g_sn, g_nm, g_ra, g_rd, g_ra2)]
         g_allmap = torch.empty_like(allmap)
+        g_dist = torch.empty_like(rest[0]) if rest else None          # gradient of the plane-distance map ("pgsr")
+        fr = ctx.fr
+        fr.rend_distance, fr.g_rend_distance = (_p(rest[0]), _p(g_dist)) if rest else (None, None)
         with _lib.guard(dev):
             st = _lib.stream_ptr(dev)
-            _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(ctx.fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]),
+            _lib.check(_lib.lib().mrgs_surfel_maps_backward(ctypes.byref(fr), _p(allmap), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(g[5]),
                                                             _p(g[6]), _p(g_allmap), st))
-        return g_allmap, None, None, None, None
+        return g_allmap, None, None, None, None, g_dist
 
 
 class _SurfelComposite(torch.autograd.Function):
@@ -273,7 +291,8 @@ def pgsr_unbiased_depth(allmap, rend_distance, viewpoint_camera):
     = sum w |n . c| (get_distance, :30-40) and allmap[2:5] = sum w n, both un-normalised sums, so the accumulated alpha cancels.  The
     ray goes through pixel (x, y) of the rasterizer's own image plane (principal point (W - 1) / 2, the ndc2pix of forward.cu:114-118),
     so the depth is consistent with where the surfels were splatted.  Empty pixels give 0 / 0; callers apply nan_to_num as the
-    reference does."""
+    reference does.  The product path evaluates this inside mrgs_surfel_maps_forward / _backward (MrgsMapsFrame::rend_distance); this
+    function is the torch statement the kernels are tested against (tests/test_shading.py)."""
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     fx = W / (2.0 * math.tan(viewpoint_camera.FoVx * 0.5))
     fy = H / (2.0 * math.tan(viewpoint_camera.FoVy * 0.5))
@@ -290,13 +309,14 @@ def compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, retu
     dictionary also holds render_surfel's `normal_map` [H,W,3] = render_normal / max(alpha, 1e-6) (:419-421).
     `rend_distance` (the "pgsr" flavour's blended plane distance): surf_depth is then the flavour's unbiased depth
     (`nan_to_num(allmap[7])`, :64-69; pgsr_unbiased_depth) instead of the expected / median mix, and surf_normal its finite differences."""
+    fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
     if rend_distance is not None:
-        # the fused kernel takes surf_depth = nan_to_num(median channel) at depth_ratio 1: the unbiased depth rides in that slot
-        allmap = torch.cat((allmap[:5], pgsr_unbiased_depth(allmap, rend_distance, viewpoint_camera), allmap[6:7]), dim=0)
-        fr = _maps_frame(viewpoint_camera, 1.0)
-    else:
-        fr = _maps_frame(viewpoint_camera, pipe.depth_ratio)
-    rn, sd, sn, nm, ra, rd, *twin = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map), bool(twin_alpha))
+        # the unbiased depth is formed inside the kernels from the plane-distance map (round 5; pgsr_unbiased_depth is the torch statement
+        # of the same expression, kept as the kernels' checker): no eight torch kernels and no [7,H,W] concatenation in front of them
+        H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+        fr.pgsr_fx = W / (2.0 * math.tan(viewpoint_camera.FoVx * 0.5))
+        fr.pgsr_fy = H / (2.0 * math.tan(viewpoint_camera.FoVy * 0.5))
+    rn, sd, sn, nm, ra, rd, *twin = _SurfelMaps.apply(allmap, fr, bool(return_depth_normal), bool(return_normal_map), bool(twin_alpha), rend_distance)
     out = {"render_alpha": ra, "render_normal": rn, "render_depth_median": None, "render_depth_expected": None,
            "render_dist": rd, "surf_depth": sd, "surf_normal": sn if return_depth_normal else None}
     if return_normal_map:
@@ -329,6 +349,22 @@ def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
         prefiltered=False, debug=getattr(pipe, "debug", False))
+
+
+def cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier=1.0):
+    """pipe.compute_cov3D_python (gaussian_renderer/__init__.py:136-147, 276-287, 572-583; optix_utils.py:138-150): the splat-to-pixel
+    matrices built in torch from `pc.get_covariance` and handed to the rasterizer as `cov3D_precomp` [P,9] instead of scales /
+    rotations -- the reference's own formula, term for term.  (Its normal-consistency caveat holds here too: with precomputed matrices
+    the rasterizer's normal is the third column of the matrix it is given, :137.)  Off by default (arguments/__init__.py); torch ops,
+    not fused."""
+    splat2world = pc.get_covariance(scaling_modifier)
+    W, H = int(viewpoint_camera.image_width), int(viewpoint_camera.image_height)
+    near, far = float(viewpoint_camera.znear), float(viewpoint_camera.zfar)
+    fpt = viewpoint_camera.full_proj_transform
+    ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near], [0, 0, 0, 1]],
+                           dtype=torch.float32, device=fpt.device).T
+    world2pix = fpt.float() @ ndc2pix
+    return (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)      # column major, as glm wants it
 
 
 _ZERO_POINTS = {}
@@ -381,9 +417,13 @@ def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, o
     dist_feature = get_distance(scaling_modifier, pc.get_xyz, viewpoint_camera, pc) if flag != "2dgs" else None
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
     shs, colors_precomp = ((pc._features_dc, pc._features_rest), None) if override_color is None else (None, override_color)
+    if getattr(pipe, "compute_cov3D_python", False):       # :136-150
+        scales, rotations, cov3D_precomp = None, None, cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier)
+    else:
+        scales, rotations, cov3D_precomp = pc.get_scaling, pc.get_rotation, None
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=pc.get_xyz, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=dist_feature, opacities=pc.get_opacity,
-        scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe,
                                                   rend_distance=rendered_features[0:1] if flag != "2dgs" else None)
     final_image = rendered_image
@@ -419,9 +459,12 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     if flag != "2dgs":          # "pgsr": + the plane distance as a ninth channel, back as "rend_distance" (:348-355, 411-413, 478-480)
         features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
 
+    cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):       # :276-290 (the fused node's scales / rotations stay unused: their gradients are None)
+        scales, rotations, cov3D_precomp = None, None, cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier)
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
-        scales=scales, rotations=rotations, cov3D_precomp=None)
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     rend_distance = rendered_features[8:9] if flag != "2dgs" else None
     if rendered_features.shape[0] != 8:          # (a slice of the full range is still an autograd node: a zero fill and a copy of 8 maps)
         rendered_features = rendered_features[:8]
@@ -470,18 +513,18 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     """gaussian_renderer/__init__.py:521-749: every gaussian is shaded on its own (per-gaussian normal, mirror direction, split-sum
     weight, environment lookups: utils/refl_utils.py:426-484) and the rasterizer blends the shaded colour (`colors_precomp =
     specular + diffuse`) plus S = 11 material channels (roughness, refl, diffuse 3, specular 3, ori_color 3; 18 with opt.indirect:
-    + visibility, indirect 3, direct_light 3).  SH-indirect branch (`pipe.use_asg` False) and the rasterizer's own covariance path
-    (`pipe.compute_cov3D_python` False), which are the reference's defaults.  Environment lookups and the rasterizer run in
-    libmrgs.so; the per-gaussian elementwise glue is torch, as in the reference."""
+    + visibility, indirect 3, direct_light 3).  SH-indirect branch (`pipe.use_asg` False) by default.  Environment lookups and the rasterizer run in
+    libmrgs.so; the per-gaussian elementwise glue is torch, as in the reference.  `pipe.compute_cov3D_python`: cov3D_precomp_of."""
     if opt is None:
         opt = SimpleNamespace(indirect=False)
-    if getattr(pipe, "compute_cov3D_python", False):
-        raise NotImplementedError("render_volume: pipe.compute_cov3D_python is not supported (reference default is False)")
     means2D = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(raster_settings=_raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
     means3D, opacity = pc.get_xyz, pc.get_opacity
     refl, ori_color, roughness = pc.get_refl, pc.get_ori_color, pc.get_rough
-    scales, rotations = pc.get_scaling, pc.get_rotation
+    if getattr(pipe, "compute_cov3D_python", False):       # :572-586
+        scales, rotations, cov3D_precomp = None, None, cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier)
+    else:
+        scales, rotations, cov3D_precomp = pc.get_scaling, pc.get_rotation, None
     dir_pp = means3D - viewpoint_camera.camera_center
     dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
     normals = pc.get_normal(scaling_modifier, dir_pp_normalized)
@@ -508,7 +551,7 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
         features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, features=features, opacities=opacity, scales=scales,
-        rotations=rotations, cov3D_precomp=None)
+        rotations=rotations, cov3D_precomp=cov3D_precomp)
     full_color = rendered_image
     render_roughness, render_refl_strength = rendered_features[:1], rendered_features[1:2]
     render_diffuse_color, render_specular_color = rendered_features[2:5], rendered_features[5:8]

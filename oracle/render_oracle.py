@@ -27,6 +27,9 @@ from . import shading_oracle as so
 from . import trace_oracle as to
 
 
+LAST_NUM_RENDERED = None
+
+
 class _OracleRaster(torch.autograd.Function):
     """diff_surfel_rasterization forward/backward through oracle/mrgs_oracle.c (inputs rounded to fp32 at the boundary, as the
     reference's fp32 tensors are)."""
@@ -41,6 +44,8 @@ class _OracleRaster(torch.autograd.Function):
                             rotations=rotations, sh_degree=sh_degree, variant=variant)
         ctx.precomp = precomp
         ctx.r = r
+        global LAST_NUM_RENDERED
+        LAST_NUM_RENDERED = int(r.R)          # diagnostics: the (tile, surfel) pair count of the most recent oracle rasterization
         ctx.dtype = means3D.dtype
         ctx.shapes = (means3D.shape, opacities.shape, shs.shape, features.shape, scales.shape, rotations.shape)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(means3D.dtype)

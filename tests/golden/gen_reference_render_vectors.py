@@ -36,6 +36,7 @@ asset, which is not redistributed (max |difference| of the two tables is stored 
 Only inputs and outputs are committed; the reference source never travels.
 
     python tests/golden/gen_reference_render_vectors.py        # needs /root/reference (absent on the GPU box); ~2 min
+    python tests/golden/gen_reference_render_vectors.py --cov3d   # the pipe.compute_cov3D_python scenarios -> reference_render_cov3d.npz
 """
 import importlib
 import math
@@ -441,6 +442,41 @@ def run_scenario(store, tag, fn, models, out_keys=MAP_KEYS, extra_out=None, weig
     return out
 
 
+def main_cov3d():
+    """`--cov3d`: the three render functions with pipe.compute_cov3D_python = True (gaussian_renderer/__init__.py:136-147, 276-287,
+    572-583: the reference's own splat-to-pixel matrices, handed to its rasterizer wrapper as cov3D_precomp) on scene A of main(), into a
+    file of their own (tests/golden/reference_render_cov3d.npz: outputs and gradients only; the inputs are reference_render.npz's A_*)."""
+    from types import SimpleNamespace
+    torch.manual_seed(0)
+    H, W, P = 64, 80, 900
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False, compute_cov3D_python=True, convert_SHs_python=False, use_asg=False)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    pc = make_model(P, seed=1, image_size=max(H, W))
+    cam = make_camera(1, H, W)
+    have = np.load(os.path.join(HERE, "reference_render.npz"))
+    for k, v in model_arrays(pc, "A_pc").items():          # the same scene A as the main fixture's, or the file would be about another model
+        assert np.array_equal(v, have[k]), k
+    store = {}
+    A = {"pc": pc}
+    # what the reference hands its rasterizer: recorded at the native boundary (the stand-in's argument list, rasterize_points.cu:41-63)
+    native = sys.modules["diff_surfel_rasterization._C"]
+    inner = native.rasterize_gaussians
+
+    def recording(*args):
+        store.setdefault("A_cov3d__precomp", args[8].detach().numpy().copy())       # cov3Ds_precomp
+        assert args[5].numel() == 0 and args[6].numel() == 0                         # no scales / rotations beside it
+        return inner(*args)
+    native.rasterize_gaussians = recording
+    run_scenario(store, "A_initial_cov3d", lambda: ref_gr.render_initial(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False)), A)
+    run_scenario(store, "A_surfel_cov3d", lambda: ref_gr.render_surfel(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False)), A)
+    set_flavour("pgsr")      # render_volume only runs under the shipped flag (see _Rasterizer2StandIn)
+    run_scenario(store, "A_volume_cov3d", lambda: ref_gr.render_volume(cam, pc, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False)), A)
+    set_flavour("2dgs")
+    dst = os.path.join(HERE, "reference_render_cov3d.npz")
+    np.savez_compressed(dst, **store)
+    print("wrote", dst, len(store), "arrays", os.path.getsize(dst), "bytes")
+
+
 def main():
     from types import SimpleNamespace
     torch.manual_seed(0)
@@ -676,4 +712,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--cov3d" in sys.argv:
+        main_cov3d()
+    else:
+        main()

@@ -15,10 +15,27 @@ PARAM_NAMES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_fe
                "_metalness", "_indirect_dc", "_indirect_rest")
 
 
+class _Fixtures:
+    """reference_render.npz and the files generated beside it by the same script (`--cov3d`: reference_render_cov3d.npz), read as one."""
+
+    def __init__(self, paths):
+        self.parts = [np.load(p) for p in paths if os.path.exists(p)]
+        self.files = [k for part in self.parts for k in part.files]
+
+    def __getitem__(self, key):
+        for part in self.parts:
+            if key in part.files:
+                return part[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return any(key in part.files for part in self.parts)
+
+
 def data():
     global _DATA
     if _DATA is None:
-        _DATA = np.load(PATH)
+        _DATA = _Fixtures([PATH, os.path.join(HERE, "golden", "reference_render_cov3d.npz")])
     return _DATA
 
 

@@ -149,7 +149,20 @@ def _worker_surfel(rank, world, port, q):
               torch.Size((P, 1)), torch.Size((P, 1)), torch.Size((P, 3)), torch.Size((P, 1, 3)), torch.Size((P, 15, 3)), torch.Size((6, 4, 4, 3))]
     from oracle import dist_oracle
     red = mdist.SurfelGradReducer(shapes, names, "cpu", expand_fn=dist_oracle.expand_surfel_sh_gradients)
-    out = red.reduce(grads, xyz, rot, campos, deg)
+    out = [o.clone() for o in red.reduce(grads, xyz, rot, campos, deg)]                 # both factors gathered at reduce() time
+    # the two factors handed out in the middle of the backward (rasterizer.set_after_blend_hook / renderer.set_after_features_hook): same sums
+    red.begin_early_rgb(drgb, campos)
+    red.begin_early_ind(ind[:, :1].contiguous())
+    early = [o.clone() for o in red.reduce(grads, xyz, rot, campos, deg)]
+    for a, b in zip(out, early):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    # a second hand-out before reduce() (two rasterizations in one step) voids the early rows: reduce() reads the gradient tensors again
+    red.begin_early_rgb(torch.full_like(drgb, 7.0), campos)
+    red.begin_early_rgb(torch.full_like(drgb, 9.0), campos)
+    red.begin_early_ind(torch.full_like(ind[:, :1], 5.0))
+    voided = [o.clone() for o in red.reduce(grads, xyz, rot, campos, deg)]
+    for a, b in zip(out, voided):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
     q.put((rank, [o.clone().numpy() for o in out], [None if g is None else g.numpy() for g in grads]))
     dist.barrier()
     dist.destroy_process_group()

@@ -83,6 +83,68 @@ def test_render_surfel_at_c3_size(gpu_device):
     assert float(grads[0][0][dead].abs().sum()) == 0.0
 
 
+def test_c3full_against_render_oracle(gpu_device):
+    """The headline workload against the CPU checkers AT FULL SIZE (what bench.py's CPU leg measures, here as a test of record):
+    render_surfel of view 0 of the bench's C3full scene -- 300 000 surfels, 800 x 800, S = 8, deferred shading -- on the GPU and through
+    oracle/render_oracle.py (oracle/mrgs_oracle.c rasterizer over OpenMP, float64 torch for maps, shading and compositing), forward and
+    backward with the bench's upstream gradients, both rasterizers fed the product's own fp32 per-gaussian inputs (identical inputs: a
+    float64 evaluation of the activations differs in the last bit and moves threshold pixels -- a comparison of inputs, not of
+    renderers; the glue has its own tests).  Bars: the pair count equal, maps <= 2e-5 of their maximum except the two ill-conditioned
+    ones (rend_dist: absolute 5e-6; surf_normal: <= 1e-3 of the pixels beyond 1e-4), gradients <= 1e-4.  ~15 s of CPU work."""
+    import materialrefgs_amd.renderer as renderer_mod
+    from materialrefgs_amd import rasterizer as rasterizer_mod
+    from materialrefgs_amd.renderer import SurfelModel, render_surfel
+    from oracle import render_oracle
+    dev = gpu_device
+    P, H, W = 300_000, 800, 800
+    pc, env, leaves = make_surfel_model(P, max(H, W), dev, seed=0, radius_px=7.0)             # bench.py's C3full scene
+    cam_cpu = orbit_camera(0, H, W, n_views=8)
+    cam = cam_cpu.to(dev)
+    bg = torch.zeros(3, device=dev)
+    env.build_mips()
+    stash, glue = {}, renderer_mod.surfel_features
+
+    def capturing(pc_, campos_, **kw):
+        o = glue(pc_, campos_, **kw)
+        for t_ in o[:4]:
+            t_.retain_grad()
+        stash["o"] = o[:4]
+        return o
+    renderer_mod.surfel_features = capturing
+    try:
+        out_h = render_surfel(cam, pc, PIPE, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+    finally:
+        renderer_mod.surfel_features = glue
+    R_hip = int(rasterizer_mod.LAST_NUM_RENDERED)
+    ups = [torch.ones_like(out_h["render"])] + [torch.full_like(out_h[k], 0.1) for k in LOSS_MAPS[1:]]      # bench.py's constants
+    torch.autograd.backward([out_h[k] for k in LOSS_MAPS], ups)
+    torch.cuda.synchronize(dev)
+    names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color", "indirect_dc",
+             "indirect_rest"]
+    f64 = lambda t_: t_.detach().cpu().double().requires_grad_(True)
+    pc_o = SurfelModel(*[f64(t_) for t_ in leaves[:6]], **{n: f64(t_) for n, t_ in zip(names[6:], leaves[6:11])})
+    inter_o = [f64(t_) for t_ in stash["o"]]
+    out_o = render_oracle.render_surfel_oracle(cam_cpu, pc_o, None, None, PIPE, bg.cpu(), srgb=False, mips=[m.detach().cpu().double() for m in env.specular],
+                                               raster_inputs=tuple(inter_o))
+    torch.autograd.backward([out_o[k] for k in LOSS_MAPS], [g_.detach().cpu().double() for g_ in ups])
+    assert render_oracle.LAST_NUM_RENDERED == R_hip, (render_oracle.LAST_NUM_RENDERED, R_hip)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    for k in ("render", "rend_alpha", "rend_normal", "surf_depth", "specular_map", "diffuse_map", "roughness_map", "base_color_map", "refl_strength_map"):
+        e = rel(out_h[k].detach().cpu().double().numpy(), out_o[k].detach().numpy())
+        print(f"  map {k:18s} {e:.2e}")
+        assert e <= 2e-5, (k, e)
+    e_dist = float(np.abs(out_h["rend_dist"].detach().cpu().double().numpy() - out_o["rend_dist"].detach().numpy()).max())
+    sn = np.abs(out_h["surf_normal"].detach().cpu().double().numpy() - out_o["surf_normal"].detach().numpy()).max(axis=0)
+    print(f"  rend_dist abs {e_dist:.2e}; surf_normal pixels beyond 1e-4: {(sn > 1e-4).mean():.2e}")
+    assert e_dist <= 5e-6 and (sn > 1e-4).mean() <= 1e-3
+    pairs = [(n, th.grad, to.grad) for n, th, to in zip(("opacities", "scales", "rotations", "features"), stash["o"], inter_o)]
+    pairs += [(n, leaves[names.index(n)].grad, getattr(pc_o, "_" + n).grad) for n in ("features_dc", "features_rest")]
+    for n, gh, go_ in pairs:
+        e = rel(gh.detach().cpu().double().numpy(), go_.numpy())
+        print(f"  grad {n:14s} {e:.2e}")
+        assert e <= 1e-4, (n, e)
+
+
 def _dense_on_gpu(o, d, pc, cam, bg, chunk):
     """oracle/surfel_trace_oracle.trace_dense for a sample of rays against ALL surfels, float64 on the GPU, `chunk` rays at a time; the
     colours are computeColorFromSH from the camera position, the placeholder `others` of render_gaussians (optix_utils.py:173-177)."""

@@ -245,7 +245,7 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     c = HipRender(scene, cam, gpu_device, rs=a.rs)          # garbage hint: still only a schedule
     # a camera whose matrices were written in place is a new camera: its old hint is not used
     a.rs.viewmatrix.add_(0.0)
-    assert rz._hint_entry(a.rs, gpu_device) is None
+    assert rz._hint_entry(a.rs, gpu_device, scene.means3D.shape[0]) is None
     # other camera tensors (even with equal values) get their own entry
     d = HipRender(scene, cam, gpu_device)
     assert len(rz._WORK_HINTS) == 2 and d.fn.prepared_grad_ws is None
@@ -259,7 +259,7 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     rz.reset_work_hints()
     rs = raster_settings_of(a)
     runs = [HipRender(scene, cam, gpu_device, rs=rs) for _ in range(5)]
-    assert rz._hint_flags(rs, gpu_device) == rz._lib.MRGS_HINT_REUSE_ORDER
+    assert rz._hint_flags(rs, gpu_device, scene.means3D.shape[0]) == rz._lib.MRGS_HINT_REUSE_ORDER
     for k, r in enumerate(runs):
         assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others), k
         assert (r.fn.prepared_grad_ws is not None) == (k >= 1), k
@@ -267,6 +267,17 @@ def test_work_hints_only_change_the_schedule(gpu_device):
         got = r.backward(*g)
         for name in ref:
             assert rel_err(got[name], ref[name]) <= 1e-5, name
+    # a prepared backward reads the forward's queues from the hint buffer THAT forward used (kept in its ctx): forgetting every hint
+    # between a forward and its backward (reset_work_hints(), an eviction, an in-place pose change) must not hand it a fresh, zeroed one
+    assert runs[3].fn.prepared_grad_ws is not None and runs[3].fn.work_hint is not None
+    rz.reset_work_hints()
+    got = runs[3].backward(*g)
+    for name in ref:
+        assert rel_err(got[name], ref[name]) <= 1e-5, name
+    # ... and the cache is keyed by the surfel count as well: another model seen through the same camera tensors gets its own entry
+    n_before = len(rz._WORK_HINTS)
+    HipRender(make_shell_scene(1500, S=S, seed=5, radius_px=6.0, image_size=160), cam, gpu_device, rs=rs)
+    assert len(rz._WORK_HINTS) == n_before + 1
 
 
 def test_backward_in_two_halves_hands_out_the_colour_factor(gpu_device):

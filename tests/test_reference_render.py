@@ -238,6 +238,15 @@ def test_ply_attribute_order_and_capture_tuple_are_the_reference_objects():
             assert cap[i] is want or cap[i] == want, (i, f)
 
 
+def test_python_cov3d_matrices_are_the_reference_function_s():
+    """pipe.compute_cov3D_python: renderer.cov3D_precomp_of against what the reference's render functions handed their rasterizer with the
+    flag set (recorded at the native boundary by the generator's --cov3d run): same torch ops on the same float32 inputs, bit for bit."""
+    from materialrefgs_amd.renderer import cov3D_precomp_of
+    pc, _ = rf.surfel_model("A_pc")
+    got = cov3D_precomp_of(pc, rf.FixtureCamera("A_cam"), 1.0).detach().numpy()
+    assert np.array_equal(got, rf.data()["A_cov3d__precomp"])
+
+
 # ============================================================================================================== GPU: the HIP path
 def _hip_models(tag, dev):
     from materialrefgs_amd.shading import EnvLight
@@ -336,6 +345,29 @@ def test_hip_render_volume_matches_the_reference(gpu_device, tag, srgb, indirect
     rf.scalar(tag, out).backward()
     if flips == 0:
         _check_grads(tag, rf.leaves(pc, envs), extra=[("viewspace_points", out["viewspace_points"])])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["initial", "surfel", "volume"])
+def test_hip_renders_with_python_cov3d_match_the_reference(gpu_device, which):
+    """pipe.compute_cov3D_python = True (gaussian_renderer/__init__.py:136-147, 276-287, 572-583): the splat-to-pixel matrices come from
+    `pc.get_covariance` in torch and reach the rasterizer as cov3D_precomp.  Expected values: the reference's own three functions run with
+    the flag set (tests/golden/gen_reference_render_vectors.py --cov3d); scales and rotations get their gradients through the matrices."""
+    from materialrefgs_amd import renderer
+    pc, envs = _hip_models("A_pc", gpu_device)
+    cam = rf.FixtureCamera("A_cam", device=gpu_device)
+    pipe = SimpleNamespace(**{**vars(PIPE), "compute_cov3D_python": True})
+    tag = f"A_{which}_cov3d"
+    fn = {"initial": renderer.render_initial, "surfel": renderer.render_surfel, "volume": renderer.render_volume}[which]
+    out = fn(cam, pc, pipe, BG.to(gpu_device), srgb=False, opt=SimpleNamespace(indirect=False), flag="pgsr" if which == "volume" else "2dgs")
+    assert set(out) == {str(k) for k in rf.data()[f"{tag}__keys"]}
+    assert torch.equal(out["radii"].cpu(), torch.from_numpy(rf.expected(tag, "radii")))
+    keys = {"initial": ("render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal"), "surfel": SURFEL_KEYS,
+            "volume": ("render", "refl_strength_map", "diffuse_map", "specular_map", "base_color_map", "roughness_map", "rend_alpha", "rend_normal",
+                       "rend_dist", "surf_depth", "surf_normal", "rend_distance")}[which]
+    _check_maps(tag, out, keys)
+    rf.scalar(tag, out).backward()
+    _check_grads(tag, rf.leaves(pc, envs), extra=[("viewspace_points", out["viewspace_points"])])
 
 
 @pytest.mark.gpu

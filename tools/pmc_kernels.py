@@ -3,6 +3,16 @@
 Usage: python tools/pmc_kernels.py <out.json> <counter_collection.csv> [<counter_collection.csv> ...] [--min-calls N]
 Kernel names are cut at the first '(' (template arguments kept); counters are averaged over the launches of a kernel, several passes
 (one csv each: rocprofv3 takes a limited set per run) are merged by kernel name.  GRBM_GUI_ACTIVE counts per XCD (8 instances summed).
+
+Cycle base of the derived fractions (round 5).  derived_launch_cycles = GRBM_GUI_ACTIVE / 8, and the kernel trace that rocprofv3 writes next
+to every counter file gives the same launches' wall durations: derived_effective_ghz = cycles / duration must come out as a clock this chip
+can run at (<= 2.4 GHz; lower under load, MI355X_MICROARCH.md "DVFS give-back") -- it is printed so that a wrong base shows.  At C4 size
+round 4 reported a "VALU busy fraction" of 1.19 for the backward blend with a plausible 2.25 GHz: the base was right, the NUMERATOR is not a
+fraction of an exclusive resource -- SQ_ACTIVE_INST_VALU x 4 counts the quad-cycles of every VALU instruction, and a kernel that keeps every
+SIMD supplied (41 000 waves at C4 against 11 000 at C3: no tail) retires more than one fp32 instruction per 4 cycles per SIMD whenever
+instructions of different waves overlap in the pipe (transcendentals and DPP moves run beside the main ALU).  So: derived_valu_issue_rate is
+the raw figure (may exceed 1), derived_valu_busy_frac is that figure capped at 1.0, and a value the cap touched is flagged
+(derived_valu_busy_saturated) instead of being read as "119 % busy".
 """
 import csv, json, re, sys
 from collections import defaultdict
@@ -22,9 +32,17 @@ def main():
         args.remove(sys.argv[sys.argv.index("--min-calls") + 1])
     dst, srcs = args[0], args[1:]
     acc = defaultdict(lambda: defaultdict(list))
+    wall = defaultdict(list)          # kernel -> launch durations in ns, from the kernel traces written beside the counter files
+    import glob, os
     for src in srcs:
         for row in csv.DictReader(open(src)):
             acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for tr in glob.glob(os.path.join(os.path.dirname(src), "*kernel_trace.csv")):
+            for row in csv.DictReader(open(tr)):
+                try:
+                    wall[short(row["Kernel_Name"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                except (KeyError, ValueError):
+                    pass
     out = {}
     for k, cs in sorted(acc.items()):
         n = max(len(v) for v in cs.values())
@@ -35,8 +53,15 @@ def main():
         cyc = o.get("GRBM_GUI_ACTIVE", 0) / 8
         if cyc > 0:
             o["derived_launch_cycles"] = round(cyc)
+            if wall.get(k):
+                o["derived_wall_us"] = round(sum(wall[k]) / len(wall[k]) / 1e3, 2)
+                o["derived_effective_ghz"] = round(cyc / (sum(wall[k]) / len(wall[k])), 3)
             if "SQ_ACTIVE_INST_VALU" in o:
-                o["derived_valu_busy_frac"] = round(o["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024), 3)
+                raw = o["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024)
+                o["derived_valu_issue_rate"] = round(raw, 3)
+                o["derived_valu_busy_frac"] = round(min(raw, 1.0), 3)
+                if raw > 1.0:
+                    o["derived_valu_busy_saturated"] = True
             if "SQ_LDS_IDX_ACTIVE" in o:
                 o["derived_lds_busy_frac"] = round(o["SQ_LDS_IDX_ACTIVE"] / (cyc * 256), 3)      # one LDS per CU
         # HBM bytes per launch as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled on gfx950 (128-byte

@@ -43,4 +43,8 @@ for i in range(n):
         status = f"FAIL line {tb.lineno}: {tb.line} | " + str(e)[:160].replace("\n", " ")
     print(f"[{i:3d}] P={P:6d} S={S:2d} {H}x{W} deg={deg} r={rpx:4.1f} view={view}: {status}", flush=True)
 print(f"{n - bad} of {n} cases passed in {time.time() - t0:.0f} s")
+# the identity of the kernels this log speaks for (tools/publish_profiles.sh refuses a log whose digest is not the tree's)
+sys.path.insert(0, ROOT)
+from bench import kernel_source_digest  # noqa: E402
+print(f"kernel_source_digest: {kernel_source_digest()}")
 sys.exit(1 if bad else 0)

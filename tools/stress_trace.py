@@ -134,6 +134,10 @@ def main():
             bad += 1
             print(json.dumps(r))
     print(json.dumps(dict(cases=n_cases, first_seed=first, failed=bad)))
+    # the identity of the kernels this log speaks for (tools/publish_profiles.sh refuses a log whose digest is not the tree's)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_digest
+    print(f"kernel_source_digest: {kernel_source_digest()}")
 
 
 main()
