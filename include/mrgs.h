@@ -483,8 +483,9 @@ size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width);
  * again; smaller -> MRGS_E_WORKSPACE.  n_rays >= 2^31 (or >= 2^27 blocks of rays) -> MRGS_E_UNSUPPORTED.  n_surfels == 0: outputs are
  * the background / zeros, `state` is not touched. */
 size_t mrgs_surfel_trace_state_floats_norecord(int64_t n_rays, int32_t ray_width);
-/* Introspection for the tests: word offsets inside `state` of [0] the lists of rays traced one per wavefront (first EIGHT words: their
- * counts, one per XCD region of the launch), [1] the lists of packets handed to the second launch (first eight words: counts),
+/* Introspection for the tests: word offsets inside `state` of [0] the lists of rays traced one per wavefront (their counts, one per
+ * XCD region of the launch, at words 0, 64, ..., 448 of the list's 512-word header), [1] the lists of packets handed to the second launch
+ * (counts the same way),
  * [2] the record header (word 0: chunks taken from the shared
  * pool, word 1: non-zero = no usable record, the backward walks again), [3] the replay record, [4] the full size. */
 int mrgs_surfel_trace_state_layout(int64_t n_rays, int32_t ray_width, size_t* offsets5);

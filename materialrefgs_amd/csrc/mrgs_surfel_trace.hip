@@ -56,6 +56,18 @@ namespace {
 #ifndef ST_REPLAY_MERGE
 #define ST_REPLAY_MERGE 1                 // the replaying backward merges neighbouring lanes that hold the same surfel BEFORE the LDS collection; 0: after (A/B)
 #endif
+#ifndef ST_NO_WET
+#define ST_NO_WET 0                       // developer A/B: 1 = the forward leaves the per-surfel weight sums out (wrong `wet`, timing only)
+#endif
+#ifndef ST_NO_STEAL
+#define ST_NO_STEAL 0
+#endif
+#ifndef ST_GLOBAL_ORDER
+#define ST_GLOBAL_ORDER 0
+#endif
+#ifndef ST_REST_SCHED_STATIC_REGION
+#define ST_REST_SCHED_STATIC_REGION 0
+#endif
 #ifndef ST_REST_SCHED
 #define ST_REST_SCHED 0                   // second launch of the forward: 0 = items by ticket, own region first; 1 = every list strided over all waves (A/B)
 #endif
@@ -75,6 +87,14 @@ constexpr int ST_REC_STATIC = 3;          // chunks of the hit record every wave
 constexpr int ST_LONE_REC_PASSES = 3;   // passes of a ray traced alone whose 16 sorted hits are kept for the backward (more: it walks again)
 constexpr int ST_REC_PASSES = 16;         // passes of a wave the record can hold (beyond: the backward traces again)
 constexpr uint32_t ST_REC_NONE = 0xFFFFFFFFu;
+// Header of the two per-region lists (StArgs::lone_list / defer_list): ST_LIST_HDR words in front of the entries; region r's count sits
+// at word 64 r and its ticket (second launch of the forward) at word 64 r + 32 -- every counter in a 128-byte line of its own.  Round 5
+// first kept the sixteen words side by side: every listing wave of the first launch and every ticket of the second then met on ONE line
+// at the memory-side atomic unit (~11 ns per operation, tools/ubench), and 20 000 tickets of two operations each put 0.4 ms of
+// serialised waiting into a 0.6 ms launch (measured: tickets without stealing 1.24 ms against 0.86 ms for computed indices).
+constexpr int ST_LIST_HDR = 512;
+#define ST_CNT(hdr, r) ((hdr)[64u * (r)])
+#define ST_TKT(hdr, r) ((hdr) + 64u * (r) + 32u)
 constexpr int SW_MAX_LEVELS = 4;          // 64^4 surfels
 struct StWide {
     int32_t n;                            // levels; level 0 holds surfels (sorted position 64 g + c), the root is node 0 of level n-1
@@ -259,9 +279,9 @@ struct StArgs {
     // trace neighbouring rays and share the subtrees and leaf records their L2 holds (round 5; before, consecutive blocks of four 8x8 ray
     // blocks went round the eight L2s, an XCD's resident waves were spread over half the image and every L2 saw the whole hierarchy:
     // 4.2 GB fetched by the second launch of a C4-size view).
-    uint32_t* defer_list;                 // [x] count of region x, [16 + x * defer_cap ..] (tile << 5 | packet): the packets traced by the second launch, one per wave
+    uint32_t* defer_list;                 // header (ST_LIST_HDR words: ST_CNT / ST_TKT), then [x * defer_cap ..] (tile << 5 | packet): the packets traced by the second launch, one per wave
     uint32_t defer_cap;                   // per region
-    uint32_t* lone_list;                  // [x] count of region x, [16 + x * lone_list_cap ..] indices of the rays that walk alone (behind the per-ray state)
+    uint32_t* lone_list;                  // header, then [x * lone_list_cap ..] indices of the rays that walk alone (behind the per-ray state)
     uint32_t lone_list_cap;               // per region (= the rays of a region: never full)
     uint32_t region_blocks;               // blocks of the first launch per region
     float cone, cone_quad, cone_group;    // 1 - cos of the half-angle within which the directions of a block / quadrant / 2x2 group must stay
@@ -886,20 +906,20 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
             if (lm) {
                 const int first = __builtin_ctzll(lm), lane = tid & 63;
                 uint32_t base = 0;
-                if (lane == first) base = atomicAdd(A.lone_list + region, (uint32_t)__popcll(lm));
+                if (lane == first) base = atomicAdd(&ST_CNT(A.lone_list, region), (uint32_t)__popcll(lm));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-                if (lone) A.lone_list[16 + (size_t)region * A.lone_list_cap + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                if (lone) A.lone_list[ST_LIST_HDR + (size_t)region * A.lone_list_cap + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
             }
             if (dm != 0 && A.defer_list != nullptr) {
                 const uint32_t cnt = (uint32_t)__popc(dm);
                 uint32_t base = 0;
-                if ((tid & 63) == 0) base = atomicAdd(A.defer_list + region, cnt);
+                if ((tid & 63) == 0) base = atomicAdd(&ST_CNT(A.defer_list, region), cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 deferred = base + cnt <= A.defer_cap;                      // else: the region's list is full and the block walks its packets itself
                 base += region * A.defer_cap;                              // the item's index over all regions (its row of the chunk table: n_tiles + index)
                 if (deferred && (tid & 63) == 0) {
                     uint32_t i = 0;
-                    for (uint32_t left = dm; left; left &= left - 1) A.defer_list[16 + base + i++] = ((uint32_t)tile << 5) | (uint32_t)__builtin_ctz(left);
+                    for (uint32_t left = dm; left; left &= left - 1) A.defer_list[ST_LIST_HDR + base + i++] = ((uint32_t)tile << 5) | (uint32_t)__builtin_ctz(left);
                     A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 1] = ST_REC_DEFERRED;
                     A.rec_chunks[(size_t)rec_row * ST_REC_PASSES + ST_REC_PASSES - 2] = base;     // where its packets' rows start (the block's own row holds no record)
                 }
@@ -1007,7 +1027,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                     X[0] += w * a0.w; X[1] += w * a1.x;
                     dist += w * (t * t * Aw + M2 - 2.0f * t * M1);
                     D += w * t; Aw += w; M1 += w * t; M2 += w * t * t;
-                    atomicAdd(A.wet + id, w);
+                    if (!ST_NO_WET) atomicAdd(A.wet + id, w);
                 }
             } else {
                 float gv[18];
@@ -1240,11 +1260,11 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
                                                    unsigned long long* slot, int lane, uint32_t region, uint32_t first_item, uint32_t item_stride)
 {
     // item_stride == 0: the one item `first_item` (the forward's second launch hands items out by ticket); otherwise every item_stride-th
-    const uint32_t listed = lone_list[region];
+    const uint32_t listed = ST_CNT(lone_list, region);
     const uint32_t count = listed < A.lone_list_cap ? listed : A.lone_list_cap;
     const StWide& W = A.wide;
     for (uint32_t item = first_item; item < count; item += item_stride) {
-        const int64_t r = lone_list[16 + (size_t)region * A.lone_list_cap + item];
+        const int64_t r = lone_list[ST_LIST_HDR + (size_t)region * A.lone_list_cap + item];
         const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
         const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
         const float ivx = 1.0f / dx, ivy = 1.0f / dy, ivz = 1.0f / dz;
@@ -1382,7 +1402,7 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
                 N0 += wave_sum_f(w * nfx); N1 += wave_sum_f(w * nfy); N2 += wave_sum_f(w * nfz);
                 X0 += wave_sum_f(w * a0.w); X1 += wave_sum_f(w * a1.x);
                 dist += wave_sum_f(w * (t * t * Ab + M2b - 2.0f * t * M1b));
-                if (bl) atomicAdd(A.wet + id, w);
+                if (bl && !ST_NO_WET) atomicAdd(A.wet + id, w);
             } else {
                 const float q = gc0 * a0.x + gc1 * a0.y + gc2 * a0.z + gd * t + ga + gn0 * nfx + gn1 * nfy + gn2 * nfz + gx0 * a0.w + gx1 * a1.x
                               + gdist * (t * t * fA - 2.0f * t * fM1 + fM2);
@@ -1456,17 +1476,18 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
 // A ticket is one L2 atomic per ~150 us walk.  BACKWARD (MODE 1 / 2): no walk to keep local (the replay reads records), and the state
 // is not the backward's to write: every list is strided over all waves of the launch.
 constexpr int ST_REST_BLOCKS = 2048;
+constexpr int ST_REST_PACKET_BLOCKS = 2048;      // ST_REST_SCHED == 2 only (A/B)
 
-// hdr[0..7] counts of the eight region lists (final: written by the launch before), hdr[8..15] tickets (zeroed by st_init_kernel).  `k`:
+// ST_CNT(hdr, r): counts of the eight region lists (final: written by the launch before); ST_TKT(hdr, r): tickets (zeroed by st_init_kernel).  `k`:
 // regions this wave has found exhausted (tickets only grow: they stay exhausted).  Wave-uniform result.
 __device__ __forceinline__ bool st_next_item(uint32_t* hdr, uint32_t cap, uint32_t own, int lane, uint32_t& k, uint32_t& region, uint32_t& local)
 {
-    for (; k < 8u; ++k) {
+    for (; k < (ST_NO_STEAL ? 1u : 8u); ++k) {
         const uint32_t r = (own + k) & 7u;
-        const uint32_t listed = hdr[r];
+        const uint32_t listed = ST_CNT(hdr, r);
         const uint32_t n = listed < cap ? listed : cap;
         uint32_t t = n;
-        if (lane == 0 && ld_agent_u(hdr + 8 + r) < n) t = atomicAdd(hdr + 8 + r, 1u);
+        if (lane == 0) t = atomicAdd(ST_TKT(hdr, r), 1u);      // (no look before the leap: a ticket beyond the end costs one atomic, a look costs one per item)
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (t < n) { region = r; local = t; return true; }
     }
@@ -1484,6 +1505,49 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
     __shared__ unsigned long long slot[ST_THREADS / 64][ST_K];
     if (MODE != 0 && A.rec_hdr != nullptr && ((A.rec_hdr[1] != 0u) != (MODE == 1))) return;     // the other backward does the work
     const int tid = threadIdx.x, lane = tid & 63;
+    if (MODE == 0 && ST_REST_SCHED == 2) {
+        // tickets, but a wave takes only its share of the items and retires (the hardware's dispatcher starts the next block): blocks below
+        // ST_REST_PACKET_BLOCKS take packets, the others single rays
+        const uint32_t own = ST_GLOBAL_ORDER ? 0u : (blockIdx.x & 7u);
+        uint32_t k = 0, region = 0, local = 0;
+        if (ST_REST_SCHED_STATIC_REGION) {
+            // (A/B) XCD x walks region x's lists, one item per wave and stride
+            const uint32_t r = blockIdx.x & 7u;
+            if (blockIdx.x < ST_REST_PACKET_BLOCKS) {
+                if (A.defer_list == nullptr) return;
+                const uint32_t listed = ST_CNT(A.defer_list, r), count = listed < A.defer_cap ? listed : A.defer_cap;
+                for (uint32_t l = (blockIdx.x >> 3) * (ST_THREADS / 64) + (tid >> 6); l < count; l += (ST_REST_PACKET_BLOCKS / 8) * (ST_THREADS / 64)) {
+                    const uint32_t item = r * A.defer_cap + l;
+                    const uint32_t code = A.defer_list[ST_LIST_HDR + item];
+                    if (code == ST_REC_NONE) continue;
+                    st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item, r);
+                }
+            } else {
+                st_trace_lone_rays<false>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, r,
+                                          ((blockIdx.x - ST_REST_PACKET_BLOCKS) >> 3) * (ST_THREADS / 64) + (tid >> 6), ((gridDim.x - ST_REST_PACKET_BLOCKS) / 8) * (ST_THREADS / 64));
+            }
+            return;
+        }
+        if (blockIdx.x < ST_REST_PACKET_BLOCKS) {
+            if (A.defer_list == nullptr) return;
+            uint32_t total = 0;
+            for (int r = 0; r < 8; ++r) total += min(ST_CNT(A.defer_list, r), A.defer_cap);
+            const uint32_t waves = ST_REST_PACKET_BLOCKS * (ST_THREADS / 64);
+            for (uint32_t q = (total + waves - 1) / waves; q > 0 && st_next_item(A.defer_list, A.defer_cap, own, lane, k, region, local); --q) {
+                const uint32_t item = region * A.defer_cap + local;
+                const uint32_t code = A.defer_list[ST_LIST_HDR + item];
+                if (code == ST_REC_NONE) continue;
+                st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item, region);
+            }
+        } else {
+            uint32_t total = 0;
+            for (int r = 0; r < 8; ++r) total += min(ST_CNT(lone_list, r), A.lone_list_cap);
+            const uint32_t waves = (gridDim.x - ST_REST_PACKET_BLOCKS) * (ST_THREADS / 64);
+            for (uint32_t q = (total + waves - 1) / waves; q > 0 && st_next_item(lone_list, A.lone_list_cap, own, lane, k, region, local); --q)
+                st_trace_lone_rays<false>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, local, 0u);
+        }
+        return;
+    }
     if (MODE == 0 && ST_REST_SCHED == 0) {
         const uint32_t own = blockIdx.x & 7u;
         uint32_t k = 0, region = 0, local = 0;
@@ -1495,7 +1559,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
         if (A.defer_list != nullptr) {
             while (st_next_item(A.defer_list, A.defer_cap, own, lane, k, region, local)) {
                 const uint32_t item = region * A.defer_cap + local;
-                const uint32_t code = A.defer_list[16 + item];
+                const uint32_t code = A.defer_list[ST_LIST_HDR + item];
                 if (code == ST_REC_NONE) continue;                 // a slot of a block that found the list full
                 st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item, region);
             }
@@ -1507,22 +1571,29 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
 #endif
         return;
     }
-    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6), stride = ST_REST_BLOCKS * (ST_THREADS / 64);
+    // every stride-th item of the eight lists laid end to end: region r's items start at the sum of the counts before it
+    const uint32_t wave = blockIdx.x * (ST_THREADS / 64) + (tid >> 6), stride = gridDim.x * (ST_THREADS / 64);
     if (MODE != 2 && A.defer_list != nullptr) {                    // (MODE 2: the replay of listed packets rides in their blocks' waves of the first launch)
+        uint32_t before = 0;
         for (uint32_t region = 0; region < 8u; ++region) {
-            const uint32_t listed = A.defer_list[region];
+            const uint32_t listed = ST_CNT(A.defer_list, region);
             const uint32_t count = listed < A.defer_cap ? listed : A.defer_cap;
-            for (uint32_t local = wave; local < count; local += stride) {
+            for (uint32_t local = (wave + stride - before % stride) % stride; local < count; local += stride) {
                 const uint32_t item = region * A.defer_cap + local;
-                const uint32_t code = A.defer_list[16 + item];
+                const uint32_t code = A.defer_list[ST_LIST_HDR + item];
                 if (code == ST_REC_NONE) continue;
                 st_trace_tile<MODE>(A, leaf_ro, wide_boxes, wide_vmask, kb_id, kb_t, kb_n, tab[MODE == 2 ? tid >> 6 : 0], tid, (int64_t)(code >> 5), (int)(code & 31u), A.n_tiles + item,
                                     region);
             }
+            before += count;
         }
     }
-    for (uint32_t region = 0; region < 8u; ++region)
-        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, wave, stride);
+    uint32_t before = 0;
+    for (uint32_t region = 0; region < 8u; ++region) {
+        const uint32_t listed = ST_CNT(lone_list, region);
+        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, (wave + stride - before % stride) % stride, stride);
+        before += listed < A.lone_list_cap ? listed : A.lone_list_cap;
+    }
 }
 
 }   // namespace
@@ -1563,9 +1634,9 @@ static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte
     L.defer_cap = (uint32_t)((4 * L.n_tiles + 1024 + 7) / 8);       // per region
     L.pool = (uint32_t)(3 * L.n_tiles + 64);
     L.lone_list_cap = (uint32_t)(n_rays < (int64_t)L.region_blocks * ST_THREADS ? n_rays : (int64_t)L.region_blocks * ST_THREADS);   // per region: every ray of the region
-    L.lone = (size_t)4 * n_rays;                                     // [x] count of region x, [16..] ray indices, region by region
-    L.defer = L.lone + 16 + (size_t)8 * L.lone_list_cap;             // [x] count of region x, [16..] packets of the second launch, region by region
-    L.rec_hdr = L.defer + 16 + (size_t)8 * L.defer_cap;
+    L.lone = (size_t)4 * n_rays;                                     // header (counts and tickets per region), ray indices region by region
+    L.defer = L.lone + ST_LIST_HDR + (size_t)8 * L.lone_list_cap;             // header, packets of the second launch region by region
+    L.rec_hdr = L.defer + ST_LIST_HDR + (size_t)8 * L.defer_cap;
     L.rec_chunks = L.rec_hdr + 16;                                   // one row per block of rays, then one per listed packet
     L.rec_arena = L.rec_chunks + ((size_t)L.n_tiles + (size_t)8 * L.defer_cap) * ST_REC_PASSES;
     L.lone_rec = (L.rec_arena + ((size_t)L.n_tiles * ST_REC_STATIC + L.pool) * (ST_K * 64) + 1) & ~(size_t)1;      // 8-byte keys
@@ -1577,8 +1648,8 @@ static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte
 size_t mrgs_surfel_trace_state_floats(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).total; }
 size_t mrgs_surfel_trace_state_floats_norecord(int64_t n_rays, int32_t ray_width) { return n_rays < 0 ? 0 : st_state(n_rays, ray_width).rec_arena; }
 
-// Introspection for the tests: word offsets inside `state` of [0] the lists of rays traced one per wavefront (first eight words: their counts per
-// region), [1] the lists of packets handed to the second launch (first eight words: counts per region), [2] the record header (word 0: chunks taken from the shared
+// Introspection for the tests: word offsets inside `state` of [0] the lists of rays traced one per wavefront (their counts per
+// region at a stride of 64 words), [1] the lists of packets handed to the second launch (counts the same way), [2] the record header (word 0: chunks taken from the shared
 // pool, word 1: non-zero = the record overflowed / was not kept and the backward walks again), [3] the replay record, [4] the full size.
 int mrgs_surfel_trace_state_layout(int64_t n_rays, int32_t ray_width, size_t* offsets5)
 {
@@ -1642,7 +1713,7 @@ __global__ __launch_bounds__(256) void st_init_kernel(uint32_t* __restrict__ lon
                                                       size_t n_ff, uint32_t rec_flag, float* __restrict__ wet, size_t n_wet)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t* ff = defer_hdr + 16;
+    uint32_t* ff = defer_hdr + ST_LIST_HDR;
     // (rec_hdr lies inside [ff, ff + n_ff): its 16 words are written by the threads that own them, with the header's values)
     if (i < n_ff) {
         uint32_t* w = ff + i;
@@ -1650,7 +1721,7 @@ __global__ __launch_bounds__(256) void st_init_kernel(uint32_t* __restrict__ lon
         if (w >= rec_hdr && w < rec_hdr + 16) v = (w == rec_hdr + 1) ? rec_flag : 0u;
         *w = v;
     }
-    if (i < 16) { lone_hdr[i] = 0u; defer_hdr[i] = 0u; }
+    if (i < (size_t)ST_LIST_HDR) { lone_hdr[i] = 0u; defer_hdr[i] = 0u; }
     if (i < n_wet && wet != nullptr) wet[i] = 0.0f;
 }
 
@@ -1684,7 +1755,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     const StateLayout SL = st_state(n_rays, a.ray_width);
     if (state_floats < SL.rec_arena) return MRGS_E_WORKSPACE;
     const bool have_arena = state_floats >= SL.total;       // a state without the replay record (forward-only callers): the backward walks again
-    const dim3 grid((unsigned)SL.grid), rgrid(ST_REST_BLOCKS);
+    const dim3 grid((unsigned)SL.grid), rgrid(ST_REST_SCHED == 2 ? ST_REST_PACKET_BLOCKS + 4096 : ST_REST_BLOCKS);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
     a.lone_list = words + SL.lone;
     a.defer_list = words + SL.defer;
