@@ -59,6 +59,12 @@ namespace {
 #ifndef ST_NO_WET
 #define ST_NO_WET 0                       // developer A/B: 1 = the forward leaves the per-surfel weight sums out (wrong `wet`, timing only)
 #endif
+#ifndef ST_LONE_IN_BLOCK
+#define ST_LONE_IN_BLOCK 1                // backward: a single ray whose record suffices is replayed by its block's wave (LDS gradient table); 0: st_replay_lone_rays4 / a wave of its own (A/B)
+#endif
+#ifndef ST_REPLAY4
+#define ST_REPLAY4 1                      // backward: single rays whose record suffices are replayed four to a wave (st_replay_lone_rays4); 0: one per wave (A/B)
+#endif
 #ifndef ST_NO_STEAL
 #define ST_NO_STEAL 0
 #endif
@@ -84,7 +90,13 @@ constexpr float ST_EXTENT = 3.0f;         // optix_utils.py:44 (3-sigma quad)
 constexpr int ST_AABB_BLOCKS = 256;
 
 constexpr int ST_REC_STATIC = 3;          // chunks of the hit record every wave owns; further passes draw from a shared pool
-constexpr int ST_LONE_REC_PASSES = 3;   // passes of a ray traced alone whose 16 sorted hits are kept for the backward (more: it walks again)
+#ifndef ST_LONE_CAP_TILES
+#define ST_LONE_CAP_TILES 8             // rays per block of rays the single rays' record has room for (x n_tiles / 8 per region); 2 was too few: the regions differ by 2x
+#endif
+#ifndef ST_LONE_PASSES
+#define ST_LONE_PASSES 8
+#endif
+constexpr int ST_LONE_REC_PASSES = ST_LONE_PASSES;   // passes of a ray traced alone whose 16 sorted hits are kept for the backward (more: it walks again)
 constexpr int ST_REC_PASSES = 16;         // passes of a wave the record can hold (beyond: the backward traces again)
 constexpr uint32_t ST_REC_NONE = 0xFFFFFFFFu;
 // Header of the two per-region lists (StArgs::lone_list / defer_list): ST_LIST_HDR words in front of the entries; region r's count sits
@@ -283,6 +295,7 @@ struct StArgs {
     uint32_t defer_cap;                   // per region
     uint32_t* lone_list;                  // header, then [x * lone_list_cap ..] indices of the rays that walk alone (behind the per-ray state)
     uint32_t lone_list_cap;               // per region (= the rays of a region: never full)
+    uint32_t* lone_slot;                  // [n_rays]: where the first launch listed a ray that walks alone, region << 28 | index in the region's list (written for exactly those rays)
     uint32_t region_blocks;               // blocks of the first launch per region
     float cone, cone_quad, cone_group;    // 1 - cos of the half-angle within which the directions of a block / quadrant / 2x2 group must stay
     const float4* attr;                   // [P][2]: (rgb, others.x) (others.y, -, -, -)
@@ -908,7 +921,11 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
                 uint32_t base = 0;
                 if (lane == first) base = atomicAdd(&ST_CNT(A.lone_list, region), (uint32_t)__popcll(lm));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-                if (lone) A.lone_list[ST_LIST_HDR + (size_t)region * A.lone_list_cap + base + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                if (lone) {
+                    const uint32_t at = base + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
+                    A.lone_list[ST_LIST_HDR + (size_t)region * A.lone_list_cap + at] = (uint32_t)r;
+                    A.lone_slot[r] = (region << 28) | at;          // (the replaying backward finds the ray's record from its block's wave)
+                }
             }
             if (dm != 0 && A.defer_list != nullptr) {
                 const uint32_t cnt = (uint32_t)__popc(dm);
@@ -939,7 +956,20 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         packets_present = 1u << only_packet;
     }
     const bool mine = only_packet < 0 ? (no_ray || (packet >= 0 && !deferred)) : (packet == only_packet);
-    bool want = !done && !lone && mine;
+    // The replaying backward also takes its block's single rays along when their recorded hits suffice (round 5): the lane follows the
+    // ray's own record (the sorted keys st_trace_lone_rays kept) through the same blend loop and the same LDS gradient table as its
+    // neighbours, who meet the same surfels.  A wave per such ray -- or per four of them, st_replay_lone_rays4 -- sent 18 float atomics
+    // per hit straight to memory: 12 300 rays cost 0.15 ms at C3 size, 52 000 cost 0.56 ms at C4 size, the atomic unit's rate.
+    bool lone_here = false;
+    const unsigned long long* lrec = nullptr;
+    if (MODE == 2 && ST_LONE_IN_BLOCK && only_packet < 0 && lone && A.lone_rec != nullptr) {
+        const uint32_t code = A.lone_slot[r], lloc = code & 0x0FFFFFFFu;
+        if (lloc < A.lone_cap && A.state[4 * r + 3] <= (float)ST_LONE_REC_PASSES) {
+            lone_here = true;
+            lrec = A.lone_rec + ((size_t)(code >> 28) * A.lone_cap + lloc) * (ST_LONE_REC_PASSES * ST_K);
+        }
+    }
+    bool want = !done && ((!lone && mine) || lone_here);
     // The replaying backward first collects a surfel's gradient terms in LDS (per wave: ST_TAB entries, open addressing on the surfel's
     // index): the rays of a block meet the same ~100 surfels at different ranks and in different passes, and the global float atomics
     // (18 per hit) are what bounds this kernel.  An entry that finds no place within four probes goes out directly.
@@ -959,13 +989,16 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
         int n = 0;
         if (MODE == 2) {
             if (pass >= ST_REC_PASSES - 1) break;
-            const uint32_t chunk = want ? A.rec_chunks[(size_t)my_row * ST_REC_PASSES + pass] : ST_REC_NONE;
-            const bool has = chunk < ST_REC_DEFERRED;                          // (a lane whose packet recorded no further pass: n = 0 ends it below)
+            const uint32_t chunk = (want && !lone_here) ? A.rec_chunks[(size_t)my_row * ST_REC_PASSES + pass] : ST_REC_NONE;
+            const bool has_lone = lone_here && want && pass < ST_LONE_REC_PASSES;
+            const bool has = chunk < ST_REC_DEFERRED || has_lone;               // (a lane whose packet recorded no further pass: n = 0 ends it below)
             if (__ballot(has) == 0) break;
-            const uint32_t* src = A.rec_arena + (size_t)(has ? chunk : 0u) * (ST_K * 64) + (tid & 63);
+            const uint32_t* src = A.rec_arena + (size_t)(chunk < ST_REC_DEFERRED ? chunk : 0u) * (ST_K * 64) + (tid & 63);
+            const unsigned long long* lsrc = lrec + (has_lone ? pass * ST_K : 0);
 #pragma unroll
             for (int j = 0; j < ST_K; ++j) {
-                const uint32_t id = has ? src[j * 64] : ST_REC_NONE;
+                // (a single ray's record holds (t, id) keys, "none" = all ones: its low word is ST_REC_NONE)
+                const uint32_t id = has_lone ? (uint32_t)lsrc[j] : (has ? src[j * 64] : ST_REC_NONE);
                 kb_id[j][tid] = id;
                 if (id != ST_REC_NONE) n = j + 1;
             }
@@ -1157,7 +1190,7 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
             }
         }
     }
-    if (!exists || !mine || lone) return;
+    if (!exists || !((mine && !lone) || lone_here)) return;
     if (!BWD) {
         A.rgb[3 * r] = C[0] + T * A.bg[0]; A.rgb[3 * r + 1] = C[1] + T * A.bg[1]; A.rgb[3 * r + 2] = C[2] + T * A.bg[2];
         A.dpt[r] = D; A.acc[r] = Aw; A.dist[r] = dist;
@@ -1257,14 +1290,17 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 template <bool BWD>
 __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4* __restrict__ leaf, const float* __restrict__ boxes,
                                                    const unsigned long long* __restrict__ vmask, const uint32_t* __restrict__ lone_list,
-                                                   unsigned long long* slot, int lane, uint32_t region, uint32_t first_item, uint32_t item_stride)
+                                                   unsigned long long* slot, int lane, uint32_t region, uint32_t first_item, uint32_t item_stride,
+                                                   bool skip_replayable = false)
 {
     // item_stride == 0: the one item `first_item` (the forward's second launch hands items out by ticket); otherwise every item_stride-th
+    // skip_replayable (backward): rays whose recorded hits suffice are st_replay_lone_rays4's, four to a wave
     const uint32_t listed = ST_CNT(lone_list, region);
     const uint32_t count = listed < A.lone_list_cap ? listed : A.lone_list_cap;
     const StWide& W = A.wide;
     for (uint32_t item = first_item; item < count; item += item_stride) {
         const int64_t r = lone_list[ST_LIST_HDR + (size_t)region * A.lone_list_cap + item];
+        if (BWD && skip_replayable && A.lone_rec != nullptr && item < A.lone_cap && A.state[4 * r + 3] <= (float)ST_LONE_REC_PASSES) continue;
         const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
         const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
         const float ivx = 1.0f / dx, ivy = 1.0f / dy, ivz = 1.0f / dz;
@@ -1465,6 +1501,116 @@ __device__ __forceinline__ void st_trace_lone_rays(const StArgs& A, const float4
     }
 }
 
+// Backward of the single rays whose recorded hits suffice (ST_LONE_REC_PASSES passes of 16 sorted keys), FOUR RAYS PER WAVE: the replay
+// needs no walk, and a ray's 16 hits fill one 16-lane DPP row -- hit j of ray `row` in lane 16 row + j.  Same arithmetic as the replaying
+// branch of st_trace_lone_rays<true> (round 3 gave every such ray a wave of its own, 48 of whose 64 lanes idled through the gathers:
+// 385 us for 12 300 rays at C3 size, 1.0 ms at C4 size), with the wave-wide scans and sums cut down to the row.
+__device__ __forceinline__ float row_sum_f(float v)             // sum over the 16-lane row, in every lane of the row
+{
+    v += ST_DPP(0.0f, v, 0xb1, 0xf); v += ST_DPP(0.0f, v, 0x4e, 0xf); v += ST_DPP(0.0f, v, 0x124, 0xf); v += ST_DPP(0.0f, v, 0x128, 0xf);
+    return v;
+}
+__device__ __forceinline__ void st_replay_lone_rays4(const StArgs& A, const uint32_t* __restrict__ lone_list, int lane, uint32_t region,
+                                                     uint32_t first_quad, uint32_t quad_stride)
+{
+    if (A.lone_rec == nullptr) return;
+    const uint32_t listed = ST_CNT(lone_list, region);
+    uint32_t count = listed < A.lone_list_cap ? listed : A.lone_list_cap;
+    if (count > A.lone_cap) count = A.lone_cap;                  // (items beyond the record's capacity walk again: st_trace_lone_rays)
+    const int row = lane >> 4, j = lane & 15;
+    for (uint32_t quad = first_quad; 4u * quad < count; quad += quad_stride) {
+        const uint32_t item = 4u * quad + (uint32_t)row;
+        bool valid = item < count;
+        const int64_t r = valid ? (int64_t)lone_list[ST_LIST_HDR + (size_t)region * A.lone_list_cap + item] : 0;
+        valid = valid && A.state[4 * r + 3] <= (float)ST_LONE_REC_PASSES;
+        if (__ballot(valid) == 0) continue;
+        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        float gc0 = 0, gc1 = 0, gc2 = 0, gd = 0, ga = 0, gn0 = 0, gn1 = 0, gn2 = 0, gx0 = 0, gx1 = 0, gdist = 0;
+        if (A.g_rgb) { gc0 = A.g_rgb[3 * r]; gc1 = A.g_rgb[3 * r + 1]; gc2 = A.g_rgb[3 * r + 2]; }
+        if (A.g_dpt) gd = A.g_dpt[r];
+        if (A.g_acc) ga = A.g_acc[r];
+        if (A.g_dist) gdist = A.g_dist[r];
+        if (A.g_norm) { gn0 = A.g_norm[3 * r]; gn1 = A.g_norm[3 * r + 1]; gn2 = A.g_norm[3 * r + 2]; }
+        if (A.g_aux) { gx0 = A.g_aux[2 * r]; gx1 = A.g_aux[2 * r + 1]; }
+        const float fA = A.acc[r], fM1 = A.dpt[r], fM2 = A.state[4 * r], fT = A.state[4 * r + 1];
+        const float bgdot = gc0 * A.bg[0] + gc1 * A.bg[1] + gc2 * A.bg[2];
+        const float Qtot = gc0 * (A.rgb[3 * r] - fT * A.bg[0]) + gc1 * (A.rgb[3 * r + 1] - fT * A.bg[1]) + gc2 * (A.rgb[3 * r + 2] - fT * A.bg[2])
+                         + gd * fM1 + ga * fA + gn0 * A.norm[3 * r] + gn1 * A.norm[3 * r + 1] + gn2 * A.norm[3 * r + 2]
+                         + gx0 * A.aux[2 * r] + gx1 * A.aux[2 * r + 1] + gdist * 2.0f * (fA * fM2 - fM1 * fM1);
+        float T = 1.0f, Qpre = 0.0f;
+        float go0 = 0, go1 = 0, go2 = 0, gv0 = 0, gv1 = 0, gv2 = 0;
+        bool done = !valid;
+        const unsigned long long* rec = A.lone_rec + ((size_t)region * A.lone_cap + (valid ? item : 0u)) * (ST_LONE_REC_PASSES * ST_K);
+        for (int pass = 0; pass < ST_LONE_REC_PASSES; ++pass) {
+            if (__ballot(!done) == 0) break;
+            const unsigned long long mine = done ? ~0ull : rec[pass * ST_K + j];
+            const uint32_t rowmask = (uint32_t)(__ballot(mine != ~0ull) >> (16 * row)) & 0xFFFFu;
+            const int nb = (int)__popc(rowmask);
+            const bool has = j < nb;
+            const uint32_t id = (uint32_t)mine;
+            const float t = has ? __uint_as_float((uint32_t)(mine >> 32)) : 0.0f;
+            float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, a0 = g0, a1 = g0;
+            float opacity = 0.f;
+            StHit h;
+            h.alpha = 0.f; h.den = 1.f; h.u = h.v = h.G = 0.f;
+            if (has) {
+                const float4* g = A.geom + (size_t)id * 4;
+                g0 = g[0]; g1 = g[1]; g2 = g[2]; opacity = g[3].x;
+                a0 = A.attr[(size_t)id * 2]; a1 = A.attr[(size_t)id * 2 + 1];
+                h = st_hit(g0, g1, g2, opacity, ox, oy, oz, dx, dy, dz);
+            }
+            const float alpha = has ? h.alpha : 0.0f;
+            const float Tj = T * scan16_mul_excl(1.0f - alpha, lane);          // transmittance in front of hit j
+            const uint32_t stop = (uint32_t)(__ballot(has && Tj * (1.0f - alpha) < 0.0001f) >> (16 * row)) & 0xFFFFu;
+            const int n_bl = stop ? min(nb, (int)__builtin_ctz(stop)) : nb;
+            const bool bl = j < n_bl;
+            const float w = bl ? alpha * Tj : 0.0f;
+            const float sgn = h.den > 0.0f ? -1.0f : 1.0f;
+            const float nfx = sgn * g2.y, nfy = sgn * g2.z, nfz = sgn * g2.w;
+            const float q = gc0 * a0.x + gc1 * a0.y + gc2 * a0.z + gd * t + ga + gn0 * nfx + gn1 * nfy + gn2 * nfz + gx0 * a0.w + gx1 * a1.x
+                          + gdist * (t * t * fA - 2.0f * t * fM1 + fM2);
+            const float wq = w * q;
+            const float Qin = Qpre + scan16_add_excl(wq, lane) + wq;            // inclusive
+            if (bl) {
+                const float inv1ma = 1.0f / (1.0f - alpha);
+                const float dalpha = Tj * q - (Qtot - Qin) * inv1ma - fT * bgdot * inv1ma;
+                const float dG = opacity * dalpha;
+                const float du = -h.u * h.G * dG, dv = -h.v * h.G * dG;
+                const float ax = g0.w, ay = g1.x, az = g1.y, bx = g1.z, by = g1.w, bz = g2.x, nx = g2.y, ny = g2.z, nz = g2.w;
+                const float px = (ox + t * dx) - g0.x, py = (oy + t * dy) - g0.y, pz = (oz + t * dz) - g0.z;
+                const float dpx = du * ax + dv * bx, dpy = du * ay + dv * by, dpz = du * az + dv * bz;
+                const float dt = w * (gd + gdist * 2.0f * (t * fA - fM1)) + (dpx * dx + dpy * dy + dpz * dz);
+                const float dnum = dt / h.den, dden = -dt * t / h.den;
+                float* gg = A.g_geom + (size_t)id * 16;
+                atomicAdd(gg + 0, -dpx + dnum * nx); atomicAdd(gg + 1, -dpy + dnum * ny); atomicAdd(gg + 2, -dpz + dnum * nz);
+                atomicAdd(gg + 3, du * px); atomicAdd(gg + 4, du * py); atomicAdd(gg + 5, du * pz);
+                atomicAdd(gg + 6, dv * px); atomicAdd(gg + 7, dv * py); atomicAdd(gg + 8, dv * pz);
+                atomicAdd(gg + 9, dnum * (g0.x - ox) + dden * dx + sgn * w * gn0);
+                atomicAdd(gg + 10, dnum * (g0.y - oy) + dden * dy + sgn * w * gn1);
+                atomicAdd(gg + 11, dnum * (g0.z - oz) + dden * dz + sgn * w * gn2);
+                atomicAdd(gg + 12, h.G * dalpha);
+                float* ga_ = A.g_attr + (size_t)id * 8;
+                atomicAdd(ga_ + 0, w * gc0); atomicAdd(ga_ + 1, w * gc1); atomicAdd(ga_ + 2, w * gc2);
+                atomicAdd(ga_ + 3, w * gx0); atomicAdd(ga_ + 4, w * gx1);
+                go0 += dpx - dnum * nx; go1 += dpy - dnum * ny; go2 += dpz - dnum * nz;
+                gv0 += t * dpx + dden * nx; gv1 += t * dpy + dden * ny; gv2 += t * dpz + dden * nz;
+            }
+            Qpre += row_sum_f(wq);
+            const float keep = bl ? 1.0f - alpha : 1.0f;
+            float prod = keep;          // product over the row's 16 lanes (the order of st_trace_lone_rays)
+            prod *= ST_DPP(1.0f, prod, 0xb1, 0xf); prod *= ST_DPP(1.0f, prod, 0x4e, 0xf); prod *= ST_DPP(1.0f, prod, 0x124, 0xf); prod *= ST_DPP(1.0f, prod, 0x128, 0xf);
+            T *= prod;
+            if (stop || nb < ST_K) done = true;
+        }
+        const float s0 = row_sum_f(go0), s1 = row_sum_f(go1), s2 = row_sum_f(go2), v0 = row_sum_f(gv0), v1 = row_sum_f(gv1), v2 = row_sum_f(gv2);
+        if (valid && j == 0) {
+            A.g_ray_o[3 * r] = s0; A.g_ray_o[3 * r + 1] = s1; A.g_ray_o[3 * r + 2] = s2;
+            A.g_ray_d[3 * r] = v0; A.g_ray_d[3 * r + 1] = v1; A.g_ray_d[3 * r + 2] = v2;
+        }
+    }
+}
+
 // second launch: every listed packet and every listed single ray gets a wave.  One launch for both: each kind ends in a tail of a few long
 // waves, and the two tails overlap instead of following each other.
 // FORWARD (MODE 0): ST_REST_BLOCKS blocks of persistent waves.  A wave of XCD x (block b, x = b % 8) takes the next packet of region x's
@@ -1588,10 +1734,20 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(MODE
             before += count;
         }
     }
+    if (MODE == 2 && ST_REPLAY4 && !ST_LONE_IN_BLOCK) {
+        // the rays whose record suffices, four to a wave; the others (more passes than the record keeps) walk again below
+        uint32_t before4 = 0;
+        for (uint32_t region = 0; region < 8u; ++region) {
+            const uint32_t listed = ST_CNT(lone_list, region);
+            st_replay_lone_rays4(A, lone_list, lane, region, (wave + stride - before4 % stride) % stride, stride);
+            before4 += ((listed < A.lone_list_cap ? listed : A.lone_list_cap) + 3u) / 4u;
+        }
+    }
     uint32_t before = 0;
     for (uint32_t region = 0; region < 8u; ++region) {
         const uint32_t listed = ST_CNT(lone_list, region);
-        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, (wave + stride - before % stride) % stride, stride);
+        st_trace_lone_rays<MODE != 0>(A, leaf_ro, wide_boxes, wide_vmask, lone_list, slot[tid >> 6], lane, region, (wave + stride - before % stride) % stride, stride,
+                                      MODE == 2 && (ST_REPLAY4 || ST_LONE_IN_BLOCK));
         before += listed < A.lone_list_cap ? listed : A.lone_list_cap;
     }
 }
@@ -1621,7 +1777,7 @@ size_t mrgs_surfel_bvh_bytes(int64_t n_surfels)
     return st_blob(n_surfels).total;
 }
 
-struct StateLayout { int64_t grid, n_tiles; size_t lone, defer, rec_hdr, rec_chunks, rec_arena, lone_rec, total; uint32_t pool, defer_cap, lone_cap, lone_list_cap, region_blocks; };
+struct StateLayout { int64_t grid, n_tiles; size_t lone_slot, lone, defer, rec_hdr, rec_chunks, rec_arena, lone_rec, total; uint32_t pool, defer_cap, lone_cap, lone_list_cap, region_blocks; };
 
 static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte words
 {
@@ -1634,13 +1790,14 @@ static StateLayout st_state(int64_t n_rays, int32_t ray_width)      // in 4-byte
     L.defer_cap = (uint32_t)((4 * L.n_tiles + 1024 + 7) / 8);       // per region
     L.pool = (uint32_t)(3 * L.n_tiles + 64);
     L.lone_list_cap = (uint32_t)(n_rays < (int64_t)L.region_blocks * ST_THREADS ? n_rays : (int64_t)L.region_blocks * ST_THREADS);   // per region: every ray of the region
-    L.lone = (size_t)4 * n_rays;                                     // header (counts and tickets per region), ray indices region by region
+    L.lone_slot = (size_t)4 * n_rays;                                // per ray: where a ray that walks alone was listed
+    L.lone = L.lone_slot + (((size_t)n_rays + 63) & ~(size_t)63);                                     // header (counts and tickets per region), ray indices region by region
     L.defer = L.lone + ST_LIST_HDR + (size_t)8 * L.lone_list_cap;             // header, packets of the second launch region by region
     L.rec_hdr = L.defer + ST_LIST_HDR + (size_t)8 * L.defer_cap;
     L.rec_chunks = L.rec_hdr + 16;                                   // one row per block of rays, then one per listed packet
     L.rec_arena = L.rec_chunks + ((size_t)L.n_tiles + (size_t)8 * L.defer_cap) * ST_REC_PASSES;
     L.lone_rec = (L.rec_arena + ((size_t)L.n_tiles * ST_REC_STATIC + L.pool) * (ST_K * 64) + 1) & ~(size_t)1;      // 8-byte keys
-    L.lone_cap = (uint32_t)((2 * L.n_tiles + 1024 + 7) / 8);        // per region
+    L.lone_cap = (uint32_t)((ST_LONE_CAP_TILES * L.n_tiles + 1024 + 7) / 8);        // per region
     L.total = L.lone_rec + (size_t)8 * L.lone_cap * ST_LONE_REC_PASSES * ST_K * 2;
     return L;
 }
@@ -1758,6 +1915,7 @@ static int st_launch(bool bwd, void* blob, int64_t n_surfels, int64_t n_rays, in
     const dim3 grid((unsigned)SL.grid), rgrid(ST_REST_SCHED == 2 ? ST_REST_PACKET_BLOCKS + 4096 : ST_REST_BLOCKS);
     uint32_t* words = reinterpret_cast<uint32_t*>(a.state);
     a.lone_list = words + SL.lone;
+    a.lone_slot = words + SL.lone_slot;
     a.defer_list = words + SL.defer;
     a.defer_cap = SL.defer_cap;
     a.lone_list_cap = SL.lone_list_cap;

@@ -304,7 +304,6 @@ class SurfelTracer(nn.Module):
         rgb, dpt, acc, norm, dist, aux, wet, state = _Trace.apply(o, d, geom, attr, self._blob, bg3, int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)
         self._blob_saved = will_save
         self.last_state = state[:4 * o.shape[0]].reshape(-1, 4)      # diagnostics: sum w t^2, final T, hits blended, passes (negative: in a packet)
-        self.last_lone = state[4 * o.shape[0]:4 * o.shape[0] + 512:64].view(torch.int32)      # per region of the launch (csrc: ST_CNT of StArgs::lone_list)
         self.last_state_all, self.last_ray_width = state, (int(ray_o.shape[-2]) if ray_o.dim() == 3 else 0)   # diagnostics (record_summary)
         r = lambda x, c: x.reshape(*shape, c)
         rgb, dpt, acc, norm, dist, aux = r(rgb, 3), r(dpt, 1), r(acc, 1), r(norm, 3), r(dist, 1), r(aux, 2)
