@@ -571,6 +571,12 @@ def main():
                             "exposed_exchange_ms": round(exposed, 4), "efficiency": round(eff, 3), "speedup": round(V * eff, 2)}
         return {"link_GBs_per_direction_derated": round(link / 1e9, 1), "single_gpu_step_ms": round(step_ms, 4),
                 "allgather_overlapped_with_preprocess_bwd_ms": round(overlap_ms, 4), **tab}
+    # (the hooks of the view-parallel step come off first: the model below runs a per-gaussian backward on rank 0 ALONE, and a hook that
+    #  starts a collective there would wait for the other ranks forever)
+    rasterizer_mod.set_after_blend_hook(None)
+    if surfel_mode:
+        import materialrefgs_amd.renderer as _renderer_mod
+        _renderer_mod.set_after_features_hook(None)
     xmodel = exchange_model() if rank == 0 and torch.cuda.is_available() else None
 
     if world > 1:

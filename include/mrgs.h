@@ -353,11 +353,17 @@ typedef struct MrgsSurfelParams {
     int32_t P;
     const float *xyz, *scaling_raw, *rotation_raw, *opacity_raw, *refl_raw, *rough_raw, *ori_color_raw, *indirect_dc, *indirect_rest,
         *campos;
+    /* ABI 7, the "pgsr" flavour (arguments/config.py:1): with viewmatrix set (world_view_transform as stored, 16 floats) the feature rows
+     * are TWELVE floats -- channel 8 = get_distance (gaussian_renderer/envgs_renderer.py:30-38: |facing normal . centre| in the camera
+     * frame, the plane distance the flavour rasterizes as its last channel, __init__.py:348-357), channels 9..11 = 0 (the row is padded
+     * to the blend kernels' 16-byte feature pieces) -- and its gradient joins the normal's and the centre's.  NULL: features[P,8]. */
+    const float* viewmatrix;
 } MrgsSurfelParams;
 typedef struct MrgsSurfelGrads {   /* gradients w.r.t. the raw parameters, same shapes, fully written */
     float *d_xyz, *d_scaling, *d_rotation, *d_opacity, *d_refl, *d_rough, *d_ori_color, *d_indirect_dc, *d_indirect_rest;
 } MrgsSurfelGrads;
-/* outputs: opacity[P,1], scales[P,2], rotations[P,4] (unit), features[P,8] -- exactly what GaussianRasterizer is fed */
+/* outputs: opacity[P,1], scales[P,2], rotations[P,4] (unit), features[P,8] ([P,12] with MrgsSurfelParams::viewmatrix) -- exactly what
+ * GaussianRasterizer is fed */
 int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, float* scales, float* rotations, float* features,
                                  void* stream);
 /* upstream gradients of the four outputs (any may be NULL = zero).  d_xyz = the part that flows through the view and mirror directions

@@ -73,7 +73,7 @@ class MrgsSpmvDesc(ctypes.Structure):
 
 class MrgsSurfelParams(ctypes.Structure):
     _fields_ = [("P", c_int32)] + [(n, c_void_p) for n in ("xyz", "scaling_raw", "rotation_raw", "opacity_raw", "refl_raw", "rough_raw",
-                                                             "ori_color_raw", "indirect_dc", "indirect_rest", "campos")]
+                                                             "ori_color_raw", "indirect_dc", "indirect_rest", "campos", "viewmatrix")]
 
 
 class MrgsSurfelGrads(ctypes.Structure):

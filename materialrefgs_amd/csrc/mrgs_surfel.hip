@@ -123,6 +123,21 @@ __device__ __forceinline__ Frame make_frame(const float p[3], const float4 q, co
     return f;
 }
 
+// get_distance (gaussian_renderer/envgs_renderer.py:30-38): normal_cam = n @ Wv[:3,:3], centre_cam = p @ Wv[:3,:3] + Wv[3,:3] with the
+// world_view_transform as stored; the distance is |normal_cam . centre_cam|.
+struct PlaneDist { float nc[3], cc[3], s; };
+__device__ __forceinline__ PlaneDist plane_distance(const float* __restrict__ Wv, const float (&n)[3], const float (&p)[3])
+{
+    PlaneDist d;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        d.nc[j] = n[0] * Wv[j] + n[1] * Wv[4 + j] + n[2] * Wv[8 + j];
+        d.cc[j] = p[0] * Wv[j] + p[1] * Wv[4 + j] + p[2] * Wv[8 + j] + Wv[12 + j];
+    }
+    d.s = d.nc[0] * d.cc[0] + d.nc[1] * d.cc[1] + d.nc[2] * d.cc[2];
+    return d;
+}
+
 __global__ void __launch_bounds__(256) surfel_features_fwd_kernel(MrgsSurfelParams prm, float* __restrict__ opacity, float* __restrict__ scales,
                                                                   float* __restrict__ rotations, float* __restrict__ features)
 {
@@ -160,10 +175,12 @@ __global__ void __launch_bounds__(256) surfel_features_fwd_kernel(MrgsSurfelPara
     // torch.nn.functional.normalize: x / max(|x|, 1e-12)
     const float rl = fmaxf(f.qlen, 1e-12f);
     reinterpret_cast<float4*>(rotations)[idx] = make_float4(q.x / rl, q.y / rl, q.z / rl, q.w / rl);
-    float4* fo = reinterpret_cast<float4*>(features) + 2 * (size_t)idx;
+    const int f4 = prm.viewmatrix != nullptr ? 3 : 2;          // float4 per feature row
+    float4* fo = reinterpret_cast<float4*>(features) + f4 * (size_t)idx;
     fo[0] = make_float4(sigmoidf(prm.refl_raw[idx]), sigmoidf(prm.rough_raw[idx]), sigmoidf(prm.ori_color_raw[3 * (size_t)idx]),
                         sigmoidf(prm.ori_color_raw[3 * (size_t)idx + 1]));
     fo[1] = make_float4(sigmoidf(prm.ori_color_raw[3 * (size_t)idx + 2]), ind[0], ind[1], ind[2]);
+    if (prm.viewmatrix != nullptr) fo[2] = make_float4(fabsf(plane_distance(prm.viewmatrix, f.nn, p).s), 0.0f, 0.0f, 0.0f);
 }
 
 __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelParams prm, const float* __restrict__ g_opacity,
@@ -188,8 +205,22 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
     const float p[3] = {prm.xyz[3 * (size_t)idx], prm.xyz[3 * (size_t)idx + 1], prm.xyz[3 * (size_t)idx + 2]};
     const float4 q = reinterpret_cast<const float4*>(prm.rotation_raw)[idx];
     const Frame f = make_frame(p, q, prm.campos);
-    const float4 gf0 = g_features ? reinterpret_cast<const float4*>(g_features)[2 * (size_t)idx] : make_float4(0, 0, 0, 0);
-    const float4 gf1 = g_features ? reinterpret_cast<const float4*>(g_features)[2 * (size_t)idx + 1] : make_float4(0, 0, 0, 0);
+    const int f4 = prm.viewmatrix != nullptr ? 3 : 2;          // float4 per feature row
+    const float4 gf0 = g_features ? reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx] : make_float4(0, 0, 0, 0);
+    const float4 gf1 = g_features ? reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx + 1] : make_float4(0, 0, 0, 0);
+    // "pgsr": the plane distance |nc . cc| (plane_distance) sends its gradient to the facing normal and to the centre
+    float d_nn_pd[3] = {0.0f, 0.0f, 0.0f}, d_p_pd[3] = {0.0f, 0.0f, 0.0f};
+    if (prm.viewmatrix != nullptr && g_features != nullptr) {
+        const float gd = reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx + 2].x;
+        const PlaneDist pd = plane_distance(prm.viewmatrix, f.nn, p);
+        const float sg = pd.s > 0.0f ? gd : (pd.s < 0.0f ? -gd : 0.0f);           // d|s| = sign(s) (torch: 0 at 0)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float* Wi = prm.viewmatrix + 4 * i;
+            d_nn_pd[i] = sg * (Wi[0] * pd.cc[0] + Wi[1] * pd.cc[1] + Wi[2] * pd.cc[2]);
+            d_p_pd[i] = sg * (Wi[0] * pd.nc[0] + Wi[1] * pd.nc[1] + Wi[2] * pd.nc[2]);
+        }
+    }
 
     // ---- indirect = clamp_min(sum_k sh[k][ch] B_k(r), 0) ----
     const float x = f.r[0], y = f.r[1], z = f.r[2];
@@ -244,7 +275,7 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
     float d_nn[3], d_v[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        d_nn[i] = 2.0f * f.c * d_r[i] - 2.0f * n_dot_dr * f.v[i];       // 2 c d_r + 2 (n . d_r) w_o
+        d_nn[i] = 2.0f * f.c * d_r[i] - 2.0f * n_dot_dr * f.v[i] + d_nn_pd[i];       // 2 c d_r + 2 (n . d_r) w_o (+ the plane distance's share)
         d_v[i] = d_r[i] - 2.0f * n_dot_dr * f.nn[i];                      // -(d_wo), d_wo = 2 (n . d_r) n - d_r
     }
     // n = nf / |nf|, nf = nr * flip
@@ -274,7 +305,7 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
     const float v_dot = f.v[0] * d_v[0] + f.v[1] * d_v[1] + f.v[2] * d_v[2];
 #pragma unroll
     for (int i = 0; i < 3; i++)           // + what reached the centres some other way (the rasterizer's dL/dmeans3D): one sum here instead of a kernel of its own
-        out.d_xyz[3 * (size_t)idx + i] = (g_xyz_upstream ? g_xyz_upstream[3 * (size_t)idx + i] : 0.0f) + (d_v[i] - f.v[i] * v_dot) / f.dlen;
+        out.d_xyz[3 * (size_t)idx + i] = (g_xyz_upstream ? g_xyz_upstream[3 * (size_t)idx + i] : 0.0f) + (d_v[i] - f.v[i] * v_dot) / f.dlen + d_p_pd[i];
 
     // ---- activations ----
     const float so = sigmoidf(prm.opacity_raw[idx]);

@@ -39,16 +39,18 @@ def sum_reduce_scatter_gather(buf: torch.Tensor, group=None):
     bytes through ONE link per rank, 7x the time on this topology; the scaling model of bench.py assumes the direct form)."""
     world = dist.get_world_size(group)
     assert buf.is_contiguous() and buf.numel() % world == 0
-    rank = dist.get_rank(group)
+    backend = dist.get_backend(group)
+    if backend != "nccl" and buf.is_cuda:
+        # gloo on device tensors (the one-GPU plumbing test, tests/test_dist_gpu.py): it stages through the host and has no reduce-scatter
+        # for them -- the library's all-reduce; the links this function is about do not exist there
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
     n = buf.numel() // world
     shard = torch.empty(n, dtype=buf.dtype, device=buf.device)
     w = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    if dist.get_backend(group) != "nccl":
+    if backend != "nccl":
         w.wait()          # gloo runs its operations on worker threads: the gather must not start before the scatter has finished
     # (RCCL: both collectives are queued on the process group's own stream, in this order; `shard` is kept alive by the work object)
-    w2 = dist.all_gather_into_tensor(buf, shard, group=group, async_op=True)
-    del rank
-    return w2
+    return dist.all_gather_into_tensor(buf, shard, group=group, async_op=True)
 
 
 class GradBucket:

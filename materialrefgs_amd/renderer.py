@@ -116,20 +116,23 @@ class _SurfelFeatures(torch.autograd.Function):
     features[P,8]) in one kernel each way (checker: oracle/glue_oracle.py, the reference's own chain of torch ops)."""
 
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos, pass_xyz=False):
+    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos, pass_xyz=False, viewmatrix=None):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
         if not xyz.is_cuda:
             raise RuntimeError("surfel_features needs CUDA(HIP) tensors: the per-gaussian glue runs in libmrgs.so, there is no CPU path")
         ts = [_c(t) for t in (xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos)]
+        # viewmatrix ("pgsr"): feature rows of 12 floats, channel 8 = the plane distance of get_distance, 9..11 zero (MrgsSurfelParams)
+        vm = None if viewmatrix is None else _c(viewmatrix)
         P, dev = ts[0].shape[0], ts[0].device
         L = _lib.lib()
-        prm = MrgsSurfelParams(P, *[_p(t) for t in ts])
+        prm = MrgsSurfelParams(P, *[_p(t) for t in ts], _p(vm))
         o = dict(dtype=torch.float32, device=dev)
-        op, sc, rot, feat = torch.empty((P, 1), **o), torch.empty((P, 2), **o), torch.empty((P, 4), **o), torch.empty((P, 8), **o)
+        op, sc, rot = torch.empty((P, 1), **o), torch.empty((P, 2), **o), torch.empty((P, 4), **o)
+        feat = torch.empty((P, 8 if vm is None else 12), **o)
         with _lib.guard(dev):
             st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_forward(ctypes.byref(prm), _p(op), _p(sc), _p(rot), _p(feat), st))
-        ctx.save_for_backward(*ts)
+        ctx.save_for_backward(*ts, *(() if vm is None else (vm,)))
         if pass_xyz:
             # the centres as a fifth output (the input itself): whoever consumes THEM -- the rasterizer -- sends its gradient through this
             # node, whose backward kernel adds it to its own: one sum inside a kernel instead of autograd's accumulation kernel
@@ -138,10 +141,11 @@ class _SurfelFeatures(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_op, g_sc, g_rot, g_feat, g_xyz=None):
-        ts = ctx.saved_tensors
+        *ts, = ctx.saved_tensors
+        vm = ts.pop() if len(ts) == 11 else None
         P, dev = ts[0].shape[0], ts[0].device
         L = _lib.lib()
-        prm = MrgsSurfelParams(P, *[_p(t) for t in ts])
+        prm = MrgsSurfelParams(P, *[_p(t) for t in ts], _p(vm))
         outs = [torch.empty_like(t) for t in ts[:9]]
         grads = MrgsSurfelGrads(*[_p(t) for t in outs])
         gs = [None if g is None else _c(g) for g in (g_op, g_sc, g_rot, g_feat, g_xyz)]
@@ -151,15 +155,16 @@ class _SurfelFeatures(torch.autograd.Function):
                                                        _p(gs[4]), st))
         if _AFTER_FEATURES_HOOK[0] is not None:
             _AFTER_FEATURES_HOOK[0](outs[7])
-        return (*outs, None, None)
+        return (*outs, None, None, None)
 
 
-def surfel_features(pc, camera_center, pass_xyz=False):
+def surfel_features(pc, camera_center, pass_xyz=False, viewmatrix=None):
     """(opacity[P,1], scales[P,2], rotations[P,4], features[P,8]) for `render_surfel` from the raw parameters of `pc`; with `pass_xyz`
     also the centres [P,3] as an output of the same node (hand THOSE to the rasterizer: its dL/dmeans3D is then summed with this node's
-    own gradient of the centres inside the backward kernel)."""
+    own gradient of the centres inside the backward kernel).  `viewmatrix` (the camera's world_view_transform; "pgsr" flavour): features
+    [P,12] with the plane distance of get_distance in channel 8 and zeros behind it."""
     return _SurfelFeatures.apply(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._refl_strength, pc._roughness, pc._ori_color,
-                                 pc._indirect_dc, pc._indirect_rest, camera_center, bool(pass_xyz))
+                                 pc._indirect_dc, pc._indirect_rest, camera_center, bool(pass_xyz), viewmatrix)
 
 
 _MAPS_FRAME_CACHE = {}
@@ -453,11 +458,16 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     # activations, facing normal, mirror direction, indirect radiance along it and the feature concat (__init__.py:338-355):
     # one HIP kernel each way
     # (the centres come back as an output of the same node: the rasterizer's dL/dmeans3D joins the node's own in its backward kernel)
-    opacities, scales, rotations, features, means3D = surfel_features(pc, viewpoint_camera.camera_center, pass_xyz=True)
-    if getattr(pipe, "use_asg", False):        # the lobes instead of the SH indirect term in channels 5..7 (:312-336)
+    # "pgsr": + the plane distance as a ninth channel, back as "rend_distance" (:348-355, 411-413, 478-480) -- from the same kernel, in
+    # rows padded to twelve floats (the blend kernels move feature rows in 16-byte pieces); get_distance (torch) with the ASG lobes only
+    use_asg = bool(getattr(pipe, "use_asg", False))
+    fused_distance = flag != "2dgs" and not use_asg
+    opacities, scales, rotations, features, means3D = surfel_features(pc, viewpoint_camera.camera_center, pass_xyz=True,
+                                                                      viewmatrix=viewpoint_camera.world_view_transform if fused_distance else None)
+    if use_asg:                 # the lobes instead of the SH indirect term in channels 5..7 (:312-336)
         features = torch.cat((features[:, :5], _asg_indirect_of(pc, viewpoint_camera, scaling_modifier)), dim=-1)
-    if flag != "2dgs":          # "pgsr": + the plane distance as a ninth channel, back as "rend_distance" (:348-355, 411-413, 478-480)
-        features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
+        if flag != "2dgs":
+            features = torch.cat((features, get_distance(scaling_modifier, means3D, viewpoint_camera, pc)), dim=-1)
 
     cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):       # :276-290 (the fused node's scales / rotations stay unused: their gradients are None)

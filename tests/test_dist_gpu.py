@@ -23,7 +23,7 @@ def _bench(tmp_path, name, *args):
     env["MRGS_DIST_BACKEND"] = "gloo"
     dump = str(tmp_path / f"{name}.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
-                        "--dump-grads", dump], env=env, capture_output=True, text=True, timeout=900)
+                        "--dump-grads", dump], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -49,7 +49,7 @@ def test_two_rank_step_equals_the_sum_of_two_single_rank_renders(gpu_device, tmp
         print(f"  {workload:9s} {k:16s} |reduced - (view0 + view1)| / max = {err:.2e}   max|g| {m:.3e}")
         assert err <= 2e-5, (k, err)
     xm = line2["exchange_model"]
-    assert xm["V"] == 8 and xm["allreduce_bytes"] < xm["dense_allreduce_bytes_avoided"] and xm["sh_expand_ms_at_V"] > 0
+    assert xm["V"] == 8 and xm["allreduce_bytes"] < xm["dense_allreduce_bytes_avoided"] and min(np.atleast_1d(xm["sh_expand_ms_at_V"])) > 0
     if workload == "tinyfull":      # BASELINE config 5's parameter set: 21 floats per gaussian on the wire instead of 111 (+ the cubemap)
         assert 110.9 < xm["floats_per_gaussian_dense"] - 6 * 128 * 128 * 3 / line2["config"]["P"] < 111.1
         assert xm["floats_per_gaussian_on_the_wire"] - 6 * 128 * 128 * 3 / line2["config"]["P"] < 21.1
