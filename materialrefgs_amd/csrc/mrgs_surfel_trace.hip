@@ -837,7 +837,10 @@ __global__ __launch_bounds__(256) void st_leaf_order_kernel(int n_slots, int P, 
 
 // MODE 0: forward (walks, blends, records what it gathered); 1: backward that walks again (no record, or it overflowed);
 // 2: backward that replays the forward's record -- same blend arithmetic on the same ids in the same order, no hierarchy.
-constexpr int ST_TAB = 96;                // surfels a wave of the replaying backward accumulates in LDS before its gradients go out
+#ifndef ST_TAB_ENTRIES
+#define ST_TAB_ENTRIES 96
+#endif
+constexpr int ST_TAB = ST_TAB_ENTRIES;                // surfels a wave of the replaying backward accumulates in LDS before its gradients go out
 constexpr int ST_TAB_WORDS = ST_TAB * 19; // 18 gradient terms + the surfel's index per entry
 constexpr uint32_t ST_REC_DEFERRED = 0xFFFFFFFEu;   // in the last slot of a block's row of the chunk table: its packets went to the second launch
 
@@ -1206,14 +1209,17 @@ __device__ __forceinline__ void st_trace_tile(const StArgs& A, const float4* __r
     }
 }
 
-// Wave w of region x of the first launch -> its 8x8 block of rays.  The blocks of rays are grouped into SUPERTILES of 8 x 8 blocks (64 x 64
-// rays, 64 waves), supertile s belongs to region s % 8 and a region walks its supertiles in order: the ~500 waves an XCD holds at a time
-// cover eight compact patches of the image -- whose mirror rays meet eight compact parts of the scene -- while every XCD gets every
-// eighth patch of the WHOLE image, i.e. an equal share of the work.  (Measured on the way, round 5: eight contiguous bands of the image, one
-// per XCD, are 29 % SLOWER than the round-robin of blocks they replaced -- a view's rays that hit nothing sit in its corners and the
-// launch lasts as long as the band through the middle.)  Ray sets that are no image: runs of 64 blocks.
+// Wave w of region x of the first launch -> its 8x8 block of rays.  The blocks of rays are grouped into SUPERTILES of ST_SUPER x ST_SUPER
+// blocks (4 x 4: 32 x 32 rays, 16 waves), supertile s belongs to region s % 8 and a region walks its supertiles in order: the ~500 waves
+// an XCD holds at a time cover ~30 compact patches of the image -- whose mirror rays meet compact parts of the scene -- while every XCD
+// gets every eighth patch of the WHOLE image, i.e. an equal share of the work.  Measured on the way (round 5, C4 size, first launch /
+// replaying backward in us): eight contiguous bands of the image, one per XCD, 2 270 / -- (a view's rays that hit nothing sit in its
+// corners: the launch lasts as long as the band through the middle); supertiles of 16 x 16 blocks 1 682 / 1 550, 8 x 8 1 600 / 1 487,
+// 4 x 4 1 582 / 1 388; round 4's round-robin of four-block rows 1 604 / 1 074 (+ 1 003 for the single rays the replay now takes along).
+// The fetched bytes fall with the patch size (first launch 1 148 -> 541 MB at 8 x 8); the time follows the balance.  Ray sets that are no
+// image: runs of ST_SUPER^2 blocks.
 #ifndef ST_SUPER_EDGE
-#define ST_SUPER_EDGE 8
+#define ST_SUPER_EDGE 4
 #endif
 constexpr uint32_t ST_SUPER = ST_SUPER_EDGE;
 __host__ __device__ __forceinline__ uint32_t st_supertiles(int64_t n_tiles, int32_t ray_width)
