@@ -277,7 +277,7 @@ def main():
             parts.setdefault(name, []).append((e0, e1))
         return done
 
-    def step_surfel(i):
+    def step_surfel_body(i):
         view = (i * world + rank) % len(settings)
         state["campos"] = cams_dev[view].camera_center
         for t_ in surfel_params:
@@ -291,7 +291,6 @@ def main():
         else:
             out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect), flag=flavour)
         done()
-        state["R"] = rasterizer_mod.LAST_NUM_RENDERED
         if use_loss:
             loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)
             loss.backward()
@@ -310,10 +309,31 @@ def main():
             reduce_surfel(view)
 
     _PHASES = [] if os.environ.get("MRGS_BENCH_STEP_TIMES") else None
+    _SYNC_COUNT = bool(os.environ.get("MRGS_BENCH_SYNC_COUNT"))     # developer A/B: every forward waits for its own pair count (rounds 1-4)
 
     def step(i):
+        """One view, forward and backward, inside ONE rasterizer.deferred_count() box: the view's pair count -- which the GPU produces only
+        when it gets to this view's tile scan, i.e. after the previous view's backward -- is collected AFTER the backward has been queued.
+        Rounds 3-4 collected it at the end of the forward: the host then queued the backward's ~25 nodes (0.33 ms) while the GPU ran the
+        rest of the forward (0.28 ms) and the GPU idled whenever the host was the slower of the two -- identical code ran 1 005 ... 1 070
+        views/s with the host's share of the step.  An overflow of the guessed workspace (its render is the EMPTY render, its gradients
+        zeros: include/mrgs.h) surfaces here and the view is done again, exactly sized; the loop INTEGRATION.md section 4d shows."""
+        if _SYNC_COUNT:
+            step_body(i)
+            state["R"] = rasterizer_mod.LAST_NUM_RENDERED
+            return
+        box = rasterizer_mod.deferred_count()
+        with box:
+            step_body(i)
+        try:
+            box.finish()
+        except rasterizer_mod.RasterWorkspaceOverflow:
+            step_body(i)
+        state["R"] = rasterizer_mod.LAST_NUM_RENDERED
+
+    def step_body(i):
         if surfel_mode:
-            return step_surfel(i)
+            return step_surfel_body(i)
         view = (i * world + rank) % len(settings)
         state["campos"] = settings[view].campos
         for t in list(params.values()) + [means2D]:
@@ -323,7 +343,6 @@ def main():
         contrib, color, feature, radii, allmap = rast(
             means3D=params["means3D"], means2D=means2D, opacities=params["opacity"], shs=params["sh"],
             features=params.get("features"), scales=params["scales"], rotations=params["rotations"])
-        state["R"] = color.grad_fn.num_rendered
         tb = time.perf_counter()
         outs, grads = [color, allmap], [g_color, g_others]
         if S > 0:

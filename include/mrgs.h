@@ -648,6 +648,12 @@ const char* mrgs_version(void);
  * ABI 7. */
 int mrgs_side_stream_fork(void* main_stream, void** side_stream);
 int mrgs_side_stream_join(void* main_stream);
+/* fork from the point of the caller's stream where the most recent rasterizer forward of this device launched its blend kernel (the
+ * library records that point once this has been asked for; before the first such forward: a plain fork): what is queued on the side
+ * stream then runs beside the forward blend -- whose duration is the lifetime of a few long waves and which leaves issue slots and memory
+ * bandwidth idle -- instead of beside the bandwidth-bound kernels in front of it.  Only for work whose inputs were final before that
+ * point (the environment prefilter: its input is the parameter the last optimizer step wrote). */
+int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream);
 
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */

@@ -198,6 +198,7 @@ SYMBOLS = {
                                                        c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_side_stream_fork": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "mrgs_side_stream_join": (ctypes.c_int, [c_void_p]),
+    "mrgs_side_stream_fork_at_blend": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "mrgs_compact_ws_bytes": (c_size_t, [c_int64]),
     "mrgs_compact_count": (ctypes.c_int, [c_int64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mrgs_compact_rows": (ctypes.c_int, [c_int64, c_void_p, c_void_p, ctypes.POINTER(MrgsCompactTensor), c_int32, c_void_p]),

@@ -215,6 +215,8 @@ MrgsHintLayout mrgs_hint_layout(int H, int W)
     return l;
 }
 // with a per-camera hint buffer the blend kernels' queue state and the forward's dealt queues live in it (see MrgsHintLayout)
+static void side_mark_pre_blend(hipStream_t stream);     // (side stream, below) an event in front of the forward blend, when somebody forks from there
+
 static void img_use_hint(MrgsImgWs& img, const MrgsRasterInputs* in, int H, int W)
 {
     if (in->work_hint == nullptr) return;
@@ -302,6 +304,7 @@ static int enqueue_render(const MrgsRasterConfig* cfg, const MrgsRasterInputs* i
     t0.stop();
     STAGE_CHECK(cfg, stream);
 
+    side_mark_pre_blend(stream);
     StageTimer t1(stream, ST_FWD);
     mrgs_launch_render_fwd(*cfg, *in, g, b.plist[cur], b.qmask, b.cflag, img, out_color, out_feature, out_others, stream);
     t1.stop();
@@ -645,6 +648,8 @@ struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t ev[MRGS_SIDE_EVENTS] = {};
     unsigned next = 0;
+    hipEvent_t pre_blend = nullptr;     // recorded on the rasterizer's stream right before its forward blend (once somebody has asked for it)
+    bool want_pre_blend = false, have_pre_blend = false;
 };
 SideStream g_side[MRGS_MAX_DEVICES];
 std::mutex g_side_mutex;
@@ -655,13 +660,50 @@ static int side_of(SideStream** out)
     if (dev < 0 || dev >= MRGS_MAX_DEVICES) return MRGS_E_UNSUPPORTED;
     SideStream& s = g_side[dev];
     if (s.stream == nullptr) {
-        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        // LOWEST priority: the side work is filler -- the dispatcher hands a free wave slot to the caller's stream first, and what runs
+        // on the side stream takes what is left (the lone-wave tails of the blend kernels); MRGS_SIDE_PRIORITY=default: same priority
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char* pr = getenv("MRGS_SIDE_PRIORITY");
+        const bool dflt = pr != nullptr && pr[0] == 'd';
+        if (dflt) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        else HIP_TRY(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, least));
         for (int i = 0; i < MRGS_SIDE_EVENTS; i++) HIP_TRY(hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.pre_blend, hipEventDisableTiming));
     }
     *out = &s;
     return MRGS_OK;
 }
 }   // namespace
+
+static void side_mark_pre_blend(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MRGS_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    SideStream& s = g_side[dev];
+    if (!s.want_pre_blend || s.pre_blend == nullptr) return;
+    s.have_pre_blend = hipEventRecord(s.pre_blend, stream) == hipSuccess;
+}
+
+int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream)
+{
+    if (!side_stream) return MRGS_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    SideStream* s = nullptr;
+    int rc = side_of(&s);
+    if (rc) return rc;
+    s->want_pre_blend = true;                    // from now on every forward marks the point
+    if (s->have_pre_blend) {
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->pre_blend, 0));
+    } else {                                     // no forward has marked it yet: everything the caller's stream holds
+        hipEvent_t e = s->ev[s->next++ % MRGS_SIDE_EVENTS];
+        HIP_TRY(hipEventRecord(e, (hipStream_t)main_stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream, e, 0));
+    }
+    *side_stream = (void*)s->stream;
+    return MRGS_OK;
+}
 
 int mrgs_side_stream_fork(void* main_stream, void** side_stream)
 {

@@ -13,7 +13,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o $TAG -- python3 $R/bench.py --workload C2 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -f csv -d $O/stats -o $TAG -- python3 $R/bench.py --workload C2 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_profiled.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o pmc --output-format csv -- python3 $R/bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/pmc_$c.log 2>&1
 done
@@ -49,6 +49,7 @@ if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C4full --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C4full.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C3trace --steps 60 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_C3trace.json 2>> $O/bench_C2.err
   timeout 600 python bench.py --workload C4trace --steps 30 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_C4trace.json 2>> $O/bench_C2.err
+  timeout 600 python bench.py --workload C3full-pgsr --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3full-pgsr.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 mirror > $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 primary >> $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
 fi
