@@ -56,6 +56,9 @@ namespace {
 #ifndef ST_REPLAY_MERGE
 #define ST_REPLAY_MERGE 1                 // the replaying backward merges neighbouring lanes that hold the same surfel BEFORE the LDS collection; 0: after (A/B)
 #endif
+#ifndef ST_REC_REFETCH
+#define ST_REC_REFETCH 0                  // st_gather_group: candidate records re-read from memory instead of ds_bpermute from the holding lane (A/B)
+#endif
 #ifndef ST_NO_WET
 #define ST_NO_WET 0                       // developer A/B: 1 = the forward leaves the per-surfel weight sums out (wrong `wet`, timing only)
 #endif
@@ -561,11 +564,16 @@ __device__ __forceinline__ int st_gather_wide(const StWide& W, const float* __re
         while (m) {
             const int c = __builtin_ctzll(m);
             m &= m - 1;
+#if ST_REC_REFETCH
+            const float4* gq = leaf + ((size_t)__builtin_amdgcn_readfirstlane(node[0]) * 64 + (size_t)c) * 4;      // (wave-uniform address)
+            const float4 h0 = gq[0], h1 = gq[1], h2 = gq[2], h3 = gq[3];
+#else
             auto bc = [c](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), c)); };
             const float4 h0 = make_float4(bc(rec0.x), bc(rec0.y), bc(rec0.z), bc(rec0.w)), h1 = make_float4(bc(rec1.x), bc(rec1.y), bc(rec1.z), bc(rec1.w));
             const float4 h2 = make_float4(bc(rec2.x), bc(rec2.y), bc(rec2.z), bc(rec2.w));
             float4 h3;
             h3.x = bc(rec3.x); h3.y = bc(rec3.y);
+#endif
 #ifdef ST_PROFILE
             ++prof.tests;
 #endif
@@ -708,11 +716,20 @@ __device__ __forceinline__ int st_gather_group(const StWide& W, const float* __r
                 ++prof.tests;
 #endif
             }
+#if ST_REC_REFETCH
+            // the candidate's record from memory again (the leaf group's 4 KB were fetched a moment ago: L1 / L2) instead of from the lane
+            // that holds it: thirteen ds_bpermute less per step and rec0..3 are dead across the candidate loop
+            const float4* gq = leaf + ((size_t)node[0] * 64 + (size_t)c) * 4;
+            const float4 h0 = gq[0], h1 = gq[1], h2 = gq[2], h3q = gq[3];
+            const float opac = h3q.x;
+            const uint32_t id = __float_as_uint(h3q.y);
+#else
             const float4 h0 = make_float4(from(c, rec0.x), from(c, rec0.y), from(c, rec0.z), from(c, rec0.w));
             const float4 h1 = make_float4(from(c, rec1.x), from(c, rec1.y), from(c, rec1.z), from(c, rec1.w));
             const float4 h2 = make_float4(from(c, rec2.x), from(c, rec2.y), from(c, rec2.z), from(c, rec2.w));
             const float opac = from(c, rec3.x);
             const uint32_t id = __float_as_uint(from(c, rec3.y));
+#endif
             const StHit h = st_hit(h0, h1, h2, opac, rox, roy, roz, rdx, rdy, rdz);
             const bool take = have && ron && h.ok && (first_pass || h.t > rprev_t || (h.t == rprev_t && id > rprev_id));
             const unsigned long long takers = __ballot(take);

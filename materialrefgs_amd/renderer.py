@@ -356,6 +356,31 @@ def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
         prefiltered=False, debug=getattr(pipe, "debug", False))
 
 
+class _SplitChannels(torch.autograd.Function):
+    """feature maps [S,H,W] -> (maps[:k], maps[k:k+1]) as VIEWS, with ONE gradient assembly in the backward: the two slices of the
+    "pgsr" flavour's rasterized channels (the eight material maps and the plane distance, gaussian_renderer/__init__.py:372-378, 411-413)
+    would otherwise each pad their gradient to [S,H,W] with a fill and a copy and meet in an accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, maps, k):
+        ctx.set_materialize_grads(False)
+        ctx.k, ctx.shape = k, tuple(maps.shape)
+        return maps[:k], maps[k:k + 1]
+
+    @staticmethod
+    def backward(ctx, g_head, g_one):
+        if g_head is None and g_one is None:
+            return None, None
+        k, shape = ctx.k, ctx.shape
+        ref = g_head if g_head is not None else g_one
+        g = torch.empty(shape, dtype=ref.dtype, device=ref.device)
+        (g[:k].copy_(g_head) if g_head is not None else g[:k].zero_())
+        (g[k:k + 1].copy_(g_one) if g_one is not None else g[k:k + 1].zero_())
+        if shape[0] > k + 1:
+            g[k + 1:].zero_()
+        return g, None
+
+
 def cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier=1.0):
     """pipe.compute_cov3D_python (gaussian_renderer/__init__.py:136-147, 276-287, 572-583; optix_utils.py:138-150): the splat-to-pixel
     matrices built in torch from `pc.get_covariance` and handed to the rasterizer as `cov3D_precomp` [P,9] instead of scales /
@@ -475,8 +500,10 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    rend_distance = rendered_features[8:9] if flag != "2dgs" else None
-    if rendered_features.shape[0] != 8:          # (a slice of the full range is still an autograd node: a zero fill and a copy of 8 maps)
+    rend_distance = None
+    if flag != "2dgs":          # the eight material maps and the plane distance out of the 9 (12: padded rows) rasterized channels
+        rendered_features, rend_distance = _SplitChannels.apply(rendered_features, 8)
+    elif rendered_features.shape[0] != 8:        # (a slice of the full range is still an autograd node: a zero fill and a copy of 8 maps)
         rendered_features = rendered_features[:8]
 
     base_color = rendered_image
