@@ -432,6 +432,15 @@ def main():
         print("host ms per step by position: " + " ".join("%d-%d: %.3f" % (a, min(a + 20, len(d)), sum(d[a:a + 20]) / len(d[a:a + 20])) for a in range(0, len(d), 20)), file=sys.stderr)
         print("host ms per step: median %.3f, longest %s, tail after the last step %.3f ms" %
               (sorted(d)[len(d) // 2], [(k, round(d[k], 2)) for k in order], 1e3 * (elapsed - (step_marks[-1] - t0))), file=sys.stderr)
+    if os.environ.get("MRGS_BENCH_TORCH_PROFILE") and rank == 0:
+        # developer diagnostic: which torch operators (fills, copies, accumulations) a step still launches, with their call sites
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof_:
+            for i in range(4):
+                step(args.warmup + args.steps + 200 + i)
+            fence()
+        with open(os.environ["MRGS_BENCH_TORCH_PROFILE"], "w") as f_:
+            f_.write(prof_.key_averages(group_by_stack_n=6).table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=60, max_src_column_width=110))
     times = MrgsKernelTimes()
     L.mrgs_get_kernel_times(times)
     # per-stage breakdown (diagnostic `stage_ms`): a few extra, untimed steps with an event pair around every stage
