@@ -288,6 +288,19 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
 /* Up to MRGS_SPMV_MAX_BATCH independent products of the kind above in ONE launch (`descs` is a host array): the levels of
  * EnvLight.build_mips each way. */
 #define MRGS_SPMV_MAX_BATCH 8
+/* image_rows != NULL (ABI 8) = TILES OF ROWS OF ONE FUNDAMENTAL DOMAIN of the cube's symmetry group, as dense matrices.  The weight
+ * of a filter is K(r, c) * area(c) / n(r) with K invariant under the 48 signed axis permutations g of the cube (K(g r, g c) = K(r, c);
+ * the reference's texel solid angle, cubemap.cu:17-30, and with it the row sum are not -- they are per-texel factors), so the rows of the
+ * texels r0 of a triangle of face 0 (y <= x < res / 2) are the whole operator:
+ *     y[image_rows[r0 * 48 + g]] = row_scale[that row] * sum_c W(r0, c) * pre_scale[g c] * x[g c]      (image_rows < 0: skipped)
+ * with g c as mrgs_cube_symmetry_rows lists it.  The rows are stored tile by tile (tile t = rows tile_ptr[t] .. tile_ptr[t + 1], at most
+ * 16: a 4 x 4 patch of the triangle); panel_src[panel_ptr[t] .. panel_ptr[t + 1]) lists the 4 x 4 texel PATCHES ((face * res / 4 +
+ * y / 4) * res / 4 + x / 4) the rows of tile t touch -- the image of a patch under a symmetry is a patch; `val` holds, for every
+ * panel patch and each of 64 lanes (lane = 16 * (x & 3) + row in tile), the 16-bit fixed-point weights of the patch's four rows y & 3
+ * as one 8-byte word (lowest row first) -- the A operand of v_mfma_f32_16x16x4_f32 as its lanes read it; the 48 symmetries x 3
+ * channels are the product's right-hand sides.  nrows = 6 res^2 (the length of x, y, pre_scale, row_scale), res a power of two in
+ * 4 .. 128; row_ptr, col, lanes_per_row, col_bytes, val_bytes are not used.  The matrices are 1/40 of the full ones and stay in cache;
+ * x is read once per (tile, g). */
 typedef struct MrgsSpmvDesc {
     int32_t nrows, lanes_per_row, col_bytes, val_bytes;
     const uint32_t* row_ptr;
@@ -296,8 +309,17 @@ typedef struct MrgsSpmvDesc {
     const float* row_scale;
     const float* x;
     float* y;
+    const int32_t* image_rows;
+    const float* pre_scale;
+    const uint32_t* tile_ptr;
+    const uint32_t* panel_ptr;
+    const uint16_t* panel_src;
+    int32_t res, n_tiles;
 } MrgsSpmvDesc;
 int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream);
+/* rows[g * 6 res^2 + t] = the texel ((face * res + y) * res + x) that the g-th of the cube's 48 symmetries (signed axis permutations,
+ * the library's order) maps texel t to; `rows` is a HOST array.  g = 0 is the identity. */
+int mrgs_cube_symmetry_rows(int32_t res, int32_t* rows);
 /* cubemap_mip applied n_steps times below `in` [6,res_in,res_in,3] (scene/light.py:74-76): outs[k] = level k + 1 ([6, res_in >> (k+1), ., 3]),
  * `outs` a host array of device pointers; bit-identical to n_steps calls of mrgs_cubemap_mip_forward, one launch per three levels.
  * The backward chain g[k] += cubemap_mip.backward(g[k + 1]) for k = n_levels - 2 ... 0 in place (g[k]: [6, res0 >> k, ., 3], g a host
@@ -657,7 +679,7 @@ int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream);
 
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 7
+#define MRGS_ABI_VERSION 8
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

@@ -68,7 +68,9 @@ class MrgsRasterTicket(ctypes.Structure):
 
 class MrgsSpmvDesc(ctypes.Structure):
     _fields_ = [("nrows", c_int32), ("lanes_per_row", c_int32), ("col_bytes", c_int32), ("val_bytes", c_int32), ("row_ptr", c_void_p),
-                ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p)]
+                ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p),
+                ("image_rows", c_void_p), ("pre_scale", c_void_p), ("tile_ptr", c_void_p), ("panel_ptr", c_void_p), ("panel_src", c_void_p),
+                ("res", c_int32), ("n_tiles", c_int32)]
 
 
 class MrgsSurfelParams(ctypes.Structure):
@@ -145,6 +147,7 @@ SYMBOLS = {
     "mrgs_cubemap_filter_fill": (ctypes.c_int, [c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_csr_spmv3": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "mrgs_csr_spmv3_batched": (ctypes.c_int, [ctypes.POINTER(MrgsSpmvDesc), c_int32, c_void_p]),
+    "mrgs_cube_symmetry_rows": (ctypes.c_int, [c_int32, c_void_p]),
     "mrgs_cubemap_mip_chain_forward": (ctypes.c_int, [c_int32, c_int32, c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
     "mrgs_cubemap_mip_chain_backward": (ctypes.c_int, [c_int32, c_int32, ctypes.POINTER(c_void_p), c_void_p]),
     "mrgs_cubemap_mip_forward": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
@@ -223,7 +226,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 7   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 8   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

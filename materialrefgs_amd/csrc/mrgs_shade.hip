@@ -948,15 +948,173 @@ __global__ void __launch_bounds__(256) csr_spmv3_kernel(int nrows, const uint32_
 // Several independent SpMVs in ONE launch (the levels of the environment prefilter: four launches of 9-18 us each were mostly the
 // latency of streaming each matrix with a fraction of the chip; together the matrices stream with every wave slot busy).  A workgroup
 // finds its product from a table in the kernel arguments (wave-uniform scan) and runs the body of its storage format.
-struct SpmvSeg { int nrows, fmt, first_block, pad; const uint32_t* row_ptr; const void* col; const void* val; const float* row_scale; const float* x; float* y; };
-struct SpmvBatch { int n; int total_blocks; SpmvSeg seg[MRGS_SPMV_MAX_BATCH]; };
-__global__ void __launch_bounds__(256) csr_spmv3_batched_kernel(SpmvBatch B)
+struct SpmvSeg {
+    int nrows, fmt, first_block, log2n;
+    const uint32_t* row_ptr; const void* col; const void* val; const float* row_scale; const float* x; float* y;
+    // format 16 (tiles of rows of ONE fundamental domain of the cube's symmetry group, below): the row -> image rows table, the factor of
+    // the vector's texels, the tiles' row ranges, their panels (the column blocks a tile's rows touch); `val` = the tiles' dense weights
+    const int32_t* image_rows; const float* pre; const uint32_t* tile_ptr; const uint32_t* panel_ptr; const uint16_t* panel_src;
+};
+struct SpmvBatch { int n; int total_blocks; uint64_t sym[48]; SpmvSeg seg[MRGS_SPMV_MAX_BATCH]; };
+
+// ---- the filters as operators on ONE fundamental domain of the cube's 48 symmetries -------------------------------------------------
+// A filter weight is K(r, c) * area(c) / n(r): K (GGX lobe x cosine x cut-off x the reference's tile cull) depends on the two directions
+// only and is invariant under the 48 signed axis permutations g, which map the texel grid of a cube map onto itself:
+// K(g r, g c) = K(r, c).  (The solid angle `area` of the reference, cubemap.cu:17-30, is NOT invariant -- it is off by one texel on the
+// negative half of a face -- and the row sum n inherits that; both are per-texel factors and stay outside.)  So
+//     y[g r0] = post[g r0] * sum_c K'(r0, c) * (pre * x)[g c]
+// for the N/2 (N/2 + 1) / 2 rows r0 of a triangle of face 0: the matrix is 1/47 of the full one (60 MB -> 1.3 MB for the 64 x 64 level)
+// and stays in the L2 of every XCD instead of streaming from HBM each call and each way.  That alone bought little: with its matrix
+// cached the gather kernel is bound by the gather of x itself (48 bytes per block of four columns, 350 MB a call: 33 us against 43 from
+// HBM), and with x staged in LDS per (tile of rows, symmetry) by the instructions of 64-lane reductions per row (measured, round 5).
+// What the symmetry really gives is a matrix PRODUCT: the rows of a 4 x 4 TILE of the triangle touch the same ~1 000-2 300 texels (the
+// tile's PANEL, 60 % of it per row), so a tile is a dense 16 x K matrix, and the 48 symmetries x 3 channels are 144 right-hand sides:
+//     Y[16 rows][48 g x 3] = W[16][K] * X[K][48 g x 3],   X[k][g, :] = (pre * x)[g panel_k]
+// on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: an fmaf chain; the 16-bit fixed-point weights are exact in f32).  A workgroup =
+// (tile, four symmetries: 16 columns with the channel padded to four); its four waves split K; a wave stages 16 texels x 4 symmetries
+// per step (one (texel, symmetry) per lane: 12 bytes of x and its factor -> 16 bytes of LDS, wave-private, double-buffered) for four MFMAs.
+// sym[g] packs, per SOURCE face s (6 bits each): image face | axes exchanged << 3 | row flipped << 4 | column flipped << 5.
+struct CubeImage { int s, y, x; };
+static inline CubeImage cube_symmetry_image(int g, int N, int s, int y, int x)
+{
+    static const int PERM[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    const int u = 2 * x - (N - 1), v = 2 * y - (N - 1);       // texel centre in units of 1 / N, the major axis at +-N (face_to_dir)
+    int d[3];
+    switch (s) {
+    case 0: d[0] = N; d[1] = -v; d[2] = -u; break;
+    case 1: d[0] = -N; d[1] = -v; d[2] = u; break;
+    case 2: d[0] = u; d[1] = N; d[2] = v; break;
+    case 3: d[0] = u; d[1] = -N; d[2] = -v; break;
+    case 4: d[0] = u; d[1] = -v; d[2] = N; break;
+    default: d[0] = -u; d[1] = -v; d[2] = -N; break;
+    }
+    int e[3];
+    for (int i = 0; i < 3; ++i) e[i] = (((g & 7) >> i) & 1) ? -d[PERM[g >> 3][i]] : d[PERM[g >> 3][i]];
+    int uu, vv, ss;
+    if (e[0] == N) { ss = 0; vv = -e[1]; uu = -e[2]; }
+    else if (e[0] == -N) { ss = 1; vv = -e[1]; uu = e[2]; }
+    else if (e[1] == N) { ss = 2; uu = e[0]; vv = e[2]; }
+    else if (e[1] == -N) { ss = 3; uu = e[0]; vv = -e[2]; }
+    else if (e[2] == N) { ss = 4; uu = e[0]; vv = -e[1]; }
+    else { ss = 5; uu = -e[0]; vv = -e[1]; }
+    return {ss, (vv + N - 1) / 2, (uu + N - 1) / 2};
+}
+static void cube_symmetry_table(uint64_t* tab)
+{
+    for (int g = 0; g < 48; ++g) {
+        uint64_t t = 0;
+        for (int s = 0; s < 6; ++s) {
+            const CubeImage o = cube_symmetry_image(g, 4, s, 0, 0), ax = cube_symmetry_image(g, 4, s, 0, 1), ay = cube_symmetry_image(g, 4, s, 1, 0);
+            const bool swap = ax.x == o.x;                       // a step along x moves the image along y
+            const bool fc = swap ? ax.y < o.y : ax.x < o.x;      // the image runs backwards along the source's x
+            const bool fr = swap ? ay.x < o.x : ay.y < o.y;      // ... along the source's y
+            t |= (uint64_t)(o.s | (swap ? 8 : 0) | (fr ? 16 : 0) | (fc ? 32 : 0)) << (6 * s);
+        }
+        tab[g] = t;
+    }
+}
+
+#define MRGS_SPMV_BATCH_THREADS 512
+#define MRGS_SPMV_SYM_WAVES (MRGS_SPMV_BATCH_THREADS / 64)      // the waves of a workgroup split the panel
+#define MRGS_SPMV_SYM_LDS (MRGS_SPMV_SYM_WAVES * (1024 + 1024))  // per wave: a staging buffer of 16 texels x 16 columns, a partial tile
+#ifndef MRGS_SPMV_SYM_DEPTH
+#define MRGS_SPMV_SYM_DEPTH 3       // steps of gathers in flight ahead of the MFMAs (a step waits for nothing younger than DEPTH steps)
+#endif
+typedef float spmv_f32x4 __attribute__((ext_vector_type(4)));
+extern __shared__ float4 spmv_lds[];
+__device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, const uint64_t* __restrict__ sym)
+{
+    constexpr int NW = MRGS_SPMV_SYM_WAVES, D = MRGS_SPMV_SYM_DEPTH;
+    const int t = block / 12, ig = block - t * 12;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int L = S.log2n, N = 1 << L;
+    const uint32_t p0 = S.panel_ptr[t], nq = S.panel_ptr[t + 1] - p0;                  // the tile's panel: 4 x 4 texel patches
+    const uint2* __restrict__ A = reinterpret_cast<const uint2*>(S.val) + (size_t)p0 * 64;     // [patch][lane] -> four 16-bit weights, one per row of the patch
+    const uint16_t* __restrict__ psrc = S.panel_src + p0;
+    // staging role of the lane: texel kk of the patch's 16 (row kk >> 2, column kk & 3) under symmetry 4 ig + (lane >> 4).  The image of a
+    // patch is a patch -- four runs of 48 bytes whichever way the symmetry turns the face (a run of 16 texels along x became 16 lines when
+    // the axes were exchanged; the lines fetched into L1, 128 bytes for every 12 used, bounded the kernel: measured, round 5)
+    const uint32_t kk = (uint32_t)lane & 15u, simg = (uint32_t)lane >> 4;
+    const uint64_t tab = sym[4 * ig + (int)simg];
+    float* Bs = reinterpret_cast<float*>(spmv_lds) + wave * 256;        // (LDS serves a wave's accesses in order: no barrier between its write and its reads)
+    const int LP = L - 2;                                               // patches per face edge = N / 4
+    auto texel_of = [&](uint32_t cb) {
+        const uint32_t x = 4u * (cb & (uint32_t)((1 << LP) - 1)) + (kk & 3u), y = 4u * ((cb >> LP) & (uint32_t)((1 << LP) - 1)) + (kk >> 2), s = cb >> (2 * LP);
+        const uint32_t e = (uint32_t)(tab >> (6u * s)) & 63u;
+        const uint32_t yy = (e & 16u) ? (uint32_t)(N - 1) - y : y, xx = (e & 32u) ? (uint32_t)(N - 1) - x : x;
+        return ((((e & 7u) << L) + ((e & 8u) ? xx : yy)) << L) + ((e & 8u) ? yy : xx);
+    };
+    // software pipeline over the wave's quads q(i) = wave + NW i: block indices D + 2 steps ahead, texels and weights D steps ahead
+    auto quad_of = [&](uint32_t i) { return (uint32_t)wave + (uint32_t)NW * i; };
+    auto load_cb = [&](uint32_t i) { return quad_of(i) < nq ? (uint32_t)psrc[quad_of(i)] : 0u; };
+    struct Step { float f, v0, v1, v2; uint2 a4; };
+    auto gather = [&](uint32_t i, uint32_t cb) {
+        Step st;
+        const uint32_t tex = texel_of(cb);
+        st.f = S.pre[tex];
+        const float* __restrict__ src = S.x + 3 * (size_t)tex;
+        st.v0 = src[0]; st.v1 = src[1]; st.v2 = src[2];
+        st.a4 = quad_of(i) < nq ? A[(size_t)quad_of(i) * 64 + lane] : make_uint2(0u, 0u);
+        return st;
+    };
+    // (the epilogue's row and its factor are asked for now: two dependent loads off the end of the workgroup's life)
+    const uint32_t r_first = S.tile_ptr[t], r_end = S.tile_ptr[t + 1];
+    const int orow_t = (int)threadIdx.x >> 4, ocol = threadIdx.x & 15;
+    int orow = -1;
+    if (threadIdx.x < 256 && (ocol & 3) < 3 && r_first + (uint32_t)orow_t < r_end) orow = S.image_rows[(r_first + (uint32_t)orow_t) * 48 + 4 * ig + (ocol >> 2)];
+    const float opost = orow >= 0 ? S.row_scale[orow] : 0.0f;
+    uint32_t cb[D + 2];
+#pragma unroll
+    for (int j = 0; j < D + 2; ++j) cb[j] = load_cb((uint32_t)j);
+    Step st[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) st[j] = gather((uint32_t)j, cb[j]);
+    spmv_f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = spmv_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t i = 0; quad_of(i) < nq; ++i) {
+        const Step nx = gather(i + (uint32_t)D, cb[D]);
+        const uint32_t cbn = load_cb(i + (uint32_t)D + 2u);
+        // this step: the wave's 16 texels x 4 symmetries into its buffer ([texel][symmetry][4] = [texel][16 columns]), four MFMAs out of it
+        const Step c0 = st[0];
+        reinterpret_cast<float4*>(Bs)[4u * kk + simg] = make_float4(c0.f * c0.v0, c0.f * c0.v1, c0.f * c0.v2, 0.0f);
+        const float* Br = Bs + lane;
+        const float b0 = Br[0], b1 = Br[64], b2 = Br[128], b3 = Br[192];         // B[k = lane >> 4][column lane & 15] of the patch's four rows
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.x & 0xFFFFu), b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.x >> 16), b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.y & 0xFFFFu), b2, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.y >> 16), b3, acc[3], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j + 1 < D; ++j) st[j] = st[j + 1];
+        st[D - 1] = nx;
+#pragma unroll
+        for (int j = 0; j + 1 < D + 2; ++j) cb[j] = cb[j + 1];
+        cb[D + 1] = cbn;
+    }
+    // the waves' partial tiles -> one; C/D of the MFMA: column lane & 15, rows 4 (lane >> 4) + register
+    float* red = reinterpret_cast<float*>(spmv_lds) + NW * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+    __syncthreads();
+    if (orow >= 0) {      // (-1: a texel on the triangle's diagonal is its own image under one reflection -- written once)
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += red[w * 256 + orow_t * 16 + ocol];
+        S.y[3 * (size_t)orow + (ocol & 3)] = sum * opost;
+    }
+}
+
+__global__ void __launch_bounds__(MRGS_SPMV_BATCH_THREADS) csr_spmv3_batched_kernel(SpmvBatch B)
 {
     int i = 0;
     for (int k = 1; k < B.n; ++k) i = ((int)blockIdx.x >= B.seg[k].first_block) ? k : i;
     const SpmvSeg& S = B.seg[i];
-    const int blk = (int)blockIdx.x - S.first_block;
-    switch (S.fmt) {   // bit 2: 64 lanes per row (else 4); bit 1: 32-bit column indices (else 16); bit 0: fp32 weights (else 16-bit fixed point); 8: blocked rows
+    const int own = (int)blockIdx.x - S.first_block;
+    // (the row-per-wave bodies count 256-thread blocks: block 2 own + (threadIdx.x >> 8), which is what their `block * 256 + threadIdx.x` makes of 2 own)
+    const int blk = S.fmt == 16 ? own : own * (MRGS_SPMV_BATCH_THREADS / 256);
+    switch (S.fmt) {   // bit 2: 64 lanes per row (else 4); bit 1: 32-bit column indices (else 16); bit 0: fp32 weights (else 16-bit fixed point); 8: blocked rows; 16: blocked rows of one fundamental domain
+    case 16: csr_spmv3_sym_body(blk, S, B.sym); break;
     case 8: csr_spmv3_blk4_body(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint2*)S.val, S.row_scale, S.x, S.y); break;
     case 0: csr_spmv3_body<4, uint16_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
     case 1: csr_spmv3_body<4, uint16_t, float>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
@@ -1230,30 +1388,60 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
+int mrgs_cube_symmetry_rows(int32_t res, int32_t* rows)
+{
+    if (res < 1 || res > 1024 || !rows) return MRGS_E_BAD_ARG;
+    const int n = 6 * res * res;
+    for (int g = 0; g < 48; ++g)
+        for (int t = 0; t < n; ++t) {
+            const CubeImage o = cube_symmetry_image(g, res, t / (res * res), (t / res) % res, t % res);
+            rows[(size_t)g * n + t] = (o.s * res + o.y) * res + o.x;
+        }
+    return MRGS_OK;
+}
+
 int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream)
 {
     if (!descs || n < 1 || n > MRGS_SPMV_MAX_BATCH) return MRGS_E_BAD_ARG;
-    SpmvBatch B;
+    static SpmvBatch proto = [] { SpmvBatch b = {}; cube_symmetry_table(b.sym); return b; }();
+    SpmvBatch B = proto;
     B.n = n;
     int blocks = 0;
+    size_t lds = 0;
     for (int i = 0; i < n; ++i) {
         const MrgsSpmvDesc& d = descs[i];
-        if (d.nrows < 1 || !d.row_ptr || !d.col || !d.val || !d.x || !d.y || (d.col_bytes != 2 && d.col_bytes != 4) ||
-            (d.val_bytes != 2 && d.val_bytes != 4 && d.val_bytes != 8) || (d.val_bytes != 4 && !d.row_scale))
+        const bool sym = d.image_rows != nullptr;
+        if (d.nrows < 1 || !d.val || !d.x || !d.y) return MRGS_E_BAD_ARG;
+        SpmvSeg& S = B.seg[i];
+        S.nrows = d.nrows;
+        S.first_block = blocks;
+        S.log2n = 0;
+        S.row_ptr = d.row_ptr; S.col = d.col; S.val = d.val; S.row_scale = d.row_scale; S.x = d.x; S.y = d.y;
+        S.image_rows = nullptr; S.pre = nullptr; S.tile_ptr = nullptr; S.panel_ptr = nullptr; S.panel_src = nullptr;
+        if (sym) {
+            // tiles of rows of one fundamental domain: a power-of-two face of 4 .. 128 texels (16-bit block indices), nrows = 6 res^2 texels
+            int L = 0;
+            while ((1 << L) < d.res) ++L;
+            if (d.res < 4 || d.res > 128 || (1 << L) != d.res || d.nrows != 6 * d.res * d.res || d.n_tiles < 1 || !d.pre_scale || !d.row_scale ||
+                !d.tile_ptr || !d.panel_ptr || !d.panel_src || ((uintptr_t)d.val & 7u))
+                return MRGS_E_BAD_ARG;
+            S.fmt = 16;
+            S.log2n = L; S.image_rows = d.image_rows; S.pre = d.pre_scale; S.tile_ptr = d.tile_ptr; S.panel_ptr = d.panel_ptr; S.panel_src = d.panel_src;
+            blocks += d.n_tiles * 12;
+            lds = MRGS_SPMV_SYM_LDS;
+            continue;
+        }
+        if (!d.row_ptr || !d.col || (d.col_bytes != 2 && d.col_bytes != 4) || (d.val_bytes != 2 && d.val_bytes != 4 && d.val_bytes != 8) ||
+            (d.val_bytes != 4 && !d.row_scale))
             return MRGS_E_BAD_ARG;
         const bool blk4 = d.val_bytes == 8;
         if (blk4 && (d.col_bytes != 2 || d.lanes_per_row < 64 || (d.nrows & 3) || ((uintptr_t)d.x & 15u) || ((uintptr_t)d.val & 7u))) return MRGS_E_BAD_ARG;
         const bool wide = d.lanes_per_row >= 64;
-        SpmvSeg& S = B.seg[i];
-        S.nrows = d.nrows;
         S.fmt = blk4 ? 8 : ((wide ? 4 : 0) | (d.col_bytes == 4 ? 2 : 0) | (d.val_bytes == 4 ? 1 : 0));
-        S.first_block = blocks;
-        S.pad = 0;
-        S.row_ptr = d.row_ptr; S.col = d.col; S.val = d.val; S.row_scale = d.row_scale; S.x = d.x; S.y = d.y;
-        blocks += (int)(((size_t)d.nrows * (wide ? 64 : 4) + 255) / 256);
+        blocks += (int)(((size_t)d.nrows * (wide ? 64 : 4) + MRGS_SPMV_BATCH_THREADS - 1) / MRGS_SPMV_BATCH_THREADS);
     }
     B.total_blocks = blocks;
-    hipLaunchKernelGGL(csr_spmv3_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B);
+    hipLaunchKernelGGL(csr_spmv3_batched_kernel, dim3((unsigned)blocks), dim3(MRGS_SPMV_BATCH_THREADS), lds, (hipStream_t)stream, B);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 

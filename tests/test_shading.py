@@ -382,6 +382,111 @@ def test_blocked_filter_rows_equal_the_plain_csr(gpu_device, monkeypatch):
             assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
 
 
+@pytest.mark.gpu
+def test_symmetric_filter_rows_equal_the_full_operator(gpu_device, monkeypatch):
+    """The long-row levels of the reference's default chain (64 / 0.29, 32 / 0.5, 16 / 1.0 and the diffuse map) as rows of one fundamental
+    domain of the cube's symmetries (MrgsSpmvDesc.image_rows, the batched launch) against the full blocked matrices (mrgs_csr_spmv3), both
+    ways, in one batch as build_mips runs them; the build-time check of each operator passed (they are in use, not the fall-back)."""
+    import materialrefgs_amd.shading as sh
+    g = torch.Generator().manual_seed(17)
+    ops = [sh.CubemapFilterOp.get(gpu_device, 64, 0, 0.29, 0.99), sh.CubemapFilterOp.get(gpu_device, 32, 0, 0.5, 0.99),
+           sh.CubemapFilterOp.get(gpu_device, 16, 0, 1.0, 0.99), sh.CubemapFilterOp.get(gpu_device, 16, 1)]
+    for op in ops:
+        assert op.sym is not None and op.t_sym is not None and max(op.sym_error) <= sh._SYM_TOL, (op.res, op.kind, op.sym_error)
+        m = (op.res // 2) * (op.res // 2 + 1) // 2
+        assert op.sym.n_rows == m and int(op.sym.tile_ptr[-1]) == m and op.sym.patches * 256 * 2 * 30 < op.nnz * 4    # (dense tiles, zeros included: < 1/30 of the full matrix)
+    xs = [torch.randn(6, op.res, op.res, 3, generator=g).to(gpu_device) * 3.0 for op in ops]
+    for tr in (False, True):
+        got = sh._spmv_batched(ops, xs, transpose=tr, cache=False)
+        for op, x, y in zip(ops, xs, got):
+            full = op.apply_matrix(x, transpose=tr)
+            assert float((y - full).abs().max()) <= 2e-5 * float(x.abs().max()), (op.res, op.kind, tr)
+    # one operator absent from the batch, and a batch of the full matrices (the developer switch) give the same
+    got = sh._spmv_batched(ops, [xs[0], None, xs[2], None], transpose=False, cache=False)
+    assert got[1] is None and got[3] is None and float((got[2] - ops[2].apply_matrix(xs[2])).abs().max()) <= 2e-5 * float(xs[2].abs().max())
+
+
+def _unpack_blocks(bptr, bcol, packed, m, ncols):
+    """dense [m, ncols] integer weights of a blocked-rows matrix (host check of CubemapFilterOp._block4 / _block4_general)"""
+    out = np.zeros((m, ncols), dtype=np.int64)
+    bp = bptr.long().numpy()
+    bc = (bcol.long() & 0xFFFF).numpy()
+    w = (packed.long() & 0xFFFFFFFF).numpy()
+    rows = np.repeat(np.arange(m), np.diff(bp))
+    for j, (word, sh) in enumerate(((0, 0), (0, 16), (1, 0), (1, 16))):
+        out[rows, 4 * bc + j] = (w[:, word] >> sh) & 0xFFFF
+    return out
+
+
+@pytest.mark.parametrize("kind,rough", [(0, 1.0), (1, 1.0)])
+def test_symmetric_rows_reproduce_the_dense_filter(kind, rough):
+    """The prefilter operator kept as the rows of ONE fundamental domain of the cube's 48 symmetries (CubemapFilterOp._symmetric, the host
+    side of MrgsSpmvDesc.image_rows -- rows in 4 x 4 tiles, block indices local to the tile's panel; mrgs_cube_symmetry_rows is host code
+    of the library): y[g r0] = post * sum_c W'(r0, c) (pre x)[g c] evaluated in numpy equals the dense oracle operator (16 x 16 faces: the reference's last specular level and its diffuse map) both ways,
+    every texel written exactly once."""
+    from oracle import envfilter_oracle as eo
+    from materialrefgs_amd import shading as sh
+    N = 16
+    n = 6 * N * N
+    img = sh._cube_symmetry_rows(N).long().numpy()
+    assert img.shape == (48, n) and all(np.array_equal(np.sort(p), np.arange(n)) for p in img) and np.array_equal(img[0], np.arange(n))
+    D = eo.cube_to_dir(N)
+    for g in (1, 7, 13, 29, 47):                       # a symmetry is a signed axis permutation of the texel directions
+        Mg = np.linalg.lstsq(D, D[img[g]], rcond=None)[0].T
+        assert np.allclose(np.abs(Mg).round(6).sum(0), 1.0) and np.allclose(np.abs(Mg).round(6).sum(1), 1.0) and np.allclose(D @ Mg.T, D[img[g]], atol=1e-12)
+    if kind == 0:
+        Wd = eo.specular_weights(N, rough, eo.cos_cutoff(rough))
+        nsum = Wd.sum(1)
+        A = Wd / nsum[:, None]
+    else:
+        A = eo.diffuse_matrix(N)
+        nsum = np.ones(n)
+    area = sh._pixel_area(N).astype(np.float64)
+    assert np.allclose(area, eo.pixel_area(N), rtol=1e-6)
+    op = object.__new__(sh.CubemapFilterOp)
+    op.res, op.nrows = N, n
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, 3))
+    for tr in (False, True):
+        M = A.T if tr else A
+        r, c = np.nonzero(M)
+        ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))])).to(torch.int32)
+        col, val = torch.from_numpy(c).to(torch.int32), torch.from_numpy(M[r, c]).float()
+        t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+        if not tr:
+            S = op._symmetric(ptr, col, val, t(1.0 / area), t(area), t(nsum))
+        else:
+            S = op._symmetric(ptr, col, val, t(nsum), t(1.0 / nsum), t(1.0 / area))
+        m = S.n_rows
+        assert m == (N // 2) * (N // 2 + 1) // 2 and S.image_rows.shape == (m, 48) and int(S.tile_ptr[-1]) == m
+        ir = S.image_rows.numpy()
+        assert np.array_equal(np.sort(ir[ir >= 0]), np.arange(n))                      # every texel written exactly once
+        # the dense tiles back to rows of global columns: [patch of the panel][lane = 16 (x & 3) + row in tile][patch row y & 3]
+        tp, pp = S.tile_ptr.long().numpy(), S.panel_ptr.long().numpy()
+        assert S.n_tiles == len(tp) - 1 == len(pp) - 1 and int(np.diff(tp).max()) <= 16 and pp[-1] == S.patches
+        src = (S.panel_src.long() & 0xFFFF).numpy()
+        dense = (S.val.long() & 0xFFFF).numpy().reshape(-1, 4, 16, 4)                   # [patch, x & 3, row in tile, y & 3]
+        Wq = np.zeros((m, n))
+        npf = N // 4
+        for ti in range(S.n_tiles):
+            rows_t = tp[ti + 1] - tp[ti]
+            for k in range(pp[ti], pp[ti + 1]):
+                assert not dense[k, :, rows_t:, :].any()
+                ps, py, px = src[k] // (npf * npf), (src[k] // npf) % npf, src[k] % npf
+                for j in range(4):
+                    c0 = (ps * N + 4 * py + j) * N + 4 * px
+                    Wq[tp[ti]:tp[ti + 1], c0:c0 + 4] = dense[k, :, :rows_t, j].T
+        post, pre = S.post, S.pre
+        xs = pre.double().numpy()[:, None] * x
+        y = np.zeros((n, 3))
+        for g in range(48):
+            rows = ir[:, g]
+            yg = Wq @ xs[img[g]]                                                        # (pre x)[g c] for the columns c of the canonical rows
+            y[rows[rows >= 0]] = (post.double().numpy()[rows[rows >= 0], None] * yg[rows >= 0])
+        ref = M @ x
+        assert float(np.abs(y - ref).max()) <= 1e-5 * float(np.abs(x).max())
+
+
 def test_block4_conversion_reproduces_the_csr_matrix():
     """CubemapFilterOp._block4 (host side of the blocked prefilter rows, pure torch): every (row, column, weight) of a random CSR
     matrix with 16-bit columns and weights comes back from the (block column, four weights) form, padding slots are zero, rows keep
