@@ -955,7 +955,7 @@ struct SpmvSeg {
     // the vector's texels, the tiles' row ranges, their panels (the column blocks a tile's rows touch); `val` = the tiles' dense weights
     const int32_t* image_rows; const float* pre; const uint32_t* tile_ptr; const uint32_t* panel_ptr; const uint16_t* panel_src;
 };
-struct SpmvBatch { int n; int total_blocks; uint64_t sym[48]; SpmvSeg seg[MRGS_SPMV_MAX_BATCH]; };
+struct SpmvBatch { int n; int total_blocks; uint64_t sym[48]; SpmvSeg seg[MRGS_SPMV_MAX_BATCH]; unsigned long long* trace; };
 
 // ---- the filters as operators on ONE fundamental domain of the cube's 48 symmetries -------------------------------------------------
 // A filter weight is K(r, c) * area(c) / n(r): K (GGX lobe x cosine x cut-off x the reference's tile cull) depends on the two directions
@@ -1016,15 +1016,22 @@ static void cube_symmetry_table(uint64_t* tab)
 
 #define MRGS_SPMV_BATCH_THREADS 512
 #define MRGS_SPMV_SYM_WAVES (MRGS_SPMV_BATCH_THREADS / 64)      // the waves of a workgroup split the panel
-#define MRGS_SPMV_SYM_LDS (MRGS_SPMV_SYM_WAVES * (1024 + 1024))  // per wave: a staging buffer of 16 texels x 16 columns, a partial tile
+#define MRGS_SPMV_SYM_BROW 20        // floats per staged texel row: 16 columns + 4 of padding (the 16-byte writes of eight lanes then cover the 32 banks)
+#define MRGS_SPMV_SYM_LDS (MRGS_SPMV_SYM_WAVES * (16 * MRGS_SPMV_SYM_BROW * 4 + 1024))  // per wave: a staging buffer of 16 texels x 16 columns, a partial tile
 #ifndef MRGS_SPMV_SYM_DEPTH
-#define MRGS_SPMV_SYM_DEPTH 3       // steps of gathers in flight ahead of the MFMAs (a step waits for nothing younger than DEPTH steps)
+#define MRGS_SPMV_SYM_DEPTH 2       // steps of gathers in flight ahead of the MFMAs (a step waits for nothing younger than DEPTH steps)
 #endif
 typedef float spmv_f32x4 __attribute__((ext_vector_type(4)));
 extern __shared__ float4 spmv_lds[];
-__device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, const uint64_t* __restrict__ sym)
+#ifdef MRGS_SPMV_TRACE
+#define MRGS_SPMV_TRACE_PTR trace_ptr
+#endif
+__device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, const uint64_t* __restrict__ sym, unsigned long long* trace_ptr)
 {
     constexpr int NW = MRGS_SPMV_SYM_WAVES, D = MRGS_SPMV_SYM_DEPTH;
+#ifdef MRGS_SPMV_TRACE
+    const unsigned long long tr0 = wall_clock64();
+#endif
     const int t = block / 12, ig = block - t * 12;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int L = S.log2n, N = 1 << L;
@@ -1036,7 +1043,7 @@ __device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, 
     // the axes were exchanged; the lines fetched into L1, 128 bytes for every 12 used, bounded the kernel: measured, round 5)
     const uint32_t kk = (uint32_t)lane & 15u, simg = (uint32_t)lane >> 4;
     const uint64_t tab = sym[4 * ig + (int)simg];
-    float* Bs = reinterpret_cast<float*>(spmv_lds) + wave * 256;        // (LDS serves a wave's accesses in order: no barrier between its write and its reads)
+    float* Bs = reinterpret_cast<float*>(spmv_lds) + wave * (16 * MRGS_SPMV_SYM_BROW);     // (LDS serves a wave's accesses in order: no barrier between its write and its reads)
     const int LP = L - 2;                                               // patches per face edge = N / 4
     auto texel_of = [&](uint32_t cb) {
         const uint32_t x = 4u * (cb & (uint32_t)((1 << LP) - 1)) + (kk & 3u), y = 4u * ((cb >> LP) & (uint32_t)((1 << LP) - 1)) + (kk >> 2), s = cb >> (2 * LP);
@@ -1044,17 +1051,27 @@ __device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, 
         const uint32_t yy = (e & 16u) ? (uint32_t)(N - 1) - y : y, xx = (e & 32u) ? (uint32_t)(N - 1) - x : x;
         return ((((e & 7u) << L) + ((e & 8u) ? xx : yy)) << L) + ((e & 8u) ? yy : xx);
     };
-    // software pipeline over the wave's quads q(i) = wave + NW i: block indices D + 2 steps ahead, texels and weights D steps ahead
-    auto quad_of = [&](uint32_t i) { return (uint32_t)wave + (uint32_t)NW * i; };
-    auto load_cb = [&](uint32_t i) { return quad_of(i) < nq ? (uint32_t)psrc[quad_of(i)] : 0u; };
+    // software pipeline over the wave's steps: step i = patch wave + NW i of the panel, texels and weights of D steps in flight.  The loop
+    // is unrolled D times over statically named stages: a stage's registers are the targets of loads in flight, and moving them down a
+    // ring would wait for every one of them (it did: 0.35 us a step, per-wave timestamps, round 5).
+    const uint32_t ni = nq > (uint32_t)wave ? (nq - (uint32_t)wave + (uint32_t)NW - 1u) / (uint32_t)NW : 0u;      // the wave's steps (<= 128)
+    // the patch ids of all its steps in two VECTOR loads (lane j: steps j and 64 + j), read back per step with v_readlane -- as scalar loads
+    // in the loop they would share the LDS reads' counter (lgkmcnt) and make every step wait for a scalar-cache miss
+    const uint32_t q0 = (uint32_t)wave + (uint32_t)NW * (uint32_t)lane, q1 = q0 + 64u * (uint32_t)NW;
+    const uint32_t ids0 = q0 < nq ? (uint32_t)psrc[q0] : 0u, ids1 = q1 < nq ? (uint32_t)psrc[q1] : 0u;
+    auto patch_of = [&](uint32_t i) {      // (i uniform; beyond the wave's steps: patch 0, whose weights the step then zeroes)
+        const uint32_t j = i < 127u ? i : 127u;
+        return j < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)ids0, (int)j) : (uint32_t)__builtin_amdgcn_readlane((int)ids1, (int)(j - 64u));
+    };
     struct Step { float f, v0, v1, v2; uint2 a4; };
-    auto gather = [&](uint32_t i, uint32_t cb) {
+    auto gather = [&](uint32_t i) {
         Step st;
-        const uint32_t tex = texel_of(cb);
+        const uint32_t tex = texel_of(patch_of(i));
         st.f = S.pre[tex];
-        const float* __restrict__ src = S.x + 3 * (size_t)tex;
+        const float* __restrict__ src = S.x + 3u * tex;
         st.v0 = src[0]; st.v1 = src[1]; st.v2 = src[2];
-        st.a4 = quad_of(i) < nq ? A[(size_t)quad_of(i) * 64 + lane] : make_uint2(0u, 0u);
+        const uint32_t qd = (uint32_t)wave + (uint32_t)NW * i;
+        st.a4 = A[(size_t)(qd < nq ? qd : nq - 1u) * 64 + lane];
         return st;
     };
     // (the epilogue's row and its factor are asked for now: two dependent loads off the end of the workgroup's life)
@@ -1063,36 +1080,39 @@ __device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, 
     int orow = -1;
     if (threadIdx.x < 256 && (ocol & 3) < 3 && r_first + (uint32_t)orow_t < r_end) orow = S.image_rows[(r_first + (uint32_t)orow_t) * 48 + 4 * ig + (ocol >> 2)];
     const float opost = orow >= 0 ? S.row_scale[orow] : 0.0f;
-    uint32_t cb[D + 2];
-#pragma unroll
-    for (int j = 0; j < D + 2; ++j) cb[j] = load_cb((uint32_t)j);
     Step st[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) st[j] = gather((uint32_t)j, cb[j]);
+    for (int j = 0; j < D; ++j) st[j] = gather((uint32_t)j);
     spmv_f32x4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = spmv_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (uint32_t i = 0; quad_of(i) < nq; ++i) {
-        const Step nx = gather(i + (uint32_t)D, cb[D]);
-        const uint32_t cbn = load_cb(i + (uint32_t)D + 2u);
-        // this step: the wave's 16 texels x 4 symmetries into its buffer ([texel][symmetry][4] = [texel][16 columns]), four MFMAs out of it
-        const Step c0 = st[0];
-        reinterpret_cast<float4*>(Bs)[4u * kk + simg] = make_float4(c0.f * c0.v0, c0.f * c0.v1, c0.f * c0.v2, 0.0f);
-        const float* Br = Bs + lane;
-        const float b0 = Br[0], b1 = Br[64], b2 = Br[128], b3 = Br[192];         // B[k = lane >> 4][column lane & 15] of the patch's four rows
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.x & 0xFFFFu), b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.x >> 16), b1, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.y & 0xFFFFu), b2, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(c0.a4.y >> 16), b3, acc[3], 0, 0, 0);
+#ifdef MRGS_SPMV_TRACE
+    unsigned long long tr1 = 0, tr2 = 0;
+    { float probe = st[0].f + st[0].v0 + (float)st[0].a4.x; asm volatile("" :: "v"(probe)); tr1 = wall_clock64(); }
+#endif
+    float4* Bw = reinterpret_cast<float4*>(Bs + kk * MRGS_SPMV_SYM_BROW) + simg;        // [texel kk][symmetry][4] = [kk][16 columns], rows padded
+    const float* Br = Bs + (lane >> 4) * MRGS_SPMV_SYM_BROW + (lane & 15);               // B[k = lane >> 4][column lane & 15] of a patch row
+    for (uint32_t i0 = 0; i0 < ni; i0 += (uint32_t)D) {
 #pragma unroll
-        for (int j = 0; j + 1 < D; ++j) st[j] = st[j + 1];
-        st[D - 1] = nx;
-#pragma unroll
-        for (int j = 0; j + 1 < D + 2; ++j) cb[j] = cb[j + 1];
-        cb[D + 1] = cbn;
+        for (int u = 0; u < D; ++u) {
+            // this step: the wave's 16 texels x 4 symmetries into its buffer, four MFMAs out of it (a step past the wave's last has zero weights)
+            const Step c0 = st[u];
+            const bool live = i0 + (uint32_t)u < ni;
+            const uint32_t ax = live ? c0.a4.x : 0u, ay = live ? c0.a4.y : 0u;
+            *Bw = make_float4(c0.f * c0.v0, c0.f * c0.v1, c0.f * c0.v2, 0.0f);
+            const float b0 = Br[0], b1 = Br[4 * MRGS_SPMV_SYM_BROW], b2 = Br[8 * MRGS_SPMV_SYM_BROW], b3 = Br[12 * MRGS_SPMV_SYM_BROW];
+            st[u] = gather(i0 + (uint32_t)(u + D));
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(ax & 0xFFFFu), b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(ax >> 16), b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(ay & 0xFFFFu), b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(ay >> 16), b3, acc[3], 0, 0, 0);
+        }
     }
+#ifdef MRGS_SPMV_TRACE
+    { float probe = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0]; asm volatile("" :: "v"(probe)); tr2 = wall_clock64(); }
+#endif
     // the waves' partial tiles -> one; C/D of the MFMA: column lane & 15, rows 4 (lane >> 4) + register
-    float* red = reinterpret_cast<float*>(spmv_lds) + NW * 256;
+    float* red = reinterpret_cast<float*>(spmv_lds) + NW * (16 * MRGS_SPMV_SYM_BROW);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
@@ -1103,6 +1123,12 @@ __device__ __forceinline__ void csr_spmv3_sym_body(int block, const SpmvSeg& S, 
         for (int w = 0; w < NW; ++w) sum += red[w * 256 + orow_t * 16 + ocol];
         S.y[3 * (size_t)orow + (ocol & 3)] = sum * opost;
     }
+#ifdef MRGS_SPMV_TRACE
+    if (MRGS_SPMV_TRACE_PTR != nullptr && lane == 0) {
+        unsigned long long* o = MRGS_SPMV_TRACE_PTR + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = wall_clock64();
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(MRGS_SPMV_BATCH_THREADS) csr_spmv3_batched_kernel(SpmvBatch B)
@@ -1114,7 +1140,7 @@ __global__ void __launch_bounds__(MRGS_SPMV_BATCH_THREADS) csr_spmv3_batched_ker
     // (the row-per-wave bodies count 256-thread blocks: block 2 own + (threadIdx.x >> 8), which is what their `block * 256 + threadIdx.x` makes of 2 own)
     const int blk = S.fmt == 16 ? own : own * (MRGS_SPMV_BATCH_THREADS / 256);
     switch (S.fmt) {   // bit 2: 64 lanes per row (else 4); bit 1: 32-bit column indices (else 16); bit 0: fp32 weights (else 16-bit fixed point); 8: blocked rows; 16: blocked rows of one fundamental domain
-    case 16: csr_spmv3_sym_body(blk, S, B.sym); break;
+    case 16: csr_spmv3_sym_body(blk, S, B.sym, B.trace); break;
     case 8: csr_spmv3_blk4_body(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint2*)S.val, S.row_scale, S.x, S.y); break;
     case 0: csr_spmv3_body<4, uint16_t, uint16_t>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const uint16_t*)S.val, S.row_scale, S.x, S.y); break;
     case 1: csr_spmv3_body<4, uint16_t, float>(blk, S.nrows, S.row_ptr, (const uint16_t*)S.col, (const float*)S.val, S.row_scale, S.x, S.y); break;
@@ -1441,6 +1467,10 @@ int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream)
         blocks += (int)(((size_t)d.nrows * (wide ? 64 : 4) + MRGS_SPMV_BATCH_THREADS - 1) / MRGS_SPMV_BATCH_THREADS);
     }
     B.total_blocks = blocks;
+    B.trace = nullptr;
+#ifdef MRGS_SPMV_TRACE
+    if (const char* tp = getenv("MRGS_SPMV_TRACE_BUF")) B.trace = (unsigned long long*)strtoull(tp, nullptr, 16);     // developer build: per-wave timestamps
+#endif
     hipLaunchKernelGGL(csr_spmv3_batched_kernel, dim3((unsigned)blocks), dim3(MRGS_SPMV_BATCH_THREADS), lds, (hipStream_t)stream, B);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
