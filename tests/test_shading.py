@@ -401,9 +401,17 @@ def test_symmetric_filter_rows_equal_the_full_operator(gpu_device, monkeypatch):
         for op, x, y in zip(ops, xs, got):
             full = op.apply_matrix(x, transpose=tr)
             assert float((y - full).abs().max()) <= 2e-5 * float(x.abs().max()), (op.res, op.kind, tr)
-    # one operator absent from the batch, and a batch of the full matrices (the developer switch) give the same
+    # one operator absent from the batch
     got = sh._spmv_batched(ops, [xs[0], None, xs[2], None], transpose=False, cache=False)
     assert got[1] is None and got[3] is None and float((got[2] - ops[2].apply_matrix(xs[2])).abs().max()) <= 2e-5 * float(xs[2].abs().max())
+    # the fall-back (and MRGS_NO_SYMMETRIC_SPMV=1): the full blocked matrices in the same batched launch, next to a symmetric level
+    monkeypatch.setattr(sh, "_NO_SYM", True)
+    full32 = sh.CubemapFilterOp(gpu_device, 32, 0, 0.5, 0.99)
+    assert full32.sym is None and full32.val.dim() == 2
+    for tr in (False, True):
+        a = sh._spmv_batched([ops[0], full32], [xs[0], xs[1]], transpose=tr, cache=False)
+        b = sh._spmv_batched([ops[0], ops[1]], [xs[0], xs[1]], transpose=tr, cache=False)
+        assert float((a[1] - b[1]).abs().max()) <= 2e-5 * float(xs[1].abs().max()) and torch.equal(a[0], b[0])
 
 
 def _unpack_blocks(bptr, bcol, packed, m, ncols):
