@@ -107,7 +107,12 @@ typedef struct MrgsRasterInputs {
                               (mrgs_work_hint_bytes covers both).  Only with work_hint set, and only after a forward WITHOUT the flag has
                               run on the same buffer; the caller (the Python wrapper: every visit of a camera but the first two and every
                               sixteenth) is responsible for that.  A schedule only: results do not depend on it. */
-    uint32_t reserved_;
+    uint32_t features_live; /* ABI 8 (was reserved, 0): 0 = every one of the S feature channels may be non-zero.  n in 1 .. S - 1: channels n .. S - 1
+                               are PADDING (the caller keeps them zero -- e.g. rows of 9 channels padded to 12 floats so that they are 16-byte
+                               pieces): the blend kernels leave them out of their per-entry arithmetic, their output maps are written as zeros,
+                               their columns of dL_dfeatures stay zero and the upstream gradient of those maps is not read.  Honoured by the
+                               instances whose rows are whole 16-byte pieces (S = 12 with n = 9: the "pgsr" flavour's rows); any other
+                               combination is treated as 0 -- the results are the same, only slower. */
 } MrgsRasterInputs;
 #define MRGS_HINT_REUSE_ORDER 1u
 

@@ -33,7 +33,7 @@ class MrgsRasterConfig(_Sized):
 class MrgsRasterInputs(_Sized):
     _fields_ = [("struct_size", ctypes.c_uint64)] + [(n, c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales",
                                         "rotations", "transMat_precomp", "viewmatrix", "projmatrix", "campos", "work_hint", "shs_rest",
-                                        "bwd_grad_ws")] + [("hint_flags", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
+                                        "bwd_grad_ws")] + [("hint_flags", ctypes.c_uint32), ("features_live", ctypes.c_uint32)]
 
 
 MRGS_HINT_REUSE_ORDER = 1

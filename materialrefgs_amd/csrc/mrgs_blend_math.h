@@ -383,7 +383,9 @@ __device__ __forceinline__ float mrgs_staged_feature(const StageBuf<SF>& sb, int
 // FV ("feature vectors"): the feature row of a gaussian is S = S_MAX floats with S % 4 == 0, i.e. 16-byte aligned 16-byte
 // pieces: S/4 DMA instructions of 16 bytes per lane instead of S of 4 bytes (each DMA instruction of a wave gathers from up
 // to 64 different cache lines, which is what it costs), and the blend reads four channels with one ds_read_b128.
-template <int S_MAX, int SF, bool FV>
+// (TAG: the instantiating kernel's live-channel count -- two kernels sharing one specialization of this function trip the host pass of
+//  clang over its device-only builtins: the second use reports a substitution failure)
+template <int S_MAX, int SF, bool FV, int TAG = 0>
 __device__ __forceinline__ void mrgs_stage_async(StageBuf<SF>& dst, const float4* __restrict__ rec, const float* __restrict__ features,
                                                  int S, uint32_t gid, bool pred)
 {

@@ -153,6 +153,16 @@ __device__ __forceinline__ void wave_reduce_atomic_add2(float a, float b, float*
     if ((lane & 31) == 16) atomic_add_at(base, byte_off + 4u * (uint32_t)(lane >> 5), a);
 }
 
+// one value apart (the ninth live feature channel of rows padded to twelve: 16 + 9 values are 24 through the transposing reduction and this one)
+__device__ __forceinline__ void wave_reduce_atomic_add1(float a, float* __restrict__ base, uint32_t byte_off, int lane)
+{
+    float z = 0.0f;
+    swap32_add(a, z);                       // lanes 0..31: a[l] + a[l + 32]
+    a = rows_reduce1(a);
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x142, 0xa, 0xf, false));      // row_bcast:15: row 1 holds the total
+    if (lane == 16) atomic_add_at(base, byte_off, a);
+}
+
 #ifdef MRGS_WAVE_STATS   // developer build only (tools/wave_stats.py): per-wave start/end time, iteration counts, placement
 __device__ unsigned long long g_wave_stats[8 * 65536];
 extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
@@ -182,7 +192,9 @@ extern "C" int mrgs_wave_stats(unsigned long long* host, int n)
 #ifndef MRGS_BWD_WPE8
 #define MRGS_BWD_WPE8 4
 #endif
-template <int S_MAX, bool FV>
+// S_LIVE: the leading channels that can be non-zero (MrgsRasterInputs::features_live); the padding channels stay out of the entry's
+// arithmetic and of the reduction, their gradient columns keep the zeros they were cleared to
+template <int S_MAX, bool FV, int S_LIVE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX == 0 ? MRGS_BWD_WPE0 : S_MAX <= 8 ? MRGS_BWD_WPE8 : 2, 8))) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ bwd_assign, uint32_t* __restrict__ q_bwd, const uint32_t* __restrict__ cu_state, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ cflag, int S, int W, int H, int tiles_x, int ntiles,
@@ -191,7 +203,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride, int slots)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
-    constexpr int K = 16 + S_MAX;   // values through the transposing reduction (the dL/dmean2D pair goes apart)
+    constexpr int K = 16 + S_LIVE;  // gradient values of an entry
+    constexpr int KT = K & ~3;      // ... through the transposing reduction (whole groups of four; the dL/dmean2D pair and a remainder go apart)
     __shared__ StageBuf<SF> stage[MRGS_BWD_STAGES];
 
     const int lane = threadIdx.x;
@@ -258,7 +271,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * HW + pix];
         if (S_MAX > 0) {
 #pragma unroll
-            for (int i = 0; i < S_MAX; i++)
+            for (int i = 0; i < S_LIVE; i++)
                 if (i < S) dL_dpixel_f[i] = dL_dpixels_f[(size_t)i * HW + pix];
         }
     }
@@ -290,7 +303,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         const bool cand0 = q0 & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         exact_cur = __builtin_amdgcn_ballot_w64((q0 & 2u) != 0u);
-        mrgs_stage_async<S_MAX, SF, FV>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
+        mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
     }
 
@@ -304,7 +317,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             exact_nxt = __builtin_amdgcn_ballot_w64(((idq1 >> 29) & 1u) != 0u);
             const uint32_t id1 = idq1 & 0x0FFFFFFFu;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
-            mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
+            mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
             idq1 = idq2;
             idq2 = 0;
@@ -359,7 +372,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             }
             if (S_MAX > 0) {
 #pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++) {
+                for (int ch = 0; ch < S_LIVE; ch++) {
                     // no branch on the runtime S (see the forward): slots beyond S read as 0 and have dL_dpixel_f = 0
                     const float f = (FV || ch < S) ? mrgs_staged_feature<FV>(sb, ch, j) : 0.0f;
                     q = fmaf(f, dL_dpixel_f[ch], q);
@@ -414,7 +427,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             }
             g[MRGS_G_OPA] = G * dL_dalpha;
             const uint32_t row_off = sb.id[j];   // byte offset of the surfel's gradient row
-            wave_reduce_atomic_add<K>(g, grad_rec, row_off, rl);
+            if constexpr (KT == K) {
+                wave_reduce_atomic_add<K>(g, grad_rec, row_off, rl);
+            } else {
+                float gt[KT];
+#pragma unroll
+                for (int k = 0; k < KT; k++) gt[k] = g[k];
+                wave_reduce_atomic_add<KT>(gt, grad_rec, row_off, rl);
+#pragma unroll
+                for (int k = KT; k < K; k++) wave_reduce_atomic_add1(g[k], grad_rec, row_off + 4u * (uint32_t)k, lane);
+            }
             const bool a2 = active & !use3d;
             if (__builtin_amdgcn_ballot_w64(a2) != 0ull) {   // low-pass-filter branch: dL/dmean2D
                 const float dL_dG2 = a2 ? dL_dG : 0.0f;
@@ -468,18 +490,19 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     // one wave per slot of the work queues (mrgs_pull_item): items rounded up to whole dealing passes; blockIdx % 8 = XCD list
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
-#define LAUNCH(SM, FVV, GS)                                                                                                       \
-    hipLaunchKernelGGL((MRGS_BWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, assign, img.q_bwd, img.blend_state + MRGS_CS_BASE, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<MRGS_BWD_KERNEL<SM, FVV>>())
+#define LAUNCH(GS, SM, ...)                                                                                                       \
+    hipLaunchKernelGGL((MRGS_BWD_KERNEL<SM, __VA_ARGS__>), grid, block, 0, stream, img.ranges, assign, img.q_bwd, img.blend_state + MRGS_CS_BASE, plist, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+                       g.rec, in.features, in.bg, img.final_T, img.n_contrib, dL_dpix, dL_dpix_f, dL_dothers, grad_rec, GS, mrgs_waves_per_simd<MRGS_BWD_KERNEL<SM, __VA_ARGS__>>())
     // the packed gradient row is as wide as the padded value count of the kernel instance (MRGS_GRAD_STRIDE)
     const int gs = MRGS_GRAD_STRIDE(cfg.S);
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
-    if (cfg.S == 0) LAUNCH(0, false, gs);
-    else if (cfg.S == 8 && fv_ok) LAUNCH(8, true, gs);
-    else if (cfg.S <= 8) LAUNCH(8, false, gs);
-    else if (cfg.S == 12 && fv_ok) LAUNCH(12, true, gs);
-    else if (cfg.S <= 12) LAUNCH(12, false, gs);
-    else if (cfg.S == 24 && fv_ok) LAUNCH(24, true, gs);
-    else LAUNCH(24, false, gs);
+    if (cfg.S == 0) LAUNCH(gs, 0, false, 0);
+    else if (cfg.S == 8 && fv_ok) LAUNCH(gs, 8, true, 8);
+    else if (cfg.S <= 8) LAUNCH(gs, 8, false, 8);
+    else if (cfg.S == 12 && fv_ok && in.features_live == 9u) LAUNCH(gs, 12, true, 9);     // rows of 9 channels padded to three 16-byte pieces
+    else if (cfg.S == 12 && fv_ok) LAUNCH(gs, 12, true, 12);
+    else if (cfg.S <= 12) LAUNCH(gs, 12, false, 12);
+    else if (cfg.S == 24 && fv_ok) LAUNCH(gs, 24, true, 24);
+    else LAUNCH(gs, 24, false, 24);
 #undef LAUNCH
 }

@@ -272,7 +272,8 @@ __global__ void __launch_bounds__(64) render_fwd_redo_kernel(
 #ifndef MRGS_FWD_REDO_INLINE
 #define MRGS_FWD_REDO_INLINE 1
 #endif
-template <int S_MAX, bool FV>
+// S_LIVE: the leading channels that can be non-zero (MrgsRasterInputs::features_live); the rest of the S_MAX are padding of the row
+template <int S_MAX, bool FV, int S_LIVE>
 // Waves per SIMD the register allocator is held to.  Round 4 (after the exact-decision logic joined the loop), forward blend stage in ms at
 // C2 / C3full: S = 0 at 7 / 6 / 5 / 4 waves 0.172 / 0.170 / 0.176 / 0.174 (72 / 80 / 95 / 96 VGPRs, 21 / 14 / 0 / 0 spilled); S = 8 at 6 / 5 / 4
 // waves 0.203 / 0.204 / 0.195 (105 VGPRs and no spills at 4).
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (2 * MRGS_CHUNK + lane < total) { id2 = plist[2 * MRGS_CHUNK + lane]; q2 = qm[2 * MRGS_CHUNK + lane]; }
         const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
-        mrgs_stage_async<S_MAX, SF, FV>(stage[0], rec, features, S, id0, cand0);
+        mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[0], rec, features, S, id0, cand0);
     }
 
     for (int base = 0, c = 0; base < total; base += MRGS_CHUNK, c++) {
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             // stage chunk c+1 (its ids and cull bits arrived during the previous iterations), prefetch those of chunk c+3
             const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
-            mrgs_stage_async<S_MAX, SF, FV>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
+            mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
             idn = id1;
             id1 = id2; q1 = q2;
             id2 = 0; q2 = 0;
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 // each LDS read and its wait into a basic block of its own (measured: +110 us for 8 channels); the slots
                 // beyond S accumulate whatever the stage buffer holds and are never written out
 #pragma unroll
-                for (int ch = 0; ch < S_MAX; ch++) F[ch] = fmaf(mrgs_staged_feature<FV>(sb, ch, j), w, F[ch]);
+                for (int ch = 0; ch < S_LIVE; ch++) F[ch] = fmaf(mrgs_staged_feature<FV>(sb, ch, j), w, F[ch]);
             }
             T = upd ? test_T : T;
             last_contributor = upd ? contributor : last_contributor;
@@ -536,7 +537,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (S_MAX > 0) {
 #pragma unroll
             for (int ch = 0; ch < S_MAX; ch++)
-                if (ch < S) out_feature[(size_t)ch * HW + pix] = F[ch];
+                if (ch < S) out_feature[(size_t)ch * HW + pix] = ch < S_LIVE ? F[ch] : 0.0f;
         }
         out_others[pix + 0 * HW] = Dp;
         out_others[pix + 1 * HW] = 1.0f - T;
@@ -591,18 +592,19 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     // one wave per slot of the work queues (mrgs_pull_item): items rounded up to whole dealing passes; blockIdx % 8 = XCD list
     const int nblocks = (((ntiles + 7) / 8) * 4 + MRGS_MAX_SIMD_QUEUES) * 8;
     const dim3 grid(nblocks), block(64);
-#define LAUNCH(SM, FVV)                                                                                                           \
-    hipLaunchKernelGGL((MRGS_FWD_KERNEL<SM, FVV>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
-                       g.rec, g.cull, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, FVV>>(), img.redo_list)
+#define LAUNCH(SM, ...)                                                                                                           \
+    hipLaunchKernelGGL((MRGS_FWD_KERNEL<SM, __VA_ARGS__>), grid, block, 0, stream, img.ranges, img.fwd_assign, img.blend_state, plist, qmask, cflag, cfg.S, cfg.W, cfg.H, tiles_x, ntiles, \
+                       g.rec, g.cull, in.features, in.bg, img.final_T, img.n_contrib, out_color, out_feature, out_others, img.item_work, img.item_est, in.work_hint, mrgs_waves_per_simd<MRGS_FWD_KERNEL<SM, __VA_ARGS__>>(), img.redo_list)
     // FV instances: the feature rows are exactly S_MAX floats (16-byte aligned pieces, see mrgs_stage_async)
     const bool fv_ok = ((uintptr_t)in.features & 15u) == 0;   // 16-byte DMA pieces need an aligned feature tensor
-    if (cfg.S == 0) LAUNCH(0, false);
-    else if (cfg.S == 8 && fv_ok) LAUNCH(8, true);
-    else if (cfg.S <= 8) LAUNCH(8, false);
-    else if (cfg.S == 12 && fv_ok) LAUNCH(12, true);
-    else if (cfg.S <= 12) LAUNCH(12, false);
-    else if (cfg.S == 24 && fv_ok) LAUNCH(24, true);
-    else LAUNCH(24, false);
+    if (cfg.S == 0) LAUNCH(0, false, 0);
+    else if (cfg.S == 8 && fv_ok) LAUNCH(8, true, 8);
+    else if (cfg.S <= 8) LAUNCH(8, false, 8);
+    else if (cfg.S == 12 && fv_ok && in.features_live == 9u) LAUNCH(12, true, 9);      // rows of 9 channels padded to three 16-byte pieces
+    else if (cfg.S == 12 && fv_ok) LAUNCH(12, true, 12);
+    else if (cfg.S <= 12) LAUNCH(12, false, 12);
+    else if (cfg.S == 24 && fv_ok) LAUNCH(24, true, 24);
+    else LAUNCH(24, false, 24);
 #undef LAUNCH
 #if !MRGS_FWD_REDO_INLINE
     // the marked pixels again, exactly (an empty list most of the time: the launch is there for the count it reads on the device)

@@ -1014,7 +1014,9 @@ static void cube_symmetry_table(uint64_t* tab)
     }
 }
 
+#ifndef MRGS_SPMV_BATCH_THREADS
 #define MRGS_SPMV_BATCH_THREADS 512
+#endif
 #define MRGS_SPMV_SYM_WAVES (MRGS_SPMV_BATCH_THREADS / 64)      // the waves of a workgroup split the panel
 #define MRGS_SPMV_SYM_BROW 20        // floats per staged texel row: 16 columns + 4 of padding (the 16-byte writes of eight lanes then cover the 32 banks)
 #define MRGS_SPMV_SYM_LDS (MRGS_SPMV_SYM_WAVES * (16 * MRGS_SPMV_SYM_BROW * 4 + 1024))  // per wave: a staging buffer of 16 texels x 16 columns, a partial tile

@@ -183,6 +183,9 @@ def _stream(device):
 
 
 _RESOLVE = object()
+# MrgsRasterInputs::features_live of the render being issued on this thread (GaussianRasterizer.features_live: the settings tuple keeps
+# the reference's fields); the autograd node notes it for its backward
+_LIVE = __import__("threading").local()
 
 
 def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None,
@@ -206,7 +209,8 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
                            _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
                            _ptr(work_hint), _ptr(sh_rest),
-                           _ptr(bwd_grad_ws), _hint_flags(raster_settings, means3D.device, P) if means3D.is_cuda else 0, 0)
+                           _ptr(bwd_grad_ws), _hint_flags(raster_settings, means3D.device, P) if means3D.is_cuda else 0,
+                           int(getattr(_LIVE, "n", 0) or 0))
     return cfg, inp, work_hint
 
 
@@ -463,6 +467,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             out = _rasterize_forward_native(*args)
         (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer, grad_ws, hint = out
+        ctx.features_live = int(getattr(_LIVE, "n", 0) or 0)
         ctx.prepared_grad_ws = grad_ws       # cleared by the forward, queues of the backward set up: good for ONE backward
         ctx.work_hint = hint                 # the buffer those queues live in: the backward is handed this very tensor (never a re-resolved one)
         ctx.raster_settings = rs
@@ -494,16 +499,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp, _f32c(grad_out_color),
                 _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest, prepared,
                 ctx.work_hint)
-        if rs.debug:
-            cpu_args = cpu_deep_copy_tuple(args[1:])
-            try:
+        _LIVE.n = getattr(ctx, "features_live", 0)       # (the autograd engine's thread: the forward's hint again)
+        try:
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple(args[1:])
+                try:
+                    out = _rasterize_backward_native(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
                 out = _rasterize_backward_native(*args)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-                raise ex
-        else:
-            out = _rasterize_backward_native(*args)
+        finally:
+            _LIVE.n = 0
         (grad_means2D, grad_colors_precomp, grad_features, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_sh_rest) = out
         # empty inputs (the `torch.Tensor([])` placeholders) get empty gradients of matching shape
@@ -585,5 +594,9 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = empty
 
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings, shs_rest)
+        _LIVE.n = int(getattr(self, "features_live", 0) or 0)      # (extension: feature channels n .. S - 1 are zero padding of the rows)
+        try:
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
+                                       raster_settings, shs_rest)
+        finally:
+            _LIVE.n = 0

@@ -362,23 +362,24 @@ class _SplitChannels(torch.autograd.Function):
     would otherwise each pad their gradient to [S,H,W] with a fill and a copy and meet in an accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, maps, k):
+    def forward(ctx, maps, k, tail_unread=False):
+        # tail_unread: the maps behind k + 1 are padding whose gradient the rasterizer's backward does not read (features_live)
         ctx.set_materialize_grads(False)
-        ctx.k, ctx.shape = k, tuple(maps.shape)
+        ctx.k, ctx.shape, ctx.tail_unread = k, tuple(maps.shape), bool(tail_unread)
         return maps[:k], maps[k:k + 1]
 
     @staticmethod
     def backward(ctx, g_head, g_one):
         if g_head is None and g_one is None:
-            return None, None
+            return None, None, None
         k, shape = ctx.k, ctx.shape
         ref = g_head if g_head is not None else g_one
         g = torch.empty(shape, dtype=ref.dtype, device=ref.device)
         (g[:k].copy_(g_head) if g_head is not None else g[:k].zero_())
         (g[k:k + 1].copy_(g_one) if g_one is not None else g[k:k + 1].zero_())
-        if shape[0] > k + 1:
+        if shape[0] > k + 1 and not ctx.tail_unread:
             g[k + 1:].zero_()
-        return g, None
+        return g, None, None
 
 
 def cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier=1.0):
@@ -497,12 +498,15 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):       # :276-290 (the fused node's scales / rotations stay unused: their gradients are None)
         scales, rotations, cov3D_precomp = None, None, cov3D_precomp_of(pc, viewpoint_camera, scaling_modifier)
+    padded = fused_distance and features.shape[1] == 12
+    if padded:      # nine channels in rows of twelve floats: the blend kernels leave the padding out of their arithmetic (features_live)
+        rasterizer.features_live = 9
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     rend_distance = None
     if flag != "2dgs":          # the eight material maps and the plane distance out of the 9 (12: padded rows) rasterized channels
-        rendered_features, rend_distance = _SplitChannels.apply(rendered_features, 8)
+        rendered_features, rend_distance = _SplitChannels.apply(rendered_features, 8, padded)
     elif rendered_features.shape[0] != 8:        # (a slice of the full range is still an autograd node: a zero fill and a copy of 8 maps)
         rendered_features = rendered_features[:8]
 

@@ -34,7 +34,7 @@ def raster_settings(cam, device, sh_degree=3, scale_modifier=1.0, bg=None, debug
 class HipRender:
     """Forward (+ optional backward) through materialrefgs_amd.rasterizer, keeping handles for introspection."""
 
-    def __init__(self, scene, cam, device, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, use_features=True, rs=None):
+    def __init__(self, scene, cam, device, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, use_features=True, rs=None, features_live=0):
         from materialrefgs_amd.rasterizer import GaussianRasterizer
         self.dev = device
         sc = scene.to(device)
@@ -56,6 +56,7 @@ class HipRender:
         else:
             kw["colors_precomp"] = leaf("colors", colors_precomp.to(device))
         rast = GaussianRasterizer(self.rs)
+        rast.features_live = features_live         # extension: feature channels from here on are zero padding of the rows
         self.contrib, self.color, self.feature, self.radii, self.others = rast(
             means3D=means3D, means2D=means2D, opacities=opac, features=feats, scales=scales, rotations=rots, **kw)
         self.fn = self.color.grad_fn

@@ -554,3 +554,33 @@ def test_more_begun_renders_than_ticket_slots_in_one_box(gpu_device):
     for r in renders:
         assert r.num_rendered == first.num_rendered
         assert torch.equal(r.color.detach(), ref)
+
+
+@pytest.mark.gpu
+def test_padding_channels_left_out_of_the_blend(gpu_device):
+    """MrgsRasterInputs::features_live (GaussianRasterizer.features_live): rows of nine channels padded to twelve floats -- the "pgsr" flavour's
+    eight material channels and plane distance -- rendered with the hint (the <12, 9> kernel instances: nine channels of arithmetic, 24 + 1
+    values through the gradient reductions) against the same rows rendered as twelve channels.  The forward is the same arithmetic per live
+    channel: bit-identical maps, the padding maps zero; the backward sums the ninth channel's gradient in another order: 2e-6 of the largest
+    entry; the padding columns of dL_dfeatures stay zero and the gradient of the padding maps is not read (NaN there changes nothing)."""
+    S, H, W = 12, 176, 144
+    scene = make_shell_scene(6000, S=S, seed=23, radius_px=7.0, image_size=176)
+    scene.features[:, 9:] = 0.0
+    cam = orbit_camera(3, H, W)
+    g = torch.Generator().manual_seed(7)
+    gc, gf, go = torch.randn(3, H, W, generator=g), torch.randn(S, H, W, generator=g), torch.randn(7, H, W, generator=g) * 0.1
+    a = HipRender(scene, cam, gpu_device)
+    b = HipRender(scene, cam, gpu_device, features_live=9)
+    assert torch.equal(a.color, b.color) and torch.equal(a.feature, b.feature) and torch.equal(a.others, b.others)
+    assert float(b.feature[9:].detach().abs().max()) == 0.0
+    gf_nan = gf.clone()
+    gf_nan[9:] = float("nan")
+    gf_zero = gf.clone()
+    gf_zero[9:] = 0.0
+    ga = a.backward(gc, gf_zero, go)
+    gb = b.backward(gc, gf_nan, go)
+    for name in ga:
+        x, y = ga[name], gb[name]
+        assert bool(np.isfinite(y).all()), name
+        assert float(np.abs(x - y).max()) <= 2e-6 * max(1e-30, float(np.abs(x).max())), name
+    assert float(np.abs(gb["features"][:, 9:]).max()) == 0.0
