@@ -374,8 +374,12 @@ class _SplitChannels(torch.autograd.Function):
             return None, None, None
         k, shape = ctx.k, ctx.shape
         ref = g_head if g_head is not None else g_one
-        g = torch.empty(shape, dtype=ref.dtype, device=ref.device)
-        (g[:k].copy_(g_head) if g_head is not None else g[:k].zero_())
+        hb = getattr(g_head, "_base", None) if g_head is not None else None
+        if hb is not None and tuple(hb.shape) == shape and g_head.storage_offset() == 0 and hb.is_contiguous() and hb.dtype == ref.dtype:
+            g = hb              # the producer laid its maps out as the head of the stack (shading._SurfelShade.backward): nothing to copy
+        else:
+            g = torch.empty(shape, dtype=ref.dtype, device=ref.device)
+            (g[:k].copy_(g_head) if g_head is not None else g[:k].zero_())
         (g[k:k + 1].copy_(g_one) if g_one is not None else g[k:k + 1].zero_())
         if shape[0] > k + 1 and not ctx.tail_unread:
             g[k + 1:].zero_()
