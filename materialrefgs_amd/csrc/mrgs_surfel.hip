@@ -195,19 +195,27 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
     const int nrows = min(64, P - row0);
     if (nrows <= 0) return;
     float* tile = s_rest[wave];
-    tile_load<REST_L>(tile, prm.indirect_rest + (size_t)row0 * REST_L, nrows, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     const int idx_ = row0 + lane;
     const bool in_range = idx_ < P;
     const int idx = in_range ? idx_ : P - 1;     // out-of-range lanes stay for the cooperative tile store
+    const int f4 = prm.viewmatrix != nullptr ? 3 : 2;          // float4 per feature row
+    const float4 gf0 = g_features ? reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx] : make_float4(0, 0, 0, 0);
+    const float4 gf1 = g_features ? reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx + 1] : make_float4(0, 0, 0, 0);
+    // The indirect radiance takes a gradient only where something looked at it (opt.indirect, a loss on "indirect_light"): where the
+    // upstream gradient of its three channels is exactly zero for all 64 rows of the wave, every term it feeds is an exact zero -- the
+    // 45 coefficient gradients, the DC's, the mirror direction's -- and the wave neither reads its 11.5 KB of coefficients nor evaluates
+    // the basis: it writes the zeros (54 of the kernel's 97 MB of reads at 300 k surfels when no row has one).  Same values as the full
+    // path for finite coefficients (0 x inf would be NaN there).
+    const bool sh_live = __builtin_amdgcn_ballot_w64(in_range && (gf1.y != 0.0f || gf1.z != 0.0f || gf1.w != 0.0f)) != 0ull;
+    if (sh_live) {
+        tile_load<REST_L>(tile, prm.indirect_rest + (size_t)row0 * REST_L, nrows, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     const float p[3] = {prm.xyz[3 * (size_t)idx], prm.xyz[3 * (size_t)idx + 1], prm.xyz[3 * (size_t)idx + 2]};
     const float4 q = reinterpret_cast<const float4*>(prm.rotation_raw)[idx];
     const Frame f = make_frame(p, q, prm.campos);
-    const int f4 = prm.viewmatrix != nullptr ? 3 : 2;          // float4 per feature row
-    const float4 gf0 = g_features ? reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx] : make_float4(0, 0, 0, 0);
-    const float4 gf1 = g_features ? reinterpret_cast<const float4*>(g_features)[f4 * (size_t)idx + 1] : make_float4(0, 0, 0, 0);
     // "pgsr": the plane distance |nc . cc| (plane_distance) sends its gradient to the facing normal and to the centre
     float d_nn_pd[3] = {0.0f, 0.0f, 0.0f}, d_p_pd[3] = {0.0f, 0.0f, 0.0f};
     if (prm.viewmatrix != nullptr && g_features != nullptr) {
@@ -224,13 +232,13 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
 
     // ---- indirect = clamp_min(sum_k sh[k][ch] B_k(r), 0) ----
     const float x = f.r[0], y = f.r[1], z = f.r[2];
-    float B[16];
-    sh_basis16(x, y, z, B);
     float* row = tile + lane * REST_STRIDE;
     const float gin[3] = {gf1.y, gf1.z, gf1.w};
     float d_r[3] = {0.0f, 0.0f, 0.0f};
-    float d_dc[3];
-    {
+    float d_dc[3] = {0.0f, 0.0f, 0.0f};
+    if (sh_live) {
+        float B[16];
+        sh_basis16(x, y, z, B);
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -263,9 +271,21 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
             d_r[0] += g * dx; d_r[1] += g * dy; d_r[2] += g * dz;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    tile_store<REST_L>(tile, out.d_indirect_rest + (size_t)row0 * REST_L, nrows, lane);
+    if (sh_live) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        tile_store<REST_L>(tile, out.d_indirect_rest + (size_t)row0 * REST_L, nrows, lane);
+    } else {
+        float* dst = out.d_indirect_rest + (size_t)row0 * REST_L;
+        if (nrows == 64) {          // the wave's 64 rows are one 16-byte aligned run of 64 * 45 floats
+            float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+            for (int k = 0; k * 64 < 16 * REST_L; k++)
+                if (k * 64 + lane < 16 * REST_L) d4[k * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            for (int e = lane; e < nrows * REST_L; e += 64) dst[e] = 0.0f;
+        }
+    }
     if (!in_range) return;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) out.d_indirect_dc[3 * (size_t)idx + ch] = d_dc[ch];

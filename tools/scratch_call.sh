@@ -1,4 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/pgsr4; mkdir -p $O; cd $R
-MRGS_BENCH_TORCH_PROFILE=$O/torch_prof.txt timeout -k 10 400 python bench.py --workload C3full-pgsr --steps 40 --warmup 10 --no-cpu-baseline --no-secondary > $O/bench.json 2> $O/bench.err < /dev/null
-tail -1 $O/bench.json | cut -c1-200
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/feat1; mkdir -p $O; cd $R
+timeout -k 10 900 python -m pytest tests/test_shading.py tests/test_render_e2e.py tests/test_reference_render.py tests/test_full_size.py -x -q -m gpu > $O/tests.log 2>&1 < /dev/null; echo "pytest rc=$?"; tail -3 $O/tests.log
+timeout -k 10 900 bash tools/run_ab.sh feat1 C3full 300 20 2 cur= < /dev/null
+timeout -k 10 400 bash tools/prof_variants.sh feat1 C3full 30 "features" cur= < /dev/null
