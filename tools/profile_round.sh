@@ -52,6 +52,13 @@ if [ "$FULL" = "full" ]; then
   timeout 600 python bench.py --workload C3full-pgsr --steps 200 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_C3full-pgsr.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 mirror > $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
   timeout 300 python tools/trace_time.py 300000 800 primary >> $O/${TAG}_trace_time.json 2>> $O/bench_C2.err
+  # the prefilter's batched product per level (matrices warm), with the symmetric tiles and with the full matrices
+  for v in sym full; do
+    (cd /tmp; [ $v = full ] && export MRGS_NO_SYMMETRIC_SPMV=1; timeout -k 10 200 rocprofv3 --kernel-trace -f csv -d $O/spmv_$v -o t -- python3 $R/tools/spmv_time.py > $O/spmv_plan_$v.json 2> $O/spmv_$v.err < /dev/null)
+    f=$(find $O/spmv_$v -name "*kernel_trace.csv" | head -1)
+    [ -n "$f" ] && { echo "== $v"; python3 tools/spmv_time_reduce.py $f $O/spmv_plan_$v.json; } >> $O/${TAG}_spmv_levels.txt
+    rm -rf $O/spmv_$v
+  done
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 tail -1 $O/${TAG}_bench_C2.json | cut -c1-600
