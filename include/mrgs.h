@@ -293,6 +293,7 @@ int mrgs_csr_spmv3(int32_t nrows, const uint32_t* row_ptr, const void* col, int3
 /* Up to MRGS_SPMV_MAX_BATCH independent products of the kind above in ONE launch (`descs` is a host array): the levels of
  * EnvLight.build_mips each way. */
 #define MRGS_SPMV_MAX_BATCH 8
+#define MRGS_SPMV_MAX_PANEL 1024       /* patches of a tile's panel (image_rows form of MrgsSpmvDesc) */
 /* image_rows != NULL (ABI 8) = TILES OF ROWS OF ONE FUNDAMENTAL DOMAIN of the cube's symmetry group, as dense matrices.  The weight
  * of a filter is K(r, c) * area(c) / n(r) with K invariant under the 48 signed axis permutations g of the cube (K(g r, g c) = K(r, c);
  * the reference's texel solid angle, cubemap.cu:17-30, and with it the row sum are not -- they are per-texel factors), so the rows of the
@@ -320,6 +321,7 @@ typedef struct MrgsSpmvDesc {
     const uint32_t* panel_ptr;
     const uint16_t* panel_src;
     int32_t res, n_tiles;
+    int32_t max_panel, reserved;   /* the longest panel, in patches: 1 .. MRGS_SPMV_MAX_PANEL */
 } MrgsSpmvDesc;
 int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream);
 /* rows[g * 6 res^2 + t] = the texel ((face * res + y) * res + x) that the g-th of the cube's 48 symmetries (signed axis permutations,

@@ -70,7 +70,7 @@ class MrgsSpmvDesc(ctypes.Structure):
     _fields_ = [("nrows", c_int32), ("lanes_per_row", c_int32), ("col_bytes", c_int32), ("val_bytes", c_int32), ("row_ptr", c_void_p),
                 ("col", c_void_p), ("val", c_void_p), ("row_scale", c_void_p), ("x", c_void_p), ("y", c_void_p),
                 ("image_rows", c_void_p), ("pre_scale", c_void_p), ("tile_ptr", c_void_p), ("panel_ptr", c_void_p), ("panel_src", c_void_p),
-                ("res", c_int32), ("n_tiles", c_int32)]
+                ("res", c_int32), ("n_tiles", c_int32), ("max_panel", c_int32), ("reserved", c_int32)]
 
 
 class MrgsSurfelParams(ctypes.Structure):

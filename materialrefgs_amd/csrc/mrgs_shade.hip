@@ -1018,6 +1018,7 @@ static void cube_symmetry_table(uint64_t* tab)
 #define MRGS_SPMV_BATCH_THREADS 512
 #endif
 #define MRGS_SPMV_SYM_WAVES (MRGS_SPMV_BATCH_THREADS / 64)      // the waves of a workgroup split the panel
+static_assert(128 * MRGS_SPMV_SYM_WAVES >= MRGS_SPMV_MAX_PANEL, "a wave holds the patch ids of 128 steps");
 #define MRGS_SPMV_SYM_BROW 20        // floats per staged texel row: 16 columns + 4 of padding (the 16-byte writes of eight lanes then cover the 32 banks)
 #define MRGS_SPMV_SYM_LDS (MRGS_SPMV_SYM_WAVES * (16 * MRGS_SPMV_SYM_BROW * 4 + 1024))  // per wave: a staging buffer of 16 texels x 16 columns, a partial tile
 #ifndef MRGS_SPMV_SYM_DEPTH
@@ -1450,8 +1451,9 @@ int mrgs_csr_spmv3_batched(const MrgsSpmvDesc* descs, int32_t n, void* stream)
             // tiles of rows of one fundamental domain: a power-of-two face of 4 .. 128 texels (16-bit block indices), nrows = 6 res^2 texels
             int L = 0;
             while ((1 << L) < d.res) ++L;
+            // (a wave of the product keeps the patch ids of its 128 steps in two registers: panels of at most 128 x its workgroup's waves)
             if (d.res < 4 || d.res > 128 || (1 << L) != d.res || d.nrows != 6 * d.res * d.res || d.n_tiles < 1 || !d.pre_scale || !d.row_scale ||
-                !d.tile_ptr || !d.panel_ptr || !d.panel_src || ((uintptr_t)d.val & 7u))
+                !d.tile_ptr || !d.panel_ptr || !d.panel_src || ((uintptr_t)d.val & 7u) || d.max_panel < 1 || d.max_panel > MRGS_SPMV_MAX_PANEL)
                 return MRGS_E_BAD_ARG;
             S.fmt = 16;
             S.log2n = L; S.image_rows = d.image_rows; S.pre = d.pre_scale; S.tile_ptr = d.tile_ptr; S.panel_ptr = d.panel_ptr; S.panel_src = d.panel_src;
@@ -1505,9 +1507,12 @@ int mrgs_cubemap_mip_chain_backward(int32_t res0, int32_t n_levels, float* const
     if (res0 < 2 || n_levels < 1 || n_levels > MRGS_MAX_MIPS || !g || (res0 >> (n_levels - 1)) < 1) return MRGS_E_BAD_ARG;
     for (int k = 0; k < n_levels; ++k) if (!g[k]) return MRGS_E_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // One launch per level, coarse to fine (3 x 6.7 us for 128..16).  Measured and dropped: the levels up to 64 x 64 in ONE workgroup behind
-    // barriers (152 us: 24 576 texels x the cross-face tap arithmetic on one CU) and one launch in which every level-0 texel gathers down
-    // the pyramid (84 us: 21 tap set-ups per texel, 12.8 k instructions) -- the tap set-up, not the launches, is the cost.
+    // One launch per level, coarse to fine (3 x 6.6 us for 128..16).  Measured and dropped: the levels up to 64 x 64 in ONE workgroup behind
+    // barriers (152 us: 24 576 texels x the cross-face tap arithmetic on one CU); one launch in which every level-0 texel gathers down
+    // the pyramid (84 us: 21 tap set-ups per texel, 12.8 k instructions); and, round 5, ONE launch whose levels wait for each other on
+    // device counters (blocks of a level behind those of the coarser one in the grid, one lane spinning, release / acquire at agent
+    // scope between the levels: correct, bit-identical, also from two streams at once -- and 91 us: an agent-scope release or acquire
+    // writes back or invalidates the XCD's WHOLE L2, once per block, in the middle of a backward pass whose other kernels' data it holds).
     for (int k = n_levels - 2; k >= 0; --k) {
         const int N = res0 >> k, n = 6 * N * N;
         hipLaunchKernelGGL(cubemap_mip_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, N, g[k + 1], g[k]);

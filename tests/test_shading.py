@@ -696,3 +696,31 @@ def test_mip_chain_in_one_launch_equals_the_level_by_level_kernel(gpu_device, re
     torch.cuda.synchronize(gpu_device)
     for a, b in zip(outs, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,levels", [(128, 4), (64, 4), (32, 3), (16, 2), (8, 1)])
+def test_mip_backward_chain_in_one_launch_equals_the_level_by_level_kernel(gpu_device, res, levels):
+    """mrgs_cubemap_mip_chain_backward accumulates the very values mrgs_cubemap_mip_backward produces level by level, coarse to fine --
+    repeatedly, on two streams at once.  (The test was written for a one-launch form of the chain that waited between its levels on device
+    counters: it passed, and the launch took 91 us against 20 -- DESIGN section 9; the call is a launch per level again.)"""
+    import ctypes
+    from materialrefgs_amd import _lib
+    from materialrefgs_amd.shading import _mip_backward_accumulate
+    g = torch.Generator().manual_seed(res * 10 + levels)
+    gl = [torch.randn(6, res >> k, res >> k, 3, generator=g).to(gpu_device) for k in range(levels)]
+    ref = [t.clone() for t in gl]
+    for k in range(levels - 2, -1, -1):
+        _mip_backward_accumulate(ref[k + 1], ref[k])
+    side = torch.cuda.Stream(device=gpu_device)
+    for rep in range(6):
+        outs = [[t.clone() for t in gl] for _ in range(2)]
+        torch.cuda.synchronize(gpu_device)
+        for o, st in zip(outs, (torch.cuda.current_stream(gpu_device), side)):
+            ptrs = (ctypes.c_void_p * levels)(*[t.data_ptr() for t in o])
+            with torch.cuda.stream(st):
+                _lib.check(_lib.lib().mrgs_cubemap_mip_chain_backward(res, levels, ptrs, ctypes.c_void_p(st.cuda_stream)))
+        torch.cuda.synchronize(gpu_device)
+        for o in outs:
+            for a, b in zip(o, ref):
+                assert torch.equal(a, b), (rep, tuple(a.shape))
