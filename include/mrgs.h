@@ -110,9 +110,10 @@ typedef struct MrgsRasterInputs {
     uint32_t features_live; /* ABI 8 (was reserved, 0): 0 = every one of the S feature channels may be non-zero.  n in 1 .. S - 1: channels n .. S - 1
                                are PADDING (the caller keeps them zero -- e.g. rows of 9 channels padded to 12 floats so that they are 16-byte
                                pieces): the blend kernels leave them out of their per-entry arithmetic, their output maps are written as zeros,
-                               their columns of dL_dfeatures stay zero and the upstream gradient of those maps is not read.  Honoured by the
-                               instances whose rows are whole 16-byte pieces (S = 12 with n = 9: the "pgsr" flavour's rows); any other
-                               combination is treated as 0 -- the results are the same, only slower. */
+                               their columns of dL_dfeatures stay zero and the upstream gradient of those maps is not read.  Honoured for
+                               S = 12 with n = 9 and a 16-byte aligned tensor (the "pgsr" flavour's rows: the blend kernels stage eight channels
+                               as for S = 8 and take the ninth from the spare float of the surfel record, where preprocess copies it); any
+                               other combination is treated as 0 -- the results are the same, only slower. */
 } MrgsRasterInputs;
 #define MRGS_HINT_REUSE_ORDER 1u
 

@@ -385,7 +385,9 @@ __device__ __forceinline__ float mrgs_staged_feature(const StageBuf<SF>& sb, int
 // to 64 different cache lines, which is what it costs), and the blend reads four channels with one ds_read_b128.
 // (TAG: the instantiating kernel's live-channel count -- two kernels sharing one specialization of this function trip the host pass of
 //  clang over its device-only builtins: the second use reports a substitution failure)
-template <int S_MAX, int SF, bool FV, int TAG = 0>
+// ROW: floats per feature row of the FV layout (S_MAX unless the rows carry more than is staged: the "pgsr" rows of twelve floats, of which
+// eight are staged and the ninth rides in the surfel record)
+template <int S_MAX, int SF, bool FV, int TAG = 0, int ROW = S_MAX>
 __device__ __forceinline__ void mrgs_stage_async(StageBuf<SF>& dst, const float4* __restrict__ rec, const float* __restrict__ features,
                                                  int S, uint32_t gid, bool pred)
 {
@@ -398,7 +400,7 @@ __device__ __forceinline__ void mrgs_stage_async(StageBuf<SF>& dst, const float4
         __builtin_amdgcn_global_load_lds(src + 4, &dst.rec[4][0], 16, 0, 0);
         if (S_MAX > 0) {
             if (FV) {
-                const float4* fsrc = reinterpret_cast<const float4*>(features + (size_t)gid * S_MAX);
+                const float4* fsrc = reinterpret_cast<const float4*>(features + (size_t)gid * ROW);
                 float4* fdst = reinterpret_cast<float4*>(&dst.feat[0][0]);
 #pragma unroll
                 for (int q = 0; q < S_MAX / 4; q++) __builtin_amdgcn_global_load_lds(fsrc + q, fdst + q * MRGS_CHUNK, 16, 0, 0);

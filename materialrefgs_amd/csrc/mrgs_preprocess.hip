@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ colors_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ campos, int32_t* __restrict__ radii, float4* __restrict__ rec, float4* __restrict__ cull,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order, uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
-    uint8_t* __restrict__ clamped, uint32_t* __restrict__ clear_ptr, unsigned clear_words)
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ clear_ptr, unsigned clear_words,
+    const float* __restrict__ rec_extra, int rec_extra_stride)   // optional: a per-gaussian value for the record's spare float (the blend kernels' ninth channel)
 {
     // SPLIT (shs = DC [P,1,3], shs_rest = [P,M-1,3]): the rows of the two tensors are staged through a per-wave LDS tile in the unsplit
     // row layout; 180-byte rows cannot be fetched per lane with 16-byte loads the way the 192-byte rows of the unsplit tensor are
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         r4[1] = make_float4(T[4], T[5], T[6], T[7]);
         r4[2] = make_float4(T[8], cx, cy, opa);
         r4[3] = make_float4(nx, ny, nz, rgb[0]);
-        r4[4] = make_float4(rgb[1], rgb[2], pvz, 0.0f);
+        r4[4] = make_float4(rgb[1], rgb[2], pvz, rec_extra != nullptr ? rec_extra[(size_t)idx * rec_extra_stride] : 0.0f);
         cull[(size_t)idx * MRGS_CULL_F4] = cull_a;
         cull[(size_t)idx * MRGS_CULL_F4 + 1] = cull_b;
         cull[(size_t)idx * MRGS_CULL_F4 + 2] = cull_c;
@@ -480,12 +481,15 @@ void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
                                 hipStream_t stream)
 {
     const int tiles_x = (cfg.W + MRGS_BLOCK_X - 1) / MRGS_BLOCK_X, tiles_y = (cfg.H + MRGS_BLOCK_Y - 1) / MRGS_BLOCK_Y;
+    // rows of nine channels in twelve floats (MrgsRasterInputs::features_live): the ninth goes into the record's spare float, where the
+    // <8, true, 9> blend instances read it (the same condition as their dispatch in mrgs_launch_render_fwd / _bwd)
+    const float* rec_extra = (cfg.S == 12 && in.features != nullptr && in.features_live == 9u && ((uintptr_t)in.features & 15u) == 0) ? in.features + 8 : nullptr;
 #define LAUNCH_PRE(SPLIT_)                                                                                                              \
     hipLaunchKernelGGL(preprocess_fwd_kernel<SPLIT_>, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H, \
                        tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs, in.shs_rest,     \
                        in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec, g.cull,              \
                        g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters,                                       \
-                       (unsigned)(g.clear_bytes / sizeof(uint32_t)))
+                       (unsigned)(g.clear_bytes / sizeof(uint32_t)), rec_extra, 12)
     if (in.shs_rest != nullptr && in.colors_precomp == nullptr) LAUNCH_PRE(true);
     else LAUNCH_PRE(false);
 #undef LAUNCH_PRE

@@ -203,6 +203,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     const float* __restrict__ dL_dpixels_f, const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int gstride, int slots)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
+    constexpr bool XREC = S_LIVE > S_MAX;                       // the ninth live channel rides in the surfel record (see render_fwd_kernel)
+    static_assert(!XREC || (S_MAX == 8 && S_LIVE == 9 && FV), "one record channel: rows of twelve floats, eight staged");
+    constexpr int S_ROW = XREC ? 12 : S_MAX;                    // floats per feature row = width of the gradient row's feature block
+    constexpr int S_STAGED = S_LIVE < S_MAX ? S_LIVE : S_MAX;
+    constexpr int SFA = S_LIVE > SF ? S_LIVE : SF;
     constexpr int K = 16 + S_LIVE;  // gradient values of an entry
     constexpr int KT = K & ~3;      // ... through the transposing reduction (whole groups of four; the dL/dmean2D pair and a remainder go apart)
     __shared__ StageBuf<SF> stage[MRGS_BWD_STAGES];
@@ -251,9 +256,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     // Not the reference's summation order: the difference is rounding of the two sums (measured against the float64 evaluation of the
     // reference's formulas in tests/test_truth_leg.py and in every default bench line, next to the literal fp32 reading).
     float dL_dpixel[3] = {0.f, 0.f, 0.f};
-    float dL_dpixel_f[SF];
+    float dL_dpixel_f[SFA];
 #pragma unroll
-    for (int i = 0; i < SF; i++) dL_dpixel_f[i] = 0.f;
+    for (int i = 0; i < SFA; i++) dL_dpixel_f[i] = 0.f;
     float accum_dot = 0.f;
     float dL_dreg = 0.f, dL_ddepth = 0.f, dL_daccum = 0.f, dL_dnormal2D[3] = {0.f, 0.f, 0.f}, dL_dmedian_depth = 0.f;
     // A pixel nothing was blended into takes no part in any sum; its upstream gradients are not even read (they may
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         const bool cand0 = q0 & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
         exact_cur = __builtin_amdgcn_ballot_w64((q0 & 2u) != 0u);
-        mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
+        mrgs_stage_async<S_MAX, SF, FV, S_LIVE, S_ROW>(stage[c_top % MRGS_BWD_STAGES], rec, features, S, id0, cand0);
         if (cand0) stage[c_top % MRGS_BWD_STAGES].id[lane] = id0 * row_bytes;
     }
 
@@ -317,7 +322,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             exact_nxt = __builtin_amdgcn_ballot_w64(((idq1 >> 29) & 1u) != 0u);
             const uint32_t id1 = idq1 & 0x0FFFFFFFu;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
-            mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
+            mrgs_stage_async<S_MAX, SF, FV, S_LIVE, S_ROW>(stage[(c + 1) % MRGS_BWD_STAGES], rec, features, S, id1, cand1);
             if (cand1) stage[(c + 1) % MRGS_BWD_STAGES].id[lane] = id1 * row_bytes;
             idq1 = idq2;
             idq2 = 0;
@@ -372,11 +377,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             }
             if (S_MAX > 0) {
 #pragma unroll
-                for (int ch = 0; ch < S_LIVE; ch++) {
+                for (int ch = 0; ch < S_STAGED; ch++) {
                     // no branch on the runtime S (see the forward): slots beyond S read as 0 and have dL_dpixel_f = 0
                     const float f = (FV || ch < S) ? mrgs_staged_feature<FV>(sb, ch, j) : 0.0f;
                     q = fmaf(f, dL_dpixel_f[ch], q);
                     g[MRGS_G_FEAT + ch] = w * dL_dpixel_f[ch];
+                }
+                if (XREC) {
+                    q = fmaf(a1.w, dL_dpixel_f[S_MAX], q);
+                    g[MRGS_G_FEAT + S_MAX] = w * dL_dpixel_f[S_MAX];
                 }
             }
 #pragma unroll
@@ -441,7 +450,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             if (__builtin_amdgcn_ballot_w64(a2) != 0ull) {   // low-pass-filter branch: dL/dmean2D
                 const float dL_dG2 = a2 ? dL_dG : 0.0f;
                 const float dGf = -G * MRGS_FILTER_INV_SQUARE;
-                wave_reduce_atomic_add2(dL_dG2 * (dGf * h.dx), dL_dG2 * (dGf * h.dy), grad_rec, row_off + 4u * MRGS_G_M2(S_MAX), lane);
+                wave_reduce_atomic_add2(dL_dG2 * (dGf * h.dx), dL_dG2 * (dGf * h.dy), grad_rec, row_off + 4u * MRGS_G_M2(S_ROW), lane);
             }
         };
 
@@ -499,7 +508,7 @@ void mrgs_launch_render_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     if (cfg.S == 0) LAUNCH(gs, 0, false, 0);
     else if (cfg.S == 8 && fv_ok) LAUNCH(gs, 8, true, 8);
     else if (cfg.S <= 8) LAUNCH(gs, 8, false, 8);
-    else if (cfg.S == 12 && fv_ok && in.features_live == 9u) LAUNCH(gs, 12, true, 9);     // rows of 9 channels padded to three 16-byte pieces
+    else if (cfg.S == 12 && fv_ok && in.features_live == 9u) LAUNCH(gs, 8, true, 9);      // rows of 9 channels in 12 floats: 8 staged, the ninth in the surfel record
     else if (cfg.S == 12 && fv_ok) LAUNCH(gs, 12, true, 12);
     else if (cfg.S <= 12) LAUNCH(gs, 12, false, 12);
     else if (cfg.S == 24 && fv_ok) LAUNCH(gs, 24, true, 24);

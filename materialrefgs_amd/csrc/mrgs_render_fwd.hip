@@ -292,6 +292,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     uint32_t* __restrict__ work_hint, int slots, uint32_t* __restrict__ redo_list)
 {
     constexpr int SF = S_MAX > 0 ? S_MAX : 1;
+    // S_LIVE > S_MAX (the <8, true, 9> instance, "pgsr" rows of nine channels in twelve floats): eight channels are staged, the ninth rides
+    // in the spare float of the surfel record (preprocess copies it there) -- the entry costs two 16-byte pieces and two LDS reads of
+    // features, as with eight channels, instead of three
+    constexpr bool XREC = S_LIVE > S_MAX;
+    static_assert(!XREC || (S_MAX == 8 && S_LIVE == 9 && FV), "one record channel: rows of twelve floats, eight staged");
+    constexpr int S_ROW = XREC ? 12 : S_MAX;                    // floats per feature row = channel maps the instance serves
+    constexpr int S_STAGED = S_LIVE < S_MAX ? S_LIVE : S_MAX;   // channels accumulated out of the stage buffer
+    constexpr int SFA = S_LIVE > SF ? S_LIVE : SF;
+    using RecTail = typename std::conditional<XREC, float4, float2>::type;      // what an entry takes of the record's last 16 bytes
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
 
     const int lane = threadIdx.x;
@@ -330,9 +339,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     uint32_t work = 0;
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-    float F[SF];
+    float F[SFA];
 #pragma unroll
-    for (int i = 0; i < SF; i++) F[i] = 0.f;
+    for (int i = 0; i < SFA; i++) F[i] = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, distortion = 0.f, median_depth = 0.f;
     uint32_t last_contributor = 0, median_contributor = 0;
     const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
@@ -354,7 +363,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (2 * MRGS_CHUNK + lane < total) { id2 = plist[2 * MRGS_CHUNK + lane]; q2 = qm[2 * MRGS_CHUNK + lane]; }
         const bool cand0 = (q0 >> quad) & 1u;
         mask_cur = __builtin_amdgcn_ballot_w64(cand0);
-        mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[0], rec, features, S, id0, cand0);
+        mrgs_stage_async<S_MAX, SF, FV, S_LIVE, S_ROW>(stage[0], rec, features, S, id0, cand0);
     }
 
     for (int base = 0, c = 0; base < total; base += MRGS_CHUNK, c++) {
@@ -365,7 +374,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             // stage chunk c+1 (its ids and cull bits arrived during the previous iterations), prefetch those of chunk c+3
             const bool cand1 = (q1 >> quad) & 1u;
             mask_nxt = __builtin_amdgcn_ballot_w64(cand1);
-            mrgs_stage_async<S_MAX, SF, FV, S_LIVE>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
+            mrgs_stage_async<S_MAX, SF, FV, S_LIVE, S_ROW>(stage[(c + 1) % MRGS_FWD_STAGES], rec, features, S, id1, cand1);
             idn = id1;
             id1 = id2; q1 = q2;
             id2 = 0; q2 = 0;
@@ -407,7 +416,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         // MEDIAN: some live pixel of the block may still have T > 0.5 in this chunk (T only falls).  Dense blocks are past that after
         // their first chunk or two, and the entry body then carries neither the T > 0.5 test and its band nor the median selects.
         const bool median_live = (MRGS_BALLOT(T > 0.5f - MRGS_T2_EPS) & ~done) != 0ull;      // wave-uniform, per chunk
-        auto blend_entry = [&](const SurfelGeom& sg, const float4& a0, const float2& a1, int j) {
+        auto blend_entry = [&](const SurfelGeom& sg, const float4& a0, const RecTail& a1, int j) {
             Hit h;
             const uint64_t may_hit = mrgs_intersect_mask(sg, px, py, h) & ~done;
 #ifdef MRGS_WAVE_STATS
@@ -466,7 +475,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 // each LDS read and its wait into a basic block of its own (measured: +110 us for 8 channels); the slots
                 // beyond S accumulate whatever the stage buffer holds and are never written out
 #pragma unroll
-                for (int ch = 0; ch < S_LIVE; ch++) F[ch] = fmaf(mrgs_staged_feature<FV>(sb, ch, j), w, F[ch]);
+                for (int ch = 0; ch < S_STAGED; ch++) F[ch] = fmaf(mrgs_staged_feature<FV>(sb, ch, j), w, F[ch]);
+                if constexpr (XREC) F[S_MAX] = fmaf(a1.w, w, F[S_MAX]);       // (the record's tail arrives one entry ahead with the rest of it)
             }
             T = upd ? test_T : T;
             last_contributor = upd ? contributor : last_contributor;
@@ -479,13 +489,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             SurfelGeom sA, sB;
             sA.g0 = sb.rec[0][j]; sA.g1 = sb.rec[1][j]; sA.g2 = sb.rec[2][j];
             float4 tA0 = sb.rec[3][j], tB0;
-            float2 tA1 = *reinterpret_cast<const float2*>(&sb.rec[4][j]), tB1;
+            RecTail tA1 = *reinterpret_cast<const RecTail*>(&sb.rec[4][j]), tB1;
             while (true) {
                 m &= m - 1;
                 bool more = m != 0ull;
                 int jn = more ? __builtin_ctzll(m) : j;
                 sB.g0 = sb.rec[0][jn]; sB.g1 = sb.rec[1][jn]; sB.g2 = sb.rec[2][jn];
-                tB0 = sb.rec[3][jn]; tB1 = *reinterpret_cast<const float2*>(&sb.rec[4][jn]);
+                tB0 = sb.rec[3][jn]; tB1 = *reinterpret_cast<const RecTail*>(&sb.rec[4][jn]);
                 blend_entry(sA, tA0, tA1, j);
                 if (!more) break;
                 j = jn;
@@ -493,7 +503,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 more = m != 0ull;
                 jn = more ? __builtin_ctzll(m) : j;
                 sA.g0 = sb.rec[0][jn]; sA.g1 = sb.rec[1][jn]; sA.g2 = sb.rec[2][jn];
-                tA0 = sb.rec[3][jn]; tA1 = *reinterpret_cast<const float2*>(&sb.rec[4][jn]);
+                tA0 = sb.rec[3][jn]; tA1 = *reinterpret_cast<const RecTail*>(&sb.rec[4][jn]);
                 blend_entry(sB, tB0, tB1, j);
                 if (!more) break;
                 j = jn;
@@ -536,8 +546,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         out_color[pix + 2 * HW] = fmaf(T, bg[2], C2);
         if (S_MAX > 0) {
 #pragma unroll
-            for (int ch = 0; ch < S_MAX; ch++)
-                if (ch < S) out_feature[(size_t)ch * HW + pix] = ch < S_LIVE ? F[ch] : 0.0f;
+            for (int ch = 0; ch < S_ROW; ch++)
+                if (ch < S) out_feature[(size_t)ch * HW + pix] = ch < S_LIVE ? F[ch < SFA ? ch : 0] : 0.0f;
         }
         out_others[pix + 0 * HW] = Dp;
         out_others[pix + 1 * HW] = 1.0f - T;
@@ -567,7 +577,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         while (redo != 0ull) {
             const int p = __builtin_ctzll(redo);
             redo &= redo - 1;
-            mrgs_redo_pixel<S_MAX>(__builtin_amdgcn_readlane(pix, p), lane, q, q + MRGS_REDO_QCAP, ranges, point_list, qmask, cflag, S, W, H, tiles_x, rec, features,
+            mrgs_redo_pixel<S_ROW>(__builtin_amdgcn_readlane(pix, p), lane, q, q + MRGS_REDO_QCAP, ranges, point_list, qmask, cflag, S, W, H, tiles_x, rec, features,
                                    bg, final_T, n_contrib, out_color, out_feature, out_others);
             __builtin_amdgcn_wave_barrier();
         }
@@ -600,7 +610,7 @@ void mrgs_launch_render_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs&
     if (cfg.S == 0) LAUNCH(0, false, 0);
     else if (cfg.S == 8 && fv_ok) LAUNCH(8, true, 8);
     else if (cfg.S <= 8) LAUNCH(8, false, 8);
-    else if (cfg.S == 12 && fv_ok && in.features_live == 9u) LAUNCH(12, true, 9);      // rows of 9 channels padded to three 16-byte pieces
+    else if (cfg.S == 12 && fv_ok && in.features_live == 9u) LAUNCH(8, true, 9);       // rows of 9 channels in 12 floats: 8 staged, the ninth in the surfel record
     else if (cfg.S == 12 && fv_ok) LAUNCH(12, true, 12);
     else if (cfg.S <= 12) LAUNCH(12, false, 12);
     else if (cfg.S == 24 && fv_ok) LAUNCH(24, true, 24);

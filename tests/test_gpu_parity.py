@@ -559,8 +559,9 @@ def test_more_begun_renders_than_ticket_slots_in_one_box(gpu_device):
 @pytest.mark.gpu
 def test_padding_channels_left_out_of_the_blend(gpu_device):
     """MrgsRasterInputs::features_live (GaussianRasterizer.features_live): rows of nine channels padded to twelve floats -- the "pgsr" flavour's
-    eight material channels and plane distance -- rendered with the hint (the <12, 9> kernel instances: nine channels of arithmetic, 24 + 1
-    values through the gradient reductions) against the same rows rendered as twelve channels.  The forward is the same arithmetic per live
+    eight material channels and plane distance -- rendered with the hint (the <8, true, 9> kernel instances: eight channels staged as for S = 8, the
+    ninth carried in the spare float of the surfel record, 24 + 1 values through the gradient reductions) against the same rows rendered as
+    twelve channels.  The forward is the same arithmetic per live
     channel: bit-identical maps, the padding maps zero; the backward sums the ninth channel's gradient in another order: 2e-6 of the largest
     entry; the padding columns of dL_dfeatures stay zero and the gradient of the padding maps is not read (NaN there changes nothing)."""
     S, H, W = 12, 176, 144
