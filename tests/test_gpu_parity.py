@@ -45,7 +45,7 @@ def _map_ok(a, b, tol, absolute=False):
     return (d <= tol).reshape(-1, *d.shape[-2:]).all(0), float(d.max())
 
 
-def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, check_grads=True, pixel_allowance=0):
+def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp=None, bg=None, check_grads=True, pixel_allowance=0, features_live=0):
     """`pixel_allowance`: number of pixels that may sit outside the map tolerances.  Zero everywhere in the suite since round 4 (the
     kernels take the blend's decisions exactly); the parameter remains for developer builds that switch that off."""
     from oracle import raster_oracle as ro
@@ -53,7 +53,8 @@ def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp
     S = scene.features.shape[1]
     orc = ro.render_scene(scene, cam, sh_degree=sh_degree, scale_modifier=scale_modifier, colors_precomp=colors_precomp, bg=bg)
     hr = HipRender(scene, cam, dev, sh_degree=sh_degree, scale_modifier=scale_modifier,
-                   colors_precomp=None if colors_precomp is None else torch.as_tensor(colors_precomp), bg=None if bg is None else torch.as_tensor(bg))
+                   colors_precomp=None if colors_precomp is None else torch.as_tensor(colors_precomp), bg=None if bg is None else torch.as_tensor(bg),
+                   features_live=features_live)     # (features_live: the caller has zeroed the scene's padding channels; the oracle blends all of them)
     # ---- integer / geometry state: bit exact
     assert hr.num_rendered == orc.R
     np.testing.assert_array_equal(hr.radii.cpu().numpy(), orc.radii)
@@ -86,6 +87,11 @@ def compare_all(scene, cam, dev, sh_degree=3, scale_modifier=1.0, colors_precomp
     # ---- gradients
     if check_grads:
         g = upstream_grads(S, H, W)
+        if features_live:            # the padding maps have no consumer: their upstream gradient is zero (and not read by the kernels)
+            g = list(g)
+            g[1] = g[1].clone()
+            g[1][features_live:] = 0.0
+            g = tuple(g)
         gh = hr.backward(*g)
         go = orc.backward(*g)
         names = ["means3D", "means2D", "opacity", "scales", "rotations"] + (["features"] if S else []) + \
