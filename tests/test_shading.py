@@ -724,3 +724,36 @@ def test_mip_backward_chain_in_one_launch_equals_the_level_by_level_kernel(gpu_d
         for o in outs:
             for a, b in zip(o, ref):
                 assert torch.equal(a, b), (rep, tuple(a.shape))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_res,min_res", [(128, 16), (64, 16), (64, 8)])
+def test_build_mips_with_symmetric_tiles_equals_the_full_matrices(gpu_device, monkeypatch, max_res, min_res):
+    """EnvLight.build_mips end to end -- every prefiltered level and the gradient of the base texels -- with the long-row levels applied from
+    the dense tiles of one fundamental domain (the default) against the same chain on the full matrices (the MRGS_NO_SYMMETRIC_SPMV switch),
+    for the reference's default chain and two shorter ones."""
+    import materialrefgs_amd.shading as sh
+    g = torch.Generator().manual_seed(max_res + min_res)
+    base = torch.rand(6, max_res, max_res, 3, generator=g)
+    ups = None
+    res = {}
+    for mode in ("sym", "full"):
+        monkeypatch.setattr(sh, "_NO_SYM", mode == "full")
+        monkeypatch.setattr(sh.CubemapFilterOp, "_cache", {})
+        sh._SPMV_DESCS.clear()
+        env = sh.EnvLight(device=gpu_device, min_res=min_res, max_res=max_res, trainable=True)
+        with torch.no_grad():
+            env.base.copy_(base.to(gpu_device))
+        env.build_mips()
+        ops = list(sh.CubemapFilterOp._cache.values())
+        assert any(o.sym is not None for o in ops) == (mode == "sym")
+        spec = [m for m in env.specular]
+        if ups is None:
+            ups = [torch.randn(m.shape, generator=g).to(gpu_device) for m in spec]
+        torch.autograd.backward(spec, ups)
+        res[mode] = ([m.detach().clone() for m in spec], env.base.grad.detach().clone())
+    for a, b in zip(res["sym"][0], res["full"][0]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    ga, gb = res["sym"][1], res["full"][1]
+    assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    sh._SPMV_DESCS.clear()
