@@ -116,6 +116,9 @@ typedef struct MrgsRasterInputs {
                                other combination is treated as 0 -- the results are the same, only slower. */
 } MrgsRasterInputs;
 #define MRGS_HINT_REUSE_ORDER 1u
+#define MRGS_HINT_VISIBLE_BYTES 2u   /* ABI 8: `radii` of the forward calls points at P int32 FOLLOWED BY P bytes, and the forward also writes
+                                        radii[i] > 0 into byte i of the tail (every render function of the reference returns that mask as
+                                        "visibility_filter": a torch kernel per view otherwise) */
 
 /* Workspace sizes.  geom <-> geomBuffer (GeometryState, rasterizer_impl.cu:157-172), img <-> imgBuffer
  * (ImageState, :174-181), binning <-> binningBuffer (BinningState, :183-196; sized from num_rendered). */

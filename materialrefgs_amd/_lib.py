@@ -37,6 +37,7 @@ class MrgsRasterInputs(_Sized):
 
 
 MRGS_HINT_REUSE_ORDER = 1
+MRGS_HINT_VISIBLE_BYTES = 2
 
 
 class MrgsRasterGrads(_Sized):

@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ campos, int32_t* __restrict__ radii, float4* __restrict__ rec, float4* __restrict__ cull,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order, uint2* __restrict__ rect, uint32_t* __restrict__ tiles_touched,
     uint8_t* __restrict__ clamped, uint32_t* __restrict__ clear_ptr, unsigned clear_words,
-    const float* __restrict__ rec_extra, int rec_extra_stride)   // optional: a per-gaussian value for the record's spare float (the blend kernels' ninth channel)
+    const float* __restrict__ rec_extra, int rec_extra_stride,   // optional: a per-gaussian value for the record's spare float (the blend kernels' ninth channel)
+    uint8_t* __restrict__ visible)                                // optional: radii > 0 as a byte per gaussian (MRGS_HINT_VISIBLE_BYTES)
 {
     // SPLIT (shs = DC [P,1,3], shs_rest = [P,M-1,3]): the rows of the two tensors are staged through a per-wave LDS tile in the unsplit
     // row layout; 180-byte rows cannot be fetched per lane with 16-byte loads the way the 192-byte rows of the unsplit tensor are
@@ -471,6 +472,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         out_rect = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
     } while (0);
     radii[idx] = out_radius;
+    if (visible != nullptr) visible[idx] = out_radius > 0 ? (uint8_t)1 : (uint8_t)0;
     tiles_touched[idx] = out_tiles;
     depth_key[idx] = out_key;
     order[idx] = (uint32_t)idx;
@@ -484,12 +486,14 @@ void mrgs_launch_preprocess_fwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
     // rows of nine channels in twelve floats (MrgsRasterInputs::features_live): the ninth goes into the record's spare float, where the
     // <8, true, 9> blend instances read it (the same condition as their dispatch in mrgs_launch_render_fwd / _bwd)
     const float* rec_extra = (cfg.S == 12 && in.features != nullptr && in.features_live == 9u && ((uintptr_t)in.features & 15u) == 0) ? in.features + 8 : nullptr;
+    // MRGS_HINT_VISIBLE_BYTES: the caller's radii buffer is P int32 followed by P bytes, which take radii > 0 (the renderers' visibility_filter)
+    uint8_t* visible = (in.hint_flags & MRGS_HINT_VISIBLE_BYTES) != 0u ? reinterpret_cast<uint8_t*>(radii + cfg.P) : nullptr;
 #define LAUNCH_PRE(SPLIT_)                                                                                                              \
     hipLaunchKernelGGL(preprocess_fwd_kernel<SPLIT_>, dim3((cfg.P + 255) / 256), dim3(256), 0, stream, cfg.P, cfg.D, cfg.M, cfg.W, cfg.H, \
                        tiles_x, tiles_y, cfg.scale_modifier, in.means3D, in.scales, in.rotations, in.opacities, in.shs, in.shs_rest,     \
                        in.transMat_precomp, in.colors_precomp, in.viewmatrix, in.projmatrix, in.campos, radii, g.rec, g.cull,              \
                        g.depth_key[0], g.order[0], g.rect, g.tiles_touched, g.clamped, g.counters,                                       \
-                       (unsigned)(g.clear_bytes / sizeof(uint32_t)), rec_extra, 12)
+                       (unsigned)(g.clear_bytes / sizeof(uint32_t)), rec_extra, 12, visible)
     if (in.shs_rest != nullptr && in.colors_precomp == nullptr) LAUNCH_PRE(true);
     else LAUNCH_PRE(false);
 #undef LAUNCH_PRE

@@ -189,7 +189,7 @@ _LIVE = __import__("threading").local()
 
 
 def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest=None,
-                     bwd_grad_ws=None, work_hint=_RESOLVE):
+                     bwd_grad_ws=None, work_hint=_RESOLVE, extra_flags=0):
     """work_hint: the camera's hint buffer (or None) -- the BACKWARD passes the very tensor its forward used (the queue state, the tickets
     and the forward's item assignment live in it: a buffer resolved anew at backward time could be a fresh, zeroed one after
     reset_work_hints(), an eviction or an in-place pose change, and a prepared backward would then pull item 0 in every wave); the
@@ -209,7 +209,7 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
                            _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
                            _ptr(work_hint), _ptr(sh_rest),
-                           _ptr(bwd_grad_ws), _hint_flags(raster_settings, means3D.device, P) if means3D.is_cuda else 0,
+                           _ptr(bwd_grad_ws), (_hint_flags(raster_settings, means3D.device, P) if means3D.is_cuda else 0) | extra_flags,
                            int(getattr(_LIVE, "n", 0) or 0))
     return cfg, inp, work_hint
 
@@ -336,7 +336,7 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         with _lib.guard(dev):
             grad_ws = torch.empty((L.mrgs_grad_bytes(means3D.shape[0], S_),), dtype=torch.uint8, device=dev)
     cfg, inp, hint = _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp,
-                                      sh_rest, grad_ws)
+                                      sh_rest, grad_ws, extra_flags=_lib.MRGS_HINT_VISIBLE_BYTES)
     P, S = cfg.P, cfg.S
     with _lib.guard(dev):
         st = _stream(dev)
@@ -344,7 +344,10 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         feature = torch.empty((S, H, W), dtype=torch.float32, device=dev)
         others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        # radii [P] int32 and, right behind them, a byte per gaussian that takes radii > 0 (MRGS_HINT_VISIBLE_BYTES): one allocation
+        rbuf = torch.empty((5 * P,), dtype=torch.uint8, device=dev)
+        radii = rbuf[:4 * P].view(torch.int32)
+        _LIVE.visible = rbuf[4 * P:].view(torch.bool)
         geom = torch.empty((L.mrgs_geom_bytes(P, H, W),), dtype=torch.uint8, device=dev)
         img = torch.empty((L.mrgs_img_bytes(H, W),), dtype=torch.uint8, device=dev)
         R = ctypes.c_int64(0)
@@ -595,8 +598,14 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = empty
 
         _LIVE.n = int(getattr(self, "features_live", 0) or 0)      # (extension: feature channels n .. S - 1 are zero padding of the rows)
+        _LIVE.visible = None
         try:
-            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
-                                       raster_settings, shs_rest)
+            out = rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
+                                      raster_settings, shs_rest)
+            # extension: radii > 0 of this render as a bool tensor, written by the forward itself (every render function of the reference
+            # returns it as "visibility_filter"; `radii > 0` is a torch kernel per view otherwise)
+            self.visible = getattr(_LIVE, "visible", None)
+            return out
         finally:
             _LIVE.n = 0
+            _LIVE.visible = None

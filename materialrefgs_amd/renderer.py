@@ -346,6 +346,12 @@ def _black_like(bg_color):
     return t
 
 
+def _visibility(rasterizer, radii):
+    """radii > 0: the mask the rasterizer's forward wrote next to the radii (GaussianRasterizer.visible), else the torch comparison."""
+    vis = getattr(rasterizer, "visible", None)
+    return vis if vis is not None and vis.shape == radii.shape else radii > 0
+
+
 def _raster_settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
     return GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -465,7 +471,7 @@ def render_initial(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, o
     if srgb:
         final_image = linear_to_srgb(final_image)
     final_image = final_image + bg_color[:, None, None] * (1 - reg["render_alpha"])
-    out = {"render": final_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+    out = {"render": final_image, "viewspace_points": means2D, "visibility_filter": _visibility(rasterizer, radii), "radii": radii,
            "rend_alpha": reg["render_alpha"], "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"],
            "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
     if flag != "2dgs":
@@ -522,7 +528,7 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
                                                   return_normal_map=(not wo_render_img), rend_distance=rend_distance,
                                                   twin_alpha=(not wo_render_img))
     render_alpha, render_normal = reg["render_alpha"], reg["render_normal"]
-    geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
+    geo = {"viewspace_points": means2D, "visibility_filter": _visibility(rasterizer, radii), "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": render_normal, "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
     if rend_distance is not None:
         geo["rend_distance"] = rend_distance
@@ -609,7 +615,7 @@ def render_volume(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     final_image = full_color + bg_color[:, None, None] * (1 - render_alpha)
     out = {"render": final_image, "refl_strength_map": render_refl_strength, "diffuse_map": render_diffuse_color,
            "specular_map": render_specular_color, "base_color_map": render_ori_color, "roughness_map": render_roughness,
-           "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
+           "viewspace_points": means2D, "visibility_filter": _visibility(rasterizer, radii), "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"]}
     if indirect_on:
         out.update({"visibility": rendered_features[11:12], "indirect_light": rendered_features[12:15], "direct_light": rendered_features[15:18]})
@@ -879,7 +885,7 @@ def render_surfel2(indirect_renderer, env, viewpoint_camera, pc, pipe, bg_color,
     reg = compute_2dgs_normal_and_regularizations(allmap, viewpoint_camera, pipe, return_depth_normal=(not wo_render_img),
                                                   return_normal_map=True, rend_distance=rendered_features[-1:] if flag != "2dgs" else None)
     render_alpha = reg["render_alpha"]
-    geo = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": render_alpha,
+    geo = {"viewspace_points": means2D, "visibility_filter": _visibility(rasterizer, radii), "radii": radii, "rend_alpha": render_alpha,
            "rend_normal": reg["render_normal"], "rend_dist": reg["render_dist"], "surf_depth": reg["surf_depth"], "surf_normal": reg["surf_normal"],
            "blend_weight": blend_weight}
     if flag != "2dgs":

@@ -591,3 +591,20 @@ def test_padding_channels_left_out_of_the_blend(gpu_device):
         assert bool(np.isfinite(y).all()), name
         assert float(np.abs(x - y).max()) <= 2e-6 * max(1e-30, float(np.abs(x).max())), name
     assert float(np.abs(gb["features"][:, 9:]).max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_visibility_bytes_equal_radii_positive(gpu_device):
+    """MRGS_HINT_VISIBLE_BYTES: the forward writes radii > 0 as a byte per gaussian behind the radii (GaussianRasterizer.visible, what the
+    render functions return as "visibility_filter") -- equal to the torch comparison, culled gaussians included, for several counts."""
+    from materialrefgs_amd.rasterizer import GaussianRasterizer
+    from helpers import raster_settings
+    for P in (1, 63, 64, 65, 3000):
+        scene = make_shell_scene(P, S=0, seed=P, radius_px=5.0, image_size=96).to(gpu_device)
+        scene.means3D[::3] *= 40.0                      # a third of them far outside the frustum
+        rast = GaussianRasterizer(raster_settings(orbit_camera(2, 96, 80), gpu_device, 3, 1.0, None))
+        out = rast(means3D=scene.means3D, means2D=torch.zeros_like(scene.means3D), opacities=scene.opacities, shs=scene.shs,
+                   scales=scene.scales, rotations=scene.rotations)
+        radii = out[3]
+        assert rast.visible is not None and rast.visible.dtype == torch.bool and rast.visible.shape == radii.shape
+        assert torch.equal(rast.visible, radii > 0) and (P < 3 or (bool((radii > 0).any()) and bool((radii == 0).any())))
