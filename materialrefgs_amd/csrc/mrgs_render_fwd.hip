@@ -299,7 +299,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     static_assert(!XREC || (S_MAX == 8 && S_LIVE == 9 && FV), "one record channel: rows of twelve floats, eight staged");
     constexpr int S_ROW = XREC ? 12 : S_MAX;                    // floats per feature row = channel maps the instance serves
     constexpr int S_STAGED = S_LIVE < S_MAX ? S_LIVE : S_MAX;   // channels accumulated out of the stage buffer
-    constexpr int SFA = S_LIVE > SF ? S_LIVE : SF;
     using RecTail = typename std::conditional<XREC, float4, float2>::type;      // what an entry takes of the record's last 16 bytes
     __shared__ StageBuf<SF> stage[MRGS_FWD_STAGES];
 
@@ -339,9 +338,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     uint32_t work = 0;
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-    float F[SFA];
+    // (the record channel's accumulator is a variable of its own, not F[S_MAX]: as a ninth array element it shifted the pairs the compiler
+    //  forms for v_pk_fma_f32 by one -- (x, F0), (F1, F2) ... (F7, F8) -- and every blended entry paid eight register moves to line the
+    //  staged features up with them: +15 % VALU instructions per launch, +17 us, measured with the SQ counters, round 5)
+    float F[SF];
 #pragma unroll
-    for (int i = 0; i < SFA; i++) F[i] = 0.f;
+    for (int i = 0; i < SF; i++) F[i] = 0.f;
+    float Fx = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, distortion = 0.f, median_depth = 0.f;
     uint32_t last_contributor = 0, median_contributor = 0;
     const float mscale = MRGS_FAR_N / (MRGS_FAR_N - MRGS_NEAR_N);
@@ -476,7 +479,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 // beyond S accumulate whatever the stage buffer holds and are never written out
 #pragma unroll
                 for (int ch = 0; ch < S_STAGED; ch++) F[ch] = fmaf(mrgs_staged_feature<FV>(sb, ch, j), w, F[ch]);
-                if constexpr (XREC) F[S_MAX] = fmaf(a1.w, w, F[S_MAX]);       // (the record's tail arrives one entry ahead with the rest of it)
+                if constexpr (XREC) Fx = fmaf(a1.w, w, Fx);       // (the record's tail arrives one entry ahead with the rest of it)
             }
             T = upd ? test_T : T;
             last_contributor = upd ? contributor : last_contributor;
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
         if (S_MAX > 0) {
 #pragma unroll
             for (int ch = 0; ch < S_ROW; ch++)
-                if (ch < S) out_feature[(size_t)ch * HW + pix] = ch < S_LIVE ? F[ch < SFA ? ch : 0] : 0.0f;
+                if (ch < S) out_feature[(size_t)ch * HW + pix] = ch < S_STAGED ? F[ch < SF ? ch : 0] : (XREC && ch == S_MAX) ? Fx : 0.0f;
         }
         out_others[pix + 0 * HW] = Dp;
         out_others[pix + 1 * HW] = 1.0f - T;
