@@ -757,3 +757,28 @@ def test_build_mips_with_symmetric_tiles_equals_the_full_matrices(gpu_device, mo
     ga, gb = res["sym"][1], res["full"][1]
     assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
     sh._SPMV_DESCS.clear()
+
+
+def test_cube_symmetry_rows_form_the_octahedral_group():
+    """mrgs_cube_symmetry_rows (host code of the library): 48 distinct permutations of the texels, the identity first, closed under composition
+    and under inversion -- the symmetry group of the cube acting on the texel grid -- and consistent between resolutions (the image of a
+    texel of the 2N grid lies in the image of the N-grid texel that contains it)."""
+    from materialrefgs_amd import shading as sh
+    for N in (4, 8):
+        P = sh._cube_symmetry_rows(N).long().numpy()
+        n = 6 * N * N
+        assert P.shape == (48, n) and np.array_equal(P[0], np.arange(n))
+        keys = {p.tobytes(): g for g, p in enumerate(P)}
+        assert len(keys) == 48
+        inv = np.empty_like(P)
+        for g in range(48):
+            inv[g][P[g]] = np.arange(n)
+            assert inv[g].tobytes() in keys
+        for g1 in range(0, 48, 5):
+            for g2 in range(48):
+                assert P[g1][P[g2]].tobytes() in keys
+    P4, P8 = sh._cube_symmetry_rows(4).long().numpy(), sh._cube_symmetry_rows(8).long().numpy()
+    t = np.arange(6 * 64)
+    parent = lambda idx, N: ((idx // (N * N)) * (N // 2) + ((idx // N) % N) // 2) * (N // 2) + (idx % N) // 2      # texel of the N/2 grid that contains it
+    for g in range(48):
+        assert np.array_equal(parent(P8[g][t], 8), P4[g][parent(t, 8)])
