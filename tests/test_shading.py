@@ -782,3 +782,24 @@ def test_cube_symmetry_rows_form_the_octahedral_group():
     parent = lambda idx, N: ((idx // (N * N)) * (N // 2) + ((idx // N) % N) // 2) * (N // 2) + (idx % N) // 2      # texel of the N/2 grid that contains it
     for g in range(48):
         assert np.array_equal(parent(P8[g][t], 8), P4[g][parent(t, 8)])
+
+
+def test_symmetric_rows_refuse_a_panel_longer_than_the_kernel_takes(monkeypatch):
+    """CubemapFilterOp._symmetric returns None (the caller then keeps the full matrices) when a tile's panel has more patches than a
+    workgroup of the product kernel walks (MRGS_SPMV_MAX_PANEL): checked with the limit lowered under the 16 x 16 level's panels."""
+    from oracle import envfilter_oracle as eo
+    from materialrefgs_amd import shading as sh
+    N = 16
+    n = 6 * N * N
+    A = eo.diffuse_matrix(N)
+    r, c = np.nonzero(A)
+    ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))])).to(torch.int32)
+    col, val = torch.from_numpy(c).to(torch.int32), torch.from_numpy(A[r, c]).float()
+    op = object.__new__(sh.CubemapFilterOp)
+    op.res, op.nrows = N, n
+    area = torch.from_numpy(sh._pixel_area(N))
+    ones = torch.ones(n)
+    full = op._symmetric(ptr, col, val, 1.0 / area, area, ones)
+    assert full is not None and 1 < full.max_panel <= sh._SYM_MAX_PANEL
+    monkeypatch.setattr(sh, "_SYM_MAX_PANEL", full.max_panel - 1)
+    assert op._symmetric(ptr, col, val, 1.0 / area, area, ones) is None
