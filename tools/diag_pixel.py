@@ -93,6 +93,13 @@ def main():
             a0 = 1.0 / 255.0
             d = col_h[:, py, px] - col_o[:, py, px]
             print(f"    hip - oracle colour: {d}, final_T hip {hr.export('final_T')[0, py, px]:.9g} oracle {orc.final_T[0, py, px]:.9g}")
+            # the same pixel in the oracle's other two readings of the reference's arithmetic (tests/test_truth_leg.py): the literal fp32 one
+            # (no fused multiply-adds) and float64
+            for v in ("lit32", "f64"):
+                o2 = ro.render_scene(scene, cam, sh_degree=deg, variant=v)
+                print(f"    oracle variant {v}: final_T {o2.final_T[0, py, px]:.9g} n_contrib {o2.n_contrib[:, py, px]} colour {o2.color[:, py, px]}")
+                o2.close()
+            print(f"    oracle (default) colour {col_o[:, py, px]} hip colour {col_h[:, py, px]}")
             rgb = orc.rgb
             for (c, g, alpha, depth, r3, r2, T, tT, hit) in rows:
                 w = alpha * T
