@@ -188,3 +188,47 @@ def test_smooth_part_is_exact_derivative():
     rep = json.loads(out.stdout.strip().splitlines()[-1])
     assert rep["A_median"] < 1e-3 and rep["A_max"] < 0.08, rep
     assert rep["B_means3D"] < 1e-5 and rep["B_scales"] < 1e-5 and rep["B_rotations"] < 1e-5, rep
+
+
+def test_cull_ellipse_guard_keeps_the_ellipse_only_where_fp64_holds_it():
+    """The block cull's ellipse (mrgs_preprocess.hip, "Cull conic for the blend kernels"): Q = M^T diag(1, 1, -tau) M in fp64, centre from
+    det = Qxx Qyy - Qxy^2, value at the centre fp = Q11 + Qx1 xc + Qy1 yc.  For a surfel seen edge-on the ellipse is a needle, det is a
+    cancelled difference, and fp inherits the centre's error times |Qx1|, |Qy1| ~ 1e7: restated here in float64 against exact rational
+    arithmetic on needles derived from the surfel of soak case 1376 of seed 4242 (the pair the cull missed).  Above
+    the guard the kernel uses now (det > 1e-5 Qxx Qyy) fp is good to 1e-3 -- the block test has a 1 % margin; in the decades the old guard
+    (1e-9) let through it is off by more than the margin, up to several times its value."""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(0)
+    T0 = np.array([-6.87743378e+01, 1.76999893e+01, 7.81085327e+02, 4.75297050e+01, 3.06270523e+01, 1.01996545e+03, -1.87566429e-02,
+                   1.02796391e-01, 3.77971935e+00], dtype=np.float32).astype(np.float64)
+    tau = 10.787
+
+    def conic(T, exact):
+        t = [Fr(float(v)) for v in T] if exact else list(T)
+        tv = Fr(tau) if exact else tau
+        u, v, w = t[0:3], t[3:6], t[6:9]
+        cr = lambda a, b: [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+        c0, c1, c2 = cr(v, w), cr(w, u), cr(u, v)
+        q = lambda a, b: a[0] * b[0] + a[1] * b[1] - tv * a[2] * b[2]
+        Qxx, Qxy, Qyy, Qx1, Qy1, Q11 = q(c0, c0), q(c0, c1), q(c1, c1), q(c0, c2), q(c1, c2), q(c2, c2)
+        det = Qxx * Qyy - Qxy * Qxy
+        if not (Qxx > 0 and Qyy > 0 and det > 0):
+            return None
+        xc, yc = -(Qyy * Qx1 - Qxy * Qy1) / det, -(Qxx * Qy1 - Qxy * Qx1) / det
+        return float(det / (Qxx * Qyy)), float(Q11 + Qx1 * xc + Qy1 * yc)
+
+    worst_kept, worst_dropped = 0.0, 0.0
+    for _ in range(700):
+        T = T0.copy()
+        T[0:6] += rng.standard_normal(6) * np.abs(T[0:6]) * 10 ** rng.uniform(-7, -1)
+        T = T.astype(np.float32).astype(np.float64)
+        a, e = conic(T, False), conic(T, True)
+        if a is None or e is None or e[1] >= 0:
+            continue
+        err = abs(a[1] - e[1]) / abs(e[1])
+        if e[0] > 1e-5:
+            worst_kept = max(worst_kept, err)
+        elif e[0] > 1e-9:
+            worst_dropped = max(worst_dropped, err)
+    assert worst_kept <= 1e-3, worst_kept
+    assert worst_dropped > 0.1, worst_dropped          # (what the old guard kept: beyond the test's 1 % margin)
