@@ -6,5 +6,5 @@ cd $R
 mkdir -p gpurun_out/round
 timeout -k 10 1500 tools/profile_round.sh $TAG full > gpurun_out/${TAG}_round.log 2>&1
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/round/${TAG}_gputests.log 2>&1; tail -3 gpurun_out/round/${TAG}_gputests.log
-timeout -k 10 1400 tools/soak_round.sh $TAG 2000 600
+timeout -k 10 2200 tools/soak_round.sh $TAG 2000 600
 tail -2 gpurun_out/${TAG}_round.log | cut -c1-300
