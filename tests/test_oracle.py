@@ -232,3 +232,31 @@ def test_cull_ellipse_guard_keeps_the_ellipse_only_where_fp64_holds_it():
             worst_dropped = max(worst_dropped, err)
     assert worst_kept <= 1e-3, worst_kept
     assert worst_dropped > 0.1, worst_dropped          # (what the old guard kept: beyond the test's 1 % margin)
+
+
+def test_block_cull_model_is_sound_on_the_needles_of_the_scene_that_found_the_miss():
+    """tools/cull_model.py -- the cull record of preprocess_fwd and the block test of the blend kernels restated in numpy, checked against the
+    blend's own alpha in float64 for every (needle surfel, 8 x 8 block) pair -- on soak case 1376 of seed 4242: with the guard the kernel
+    had (det > 1e-9 Qxx Qyy) it reproduces the GPU's miss, the same surfel, block and lower bound (1.69 for an exact 0.998); with the guard
+    it has now (1e-5) no block that a needle reaches is culled."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cull_model as cm
+    from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera
+    rng = np.random.default_rng(4242)
+    for i in range(1377):
+        P = int(rng.choice([1, 7, 63, 64, 65, 500, 3000, 12000, 40000]))
+        S = int(rng.choice([0, 1, 3, 4, 8, 11, 12, 24]))
+        H, W = int(rng.integers(17, 420)), int(rng.integers(17, 420))
+        deg = int(rng.integers(0, 4))
+        rpx = float(rng.choice([1.5, 4.0, 7.0, 15.0, 40.0]))
+        view = int(rng.integers(0, 8))
+        scene_seed = int(rng.integers(1 << 30))
+    scene = make_shell_scene(P, S=S, seed=scene_seed, radius_px=rpx, image_size=max(H, W))
+    cam = orbit_camera(view, H, W)
+    old = cm.check_scene(scene, cam, 1e-9, 1e-6)                      # (the needles flat enough to matter: quick)
+    assert [(m["surfel"], m["block"]) for m in old["misses"]] == [(28209, (32, 28))] and 1.6 < old["misses"][0]["g"] < 1.8
+    assert 1.009 < old["misses"][0]["alpha255"] < 1.010
+    new = cm.check_scene(scene, cam, 1e-5, 1e-3)
+    assert new["reach"] > 3000 and not new["misses"]
