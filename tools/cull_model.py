@@ -103,17 +103,20 @@ def alpha_block(T, opa, mean2d, x0, y0):
     return np.where(ok, alpha, 0.0)
 
 
-def check_scene(scene, cam, guard, ratio_max, sh_degree=0):
+def check_scene(scene, cam, guard, ratio_max, sh_degree=0, sample=0, rng=None):
+    """sample: also examine that many randomly chosen visible surfels that are NOT needles (ordinary, huge, off-image ellipses)."""
     from oracle import raster_oracle as ro
     o = ro.render_scene(scene, cam, sh_degree=sh_degree)
     H, W = cam.image_height, cam.image_width
     T, m2, no, radii = o.transMat, o.means2D, o.normal_opacity, o.radii
     stats = dict(needles=0, kept_ellipse=0, blocks=0, reach=0, misses=[])
     vis = np.nonzero(radii > 0)[0]
-    # needles only: the ratio from the fp64 conic, vectorised pre-filter with tau of each surfel
+    extra = set((rng or np.random.default_rng(0)).choice(vis, size=min(sample, len(vis)), replace=False).tolist()) if sample and len(vis) else set()
     for g in vis:
         rec, info = cull_record(T[g], no[g][3], m2[g], guard)
-        if info is None or info[0] is None or not (info[0] < ratio_max):
+        if info is None or info[0] is None:
+            continue
+        if not (info[0] < ratio_max) and int(g) not in extra:
             continue
         stats["needles"] += 1
         stats["kept_ellipse"] += int(rec[0][2] != 0)
@@ -142,6 +145,7 @@ def main():
     ap.add_argument("seed", type=int, nargs="?", default=0)
     ap.add_argument("--guard", type=float, default=1e-5)
     ap.add_argument("--ratio", type=float, default=1e-3)
+    ap.add_argument("--sample", type=int, default=0, help="per scene, also this many random surfels that are not needles")
     a = ap.parse_args()
     from materialrefgs_amd.synthetic import make_shell_scene, orbit_camera
     rng = np.random.default_rng(a.seed)
@@ -151,7 +155,7 @@ def main():
         H, W = int(rng.integers(120, 420)), int(rng.integers(120, 420))
         rpx = float(rng.choice([15.0, 40.0]))
         view, sseed = int(rng.integers(0, 8)), int(rng.integers(1 << 30))
-        st = check_scene(make_shell_scene(P, S=0, seed=sseed, radius_px=rpx, image_size=max(H, W)), orbit_camera(view, H, W), a.guard, a.ratio)
+        st = check_scene(make_shell_scene(P, S=0, seed=sseed, radius_px=rpx, image_size=max(H, W)), orbit_camera(view, H, W), a.guard, a.ratio, sample=a.sample, rng=rng)
         for k in ("needles", "kept_ellipse", "blocks", "reach"):
             tot[k] += st[k]
         tot["misses"] += len(st["misses"])
