@@ -181,10 +181,13 @@ def main():
     scene_kw.update(SCENE_KW.get(args.workload, {}))
     scene_cpu = make_shell_scene(P, S=S, seed=0, image_size=max(H, W), **scene_kw)
     scene = scene_cpu.to(dev)
-    # Eight orbit cameras, or fewer when the warm-up is too short to visit them all: a training run revisits every camera thousands of
-    # times, so the timed steps are steady-state visits (per-camera work hints in place); what a FIRST visit costs is measured apart
-    # and reported as `cold_ms_per_step`.  MRGS_BENCH_VIEWS overrides (developer A/B).
-    n_views = int(os.environ.get("MRGS_BENCH_VIEWS", "0")) or min(8, max(1, args.warmup) * world)
+    # Eight orbit cameras, or fewer when the warm-up is too short to visit each of them TWICE: the timed steps are then steady-state
+    # visits -- a camera's second visit still launches the ordering kernel (the first visit has no measured work to order by), from the
+    # third on the queues are reused (rasterizer._hint_flags).  With the driver's --warmup 5 that is two cameras; round 5 cycled five
+    # and had every camera's second visit inside its 20 timed steps.  What a FIRST visit costs (every camera once per training run and
+    # again after each densification: the normal case of the reference's first 25 000-30 000 iterations, arguments/__init__.py:159-162)
+    # is measured apart and reported as `cold_ms_per_step`.  MRGS_BENCH_VIEWS overrides (developer A/B).
+    n_views = int(os.environ.get("MRGS_BENCH_VIEWS", "0")) or min(8, max(1, args.warmup // 2) * world)
     cams = [orbit_camera(v, H, W, n_views=8) for v in range(n_views)]
     settings = []
     for cam in cams:
@@ -277,7 +280,7 @@ def main():
             parts.setdefault(name, []).append((e0, e1))
         return done
 
-    def step_surfel_body(i):
+    def surfel_forward(i):
         view = (i * world + rank) % len(settings)
         state["campos"] = cams_dev[view].camera_center
         for t_ in surfel_params:
@@ -291,12 +294,13 @@ def main():
         else:
             out = render_surfel(cams_dev[view], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect), flag=flavour)
         done()
+        return view, out
+
+    def surfel_backward(view, out):
+        """Loss (or the fixed upstream gradients) and the backward pass; with world > 1 its hooks start the early all-gathers."""
         if use_loss:
             loss, _tb = losses.calculate_loss(gt_cams[view], pc, out, loss_opt, 5000, gt_cams[view].image_weight, None)
             loss.backward()
-            if world > 1:
-                reduce_surfel(view)
-            optimizer.step()
             return
         # the maps calculate_loss consumes (utils/loss_utils.py:147-152,166), with fixed upstream gradients
         outs = [out["render"], out["rend_alpha"], out["rend_normal"], out["rend_dist"], out["surf_depth"], out["surf_normal"]]
@@ -305,55 +309,83 @@ def main():
         done = mark("backward_total")
         torch.autograd.backward(outs, state["g"])
         done()
+
+    def surfel_exchange_and_update(view):
+        """What couples the ranks and what changes state: the gradient exchange and the optimizer step.  NEVER inside a deferred_count
+        box: a workspace overflow surfaces at box.finish(), and by then a rank must not have joined a collective with the empty
+        render's zero gradients, nor stepped Adam on them."""
         if world > 1:
             reduce_surfel(view)
+        if use_loss:
+            optimizer.step()
 
     _PHASES = [] if os.environ.get("MRGS_BENCH_STEP_TIMES") else None
     _SYNC_COUNT = bool(os.environ.get("MRGS_BENCH_SYNC_COUNT"))     # developer A/B: every forward waits for its own pair count (rounds 1-4)
 
-    def step(i):
-        """One view, forward and backward, inside ONE rasterizer.deferred_count() box: the view's pair count -- which the GPU produces only
-        when it gets to this view's tile scan, i.e. after the previous view's backward -- is collected AFTER the backward has been queued.
-        Rounds 3-4 collected it at the end of the forward: the host then queued the backward's ~25 nodes (0.33 ms) while the GPU ran the
-        rest of the forward (0.28 ms) and the GPU idled whenever the host was the slower of the two -- identical code ran 1 005 ... 1 070
-        views/s with the host's share of the step.  An overflow of the guessed workspace (its render is the EMPTY render, its gradients
-        zeros: include/mrgs.h) surfaces here and the view is done again, exactly sized; the loop INTEGRATION.md section 4d shows."""
-        if _SYNC_COUNT:
-            step_body(i)
-            state["R"] = rasterizer_mod.LAST_NUM_RENDERED
-            return
-        box = rasterizer_mod.deferred_count()
-        with box:
-            step_body(i)
-        try:
-            box.finish()
-        except rasterizer_mod.RasterWorkspaceOverflow:
-            step_body(i)
-        state["R"] = rasterizer_mod.LAST_NUM_RENDERED
-
-    def step_body(i):
-        if surfel_mode:
-            return step_surfel_body(i)
+    def raster_forward(i):
         view = (i * world + rank) % len(settings)
         state["campos"] = settings[view].campos
         for t in list(params.values()) + [means2D]:
             t.grad = None
-        ta = time.perf_counter()
         rast = GaussianRasterizer(settings[view])
-        contrib, color, feature, radii, allmap = rast(
-            means3D=params["means3D"], means2D=means2D, opacities=params["opacity"], shs=params["sh"],
-            features=params.get("features"), scales=params["scales"], rotations=params["rotations"])
-        tb = time.perf_counter()
+        return view, rast(means3D=params["means3D"], means2D=means2D, opacities=params["opacity"], shs=params["sh"],
+                          features=params.get("features"), scales=params["scales"], rotations=params["rotations"])
+
+    def raster_backward(view, res):
+        contrib, color, feature, radii, allmap = res
         outs, grads = [color, allmap], [g_color, g_others]
         if S > 0:
             outs.append(feature)
             grads.append(g_feat)
         torch.autograd.backward(outs, grads)
-        tc = time.perf_counter()
-        if _PHASES is not None:
-            _PHASES.append((ta, tb, tc))
+
+    def raster_exchange(view):
         if world > 1:
             state["reduced"] = reducer.reduce([params[k].grad for k in params] + [means2D.grad], params["means3D"], settings[view].campos, 3)
+
+    forward_fn, backward_fn, exchange_fn = (surfel_forward, surfel_backward, surfel_exchange_and_update) if surfel_mode else \
+        (raster_forward, raster_backward, raster_exchange)
+
+    def step(i):
+        """One view, forward and backward, then the exchange and the optimizer step.
+        ONE rank: forward AND backward inside ONE rasterizer.deferred_count() box -- the view's pair count, which the GPU produces only
+        when it gets to this view's tile scan, i.e. after the previous view's backward, is collected AFTER the backward has been queued.
+        (Rounds 3-4 collected it at the end of the forward: the host then queued the backward's ~25 nodes (0.33 ms) while the GPU ran the
+        rest of the forward (0.28 ms) and the GPU idled whenever the host was the slower of the two.)  An overflow of the guessed
+        workspace (its render is the EMPTY render, its gradients zeros: include/mrgs.h) surfaces at box.finish(); the view is then done
+        again, exactly sized -- before anything was exchanged or stepped.
+        SEVERAL ranks: the backward's hooks start collectives (the early all-gathers of the SH factors), which every rank must enter
+        exactly once per step.  The count is therefore collected between forward and backward -- an overflowing rank renders its forward
+        again ALONE (no collective is inside a forward), then all ranks run backward + exchange in step.  That costs the deferral's gain
+        (<= 6 % on a slow host) where the exchange is exposed anyway, and keeps the rank sequence matched by construction."""
+        ta = time.perf_counter()
+        if _SYNC_COUNT:
+            view, res = forward_fn(i)
+            backward_fn(view, res)
+        elif world > 1:
+            box = rasterizer_mod.deferred_count()
+            with box:
+                view, res = forward_fn(i)
+            try:
+                box.finish()
+            except rasterizer_mod.RasterWorkspaceOverflow:
+                view, res = forward_fn(i)
+            backward_fn(view, res)
+        else:
+            box = rasterizer_mod.deferred_count()
+            with box:
+                view, res = forward_fn(i)
+                tb = time.perf_counter()
+                backward_fn(view, res)
+            try:
+                box.finish()
+            except rasterizer_mod.RasterWorkspaceOverflow:
+                view, res = forward_fn(i)
+                backward_fn(view, res)
+            if _PHASES is not None:
+                _PHASES.append((ta, tb, time.perf_counter()))
+        exchange_fn(view)
+        state["R"] = rasterizer_mod.LAST_NUM_RENDERED
 
     def fence():
         if world > 1:
@@ -704,7 +736,10 @@ def main():
             # Both rasterizers get the SAME per-gaussian inputs: the product's own fp32 activations / feature rows (captured from inside
             # render_surfel).  Evaluated in float64 on the CPU they differ from the fp32 kernel's in the last bit, and one ulp of an
             # opacity moves a handful of the image's 640 000 pixels across the alpha = 1/255 and T = 1e-4 tests -- a comparison of
-            # inputs, not of renderers.  The per-gaussian glue has its own parity tests (tests/test_shading.py, test_reference_render.py).
+            # inputs, not of renderers.  The gradient that arrives at those inputs is then pulled back through the checker's float64
+            # glue to the raw leaves, and the gradient of the prefiltered levels through the float64 prefilter operators to the texels
+            # (oracle/render_oracle.surfel_leaf_gradients): EVERY leaf of the headline workload is compared, xyz and viewspace_points
+            # (what densification reads, backward.cu:665-668), the raw material parameters and env.base included.
             stash, glue = {}, renderer_mod.surfel_features
             def capturing(pc_, campos_, **kw):
                 o = glue(pc_, campos_, **kw)
@@ -720,34 +755,42 @@ def main():
             keys = ["render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal"]
             torch.autograd.backward([out_h[k] for k in keys], state["g"])
             torch.cuda.synchronize(dev)
-            mips_cpu = [m.detach().cpu().double() for m in env.specular]
-            names11 = surfel_names[:11]
-            pc_o = SurfelModel(*[t_.detach().cpu().double().requires_grad_(True) for t_ in surfel_params[:6]],
-                               **{n: t_.detach().cpu().double().requires_grad_(True) for n, t_ in zip(names11[6:], surfel_params[6:11])})
-            inter_names = ["opacities", "scales", "rotations", "features"]
-            inter_o = [t_.detach().cpu().double().requires_grad_(True) for t_ in stash["o"]]
-            t = time.perf_counter()
             R_hip = int(rasterizer_mod.LAST_NUM_RENDERED)
-            out_o = render_oracle.render_surfel_oracle(cam0, pc_o, None, None, pipe, bg_color.cpu(), srgb=False, mips=mips_cpu, raster_inputs=tuple(inter_o))
-            torch.autograd.backward([out_o[k] for k in keys], [g_.detach().cpu().double() for g_ in state["g"]])
-            cpu_s = time.perf_counter() - t
+            # (the two prefilter levels above 32^2 are applied blocked in float64 on the GPU, as a calculator -- 98 304^2 weights do not
+            #  fit a host; they are outside the CPU figure, as is the glue)
+            # (shaded with the product's own levels on both sides; the prefilter is compared apart, `env_level_*`: at roughness 0.08 the
+            #  reference's fp32 filter weights are ill-conditioned and levels built in fp32 and in float64 differ by per cents)
+            levels_h = [m_.detach().cpu().double().numpy() for m_ in env.specular]
+            out_o, g_o, info = render_oracle.surfel_leaf_gradients(cam0, surfel_params[:11], env.base, stash["o"], keys, state["g"], pipe, bg_color,
+                                                                   env_min_res=env.min_res, mips_device=dev, shade_levels=levels_h, literal32_prefilter=True)
+            cpu_s = info["raster_shading_seconds"]
             out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "views/s", "cores": ro.num_threads(), "kind": "port",
                                    "sample": f"1 view fwd+bwd of the same workload ({args.workload}, view 0) through oracle/render_oracle.py: oracle/mrgs_oracle.c "
                                              f"rasterizer (OpenMP) + torch float64 map post-processing, split-sum shading and compositing; per-gaussian glue "
                                              f"and environment prefilter excluded ({cpu_s:.1f} s)"}
-            errs, maps = {}, {}
-            pairs = [(n, th.grad, to.grad) for n, th, to in zip(inter_names, stash["o"], inter_o)]
-            pairs += [(n, surfel_params[surfel_names.index(n)].grad, getattr(pc_o, "_" + n).grad) for n in ("features_dc", "features_rest")]
-            for n, gh_, go_ in pairs:
-                a, b = gh_.detach().cpu().double().numpy(), go_.numpy()
-                errs[n] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+            hip = {n: t_.grad.detach().cpu().numpy() for n, t_ in zip(render_oracle.LEAF_NAMES, surfel_params[:11])}
+            hip["env_base"] = env.base.grad.detach().cpu().numpy()
+            hip["viewspace_points"] = out_h["viewspace_points"].grad.detach().cpu().numpy()
+            for n, t_ in zip(render_oracle.RASTER_INPUT_NAMES, stash["o"]):
+                hip[n] = t_.grad.detach().cpu().numpy()
+            names = list(render_oracle.LEAF_NAMES) + ["env_base", "viewspace_points"] + list(render_oracle.RASTER_INPUT_NAMES)
+            rows, ok = render_oracle.leaf_gradient_report(hip, g_o, names, bar=1e-4)
+            maps = {}
             for k in keys + ["specular_map", "diffuse_map", "roughness_map", "base_color_map", "refl_strength_map"]:
                 a, b = out_h[k].detach().cpu().double().numpy(), out_o[k].detach().numpy()
                 maps[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-            out["grad_max_rel_err"] = round(max(errs.values()), 8)
-            out["grad_rel_err"] = {k: float(f"{v:.3e}") for k, v in errs.items()}
-            out["grad_rel_err_note"] = ("gradients w.r.t. the rasterizer's per-gaussian inputs (activated opacity / scale / rotation, the 8 material "
-                                        "channels) and the colour SH, through rasterizer + maps + shading + compositing, identical fp32 inputs on both sides")
+            lrows, lok = render_oracle.level_report(levels_h, info["levels"], info["levels_lit32"])
+            out["env_level_rel_err"] = {f"{r_['res']}^2": (float(f"{r_['err']:.3e}") if r_["rule"] == "bar" else
+                                                         f"{r_['err']:.3e} {r_['rule']} (fp32 filter weights {r_['lit32_err']:.2e})") for r_ in lrows}
+            ok = ok and lok
+            out["grad_max_rel_err"] = round(max(r_["err"] for r_ in rows.values()), 8)
+            out["grad_rel_err"] = {k: float(f"{v['err']:.3e}") for k, v in rows.items()}
+            out["grad_rule"] = {k: (v["rule"] if "lit32_err" not in v else f"{v['rule']} (fp32 torch glue {v['lit32_err']:.2e})") for k, v in rows.items()
+                                if v["rule"] != "bar"}
+            out["grad_all_leaves_within_1e-4_or_truth_leg"] = bool(ok)
+            out["grad_rel_err_note"] = ("every leaf of render_surfel (raw xyz / scaling / rotation / opacity / material parameters, both SH families, "
+                                        "env_base) + viewspace_points + the rasterizer's per-gaussian inputs, through glue + rasterizer + maps + prefilter "
+                                        "+ shading + compositing; max-norm relative to the tensor's largest element; identical fp32 rasterizer inputs on both sides")
             out["map_rel_err"] = {k: float(f"{v:.3e}") for k, v in maps.items()}
             # two maps are ill-conditioned functions of what the rasterizer blends, in the reference's formulas as much as here: rend_dist
             # (m^2 A + M2 - 2 m M1, forward.cu:412: O(1) terms cancel to a value of order 1e-5; the tests hold it to an ABSOLUTE 5e-6) and

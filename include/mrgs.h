@@ -681,16 +681,24 @@ const char* mrgs_version(void);
  * ABI 7. */
 int mrgs_side_stream_fork(void* main_stream, void** side_stream);
 int mrgs_side_stream_join(void* main_stream);
-/* fork from the point of the caller's stream where the most recent rasterizer forward of this device launched its blend kernel (the
- * library records that point once this has been asked for; before the first such forward: a plain fork): what is queued on the side
- * stream then runs beside the forward blend -- whose duration is the lifetime of a few long waves and which leaves issue slots and memory
- * bandwidth idle -- instead of beside the bandwidth-bound kernels in front of it.  Only for work whose inputs were final before that
- * point (the environment prefilter: its input is the parameter the last optimizer step wrote). */
+/* fork from the point of `main_stream` where a rasterizer forward launched its blend kernel: what is queued on the side stream then runs
+ * beside the forward blend -- whose duration is the lifetime of a few long waves and which leaves issue slots and memory bandwidth idle --
+ * instead of beside the bandwidth-bound kernels in front of it.  The point is a ONE-SHOT mark (ABI 9):
+ *   mrgs_side_stream_arm_blend_mark(main_stream)   the caller owes side work and wants it forked from the NEXT forward's blend on this
+ *                                                  stream; forgets any older mark.  Call it where the side work's inputs are final and
+ *                                                  its buffers are allocated (EnvLight.build_mips does, after the optimizer step);
+ *   the next mrgs_rasterize_forward* on that stream records the mark in front of its blend kernel;
+ *   mrgs_side_stream_fork_at_blend(main_stream, &side) consumes it.  Without a mark recorded on `main_stream` since the arming (no forward
+ *                                                  came, or it ran on another stream) this is a plain fork; a join drops an unconsumed mark.
+ * Contract of the caller: every buffer the side work reads or writes was allocated BEFORE the arming call (a caching allocator may hand
+ * out, after the forward, memory whose last reader is the very blend kernel the side work runs beside), and the side work's inputs are not
+ * written on `main_stream` between the arming and the join. */
+int mrgs_side_stream_arm_blend_mark(void* main_stream);
 int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream);
 
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 8
+#define MRGS_ABI_VERSION 9
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

@@ -203,6 +203,7 @@ SYMBOLS = {
     "mrgs_side_stream_fork": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "mrgs_side_stream_join": (ctypes.c_int, [c_void_p]),
     "mrgs_side_stream_fork_at_blend": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "mrgs_side_stream_arm_blend_mark": (ctypes.c_int, [c_void_p]),
     "mrgs_compact_ws_bytes": (c_size_t, [c_int64]),
     "mrgs_compact_count": (ctypes.c_int, [c_int64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mrgs_compact_rows": (ctypes.c_int, [c_int64, c_void_p, c_void_p, ctypes.POINTER(MrgsCompactTensor), c_int32, c_void_p]),
@@ -227,7 +228,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 8   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 9   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

@@ -649,7 +649,11 @@ struct SideStream {
     hipEvent_t ev[MRGS_SIDE_EVENTS] = {};
     unsigned next = 0;
     hipEvent_t pre_blend = nullptr;     // recorded on the rasterizer's stream right before its forward blend (once somebody has asked for it)
+    // The mark is ONE-SHOT: armed by mrgs_side_stream_arm_blend_mark (whoever owes side work says so BEFORE the forward it wants to fork
+    // from), recorded by the next forward on `armed_on`, consumed by the first fork_at_blend, dropped by a join.  A mark of an earlier
+    // iteration can therefore never order side work (it would not cover what the caller's stream did since, e.g. an optimizer step).
     bool want_pre_blend = false, have_pre_blend = false;
+    hipStream_t armed_on = nullptr, marked_on = nullptr;
 };
 SideStream g_side[MRGS_MAX_DEVICES];
 std::mutex g_side_mutex;
@@ -682,8 +686,22 @@ static void side_mark_pre_blend(hipStream_t stream)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MRGS_MAX_DEVICES) return;
     std::lock_guard<std::mutex> lk(g_side_mutex);
     SideStream& s = g_side[dev];
-    if (!s.want_pre_blend || s.pre_blend == nullptr) return;
+    if (!s.want_pre_blend || s.pre_blend == nullptr || stream != s.armed_on) return;
     s.have_pre_blend = hipEventRecord(s.pre_blend, stream) == hipSuccess;
+    s.marked_on = stream;
+    s.want_pre_blend = false;                    // the first forward after the arming is the one meant
+}
+
+int mrgs_side_stream_arm_blend_mark(void* main_stream)
+{
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    SideStream* s = nullptr;
+    int rc = side_of(&s);
+    if (rc) return rc;
+    s->want_pre_blend = true;
+    s->have_pre_blend = false;                   // whatever an earlier forward marked is history
+    s->armed_on = (hipStream_t)main_stream;
+    return MRGS_OK;
 }
 
 int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream)
@@ -693,10 +711,11 @@ int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream)
     SideStream* s = nullptr;
     int rc = side_of(&s);
     if (rc) return rc;
-    s->want_pre_blend = true;                    // from now on every forward marks the point
-    if (s->have_pre_blend) {
+    if (s->have_pre_blend && s->marked_on == (hipStream_t)main_stream) {
+        s->have_pre_blend = false;               // consumed: a second fork without a new arming + forward takes the plain path
         HIP_TRY(hipStreamWaitEvent(s->stream, s->pre_blend, 0));
-    } else {                                     // no forward has marked it yet: everything the caller's stream holds
+    } else {                                     // no forward on this stream has marked the point since the arming: everything the caller's stream holds
+        s->have_pre_blend = false;
         hipEvent_t e = s->ev[s->next++ % MRGS_SIDE_EVENTS];
         HIP_TRY(hipEventRecord(e, (hipStream_t)main_stream));
         HIP_TRY(hipStreamWaitEvent(s->stream, e, 0));
@@ -728,6 +747,7 @@ int mrgs_side_stream_join(void* main_stream)
     hipEvent_t e = s->ev[s->next++ % MRGS_SIDE_EVENTS];
     HIP_TRY(hipEventRecord(e, s->stream));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)main_stream, e, 0));
+    s->have_pre_blend = false;                   // a mark older than a join is stale
     return MRGS_OK;
 }
 

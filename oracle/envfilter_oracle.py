@@ -15,7 +15,11 @@ face axis (resolutions that are multiples of 32) and drops qualifying texels bel
 face is one tile whose corner directions all have the same major component, the test fails for the face's own centre, the window
 is empty and the reference divides 0 by 0.  (Rows with an empty window are NaN here, as in the reference; the HIP operator leaves
 them zero.  The reference's defaults, 128 -> 16 with roughness 1 on the 16x16 level, never get there.)
-Usable for cubemaps up to ~32x32 (6144^2 weights).
+The dense operators are usable for cubemaps up to ~32x32 (6144^2 weights).  For the reference's default chain (128 -> 16) the levels whose
+resolution is a multiple of 32 -- where the bounding boxes are conservative and the window is exactly {dot(L, V) >= cos_cutoff} -- are
+applied by `BlockedSpecular`: the same weights, formed a block of output texels at a time in float64 torch and never stored (on
+whatever device the caller names; at 128^2 the full-size checks run it on the GPU as a float64 calculator -- it shares no code with the
+product's sparse / MFMA operators).  tests/test_shading.py checks the blocked form against the dense one at 32^2.
 """
 import numpy as np
 import torch
@@ -23,23 +27,25 @@ import torch
 from . import shading_oracle as so
 
 
-def cube_to_dir(N):
-    """[6*N*N, 3] unit directions of the texel centres, index (s*N + y)*N + x (cubemap.cu:32-46)."""
+def cube_to_dir(N, normalize=True):
+    """[6*N*N, 3] unit directions of the texel centres, index (s*N + y)*N + x (cubemap.cu:32-46); normalize=False: before the division."""
     x = (2.0 * ((np.arange(N) + 0.5) / N) - 1.0)
     fx, fy = np.meshgrid(x, x, indexing="xy")          # fx varies along x (columns), fy along y (rows)
     one = np.ones_like(fx)
     faces = [(one, -fy, -fx), (-one, -fy, fx), (fx, one, fy), (fx, -one, -fy), (fx, -fy, one), (-fx, -fy, -one)]
     d = np.stack([np.stack(f, -1) for f in faces], 0).reshape(-1, 3)
+    if not normalize:
+        return d
     return d / np.sqrt(np.maximum((d * d).sum(-1, keepdims=True), 1e-20))
 
 
-def pixel_area(N):
-    """[6*N*N] (cubemap.cu:17-30)."""
+def pixel_area(N, dtype=np.float64):
+    """[6*N*N] (cubemap.cu:17-30); dtype float32: evaluated in fp32 as the kernel does."""
     if N <= 1:
-        return np.ones(6)
+        return np.ones(6, dtype)
     H = N // 2
-    i = np.abs(np.arange(N) - H)
-    d = np.arctan((i + 1) / H) - np.arctan(i / H)
+    i = np.abs(np.arange(N) - H).astype(dtype)
+    d = np.arctan((i + 1) / dtype(H)) - np.arctan(i / dtype(H))
     a = d[None, :] * d[:, None]                          # [y, x]
     return np.tile(a.reshape(-1), 6)
 
@@ -125,6 +131,95 @@ def _specular_matrix(N, roughness, cutoff):
         return W / W.sum(1, keepdims=True)
 
 
+class DenseOp:
+    """A dense operator behind the matvec / rmatvec interface of BlockedSpecular."""
+
+    def __init__(self, P):
+        self.P = P
+        self.shape = P.shape
+        self.res = int(round(np.sqrt(P.shape[0] / 6)))
+
+    def matvec(self, x):
+        return self.P @ np.asarray(x, dtype=np.float64).reshape(-1, 3)
+
+    def rmatvec(self, g):
+        return self.P.T @ np.asarray(g, dtype=np.float64).reshape(-1, 3)
+
+
+class BlockedSpecular:
+    """The row-normalised operator of specular_matrix(N, roughness) for N a multiple of 32, never stored: weights of `block` output texels
+    against all source texels at a time, torch on `device`.  Same formulas as specular_weights (cubemap.cu:238-290).
+    literal32 = False: float64; with unit directions the half vector's cosine  dot(normalize(L + V), V)  is  (1 + dot(L, V)) / sqrt(2 + 2 dot(L, V)).
+    literal32 = True: THE WEIGHTS as the reference's kernel forms them -- float32, its expression tree (directions normalised in fp32, the half
+    vector normalised, ndfGGX as  a2 / (d d pi)  with  d = (c a2 - c) c + 1) -- and then applied in float64.  At roughness 0.08 (a2 = 4e-5)
+    the window is a cone of 1.2 degrees and  d = 1 - c^2 (1 - a2)  is a difference of two numbers near 1 that comes out around 5e-5: fp32
+    holds it to ~1e-3, the weight to a few 1e-3, and a texel at the rim of the window is in or out by the last bit of a dot product --
+    the fp32 formula of the REFERENCE is ill-conditioned there (measured at 128^2: the literal fp32 weights sit up to several per cent
+    of a level's range from the float64 ones).  This is the truth leg of the prefilter: a product operator is held to be no further
+    from the float64 levels than this literal reading is (render_oracle.leaf_gradient_report)."""
+
+    def __init__(self, N, roughness, cutoff=0.99, device="cpu", block=1024, literal32=False):
+        assert N % 32 == 0, "the bounding boxes of SpecularBoundsKernel are conservative for multiples of 32 only (module docstring)"
+        self.res, self.block, self.device, self.literal32 = int(N), int(block), torch.device(device), bool(literal32)
+        self.shape = (6 * N * N, 6 * N * N)
+        self.a2 = float((roughness * roughness) ** 2)
+        self.cosc = float(np.float32(cos_cutoff(roughness, cutoff)))
+        self.D = torch.from_numpy(cube_to_dir(N)).to(self.device)
+        self.area = torch.from_numpy(pixel_area(N)).to(self.device)
+        if literal32:
+            d = torch.from_numpy(cube_to_dir(N, normalize=False).astype(np.float32)).to(self.device)
+            self.D = d / torch.sqrt(torch.clamp((d * d).sum(-1, keepdim=True), min=1e-20))
+            self.area = torch.from_numpy(pixel_area(N, np.float32)).to(self.device)
+
+    def _weights(self, r0, r1):
+        if self.literal32:
+            f = torch.float32
+            a2, pi = torch.tensor(self.a2, dtype=f, device=self.device), torch.tensor(3.14159265358979323846, dtype=f, device=self.device)
+            V = self.D[r0:r1]
+            dots = V @ self.D.T                                                  # dot(L, VNR), fp32
+            Hh = self.D[None, :, :] + V[:, None, :]
+            Hh = Hh / torch.sqrt(torch.clamp((Hh * Hh).sum(-1, keepdim=True), min=1e-20))
+            c = torch.clamp((Hh * V[:, None, :]).sum(-1), min=0.0).clamp_(0.0, 1.0)
+            dd = (c * a2 - c) * c + 1.0
+            W = torch.clamp(dots, min=0.0) * (a2 / (dd * dd * pi)) * self.area[None, :] / 4.0
+            W = torch.where(dots >= torch.tensor(self.cosc, dtype=f, device=self.device), W, torch.zeros((), dtype=f, device=self.device))
+            return W.double()
+        dots = self.D[r0:r1] @ self.D.T                                       # [block (output texel), source texel]
+        vh = ((1.0 + dots) / torch.sqrt(torch.clamp(2.0 + 2.0 * dots, min=1e-20))).clamp_(0.0, 1.0)
+        dd = (vh * self.a2 - vh) * vh + 1.0
+        W = torch.clamp(dots, min=0.0) * (self.a2 / (dd * dd * np.pi)) * self.area[None, :] / 4.0
+        return torch.where(dots >= self.cosc, W, torch.zeros((), dtype=W.dtype, device=W.device))
+
+    def _blocks(self):
+        blk = max(64, self.block // 8) if self.literal32 else self.block       # (the literal half vectors are a [block, 6 N^2, 3] tensor)
+        for r0 in range(0, self.shape[0], blk):
+            yield r0, self._weights(r0, min(r0 + blk, self.shape[0]))
+
+    def matvec(self, x):
+        x = torch.as_tensor(np.asarray(x, dtype=np.float64).reshape(-1, 3)).to(self.device)
+        out = torch.empty_like(x)
+        for r0, W in self._blocks():
+            out[r0:r0 + W.shape[0]] = (W @ x) / W.sum(1, keepdim=True)
+        return out.cpu().numpy()
+
+    def rmatvec(self, g):
+        g = torch.as_tensor(np.asarray(g, dtype=np.float64).reshape(-1, 3)).to(self.device)
+        out = torch.zeros_like(g)
+        for r0, W in self._blocks():
+            out += W.T @ (g[r0:r0 + W.shape[0]] / W.sum(1, keepdim=True))
+        return out.cpu().numpy()
+
+
+def specular_operator(N, roughness, cutoff=0.99, device=None, literal32=False):
+    """The operator of one level: dense (cached) up to 32^2 or when no device is named, blocked above.  literal32: the weights in the
+    reference's fp32 arithmetic (BlockedSpecular; levels it cannot serve -- resolutions that are not multiples of 32 -- stay float64)."""
+    if literal32 and N % 32 == 0:
+        return BlockedSpecular(N, roughness, cutoff, device or "cpu", literal32=True)
+    if device is None or N <= 32 or N % 32 != 0:
+        return DenseOp(specular_matrix(N, roughness, cutoff))
+    return BlockedSpecular(N, roughness, cutoff, device)
+
+
 def diffuse_matrix(N):
     D = cube_to_dir(N)
     ct = np.minimum(np.maximum(D @ D.T, 0.0), 0.999)
@@ -151,8 +246,10 @@ def mip_backward(dout):
     return out
 
 
-def build_mips(base, min_res, min_roughness=0.08, max_roughness=0.5, cutoff=0.99):
-    """EnvLight.build_mips forward: returns (specular levels, diffuse, per-level operators)."""
+def build_mips(base, min_res, min_roughness=0.08, max_roughness=0.5, cutoff=0.99, device=None, literal32=False):
+    """EnvLight.build_mips forward: returns (specular levels, diffuse, per-level operators -- objects with matvec / rmatvec).
+    device: where the levels above 32^2 are evaluated (BlockedSpecular); None: dense everywhere (small cubemaps only).
+    literal32: the filter weights of the levels that are multiples of 32 as the reference's fp32 kernel forms them (the truth leg)."""
     raw = [np.asarray(base, dtype=np.float64)]
     while raw[-1].shape[1] > min_res:
         raw.append(mip_forward(raw[-1]))
@@ -160,9 +257,9 @@ def build_mips(base, min_res, min_roughness=0.08, max_roughness=0.5, cutoff=0.99
     ops = []
     for idx in range(n - 1):
         rough = (idx / (n - 2)) * (max_roughness - min_roughness) + min_roughness
-        ops.append(specular_matrix(raw[idx].shape[1], rough, cutoff))
-    ops.append(specular_matrix(raw[-1].shape[1], 1.0, cutoff))
-    spec = [(P @ r.reshape(-1, 3)).reshape(r.shape) for P, r in zip(ops, raw)]
+        ops.append(specular_operator(raw[idx].shape[1], rough, cutoff, device, literal32))
+    ops.append(specular_operator(raw[-1].shape[1], 1.0, cutoff, device, literal32))
+    spec = [P.matvec(r).reshape(r.shape) for P, r in zip(ops, raw)]
     diffuse = (diffuse_matrix(raw[-1].shape[1]) @ raw[-1].reshape(-1, 3)).reshape(raw[-1].shape)
     return spec, diffuse, ops
 
@@ -171,7 +268,7 @@ def build_mips_backward(ops, g_spec, g_diffuse=None):
     """Gradient w.r.t. base of sum_l <g_spec[l], specular[l]> (+ <g_diffuse, diffuse>) under the reference's autograd rules."""
     g = None
     for l in range(len(ops) - 1, -1, -1):
-        gl = (ops[l].T @ np.asarray(g_spec[l], dtype=np.float64).reshape(-1, 3)).reshape(g_spec[l].shape)
+        gl = ops[l].rmatvec(g_spec[l]).reshape(g_spec[l].shape)
         if l == len(ops) - 1 and g_diffuse is not None:      # diffuse_cubemap reads the raw last level (scene/light.py:84-86)
             N = g_spec[l].shape[1]
             gl = gl + (diffuse_matrix(N).T @ np.asarray(g_diffuse, dtype=np.float64).reshape(-1, 3)).reshape(g_spec[l].shape)

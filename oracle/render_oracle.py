@@ -78,7 +78,7 @@ class _OracleBuildMips(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g_all):
         g_spec, g_diff = g_all[:-1], g_all[-1]
-        shapes = [(6, int(round(math.sqrt(op.shape[0] / 6))), int(round(math.sqrt(op.shape[0] / 6))), 3) for op in ctx.ops]
+        shapes = [(6, op.res, op.res, 3) for op in ctx.ops]
         g = [np.zeros(s) if gi is None else gi.detach().numpy() for gi, s in zip(g_spec, shapes)]
         gd = None if g_diff is None else g_diff.detach().numpy()
         return torch.from_numpy(ef.build_mips_backward(ctx.ops, g, gd)).to(ctx.dtype), None, None, None
@@ -248,3 +248,141 @@ def render_volume_oracle(cam, pc, env_base, env_min_res, pipe, bg_color, srgb=Fa
     if flag != "2dgs":
         out["rend_distance"] = feat[-1:]
     return out
+
+
+LEAF_NAMES = ("xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color",
+              "indirect_dc", "indirect_rest")
+RASTER_INPUT_NAMES = ("opacities", "scales", "rotations", "features")
+
+
+def surfel_leaf_gradients(cam, leaves, env_base, raster_inputs, keys, upstream, pipe, bg_color, env_min_res=16, mips_device=None,
+                          min_roughness=0.08, max_roughness=0.5, shade_levels=None, literal32_prefilter=False):
+    """render_surfel of ONE view through the checkers, forward and backward, down to EVERY leaf -- the full-size form of the end-to-end
+    comparison (bench.py's CPU leg at C3full, tests/test_full_size.py):
+
+      `leaves`          the 11 raw parameter tensors in LEAF_NAMES order (any dtype / device; evaluated here in float64 on the CPU)
+      `env_base`        the environment's pre-sigmoid texels [6,N,N,3]
+      `raster_inputs`   the product's OWN fp32 per-gaussian rasterizer inputs (activated opacity / scale / rotation, the material rows)
+                        captured from inside its render: both rasterizers then see identical numbers, and no alpha = 1/255 or
+                        T = 1e-4 decision of a 640 000-pixel image hangs on the last bit of an activation (render_surfel_oracle)
+      `keys`, `upstream` the output maps the scalar reads and their fixed upstream gradients
+
+      `shade_levels`    prefiltered levels to SHADE with instead of the checker's own float64 ones (the product's levels at full size:
+                        the reference's fp32 filter weights are ill-conditioned at roughness 0.08 -- envfilter_oracle.BlockedSpecular --
+                        so levels built in fp32 and in float64 differ by per cents of a level's range at 128^2, which is a statement
+                        about the prefilter, checked on its own below, and must not leak into the comparison of the shading)
+      `literal32_prefilter`  also evaluate the prefilter's truth leg: the levels and the texel gradient with the filter weights formed in
+                        the reference's fp32 arithmetic (info["levels_lit32"], grads["lit32"]["env_base"])
+
+    Chain: prefiltered levels from `env_base` (envfilter_oracle.build_mips; levels above 32^2 blocked in float64 on `mips_device`) ->
+    rasterizer (mrgs_oracle.c) + maps + shading + compositing at `raster_inputs` -> the gradient arriving at `raster_inputs` is pulled
+    back through the float64 glue of gaussian_renderer/__init__.py:338-355 (glue_oracle.surfel_features_reference, evaluated at the raw
+    leaves) and added to what reaches the leaves directly (xyz through the rasterizer and the SH view direction; the colour SH); the
+    gradient arriving at the levels through build_mips_backward to the texels.
+    Returns (out, grads, info): `out` the checker's dictionary; `grads` name -> float64 numpy for LEAF_NAMES + "env_base" +
+    "viewspace_points" + RASTER_INPUT_NAMES + "env_levels" (list) + "lit32" (name -> the same leaf gradient with the glue's pull-back
+    evaluated as the reference evaluates it -- torch float32, the reference's own ops -- from the SAME upstream gradient: the truth leg of
+    the glue, see leaf_gradient_report; with literal32_prefilter also "env_base" through the fp32-weight operators); info = {"raster_shading_seconds": the part a CPU baseline may be quoted on (rasterizer + maps +
+    shading + compositing, forward and backward), "levels": the float64 levels}."""
+    import time
+    from materialrefgs_amd.renderer import SurfelModel
+    f64 = lambda t_: t_.detach().cpu().double().requires_grad_(True)
+    pc = SurfelModel(*[f64(t_) for t_ in leaves[:6]], **{n: f64(t_) for n, t_ in zip(LEAF_NAMES[6:], leaves[6:11])})
+    inter = [f64(t_) for t_ in raster_inputs]
+    spec, _diffuse, ops = ef.build_mips(env_base.detach().cpu().double().numpy(), env_min_res, min_roughness, max_roughness, device=mips_device)
+    levels = [torch.from_numpy(np.ascontiguousarray(np.asarray(s, dtype=np.float64))).requires_grad_(True) for s in (shade_levels if shade_levels is not None else spec)]
+    cam = cam.to("cpu") if hasattr(cam, "to") else cam
+    t0 = time.perf_counter()
+    out = render_surfel_oracle(cam, pc, None, None, pipe, bg_color.detach().cpu(), srgb=False, mips=levels, raster_inputs=tuple(inter),
+                               min_roughness=min_roughness, max_roughness=max_roughness)
+    torch.autograd.backward([out[k] for k in keys], [g_.detach().cpu().double() for g_ in upstream])
+    seconds = time.perf_counter() - t0
+    g_inter = [t_.grad if t_.grad is not None else torch.zeros_like(t_) for t_ in inter]
+    # the glue, float64, at the raw leaves: its Jacobian transposed applied to what arrived at the rasterizer's inputs
+    glue_out = go.surfel_features_reference(pc, cam.camera_center.double())
+    torch.autograd.backward(list(glue_out), g_inter)
+    grads = {n: (getattr(pc, "_" + n).grad if getattr(pc, "_" + n).grad is not None else torch.zeros_like(getattr(pc, "_" + n))).numpy()
+             for n in LEAF_NAMES}
+    lit = glue_lit32_leg(leaves, cam.camera_center, g_inter, grads)
+    g_levels = [np.zeros(tuple(l_.shape)) if l_.grad is None else l_.grad.numpy() for l_ in levels]
+    grads["env_base"] = ef.build_mips_backward(ops, g_levels)
+    grads["env_levels"] = g_levels
+    info = {"raster_shading_seconds": seconds, "levels": [np.asarray(s) for s in spec]}
+    if literal32_prefilter:
+        spec32, _d32, ops32 = ef.build_mips(env_base.detach().cpu().double().numpy(), env_min_res, min_roughness, max_roughness, device=mips_device,
+                                            literal32=True)
+        lit["env_base"] = ef.build_mips_backward(ops32, g_levels)
+        info["levels_lit32"] = [np.asarray(s) for s in spec32]
+    grads["lit32"] = lit
+    grads["viewspace_points"] = out["viewspace_points"].grad.numpy()
+    for n, g_ in zip(RASTER_INPUT_NAMES, g_inter):
+        grads[n] = g_.numpy()
+    return out, grads, info
+
+
+def glue_lit32_leg(leaves, campos, g_inter, total):
+    """The truth leg of the per-gaussian glue: `total` (name -> float64 leaf gradient of the whole chain) with the glue's pull-back of
+    `g_inter` (the gradient at the rasterizer's per-gaussian inputs) evaluated the way the REFERENCE evaluates it -- its own torch ops
+    (gaussian_renderer/__init__.py:338-355, the GaussianModel getters) on fp32 tensors -- instead of in float64:
+    lit[n] = total[n] - pullback_f64[n] + pullback_f32[n].  Everything else (rasterizer, maps, shading: the upstream gradient) is common
+    to both, so the distance lit - total is exactly what fp32 arithmetic costs the glue's backward for this scene."""
+    from materialrefgs_amd.renderer import SurfelModel
+    parts = {}
+    for dt in (torch.float64, torch.float32):
+        conv = lambda t_: t_.detach().cpu().to(dt).requires_grad_(True)
+        pc_ = SurfelModel(*[conv(t_) for t_ in leaves[:6]], **{n: conv(t_) for n, t_ in zip(LEAF_NAMES[6:], leaves[6:11])})
+        torch.autograd.backward(list(go.surfel_features_reference(pc_, campos.detach().cpu().to(dt))), [g_.detach().to(dt) for g_ in g_inter])
+        parts[dt] = {n: getattr(pc_, "_" + n).grad for n in LEAF_NAMES}
+    lit = {}
+    for n in LEAF_NAMES:
+        if parts[torch.float32][n] is not None:
+            lit[n] = np.asarray(total[n], dtype=np.float64) - parts[torch.float64][n].numpy() + parts[torch.float32][n].double().numpy()
+    return lit
+
+
+def leaf_gradient_report(hip, oracle_grads, names, bar=1e-4):
+    """Per leaf: max-norm distance of the product's gradient from the checker's, relative to the checker's largest element; a leaf
+    above `bar` passes only by the truth-leg rule of tests/test_gpu_parity.py:97-116, applied to the stage whose fp32 arithmetic is the
+    reference's own (oracle_grads["lit32"]: the glue's pull-back in the reference's fp32 torch ops; the prefilter's with its fp32 filter
+    weights): the product may be no further from the float64 value than that literal fp32 reading is (x 1.5), and the reading must
+    itself be beyond half the bar (an ill-conditioned stage -- the quaternion normalisation's projector applied to a mostly radial
+    gradient, GGX weights at roughness 0.08 -- not a loose kernel).  hip: name -> array-like.  Returns (rows, ok): rows name -> {"err", "lit32_err"?, "rule"}."""
+    rows, ok = {}, True
+    for n in names:
+        b = np.asarray(oracle_grads[n], dtype=np.float64)
+        a = np.asarray(hip[n], dtype=np.float64).reshape(b.shape)
+        scale = max(float(np.abs(b).max()), 1e-30)
+        e = float(np.abs(a - b).max() / scale)
+        row = {"err": e, "rule": "bar"}
+        if e > bar:
+            lit = oracle_grads.get("lit32", {}).get(n)
+            if lit is None:
+                row["rule"], ok = "FAIL", False
+            else:
+                e_lit = float(np.abs(np.asarray(lit, dtype=np.float64).reshape(b.shape) - b).max() / scale)
+                row["lit32_err"] = e_lit
+                good = e <= 1.5 * e_lit and e_lit > 0.5 * bar
+                row["rule"] = "truth-leg" if good else "FAIL"
+                ok = ok and good
+        rows[n] = row
+    return rows, ok
+
+
+def level_report(product_levels, levels64, levels_lit32, bar=2e-5):
+    """The prefiltered levels of the product against the float64 ones: per level max-norm relative error; above `bar` a level passes by
+    the truth-leg rule only (no further from float64 than the levels built with the reference's fp32 filter weights, x 1.5, and those
+    beyond half the bar themselves).  Returns (rows, ok)."""
+    rows, ok = [], True
+    for i, (a, b) in enumerate(zip(product_levels, levels64)):
+        b = np.asarray(b, dtype=np.float64)
+        scale = max(float(np.abs(b).max()), 1e-30)
+        e = float(np.abs(np.asarray(a, dtype=np.float64).reshape(b.shape) - b).max() / scale)
+        row = {"res": int(b.shape[1]), "err": e, "rule": "bar"}
+        if e > bar:
+            e_lit = float(np.abs(np.asarray(levels_lit32[i], dtype=np.float64) - b).max() / scale) if levels_lit32 is not None else 0.0
+            row["lit32_err"] = e_lit
+            good = e <= 1.5 * e_lit and e_lit > 0.5 * bar
+            row["rule"] = "truth-leg" if good else "FAIL"
+            ok = ok and good
+        rows.append(row)
+    return rows, ok

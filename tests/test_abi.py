@@ -80,12 +80,12 @@ def test_struct_size_guard():
     from materialrefgs_amd import _lib
     from materialrefgs_amd._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
     L = _lib.lib()
-    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 8
+    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 9
     assert ctypes.sizeof(MrgsRasterConfig) == 4 + 11 * 4          # struct_size + 6 ints + 3 floats + 2 ints
     assert ctypes.sizeof(MrgsRasterInputs) == 8 + 15 * 8 + 8      # struct_size + 12 pointers + work_hint, shs_rest, bwd_grad_ws + hint_flags, reserved
     assert ctypes.sizeof(MrgsRasterGrads) == 8 + 10 * 8
     hdr = open(os.path.join(ROOT, "include", "mrgs.h")).read()
-    assert "#define MRGS_ABI_VERSION 8" in hdr
+    assert "#define MRGS_ABI_VERSION 9" in hdr
 
     class OldInputs(ctypes.Structure):                           # the struct as INTEGRATION.md printed it in round 2: 14 pointers, no size
         _fields_ = [(n, ctypes.c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales", "rotations",

@@ -84,16 +84,20 @@ def test_render_surfel_at_c3_size(gpu_device):
 
 
 def test_c3full_against_render_oracle(gpu_device):
-    """The headline workload against the CPU checkers AT FULL SIZE (what bench.py's CPU leg measures, here as a test of record):
-    render_surfel of view 0 of the bench's C3full scene -- 300 000 surfels, 800 x 800, S = 8, deferred shading -- on the GPU and through
-    oracle/render_oracle.py (oracle/mrgs_oracle.c rasterizer over OpenMP, float64 torch for maps, shading and compositing), forward and
-    backward with the bench's upstream gradients, both rasterizers fed the product's own fp32 per-gaussian inputs (identical inputs: a
-    float64 evaluation of the activations differs in the last bit and moves threshold pixels -- a comparison of inputs, not of
-    renderers; the glue has its own tests).  Bars: the pair count equal, maps <= 2e-5 of their maximum except the two ill-conditioned
-    ones (rend_dist: absolute 5e-6; surf_normal: <= 1e-2 of the pixels beyond 1e-4), gradients <= 1e-4.  ~15 s of CPU work."""
+    """The headline workload against the checkers AT FULL SIZE (what bench.py's CPU leg measures, here as a test of record):
+    render_surfel of view 0 of the bench's C3full scene -- 300 000 surfels, 800 x 800, S = 8, deferred shading, the 128 -> 16 environment
+    chain -- on the GPU and through oracle/render_oracle.surfel_leaf_gradients (oracle/mrgs_oracle.c rasterizer over OpenMP, float64
+    torch for maps, shading and compositing, the float64 glue, the float64 prefilter operators -- the two levels above 32^2 blocked
+    on the GPU as a float64 calculator), forward and backward with the bench's upstream gradients, down to EVERY leaf: xyz, the raw
+    scale / rotation / opacity / material parameters, both SH families, the environment texels, and viewspace_points (the
+    densification signal, backward.cu:665-668).  Both rasterizers are fed the product's own fp32 per-gaussian inputs (a float64
+    evaluation of the activations differs in the last bit and moves threshold pixels -- a comparison of inputs, not of renderers).
+    Bars: the pair count equal, prefiltered levels <= 2e-5, maps <= 2e-5 of their maximum except the two ill-conditioned ones (rend_dist:
+    absolute 5e-6; surf_normal: <= 1e-2 of the pixels beyond 1e-4), every gradient <= 1e-4 of its tensor's maximum or the truth-leg
+    rule (render_oracle.leaf_gradient_report).  ~20 s of CPU work."""
     import materialrefgs_amd.renderer as renderer_mod
     from materialrefgs_amd import rasterizer as rasterizer_mod
-    from materialrefgs_amd.renderer import SurfelModel, render_surfel
+    from materialrefgs_amd.renderer import render_surfel
     from oracle import render_oracle
     dev = gpu_device
     P, H, W = 300_000, 800, 800
@@ -119,16 +123,17 @@ def test_c3full_against_render_oracle(gpu_device):
     ups = [torch.ones_like(out_h["render"])] + [torch.full_like(out_h[k], 0.1) for k in LOSS_MAPS[1:]]      # bench.py's constants
     torch.autograd.backward([out_h[k] for k in LOSS_MAPS], ups)
     torch.cuda.synchronize(dev)
-    names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color", "indirect_dc",
-             "indirect_rest"]
-    f64 = lambda t_: t_.detach().cpu().double().requires_grad_(True)
-    pc_o = SurfelModel(*[f64(t_) for t_ in leaves[:6]], **{n: f64(t_) for n, t_ in zip(names[6:], leaves[6:11])})
-    inter_o = [f64(t_) for t_ in stash["o"]]
-    out_o = render_oracle.render_surfel_oracle(cam_cpu, pc_o, None, None, PIPE, bg.cpu(), srgb=False, mips=[m.detach().cpu().double() for m in env.specular],
-                                               raster_inputs=tuple(inter_o))
-    torch.autograd.backward([out_o[k] for k in LOSS_MAPS], [g_.detach().cpu().double() for g_ in ups])
+    # (shaded with the product's own levels on both sides; the prefilter is compared on its own: at roughness 0.08 the reference's fp32 filter
+    #  weights are ill-conditioned -- envfilter_oracle.BlockedSpecular -- and levels built in fp32 differ from float64 ones by per cents)
+    levels_h = [m_.detach().cpu().double().numpy() for m_ in env.specular]
+    out_o, g_o, info = render_oracle.surfel_leaf_gradients(cam_cpu, leaves[:11], env.base, stash["o"], LOSS_MAPS, ups, PIPE, bg, env_min_res=env.min_res,
+                                                           mips_device=dev, shade_levels=levels_h, literal32_prefilter=True)
     assert render_oracle.LAST_NUM_RENDERED == R_hip, (render_oracle.LAST_NUM_RENDERED, R_hip)
     rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    lrows, lok = render_oracle.level_report(levels_h, info["levels"], info["levels_lit32"])      # the prefilter at the reference's default sizes
+    for r_ in lrows:
+        print(f"  prefiltered level {r_['res']}^2 {r_['err']:.2e}  {r_['rule']}" + (f" (fp32 filter weights: {r_['lit32_err']:.2e})" if "lit32_err" in r_ else ""))
+    assert lok, lrows
     for k in ("render", "rend_alpha", "rend_normal", "surf_depth", "specular_map", "diffuse_map", "roughness_map", "base_color_map", "refl_strength_map"):
         e = rel(out_h[k].detach().cpu().double().numpy(), out_o[k].detach().numpy())
         print(f"  map {k:18s} {e:.2e}")
@@ -139,12 +144,22 @@ def test_c3full_against_render_oracle(gpu_device):
     # (surf_normal: a normalised cross product of finite differences of neighbouring surface points, utils/point_utils.py:26-39 -- fp32 on one side,
     #  float64 on the other; round 4's bench line reported the same 5.5e-3 of the pixels for this view)
     assert e_dist <= 5e-6 and (sn > 1e-4).mean() <= 1e-2 and (sn > 2e-2).mean() <= 1e-4
-    pairs = [(n, th.grad, to.grad) for n, th, to in zip(("opacities", "scales", "rotations", "features"), stash["o"], inter_o)]
-    pairs += [(n, leaves[names.index(n)].grad, getattr(pc_o, "_" + n).grad) for n in ("features_dc", "features_rest")]
-    for n, gh, go_ in pairs:
-        e = rel(gh.detach().cpu().double().numpy(), go_.numpy())
-        print(f"  grad {n:14s} {e:.2e}")
-        assert e <= 1e-4, (n, e)
+    hip = {n: t_.grad.detach().cpu().numpy() for n, t_ in zip(render_oracle.LEAF_NAMES, leaves[:11])}
+    hip["env_base"] = env.base.grad.detach().cpu().numpy()
+    hip["viewspace_points"] = out_h["viewspace_points"].grad.detach().cpu().numpy()
+    for n, t_ in zip(render_oracle.RASTER_INPUT_NAMES, stash["o"]):
+        hip[n] = t_.grad.detach().cpu().numpy()
+    names = list(render_oracle.LEAF_NAMES) + ["env_base", "viewspace_points"] + list(render_oracle.RASTER_INPUT_NAMES)
+    rows, ok = render_oracle.leaf_gradient_report(hip, g_o, names, bar=1e-4)
+    for n in names:
+        r_ = rows[n]
+        print(f"  grad {n:18s} {r_['err']:.2e}  {r_['rule']}" + (f" (fp32 torch glue: {r_['lit32_err']:.2e})" if "lit32_err" in r_ else ""))
+    assert ok, rows
+    for n in ("indirect_dc", "indirect_rest"):        # the blended indirect radiance only enters the image under opt.indirect (:423-430)
+        assert float(np.abs(hip[n]).max()) == 0.0 and float(np.abs(g_o[n]).max()) == 0.0
+    for n in names:
+        if n not in ("indirect_dc", "indirect_rest"):
+            assert float(np.abs(g_o[n]).max()) > 0.0, n
 
 
 def _dense_on_gpu(o, d, pc, cam, bg, chunk):

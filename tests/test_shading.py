@@ -784,6 +784,24 @@ def test_cube_symmetry_rows_form_the_octahedral_group():
         assert np.array_equal(parent(P8[g][t], 8), P4[g][parent(t, 8)])
 
 
+def test_blocked_float64_prefilter_operator_equals_the_dense_one():
+    """oracle/envfilter_oracle.BlockedSpecular (what the full-size checks apply at 128^2 and 64^2, where the dense operator does not fit)
+    against the dense operator of the same level at 32^2, both directions; and build_mips / build_mips_backward give the same levels
+    and base gradient whichever form carries the 32^2 level."""
+    from oracle import envfilter_oracle as eo
+    rng = np.random.default_rng(5)
+    P = eo.specular_matrix(32, 0.08)
+    B = eo.BlockedSpecular(32, 0.08, device="cpu", block=512)
+    x = rng.normal(size=(6 * 32 * 32, 3))
+    assert np.abs(B.matvec(x) - P @ x).max() < 1e-12 and np.abs(B.rmatvec(x) - P.T @ x).max() < 1e-12
+    base = rng.normal(size=(6, 32, 32, 3))
+    spec_d, _, ops_d = eo.build_mips(base, 8)
+    ops_b = [B] + list(ops_d[1:])
+    ups = [rng.normal(size=s_.shape) for s_ in spec_d]
+    assert np.abs(ops_b[0].matvec(base).reshape(base.shape) - spec_d[0]).max() < 1e-12
+    assert np.abs(eo.build_mips_backward(ops_b, ups) - eo.build_mips_backward(ops_d, ups)).max() < 1e-12
+
+
 def test_symmetric_rows_refuse_a_panel_longer_than_the_kernel_takes(monkeypatch):
     """CubemapFilterOp._symmetric returns None (the caller then keeps the full matrices) when a tile's panel has more patches than a
     workgroup of the product kernel walks (MRGS_SPMV_MAX_PANEL): checked with the limit lowered under the 16 x 16 level's panels."""
