@@ -253,14 +253,17 @@ typedef struct MrgsShadeFrame {
 int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, float* specular, float* direct_light,
                                 float* specular_weight, void* stream);
 /* ... and render_surfel's compositing in the same pass (ABI 6; mrgs_surfel_composite_forward's arithmetic on the specular just computed):
- * diffuse[3,H,W] = (1 - refl) base_color, render[3,H,W] = [linear_to_srgb](diffuse + specular) + bg (1 - alpha). */
+ * diffuse[3,H,W] = (1 - refl) base_color, render[3,H,W] = [linear_to_srgb](diffuse + specular) + bg (1 - alpha).
+ * zero_fill / zero_floats (ABI 9): a buffer this launch clears on the side (NULL / 0 = nothing) -- the texel-gradient buffers the
+ * backward of this render will accumulate into (mrgs_surfel_shade_composite_backward expects them zeroed and has no launch in front
+ * of it that could do it). */
 int mrgs_shade_specular_forward_composite(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* base_color, const float* bg,
                                           int32_t srgb, float* specular, float* direct_light, float* specular_weight, float* render,
-                                          float* diffuse, void* stream);
+                                          float* diffuse, float* zero_fill, int64_t zero_floats, void* stream);
 /* Gradients w.r.t. the five maps (dense, fully written: g_albedo[H,W,3], g_normal[H,W,3], g_alpha[H,W], g_refl[H,W],
- * g_roughness[H,W]) and, through mips->grad, w.r.t. the cubemap texels.  Any of the three upstream gradients may be NULL.
- * A level that receives gradients must have fewer than 2^24 texels (res < 1673; the reference's EnvLight uses 16 ... 128, at most
- * 512): larger ones return MRGS_E_UNSUPPORTED. */
+ * g_roughness[H,W]) and, through mips->grad, w.r.t. the cubemap texels (ACCUMULATED into mips->grad: the caller clears them).  Any of
+ * the three upstream gradients may be NULL.  A level that receives gradients must have fewer than 2^24 texels (res < 1673; the
+ * reference's EnvLight uses 16 ... 128, at most 512): larger ones return MRGS_E_UNSUPPORTED. */
 int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* g_specular, const float* g_direct_light,
                                  const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
                                  float* g_roughness, void* stream);
@@ -271,6 +274,17 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
 int mrgs_shade_specular_backward_features(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, const float* g_specular,
                                           const float* g_direct_light, const float* g_specular_weight, const float* g_refl_composite,
                                           const float* g_alpha_composite, float* g_normal, float* g_features, float* g_alpha, void* stream);
+/* render_surfel's compositing backward AND the shading backward in ONE launch (ABI 9; gaussian_renderer/__init__.py:436-445 then
+ * utils/refl_utils.py:364-419 backwards): what mrgs_surfel_composite_backward followed by mrgs_shade_specular_backward_features computes, with
+ * the compositing's g_specular / g_refl / g_alpha shares kept in the pixel's registers.  g_render / g_diffuse [3,H,W]: upstream gradients
+ * of the two composited maps (either may be NULL); g_specular_extra [3,H,W]: an upstream gradient of the specular map itself (NULL =
+ * none); base_color, specular [3,H,W]: the forward's inputs / output; bg[3].  Outputs, fully written: g_base[3,H,W], g_normal[H,W,3],
+ * g_features[8,H,W], g_alpha[H,W] (total).  The texel gradients are accumulated into mips->grad, which must be zero on entry
+ * (mrgs_shade_specular_forward_composite's zero_fill clears them in the forward of the same render). */
+int mrgs_surfel_shade_composite_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* frame, int32_t srgb, const float* base_color,
+                                         const float* specular, const float* bg, const float* g_render, const float* g_diffuse,
+                                         const float* g_specular_extra, const float* g_direct_light, const float* g_specular_weight,
+                                         float* g_base, float* g_normal, float* g_features, float* g_alpha, void* stream);
 
 /* ---- environment prefilter: EnvLight.build_mips (scene/light.py:72-86) ------------------------------------------------
  * renderutils' specular_cubemap / diffuse_cubemap (scene/renderutils/c_src/cubemap.cu:110-354, ops.py:390-459) are fixed linear

@@ -214,11 +214,12 @@ SYMBOLS = {
     "mrgs_shade_specular_forward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
                                                    c_void_p, c_void_p]),
     "mrgs_shade_specular_forward_composite": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p, c_int32,
-                                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mrgs_shade_specular_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mrgs_shade_specular_backward_features": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_void_p, c_void_p,
                                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mrgs_surfel_shade_composite_backward": (ctypes.c_int, [ctypes.POINTER(MrgsEnvMips), ctypes.POINTER(MrgsShadeFrame), c_int32] + [c_void_p] * 13),
     "mrgs_debug_export": (ctypes.c_int, [ctypes.POINTER(MrgsRasterConfig), c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p]),
     "mrgs_set_profiling": (ctypes.c_int, [c_int32]),

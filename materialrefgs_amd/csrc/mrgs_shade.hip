@@ -37,6 +37,12 @@ struct MapOut {
     long long sh, sw, sc;
 };
 
+// v_rcp_f32 (1 ulp) instead of the IEEE quotient (ten instructions and two mode switches each): the lookups and the split-sum shading are
+// compared to 2e-5 of a map's range and their sampling rule is a restatement to begin with (header); the filter-building kernels further
+// down, which restate the reference's weights operation for operation, keep the IEEE quotient.  Every kernel of a fetch (forward, the
+// backward's per-pixel launch, its scatter launch) goes through the same inline functions, so the three agree on a pixel's taps.
+__device__ __forceinline__ float shade_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r = {x, y, z}; return r; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -52,7 +58,7 @@ __device__ __forceinline__ FaceUV dir_to_face(f3 d)
     const bool pos = mc >= 0.f;
     r.axis = mx ? 0 : (my ? 1 : 2);
     r.sgn = pos ? 1.f : -1.f;
-    r.inv_ma = 1.0f / ma;
+    r.inv_ma = shade_rcp(ma);
     r.face = 2 * r.axis + (pos ? 0 : 1);
     // x-major: u = -+z, v = -y; y-major: u = x, v = +-z; z-major: u = +-x, v = -y
     const float un = mx ? (pos ? -d.z : d.z) : (my ? d.x : (pos ? d.x : -d.x));
@@ -107,7 +113,7 @@ __device__ __forceinline__ Taps cube_taps(const FaceUV& f, int res)
     t.norm = 1.0f;
     if (t.corner) {   // three faces meet: the diagonal tap does not exist
         if (c0) t.w[0] = 0.f; if (c1) t.w[1] = 0.f; if (c2) t.w[2] = 0.f; if (c3) t.w[3] = 0.f;
-        const float s = 1.0f / (t.w[0] + t.w[1] + t.w[2] + t.w[3]);
+        const float s = shade_rcp(t.w[0] + t.w[1] + t.w[2] + t.w[3]);
         t.norm = s;
         t.w[0] *= s; t.w[1] *= s; t.w[2] *= s; t.w[3] *= s;
     }
@@ -123,14 +129,16 @@ __device__ __forceinline__ float mip_level(const EnvMips& m, float r, float& dle
 {
     const float lo = m.min_roughness, hi = m.max_roughness;
     const float n2 = (float)(m.n - 2);
+    // (the two slopes are uniform: one scalar-sourced reciprocal each instead of a quotient per lane)
+    const float inv_a = shade_rcp(hi - lo), inv_b = shade_rcp(1.0f - hi);
     if (r < hi) {
         const float c = fminf(fmaxf(r, lo), hi);
-        dlevel = (r >= lo && r <= hi) ? n2 / (hi - lo) : 0.f;
-        return (c - lo) / (hi - lo) * n2;
+        dlevel = (r >= lo && r <= hi) ? n2 * inv_a : 0.f;
+        return (c - lo) * inv_a * n2;
     }
     const float c = fminf(fmaxf(r, hi), 1.0f);
-    dlevel = (r >= hi && r <= 1.0f) ? 1.0f / (1.0f - hi) : 0.f;
-    return (c - hi) / (1.0f - hi) + n2;
+    dlevel = (r >= hi && r <= 1.0f) ? inv_b : 0.f;
+    return (c - hi) * inv_b + n2;
 }
 
 struct __attribute__((aligned(4))) Tex3 { float x, y, z; };     // one texel: a 12-byte load at 4-byte alignment
@@ -153,8 +161,8 @@ __device__ __forceinline__ const float* level_tex(const EnvMips& m, int l)
     return p;
 }
 
-// trilinear seamless cube fetch (pre-sigmoid); fills what the backward needs
-__device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, float level, bool use_mips, EnvSample& s, Taps tp[2])
+// the two levels a fetch blends and the blend factor (s.l0, s.l1, s.f, s.lev_in)
+__device__ __forceinline__ void env_levels(const EnvMips& m, float level, bool use_mips, EnvSample& s)
 {
     const int top = use_mips ? m.n - 1 : 0;
     const float lc = fminf(fmaxf(level, 0.f), (float)top);
@@ -162,6 +170,12 @@ __device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, fl
     s.l0 = min((int)floorf(lc), top);
     s.l1 = min(s.l0 + 1, top);
     s.f = lc - (float)s.l0;
+}
+
+// trilinear seamless cube fetch (pre-sigmoid); fills what the backward needs
+__device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, float level, bool use_mips, EnvSample& s, Taps tp[2])
+{
+    env_levels(m, level, use_mips, s);
     float v[2][3];
     // the taps of both levels first, then all eight 12-byte texel loads in flight together (unconditional: a missing corner tap has
     // index 0 and weight 0 -- behind a condition every load waited for the one before)
@@ -200,7 +214,7 @@ __device__ __forceinline__ void env_fetch(const EnvMips& m, const FaceUV& fu, fl
     }
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return shade_rcp(1.0f + __expf(-x)); }
 
 // wave64 sum (DPP), result valid in every lane after the final readlane
 __device__ __forceinline__ float wave_sum_all(float v)
@@ -344,7 +358,11 @@ __device__ __forceinline__ void acc_add(const EnvMips& m, const ShadeAcc& A, int
 {
     if (loff >= 0) {
         float* a = A.dense + loff + idx * 3;
+#ifdef MRGS_X_INT_ATOMICS   // developer timing build (results are wrong): what the accumulation would cost with integer LDS atomics
+        atomicAdd((int*)a, (int)(v[0] * 65536.f)); atomicAdd((int*)a + 1, (int)(v[1] * 65536.f)); atomicAdd((int*)a + 2, (int)(v[2] * 65536.f));
+#else
         atomicAdd(a, v[0]); atomicAdd(a + 1, v[1]); atomicAdd(a + 2, v[2]);
+#endif
         return;
     }
     const unsigned key = ((unsigned)lk << 24) | (unsigned)idx;
@@ -358,7 +376,11 @@ __device__ __forceinline__ void acc_add(const EnvMips& m, const ShadeAcc& A, int
     }
     if (slot >= 0) {
         float* a = A.vals + slot * 3;
+#ifdef MRGS_X_INT_ATOMICS
+        atomicAdd((int*)a, (int)(v[0] * 65536.f)); atomicAdd((int*)a + 1, (int)(v[1] * 65536.f)); atomicAdd((int*)a + 2, (int)(v[2] * 65536.f));
+#else
         atomicAdd(a, v[0]); atomicAdd(a + 1, v[1]); atomicAdd(a + 2, v[2]);
+#endif
     } else {
         float* g = m.grad[lk] + (size_t)(blockIdx.x % (unsigned)m.copies[lk]) * (size_t)(6 * m.res[lk] * m.res[lk] * 3) + (size_t)idx * 3;
         atomicAdd(g, v[0]); atomicAdd(g + 1, v[1]); atomicAdd(g + 2, v[2]);
@@ -391,7 +413,11 @@ __device__ __forceinline__ void env_scatter_tile(const EnvMips& m, unsigned grad
 #else
             const bool last = run_merge(key, v);
 #endif
+#ifdef MRGS_X_NO_ACC       // developer timing build: everything but the accumulation (results are wrong)
+            if (last && key == 0x12345678u && v[0] == 1e30f) acc_add(m, A, lk, loff, tp[k].idx[q], v);
+#else
             if (last && key != MRGS_SHADE_KEY_NONE) acc_add(m, A, lk, loff, tp[k].idx[q], v);
+#endif
         }
     }
 }
@@ -518,9 +544,9 @@ __device__ __forceinline__ ShadeIn shade_load(int x, int y, const Map& albedo, c
     return in;
 }
 
-__device__ __forceinline__ void shade_setup(const ShadeCamS& cam, int x, int y, const ShadeIn& in, const float* __restrict__ lut, int lres, ShadePix& p)
+// w_o of a pixel: sample_camera_rays (utils/refl_utils.py:54-73), pixel centres at integer coordinates
+__device__ __forceinline__ f3 shade_view_dir(const ShadeCamS& cam, int x, int y)
 {
-    // sample_camera_rays (utils/refl_utils.py:54-73): pixel centres at integer coordinates
     const float fx_ = (float)x, fy_ = (float)y;
     const f3 pc = mk(cam.Kinv[0] * fx_ + cam.Kinv[1] * fy_ + cam.Kinv[2], cam.Kinv[3] * fx_ + cam.Kinv[4] * fy_ + cam.Kinv[5],
                      cam.Kinv[6] * fx_ + cam.Kinv[7] * fy_ + cam.Kinv[8]);
@@ -529,14 +555,31 @@ __device__ __forceinline__ void shade_setup(const ShadeCamS& cam, int x, int y, 
     const f3 q = mk(pc.x - cam.t[0], pc.y - cam.t[1], pc.z - cam.t[2]);
     const f3 pw = mk(R[0] * q.x + R[1] * q.y + R[2] * q.z, R[3] * q.x + R[4] * q.y + R[5] * q.z, R[6] * q.x + R[7] * q.y + R[8] * q.z);
     f3 rd = mk(pw.x - cam.ro[0], pw.y - cam.ro[1], pw.z - cam.ro[2]);
-    const float inv = 1.0f / sqrtf(dot3(rd, rd));
+    const float inv = __builtin_amdgcn_rsqf(dot3(rd, rd));
     rd = mk(rd.x * inv, rd.y * inv, rd.z * inv);
-    p.wo = mk(-rd.x, -rd.y, -rd.z);
+    return mk(-rd.x, -rd.y, -rd.z);
+}
+
+// the unit mirror direction of a pixel (what shade_setup leaves in ShadePix::rn: the scatter launch of the backward forms it again)
+__device__ __forceinline__ f3 shade_mirror_dir(const ShadeCamS& cam, int x, int y, f3 n)
+{
+    const f3 wo = shade_view_dir(cam, x, y);
+    const float ndv = dot3(wo, n);                              // reflection(), :95-98
+    const f3 r = mk(2.f * n.x * ndv - wo.x, 2.f * n.y * ndv - wo.y, 2.f * n.z * ndv - wo.z);
+    const float rlen = fmaxf(__builtin_amdgcn_sqrtf(dot3(r, r)), 1e-20f);        // safe_normalize
+    const float irl = shade_rcp(rlen);
+    return mk(r.x * irl, r.y * irl, r.z * irl);
+}
+
+__device__ __forceinline__ void shade_setup(const ShadeCamS& cam, int x, int y, const ShadeIn& in, const float* __restrict__ lut, int lres, ShadePix& p)
+{
+    p.wo = shade_view_dir(cam, x, y);
     p.n = mk(in.n[0], in.n[1], in.n[2]);
     p.ndv = dot3(p.wo, p.n);                                    // reflection(), :95-98
     p.r = mk(2.f * p.n.x * p.ndv - p.wo.x, 2.f * p.n.y * p.ndv - p.wo.y, 2.f * p.n.z * p.ndv - p.wo.z);
-    p.rlen = fmaxf(sqrtf(dot3(p.r, p.r)), 1e-20f);              // safe_normalize
-    p.rn = mk(p.r.x / p.rlen, p.r.y / p.rlen, p.r.z / p.rlen);
+    p.rlen = fmaxf(__builtin_amdgcn_sqrtf(dot3(p.r, p.r)), 1e-20f);              // safe_normalize
+    const float irl = shade_rcp(p.rlen);
+    p.rn = mk(p.r.x * irl, p.r.y * irl, p.r.z * irl);
     p.rough = in.rough;
     p.refl = in.refl;
     p.alpha = in.alpha;
@@ -555,15 +598,28 @@ __device__ __forceinline__ float shade_lin2srgb(float x)        // linear_to_srg
     return x <= 0.0031308f ? (323.0f / 25.0f) * x : (211.0f * powf(fmaxf(x, eps), 5.0f / 12.0f) - 11.0f) / 200.0f;
 }
 
+__device__ __forceinline__ float shade_lin2srgb_grad(float x)   // d linear_to_srgb / dx (mrgs_maps.hip: lin2srgb_grad, the same expression)
+{
+    const float eps = 1.1920928955078125e-07f;
+    if (x <= 0.0031308f) return 323.0f / 25.0f;
+    return x >= eps ? (211.0f / 200.0f) * (5.0f / 12.0f) * powf(x, -7.0f / 12.0f) : 0.0f;
+}
+
 __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha,
                                                                  Map refl, Map rough, const float* __restrict__ lut, int lres,
                                                                  float* __restrict__ specular /*[3,H,W]*/, float* __restrict__ direct /*[3,H,W]*/,
                                                                  float* __restrict__ weight /*[H,W,3]*/,
                                                                  // render_surfel's compositing in the same pass (render != nullptr; mrgs_surfel_composite_forward)
                                                                  const float* __restrict__ base /*[3,H,W]*/, const float* __restrict__ bg, int srgb,
-                                                                 float* __restrict__ render /*[3,H,W]*/, float* __restrict__ diffuse /*[3,H,W]*/)
+                                                                 float* __restrict__ render /*[3,H,W]*/, float* __restrict__ diffuse /*[3,H,W]*/,
+                                                                 float* __restrict__ zero_fill, long long zero_floats)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    {   // side job for the backward of this very render: clear the texel-gradient buffers its shading backward accumulates into (a fill
+        // launch of its own otherwise: the backward's first kernel is the one that accumulates)
+        const long long tid = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, nthr = (long long)gridDim.x * gridDim.y * 256;
+        for (long long i = tid; i < zero_floats; i += nthr) zero_fill[i] = 0.0f;
+    }
     if (x >= W || y >= H) return;
     const ShadeCamS cs = shade_cam_load(cam);
     const ShadeIn in = shade_load(x, y, albedo, normal, alpha, refl, rough);
@@ -594,32 +650,37 @@ __global__ void __launch_bounds__(256) shade_specular_fwd_kernel(EnvMips m, Shad
     }
 }
 
+// ---- backward of the deferred shading -----------------------------------------------------------------------------------------
 // Persistent workgroups (one per CU, 12 waves): each keeps an LDS copy of the texel gradients of the coarse mip levels
 // (<= MRGS_SHADE_LDS_FLOATS floats: 32x32 and 16x16 cubemap levels = 90 KB) and a hash table for the finer ones (64 KB), walks
-// 64x12-pixel tiles of the image and flushes both at the end (see "texel-gradient accumulation" above).
-#ifndef MRGS_SHADE_BWD_THREADS
-#define MRGS_SHADE_BWD_THREADS 768
-#endif
+// 64x12-pixel tiles of the image and flushes both at the end (see "texel-gradient accumulation" above).  COMPOSITE: render_surfel's
+// compositing backward (gaussian_renderer/__init__.py:436-445) in front of the shading's, in the same lane: its shares of g_specular,
+// g_refl and g_alpha never leave registers (rounds 2-5 ran it as a launch of its own, 10.7 us for 36 bytes a pixel each way).
+// Round 6 measured the alternative the register count suggests (168 VGPRs, a dozen spilled, three waves per SIMD) -- a per-pixel launch
+// without LDS (134 VGPRs, no spill) that leaves the pixel's d loss / d sample in a scratch map, and a scatter launch that recomputes the
+// taps (72 VGPRs): 35 + 45 us against this kernel's 69.  The scatter launch alone is 11 us of loop, loads, accumulator set-up and flush,
+// + 10 of recomputed taps, + 4 of run merging, + 20 of LDS float atomics and hash probes (8 with integer atomics): the persistent
+// form hides the accumulation's latency behind the fetch of the next pixel, the split form pays both in turn.  Dropped.
 #define MRGS_SHADE_LDS_FLOATS 23552
-#ifndef MRGS_SHADE_FLUSH_EVERY
-#define MRGS_SHADE_FLUSH_EVERY 4      // tiles between two looks at the hash table's fill (a barrier pair each: 69.8 us with 1, 62.5 with 4 or 8)
+#ifndef MRGS_SHADE_FUSED_THREADS
+#define MRGS_SHADE_FUSED_THREADS 768
 #endif
-__global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_kernel(
+template <bool COMPOSITE>
+__global__ void __launch_bounds__(MRGS_SHADE_FUSED_THREADS) shade_fused_bwd_kernel(
     EnvMips m, ShadeCam cam, int H, int W, Map albedo, Map normal, Map alpha, Map refl, Map rough, const float* __restrict__ lut, int lres,
     const float* __restrict__ g_specular, const float* __restrict__ g_direct, const float* __restrict__ g_weight,
     float* __restrict__ g_albedo /*[H,W,3]*/, float* __restrict__ g_normal /*[H,W,3]*/, float* __restrict__ g_alpha /*[H,W]*/,
     float* __restrict__ g_refl /*[H,W]*/, float* __restrict__ g_rough /*[H,W]*/, int tiles_x, int ntiles, int lds_floats,
-    // render_surfel's form (g_features != nullptr): the per-pixel gradients leave as the rasterizer's [8,H,W] feature-map gradient
-    // (refl + the compositing backward's share, roughness, albedo, zeros for the indirect radiance) and as the TOTAL alpha gradient
-    // (+ the compositing backward's) -- what mrgs_surfel_feature_grads would assemble from five maps in a launch of its own
-    float* __restrict__ g_features, const float* __restrict__ g_refl_composite, const float* __restrict__ g_alpha_composite)
+    float* __restrict__ g_features, const float* __restrict__ g_refl_composite, const float* __restrict__ g_alpha_composite,
+    int srgb, const float* __restrict__ base, const float* __restrict__ spec_fwd, const float* __restrict__ bg,
+    const float* __restrict__ g_render, const float* __restrict__ g_diffuse, float* __restrict__ g_base)
 {
     __shared__ float s_grad[MRGS_SHADE_LDS_FLOATS];
     __shared__ unsigned s_keys[MRGS_SHADE_HASH_SIZE];
     __shared__ float s_vals[MRGS_SHADE_HASH_SIZE * 3];
     __shared__ unsigned s_count;
-    for (int i = threadIdx.x; i < lds_floats; i += MRGS_SHADE_BWD_THREADS) s_grad[i] = 0.f;
-    for (int i = threadIdx.x; i < MRGS_SHADE_HASH_SIZE; i += MRGS_SHADE_BWD_THREADS) { s_keys[i] = MRGS_SHADE_KEY_NONE; s_vals[3 * i] = 0.f; s_vals[3 * i + 1] = 0.f; s_vals[3 * i + 2] = 0.f; }
+    for (int i = threadIdx.x; i < lds_floats; i += MRGS_SHADE_FUSED_THREADS) s_grad[i] = 0.f;
+    for (int i = threadIdx.x; i < MRGS_SHADE_HASH_SIZE; i += MRGS_SHADE_FUSED_THREADS) { s_keys[i] = MRGS_SHADE_KEY_NONE; s_vals[3 * i] = 0.f; s_vals[3 * i + 1] = 0.f; s_vals[3 * i + 2] = 0.f; }
     if (threadIdx.x == 0) s_count = 0u;
     __syncthreads();
     const ShadeAcc A = {s_grad, s_keys, s_vals, &s_count};
@@ -631,18 +692,38 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
 #pragma unroll
     for (int i = 0; i < MRGS_MAX_MIPS; i++) grad_mask |= (i < m.n && m.grad[i] != nullptr) ? (1u << i) : 0u;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int x_ = (t % tiles_x) * 64 + (threadIdx.x & 63), y_ = (t / tiles_x) * (MRGS_SHADE_BWD_THREADS / 64) + (threadIdx.x >> 6);
+        const int x_ = (t % tiles_x) * 64 + (threadIdx.x & 63), y_ = (t / tiles_x) * (MRGS_SHADE_FUSED_THREADS / 64) + (threadIdx.x >> 6);
         const bool valid = x_ < W && y_ < H;    // out-of-image lanes stay alive (the texel scatter is wave-convergent)
         const int x = min(x_, W - 1), y = min(y_, H - 1);
         const size_t pix = (size_t)y * W + x;
         // every input of the pixel first: the maps and the upstream gradients are independent loads
         const ShadeIn in = shade_load(x, y, albedo, normal, alpha, refl, rough);
         float gs_[3], gd_[3], gw_[3];
+        float g_refl_c = 0.f, g_alpha_c = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             gs_[c] = (valid && g_specular) ? g_specular[c * HW + pix] : 0.f;
             gd_[c] = (valid && g_direct) ? g_direct[c * HW + pix] : 0.f;
             gw_[c] = (valid && g_weight) ? g_weight[pix * 3 + c] : 0.f;
+        }
+        if constexpr (COMPOSITE) {
+            // render = [srgb](k base + specular) + bg (1 - alpha), diffuse = k base, k = 1 - refl   (gaussian_renderer/__init__.py:436-445)
+            const float k = 1.0f - in.refl;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float b = base[c * HW + pix];
+                const float gR = (valid && g_render != nullptr) ? g_render[c * HW + pix] : 0.0f;
+                g_alpha_c -= bg[c] * gR;
+                float gl = gR;
+                if (srgb) gl *= shade_lin2srgb_grad(k * b + spec_fwd[c * HW + pix]);
+                const float gd = gl + ((valid && g_diffuse != nullptr) ? g_diffuse[c * HW + pix] : 0.0f);
+                if (valid) g_base[c * HW + pix] = k * gd;
+                g_refl_c -= b * gd;
+                gs_[c] += gl;
+            }
+        } else if (g_features != nullptr) {
+            g_refl_c = g_refl_composite[pix];
+            g_alpha_c = g_alpha_composite[pix];
         }
         ShadePix p;
         shade_setup(cs, x, y, in, lut, lres, p);
@@ -656,8 +737,8 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float light = sigmoidf(s.L[c]);
-            const float base = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
-            const float wgt = base * p.fg[0] + p.fg[1];
+            const float basec = 0.04f * (1.f - p.refl) + p.albedo[c] * p.refl;
+            const float wgt = basec * p.fg[0] + p.fg[1];
             const float gs = gs_[c];
             const float gd = gd_[c] + gs * p.alpha * wgt;
             const float gw = gw_[c] + gs * light * p.alpha;
@@ -665,7 +746,7 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
             gL[c] = gd * light * (1.f - light);
             galb[c] = gw * p.refl * p.fg[0];
             gm += gw * (p.albedo[c] - 0.04f) * p.fg[0];
-            gfg0 += gw * base;
+            gfg0 += gw * basec;
             gfg1 += gw;
         }
         f3 g_rn;
@@ -673,7 +754,8 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
         env_fetch_bwd<false>(m, fu, p.rn, s, tp, gL, g_rn, g_level);
         // safe_normalize backward (the 1e-20 clamp never binds for finite normals)
         const float rg = dot3(p.rn, g_rn);
-        const f3 g_r = mk((g_rn.x - p.rn.x * rg) / p.rlen, (g_rn.y - p.rn.y * rg) / p.rlen, (g_rn.z - p.rn.z * rg) / p.rlen);
+        const float irl = shade_rcp(p.rlen);
+        const f3 g_r = mk((g_rn.x - p.rn.x * rg) * irl, (g_rn.y - p.rn.y * rg) * irl, (g_rn.z - p.rn.z * rg) * irl);
         // r = 2 n (n.wo) - wo ; NdotV = n.wo feeds the LUT's u coordinate
         const float g_ndv = p.u_in ? gfg0 * p.dfg_du[0] + gfg1 * p.dfg_du[1] : 0.f;
         const float grn = dot3(g_r, p.n);
@@ -683,8 +765,8 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
         if (valid) {
             g_normal[pix * 3] = gn.x; g_normal[pix * 3 + 1] = gn.y; g_normal[pix * 3 + 2] = gn.z;
             if (g_features != nullptr) {
-                g_alpha[pix] = g_alpha_composite[pix] + ga;
-                g_features[pix] = g_refl_composite[pix] + gm;
+                g_alpha[pix] = g_alpha_c + ga;
+                g_features[pix] = g_refl_c + gm;
                 g_features[HW + pix] = g_rough_v;
 #pragma unroll
                 for (int c = 0; c < 3; c++) { g_features[(2 + c) * HW + pix] = galb[c]; g_features[(5 + c) * HW + pix] = 0.0f; }
@@ -696,26 +778,29 @@ __global__ void __launch_bounds__(MRGS_SHADE_BWD_THREADS) shade_specular_bwd_ker
                 g_rough[pix] = g_rough_v;
             }
         }
-        env_scatter_tile(m, grad_mask, A, s, tp, gL);
+        if (!valid) { gL[0] = 0.f; gL[1] = 0.f; gL[2] = 0.f; }
+        // (a wave of pixels that saw no environment light -- background: alpha = 0 makes gL an exact zero -- has nothing to add)
+        if (grad_mask != 0u && __builtin_amdgcn_ballot_w64(gL[0] != 0.f || gL[1] != 0.f || gL[2] != 0.f) != 0ull)
+            env_scatter_tile(m, grad_mask, A, s, tp, gL);
         // between tiles: a hash table more than half full goes out
-        if (++since_check < MRGS_SHADE_FLUSH_EVERY) continue;
+        if (++since_check < 4) continue;
         since_check = 0;
         __syncthreads();
         const unsigned taken = s_count;                    // same value in every thread: entries are only taken before the barrier above
         if (taken - flushed_at > MRGS_SHADE_HASH_SIZE / 2) {
-            acc_flush_hash(m, A, MRGS_SHADE_BWD_THREADS);
+            acc_flush_hash(m, A, MRGS_SHADE_FUSED_THREADS);
             flushed_at = taken;
         }
         __syncthreads();
     }
     // flush: the hash table, then the LDS-resident levels into one of the level's global copies (untouched texels are skipped)
-    __syncthreads();                 // every wave has left the tile loop (the loop only meets at a barrier every MRGS_SHADE_FLUSH_EVERY tiles)
-    acc_flush_hash(m, A, MRGS_SHADE_BWD_THREADS);
+    __syncthreads();                 // every wave has left the tile loop (the loop only meets at a barrier every fourth tile)
+    acc_flush_hash(m, A, MRGS_SHADE_FUSED_THREADS);
     for (int l = 0; l < m.n; l++) {
         if (m.lds_off[l] < 0 || m.grad[l] == nullptr) continue;
         const int n = 6 * m.res[l] * m.res[l] * 3;
         float* dst = m.grad[l] + (size_t)(blockIdx.x % (unsigned)m.copies[l]) * (size_t)n;
-        for (int i = threadIdx.x; i < n; i += MRGS_SHADE_BWD_THREADS) {
+        for (int i = threadIdx.x; i < n; i += MRGS_SHADE_FUSED_THREADS) {
             const float v = s_grad[m.lds_off[l] + i];
             if (v != 0.f) atomicAdd(dst + i, v);
         }
@@ -1285,52 +1370,66 @@ int mrgs_envmap_lookup_backward(const MrgsEnvMips* mips, int64_t N, const float*
 }
 
 static int shade_specular_forward_impl(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, float* specular, float* direct_light, float* specular_weight,
-                                       const float* base_color, const float* bg, int srgb, float* render, float* diffuse, void* stream)
+                                       const float* base_color, const float* bg, int srgb, float* render, float* diffuse, float* zero_fill,
+                                       int64_t zero_floats, void* stream)
 {
     EnvMips m;
     int rc = make_mips(mips, m);
     if (rc) return rc;
     if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || fr->lut_res < 1 || !specular || !direct_light || !specular_weight)
         return MRGS_E_BAD_ARG;
+    if (zero_floats < 0 || (zero_floats > 0 && !zero_fill)) return MRGS_E_BAD_ARG;
     ShadeCam cam;
     for (int i = 0; i < 9; i++) cam.Kinv[i] = fr->Kinv[i];
     cam.R = fr->R; cam.T = fr->T;
     const dim3 grid((fr->W + 63) / 64, (fr->H + 3) / 4), block(256);
     hipLaunchKernelGGL(shade_specular_fwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
                        to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, specular, direct_light, specular_weight,
-                       base_color, bg, srgb, render, diffuse);
+                       base_color, bg, srgb, render, diffuse, zero_fill, (long long)zero_floats);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
 int mrgs_shade_specular_forward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, float* specular, float* direct_light, float* specular_weight,
                                 void* stream)
 {
-    return shade_specular_forward_impl(mips, fr, specular, direct_light, specular_weight, nullptr, nullptr, 0, nullptr, nullptr, stream);
+    return shade_specular_forward_impl(mips, fr, specular, direct_light, specular_weight, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int mrgs_shade_specular_forward_composite(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* base_color, const float* bg, int32_t srgb,
-                                          float* specular, float* direct_light, float* specular_weight, float* render, float* diffuse, void* stream)
+                                          float* specular, float* direct_light, float* specular_weight, float* render, float* diffuse,
+                                          float* zero_fill, int64_t zero_floats, void* stream)
 {
     if (!base_color || !bg || !render || !diffuse) return MRGS_E_BAD_ARG;
-    return shade_specular_forward_impl(mips, fr, specular, direct_light, specular_weight, base_color, bg, srgb ? 1 : 0, render, diffuse, stream);
+    return shade_specular_forward_impl(mips, fr, specular, direct_light, specular_weight, base_color, bg, srgb ? 1 : 0, render, diffuse, zero_fill,
+                                       zero_floats, stream);
 }
+
+// composite != nullptr: render_surfel's compositing backward in the same launch (mrgs_surfel_shade_composite_backward)
+struct ShadeCompositeArgs { int srgb; const float *base, *spec_fwd, *bg, *g_render, *g_diffuse; float* g_base; };
 
 static int shade_specular_backward_impl(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
                                         const float* g_specular_weight, float* g_albedo, float* g_normal, float* g_alpha, float* g_refl,
                                         float* g_roughness, float* g_features, const float* g_refl_composite, const float* g_alpha_composite,
-                                        void* stream)
+                                        const ShadeCompositeArgs* composite, void* stream)
 {
     EnvMips m;
     int rc = make_mips(mips, m);
     if (rc) return rc;
     if (!fr || fr->H <= 0 || fr->W <= 0 || !fr->R || !fr->T || !fr->lut || !g_normal || !g_alpha) return MRGS_E_BAD_ARG;
-    if (g_features ? (!g_refl_composite || !g_alpha_composite) : (!g_albedo || !g_refl || !g_roughness)) return MRGS_E_BAD_ARG;
+    if (composite ? (!g_features || !composite->base || !composite->spec_fwd || !composite->bg || !composite->g_base)
+                  : (g_features ? (!g_refl_composite || !g_alpha_composite) : (!g_albedo || !g_refl || !g_roughness))) return MRGS_E_BAD_ARG;
     // the scatter keys pack (level << 24 | texel index): a level with 6 res^2 >= 2^24 texels (res >= 1673) would alias into the level bits
     for (int l = 0; l < m.n; l++)
         if (m.grad[l] != nullptr && 6ll * m.res[l] * m.res[l] >= (1ll << 24)) return MRGS_E_UNSUPPORTED;
     ShadeCam cam;
     for (int i = 0; i < 9; i++) cam.Kinv[i] = fr->Kinv[i];
     cam.R = fr->R; cam.T = fr->T;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+        else n_cu = 256;
+    }
     // LDS-resident levels: from the coarsest up while they fit
     int lds_floats = 0;
     for (int l = m.n - 1; l >= 0; l--) {
@@ -1339,19 +1438,19 @@ static int shade_specular_backward_impl(const MrgsEnvMips* mips, const MrgsShade
         m.lds_off[l] = lds_floats;
         lds_floats += n;
     }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
-        else n_cu = 256;
-    }
-    const int rows = MRGS_SHADE_BWD_THREADS / 64;
+    const int rows = MRGS_SHADE_FUSED_THREADS / 64;
     const int tiles_x = (fr->W + 63) / 64, ntiles = tiles_x * ((fr->H + rows - 1) / rows);
-    const dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(MRGS_SHADE_BWD_THREADS);
-    hipLaunchKernelGGL(shade_specular_bwd_kernel, grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
-                       to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, g_specular, g_direct_light,
-                       g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness, tiles_x, ntiles, lds_floats, g_features, g_refl_composite,
-                       g_alpha_composite);
+    const dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(MRGS_SHADE_FUSED_THREADS);
+    if (composite)
+        hipLaunchKernelGGL((shade_fused_bwd_kernel<true>), grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
+                           to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, g_specular, g_direct_light, g_specular_weight,
+                           g_albedo, g_normal, g_alpha, g_refl, g_roughness, tiles_x, ntiles, lds_floats, g_features, g_refl_composite, g_alpha_composite,
+                           composite->srgb, composite->base, composite->spec_fwd, composite->bg, composite->g_render, composite->g_diffuse, composite->g_base);
+    else
+        hipLaunchKernelGGL((shade_fused_bwd_kernel<false>), grid, block, 0, (hipStream_t)stream, m, cam, fr->H, fr->W, to_map(fr->albedo), to_map(fr->normal),
+                           to_map(fr->alpha), to_map(fr->refl), to_map(fr->roughness), fr->lut, fr->lut_res, g_specular, g_direct_light, g_specular_weight,
+                           g_albedo, g_normal, g_alpha, g_refl, g_roughness, tiles_x, ntiles, lds_floats, g_features, g_refl_composite, g_alpha_composite,
+                           0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? MRGS_OK : MRGS_E_HIP;
 }
 
@@ -1360,7 +1459,7 @@ int mrgs_shade_specular_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* 
                                  float* g_roughness, void* stream)
 {
     return shade_specular_backward_impl(mips, fr, g_specular, g_direct_light, g_specular_weight, g_albedo, g_normal, g_alpha, g_refl, g_roughness,
-                                        nullptr, nullptr, nullptr, stream);
+                                        nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int mrgs_shade_specular_backward_features(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, const float* g_specular, const float* g_direct_light,
@@ -1369,7 +1468,18 @@ int mrgs_shade_specular_backward_features(const MrgsEnvMips* mips, const MrgsSha
 {
     if (!g_features) return MRGS_E_BAD_ARG;
     return shade_specular_backward_impl(mips, fr, g_specular, g_direct_light, g_specular_weight, nullptr, g_normal, g_alpha, nullptr, nullptr,
-                                        g_features, g_refl_composite, g_alpha_composite, stream);
+                                        g_features, g_refl_composite, g_alpha_composite, nullptr, stream);
+}
+
+int mrgs_surfel_shade_composite_backward(const MrgsEnvMips* mips, const MrgsShadeFrame* fr, int32_t srgb, const float* base_color, const float* specular,
+                                         const float* bg, const float* g_render, const float* g_diffuse, const float* g_specular_extra,
+                                         const float* g_direct_light, const float* g_specular_weight, float* g_base, float* g_normal, float* g_features,
+                                         float* g_alpha, void* stream)
+{
+    if (!g_features) return MRGS_E_BAD_ARG;
+    const ShadeCompositeArgs ca = {srgb, base_color, specular, bg, g_render, g_diffuse, g_base};
+    return shade_specular_backward_impl(mips, fr, g_specular_extra, g_direct_light, g_specular_weight, nullptr, g_normal, g_alpha, nullptr, nullptr,
+                                        g_features, nullptr, nullptr, &ca, stream);
 }
 
 int mrgs_cubemap_filter_count(int32_t res, int32_t kind, float roughness, float cos_cutoff, uint32_t* row_count, float* row_wsum, void* stream)

@@ -26,6 +26,27 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SYMBOLS) == set(names)
 
 
+def declared_prototypes():
+    """name -> number of parameters, from the prototypes of include/mrgs.h (comments removed; `(void)` = 0)."""
+    src = open(os.path.join(ROOT, "include", "mrgs.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(mrgs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        params = m.group(2).strip()
+        out[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_ctypes_prototypes_have_the_headers_parameter_counts():
+    """Every prototype of materialrefgs_amd/_lib.py takes as many arguments as the declaration in include/mrgs.h it binds (a binding that is
+    one pointer short or long fails on the CPU, not in the first backward on a GPU box)."""
+    from materialrefgs_amd import _lib
+    protos = declared_prototypes()
+    assert set(protos) == set(_lib.SYMBOLS)
+    for name, (_res, argtypes) in _lib.SYMBOLS.items():
+        assert len(argtypes) == protos[name], (name, len(argtypes), protos[name])
+
+
 def test_size_queries_and_error_strings():
     from materialrefgs_amd import _lib
     L = _lib.lib()

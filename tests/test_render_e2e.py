@@ -257,6 +257,29 @@ def test_lazy_prefilter_on_the_side_stream_equals_the_plain_path(gpu_device, gra
             assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-12), i
 
 
+@pytest.mark.gpu
+def test_a_second_backward_over_the_same_render_gets_clean_texel_gradients(gpu_device):
+    """The texel-gradient buffers of render_surfel's shading backward are allocated and cleared by the FORWARD of the render (the backward
+    is one launch that accumulates into them) and are good for one backward: a second backward over the retained graph must not add to
+    what the first one left there."""
+    from materialrefgs_amd.renderer import render_surfel
+    dev = gpu_device
+    P, H, W = 5000, 128, 160
+    _, _, pc_h, env = _models(P, H, W, seed=6, dev=dev)
+    env.build_mips()
+    out = render_surfel(orbit_camera(1, H, W).to(dev), pc_h, SimpleNamespace(depth_ratio=0.0, debug=False), torch.zeros(3, device=dev), srgb=False,
+                        opt=SimpleNamespace(indirect=False))
+    loss = out["render"].sum() + 0.5 * out["specular_map"].sum()
+    grads = []
+    for _ in range(3):
+        env.base.grad = None
+        loss.backward(retain_graph=True)
+        grads.append(env.base.grad.clone())
+    assert float(grads[0].abs().max()) > 0
+    for g in grads[1:]:
+        assert float((g - grads[0]).abs().max()) <= 1e-5 * float(grads[0].abs().max())      # (float atomics: equal to rounding)
+
+
 # ---------------------------------------------------------------------------------------------------------------- render_volume
 VOL_KEYS = ("render", "refl_strength_map", "diffuse_map", "specular_map", "base_color_map", "roughness_map", "rend_alpha", "rend_normal",
             "rend_dist", "surf_depth", "surf_normal")
