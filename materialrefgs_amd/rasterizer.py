@@ -35,79 +35,108 @@ _WORK_HINTS_MAX_BYTES = 256 << 20         # ... and device bytes the cache may p
 _WORK_HINTS_BYTES = [0]
 
 
-def _hint_key(raster_settings, device, P):
-    # P: the hint orders the blend waves of ONE surfel set seen from one camera; after densification / pruning, or for another model
-    # rendered through the same camera object, the deal would be balanced for a different scene (results would still be right)
+def _hint_key(raster_settings, device):
+    """A camera's identity for the hint cache: the device, the image size and the addresses of its two matrices.  NOT the surfel count:
+    what a hint holds is image-space -- the work each 8x8 block cost, the queues its (tile, quadrant) items were dealt into -- and a
+    densification or pruning step (every 100 iterations until iteration 25 000-30 000 of the reference's 50 000,
+    arguments/__init__.py:159-162) changes that picture by a few per cent, not into another one: the next visit orders its waves by the
+    work the camera measured before the step (round 5 keyed by P as well, and every visit of the densifying phase was a first visit)."""
     vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
-    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr(), int(P))
+    return (device.index, int(raster_settings.image_height), int(raster_settings.image_width), vm.data_ptr(), pm.data_ptr())
 
 
-def _hint_entry(raster_settings, device, P):
-    """The (hint buffer, viewmatrix, projmatrix, versions, visits) entry of this camera and surfel count, or None when it was never
-    rendered or when its matrices were written in place since."""
-    key = _hint_key(raster_settings, device, P)
+class _Hint:
+    """One camera's entry: the hint buffer, the two matrices (kept alive: their addresses are the key) with their versions, the number
+    of renders whose measured work the buffer has received, and which surfel set the queues in the buffer were last DEALT for -- the
+    condition of MRGS_HINT_REUSE_ORDER (a reused deal balances the scene it was made for; after a change of the set the next visit
+    orders anew, from the measured work that is there)."""
+    __slots__ = ("buf", "vm", "pm", "versions", "visits", "dealt_for")
+
+    def __init__(self, buf, vm, pm):
+        self.buf, self.vm, self.pm, self.versions, self.visits, self.dealt_for = buf, vm, pm, (vm._version, pm._version), 0, None
+
+
+_GENERATION = [0]       # bumped by note_surfel_set_changed(): a surfel set of the same size as before is still another set
+
+
+def _hint_entry(raster_settings, device, P=None):
+    """The entry of this camera, or None when it was never rendered or when its matrices were written in place since."""
+    key = _hint_key(raster_settings, device)
     ent = _WORK_HINTS.get(key)
     if ent is None:
         return None
     vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
-    if ent[3] != (vm._version, pm._version):
+    if ent.versions != (vm._version, pm._version):
         return None
     _WORK_HINTS[key] = _WORK_HINTS.pop(key)      # most recently used last (dicts keep insertion order)
     return ent
 
 
-def _hint_is_warm(raster_settings, device, P):
-    """True when this camera was rendered before, i.e. its hint holds measured work.  Only then may the forward set up the backward's
-    queues (they are a copy of its own): built from the cull counts alone they balance the backward a third worse than the
-    backward's own ordering by what the forward waves walked."""
-    ent = _hint_entry(raster_settings, device, P)
-    return ent is not None and ent[4][0] > 0
+def _hint_is_warm(raster_settings, device, P=None):
+    """True when this camera was rendered before, i.e. its hint holds measured work (of whichever surfel set).  Only then may the forward
+    set up the backward's queues (they are a copy of its own): built from the cull counts alone they balance the backward a third worse
+    than the backward's own ordering by what the forward waves walked."""
+    ent = _hint_entry(raster_settings, device)
+    return ent is not None and ent.visits > 0
 
 
 _REORDER_EVERY = 16     # visits of a camera between two orderings of its blend waves (MRGS_HINT_REUSE_ORDER in between)
 _NO_REUSE = bool(int(__import__("os").environ.get("MRGS_NO_REUSE_ORDER", "0")))   # developer switch for A/B timing
 
 
-def _hint_flags(raster_settings, device, P):
-    """MRGS_HINT_REUSE_ORDER for this forward: the camera's hint buffer holds the queues an ordering launch dealt at its second visit or
-    later (from measured work), and the forward deals its waves the same way again instead of ordering them anew -- the ordering is 15 us
-    of a 0.5 ms view and changes little from one visit to the next.  Every _REORDER_EVERY-th visit orders again."""
-    if _NO_HINT or _NO_REUSE:
+def _hint_flags(raster_settings, device, P, forward=False):
+    """MRGS_HINT_REUSE_ORDER for this forward: the camera's hint buffer holds the queues an ordering launch dealt from measured work for
+    THIS surfel set, and the forward deals its waves the same way again instead of ordering them anew -- the ordering is 15 us of a
+    0.5 ms view and changes little from one visit to the next.  Every _REORDER_EVERY-th visit orders again, and so does the first visit
+    after the surfel set changed (another P, or note_surfel_set_changed()).  forward=True: the call that decides for a forward -- it
+    records that the ordering launch of this forward deals the queues for (P, generation); the backward's struct carries no such flag."""
+    if _NO_HINT or _NO_REUSE or not forward:
         return 0
-    ent = _hint_entry(raster_settings, device, P)
+    ent = _hint_entry(raster_settings, device)
     if ent is None:
         return 0
-    visits = ent[4][0]
-    return _lib.MRGS_HINT_REUSE_ORDER if (visits >= 2 and visits % _REORDER_EVERY != 0) else 0
+    now = (int(P), _GENERATION[0])
+    if ent.visits >= 2 and ent.visits % _REORDER_EVERY != 0 and ent.dealt_for == now:
+        return _lib.MRGS_HINT_REUSE_ORDER
+    if ent.visits >= 1:
+        ent.dealt_for = now           # this forward orders from measured work: the deal in the buffer is this set's from here on
+    return 0
 
 
-def _work_hint(raster_settings, device, P, count_visit=False):
+def _work_hint(raster_settings, device, P=None, count_visit=False):
     if _NO_HINT:
         return None
-    ent = _hint_entry(raster_settings, device, P)
+    ent = _hint_entry(raster_settings, device)
     if ent is None:
         n = _lib.lib().mrgs_work_hint_bytes(int(raster_settings.image_height), int(raster_settings.image_width)) // 4
-        key = _hint_key(raster_settings, device, P)
+        key = _hint_key(raster_settings, device)
         old = _WORK_HINTS.pop(key, None)              # (stale: its matrices were written in place)
         if old is not None:
-            _WORK_HINTS_BYTES[0] -= old[0].numel() * 4
+            _WORK_HINTS_BYTES[0] -= old.buf.numel() * 4
         while _WORK_HINTS and (len(_WORK_HINTS) >= _WORK_HINTS_MAX or _WORK_HINTS_BYTES[0] + 4 * n > _WORK_HINTS_MAX_BYTES):
-            _WORK_HINTS_BYTES[0] -= _WORK_HINTS.pop(next(iter(_WORK_HINTS)))[0].numel() * 4      # (a render in flight keeps its buffer alive through its ctx)
-        vm, pm = raster_settings.viewmatrix, raster_settings.projmatrix
-        ent = (torch.zeros(max(int(n), 1), dtype=torch.int32, device=device), vm, pm, (vm._version, pm._version), [0])
+            _WORK_HINTS_BYTES[0] -= _WORK_HINTS.pop(next(iter(_WORK_HINTS))).buf.numel() * 4      # (a render in flight keeps its buffer alive through its ctx)
+        ent = _Hint(torch.zeros(max(int(n), 1), dtype=torch.int32, device=device), raster_settings.viewmatrix, raster_settings.projmatrix)
         _WORK_HINTS[key] = ent
-        _WORK_HINTS_BYTES[0] += ent[0].numel() * 4
+        _WORK_HINTS_BYTES[0] += ent.buf.numel() * 4
     if count_visit:
-        ent[4][0] += 1
-    return ent[0]
+        ent.visits += 1
+    return ent.buf
 
 
 def reset_work_hints():
-    """Forget every camera's measured work (the next render of each camera is a first visit again).  A training loop calls this after
-    densification / pruning changed the surfel set; bench.py uses it to time first visits."""
+    """Forget every camera's measured work (the next render of each camera is a first visit again); bench.py uses it to time first
+    visits.  A training loop does NOT need to call this after densification / pruning: see note_surfel_set_changed()."""
     _WORK_HINTS.clear()
     _WORK_HINTS_BYTES[0] = 0
     _CAM_COPIES.clear()
+
+
+def note_surfel_set_changed():
+    """The surfel set was replaced by another one of the SAME size (a prune and a clone that cancel, a re-initialisation in place): the
+    measured work of every camera stays -- it is image-space and still the best estimate there is -- but the next visit of each camera
+    orders its blend waves anew instead of reusing the deal made for the old set.  A change of the surfel COUNT is seen by the
+    rasterizer itself and needs no call."""
+    _GENERATION[0] += 1
 
 
 _ZERO_CONTRIB = {}
@@ -195,8 +224,9 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
     reset_work_hints(), an eviction or an in-place pose change, and a prepared backward would then pull item 0 in every wave); the
     forward leaves it out and gets the cache's.  Returns (cfg, inp, hint tensor)."""
     P = means3D.shape[0]
+    is_forward = work_hint is _RESOLVE
     if work_hint is _RESOLVE:
-        work_hint = _work_hint(raster_settings, means3D.device, P) if means3D.is_cuda else None
+        work_hint = _work_hint(raster_settings, means3D.device) if means3D.is_cuda else None
     S = features.shape[1] if features.dim() == 2 else 0
     M = sh.shape[1] if sh.numel() != 0 else 0
     if sh_rest is not None:       # split layout: sh = DC [P,1,3], sh_rest = [P,M-1,3]
@@ -209,7 +239,7 @@ def _make_cfg_inputs(raster_settings, means3D, sh, colors_precomp, features, opa
                            _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp),
                            _ptr(raster_settings.viewmatrix), _ptr(raster_settings.projmatrix), _ptr(raster_settings.campos),
                            _ptr(work_hint), _ptr(sh_rest),
-                           _ptr(bwd_grad_ws), (_hint_flags(raster_settings, means3D.device, P) if means3D.is_cuda else 0) | extra_flags,
+                           _ptr(bwd_grad_ws), (_hint_flags(raster_settings, means3D.device, P, forward=is_forward) if means3D.is_cuda else 0) | extra_flags,
                            int(getattr(_LIVE, "n", 0) or 0))
     return cfg, inp, work_hint
 
@@ -232,7 +262,7 @@ def _note_count(guess_key, num_rendered, hint_settings, dev):
         _PAIR_GUESS.pop(next(iter(_PAIR_GUESS)))
     _PAIR_GUESS[guess_key] = max(int(num_rendered * 1.25) + 65536, 1)
     if hint_settings is not None:
-        _work_hint(hint_settings, dev, guess_key[1], count_visit=True)   # this camera's hint now holds measured work (guess_key[1] = P)
+        _work_hint(hint_settings, dev, count_visit=True)   # this camera's hint now holds measured work
 
 
 class _PendingCount:
@@ -354,6 +384,13 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
         global LAST_NUM_RENDERED
         guess_key = (dev.index, P, H, W)
         guess = _PAIR_GUESS.get(guess_key)
+        if guess is None and P > 0:
+            # another surfel count at this image size (the step after a densification / pruning): the most recent count, scaled by the
+            # count ratio + 30 % -- a guess like any other (an overflow is reported and the view redone, exactly sized)
+            for (d_, p_, h_, w_), g_ in reversed(list(_PAIR_GUESS.items())):
+                if (d_, h_, w_) == (dev.index, H, W) and p_ > 0:
+                    guess = int(g_ * max(P / p_, 1.0) * 1.3)
+                    break
         pairs = None            # pair count the binning workspace is carved for (what the backward must be given)
         box = getattr(_DEFER, "box", None)
         if guess is not None and P > 0:
@@ -458,7 +495,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings._replace(bg=_f32c(raster_settings.bg), viewmatrix=_camera_f32c(raster_settings.viewmatrix),
                                       projmatrix=_camera_f32c(raster_settings.projmatrix), campos=_camera_f32c(raster_settings.campos))
         args = (rs, means3D, sh, colors_precomp, features, opacities, scales, rotations, cov3Ds_precomp, sh_rest,
-                any(ctx.needs_input_grad) and not _NO_PREPARE and means3D.is_cuda and _hint_is_warm(rs, means3D.device, means3D.shape[0]))
+                any(ctx.needs_input_grad) and not _NO_PREPARE and means3D.is_cuda and _hint_is_warm(rs, means3D.device))
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args[1:])   # copy them before they can be corrupted
             try:

@@ -241,17 +241,18 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     rz.reset_work_hints()
     a = HipRender(scene, cam, gpu_device)                   # hint zero -> cull counts
     assert len(rz._WORK_HINTS) == 1
-    (hint, vm, pm, _versions, visits), = rz._WORK_HINTS.values()
-    assert vm is a.rs.viewmatrix and pm is a.rs.projmatrix                     # the entry keeps the camera's tensors alive
-    assert int(hint.sum()) > 0 and visits[0] == 1                              # the forward stored its measured work
+    ent, = rz._WORK_HINTS.values()
+    hint = ent.buf
+    assert ent.vm is a.rs.viewmatrix and ent.pm is a.rs.projmatrix             # the entry keeps the camera's tensors alive
+    assert int(hint.sum()) > 0 and ent.visits == 1                             # the forward stored its measured work
     b = HipRender(scene, cam, gpu_device, rs=a.rs)          # same camera tensors: ordered by the measured work, backward prepared
-    assert len(rz._WORK_HINTS) == 1 and visits[0] == 2 and b.fn.prepared_grad_ws is not None and a.fn.prepared_grad_ws is None
+    assert len(rz._WORK_HINTS) == 1 and ent.visits == 2 and b.fn.prepared_grad_ws is not None and a.fn.prepared_grad_ws is None
     n_work = 4 * ((W + 15) // 16) * ((H + 15) // 16)      # the per-(tile, quadrant) work; the dealt queues of the camera lie behind it
     hint[:n_work].copy_(torch.randint(1, 4000, (n_work,), device=hint.device, dtype=torch.int32))
     c = HipRender(scene, cam, gpu_device, rs=a.rs)          # garbage hint: still only a schedule
     # a camera whose matrices were written in place is a new camera: its old hint is not used
     a.rs.viewmatrix.add_(0.0)
-    assert rz._hint_entry(a.rs, gpu_device, scene.means3D.shape[0]) is None
+    assert rz._hint_entry(a.rs, gpu_device) is None
     # other camera tensors (even with equal values) get their own entry
     d = HipRender(scene, cam, gpu_device)
     assert len(rz._WORK_HINTS) == 2 and d.fn.prepared_grad_ws is None
@@ -265,7 +266,9 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     rz.reset_work_hints()
     rs = raster_settings_of(a)
     runs = [HipRender(scene, cam, gpu_device, rs=rs) for _ in range(5)]
-    assert rz._hint_flags(rs, gpu_device, scene.means3D.shape[0]) == rz._lib.MRGS_HINT_REUSE_ORDER
+    P_ = scene.means3D.shape[0]
+    assert rz._hint_entry(rs, gpu_device).dealt_for == (P_, rz._GENERATION[0])
+    assert rz._hint_flags(rs, gpu_device, P_, forward=True) == rz._lib.MRGS_HINT_REUSE_ORDER and rz._hint_flags(rs, gpu_device, P_) == 0
     for k, r in enumerate(runs):
         assert torch.equal(r.color, a.color) and torch.equal(r.others, a.others), k
         assert (r.fn.prepared_grad_ws is not None) == (k >= 1), k
@@ -280,10 +283,27 @@ def test_work_hints_only_change_the_schedule(gpu_device):
     got = runs[3].backward(*g)
     for name in ref:
         assert rel_err(got[name], ref[name]) <= 1e-5, name
-    # ... and the cache is keyed by the surfel count as well: another model seen through the same camera tensors gets its own entry
+    # The cache is keyed by the camera alone: after densification / pruning (another surfel count) the camera's measured work serves on --
+    # the visit is WARM (ordered by that work, backward prepared) -- but the deal made for the old set is not reused: that visit orders anew,
+    # the ones after it reuse again.  The same after note_surfel_set_changed().  Results: those of a first visit, bit for bit.
+    rs2 = raster_settings_of(a)
+    [HipRender(scene, cam, gpu_device, rs=rs2) for _ in range(3)]
     n_before = len(rz._WORK_HINTS)
-    HipRender(make_shell_scene(1500, S=S, seed=5, radius_px=6.0, image_size=160), cam, gpu_device, rs=rs)
-    assert len(rz._WORK_HINTS) == n_before + 1
+    other = make_shell_scene(1500, S=S, seed=5, radius_px=6.0, image_size=160)
+    cold = HipRender(other, cam, gpu_device)                                  # the other scene through fresh camera tensors: a first visit
+    assert rz._hint_flags(rs2, gpu_device, 1500, forward=True) == 0           # (decides for the next forward: orders anew, deals for P = 1500)
+    warm = HipRender(other, cam, gpu_device, rs=rs2)
+    assert len(rz._WORK_HINTS) == n_before + 1 and warm.fn.prepared_grad_ws is not None and cold.fn.prepared_grad_ws is None
+    assert torch.equal(warm.color, cold.color) and torch.equal(warm.others, cold.others) and warm.num_rendered == cold.num_rendered
+    assert rz._hint_entry(rs2, gpu_device).dealt_for == (1500, rz._GENERATION[0])
+    again = HipRender(other, cam, gpu_device, rs=rs2)
+    assert torch.equal(again.color, cold.color)
+    assert rz._hint_flags(rs2, gpu_device, 1500, forward=True) == rz._lib.MRGS_HINT_REUSE_ORDER
+    rz.note_surfel_set_changed()
+    assert rz._hint_flags(rs2, gpu_device, 1500, forward=True) == 0
+    got, want = again.backward(*g), cold.backward(*g)
+    for name in want:
+        assert rel_err(got[name], want[name]) <= 1e-5, name
 
 
 def test_backward_in_two_halves_hands_out_the_colour_factor(gpu_device):
