@@ -669,7 +669,9 @@ int mrgs_sh_grad_expand_surfel_rows(int32_t P, int32_t D, int32_t V, const float
  * which: 0 depths f32[P], 1 means2D f32[P,2], 2 transMat f32[P,9], 3 normal_opacity f32[P,4], 4 rgb f32[P,3],
  * 5 tiles_touched u32[P], 6 clamped u8[P,3], 7 point_list u32[R], 8 ranges u32[tiles,2], 9 final_T f32[3,H,W],
  * 10 n_contrib u32[2,H,W], 11 depth-sorted gaussian order u32[P], 12 pixels the forward re-rendered exactly u32[2 + H W] ([0] their
- * count, from [2] their indices), 13 quadrant masks of the tile lists u8[R] (which 8x8 blocks of its tile an entry's box touches).
+ * count, from [2] their indices), 13 quadrant masks of the tile lists u8[R] (which 8x8 blocks of its tile an entry's box touches),
+ * 14 the block-cull records f32[P,12] (centre, A, C | B/C, B/A, det/C, det/A | mean2D, r^2 of the low-pass disc, bound of the centre's
+ * error -- csrc/mrgs_blend_math.h: CullConic; tools/cull_model.py restates them on the CPU).
  * dst is a device pointer. */
 int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const void* binning_ws, const void* img_ws,
                       int64_t num_rendered, int32_t which, void* dst, void* stream);

@@ -597,6 +597,7 @@ int mrgs_debug_export(const MrgsRasterConfig* cfg, const void* geom_ws, const vo
         MrgsBinWs b = mrgs_carve_bin(const_cast<void*>(binning_ws), R);
         if (R > 0) HIP_TRY(hipMemcpyAsync(dst, b.qmask, sizeof(uint8_t) * R, hipMemcpyDeviceToDevice, stream));
     } break;
+    case 14: if (P > 0) HIP_TRY(hipMemcpyAsync(dst, g.cull, sizeof(float4) * MRGS_CULL_F4 * (size_t)P, hipMemcpyDeviceToDevice, stream)); break;
     default: return MRGS_E_BAD_ARG;
     }
     HIP_TRY(hipGetLastError());

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_emit_kernel(int P, int per_g
             CullConic cc;
             cc.a = make_float4(rl(c.a.x, src), rl(c.a.y, src), rl(c.a.z, src), rl(c.a.w, src));
             cc.b = make_float4(rl(c.b.x, src), rl(c.b.y, src), rl(c.b.z, src), rl(c.b.w, src));
-            cc.c = make_float4(rl(c.c.x, src), rl(c.c.y, src), rl(c.c.z, src), 0.0f);
+            cc.c = make_float4(rl(c.c.x, src), rl(c.c.y, src), rl(c.c.z, src), rl(c.c.w, src));
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dk, src);
             const uint32_t id = (uint32_t)(i0 + (int)(threadIdx.x & ~63u) + src);
             for (int k = lane; k < sn; k += 64) {

@@ -316,7 +316,7 @@ __device__ __forceinline__ void mrgs_block_pixel(int block_x, int block_y, int l
 // two non-negative terms whose coefficients det / C, det / A, B / C, B / A are formed in fp64 by the preprocess; what is left of the
 // rounding (the centre and t0 are stored / formed in fp32) is taken off the distances before they are squared, so the value returned
 // is a LOWER bound of the true minimum.  A = 0 encodes "not an ellipse, always a candidate".
-struct CullConic { float4 a, b, c; };    // a = ex, ey, A, C | b = B/C, B/A, det/C, det/A | c = mean2D.xy, r^2 of the disc, unused
+struct CullConic { float4 a, b, c; };    // a = ex, ey, A, C | b = B/C, B/A, det/C, det/A | c = mean2D.xy, r^2 of the disc, bound of the centre's fp64 error
 __device__ __forceinline__ float mrgs_edge_min(float D, float Q, float slope, float X, float lo, float hi, float errX)
 {   // lower bound of min over t in [lo, hi] of D X^2 + Q (t - t0)^2, t0 = -slope X; X known to +- errX
     const float Xs = fmaxf(fabsf(X) - errX, 0.0f);
@@ -327,8 +327,10 @@ __device__ __forceinline__ float mrgs_edge_min(float D, float Q, float slope, fl
 }
 __device__ __forceinline__ bool mrgs_block_may_touch(const CullConic& c, float x0, float y0, float w, float h)
 {
-    // the centre is an fp32 rounding of the fp64 one, and it can lie far outside the image: the rectangle grows by that much
-    const float ex_err = 2e-7f * fabsf(c.a.x) + 1e-5f, ey_err = 2e-7f * fabsf(c.a.y) + 1e-5f;
+    // the centre is an fp32 rounding (2^-24 relative: 6e-8 < 2e-7) of an fp64 value that is itself known to +- c.c.w (the preprocess'
+    // running error bound: a needle's centre is a quotient by a determinant that may have lost most of its digits), and it can lie far
+    // outside the image: the rectangle grows by that much
+    const float ex_err = 2e-7f * fabsf(c.a.x) + 1e-5f + c.c.w, ey_err = 2e-7f * fabsf(c.a.y) + 1e-5f + c.c.w;
     const float dx0 = x0 - c.a.x, dx1 = dx0 + w, dy0 = y0 - c.a.y, dy1 = dy0 + h;
     const float A = c.a.z, C = c.a.w;
     const bool inside = (dx0 <= ex_err) & (dx1 >= -ex_err) & (dy0 <= ey_err) & (dy1 >= -ey_err);

@@ -425,41 +425,86 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             const float lg = logf(oa);
             const double tau = (double)(2.0f * (lg > 0.0f ? lg : 0.0f) * 1.0001f + 1e-3f);
             const double u[3] = {T0[0], T0[1], T0[2]}, v[3] = {T1[0], T1[1], T1[2]}, w[3] = {T3[0], T3[1], T3[2]};
-            const double c0[3] = {v[1] * w[2] - v[2] * w[1], v[2] * w[0] - v[0] * w[2], v[0] * w[1] - v[1] * w[0]};   // Tv x Tw
-            const double c1[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};   // Tw x Tu
-            const double c2[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};   // Tu x Tv
-            const double Qxx = c0[0] * c0[0] + c0[1] * c0[1] - tau * c0[2] * c0[2];
-            const double Qxy = c0[0] * c1[0] + c0[1] * c1[1] - tau * c0[2] * c1[2];
-            const double Qyy = c1[0] * c1[0] + c1[1] * c1[1] - tau * c1[2] * c1[2];
-            const double Qx1 = c0[0] * c2[0] + c0[1] * c2[1] - tau * c0[2] * c2[2];
-            const double Qy1 = c1[0] * c2[0] + c1[1] * c2[1] - tau * c1[2] * c2[2];
-            const double Q11 = c2[0] * c2[0] + c2[1] * c2[1] - tau * c2[2] * c2[2];
-            const double det = Qxx * Qyy - Qxy * Qxy;
-            // default: not an ellipse -> always a candidate (A = 0).  det is itself a difference of fp64 products, and what it loses the
-            // centre loses too, and the value at the centre, fp = Q11 + Qx1 xc + Qy1 yc, multiplies that by |Qx1|, |Qy1| ~ 1e7: at
-            // det = 9e-8 Qxx Qyy (a surfel seen edge-on to within 3e-4 rad) fp came out as -5.44 for -11.81, the ellipse 0.68 of its size,
-            // and a pair with alpha = 1.0096 / 255 at one pixel was culled (soak seed 4242, case 1376: the only miss in 5 500 random scenes
-            // across three seeds, found after the round's evidence runs -- DESIGN.md section 3).  The error of fp is ~2e-7 |q1| / (det /
-            // (Qxx Qyy)) x 1e-8: below 1e-5 the needle is treated as "no ellipse" (it was 1e-9 until then)
+            // Every quantity below is formed in fp64 TOGETHER WITH A BOUND OF ITS ROUNDING ERROR (running error analysis: one rounding of
+            // relative size EPS = 2^-53 per operation, first order, each bound doubled for the second-order terms), and the ellipse that
+            // leaves here contains the exact level set of the conic the fp32 inputs define, by construction -- DESIGN.md section 3:
+            //   1. cross products c_i = a b - c d: |err| <= 2 EPS (|a b| + |c d|);
+            //   2. Q entries q(x, y) = x0 y0 + x1 y1 - tau x2 y2: |err| <= E = 4 EPS sum |terms| + the inputs' bounds propagated;
+            //   3. for every pixel p = (x, y) of the image, f(p) = p' Q2 p + 2 q' p + Q11 >= p' (Q2~ - lam I) p + 2 q~' p + (Q11~ - sigma) =: f'(p),
+            //      lam = ||E2||_inf >= ||E2||_2, sigma = E11 + 2 (Ex1 W + Ey1 H): the level set of f' contains that of f inside the image;
+            //   4. f' has fp64 coefficients: its determinant, centre and minimum are formed with their own bounds -- det' >= det_lo > 0 or
+            //      "not an ellipse"; the centre to +-(dxc, dyc), which goes into the record and widens the block's rectangle in the test;
+            //      the minimum f'* >= f'(centre~) - e_f - trace(Q2') (dxc^2 + dyc^2) =: f_lo (a point's value bounds the minimum from
+            //      above, the centre's error enters at second order), and the ellipse is scaled by f_lo.
+            // A needle whose determinant drowns in its own rounding (round 5's miss: det = 9e-8 Qxx Qyy, a surfel edge-on to 3e-4 rad) ends
+            // in "not an ellipse" at step 4 or with a rectangle widened by its centre's uncertainty -- no constant decides that (rounds 1-5
+            // compared det with 1e-9, then 1e-5 Qxx Qyy, thresholds found by soaking).
+            const double EPS = 1.1102230246251565e-16;
+            auto crossE = [&](const double (&a_)[3], const double (&b_)[3], double (&c_)[3], double (&e_)[3]) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int j = (i + 1) % 3, k = (i + 2) % 3;
+                    const double t0 = a_[j] * b_[k], t1 = a_[k] * b_[j];
+                    c_[i] = t0 - t1;
+                    e_[i] = 2.0 * EPS * (fabs(t0) + fabs(t1));
+                }
+            };
+            double c0[3], c1[3], c2[3], e0[3], e1[3], e2[3];
+            crossE(v, w, c0, e0);   // Tv x Tw
+            crossE(w, u, c1, e1);   // Tw x Tu
+            crossE(u, v, c2, e2);   // Tu x Tv
+            auto qE = [&](const double (&x_)[3], const double (&ex_)[3], const double (&y_)[3], const double (&ey_)[3], double& val, double& err) {
+                const double t0 = x_[0] * y_[0], t1 = x_[1] * y_[1], t2 = tau * (x_[2] * y_[2]);
+                val = t0 + t1 - t2;
+                const double p0 = fabs(x_[0]) * ey_[0] + fabs(y_[0]) * ex_[0] + ex_[0] * ey_[0];
+                const double p1 = fabs(x_[1]) * ey_[1] + fabs(y_[1]) * ex_[1] + ex_[1] * ey_[1];
+                const double p2 = fabs(x_[2]) * ey_[2] + fabs(y_[2]) * ex_[2] + ex_[2] * ey_[2];
+                err = 2.0 * (4.0 * EPS * (fabs(t0) + fabs(t1) + fabs(t2)) + p0 + p1 + tau * p2);
+            };
+            double Qxx, Qxy, Qyy, Qx1, Qy1, Q11, Exx, Exy, Eyy, Ex1, Ey1, E11;
+            qE(c0, e0, c0, e0, Qxx, Exx);
+            qE(c0, e0, c1, e1, Qxy, Exy);
+            qE(c1, e1, c1, e1, Qyy, Eyy);
+            qE(c0, e0, c2, e2, Qx1, Ex1);
+            qE(c1, e1, c2, e2, Qy1, Ey1);
+            qE(c2, e2, c2, e2, Q11, E11);
+            // default: not an ellipse -> always a candidate (A = 0)
             cull_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             cull_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (Qxx > 0.0 && Qyy > 0.0 && det > 1e-5 * Qxx * Qyy) {
-                const double xc = -(Qyy * Qx1 - Qxy * Qy1) / det, yc = -(Qxx * Qy1 - Qxy * Qx1) / det;
-                const double fp = Q11 + Qx1 * xc + Qy1 * yc;
-                if (fp < 0.0) {
-                    const double sc_ = -1.0 / fp;
-                    const double A = Qxx * sc_, B = Qxy * sc_, C = Qyy * sc_, dn = det * sc_ * sc_;
-                    cull_a = make_float4((float)xc, (float)yc, (float)A, (float)C);
-                    cull_b = make_float4((float)(B / C), (float)(B / A), (float)(dn / C), (float)(dn / A));
-                    const float chk = cull_a.x + cull_a.y + cull_a.z + cull_a.w + cull_b.x + cull_b.y + cull_b.z + cull_b.w;
-                    if (!(chk - chk == 0.0f) || !(cull_a.z > 0.0f)) {      // inf / NaN / underflow: never cull
-                        cull_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        cull_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                }   // else: empty level set (cannot happen for a visible splat; stay conservative)
+            float centre_slack = 0.0f;
+            const double lam = 2.0 * fmax(Exx + Exy, Exy + Eyy);
+            const double sigma = 2.0 * (E11 + 2.0 * (Ex1 * (double)W + Ey1 * (double)H));
+            const double Qxx_ = Qxx - lam, Qyy_ = Qyy - lam, Q11_ = Q11 - sigma;      // f' (step 3); from here on these ARE the coefficients
+            if (Qxx_ > 0.0 && Qyy_ > 0.0) {
+                const double dp = Qxx_ * Qyy_, dq = Qxy * Qxy;
+                const double det_ = dp - dq, det_lo = det_ - 2.0 * (2.0 * EPS * (dp + dq));
+                if (det_lo > 0.0) {
+                    const double n1 = Qyy_ * Qx1, n2 = Qxy * Qy1, m1 = Qxx_ * Qy1, m2 = Qxy * Qx1;
+                    const double xc = -(n1 - n2) / det_, yc = -(m1 - m2) / det_;
+                    const double e_det = det_ - det_lo;
+                    const double dxc = 2.0 * ((2.0 * EPS * (fabs(n1) + fabs(n2)) + fabs(xc) * e_det) / det_lo + 2.0 * EPS * fabs(xc));
+                    const double dyc = 2.0 * ((2.0 * EPS * (fabs(m1) + fabs(m2)) + fabs(yc) * e_det) / det_lo + 2.0 * EPS * fabs(yc));
+                    const double a1 = 2.0 * Qx1 * xc, a2 = 2.0 * Qy1 * yc, a3 = Qxx_ * xc * xc, a4 = 2.0 * Qxy * xc * yc, a5 = Qyy_ * yc * yc;
+                    const double fc = ((Q11_ + a1) + a2) + ((a3 + a4) + a5);
+                    const double e_f = 2.0 * (8.0 * EPS * (fabs(Q11_) + fabs(a1) + fabs(a2) + fabs(a3) + fabs(a4) + fabs(a5)));
+                    const double f_lo = fc - e_f - (Qxx_ + Qyy_) * (dxc * dxc + dyc * dyc);
+                    if (f_lo < 0.0) {
+                        const double sc_ = -1.0 / f_lo;
+                        const double A = Qxx_ * sc_, B = Qxy * sc_, C = Qyy_ * sc_, dn = det_lo * sc_ * sc_;
+                        cull_a = make_float4((float)xc, (float)yc, (float)A, (float)C);
+                        cull_b = make_float4((float)(B / C), (float)(B / A), (float)(dn / C), (float)(dn / A));
+                        centre_slack = (float)fmax(dxc, dyc) * 1.000001f + 1e-30f;        // (rounded up)
+                        const float chk = cull_a.x + cull_a.y + cull_a.z + cull_a.w + cull_b.x + cull_b.y + cull_b.z + cull_b.w + centre_slack;
+                        if (!(chk - chk == 0.0f) || !(cull_a.z > 0.0f)) {      // inf / NaN / underflow: never cull
+                            cull_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            cull_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            centre_slack = 0.0f;
+                        }
+                    }   // else: the level set may be empty -- or not: stay conservative
+                }
             }
             const float rr = sqrtf(0.5f * (float)tau) + 0.05f;
-            cull_c = make_float4(cx, cy, rr * rr, 0.0f);
+            cull_c = make_float4(cx, cy, rr * rr, centre_slack);
         }
         float4* r4 = rec + (size_t)idx * MRGS_REC_F4;
         r4[0] = make_float4(T[0], T[1], T[2], T[3]);

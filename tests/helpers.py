@@ -18,7 +18,8 @@ EXPORT = {"depths": (0, torch.float32, lambda P, R, T, H, W: (P,)),
           "n_contrib": (10, torch.int32, lambda P, R, T, H, W: (2, H, W)),
           "order": (11, torch.int32, lambda P, R, T, H, W: (P,)),
           "redo_list": (12, torch.int32, lambda P, R, T, H, W: (2 + H * W,)),
-          "qmask": (13, torch.uint8, lambda P, R, T, H, W: (R,))}
+          "qmask": (13, torch.uint8, lambda P, R, T, H, W: (R,)),
+          "cull": (14, torch.float32, lambda P, R, T, H, W: (P, 12))}
 
 
 def raster_settings(cam, device, sh_degree=3, scale_modifier=1.0, bg=None, debug=False):

@@ -53,6 +53,71 @@ def cull_record(T, opa, mean2d, guard):
     return (a, b, c), (ratio, tau)
 
 
+EPS = 2.0 ** -53
+
+
+def cull_record_bounded(T, opa, mean2d, W, H, lg=None):
+    """The cull record as preprocess_fwd writes it since round 6: every fp64 quantity with a running bound of its rounding error, the
+    ellipse a provable superset of the exact level set inside the image (mrgs_preprocess.hip, "Cull conic").
+    lg: logf(255 opacity) as the device evaluated it (a test that compares with the kernel bit for bit hands it over; numpy's differs
+    in the last bit now and then, and a needle's numbers amplify that by 1 / (det / (Qxx Qyy)))."""
+    never = (np.array([1e30] * 4, f32), np.array([0, 0, 1e30, 1e30], f32), np.array([1e30, 0, -1, 0], f32))
+    oa = f32(255.0) * f32(opa)
+    if oa < f32(0.999):
+        return never, None
+    lg = np.log(oa).astype(f32) if lg is None else f32(lg)
+    tau = float(f32(2.0) * (lg if lg > 0 else f32(0)) * f32(1.0001) + f32(1e-3))
+    u, v, w = [np.asarray(T[i:i + 3], dtype=np.float64) for i in (0, 3, 6)]
+
+    def crossE(a_, b_):
+        c_, e_ = np.zeros(3), np.zeros(3)
+        for i in range(3):
+            j, k = (i + 1) % 3, (i + 2) % 3
+            t0, t1 = a_[j] * b_[k], a_[k] * b_[j]
+            c_[i], e_[i] = t0 - t1, 2.0 * EPS * (abs(t0) + abs(t1))
+        return c_, e_
+
+    def qE(x_, ex_, y_, ey_):
+        t0, t1, t2 = x_[0] * y_[0], x_[1] * y_[1], tau * (x_[2] * y_[2])
+        p = [abs(x_[i]) * ey_[i] + abs(y_[i]) * ex_[i] + ex_[i] * ey_[i] for i in range(3)]
+        return t0 + t1 - t2, 2.0 * (4.0 * EPS * (abs(t0) + abs(t1) + abs(t2)) + p[0] + p[1] + tau * p[2])
+    (c0, e0), (c1, e1), (c2, e2) = crossE(v, w), crossE(w, u), crossE(u, v)
+    (Qxx, Exx), (Qxy, Exy), (Qyy, Eyy) = qE(c0, e0, c0, e0), qE(c0, e0, c1, e1), qE(c1, e1, c1, e1)
+    (Qx1, Ex1), (Qy1, Ey1), (Q11, E11) = qE(c0, e0, c2, e2), qE(c1, e1, c2, e2), qE(c2, e2, c2, e2)
+    a, b, slack = np.zeros(4, f32), np.zeros(4, f32), f32(0)
+    lam = 2.0 * max(Exx + Exy, Exy + Eyy)
+    sigma = 2.0 * (E11 + 2.0 * (Ex1 * float(W) + Ey1 * float(H)))
+    Qxx_, Qyy_, Q11_ = Qxx - lam, Qyy - lam, Q11 - sigma
+    ratio = (Qxx * Qyy - Qxy * Qxy) / (Qxx * Qyy) if (Qxx > 0 and Qyy > 0) else None
+    if Qxx_ > 0 and Qyy_ > 0:
+        dp, dq = Qxx_ * Qyy_, Qxy * Qxy
+        det_ = dp - dq
+        det_lo = det_ - 2.0 * (2.0 * EPS * (dp + dq))
+        if det_lo > 0:
+            n1, n2, m1, m2 = Qyy_ * Qx1, Qxy * Qy1, Qxx_ * Qy1, Qxy * Qx1
+            xc, yc = -(n1 - n2) / det_, -(m1 - m2) / det_
+            e_det = det_ - det_lo
+            dxc = 2.0 * ((2.0 * EPS * (abs(n1) + abs(n2)) + abs(xc) * e_det) / det_lo + 2.0 * EPS * abs(xc))
+            dyc = 2.0 * ((2.0 * EPS * (abs(m1) + abs(m2)) + abs(yc) * e_det) / det_lo + 2.0 * EPS * abs(yc))
+            a1, a2, a3, a4, a5 = 2.0 * Qx1 * xc, 2.0 * Qy1 * yc, Qxx_ * xc * xc, 2.0 * Qxy * xc * yc, Qyy_ * yc * yc
+            fc = ((Q11_ + a1) + a2) + ((a3 + a4) + a5)
+            e_f = 2.0 * (8.0 * EPS * (abs(Q11_) + abs(a1) + abs(a2) + abs(a3) + abs(a4) + abs(a5)))
+            f_lo = fc - e_f - (Qxx_ + Qyy_) * (dxc * dxc + dyc * dyc)
+            if f_lo < 0:
+                sc = -1.0 / f_lo
+                A, B, C, dn = Qxx_ * sc, Qxy * sc, Qyy_ * sc, det_lo * sc * sc
+                with np.errstate(over="ignore"):
+                    a = np.array([xc, yc, A, C]).astype(f32)
+                    b = np.array([B / C, B / A, dn / C, dn / A]).astype(f32)
+                    slack = f32(f32(max(dxc, dyc)) * f32(1.000001) + f32(1e-30))
+                chk = float(a.astype(np.float64).sum() + b.astype(np.float64).sum() + float(slack))
+                if not np.isfinite(chk) or not a[2] > 0:
+                    a, b, slack = np.zeros(4, f32), np.zeros(4, f32), f32(0)
+    rr = f32(np.sqrt(f32(0.5) * f32(tau))) + f32(0.05)
+    c = np.array([mean2d[0], mean2d[1], rr * rr, slack], f32)
+    return (a, b, c), (ratio, tau)
+
+
 def fma32(x, y, z):
     return f32(np.float64(x) * np.float64(y) + np.float64(z))
 
@@ -68,7 +133,7 @@ def edge_min(D, Q, slope, X, lo, hi, errX):
 def block_may_touch(rec, x0, y0, w, h):
     a, b, c = rec
     x0, y0, w, h = f32(x0), f32(y0), f32(w), f32(h)
-    ex_err, ey_err = f32(f32(2e-7) * abs(a[0]) + f32(1e-5)), f32(f32(2e-7) * abs(a[1]) + f32(1e-5))
+    ex_err, ey_err = f32(f32(f32(2e-7) * abs(a[0]) + f32(1e-5)) + c[3]), f32(f32(f32(2e-7) * abs(a[1]) + f32(1e-5)) + c[3])
     dx0 = f32(x0 - a[0]); dx1 = f32(dx0 + w); dy0 = f32(y0 - a[1]); dy1 = f32(dy0 + h)
     A, C = a[2], a[3]
     inside = (dx0 <= ex_err) and (dx1 >= -ex_err) and (dy0 <= ey_err) and (dy1 >= -ey_err)
@@ -113,7 +178,7 @@ def check_scene(scene, cam, guard, ratio_max, sh_degree=0, sample=0, rng=None):
     vis = np.nonzero(radii > 0)[0]
     extra = set((rng or np.random.default_rng(0)).choice(vis, size=min(sample, len(vis)), replace=False).tolist()) if sample and len(vis) else set()
     for g in vis:
-        rec, info = cull_record(T[g], no[g][3], m2[g], guard)
+        rec, info = cull_record_bounded(T[g], no[g][3], m2[g], W, H) if guard is None else cull_record(T[g], no[g][3], m2[g], guard)
         if info is None or info[0] is None:
             continue
         if not (info[0] < ratio_max) and int(g) not in extra:
@@ -143,7 +208,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("n", type=int, nargs="?", default=20)
     ap.add_argument("seed", type=int, nargs="?", default=0)
-    ap.add_argument("--guard", type=float, default=1e-5)
+    ap.add_argument("--guard", type=float, default=None, help="the constant-guard record of rounds 1-5 with this det / (Qxx Qyy) threshold (default: the bounded record)")
     ap.add_argument("--ratio", type=float, default=1e-3)
     ap.add_argument("--sample", type=int, default=0, help="per scene, also this many random surfels that are not needles")
     a = ap.parse_args()
