@@ -143,11 +143,30 @@ struct Hit {
 #define MRGS_RHO_EPS 2e-5f
 // transmittance: the fast product of (1 - alpha) against the exact one.  T > 0.5: every earlier alpha is below 0.5, the relative
 // difference is at most sum alpha_i / (1 - alpha_i) x 2.7e-6 <= 2 ln 2 x 2.7e-6 = 3.7e-6 (measured over 1.4 M pixels: 5.5e-7) -> 4e-6.
-// T (1 - alpha) < 1e-4: the same sum over a whole list has no useful bound (5e-5 if every pair sat at its worst case); measured over the
-// same pixels (tools/margin_stats.py: fast against -DMRGS_FWD_REDO_ALL) the largest difference at T <= 1e-3 is 5.2e-6, the 99.99th
-// percentile 1.9e-6 -> 1.5e-5.  A wider band only marks more pixels (each costs its wave ~6 us of exact rendering).
+// T (1 - alpha) < 1e-4: no constant bounds the difference at the END of a list -- a pair with alpha = 0.99 alone moves the relative
+// difference by alpha / (1 - alpha) x 2.5e-7 = 2.5e-5 -- so the forward carries the bound per pixel (MRGS_T1_RUNNING, round 6; rounds
+// 4-5 used MRGS_T1_EPS = 1.5e-5 relative, three times the largest difference MEASURED over 1.4 M pixels: a measurement, not a bound).
+// With F_n >= |T~_n - T_n| (T~: the fast product; T: the oracle's fp32 product of its exactly evaluated factors):
+//     T~_n = fl(T~_{n-1} fl(1 - a~_n)),  T_n = fl(T_{n-1} fl(1 - a_n)),  |a~_n - a_n| <= d_n a_n,  d_n = 2.1e-7 rho_n + 2.5e-7 (above)
+//     |T~_n - T_n| <= |T~_{n-1} - T_{n-1}| (1 - a_n) + T_{n-1} d_n a_n + 4 x 2^-24 T_n          (two roundings on either side)
+// and, since a_n <= exp(-rho_n / 2) and x exp(-x / 2) <= 2 / e:  d_n a_n <= 1.55e-7 + 2.5e-7 a_n, so that
+//     T_{n-1} d_n a_n + 2.4e-7 T_{n-1} (1 - a_n) <= T_{n-1} (1.55e-7 + 2.5e-7 (a_n + (1 - a_n))) = 4.05e-7 T_{n-1}:
+//     F_n := F_{n-1} (1 - a~_n) + 4.1e-7 T~_{n-1},   F_0 = 0        (relative form: F_n / T_n = sum_i 4.1e-7 / (1 - a_i))
+// first order in the errors; the second-order terms (F d a, the fast values standing in for the exact ones on the right-hand side) are
+// covered by the factor MRGS_T1_SLACK = 1.25 -- they are 1e-5 of the first-order ones -- plus 1e-11 absolute (1e-7 of the threshold)
+// for the rounding of the recurrence itself (the kernel carries MRGS_T1_SLACK F: the recurrence is linear).  A test value T~ (1 - a~)
+// within MRGS_T1_SLACK F_n + 1e-11 of 1e-4 marks the pixel.  No division: a multiplication, a multiply-add, a select and a subtraction
+// per blended entry.  Typical pixel (six pairs of alpha ~ 0.8): F / T = 1.2e-5; a pair of alpha 0.99: + 4e-5.  Measured at C3full /
+// C2 (MI355X, 100 views each, twice): 110-124 marked pixels a view against 67-84 with the constant band, forward blend 182-185 us
+// against 178-179 (C2: 156 against 151); carrying rho per pair (MRGS_T1_RUNNING=2: d_n exactly) marks 89-107 and costs the same.
+#ifndef MRGS_T1_RUNNING
+#define MRGS_T1_RUNNING 1
+#endif
+#define MRGS_T_STEP_ERR 4.1e-7f
+#define MRGS_T1_SLACK 1.25f
+#define MRGS_T1_ABS 1e-11f
 #ifndef MRGS_T1_EPS
-#define MRGS_T1_EPS (MRGS_T_MIN * 1.5e-5f)
+#define MRGS_T1_EPS (MRGS_T_MIN * 1.5e-5f)      // (the constant band of rounds 4-5: MRGS_T1_RUNNING=0 builds)
 #endif
 #ifndef MRGS_T2_EPS
 #define MRGS_T2_EPS (0.5f * 4e-6f)

@@ -337,6 +337,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
     int cf_end = 0;                  // list entries whose cflag this wave has written
     uint32_t work = 0;
     float T = 1.0f;
+#if MRGS_T1_RUNNING
+    float Terr = 0.0f;               // MRGS_T1_SLACK x the bound of |T - the transmittance exact arithmetic has at this point| (mrgs_blend_math.h)
+#endif
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     // (the record channel's accumulator is a variable of its own, not F[S_MAX]: as a ninth array element it shifted the pairs the compiler
     //  forms for v_pk_fma_f32 by one -- (x, F0), (F1, F2) ... (F7, F8) -- and every blended entry paid eight register moves to line the
@@ -438,12 +441,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
             // block, flag bit 1.  Resolving it here for the lanes concerned instead of marking their pixels was measured: the exact
             // evaluation as a cold branch of the entry body costs the loop 5 us, the ~20 more marked pixels 3)
             if (ambiguous != 0ull) unsure |= 1ull << j;
-            const float test_T = T * (1.0f - h.alpha);
+            const float oma = 1.0f - h.alpha;
+            const float test_T = T * oma;
             // a decision the fast arithmetic cannot be sure of marks the pixel: it is rendered again, exactly, at the end of the wave
             // (mrgs_blend_math.h "Exact decisions"; mrgs_redo_pixel).  Three quarters of the marks are transmittance bands.
             // (the two transmittance tests as two comparisons each, against the near and the far edge of the band: between them the
             // pixel is marked, and what the fast path does with a marked pixel does not matter)
+#if MRGS_T1_RUNNING
+            // the band of the 1e-4 test: a running BOUND of |T_fast - T_exact| carried per pixel (mrgs_blend_math.h: MRGS_T1_RUNNING)
+#if MRGS_T1_RUNNING == 2     // (the recurrence with d_n = 2.1e-7 rho_n + 2.5e-7 carried per pair: a tighter band for three more instructions)
+            const float Terr_new = fmaf(Terr, oma, MRGS_T1_SLACK * fmaf(fmaf(2.1e-7f, fminf(h.rho3d, h.rho2d), 2.5e-7f) * h.alpha, T, 2.4e-7f * test_T));
+#else
+            const float Terr_new = fmaf(Terr, oma, (MRGS_T1_SLACK * MRGS_T_STEP_ERR) * T);
+#endif
+            const uint64_t below = MRGS_BALLOT(test_T < (MRGS_T_MIN - MRGS_T1_ABS) - Terr_new);
+#else
             const uint64_t below = MRGS_BALLOT(test_T < MRGS_T_MIN - MRGS_T1_EPS);
+#endif
             // (a T (1 - alpha) inside the band of the 1e-4 test is not looked for here: it does not end the pixel -- `below` is the near
             // edge of the band --, becomes the pixel's T, and nothing but a terminating entry can follow it: the pixel's FINAL T lies in
             // the band exactly when some entry's did, and is tested once, after the list)
@@ -482,6 +496,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
                 if constexpr (XREC) Fx = fmaf(a1.w, w, Fx);       // (the record's tail arrives one entry ahead with the rest of it)
             }
             T = upd ? test_T : T;
+#if MRGS_T1_RUNNING
+            Terr = upd ? Terr_new : Terr;
+#endif
             last_contributor = upd ? contributor : last_contributor;
         };
 
@@ -567,11 +584,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S_MAX =
 #ifdef MRGS_FWD_REDO_ALL   // developer build: every pixel goes through the exact path (what the margins are measured against)
     redo = ~0ull;
 #endif
+#if MRGS_T1_RUNNING
+    redo |= MRGS_BALLOT(T < (MRGS_T_MIN + MRGS_T1_ABS) + Terr);
+#else
     redo |= MRGS_BALLOT(T < MRGS_T_MIN + MRGS_T1_EPS);
+#endif
     redo &= __builtin_amdgcn_ballot_w64(inside);
     if (redo != 0ull) {
         for (int e = cf_end + lane; e < total; e += MRGS_CHUNK) cf[(size_t)e * 4] = 0;
 #if MRGS_FWD_REDO_INLINE
+        if (lane == 0) atomicAdd(&redo_list[0], (uint32_t)__builtin_popcountll(redo));      // (diagnostics: mrgs_debug_export 12 reports the count)
         // (the list staging buffer is free by now: the candidate queue of the redo lives there)
         uint32_t* q = reinterpret_cast<uint32_t*>(&stage[0]);
         static_assert(sizeof(StageBuf<SF>) >= 2 * MRGS_REDO_QCAP * sizeof(uint32_t), "the redo's queue must fit the staging buffer");
