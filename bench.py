@@ -254,7 +254,9 @@ def main():
     # render_surfel's parameter set: both SH families (96 of 111 floats per gaussian) travel factored (dist.SurfelGradReducer)
     surfel_names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest", "refl_strength", "roughness", "ori_color",
                     "indirect_dc", "indirect_rest", "env_base"]
-    surfel_reducer = mdist.SurfelGradReducer([t_.shape for t_ in surfel_params], surfel_names, dev) if (surfel_mode and world > 1) else None
+    # (the dense part as the union of the rows the ranks' views touched: dist.TouchedRowsExchange; MRGS_BENCH_DENSE_EXCHANGE=1 for A/B)
+    surfel_reducer = mdist.SurfelGradReducer([t_.shape for t_ in surfel_params], surfel_names, dev,
+                                             touched_rows_only=not os.environ.get("MRGS_BENCH_DENSE_EXCHANGE")) if (surfel_mode and world > 1) else None
     if surfel_reducer is not None and not traced and not os.environ.get("MRGS_BENCH_NO_EARLY_GATHER"):
         # both factors of the SH exchange leave the backward as soon as they are final: the colour factor between the rasterizer's blend
         # backward and its per-gaussian backward, the indirect-radiance factor after the per-gaussian glue's backward.  (Not with the
@@ -599,6 +601,31 @@ def main():
             feat_bwd_ms = timed(lambda: torch.autograd.grad(o_, leaves_, gs_, retain_graph=True, allow_unused=True))
             m.update({"allgather_rows_bytes": [4 * (3 * P + 3), 4 * 3 * P], "sh_expand_ms_at_V": [round(expand_ms, 4), round(expand_b_ms, 4)],
                       "surfel_features_bwd_ms": round(feat_bwd_ms, 4), "_expand_b_ms": expand_b_ms, "_feat_bwd_ms": feat_bwd_ms})
+            # Which rows a view touches, measured: the dense part of the exchange travels as the UNION of the rows the V ranks' views touched
+            # (dist.TouchedRowsExchange).  One backward per orbit camera here; rank r of a V-rank step renders camera (step V + r) mod 8, i.e.
+            # V neighbouring cameras of the orbit.
+            masks = []
+            for v_ in range(len(cams_dev)):
+                for t_ in surfel_params:
+                    t_.grad = None
+                env.build_mips()
+                o2 = render_surfel(cams_dev[v_], pc, pipe, bg_color, srgb=False, opt=SimpleNamespace(indirect=indirect), flag=flavour)
+                outs2 = [o2[k_] for k_ in ("render", "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal")]
+                torch.autograd.backward(outs2, state.get("g") or ([torch.ones_like(outs2[0])] + [torch.full_like(o_x, 0.1) for o_x in outs2[1:]]))
+                rows_ = torch.cat([t_.grad.reshape(P, -1) for n_, t_ in zip(surfel_names, surfel_params)
+                                   if n_ not in mdist.SurfelGradReducer.SH_NAMES and t_.shape[0] == P], dim=1)
+                masks.append((rows_ != 0).any(dim=1))
+            n_cam_ = len(masks)
+            row_floats = int(rows_.shape[1])
+            tail_floats = dense_floats - sh_floats - row_floats * P
+            union = {}
+            for V_ in (2, 4, 8):
+                if n_cam_ >= V_:
+                    fr = [float(torch.stack(masks[s_:s_ + V_]).any(dim=0).float().mean()) for s_ in range(0, n_cam_ - V_ + 1, V_)]
+                    union[f"V{V_}"] = round(sum(fr) / len(fr), 4)
+            m.update({"touched_rows_fraction_per_view": round(float(torch.stack(masks).float().mean()), 4), "union_rows_fraction": union,
+                      "dense_row_floats": row_floats, "dense_tail_floats": tail_floats, "mask_bytes_per_rank": P,
+                      "indirect_factor_gathered": bool(indirect), "_union": union, "_row_floats": row_floats, "_tail_floats": tail_floats})
         return m
 
     def predicted_scaling(xm, step_ms, overlap_ms):
@@ -614,6 +641,13 @@ def main():
         tab = {}
         for V in (2, 4, 8):
             t_ar = 2.0 * xm["_ar_bytes"] / V / link * 1e3 + 0.020
+            ar_bytes_V = xm["_ar_bytes"]
+            if xm.get("_union", {}).get(f"V{V}") is not None:
+                # the dense part as the union of the touched rows (dist.TouchedRowsExchange): the measured union's share of the per-surfel rows
+                # + the tail (the cubemap) through reduce-scatter + all-gather, in front of it the all-gather of the masks (P bytes per rank,
+                # one more collective phase) -- and one host read of the union's size, which the model does not price
+                ar_bytes_V = 4.0 * (xm["_union"][f"V{V}"] * P * xm["_row_floats"] + xm["_tail_floats"])
+                t_ar = 2.0 * ar_bytes_V / V / link * 1e3 + 0.020 + (P / link * 1e3 + 0.010)
             if "_expand_b_ms" in xm:
                 # render_surfel's exchange (dist.SurfelGradReducer): the colour factor's gather starts `overlap_ms` before the backward ends
                 # (after the blend backward: the rasterizer's per-gaussian backward and the glue's backward follow), the indirect factor's
@@ -621,6 +655,10 @@ def main():
                 # compute stream: expansion 1 when gather 1 has landed, expansion 2 when gather 2 has landed and expansion 1 is done
                 t_ag1, t_ag2 = 4 * (3 * P + 3) / link * 1e3 + 0.010, 4 * 3 * P / link * 1e3 + 0.010
                 t_e1, t_e2 = xm["_expand_ms"] * V / 8.0, xm["_expand_b_ms"] * V / 8.0
+                if not xm.get("indirect_factor_gathered", True):
+                    # render_surfel without opt.indirect: the indirect factor is zero by the structure of the step (renderer.surfel_features,
+                    # indirect_live) -- not gathered, not expanded (dist.SurfelGradReducer.begin_early_ind(None))
+                    t_ag2, t_e2 = 0.0, 0.0
                 left1 = max(t_ag1 - overlap_ms, 0.0)
                 links_done = left1 + t_ag2 + t_ar
                 compute_done = max(left1 + t_e1, left1 + t_ag2) + t_e2
@@ -632,7 +670,7 @@ def main():
                 # runs on the compute stream as soon as the gather has landed, next to the all-reduce
                 exposed = max(t_ag - overlap_ms, 0.0) + max(t_ar, t_exp)
             eff = step_ms / (step_ms + exposed)
-            tab[f"V{V}"] = {"allgather_ms": round(t_ag, 4), "allreduce_ms": round(t_ar, 4), "sh_expand_ms": round(t_exp, 4),
+            tab[f"V{V}"] = {"allgather_ms": round(t_ag, 4), "allreduce_ms": round(t_ar, 4), "dense_bytes_exchanged": int(ar_bytes_V), "sh_expand_ms": round(t_exp, 4),
                             "exposed_exchange_ms": round(exposed, 4), "efficiency": round(eff, 3), "speedup": round(V * eff, 2)}
         return {"link_GBs_per_direction_derated": round(link / 1e9, 1), "single_gpu_step_ms": round(step_ms, 4),
                 "allgather_overlapped_with_preprocess_bwd_ms": round(overlap_ms, 4), **tab}

@@ -53,6 +53,52 @@ def sum_reduce_scatter_gather(buf: torch.Tensor, group=None):
     return dist.all_gather_into_tensor(buf, shard, group=group, async_op=True)
 
 
+class TouchedRowsExchange:
+    """Sum over ranks of a [P, C] row matrix (+ a small dense tail) in which every rank holds non-zero rows only for the surfels ITS view
+    touched -- a view blends the surfels in front of its camera, not the whole model -- by exchanging the union of the touched rows only:
+
+        1. all-gather of the ranks' touched-row masks (a byte per surfel: P bytes per rank against 4 C P of the dense bucket);
+        2. union of the masks -> row index list, the same on every rank (one host read of its length: the collectives need sizes);
+        3. the union's rows compacted into one buffer [n_union, C] | tail, summed with sum_reduce_scatter_gather, scattered back.
+
+    Exact: rows outside the union are zero on every rank, and zero is what comes back for them.  What it saves is the union's share of
+    P -- two neighbouring views of an orbit share most of what they see (measured on the bench scene: bench.py `exchange_model`), eight
+    views around an object cover it and save nothing -- so the wire bytes are reported per V, not claimed as a constant.
+    `last` holds the byte counts of the most recent call."""
+
+    def __init__(self, P: int, C: int, tail_numel: int, device, dtype=torch.float32):
+        self.P, self.C, self.tail = int(P), int(C), int(tail_numel)
+        self.device, self.dtype = device, dtype
+        self.masks = None
+        self.last = {}
+
+    def exchange(self, rows: torch.Tensor, tail: Optional[torch.Tensor], group=None):
+        """rows [P, C] (this rank's, zero where untouched), tail [tail_numel] or None -> (summed rows [P, C], summed tail)."""
+        world = dist.get_world_size(group)
+        P, C = self.P, self.C
+        assert rows.shape == (P, C) and rows.is_contiguous()
+        mine = (rows != 0).any(dim=1).to(torch.uint8)
+        if self.masks is None or self.masks.shape[0] != world:
+            self.masks = torch.empty((world, P), dtype=torch.uint8, device=rows.device)
+        dist.all_gather_into_tensor(self.masks.view(-1), mine, group=group)
+        idx = self.masks.any(dim=0).nonzero(as_tuple=False).squeeze(1)          # (one host read: the union's size)
+        n = int(idx.numel())
+        total = n * C + self.tail
+        padded = (total + world - 1) // world * world
+        buf = torch.zeros(max(padded, world), dtype=self.dtype, device=rows.device)
+        if n:
+            buf[:n * C].view(n, C).copy_(rows.index_select(0, idx))
+        if self.tail:
+            buf[n * C:n * C + self.tail].copy_(tail.reshape(-1))
+        sum_reduce_scatter_gather(buf, group).wait()
+        out = torch.zeros_like(rows)
+        if n:
+            out.index_copy_(0, idx, buf[:n * C].view(n, C))
+        self.last = {"touched_rows_this_rank": int(mine.sum()), "union_rows": n, "rows": P, "mask_bytes_per_rank": P,
+                     "dense_bytes": 4 * (P * C + self.tail), "exchanged_bytes": 4 * padded}
+        return out, (buf[n * C:n * C + self.tail] if self.tail else None)
+
+
 class GradBucket:
     """Flat fp32 bucket that packs a fixed list of gradient tensors for a single all-reduce."""
 
@@ -243,7 +289,9 @@ class SurfelGradReducer:
     (incl. tensors that are not per-gaussian, e.g. the environment cubemap) goes through one flat all-reduce."""
     SH_NAMES = ("features_dc", "features_rest", "indirect_dc", "indirect_rest")
 
-    def __init__(self, shapes: Sequence[torch.Size], names: Sequence[str], device, expand_fn=None):
+    def __init__(self, shapes: Sequence[torch.Size], names: Sequence[str], device, expand_fn=None, touched_rows_only=False):
+        """touched_rows_only: the dense part (everything but the four SH tensors) travels as the UNION OF THE TOUCHED ROWS of the ranks'
+        views instead of all P rows (TouchedRowsExchange: one more small collective and one host read per step; exact)."""
         self.expand_fn = expand_fn or expand_surfel_sh_gradients   # tests on CPU tensors pass the oracle.dist_oracle restatement
         self.names = list(names)
         assert all(n in self.names for n in self.SH_NAMES + ("xyz", "rotation"))
@@ -251,6 +299,14 @@ class SurfelGradReducer:
         self.dense_pos = [i for i in range(len(self.names)) if i not in self.sh_pos]
         self.dense = GradBucket([shapes[i] for i in self.dense_pos], device)
         self.P = int(shapes[self.names.index("xyz")][0])
+        self.shapes = [torch.Size(s_) for s_ in shapes]
+        # the dense tensors that are one row per surfel (their columns side by side make the row matrix), and the rest (the cubemap)
+        self.row_pos = [i for i in self.dense_pos if len(shapes[i]) >= 1 and int(shapes[i][0]) == self.P]
+        self.tail_pos = [i for i in self.dense_pos if i not in self.row_pos]
+        self.row_cols = [int(torch.Size(shapes[i]).numel()) // self.P for i in self.row_pos]
+        self.touched = TouchedRowsExchange(self.P, sum(self.row_cols), sum(int(torch.Size(shapes[i]).numel()) for i in self.tail_pos), device) \
+            if touched_rows_only else None
+        self._ind_zero = False
         # the two factors travel apart (they are final at different times of a backward): [dRGB | campos] and [dIND]
         self.row_rgb = torch.empty(3 * self.P + 3, dtype=torch.float32, device=device)
         self.row_ind = torch.empty(3 * self.P, dtype=torch.float32, device=device)
@@ -292,6 +348,12 @@ class SurfelGradReducer:
         world = self._world(group)
         if world == 1:
             return
+        if d_indirect_dc is None:
+            # the indirect radiance is not looked at in this step (render_surfel without opt.indirect: the blended indirect light feeds no
+            # output) -- its factor is zero on EVERY rank by the structure of the step, not by its data: nothing is gathered, nothing
+            # expanded, the two indirect SH gradients come back as the zeros they are
+            self._ind_zero = True
+            return
         if self._early_ind is not None or self._void:
             if self._early_ind is not None:
                 self._early_ind.wait()
@@ -322,29 +384,59 @@ class SurfelGradReducer:
                 out.zero_()
             else:
                 torch.div(t[:, 0, :], SH_C0, out=out.view(P, 3))
+        ind_zero, self._ind_zero = self._ind_zero, False
         if w_rgb is None:
             seg("features_dc", self.row_rgb[:3 * P])
             self.row_rgb[3 * P:].copy_(campos.reshape(-1))
             w_rgb = dist.all_gather_into_tensor(self.gathered_rgb.view(-1), self.row_rgb, group=group, async_op=True)
-        if w_ind is None:
+        if w_ind is None and not ind_zero:
             seg("indirect_dc", self.row_ind)
             w_ind = dist.all_gather_into_tensor(self.gathered_ind.view(-1), self.row_ind, group=group, async_op=True)
-        self.dense.pack([tensors[i] for i in self.dense_pos])
-        w2 = sum_reduce_scatter_gather(self.dense.padded(world), group)
+        dense_out = None
+        if self.touched is not None:
+            rows = torch.cat([(tensors[i] if tensors[i] is not None else torch.zeros(self.shapes[i], dtype=torch.float32, device=self.row_rgb.device))
+                              .reshape(P, -1) for i in self.row_pos], dim=1).contiguous()
+            tail = torch.cat([(tensors[i] if tensors[i] is not None else torch.zeros(self.shapes[i], dtype=torch.float32, device=self.row_rgb.device))
+                              .reshape(-1) for i in self.tail_pos]) if self.tail_pos else None
+            rows_sum, tail_sum = self.touched.exchange(rows, tail, group)
+            dense_out, c0, t0 = {}, 0, 0
+            for i, c in zip(self.row_pos, self.row_cols):
+                dense_out[i] = rows_sum[:, c0:c0 + c].reshape(self.shapes[i])
+                c0 += c
+            for i in self.tail_pos:
+                n_ = int(self.shapes[i].numel())
+                dense_out[i] = tail_sum[t0:t0 + n_].view(self.shapes[i])
+                t0 += n_
+            w2 = _Done()
+        else:
+            self.dense.pack([tensors[i] for i in self.dense_pos])
+            w2 = sum_reduce_scatter_gather(self.dense.padded(world), group)
         w_rgb.wait()
+        zeros_ind = lambda: [torch.zeros((P, 1, 3), dtype=torch.float32, device=self.row_rgb.device),
+                             torch.zeros((P, 15, 3), dtype=torch.float32, device=self.row_rgb.device)]
         if self.expand_fn is expand_surfel_sh_gradients:
             # each family as soon as ITS rows are there: the first expansion runs under the second gather and the dense exchange
             sh = expand_surfel_sh_gradient_rows(self.gathered_rgb, None, xyz, rotation_raw, sh_degree, family="rgb")
-            w_ind.wait()
-            sh = sh + expand_surfel_sh_gradient_rows(self.gathered_rgb, self.gathered_ind, xyz, rotation_raw, sh_degree, family="ind")
+            if ind_zero:
+                sh = sh + zeros_ind()
+            else:
+                w_ind.wait()
+                sh = sh + expand_surfel_sh_gradient_rows(self.gathered_rgb, self.gathered_ind, xyz, rotation_raw, sh_degree, family="ind")
         else:       # (an injected checker takes the rows in one piece: [dRGB | dIND | campos])
-            w_ind.wait()
-            rows = torch.cat((self.gathered_rgb[:, :3 * P], self.gathered_ind, self.gathered_rgb[:, 3 * P:]), dim=1).contiguous()
-            sh = self.expand_fn(rows, xyz, rotation_raw, sh_degree)
+            if ind_zero:
+                self.gathered_ind.zero_()
+            else:
+                w_ind.wait()
+            rows_ = torch.cat((self.gathered_rgb[:, :3 * P], self.gathered_ind, self.gathered_rgb[:, 3 * P:]), dim=1).contiguous()
+            sh = self.expand_fn(rows_, xyz, rotation_raw, sh_degree)
         w2.wait()
         out = [None] * len(self.names)
-        for i, v in zip(self.dense_pos, self.dense.views()):
-            out[i] = v
+        if dense_out is not None:
+            for i in self.dense_pos:
+                out[i] = dense_out[i]
+        else:
+            for i, v in zip(self.dense_pos, self.dense.views()):
+                out[i] = v
         for i, v in zip(self.sh_pos, sh):
             out[i] = v
         return out

@@ -116,8 +116,10 @@ class _SurfelFeatures(torch.autograd.Function):
     features[P,8]) in one kernel each way (checker: oracle/glue_oracle.py, the reference's own chain of torch ops)."""
 
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos, pass_xyz=False, viewmatrix=None):
+    def forward(ctx, xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos, pass_xyz=False, viewmatrix=None,
+                indirect_live=True):
         ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward, not as zero-filled tensors
+        ctx.indirect_live = bool(indirect_live)
         if not xyz.is_cuda:
             raise RuntimeError("surfel_features needs CUDA(HIP) tensors: the per-gaussian glue runs in libmrgs.so, there is no CPU path")
         ts = [_c(t) for t in (xyz, scaling, rotation, opacity, refl, rough, ori_color, ind_dc, ind_rest, campos)]
@@ -154,17 +156,19 @@ class _SurfelFeatures(torch.autograd.Function):
             _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads),
                                                        _p(gs[4]), st))
         if _AFTER_FEATURES_HOOK[0] is not None:
-            _AFTER_FEATURES_HOOK[0](outs[7])
-        return (*outs, None, None, None)
+            # (indirect_live False: the caller's step does not look at the blended indirect radiance -- its gradient is zero by the structure of
+            #  the step, on every rank: the hook is told so instead of being handed a tensor of zeros to gather)
+            _AFTER_FEATURES_HOOK[0](outs[7] if ctx.indirect_live else None)
+        return (*outs, None, None, None, None)
 
 
-def surfel_features(pc, camera_center, pass_xyz=False, viewmatrix=None):
+def surfel_features(pc, camera_center, pass_xyz=False, viewmatrix=None, indirect_live=True):
     """(opacity[P,1], scales[P,2], rotations[P,4], features[P,8]) for `render_surfel` from the raw parameters of `pc`; with `pass_xyz`
     also the centres [P,3] as an output of the same node (hand THOSE to the rasterizer: its dL/dmeans3D is then summed with this node's
     own gradient of the centres inside the backward kernel).  `viewmatrix` (the camera's world_view_transform; "pgsr" flavour): features
     [P,12] with the plane distance of get_distance in channel 8 and zeros behind it."""
     return _SurfelFeatures.apply(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._refl_strength, pc._roughness, pc._ori_color,
-                                 pc._indirect_dc, pc._indirect_rest, camera_center, bool(pass_xyz), viewmatrix)
+                                 pc._indirect_dc, pc._indirect_rest, camera_center, bool(pass_xyz), viewmatrix, bool(indirect_live))
 
 
 _MAPS_FRAME_CACHE = {}
@@ -498,8 +502,11 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     # rows padded to twelve floats (the blend kernels move feature rows in 16-byte pieces); get_distance (torch) with the ASG lobes only
     use_asg = bool(getattr(pipe, "use_asg", False))
     fused_distance = flag != "2dgs" and not use_asg
+    # (indirect_live: the blended indirect radiance reaches an output only under opt.indirect -- :423-430, 472-473 --; without it the SH
+    #  indirect term's gradient is zero by construction, which a view-parallel step's exchange is told: dist.SurfelGradReducer.begin_early_ind)
     opacities, scales, rotations, features, means3D = surfel_features(pc, viewpoint_camera.camera_center, pass_xyz=True,
-                                                                      viewmatrix=viewpoint_camera.world_view_transform if fused_distance else None)
+                                                                      viewmatrix=viewpoint_camera.world_view_transform if fused_distance else None,
+                                                                      indirect_live=bool(getattr(opt, "indirect", False)) and not use_asg)
     if use_asg:                 # the lobes instead of the SH indirect term in channels 5..7 (:312-336)
         features = torch.cat((features[:, :5], _asg_indirect_of(pc, viewpoint_camera, scaling_modifier)), dim=-1)
         if flag != "2dgs":

@@ -163,6 +163,27 @@ def _worker_surfel(rank, world, port, q):
     voided = [o.clone() for o in red.reduce(grads, xyz, rot, campos, deg)]
     for a, b in zip(out, voided):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    # ---- the dense part as the union of the rows the ranks' views TOUCHED (TouchedRowsExchange): every rank's view leaves most rows zero
+    touched = torch.rand(P, generator=gen) < 0.4
+    sparse = [None if g is None else (g * touched.reshape((P,) + (1,) * (g.dim() - 1)).to(g.dtype) if g.shape[0] == P else g) for g in grads]
+    want = [o.clone() for o in red.reduce(sparse, xyz, rot, campos, deg)]
+    red_t = mdist.SurfelGradReducer(shapes, names, "cpu", expand_fn=dist_oracle.expand_surfel_sh_gradients, touched_rows_only=True)
+    got = [o.clone() for o in red_t.reduce(sparse, xyz, rot, campos, deg)]
+    for a, b in zip(want, got):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    st = red_t.touched.last
+    assert st["rows"] == P and st["touched_rows_this_rank"] <= st["union_rows"] < P and st["exchanged_bytes"] < st["dense_bytes"]
+    assert st["union_rows"] >= int(touched.sum())
+    # ---- the indirect factor is structurally zero (render_surfel without opt.indirect): nothing gathered, zeros back -- told through the hook
+    no_ind = list(sparse)
+    no_ind[9], no_ind[10] = torch.zeros(P, 1, 3), torch.zeros(P, 15, 3)
+    want0 = [o.clone() for o in red.reduce(no_ind, xyz, rot, campos, deg)]
+    red_t.begin_early_rgb(torch.where(touched[:, None], drgb, torch.zeros_like(drgb)), campos)
+    red_t.begin_early_ind(None)
+    got0 = [o.clone() for o in red_t.reduce(no_ind, xyz, rot, campos, deg)]
+    for a, b in zip(want0, got0):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert float(got0[9].abs().max()) == 0.0 and float(got0[10].abs().max()) == 0.0
     q.put((rank, [o.clone().numpy() for o in out], [None if g is None else g.numpy() for g in grads]))
     dist.barrier()
     dist.destroy_process_group()

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 def _bench(tmp_path, name, *args):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MRGS_DIST_BACKEND"] = "gloo"
+    env["MRGS_BENCH_VIEWS"] = "8"          # all eight orbit cameras whatever the warm-up: --dump-step k then names camera k in every run
     dump = str(tmp_path / f"{name}.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
                         "--dump-grads", dump], env=env, capture_output=True, text=True, timeout=300)
