@@ -415,7 +415,11 @@ int mrgs_surfel_features_forward(const MrgsSurfelParams* p, float* opacity, floa
                                  void* stream);
 /* upstream gradients of the four outputs (any may be NULL = zero).  d_xyz = the part that flows through the view and mirror directions
  * + g_xyz_upstream [P,3] (NULL = zero): what reached the centres some other way -- the rasterizer's own dL/dmeans3D --, so that the
- * caller's sum of the two is no kernel of its own (ABI 6; must not alias d_xyz) */
+ * caller's sum of the two is no kernel of its own (ABI 6; must not alias d_xyz).
+ * Where the upstream gradient of the three indirect-radiance channels (g_features[:, 5:8]) is exactly zero for all 64 rows of a wave, the
+ * wave writes zeros to d_indirect_dc / d_indirect_rest without reading the coefficients: for FINITE coefficients that is what the chain
+ * rule gives; a non-finite coefficient, which the reference's torch chain would turn into a NaN gradient (0 x inf), stays unnoticed
+ * there.  d_indirect_rest may have any 4-byte alignment (16-byte aligned tensors take the wide stores). */
 int mrgs_surfel_features_backward(const MrgsSurfelParams* p, const float* g_opacity, const float* g_scales, const float* g_rotations,
                                   const float* g_features, const MrgsSurfelGrads* grads, const float* g_xyz_upstream, void* stream);
 

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelPara
         tile_store<REST_L>(tile, out.d_indirect_rest + (size_t)row0 * REST_L, nrows, lane);
     } else {
         float* dst = out.d_indirect_rest + (size_t)row0 * REST_L;
-        if (nrows == 64) {          // the wave's 64 rows are one 16-byte aligned run of 64 * 45 floats
+        if (nrows == 64 && (((uintptr_t)dst) & 15u) == 0) {          // the wave's 64 rows are one run of 64 * 45 floats, 16-byte aligned when the tensor is
             float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
             for (int k = 0; k * 64 < 16 * REST_L; k++)

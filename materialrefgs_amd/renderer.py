@@ -385,8 +385,13 @@ class _SplitChannels(torch.autograd.Function):
         k, shape = ctx.k, ctx.shape
         ref = g_head if g_head is not None else g_one
         hb = getattr(g_head, "_base", None) if g_head is not None else None
-        if hb is not None and tuple(hb.shape) == shape and g_head.storage_offset() == 0 and hb.is_contiguous() and hb.dtype == ref.dtype:
-            g = hb              # the producer laid its maps out as the head of the stack (shading._SurfelShade.backward): nothing to copy
+        from . import shading as _sh
+        if hb is not None and tuple(hb.shape) == shape and g_head.storage_offset() == 0 and hb.is_contiguous() and hb.dtype == ref.dtype and \
+                _sh.take_owned_stack(hb):
+            # the producer laid its maps out as the head of a stack it allocated FOR this node (shading._SurfelShade.backward marks it):
+            # nothing to copy.  A base of the right shape that is not so marked (e.g. the gradient of torch.cat((the eight maps, other
+            # maps)): its rows behind the head belong to another branch) is left alone and copied from.
+            g = hb
         else:
             g = torch.empty(shape, dtype=ref.dtype, device=ref.device)
             (g[:k].copy_(g_head) if g_head is not None else g[:k].zero_())

@@ -784,6 +784,30 @@ def test_cube_symmetry_rows_form_the_octahedral_group():
         assert np.array_equal(parent(P8[g][t], 8), P4[g][parent(t, 8)])
 
 
+def test_split_channels_only_takes_over_a_stack_it_was_given():
+    """renderer._SplitChannels.backward reuses the base of its head gradient as its own output ONLY when shading._SurfelShade.backward
+    allocated that base for it (marked): a head gradient that is a view into somebody else's [S,H,W] tensor -- torch.cat of the eight maps
+    with another branch's maps hands out exactly that -- is copied from, and the other branch's rows stay what they were (CPU: pure torch)."""
+    from materialrefgs_amd import shading as sh
+    from materialrefgs_amd.renderer import _SplitChannels
+    H, W = 4, 5
+    maps = torch.randn(12, H, W, requires_grad=True)
+    head, one = _SplitChannels.apply(maps, 8, True)
+    other = torch.randn(4, H, W, requires_grad=True)
+    torch.cat((head, other * 2.0)).mul(torch.arange(12.0).reshape(12, 1, 1)).sum().backward()     # head's gradient: rows 0..7 of a [12,H,W] tensor
+    assert torch.equal(other.grad, (2.0 * torch.arange(8.0, 12.0)).reshape(4, 1, 1).expand(4, H, W))
+    assert torch.equal(maps.grad[:8], torch.arange(8.0).reshape(8, 1, 1).expand(8, H, W)) and float(maps.grad[8].abs().max()) == 0.0
+    # ... and a stack that IS marked is taken over (no copy): the returned gradient is that very memory
+    stack = torch.zeros(12, H, W)
+    sh.OWNED_STACKS[stack.data_ptr()] = __import__("weakref").ref(stack)
+    stack[:8] = 3.0
+    maps2 = torch.randn(12, H, W, requires_grad=True)
+    h2, o2 = _SplitChannels.apply(maps2, 8, True)
+    torch.autograd.backward([h2, o2], [stack[:8], torch.full((1, H, W), 5.0)])
+    assert float(stack[8].min()) == 5.0 and not sh.OWNED_STACKS          # written in place, the mark consumed
+    assert torch.equal(maps2.grad[:8], torch.full((8, H, W), 3.0)) and torch.equal(maps2.grad[8], torch.full((H, W), 5.0))
+
+
 def test_blocked_float64_prefilter_operator_equals_the_dense_one():
     """oracle/envfilter_oracle.BlockedSpecular (what the full-size checks apply at 128^2 and 64^2, where the dense operator does not fit)
     against the dense operator of the same level at 32^2, both directions; and build_mips / build_mips_backward give the same levels

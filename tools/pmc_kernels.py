@@ -32,17 +32,29 @@ def main():
         args.remove(sys.argv[sys.argv.index("--min-calls") + 1])
     dst, srcs = args[0], args[1:]
     acc = defaultdict(lambda: defaultdict(list))
-    wall = defaultdict(list)          # kernel -> launch durations in ns, from the kernel traces written beside the counter files
-    import glob, os
+    # kernel -> (launch duration in ns, GRBM_GUI_ACTIVE of THE SAME launch): a counter csv is paired with the kernel trace rocprofv3 wrote
+    # for the same process (same file prefix: <pid>_counter_collection.csv / <pid>_kernel_trace.csv), and its rows with the trace's by
+    # Dispatch_Id -- never with another pass's trace that happens to lie in the directory (another clock state), never twice
+    paired = defaultdict(list)
+    import os
+    seen_traces = set()
     for src in srcs:
-        for row in csv.DictReader(open(src)):
+        rows = list(csv.DictReader(open(src)))
+        for row in rows:
             acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for tr in glob.glob(os.path.join(os.path.dirname(src), "*kernel_trace.csv")):
-            for row in csv.DictReader(open(tr)):
-                try:
-                    wall[short(row["Kernel_Name"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
-                except (KeyError, ValueError):
-                    pass
+        tr = src.replace("counter_collection.csv", "kernel_trace.csv")
+        if tr == src or not os.path.exists(tr) or os.path.realpath(tr) in seen_traces:
+            continue
+        seen_traces.add(os.path.realpath(tr))
+        dur = {}
+        for row in csv.DictReader(open(tr)):
+            try:
+                dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
+        for row in rows:
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("Dispatch_Id") in dur:
+                paired[short(row["Kernel_Name"])].append((dur[row["Dispatch_Id"]], float(row["Counter_Value"]) / 8))
     out = {}
     for k, cs in sorted(acc.items()):
         n = max(len(v) for v in cs.values())
@@ -53,9 +65,13 @@ def main():
         cyc = o.get("GRBM_GUI_ACTIVE", 0) / 8
         if cyc > 0:
             o["derived_launch_cycles"] = round(cyc)
-            if wall.get(k):
-                o["derived_wall_us"] = round(sum(wall[k]) / len(wall[k]) / 1e3, 2)
-                o["derived_effective_ghz"] = round(cyc / (sum(wall[k]) / len(wall[k])), 3)
+            if paired.get(k):
+                w_ns = sum(d for d, _ in paired[k]) / len(paired[k])
+                o["derived_wall_us"] = round(w_ns / 1e3, 2)
+                # the sanity figure, launch by launch matched: only where the launch is long enough for its ~3 us of dispatch overhead (counted
+                # by GRBM, not by the trace's timestamps) not to be the figure -- a 4 us kernel "runs at 12 GHz" otherwise
+                if w_ns >= 20e3:
+                    o["derived_effective_ghz"] = round(sum(c for _, c in paired[k]) / sum(d for d, _ in paired[k]), 3)
             if "SQ_ACTIVE_INST_VALU" in o:
                 raw = o["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024)
                 o["derived_valu_issue_rate"] = round(raw, 3)
