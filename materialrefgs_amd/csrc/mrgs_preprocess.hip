@@ -234,6 +234,9 @@ __device__ __forceinline__ void wave_rows_store_linear(const float* __restrict__
         if (k * 64 + lane < 720) reinterpret_cast<float4*>(rest)[k * 64 + lane] = t4[SH_LIN_REST / 4 + k * 64 + lane];
 }
 
+#ifndef MRGS_PRE_STAGE_REC
+#define MRGS_PRE_STAGE_REC 1
+#endif
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, int D, int M, int W, int H, int tiles_x, int tiles_y, float scale_modifier, const float* __restrict__ means3D,
@@ -248,7 +251,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
 {
     // SPLIT (shs = DC [P,1,3], shs_rest = [P,M-1,3]): the rows of the two tensors are staged through a per-wave LDS tile in the unsplit
     // row layout; 180-byte rows cannot be fetched per lane with 16-byte loads the way the 192-byte rows of the unsplit tensor are
-    __shared__ __attribute__((aligned(16))) float s_sh[SPLIT ? 4 * 64 * SH_LDS_STRIDE : 1];
+    // (without the SH tile the records still leave through LDS: 64 x 32 floats per wave, see MRGS_PRE_STAGE_REC below)
+    __shared__ __attribute__((aligned(16))) float s_sh[SPLIT ? 4 * 64 * SH_LDS_STRIDE : (MRGS_PRE_STAGE_REC ? 4 * 64 * 32 : 1)];
+    // first kernel of a forward: clears the per-call state of the later binning kernels (num_rendered, error flag, CU census,
+    // tickets / totals / look-back words of the depth sort and the scan) instead of a separate memset launch
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < clear_words; i += gridDim.x * blockDim.x) clear_ptr[i] = 0u;
+    // (Round 6 measured persistent workgroups here -- as many as the chip holds, each walking its share of the 256-gaussian blocks --: the
+    //  loop form of this body costs the compiler 234 registers (168 with 40 spilled when capped) and the launch 41 - 51 us against 36.)
     bool sh_linear = false;                 // (wave-uniform) the wave's tile is the verbatim copy: wave_rows_load_linear
     if (SPLIT) {
         const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
@@ -263,19 +272,27 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    // first kernel of a forward: clears the per-call state of the later binning kernels (num_rendered, error flag, CU census,
-    // tickets / totals / look-back words of the depth sort and the scan) instead of a separate memset launch
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < clear_words; i += gridDim.x * blockDim.x) clear_ptr[i] = 0u;
     // (the SH rows are read straight from global memory here: staging them through LDS as the backward does costs more in
     // occupancy -- 50 KB per workgroup -- than the coalescing gains; 0.060 ms staged vs 0.054 ms direct at P = 300k)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+#if !MRGS_PRE_STAGE_REC
     if (idx >= P) return;
+#endif
     float V[16], PM[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { V[i] = viewmatrix[i]; PM[i] = projmatrix[i]; }
     int out_radius = 0;
     uint32_t out_tiles = 0, out_key = 0xFFFFFFFFu;
     uint2 out_rect = make_uint2(0, 0);
+#if MRGS_PRE_STAGE_REC
+    // The surfel record (80 bytes) and the cull record (48 bytes) of a lane's gaussian leave through the wave's LDS tile: written per lane
+    // they are 5 + 3 store instructions that each touch 64 different 128-byte lines 80 / 48 bytes apart; from the tile the wave's 64
+    // records are one contiguous run of 5 120 / 3 072 bytes that leaves as 16 bytes per lane and instruction, lane-contiguous.
+    bool wrote_rec = false;
+    float4* const st4 = reinterpret_cast<float4*>(s_sh + (threadIdx.x >> 6) * (SPLIT ? 64 * SH_LDS_STRIDE : 64 * 32));
+    const int st_lane = threadIdx.x & 63;
+    if (idx < P)
+#endif
     do {
         const float p[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
         const float pvx = V[0] * p[0] + V[4] * p[1] + V[8] * p[2] + V[12];
@@ -506,20 +523,52 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
             const float rr = sqrtf(0.5f * (float)tau) + 0.05f;
             cull_c = make_float4(cx, cy, rr * rr, centre_slack);
         }
+#if MRGS_PRE_STAGE_REC
+        __builtin_amdgcn_wave_barrier();         // (the SH rows of the tile have been read by every lane that gets here)
+        float4* r4 = st4 + st_lane * MRGS_REC_F4;
+        float4* c4 = st4 + 64 * MRGS_REC_F4 + st_lane * MRGS_CULL_F4;
+        wrote_rec = true;
+#else
         float4* r4 = rec + (size_t)idx * MRGS_REC_F4;
+        float4* c4 = cull + (size_t)idx * MRGS_CULL_F4;
+#endif
         r4[0] = make_float4(T[0], T[1], T[2], T[3]);
         r4[1] = make_float4(T[4], T[5], T[6], T[7]);
         r4[2] = make_float4(T[8], cx, cy, opa);
         r4[3] = make_float4(nx, ny, nz, rgb[0]);
         r4[4] = make_float4(rgb[1], rgb[2], pvz, rec_extra != nullptr ? rec_extra[(size_t)idx * rec_extra_stride] : 0.0f);
-        cull[(size_t)idx * MRGS_CULL_F4] = cull_a;
-        cull[(size_t)idx * MRGS_CULL_F4 + 1] = cull_b;
-        cull[(size_t)idx * MRGS_CULL_F4 + 2] = cull_c;
+        c4[0] = cull_a;
+        c4[1] = cull_b;
+        c4[2] = cull_c;
         out_radius = iradius;
         out_tiles = (uint32_t)((rmax[1] - rmin[1]) * (rmax[0] - rmin[0]));
         out_key = __float_as_uint(pvz);
         out_rect = make_uint2((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16), (uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16));
     } while (0);
+#if MRGS_PRE_STAGE_REC
+    {
+        const uint64_t wm = __builtin_amdgcn_ballot_w64(wrote_rec);          // lanes whose records are in the tile (the others' stay unwritten, as ever)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (wm != 0ull) {
+            const size_t row0 = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+            float4* g_rec = rec + row0 * MRGS_REC_F4;
+            float4* g_cull = cull + row0 * MRGS_CULL_F4;
+#pragma unroll
+            for (int k = 0; k < MRGS_REC_F4; k++) {
+                const int t = k * 64 + st_lane;
+                if ((wm >> (t / MRGS_REC_F4)) & 1ull) g_rec[t] = st4[t];
+            }
+#pragma unroll
+            for (int k = 0; k < MRGS_CULL_F4; k++) {
+                const int t = k * 64 + st_lane;
+                if ((wm >> (t / MRGS_CULL_F4)) & 1ull) g_cull[t] = st4[64 * MRGS_REC_F4 + t];
+            }
+        }
+        if (idx >= P) return;
+    }
+#endif
     radii[idx] = out_radius;
     if (visible != nullptr) visible[idx] = out_radius > 0 ? (uint8_t)1 : (uint8_t)0;
     tiles_touched[idx] = out_tiles;
