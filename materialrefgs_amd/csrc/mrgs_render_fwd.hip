@@ -277,8 +277,10 @@ template <int S_MAX, bool FV, int S_LIVE>
 // Waves per SIMD the register allocator is held to.  Round 4 (after the exact-decision logic joined the loop), forward blend stage in ms at
 // C2 / C3full: S = 0 at 7 / 6 / 5 / 4 waves 0.172 / 0.170 / 0.176 / 0.174 (72 / 80 / 95 / 96 VGPRs, 21 / 14 / 0 / 0 spilled); S = 8 at 6 / 5 / 4
 // waves 0.203 / 0.204 / 0.195 (105 VGPRs and no spills at 4).
+// Round 6 (with the running transmittance bound in the loop): S = 0 at 6 / 5 waves 153.1-154.4 / 154.7-156.4 us (80 VGPRs with 12 spilled /
+// 94 with none): the same within the run-to-run spread -- 5, the instance without scratch.
 #ifndef MRGS_FWD_WAVES_S0
-#define MRGS_FWD_WAVES_S0 6
+#define MRGS_FWD_WAVES_S0 5
 #endif
 #ifndef MRGS_FWD_WAVES_S8
 #define MRGS_FWD_WAVES_S8 4
