@@ -377,7 +377,10 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
 __device__ __forceinline__ int bs_pad(int b) { return b + b / BS_OWN; }    // ... read without bank conflicts (lane stride BS_OWN + 1 words)
 // (amdgpu_waves_per_eu: without the cap the compiler has been seen to spend 237 VGPRs on this kernel -- one workgroup per CU -- and the
 // sort took three times as long)
-__global__ void __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
+#ifndef MRGS_TILE_SORT_WAVES
+#define MRGS_TILE_SORT_WAVES 4
+#endif
+__global__ void __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(MRGS_TILE_SORT_WAVES, 8))) tile_sort_kernel(int T, const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_loc,
                                                                const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ state,
                                                                int64_t capacity, const unsigned long long* __restrict__ pairs,
                                                                uint32_t* __restrict__ plist, uint8_t* __restrict__ qmask,

@@ -183,7 +183,10 @@ __global__ void __launch_bounds__(256) surfel_features_fwd_kernel(MrgsSurfelPara
     if (prm.viewmatrix != nullptr) fo[2] = make_float4(fabsf(plane_distance(prm.viewmatrix, f.nn, p).s), 0.0f, 0.0f, 0.0f);
 }
 
-__global__ void __launch_bounds__(256) surfel_features_bwd_kernel(MrgsSurfelParams prm, const float* __restrict__ g_opacity,
+#ifndef MRGS_FEAT_BWD_WAVES
+#define MRGS_FEAT_BWD_WAVES 3        // 46 KB of LDS per workgroup: three workgroups (twelve waves) per CU, if the registers allow it
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MRGS_FEAT_BWD_WAVES, 8))) surfel_features_bwd_kernel(MrgsSurfelParams prm, const float* __restrict__ g_opacity,
                                                                   const float* __restrict__ g_scales, const float* __restrict__ g_rotations,
                                                                   const float* __restrict__ g_features, MrgsSurfelGrads out,
                                                                   const float* __restrict__ g_xyz_upstream)
