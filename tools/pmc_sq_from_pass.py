@@ -7,6 +7,10 @@ workload, path = sys.argv[1:3]
 red = json.load(open(path))
 out_path = os.path.join(ROOT, "profiles", "pmc_sq.json")
 data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+sys.path.insert(0, ROOT)
+from bench import kernel_source_digest
+if data.get("kernel_source_digest") != kernel_source_digest():
+    data = {"kernel_source_digest": kernel_source_digest(), "measured_by": "tools/pmc_pass.sh (rocprofv3 --kernel-trace --pmc SQ_* -- python3 bench.py)"}
 entry = {}
 for short, pat in (("render_bwd", "render_bwd_kernel"), ("render_fwd", "render_fwd_kernel")):
     for name, k in red.items():

@@ -29,7 +29,11 @@ def main():
     workload, fpath, wpath = sys.argv[1:4]
     fetch, write = per_launch(fpath, "FETCH_SIZE"), per_launch(wpath, "WRITE_SIZE")
     out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_digest
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    if data.get("kernel_source_digest") != kernel_source_digest():
+        data = {}             # figures of other kernel sources do not ride along under this tree's digest
     entry, detail = {}, {}
     for k in KERNELS:
         if k in fetch and k in write:
@@ -37,8 +41,6 @@ def main():
             entry[k] = int(rd + wr)
             detail[k] = {"fetch_bytes_corrected_x2": int(rd), "write_bytes": int(wr)}
     data[workload] = entry
-    sys.path.insert(0, ROOT)
-    from bench import kernel_source_digest
     data["kernel_source_digest"] = kernel_source_digest()     # bench.py reports the traffic only for these very sources
     data["measured_by"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 5 --warmup 2 (tools/profile_round.sh)"
     data.setdefault("_detail", {})[workload] = detail

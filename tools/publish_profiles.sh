@@ -14,7 +14,7 @@ for f in $O/${TAG}_soak_*.txt; do
   if [ "$D" != "$NOW" ]; then echo "REFUSED $(basename $f): stamped '$D', the tree's kernels are '$NOW' -- run the soak again"; rc=1; continue; fi
   cp "$f" $R/profiles/; echo "published $(basename $f) ($D)"
 done
-for f in $O/${TAG}_*kernel_stats.csv $O/${TAG}_bench_*.json $O/${TAG}_pmc_*.json $O/${TAG}_pmc_*_C2.csv $O/${TAG}_trace_time.json $O/${TAG}_spmv_levels.txt $O/${TAG}_gputests.log; do
+for f in $O/${TAG}_*kernel_stats.csv $O/${TAG}_bench_*.json $O/${TAG}_pmc_*.json $O/${TAG}_pmc_*_C2.csv $O/${TAG}_trace_time.json $O/${TAG}_spmv_levels.txt $O/${TAG}_gputests.log $O/${TAG}_driver_line.txt; do
   [ -e "$f" ] && cp "$f" $R/profiles/
 done
 for f in pmc_traffic.json pmc_sq.json; do [ -e "$O/$f" ] && cp $O/$f $R/profiles/$f; done
