@@ -41,6 +41,8 @@ __global__ void __launch_bounds__(1024) k(float* out, int iters, int active)
                 if (OP == 0) atomicAdd(&tab[w], 1.0f);
                 else if (OP == 1) acc += atomicAdd(&tab[w], 1.0f);                   // returning
                 else if (OP == 2) acc += __int_as_float(atomicCAS((int*)&tab[w], 0, (int)h | 1));
+                else if (OP == 4) atomicAdd((unsigned*)&tab[w], 3u);                  // ds_add_u32
+                else if (OP == 5) atomicAdd((unsigned long long*)&tab[w & ~1u], 3ull); // ds_add_u64 (12 288 entries of 8 bytes)
                 else tab[w] = 1.0f;                                                   // plain store (reference)
             }
         }
@@ -82,6 +84,12 @@ int main()
         run<0, 2>("ds_add_f32 one word", waves, 64);
         run<0, 2>("ds_add_f32 one word", waves, 8);
         run<0, 3>("ds_add_f32 8 lanes per word", waves, 64);
+        run<4, 1>("ds_add_u32 random words", waves, 64);
+        run<4, 4>("ds_add_u32 random texel*3+c", waves, 64);
+        run<4, 3>("ds_add_u32 8 lanes per word", waves, 64);
+        run<5, 1>("ds_add_u64 random words", waves, 64);
+        run<5, 4>("ds_add_u64 random texel*3+c", waves, 64);
+        run<5, 3>("ds_add_u64 8 lanes per word", waves, 64);
         run<1, 1>("ds_add_rtn_f32 random words", waves, 64);
         run<2, 1>("ds_cmpst_rtn_b32 random words", waves, 64);
         run<2, 3>("ds_cmpst_rtn_b32 8 lanes per word", waves, 64);
