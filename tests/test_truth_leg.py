@@ -89,3 +89,67 @@ def test_hip_is_no_further_from_float64_than_the_literal_fp32_reading(P, S, H, W
         # per-element relative error above 1e-3 max|g|: the bulk of the elements, not only the largest one
         assert row["hip"]["elem_median"] <= max(2.0 * row["literal32"]["elem_median"], 1e-6), (k, row)
         assert row["hip"]["elem_p99"] <= max(2.0 * row["literal32"]["elem_p99"], 1e-4), (k, row)
+
+
+# ---- lone tiny surfels: the truth-leg rule holds in distribution, not per draw ------------------------------------------------------
+# Round 6's soak on a fresh seed (profiles/r6_v2_soak_raster_seed448141_2000.txt, case 1478) met a lone 1.5-pixel surfel whose `scales`
+# gradient -- a 1e-3 residue of per-pixel terms that cancel -- was 5.3e-4 from float64 in the kernels and 5.2e-5 in the literal fp32
+# reading: the x 1.5 rule compares with ONE draw of the literal's rounding.  Over a set of such surfels both readings spread over
+# four decades with the same median; that is what is asserted here, together with the case itself.
+LONE_CASE = dict(P=1, S=0, H=80, W=412, deg=3, rpx=1.5, view=5, seed=491724934)      # case 1478 of seed 448141 (tools/scratch/diag_case.py)
+
+
+def _lone_scenes(n, rng_seed=5):
+    rng = np.random.default_rng(rng_seed)
+    for _ in range(n):
+        H, W = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+        yield dict(P=1, S=0, H=H, W=W, deg=3, rpx=1.5, view=int(rng.integers(0, 8)), seed=int(rng.integers(1 << 30)))
+
+
+def _lone_errors(case, hip_dev=None):
+    """(err of the fused oracle, err of the literal reading, err of the kernels or None) of the `scales` gradient against float64;
+    None when the surfel is not rendered or its gradient is zero."""
+    scene = make_shell_scene(case["P"], S=case["S"], seed=case["seed"], radius_px=case["rpx"], image_size=max(case["H"], case["W"]))
+    cam = orbit_camera(case["view"], case["H"], case["W"])
+    g = upstream_grads(case["S"], case["H"], case["W"])
+    legs = {}
+    for v in ("fused", "lit32", "f64"):
+        r = ro.render_scene(scene, cam, sh_degree=case["deg"], variant=v)
+        if r.R == 0:
+            r.close()
+            return None
+        legs[v] = r.backward(*g)["scales"]
+        r.close()
+    if float(np.abs(legs["f64"]).max()) == 0.0:
+        return None
+    rel = lambda a: float(np.abs(np.asarray(a, np.float64).reshape(legs["f64"].shape) - legs["f64"]).max() / np.abs(legs["f64"]).max())
+    e_hip = None
+    if hip_dev is not None:
+        from helpers import HipRender
+        hr = HipRender(scene, cam, hip_dev, sh_degree=case["deg"])
+        e_hip = rel(hr.backward(*g)["scales"])
+    return rel(legs["fused"]), rel(legs["lit32"]), e_hip
+
+
+def test_lone_tiny_surfels_fused_and_literal_readings_spread_alike():
+    errs = [e for e in (_lone_errors(c) for c in _lone_scenes(40)) if e is not None]
+    assert len(errs) >= 20
+    fused, lit = np.array([e[0] for e in errs]), np.array([e[1] for e in errs])
+    print(f"lone 1.5-pixel surfels, scales gradient vs float64 over {len(errs)} scenes: literal fp32 min {lit.min():.1e} median {np.median(lit):.1e} "
+          f"max {lit.max():.1e}; fused min {fused.min():.1e} median {np.median(fused):.1e} max {fused.max():.1e}")
+    assert lit.max() / max(lit.min(), 1e-12) > 100.0                     # the quantity IS ill-conditioned: one draw says little
+    ratio = np.exp(np.mean(np.log(np.maximum(fused, 1e-12) / np.maximum(lit, 1e-12))))
+    assert 1 / 1.5 <= ratio <= 1.5, ratio                               # ... and the two readings are equally far from the truth on average
+    f, l, _ = _lone_errors(LONE_CASE)
+    assert l < 0.2 * np.median(lit) and f <= np.median(lit)             # the soak's case: the literal at the lucky end, the fused reading below the median
+
+
+@pytest.mark.gpu
+def test_lone_tiny_surfels_kernels_and_literal_reading_spread_alike(gpu_device):
+    errs = [e for e in (_lone_errors(c, gpu_device) for c in _lone_scenes(40)) if e is not None]
+    hip, lit = np.array([e[2] for e in errs]), np.array([e[1] for e in errs])
+    ratio = np.exp(np.mean(np.log(np.maximum(hip, 1e-12) / np.maximum(lit, 1e-12))))
+    print(f"kernels: min {hip.min():.1e} median {np.median(hip):.1e} max {hip.max():.1e}; geometric-mean ratio to the literal reading {ratio:.2f}")
+    assert 1 / 1.5 <= ratio <= 1.5, ratio
+    _, l, h = _lone_errors(LONE_CASE, gpu_device)
+    assert h <= np.median(lit) and h <= 1e-3, (h, l, float(np.median(lit)))
