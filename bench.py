@@ -701,6 +701,11 @@ def main():
         "config": {"workload": desc, "P": P, "H": H, "W": W, "S": S, "sh_degree": 3, "num_rendered": int(state["R"]),
                    "views_per_step": world, "cameras_cycled": n_views, "parallelism": f"view-parallel x{world}" if world > 1 else "single GPU"},
     }
+    if surfel_mode:
+        # (the rasterizer's per-gaussian backward carries on through the glue's backward in one kernel where nothing reads the blended
+        #  indirect radiance -- MrgsRasterGrads::glue_params; MRGS_NO_GLUE_EPILOGUE=1 restores the two-kernel backward)
+        import materialrefgs_amd.renderer as _rm
+        out["config"]["glue_epilogue"] = bool(_rm._FUSE_GLUE and not indirect and flavour == "2dgs" and not getattr(pipe, "use_asg", False))
     if rank == 0:
         R, HW = int(state["R"]), H * W
         stage_ms = {"preprocess_fwd": stage_times.preprocess_ms, "depth_sort_scan": stage_times.sort_ms,
@@ -815,9 +820,13 @@ def main():
             hip = {n: t_.grad.detach().cpu().numpy() for n, t_ in zip(render_oracle.LEAF_NAMES, surfel_params[:11])}
             hip["env_base"] = env.base.grad.detach().cpu().numpy()
             hip["viewspace_points"] = out_h["viewspace_points"].grad.detach().cpu().numpy()
+            # (the rasterizer's per-gaussian inputs have gradient tensors of their own only when the glue's backward is a kernel of its own: with
+            #  the glue epilogue -- the default for this workload -- the chain runs from the gradient rows to the raw leaves inside one kernel)
+            mid = [n for n, t_ in zip(render_oracle.RASTER_INPUT_NAMES, stash["o"]) if t_.grad is not None]
             for n, t_ in zip(render_oracle.RASTER_INPUT_NAMES, stash["o"]):
-                hip[n] = t_.grad.detach().cpu().numpy()
-            names = list(render_oracle.LEAF_NAMES) + ["env_base", "viewspace_points"] + list(render_oracle.RASTER_INPUT_NAMES)
+                if t_.grad is not None:
+                    hip[n] = t_.grad.detach().cpu().numpy()
+            names = list(render_oracle.LEAF_NAMES) + ["env_base", "viewspace_points"] + mid
             rows, ok = render_oracle.leaf_gradient_report(hip, g_o, names, bar=1e-4)
             maps = {}
             for k in keys + ["specular_map", "diffuse_map", "roughness_map", "base_color_map", "refl_strength_map"]:

@@ -183,6 +183,20 @@ typedef struct MrgsRasterGrads {
     float* dL_dscales;     /* [P,2] */
     float* dL_drotations;  /* [P,4] */
     float* dL_dsh_rest;    /* [P,M-1,3] with the split SH layout (MrgsRasterInputs::shs_rest; dL_dsh is then [P,1,3]), else NULL */
+    /* ABI 10 -- the glue epilogue: both NULL, or both set by render_surfel's caller (declared further down: the raw GaussianModel parameters
+     * and their gradient tensors, the arguments of mrgs_surfel_features_backward).  Set: the per-gaussian backward applies the backward of the
+     * per-gaussian glue (gaussian_renderer/__init__.py:338-355 and the GaussianModel getters: sigmoid / exp / normalize) to its results while
+     * they are in registers and writes glue_grads' nine tensors (fully; d_indirect_dc / d_indirect_rest as zeros) INSTEAD of dL_dopacity,
+     * dL_dscales, dL_drotations, dL_dfeatures and dL_dmeans3D, which are not touched and may be NULL; dL_dcolors and dL_dtransMat are written
+     * if not NULL.  One pass over the P rows instead of two (mrgs_surfel_features_backward is not called for this render).
+     * Contract: S = 8 with the rows mrgs_surfel_features_forward wrote for the same parameters (scales / rotations given, no precomputed
+     * transMat), NO upstream gradient at feature channels 5..7 (nothing reads the blended indirect radiance: render_surfel without
+     * opt.indirect) and glue_params->viewmatrix NULL (no "pgsr" plane distance) -- the mirror direction then takes no gradient.  Another
+     * channel count, a precomputed transMat or a viewmatrix: MRGS_E_UNSUPPORTED; the channels' zero gradient is the caller's word (it is
+     * not read).
+     * glue_params' indirect_dc / indirect_rest / xyz / campos are not read. */
+    const struct MrgsSurfelParams* glue_params;
+    const struct MrgsSurfelGrads* glue_grads;
 } MrgsRasterGrads;
 
 /* Backward.  Replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:353-462).  The three
@@ -718,7 +732,7 @@ int mrgs_side_stream_fork_at_blend(void* main_stream, void** side_stream);
 
 /* Revision of this header's struct layouts and call signatures; a binding compares it with the MRGS_ABI_VERSION it was written
  * against before the first call (materialrefgs_amd/_lib.py does). */
-#define MRGS_ABI_VERSION 9
+#define MRGS_ABI_VERSION 10
 int32_t mrgs_abi_version(void);
 
 #ifdef __cplusplus

@@ -42,7 +42,8 @@ MRGS_HINT_VISIBLE_BYTES = 2
 
 class MrgsRasterGrads(_Sized):
     _fields_ = [("struct_size", ctypes.c_uint64)] + [(n, c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dfeatures", "dL_dopacity", "dL_dmeans3D",
-                                        "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dsh_rest")]
+                                        "dL_dtransMat", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dsh_rest",
+                                        "glue_params", "glue_grads")]     # ABI 10: the glue epilogue (pointers to MrgsSurfelParams / MrgsSurfelGrads)
 
 
 MRGS_MAX_MIPS = 8
@@ -229,7 +230,7 @@ SYMBOLS = {
     "mrgs_version": (ctypes.c_char_p, []),
     "mrgs_abi_version": (c_int32, []),
 }
-MRGS_ABI_VERSION = 9   # the revision of include/mrgs.h these ctypes declarations were written against
+MRGS_ABI_VERSION = 10   # the revision of include/mrgs.h these ctypes declarations were written against
 
 _lib = None
 

@@ -453,6 +453,23 @@ int mrgs_rasterize_forward(const MrgsRasterConfig* cfg, const MrgsRasterInputs* 
 // The backward in two halves: the blend backward (+ optionally the clamp-masked colour gradients of the visible surfels, which are final
 // once it has run) and the per-gaussian backward.  A view-parallel caller puts its all-gather of those colour gradients on the wire
 // between the two (materialrefgs_amd/dist.py), where it overlaps the second half.
+// the gradient tensors a backward needs for this configuration (MrgsRasterGrads; with the glue epilogue the five tensors it replaces may be
+// NULL): MRGS_OK, MRGS_E_BAD_ARG (a tensor missing) or MRGS_E_UNSUPPORTED (the epilogue asked for a render it does not serve)
+static int grads_check(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const MrgsRasterGrads* g)
+{
+    if (!g->dL_dmeans2D || (cfg->M > 0 && !g->dL_dsh) || ((in->shs_rest != nullptr) != (g->dL_dsh_rest != nullptr))) return MRGS_E_BAD_ARG;
+    if ((g->glue_params != nullptr) != (g->glue_grads != nullptr)) return MRGS_E_BAD_ARG;
+    if (g->glue_params == nullptr)
+        return (g->dL_dcolors && g->dL_dopacity && g->dL_dmeans3D && g->dL_dtransMat && g->dL_dscales && g->dL_drotations && (cfg->S == 0 || g->dL_dfeatures))
+                   ? MRGS_OK : MRGS_E_BAD_ARG;
+    const MrgsSurfelParams* p = g->glue_params;
+    const MrgsSurfelGrads* o = g->glue_grads;
+    if (cfg->S != 8 || !in->scales || !in->rotations || in->transMat_precomp || p->viewmatrix) return MRGS_E_UNSUPPORTED;
+    if (cfg->P != p->P || !p->scaling_raw || !p->rotation_raw || !p->opacity_raw || !p->refl_raw || !p->rough_raw || !p->ori_color_raw) return MRGS_E_BAD_ARG;
+    return (o->d_xyz && o->d_scaling && o->d_rotation && o->d_opacity && o->d_refl && o->d_rough && o->d_ori_color && o->d_indirect_dc && o->d_indirect_rest)
+               ? MRGS_OK : MRGS_E_BAD_ARG;
+}
+
 int mrgs_rasterize_backward_blend(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, const int32_t* radii, const void* geom_ws,
                                   const void* binning_ws, const void* img_ws, int64_t R, const float* dL_dout_color,
                                   const float* dL_dout_feature, const float* dL_dout_others, void* grad_ws, float* dL_dRGB_masked,
@@ -495,11 +512,9 @@ int mrgs_rasterize_backward_finish(const MrgsRasterConfig* cfg, const MrgsRaster
     if (rc) return rc;
     if (!grads || grads->struct_size != sizeof(MrgsRasterGrads)) return MRGS_E_BAD_ARG;
     if (cfg->P == 0) return MRGS_OK;   // every gradient tensor has zero elements
+    rc = grads_check(cfg, in, grads);
+    if (rc) return rc;
     if (!radii || !geom_ws || !grad_ws) return MRGS_E_BAD_ARG;
-    if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
-        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh) ||
-        ((in->shs_rest != nullptr) != (grads->dL_dsh_rest != nullptr)))
-        return MRGS_E_BAD_ARG;
     MrgsGeomWs g = mrgs_carve_geom(const_cast<void*>(geom_ws), cfg->P, cfg->H, cfg->W);
     StageTimer t1(stream, ST_PREB);
     mrgs_launch_preprocess_bwd(*cfg, *in, g, radii, (const float*)grad_ws, *grads, stream);
@@ -518,12 +533,10 @@ int mrgs_rasterize_backward(const MrgsRasterConfig* cfg, const MrgsRasterInputs*
     if (rc) return rc;
     if (!grads || grads->struct_size != sizeof(MrgsRasterGrads)) return MRGS_E_BAD_ARG;
     if (cfg->P == 0) return MRGS_OK;
+    rc = grads_check(cfg, in, grads);
+    if (rc) return rc;
     if (!radii || !geom_ws || !binning_ws || !img_ws || !grad_ws || !dL_dout_color || !dL_dout_others) return MRGS_E_BAD_ARG;
     if (cfg->S > 0 && !dL_dout_feature) return MRGS_E_BAD_ARG;
-    if (!grads->dL_dmeans2D || !grads->dL_dcolors || !grads->dL_dopacity || !grads->dL_dmeans3D || !grads->dL_dtransMat ||
-        !grads->dL_dscales || !grads->dL_drotations || (cfg->S > 0 && !grads->dL_dfeatures) || (cfg->M > 0 && !grads->dL_dsh) ||
-        ((in->shs_rest != nullptr) != (grads->dL_dsh_rest != nullptr)))
-        return MRGS_E_BAD_ARG;
     rc = mrgs_rasterize_backward_blend(cfg, in, radii, geom_ws, binning_ws, img_ws, R, dL_dout_color, dL_dout_feature, dL_dout_others, grad_ws,
                                        nullptr, stream_);
     if (rc) return rc;

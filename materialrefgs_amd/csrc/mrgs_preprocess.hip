@@ -618,6 +618,19 @@ __device__ __forceinline__ f3 dnormvdv(f3 v, f3 dv)
 #define MRGS_PREB_WAVES 1      // wavefronts per workgroup of the backward (each owns a 12.5 KB LDS tile): single waves start as slots free up
                                // instead of four in lock step through the load / compute / store phases (46.5 -> 44.9 us at C2)
 #endif
+// GLUE (MrgsRasterGrads::glue_params / glue_grads): the backward of render_surfel's per-gaussian glue (mrgs_surfel.hip,
+// gaussian_renderer/__init__.py:338-355 + the GaussianModel getters) applied to this kernel's results while they are in registers -- the raw
+// parameters' gradients leave instead of dL/d(activated opacity, scales, rotations, features, means3D), which are neither written nor read
+// back by a second pass over the P rows.  Only for the case in which nothing reads the blended indirect radiance (feature channels 5..7
+// have no upstream gradient: render_surfel without opt.indirect) and without the "pgsr" plane distance: the mirror direction then takes no
+// gradient and the glue's backward is the activations' (sigmoid, exp, normalize); the indirect coefficients' gradients are zeros.
+struct GlueBwd {
+    const float *rotation_raw, *opacity_raw, *scaling_raw, *refl_raw, *rough_raw, *ori_color_raw;
+    float *d_xyz, *d_scaling, *d_rotation, *d_opacity, *d_refl, *d_rough, *d_ori_color, *d_indirect_dc, *d_indirect_rest;
+};
+__device__ __forceinline__ float glue_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }     // mrgs_surfel.hip's sigmoidf
+
+template <bool GLUE>
 __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
     int P, int D, int M, int S, int Wimg, int Himg, float tanfovx, float tanfovy, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ shs,
@@ -626,7 +639,7 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
     const float4* __restrict__ rec, const float* __restrict__ grad_rec, int gstride, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dfeatures, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drotations, const float* __restrict__ shs_rest, float* __restrict__ dL_dsh_rest)
+    float* __restrict__ dL_drotations, const float* __restrict__ shs_rest, float* __restrict__ dL_dsh_rest, GlueBwd gl)
 {
     __shared__ __attribute__((aligned(16))) float s_sh[MRGS_PREB_WAVES][64 * SH_LDS_STRIDE];
     const int idx_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -885,14 +898,66 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
         if (nrows > 0) {
             const float m2v[3] = {dm2[0], dm2[1], 0.0f};
             wave_store_rows<3>(tile, m2v, dL_dmeans2D + 3 * r0, nrows, lane);
-            wave_store_rows<3>(tile, dcol, dL_dcolors + 3 * r0, nrows, lane);
-            wave_store_rows<3>(tile, dm3, dL_dmeans3D + 3 * r0, nrows, lane);
-            wave_store_rows<9>(tile, dT_out, dL_dtransMat + 9 * r0, nrows, lane);
-            wave_store_rows<2>(tile, dsc, dL_dscales + 2 * r0, nrows, lane);
-            wave_store_rows<4>(tile, drot, dL_drotations + 4 * r0, nrows, lane);
+            if constexpr (!GLUE) {
+                wave_store_rows<3>(tile, dcol, dL_dcolors + 3 * r0, nrows, lane);
+                wave_store_rows<3>(tile, dm3, dL_dmeans3D + 3 * r0, nrows, lane);
+                wave_store_rows<9>(tile, dT_out, dL_dtransMat + 9 * r0, nrows, lane);
+                wave_store_rows<2>(tile, dsc, dL_dscales + 2 * r0, nrows, lane);
+                wave_store_rows<4>(tile, drot, dL_drotations + 4 * r0, nrows, lane);
+            } else {
+                // (dL_dcolors / dL_dtransMat: of interest with precomputed colours / transMat only; NULL = not wanted)
+                if (dL_dcolors != nullptr) wave_store_rows<3>(tile, dcol, dL_dcolors + 3 * r0, nrows, lane);
+                if (dL_dtransMat != nullptr) wave_store_rows<9>(tile, dT_out, dL_dtransMat + 9 * r0, nrows, lane);
+                // ---- the glue's backward on this lane's row (surfel_features_bwd_kernel with a zero gradient at the mirror direction) ----
+                // centres: what the rasterizer sends them is all there is
+                wave_store_rows<3>(tile, dm3, gl.d_xyz + 3 * r0, nrows, lane);
+                // scales = exp(raw)
+                const float2 sr = reinterpret_cast<const float2*>(gl.scaling_raw)[idx];
+                const float ds_raw[2] = {dsc[0] * expf(sr.x), dsc[1] * expf(sr.y)};
+                wave_store_rows<2>(tile, ds_raw, gl.d_scaling + 2 * r0, nrows, lane);
+                // rotations = q / max(|q|, 1e-12) (torch.nn.functional.normalize)
+                const float4 q = reinterpret_cast<const float4*>(gl.rotation_raw)[idx];
+                const float qlen = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+                const float qn[4] = {q.x / qlen, q.y / qlen, q.z / qlen, q.w / qlen};
+                const float dot2 = ((qn[0] * drot[0] + qn[1] * drot[1]) + qn[2] * drot[2]) + qn[3] * drot[3];
+                const float rl = fmaxf(qlen, 1e-12f);
+                const float dq_raw[4] = {(drot[0] - qn[0] * dot2) / rl, (drot[1] - qn[1] * dot2) / rl, (drot[2] - qn[2] * dot2) / rl,
+                                         (drot[3] - qn[3] * dot2) / rl};
+                wave_store_rows<4>(tile, dq_raw, gl.d_rotation + 4 * r0, nrows, lane);
+                // material channels: refl, roughness, ori_color = sigmoid(raw); rows 0..4 of the feature block of the gradient row
+                float gfe[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) gfe[c] = live ? gr[MRGS_G_FEAT + c] : 0.0f;
+                float d_ori[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float so = glue_sigmoid(gl.ori_color_raw[3 * (size_t)idx + c]);
+                    d_ori[c] = gfe[2 + c] * so * (1.0f - so);
+                }
+                wave_store_rows<3>(tile, d_ori, gl.d_ori_color + 3 * r0, nrows, lane);
+                const float zero3[3] = {0.0f, 0.0f, 0.0f};
+                wave_store_rows<3>(tile, zero3, gl.d_indirect_dc + 3 * r0, nrows, lane);
+                {   // the 45 higher indirect coefficients of the wave's rows: one run of nrows * 45 floats
+                    float* dst = gl.d_indirect_rest + r0 * 45;
+                    if (nrows == 64 && (((uintptr_t)dst) & 15u) == 0) {
+                        float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+                        for (int k = 0; k * 64 < 16 * 45; k++)
+                            if (k * 64 + lane < 16 * 45) d4[k * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    } else {
+                        for (int e = lane; e < nrows * 45; e += 64) dst[e] = 0.0f;
+                    }
+                }
+                if (in_range) {
+                    const float s0 = glue_sigmoid(gl.refl_raw[idx]), s1 = glue_sigmoid(gl.rough_raw[idx]), so = glue_sigmoid(gl.opacity_raw[idx]);
+                    gl.d_refl[idx] = gfe[0] * s0 * (1.0f - s0);
+                    gl.d_rough[idx] = gfe[1] * s1 * (1.0f - s1);
+                    gl.d_opacity[idx] = dop * so * (1.0f - so);
+                }
+            }
         }
     }
-    if (!in_range) return;
+    if (!in_range || GLUE) return;
     if ((S & 3) == 0 && (((uintptr_t)dL_dfeatures) & 15u) == 0) {
         // feature gradients as 16-byte pieces (the row's feature part starts 16-byte aligned: MRGS_G_FEAT = 16 floats, stride % 4 == 0):
         // a 4-byte access per channel touched 64 cache lines per instruction, S times each way
@@ -908,11 +973,21 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
 void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInputs& in, const MrgsGeomWs& g,
                                 const int32_t* radii, const float* grad_rec, const MrgsRasterGrads& out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((cfg.P + 64 * MRGS_PREB_WAVES - 1) / (64 * MRGS_PREB_WAVES)), dim3(64 * MRGS_PREB_WAVES), 0, stream, cfg.P, cfg.D, cfg.M, cfg.S, cfg.W,
-                       cfg.H, cfg.tanfovx, cfg.tanfovy, in.means3D, in.scales, in.rotations, in.shs, in.transMat_precomp,
-                       in.viewmatrix, in.projmatrix, in.campos, radii, g.clamped, g.rec, grad_rec, MRGS_GRAD_STRIDE(cfg.S),
-                       out.dL_dmeans2D, out.dL_dcolors, out.dL_dfeatures, out.dL_dopacity, out.dL_dmeans3D, out.dL_dtransMat,
-                       out.dL_dsh, out.dL_dscales, out.dL_drotations, in.shs_rest, out.dL_dsh_rest);
+    const dim3 grid((cfg.P + 64 * MRGS_PREB_WAVES - 1) / (64 * MRGS_PREB_WAVES)), block(64 * MRGS_PREB_WAVES);
+#define PREB_ARGS cfg.P, cfg.D, cfg.M, cfg.S, cfg.W, cfg.H, cfg.tanfovx, cfg.tanfovy, in.means3D, in.scales, in.rotations, in.shs, in.transMat_precomp, \
+                  in.viewmatrix, in.projmatrix, in.campos, radii, g.clamped, g.rec, grad_rec, MRGS_GRAD_STRIDE(cfg.S), \
+                  out.dL_dmeans2D, out.dL_dcolors, out.dL_dfeatures, out.dL_dopacity, out.dL_dmeans3D, out.dL_dtransMat, \
+                  out.dL_dsh, out.dL_dscales, out.dL_drotations, in.shs_rest, out.dL_dsh_rest
+    if (out.glue_params != nullptr) {
+        const MrgsSurfelParams& p = *out.glue_params;
+        const MrgsSurfelGrads& o = *out.glue_grads;
+        const GlueBwd gl = {p.rotation_raw, p.opacity_raw, p.scaling_raw, p.refl_raw, p.rough_raw, p.ori_color_raw,
+                            o.d_xyz, o.d_scaling, o.d_rotation, o.d_opacity, o.d_refl, o.d_rough, o.d_ori_color, o.d_indirect_dc, o.d_indirect_rest};
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, stream, PREB_ARGS, gl);
+    } else {
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, stream, PREB_ARGS, GlueBwd{});
+    }
+#undef PREB_ARGS
 }
 
 // dL/dRGB of every surfel as the SH backward consumes it (backward.cu:33-36: zero where the forward clamped the channel; zero for culled

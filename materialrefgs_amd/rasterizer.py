@@ -435,10 +435,13 @@ def _rasterize_forward_native(raster_settings, means3D, sh, colors_precomp, feat
 
 def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp,
                                grad_out_color, grad_out_feature, grad_out_others, sh, opacities, geom, num_rendered, binning, img,
-                               sh_rest=None, prepared_grad_ws=None, work_hint=_RESOLVE):
+                               sh_rest=None, prepared_grad_ws=None, work_hint=_RESOLVE, glue=None):
     """Counterpart of `_C.rasterize_gaussians_backward` (rasterize_points.cu:146-252).  prepared_grad_ws: the workspace the forward of
     this render was given (cleared, queues set up) -- valid for one backward.  work_hint: the hint buffer that forward used (its ctx
-    keeps it); a prepared backward without it takes the non-prepared path (it orders and clears by itself)."""
+    keeps it); a prepared backward without it takes the non-prepared path (it orders and clears by itself).
+    glue (MrgsRasterGrads::glue_params, the glue epilogue): an object with `.raw` = the nine raw GaussianModel tensors of
+    renderer._SurfelFeatures (xyz, scaling, rotation, opacity, refl, rough, ori_color, indirect_dc, indirect_rest) whose outputs this render
+    was fed; their gradients are left in `glue.results` and the five gradients they replace come back as None."""
     L = _lib.lib()
     dev = means3D.device
     if prepared_grad_ws is not None and (work_hint is _RESOLVE or work_hint is None):
@@ -449,13 +452,24 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
     with _lib.guard(dev):
         st = _stream(dev)
         opts = dict(dtype=torch.float32, device=dev)
-        g = {"dL_dmeans2D": torch.empty((P, 3), **opts), "dL_dcolors": torch.empty((P, 3), **opts),
-             "dL_dfeatures": torch.empty((P, S), **opts), "dL_dopacity": torch.empty((P, 1), **opts),
-             "dL_dmeans3D": torch.empty((P, 3), **opts), "dL_dtransMat": torch.empty((P, 9), **opts),
-             "dL_dsh": torch.empty((P, 1 if sh_rest is not None else M, 3), **opts), "dL_dscales": torch.empty((P, 2), **opts),
-             "dL_drotations": torch.empty((P, 4), **opts),
+        fused = glue is not None and P > 0
+        keep = (lambda name, shape: None) if fused else (lambda name, shape: torch.empty(shape, **opts))    # what the glue epilogue replaces
+        g = {"dL_dmeans2D": torch.empty((P, 3), **opts),
+             "dL_dcolors": None if fused and colors_precomp.numel() == 0 else torch.empty((P, 3), **opts),
+             "dL_dfeatures": keep("dL_dfeatures", (P, S)), "dL_dopacity": keep("dL_dopacity", (P, 1)),
+             "dL_dmeans3D": keep("dL_dmeans3D", (P, 3)),
+             "dL_dtransMat": None if fused and cov3Ds_precomp.numel() == 0 else torch.empty((P, 9), **opts),
+             "dL_dsh": torch.empty((P, 1 if sh_rest is not None else M, 3), **opts), "dL_dscales": keep("dL_dscales", (P, 2)),
+             "dL_drotations": keep("dL_drotations", (P, 4)),
              "dL_dsh_rest": torch.empty((P, M - 1, 3), **opts) if sh_rest is not None else None}
-        grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_[1:]])
+        glue_prm = glue_out = raw_grads = None
+        if fused:
+            from ._lib import MrgsSurfelGrads, MrgsSurfelParams
+            raw_grads = [torch.empty_like(t_) for t_ in glue.raw]
+            glue_prm = MrgsSurfelParams(P, *[_ptr(t_) for t_ in glue.raw], None, None)          # (campos, viewmatrix: not read)
+            glue_out = MrgsSurfelGrads(*[_ptr(t_) for t_ in raw_grads])
+        grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_[1:11]],
+                                ctypes.addressof(glue_prm) if fused else None, ctypes.addressof(glue_out) if fused else None)
         grad_ws = prepared_grad_ws if prepared_grad_ws is not None else torch.empty((L.mrgs_grad_bytes(P, S),), dtype=torch.uint8, device=dev)
         hook = _AFTER_BLEND_HOOK[0]
         if hook is None or P == 0:
@@ -472,6 +486,8 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
             hook(drgb)
             _lib.check(L.mrgs_rasterize_backward_finish(ctypes.byref(cfg), ctypes.byref(inp), _ptr(radii), _ptr(geom), _ptr(grad_ws),
                                                         ctypes.byref(grads), st))
+    if fused:
+        glue.results = raw_grads
     return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dfeatures"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dtransMat"],
             g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dsh_rest"])
 
@@ -508,6 +524,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             out = _rasterize_forward_native(*args)
         (num_rendered, binning_pairs), contrib, color, feature, depth, radii, geomBuffer, binningBuffer, imgBuffer, grad_ws, hint = out
         ctx.features_live = int(getattr(_LIVE, "n", 0) or 0)
+        ctx.glue = getattr(_LIVE, "glue", None)          # the glue epilogue of the backward (GaussianRasterizer.glue, set by render_surfel)
         ctx.prepared_grad_ws = grad_ws       # cleared by the forward, queues of the backward set up: good for ONE backward
         ctx.work_hint = hint                 # the buffer those queues live in: the backward is handed this very tensor (never a re-resolved one)
         ctx.raster_settings = rs
@@ -538,11 +555,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         prepared, ctx.prepared_grad_ws = ctx.prepared_grad_ws, None
         args = (rs, means3D, radii, colors_precomp, features, scales, rotations, cov3Ds_precomp, _f32c(grad_out_color),
                 _f32c(grad_out_feature), _f32c(grad_depth), sh, opacities, geomBuffer, num_rendered, binningBuffer, imgBuffer, sh_rest, prepared,
-                ctx.work_hint)
+                ctx.work_hint, getattr(ctx, "glue", None))
         _LIVE.n = getattr(ctx, "features_live", 0)       # (the autograd engine's thread: the forward's hint again)
         try:
             if rs.debug:
-                cpu_args = cpu_deep_copy_tuple(args[1:])
+                cpu_args = cpu_deep_copy_tuple(args[1:-1])
                 try:
                     out = _rasterize_backward_native(*args)
                 except Exception as ex:
@@ -635,6 +652,7 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = empty
 
         _LIVE.n = int(getattr(self, "features_live", 0) or 0)      # (extension: feature channels n .. S - 1 are zero padding of the rows)
+        _LIVE.glue = getattr(self, "glue", None)                   # (extension: the glue epilogue of the backward, _rasterize_backward_native)
         _LIVE.visible = None
         try:
             out = rasterize_gaussians(means3D, means2D, shs, colors_precomp, features, opacities, scales, rotations, cov3D_precomp,
@@ -645,4 +663,5 @@ class GaussianRasterizer(nn.Module):
             return out
         finally:
             _LIVE.n = 0
+            _LIVE.glue = None
             _LIVE.visible = None

@@ -14,6 +14,7 @@ Rasterization, shading and the per-gaussian glue (activations, normals, mirror d
 """
 import ctypes
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -111,6 +112,31 @@ def set_after_features_hook(fn):
     _AFTER_FEATURES_HOOK[0] = fn
 
 
+class _GlueLink:
+    """What ties a _SurfelFeatures node to the rasterizer node that consumes its outputs (the glue epilogue, MrgsRasterGrads::glue_params):
+    `raw` = the node's nine raw parameter tensors; the rasterizer's backward leaves their gradients in `results`, the node's own backward
+    hands them on instead of launching its kernel."""
+    __slots__ = ("raw", "results")
+
+    def __init__(self, raw):
+        self.raw, self.results = raw, None
+
+
+class _LastLink(__import__("threading").local):      # the link of the most recent _SurfelFeatures.forward on THIS thread (render_surfel picks it up)
+    def __init__(self):
+        self.link = None
+
+    def __getitem__(self, i):
+        return self.link
+
+    def __setitem__(self, i, v):
+        self.link = v
+
+
+_LAST_LINK = _LastLink()
+_FUSE_GLUE = os.environ.get("MRGS_NO_GLUE_EPILOGUE", "0") != "1"
+
+
 class _SurfelFeatures(torch.autograd.Function):
     """mrgs_surfel_features_forward/backward (include/mrgs.h): raw GaussianModel parameters -> (opacity, scales, rotations,
     features[P,8]) in one kernel each way (checker: oracle/glue_oracle.py, the reference's own chain of torch ops)."""
@@ -135,6 +161,7 @@ class _SurfelFeatures(torch.autograd.Function):
             st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_forward(ctypes.byref(prm), _p(op), _p(sc), _p(rot), _p(feat), st))
         ctx.save_for_backward(*ts, *(() if vm is None else (vm,)))
+        ctx.link = _LAST_LINK[0] = _GlueLink(ts[:9])
         if pass_xyz:
             # the centres as a fifth output (the input itself): whoever consumes THEM -- the rasterizer -- sends its gradient through this
             # node, whose backward kernel adds it to its own: one sum inside a kernel instead of autograd's accumulation kernel
@@ -146,6 +173,12 @@ class _SurfelFeatures(torch.autograd.Function):
         *ts, = ctx.saved_tensors
         vm = ts.pop() if len(ts) == 11 else None
         P, dev = ts[0].shape[0], ts[0].device
+        fused, ctx.link.results = ctx.link.results, None
+        if fused is not None and all(g is None for g in (g_op, g_sc, g_rot, g_feat, g_xyz)):
+            # the rasterizer's per-gaussian backward has applied this node's backward already (the glue epilogue): nothing to launch
+            if _AFTER_FEATURES_HOOK[0] is not None:
+                _AFTER_FEATURES_HOOK[0](None)              # (only without a reader of the indirect radiance: its factor is structurally zero)
+            return (*fused, None, None, None, None)
         L = _lib.lib()
         prm = MrgsSurfelParams(P, *[_p(t) for t in ts], _p(vm))
         outs = [torch.empty_like(t) for t in ts[:9]]
@@ -155,6 +188,8 @@ class _SurfelFeatures(torch.autograd.Function):
             st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_backward(ctypes.byref(prm), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), ctypes.byref(grads),
                                                        _p(gs[4]), st))
+        if fused is not None:          # somebody else read this node's outputs as well: their share through the kernel, plus the epilogue's
+            outs = [a + b for a, b in zip(outs, fused)]
         if _AFTER_FEATURES_HOOK[0] is not None:
             # (indirect_live False: the caller's step does not look at the blended indirect radiance -- its gradient is zero by the structure of
             #  the step, on every rank: the hook is told so instead of being handed a tensor of zeros to gather)
@@ -523,6 +558,12 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     padded = fused_distance and features.shape[1] == 12
     if padded:      # nine channels in rows of twelve floats: the blend kernels leave the padding out of their arithmetic (features_live)
         rasterizer.features_live = 9
+    # The glue epilogue (MrgsRasterGrads::glue_params): nothing reads the blended indirect radiance and the rows are the fused node's own ->
+    # the rasterizer's per-gaussian backward continues through the activations' backward in the same kernel, the node above launches none.
+    indirect_live = bool(getattr(opt, "indirect", False)) and not use_asg
+    if _FUSE_GLUE and not indirect_live and not use_asg and not fused_distance and cov3D_precomp is None and means3D.is_cuda and torch.is_grad_enabled():
+        rasterizer.glue = _LAST_LINK[0]
+    _LAST_LINK[0] = None
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, features=features, opacities=opacities,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)

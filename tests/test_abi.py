@@ -101,12 +101,12 @@ def test_struct_size_guard():
     from materialrefgs_amd import _lib
     from materialrefgs_amd._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs
     L = _lib.lib()
-    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 9
+    assert L.mrgs_abi_version() == _lib.MRGS_ABI_VERSION == 10
     assert ctypes.sizeof(MrgsRasterConfig) == 4 + 11 * 4          # struct_size + 6 ints + 3 floats + 2 ints
     assert ctypes.sizeof(MrgsRasterInputs) == 8 + 15 * 8 + 8      # struct_size + 12 pointers + work_hint, shs_rest, bwd_grad_ws + hint_flags, reserved
-    assert ctypes.sizeof(MrgsRasterGrads) == 8 + 10 * 8
+    assert ctypes.sizeof(MrgsRasterGrads) == 8 + 12 * 8          # struct_size + 10 gradient pointers + glue_params, glue_grads (ABI 10)
     hdr = open(os.path.join(ROOT, "include", "mrgs.h")).read()
-    assert "#define MRGS_ABI_VERSION 9" in hdr
+    assert "#define MRGS_ABI_VERSION 10" in hdr
 
     class OldInputs(ctypes.Structure):                           # the struct as INTEGRATION.md printed it in round 2: 14 pointers, no size
         _fields_ = [(n, ctypes.c_void_p) for n in ("bg", "means3D", "shs", "colors_precomp", "features", "opacities", "scales", "rotations",
@@ -252,3 +252,36 @@ def test_camera_constants_follow_an_in_place_pose_change():
     K[0, 0] = 250.0
     k4, _, _ = renderer._camera_consts(cam, dev)
     assert abs(k4[0] - 1.0 / 250.0) < 1e-9
+
+
+def test_glue_epilogue_arguments_are_checked_before_any_launch():
+    """MrgsRasterGrads::glue_params / glue_grads (ABI 10): one pointer without the other or a missing tensor is MRGS_E_BAD_ARG, a render the
+    epilogue does not serve -- a channel count other than eight, the "pgsr" viewmatrix -- MRGS_E_UNSUPPORTED, both before anything is
+    queued (no GPU needed: the calls below carry no `radii`, which is the next check and fails them all the same).  With the epilogue the five
+    tensors it replaces may be NULL."""
+    from materialrefgs_amd import _lib
+    from materialrefgs_amd._lib import MrgsRasterConfig, MrgsRasterGrads, MrgsRasterInputs, MrgsSurfelGrads, MrgsSurfelParams
+    L = _lib.lib()
+    BAD_ARG, UNSUPPORTED = 1, 6
+    P = 4
+    buf = (ctypes.c_float * 4096)()
+    ptr = ctypes.addressof(buf)
+    cfg = MrgsRasterConfig(P, 8, 3, 16, 32, 32, 0.5, 0.5, 1.0, 0, 0)
+    cfg12 = MrgsRasterConfig(P, 12, 3, 16, 32, 32, 0.5, 0.5, 1.0, 0, 0)
+    inp = MrgsRasterInputs(ptr, ptr, ptr, None, ptr, ptr, ptr, ptr, None, ptr, ptr, ptr, None, None, None, 0, 0)
+    prm, prm_vm = MrgsSurfelParams(P, *([ptr] * 10), None), MrgsSurfelParams(P, *([ptr] * 11))
+    out = MrgsSurfelGrads(*([ptr] * 9))
+    out_short = MrgsSurfelGrads(*([ptr] * 8), None)
+
+    def finish(grads, cfg_=cfg):
+        return L.mrgs_rasterize_backward_finish(ctypes.byref(cfg_), ctypes.byref(inp), None, ptr, ptr, ctypes.byref(grads), None)
+    full = [ptr] * 9 + [None]
+    lean = [ptr, None, None, None, None, None, ptr, None, None, None]                                 # only dL_dmeans2D and dL_dsh
+    a = ctypes.addressof
+    assert finish(MrgsRasterGrads(*full, None, None)) == BAD_ARG                                      # (well formed: stops at `radii`)
+    assert finish(MrgsRasterGrads(*lean, a(prm), a(out))) == BAD_ARG                                  # (well formed with the epilogue: stops at `radii`)
+    assert finish(MrgsRasterGrads(*lean, None, None)) == BAD_ARG                                      # tensors missing without it
+    assert finish(MrgsRasterGrads(*full, a(prm), None)) == BAD_ARG                                    # one pointer without the other
+    assert finish(MrgsRasterGrads(*lean, a(prm), a(out_short))) == BAD_ARG                            # a raw gradient tensor missing
+    assert finish(MrgsRasterGrads(*lean, a(prm), a(out)), cfg12) == UNSUPPORTED                       # twelve channels
+    assert finish(MrgsRasterGrads(*lean, a(prm_vm), a(out))) == UNSUPPORTED                           # the "pgsr" plane distance

@@ -83,7 +83,8 @@ def test_render_surfel_at_c3_size(gpu_device):
     assert float(grads[0][0][dead].abs().sum()) == 0.0
 
 
-def test_c3full_against_render_oracle(gpu_device):
+@pytest.mark.parametrize("glue_epilogue", [True, False])
+def test_c3full_against_render_oracle(gpu_device, glue_epilogue, monkeypatch):
     """The headline workload against the checkers AT FULL SIZE (what bench.py's CPU leg measures, here as a test of record):
     render_surfel of view 0 of the bench's C3full scene -- 300 000 surfels, 800 x 800, S = 8, deferred shading, the 128 -> 16 environment
     chain -- on the GPU and through oracle/render_oracle.surfel_leaf_gradients (oracle/mrgs_oracle.c rasterizer over OpenMP, float64
@@ -94,8 +95,12 @@ def test_c3full_against_render_oracle(gpu_device):
     evaluation of the activations differs in the last bit and moves threshold pixels -- a comparison of inputs, not of renderers).
     Bars: the pair count equal, prefiltered levels <= 2e-5, maps <= 2e-5 of their maximum except the two ill-conditioned ones (rend_dist:
     absolute 5e-6; surf_normal: <= 1e-2 of the pixels beyond 1e-4), every gradient <= 1e-4 of its tensor's maximum or the truth-leg
-    rule (render_oracle.leaf_gradient_report).  ~20 s of CPU work."""
+    rule (render_oracle.leaf_gradient_report).  ~20 s of CPU work.
+    glue_epilogue: the product's default for this workload -- the rasterizer's per-gaussian backward carries on through the glue's
+    backward in one kernel (MrgsRasterGrads::glue_params) -- and the two-kernel path, which also exposes the gradients at the rasterizer's
+    per-gaussian inputs."""
     import materialrefgs_amd.renderer as renderer_mod
+    monkeypatch.setattr(renderer_mod, "_FUSE_GLUE", glue_epilogue)
     from materialrefgs_amd import rasterizer as rasterizer_mod
     from materialrefgs_amd.renderer import render_surfel
     from oracle import render_oracle
@@ -147,9 +152,12 @@ def test_c3full_against_render_oracle(gpu_device):
     hip = {n: t_.grad.detach().cpu().numpy() for n, t_ in zip(render_oracle.LEAF_NAMES, leaves[:11])}
     hip["env_base"] = env.base.grad.detach().cpu().numpy()
     hip["viewspace_points"] = out_h["viewspace_points"].grad.detach().cpu().numpy()
+    mid = [] if glue_epilogue else list(render_oracle.RASTER_INPUT_NAMES)
     for n, t_ in zip(render_oracle.RASTER_INPUT_NAMES, stash["o"]):
-        hip[n] = t_.grad.detach().cpu().numpy()
-    names = list(render_oracle.LEAF_NAMES) + ["env_base", "viewspace_points"] + list(render_oracle.RASTER_INPUT_NAMES)
+        assert (t_.grad is None) == glue_epilogue, n          # (with the epilogue those gradients never exist as tensors)
+        if t_.grad is not None:
+            hip[n] = t_.grad.detach().cpu().numpy()
+    names = list(render_oracle.LEAF_NAMES) + ["env_base", "viewspace_points"] + mid
     rows, ok = render_oracle.leaf_gradient_report(hip, g_o, names, bar=1e-4)
     for n in names:
         r_ = rows[n]

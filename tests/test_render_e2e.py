@@ -206,6 +206,101 @@ def test_render_surfel_matches_the_composed_oracle(gpu_device, indirect, srgb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra_reader", [False, True])
+def test_glue_epilogue_equals_the_two_kernel_backward(gpu_device, extra_reader, monkeypatch):
+    """render_surfel without opt.indirect: the rasterizer's per-gaussian backward carries on through the glue's backward in the same
+    kernel (MrgsRasterGrads::glue_params: the activations' derivatives applied to the gradient row's results in registers; the
+    surfel_features backward kernel is not launched) against the two-kernel path (MRGS_NO_GLUE_EPILOGUE=1).  Same forward: bit-identical
+    maps.  Gradients: the epilogue is the same arithmetic compiled without FMA contraction (the rasterizer's flags): every leaf within 2e-6 of
+    its largest element; the indirect coefficients take exact zeros both ways.  extra_reader: a second consumer of the glue node's
+    outputs (a loss on the activated opacity and the material rows) -- its share goes through the glue's own kernel and is ADDED to the
+    epilogue's."""
+    import materialrefgs_amd.renderer as renderer_mod
+    from materialrefgs_amd.renderer import render_surfel
+    P, H, W = 3000, 96, 128
+    cam = orbit_camera(1, H, W).to(gpu_device)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=gpu_device)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(renderer_mod, "_FUSE_GLUE", fused)
+        _pc_o, _base_o, pc_h, env = _models(P, H, W, seed=4, dev=gpu_device)
+        env.build_mips()
+        stash, glue = {}, renderer_mod.surfel_features
+
+        def capturing(pc_, campos_, **kw):
+            o = glue(pc_, campos_, **kw)
+            stash["o"] = o
+            return o
+        renderer_mod.surfel_features = capturing
+        try:
+            out = render_surfel(cam, pc_h, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+        finally:
+            renderer_mod.surfel_features = glue
+        loss = _loss(out, H, W, False, gpu_device)
+        if extra_reader:
+            g = torch.Generator().manual_seed(3)
+            loss = loss + (stash["o"][0] * torch.rand(P, 1, generator=g).to(gpu_device)).sum() + (stash["o"][3] * torch.rand(P, 8, generator=g).to(gpu_device)).sum()
+        loss.backward()
+        grads = {n: getattr(pc_h, n).grad.detach().clone() for n in PARAMS}
+        grads["env.base"] = env.base.grad.detach().clone()
+        grads["viewspace_points"] = out["viewspace_points"].grad.detach().clone()
+        res[fused] = ({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, grads)
+    (maps1, g1), (maps0, g0) = res[True], res[False]
+    for k in maps0:
+        assert torch.equal(maps0[k], maps1[k]), k
+    for n in g0:
+        assert bool(torch.isfinite(g1[n]).all()), n
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-6 * max(1e-30, float(g0[n].abs().max())), (n, float((g0[n] - g1[n]).abs().max()), float(g0[n].abs().max()))
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_refl_strength", "_roughness", "_ori_color"):
+        assert float(g1[n].abs().max()) > 0.0, n
+    if not extra_reader:          # (the extra reader looks at the indirect rows too)
+        for n in ("_indirect_dc", "_indirect_rest"):
+            assert float(g0[n].abs().max()) == 0.0 and float(g1[n].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_glue_epilogue_launches_no_glue_backward_kernel(gpu_device, monkeypatch):
+    """With the epilogue the glue node's backward hands on what the rasterizer left for it: mrgs_surfel_features_backward is not called
+    (counted at the ctypes boundary); without it, once."""
+    import materialrefgs_amd.renderer as renderer_mod
+    from materialrefgs_amd.renderer import render_surfel
+    P, H, W = 2000, 64, 80
+    cam = orbit_camera(2, H, W).to(gpu_device)
+    pipe = SimpleNamespace(depth_ratio=0.0, debug=False)
+    bg = torch.zeros(3, device=gpu_device)
+    L = renderer_mod._lib.lib()
+    real = L.mrgs_surfel_features_backward
+    for fused, want in ((True, 0), (False, 1)):
+        monkeypatch.setattr(renderer_mod, "_FUSE_GLUE", fused)
+        _pc_o, _base_o, pc_h, env = _models(P, H, W, seed=6, dev=gpu_device)
+        env.build_mips()
+        out = render_surfel(cam, pc_h, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+        calls = []
+
+        class Counting:
+            def __getattr__(self, name):
+                if name == "mrgs_surfel_features_backward":
+                    return lambda *a: (calls.append(1), real(*a))[1]
+                return getattr(L, name)
+        orig_lib = renderer_mod._lib.lib
+        renderer_mod._lib.lib = lambda: Counting()
+        try:
+            _loss(out, H, W, False, gpu_device).backward()
+        finally:
+            renderer_mod._lib.lib = orig_lib
+        assert len(calls) == want, (fused, len(calls))
+        assert pc_h._opacity.grad is not None and float(pc_h._opacity.grad.abs().max()) > 0.0
+        # (opt.indirect: the blended indirect radiance is read -- never the epilogue)
+    monkeypatch.setattr(renderer_mod, "_FUSE_GLUE", True)
+    _pc_o, _base_o, pc_h, env = _models(P, H, W, seed=6, dev=gpu_device)
+    env.build_mips()
+    out = render_surfel(cam, pc_h, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=True))
+    (out["render"].sum() + out["indirect_light"].sum()).backward()
+    assert float(pc_h._indirect_dc.grad.abs().max()) > 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("grad_mode", [True, False])
 def test_lazy_prefilter_on_the_side_stream_equals_the_plain_path(gpu_device, grad_mode):
     """EnvLight.overlap_prefilter (MRGS_SIDE_STREAM=1): the prefilter launched lazily on the library's side stream, forked from the point
