@@ -705,7 +705,7 @@ def main():
         # (the rasterizer's per-gaussian backward carries on through the glue's backward in one kernel where nothing reads the blended
         #  indirect radiance -- MrgsRasterGrads::glue_params; MRGS_NO_GLUE_EPILOGUE=1 restores the two-kernel backward)
         import materialrefgs_amd.renderer as _rm
-        out["config"]["glue_epilogue"] = bool(_rm._FUSE_GLUE and not indirect and flavour == "2dgs" and not getattr(pipe, "use_asg", False))
+        out["config"]["glue_epilogue"] = bool(_rm._FUSE_GLUE and not indirect and not getattr(pipe, "use_asg", False))
     if rank == 0:
         R, HW = int(state["R"]), H * W
         stage_ms = {"preprocess_fwd": stage_times.preprocess_ms, "depth_sort_scan": stage_times.sort_ms,
@@ -842,7 +842,7 @@ def main():
                                 if v["rule"] != "bar"}
             out["grad_all_leaves_within_1e-4_or_truth_leg"] = bool(ok)
             out["grad_rel_err_note"] = ("every leaf of render_surfel (raw xyz / scaling / rotation / opacity / material parameters, both SH families, "
-                                        "env_base) + viewspace_points + the rasterizer's per-gaussian inputs, through glue + rasterizer + maps + prefilter "
+                                        "env_base) + viewspace_points (+ the rasterizer's per-gaussian inputs where they exist as tensors: not with the glue epilogue), through glue + rasterizer + maps + prefilter "
                                         "+ shading + compositing; max-norm relative to the tensor's largest element; identical fp32 rasterizer inputs on both sides")
             out["map_rel_err"] = {k: float(f"{v:.3e}") for k, v in maps.items()}
             # two maps are ill-conditioned functions of what the rasterizer blends, in the reference's formulas as much as here: rend_dist

@@ -189,12 +189,12 @@ typedef struct MrgsRasterGrads {
      * they are in registers and writes glue_grads' nine tensors (fully; d_indirect_dc / d_indirect_rest as zeros) INSTEAD of dL_dopacity,
      * dL_dscales, dL_drotations, dL_dfeatures and dL_dmeans3D, which are not touched and may be NULL; dL_dcolors and dL_dtransMat are written
      * if not NULL.  One pass over the P rows instead of two (mrgs_surfel_features_backward is not called for this render).
-     * Contract: S = 8 with the rows mrgs_surfel_features_forward wrote for the same parameters (scales / rotations given, no precomputed
-     * transMat), NO upstream gradient at feature channels 5..7 (nothing reads the blended indirect radiance: render_surfel without
-     * opt.indirect) and glue_params->viewmatrix NULL (no "pgsr" plane distance) -- the mirror direction then takes no gradient.  Another
-     * channel count, a precomputed transMat or a viewmatrix: MRGS_E_UNSUPPORTED; the channels' zero gradient is the caller's word (it is
-     * not read).
-     * glue_params' indirect_dc / indirect_rest / xyz / campos are not read. */
+     * Contract: the rows mrgs_surfel_features_forward wrote for the same parameters (scales / rotations given, no precomputed transMat) --
+     * S = 8 with glue_params->viewmatrix NULL, or the "pgsr" rows (S = 12, features_live = 9) with the viewmatrix they were built with: the
+     * plane distance's gradient then goes to the raw rotation and the centre inside the epilogue (campos = MrgsRasterInputs::campos) --
+     * and NO upstream gradient at feature channels 5..7 (nothing reads the blended indirect radiance: render_surfel without opt.indirect),
+     * so that the mirror direction takes no gradient.  Other row shapes or a precomputed transMat: MRGS_E_UNSUPPORTED; the three channels'
+     * zero gradient is the caller's word (it is not read).  glue_params' indirect_dc / indirect_rest / xyz / campos are not read. */
     const struct MrgsSurfelParams* glue_params;
     const struct MrgsSurfelGrads* glue_grads;
 } MrgsRasterGrads;

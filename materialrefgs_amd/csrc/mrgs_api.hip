@@ -464,7 +464,9 @@ static int grads_check(const MrgsRasterConfig* cfg, const MrgsRasterInputs* in, 
                    ? MRGS_OK : MRGS_E_BAD_ARG;
     const MrgsSurfelParams* p = g->glue_params;
     const MrgsSurfelGrads* o = g->glue_grads;
-    if (cfg->S != 8 || !in->scales || !in->rotations || in->transMat_precomp || p->viewmatrix) return MRGS_E_UNSUPPORTED;
+    // rows of eight channels, or the "pgsr" rows (nine channels in twelve floats, features_live = 9) with the glue's viewmatrix
+    const bool rows8 = cfg->S == 8 && p->viewmatrix == nullptr, rows12 = cfg->S == 12 && in->features_live == 9u && p->viewmatrix != nullptr;
+    if (!(rows8 || rows12) || !in->scales || !in->rotations || in->transMat_precomp) return MRGS_E_UNSUPPORTED;
     if (cfg->P != p->P || !p->scaling_raw || !p->rotation_raw || !p->opacity_raw || !p->refl_raw || !p->rough_raw || !p->ori_color_raw) return MRGS_E_BAD_ARG;
     return (o->d_xyz && o->d_scaling && o->d_rotation && o->d_opacity && o->d_refl && o->d_rough && o->d_ori_color && o->d_indirect_dc && o->d_indirect_rest)
                ? MRGS_OK : MRGS_E_BAD_ARG;

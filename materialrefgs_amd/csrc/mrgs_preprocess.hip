@@ -627,8 +627,55 @@ __device__ __forceinline__ f3 dnormvdv(f3 v, f3 dv)
 struct GlueBwd {
     const float *rotation_raw, *opacity_raw, *scaling_raw, *refl_raw, *rough_raw, *ori_color_raw;
     float *d_xyz, *d_scaling, *d_rotation, *d_opacity, *d_refl, *d_rough, *d_ori_color, *d_indirect_dc, *d_indirect_rest;
+    const float* plane_view;        // "pgsr" (rows of 12 floats, channel 8 = get_distance): the camera's world_view_transform as stored, else NULL
 };
 __device__ __forceinline__ float glue_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }     // mrgs_surfel.hip's sigmoidf
+
+// "pgsr": the plane distance |n_cam . c_cam| (gaussian_renderer/envgs_renderer.py:30-38; mrgs_surfel.hip: make_frame, plane_distance) sends its
+// gradient gd to the raw rotation (through the facing unit normal = third column of R(q / |q|), flipped towards the camera) and to the
+// centre: d_q[4] is ADDED to, d_p[3] is set.  The formulas of surfel_features_bwd_kernel with a zero gradient at the mirror direction.
+__device__ __forceinline__ void glue_plane_distance_bwd(const float* __restrict__ Wv, const float (&p)[3], const float4 q, const float* __restrict__ campos,
+                                                        float gd, float (&d_q)[4], float (&d_p)[3])
+{
+    const float qlen = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float qn[4] = {q.x / qlen, q.y / qlen, q.z / qlen, q.w / qlen};
+    const float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+    const float nr[3] = {2.0f * (x * z + w * y), 2.0f * (y * z - w * x), 1.0f - 2.0f * (x * x + y * y)};
+    const float d[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+    const float dlen = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float v[3] = {d[0] / dlen, d[1] / dlen, d[2] / dlen};
+    const float flip = -(nr[0] * v[0] + nr[1] * v[1] + nr[2] * v[2]) >= 0.0f ? 1.0f : -1.0f;
+    const float nf[3] = {nr[0] * flip, nr[1] * flip, nr[2] * flip};
+    const float nflen = fmaxf(sqrtf(nf[0] * nf[0] + nf[1] * nf[1] + nf[2] * nf[2]), 1e-20f);
+    const float nn[3] = {nf[0] / nflen, nf[1] / nflen, nf[2] / nflen};
+    float nc[3], cc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        nc[j] = nn[0] * Wv[j] + nn[1] * Wv[4 + j] + nn[2] * Wv[8 + j];
+        cc[j] = p[0] * Wv[j] + p[1] * Wv[4 + j] + p[2] * Wv[8 + j] + Wv[12 + j];
+    }
+    const float sdist = nc[0] * cc[0] + nc[1] * cc[1] + nc[2] * cc[2];
+    const float sg = sdist > 0.0f ? gd : (sdist < 0.0f ? -gd : 0.0f);           // d|s| = sign(s) (torch: 0 at 0)
+    float d_nn[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float* Wi = Wv + 4 * i;
+        d_nn[i] = sg * (Wi[0] * cc[0] + Wi[1] * cc[1] + Wi[2] * cc[2]);
+        d_p[i] = sg * (Wi[0] * nc[0] + Wi[1] * nc[1] + Wi[2] * nc[2]);
+    }
+    const float nn_dot = nn[0] * d_nn[0] + nn[1] * d_nn[1] + nn[2] * d_nn[2];
+    float a[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) a[i] = (d_nn[i] - nn[i] * nn_dot) / nflen * flip;
+    float d_qn[4];
+    d_qn[0] = 2.0f * y * a[0] - 2.0f * x * a[1];
+    d_qn[1] = 2.0f * z * a[0] - 2.0f * w * a[1] - 4.0f * x * a[2];
+    d_qn[2] = 2.0f * w * a[0] + 2.0f * z * a[1] - 4.0f * y * a[2];
+    d_qn[3] = 2.0f * x * a[0] + 2.0f * y * a[1];
+    const float dot1 = ((qn[0] * d_qn[0] + qn[1] * d_qn[1]) + qn[2] * d_qn[2]) + qn[3] * d_qn[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d_q[i] += (d_qn[i] - qn[i] * dot1) / qlen;
+}
 
 template <bool GLUE>
 __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
@@ -909,21 +956,28 @@ __global__ void __launch_bounds__(64 * MRGS_PREB_WAVES) preprocess_bwd_kernel(
                 if (dL_dcolors != nullptr) wave_store_rows<3>(tile, dcol, dL_dcolors + 3 * r0, nrows, lane);
                 if (dL_dtransMat != nullptr) wave_store_rows<9>(tile, dT_out, dL_dtransMat + 9 * r0, nrows, lane);
                 // ---- the glue's backward on this lane's row (surfel_features_bwd_kernel with a zero gradient at the mirror direction) ----
-                // centres: what the rasterizer sends them is all there is
-                wave_store_rows<3>(tile, dm3, gl.d_xyz + 3 * r0, nrows, lane);
-                // scales = exp(raw)
-                const float2 sr = reinterpret_cast<const float2*>(gl.scaling_raw)[idx];
-                const float ds_raw[2] = {dsc[0] * expf(sr.x), dsc[1] * expf(sr.y)};
-                wave_store_rows<2>(tile, ds_raw, gl.d_scaling + 2 * r0, nrows, lane);
                 // rotations = q / max(|q|, 1e-12) (torch.nn.functional.normalize)
                 const float4 q = reinterpret_cast<const float4*>(gl.rotation_raw)[idx];
                 const float qlen = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
                 const float qn[4] = {q.x / qlen, q.y / qlen, q.z / qlen, q.w / qlen};
                 const float dot2 = ((qn[0] * drot[0] + qn[1] * drot[1]) + qn[2] * drot[2]) + qn[3] * drot[3];
                 const float rl = fmaxf(qlen, 1e-12f);
-                const float dq_raw[4] = {(drot[0] - qn[0] * dot2) / rl, (drot[1] - qn[1] * dot2) / rl, (drot[2] - qn[2] * dot2) / rl,
-                                         (drot[3] - qn[3] * dot2) / rl};
+                float dq_raw[4] = {(drot[0] - qn[0] * dot2) / rl, (drot[1] - qn[1] * dot2) / rl, (drot[2] - qn[2] * dot2) / rl,
+                                   (drot[3] - qn[3] * dot2) / rl};
+                // centres: what the rasterizer sends them (+ the plane distance's share, "pgsr")
+                float dxyz[3] = {dm3[0], dm3[1], dm3[2]};
+                if (gl.plane_view != nullptr) {
+                    const float pc3[3] = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+                    float d_p[3];
+                    glue_plane_distance_bwd(gl.plane_view, pc3, q, campos, live ? gr[MRGS_G_FEAT + 8] : 0.0f, dq_raw, d_p);
+                    dxyz[0] += d_p[0]; dxyz[1] += d_p[1]; dxyz[2] += d_p[2];
+                }
+                wave_store_rows<3>(tile, dxyz, gl.d_xyz + 3 * r0, nrows, lane);
                 wave_store_rows<4>(tile, dq_raw, gl.d_rotation + 4 * r0, nrows, lane);
+                // scales = exp(raw)
+                const float2 sr = reinterpret_cast<const float2*>(gl.scaling_raw)[idx];
+                const float ds_raw[2] = {dsc[0] * expf(sr.x), dsc[1] * expf(sr.y)};
+                wave_store_rows<2>(tile, ds_raw, gl.d_scaling + 2 * r0, nrows, lane);
                 // material channels: refl, roughness, ori_color = sigmoid(raw); rows 0..4 of the feature block of the gradient row
                 float gfe[5];
 #pragma unroll
@@ -982,7 +1036,8 @@ void mrgs_launch_preprocess_bwd(const MrgsRasterConfig& cfg, const MrgsRasterInp
         const MrgsSurfelParams& p = *out.glue_params;
         const MrgsSurfelGrads& o = *out.glue_grads;
         const GlueBwd gl = {p.rotation_raw, p.opacity_raw, p.scaling_raw, p.refl_raw, p.rough_raw, p.ori_color_raw,
-                            o.d_xyz, o.d_scaling, o.d_rotation, o.d_opacity, o.d_refl, o.d_rough, o.d_ori_color, o.d_indirect_dc, o.d_indirect_rest};
+                            o.d_xyz, o.d_scaling, o.d_rotation, o.d_opacity, o.d_refl, o.d_rough, o.d_ori_color, o.d_indirect_dc, o.d_indirect_rest,
+                            p.viewmatrix};
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, block, 0, stream, PREB_ARGS, gl);
     } else {
         hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, block, 0, stream, PREB_ARGS, GlueBwd{});

@@ -466,7 +466,7 @@ def _rasterize_backward_native(raster_settings, means3D, radii, colors_precomp, 
         if fused:
             from ._lib import MrgsSurfelGrads, MrgsSurfelParams
             raw_grads = [torch.empty_like(t_) for t_ in glue.raw]
-            glue_prm = MrgsSurfelParams(P, *[_ptr(t_) for t_ in glue.raw], None, None)          # (campos, viewmatrix: not read)
+            glue_prm = MrgsSurfelParams(P, *[_ptr(t_) for t_ in glue.raw], None, _ptr(getattr(glue, "viewmatrix", None)))   # (campos: the rasterizer's)
             glue_out = MrgsSurfelGrads(*[_ptr(t_) for t_ in raw_grads])
         grads = MrgsRasterGrads(*[_ptr(g[name]) for name, _ in MrgsRasterGrads._fields_[1:11]],
                                 ctypes.addressof(glue_prm) if fused else None, ctypes.addressof(glue_out) if fused else None)

@@ -116,10 +116,10 @@ class _GlueLink:
     """What ties a _SurfelFeatures node to the rasterizer node that consumes its outputs (the glue epilogue, MrgsRasterGrads::glue_params):
     `raw` = the node's nine raw parameter tensors; the rasterizer's backward leaves their gradients in `results`, the node's own backward
     hands them on instead of launching its kernel."""
-    __slots__ = ("raw", "results")
+    __slots__ = ("raw", "results", "viewmatrix")
 
-    def __init__(self, raw):
-        self.raw, self.results = raw, None
+    def __init__(self, raw, viewmatrix=None):
+        self.raw, self.results, self.viewmatrix = raw, None, viewmatrix       # viewmatrix: the "pgsr" rows' (plane distance in channel 8)
 
 
 class _LastLink(__import__("threading").local):      # the link of the most recent _SurfelFeatures.forward on THIS thread (render_surfel picks it up)
@@ -161,7 +161,7 @@ class _SurfelFeatures(torch.autograd.Function):
             st = _lib.stream_ptr(dev)
             _lib.check(L.mrgs_surfel_features_forward(ctypes.byref(prm), _p(op), _p(sc), _p(rot), _p(feat), st))
         ctx.save_for_backward(*ts, *(() if vm is None else (vm,)))
-        ctx.link = _LAST_LINK[0] = _GlueLink(ts[:9])
+        ctx.link = _LAST_LINK[0] = _GlueLink(ts[:9], vm)
         if pass_xyz:
             # the centres as a fifth output (the input itself): whoever consumes THEM -- the rasterizer -- sends its gradient through this
             # node, whose backward kernel adds it to its own: one sum inside a kernel instead of autograd's accumulation kernel
@@ -561,7 +561,9 @@ def render_surfel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ov
     # The glue epilogue (MrgsRasterGrads::glue_params): nothing reads the blended indirect radiance and the rows are the fused node's own ->
     # the rasterizer's per-gaussian backward continues through the activations' backward in the same kernel, the node above launches none.
     indirect_live = bool(getattr(opt, "indirect", False)) and not use_asg
-    if _FUSE_GLUE and not indirect_live and not use_asg and not fused_distance and cov3D_precomp is None and means3D.is_cuda and torch.is_grad_enabled():
+    # ("pgsr": with the padded rows of the fused node only -- nine channels in twelve floats -- ; the plane distance's gradient is part of the epilogue)
+    if (_FUSE_GLUE and not indirect_live and not use_asg and (padded or not fused_distance) and cov3D_precomp is None and means3D.is_cuda
+            and torch.is_grad_enabled()):
         rasterizer.glue = _LAST_LINK[0]
     _LAST_LINK[0] = None
     contrib, rendered_image, rendered_features, radii, allmap = rasterizer(

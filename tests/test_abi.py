@@ -256,7 +256,7 @@ def test_camera_constants_follow_an_in_place_pose_change():
 
 def test_glue_epilogue_arguments_are_checked_before_any_launch():
     """MrgsRasterGrads::glue_params / glue_grads (ABI 10): one pointer without the other or a missing tensor is MRGS_E_BAD_ARG, a render the
-    epilogue does not serve -- a channel count other than eight, the "pgsr" viewmatrix -- MRGS_E_UNSUPPORTED, both before anything is
+    epilogue does not serve -- row shapes other than eight channels or the "pgsr" nine-in-twelve with its viewmatrix -- MRGS_E_UNSUPPORTED, both before anything is
     queued (no GPU needed: the calls below carry no `radii`, which is the next check and fails them all the same).  With the epilogue the five
     tensors it replaces may be NULL."""
     from materialrefgs_amd import _lib
@@ -273,8 +273,10 @@ def test_glue_epilogue_arguments_are_checked_before_any_launch():
     out = MrgsSurfelGrads(*([ptr] * 9))
     out_short = MrgsSurfelGrads(*([ptr] * 8), None)
 
-    def finish(grads, cfg_=cfg):
-        return L.mrgs_rasterize_backward_finish(ctypes.byref(cfg_), ctypes.byref(inp), None, ptr, ptr, ctypes.byref(grads), None)
+    inp9 = MrgsRasterInputs(ptr, ptr, ptr, None, ptr, ptr, ptr, ptr, None, ptr, ptr, ptr, None, None, None, 0, 9)
+
+    def finish(grads, cfg_=cfg, inp_=inp):
+        return L.mrgs_rasterize_backward_finish(ctypes.byref(cfg_), ctypes.byref(inp_), None, ptr, ptr, ctypes.byref(grads), None)
     full = [ptr] * 9 + [None]
     lean = [ptr, None, None, None, None, None, ptr, None, None, None]                                 # only dL_dmeans2D and dL_dsh
     a = ctypes.addressof
@@ -283,5 +285,7 @@ def test_glue_epilogue_arguments_are_checked_before_any_launch():
     assert finish(MrgsRasterGrads(*lean, None, None)) == BAD_ARG                                      # tensors missing without it
     assert finish(MrgsRasterGrads(*full, a(prm), None)) == BAD_ARG                                    # one pointer without the other
     assert finish(MrgsRasterGrads(*lean, a(prm), a(out_short))) == BAD_ARG                            # a raw gradient tensor missing
-    assert finish(MrgsRasterGrads(*lean, a(prm), a(out)), cfg12) == UNSUPPORTED                       # twelve channels
-    assert finish(MrgsRasterGrads(*lean, a(prm_vm), a(out))) == UNSUPPORTED                           # the "pgsr" plane distance
+    assert finish(MrgsRasterGrads(*lean, a(prm), a(out)), cfg12) == UNSUPPORTED                       # twelve channels without the "pgsr" viewmatrix
+    assert finish(MrgsRasterGrads(*lean, a(prm_vm), a(out))) == UNSUPPORTED                           # the viewmatrix with rows of eight
+    assert finish(MrgsRasterGrads(*lean, a(prm_vm), a(out)), cfg12) == UNSUPPORTED                    # twelve channels, all of them live
+    assert finish(MrgsRasterGrads(*lean, a(prm_vm), a(out)), cfg12, inp9) == BAD_ARG                  # "pgsr" rows (features_live = 9): well formed, stops at `radii`

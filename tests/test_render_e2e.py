@@ -206,15 +206,16 @@ def test_render_surfel_matches_the_composed_oracle(gpu_device, indirect, srgb):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra_reader", [False, True])
-def test_glue_epilogue_equals_the_two_kernel_backward(gpu_device, extra_reader, monkeypatch):
+@pytest.mark.parametrize("extra_reader,flag", [(False, "2dgs"), (True, "2dgs"), (False, "pgsr"), (True, "pgsr")])
+def test_glue_epilogue_equals_the_two_kernel_backward(gpu_device, extra_reader, flag, monkeypatch):
     """render_surfel without opt.indirect: the rasterizer's per-gaussian backward carries on through the glue's backward in the same
     kernel (MrgsRasterGrads::glue_params: the activations' derivatives applied to the gradient row's results in registers; the
     surfel_features backward kernel is not launched) against the two-kernel path (MRGS_NO_GLUE_EPILOGUE=1).  Same forward: bit-identical
     maps.  Gradients: the epilogue is the same arithmetic compiled without FMA contraction (the rasterizer's flags): every leaf within 2e-6 of
     its largest element; the indirect coefficients take exact zeros both ways.  extra_reader: a second consumer of the glue node's
     outputs (a loss on the activated opacity and the material rows) -- its share goes through the glue's own kernel and is ADDED to the
-    epilogue's."""
+    epilogue's.  flag "pgsr" (the flavour the reference ships): rows of nine channels in twelve floats; the plane distance's gradient
+    reaches the raw rotation and the centre inside the epilogue."""
     import materialrefgs_amd.renderer as renderer_mod
     from materialrefgs_amd.renderer import render_surfel
     P, H, W = 3000, 96, 128
@@ -234,13 +235,17 @@ def test_glue_epilogue_equals_the_two_kernel_backward(gpu_device, extra_reader, 
             return o
         renderer_mod.surfel_features = capturing
         try:
-            out = render_surfel(cam, pc_h, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False))
+            out = render_surfel(cam, pc_h, pipe, bg, srgb=False, opt=SimpleNamespace(indirect=False), flag=flag)
         finally:
             renderer_mod.surfel_features = glue
         loss = _loss(out, H, W, False, gpu_device)
+        if flag != "2dgs":
+            g = torch.Generator().manual_seed(17)
+            loss = loss + (out["rend_distance"] * torch.rand(out["rend_distance"].shape, generator=g).to(gpu_device)).sum()
         if extra_reader:
             g = torch.Generator().manual_seed(3)
-            loss = loss + (stash["o"][0] * torch.rand(P, 1, generator=g).to(gpu_device)).sum() + (stash["o"][3] * torch.rand(P, 8, generator=g).to(gpu_device)).sum()
+            C = stash["o"][3].shape[1]
+            loss = loss + (stash["o"][0] * torch.rand(P, 1, generator=g).to(gpu_device)).sum() + (stash["o"][3] * torch.rand(P, C, generator=g).to(gpu_device)).sum()
         loss.backward()
         grads = {n: getattr(pc_h, n).grad.detach().clone() for n in PARAMS}
         grads["env.base"] = env.base.grad.detach().clone()
