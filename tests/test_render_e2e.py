@@ -211,8 +211,9 @@ def test_glue_epilogue_equals_the_two_kernel_backward(gpu_device, extra_reader, 
     """render_surfel without opt.indirect: the rasterizer's per-gaussian backward carries on through the glue's backward in the same
     kernel (MrgsRasterGrads::glue_params: the activations' derivatives applied to the gradient row's results in registers; the
     surfel_features backward kernel is not launched) against the two-kernel path (MRGS_NO_GLUE_EPILOGUE=1).  Same forward: bit-identical
-    maps.  Gradients: the epilogue is the same arithmetic compiled without FMA contraction (the rasterizer's flags): every leaf within 2e-6 of
-    its largest element; the indirect coefficients take exact zeros both ways.  extra_reader: a second consumer of the glue node's
+    maps.  Gradients: the epilogue is the same arithmetic compiled without FMA contraction (the rasterizer's flags), and the blend backward's
+    float atomics order their sums differently in any two runs (two runs of the SAME path differ by up to 2e-6 of a tensor's largest element
+    on such scenes: tools/stress_glue.py): every leaf within 1e-5 of its largest element; the indirect coefficients take exact zeros both ways.  extra_reader: a second consumer of the glue node's
     outputs (a loss on the activated opacity and the material rows) -- its share goes through the glue's own kernel and is ADDED to the
     epilogue's.  flag "pgsr" (the flavour the reference ships): rows of nine channels in twelve floats; the plane distance's gradient
     reaches the raw rotation and the centre inside the epilogue."""
@@ -256,7 +257,7 @@ def test_glue_epilogue_equals_the_two_kernel_backward(gpu_device, extra_reader, 
         assert torch.equal(maps0[k], maps1[k]), k
     for n in g0:
         assert bool(torch.isfinite(g1[n]).all()), n
-        assert float((g0[n] - g1[n]).abs().max()) <= 2e-6 * max(1e-30, float(g0[n].abs().max())), (n, float((g0[n] - g1[n]).abs().max()), float(g0[n].abs().max()))
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * max(1e-30, float(g0[n].abs().max())), (n, float((g0[n] - g1[n]).abs().max()), float(g0[n].abs().max()))
     for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_refl_strength", "_roughness", "_ori_color"):
         assert float(g1[n].abs().max()) > 0.0, n
     if not extra_reader:          # (the extra reader looks at the indirect rows too)

@@ -14,3 +14,5 @@ for SD in $OWN $((OWN + 1)); do
 done
 timeout 2400 python tools/stress_trace.py $NT > $O/${TAG}_soak_tracer_$NT.txt 2>&1; tail -2 $O/${TAG}_soak_tracer_$NT.txt
 timeout 1200 python tools/stress_trace.py $((NT / 3)) $OWN > $O/${TAG}_soak_tracer_first${OWN}_$((NT / 3)).txt 2>&1; tail -2 $O/${TAG}_soak_tracer_first${OWN}_$((NT / 3)).txt
+# the glue epilogue against the two-kernel backward (both flavours, partial and single-lane waves), with the run-to-run noise floor per case
+timeout 1200 python tools/stress_glue.py 1000 $OWN > $O/${TAG}_soak_glue_1000.txt 2>&1; tail -2 $O/${TAG}_soak_glue_1000.txt
